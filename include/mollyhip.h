@@ -1,0 +1,223 @@
+/*
+ * mollyhip.h — C ABI of libmollyhip.so, the MI355X-native nonbonded force engine that sits
+ * behind Molly.jl's `System` / `pairwise_inters` / `simulate!` API.
+ *
+ * Every entry point below replaces one reference interface (paths relative to the Molly.jl
+ * checkout, v0.23.3); INTEGRATION.md shows the Julia `ccall` stubs that bind them.
+ *
+ *   mhip_forces               ≙ Molly.pairwise_forces_loop_gpu!   ext/MollyCUDAExt.jl:845, src/kernels.jl:91,
+ *                                                                  caller src/force.jl:1228
+ *   mhip_specific_forces      ≙ Molly.specific_forces_gpu!        src/kernels.jl:142-205, caller src/force.jl:1231
+ *   mhip_potential_energy     ≙ Molly.pairwise_pe_loop_gpu!       ext/MollyCUDAExt.jl:936, src/kernels.jl:393,
+ *                                                                  caller src/energy.jl:427
+ *   mhip_specific_potential_energy ≙ specific_pe_gpu!             src/kernels.jl:430-567, caller src/energy.jl:431
+ *   mhip_kinetic_energy       ≙ kinetic_energy                    src/energy.jl:56-89
+ *   mhip_remove_cm            ≙ Molly.remove_CM_motion!           ext/MollyCUDAExt.jl:2373, src/spatial.jl:901-929
+ *   mhip_vv_run               ≙ simulate!(sys, ::VelocityVerlet)  src/simulators.jl:547-668 (loop 589-666)
+ *   mhip_export_neighbors     ≙ find_neighbors → NeighborList     src/neighbors.jl:390-423, 665-693; src/types.jl:611-654
+ *   mhip_set_exceptions       ≙ GPUNeighborFinder excluded/special src/neighbors.jl:104-115, 171-195
+ *   mhip_set_atoms            ≙ Atom{…} fields charge, σ, ϵ, mass, λ   src/types.jl:466-475
+ *   mhip_set_state/get_state  ≙ sys.coords / sys.velocities       src/types.jl:798-800
+ *
+ * Conventions: plain C, no exceptions across the ABI. Every function returns an int32 status
+ * (0 = ok, <0 = enum mhip_status); the message is available from mhip_last_error(ctx).
+ * Units: nm, ps, g/mol, kJ/mol, elementary charge (Molly strips Unitful units before touching
+ * buffers: src/force.jl:844-846).  Atom indices are 0-BASED here (the Julia shim subtracts 1).
+ * Coordinate / velocity / force arrays are packed xyzxyz… of `float` (precision 32) or `double`
+ * (precision 64) — bit-compatible with Vector{SVector{3,T}} and with fs_mat (3×N column-major,
+ * src/force.jl:623) — so the caller passes pointers with zero copies.  `mem_kind` says whether a
+ * pointer is host or device (gfx950 HBM) memory.  A context is NOT thread-safe: one host thread
+ * drives it (as Julia does for one System).  The context owns all device memory it allocates;
+ * the caller owns every pointer it passes and may free it when the call returns.
+ */
+#ifndef MOLLYHIP_H
+#define MOLLYHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mhip_ctx mhip_ctx;
+
+enum mhip_status {
+    MHIP_OK               =  0,
+    MHIP_ERR_INVALID      = -1,   /* bad argument / inconsistent configuration            */
+    MHIP_ERR_HIP          = -2,   /* a HIP runtime call failed (message has the hipError)  */
+    MHIP_ERR_STATE        = -3,   /* call order violated (e.g. forces before set_state)    */
+    MHIP_ERR_CAPACITY     = -4,   /* caller buffer too small (export_neighbors)            */
+    MHIP_ERR_NO_DEVICE    = -5,   /* no gfx950 device visible: the product path never falls back to CPU */
+    MHIP_ERR_UNSUPPORTED  = -6,   /* feature outside the hot-path scope (e.g. virial)      */
+    MHIP_ERR_NAN          = -7    /* NaN detected by mhip_check_finite                     */
+};
+
+/* src/cutoffs.jl */
+enum mhip_cutoff_kind {
+    MHIP_CUTOFF_NONE              = 0,   /* NoCutoff               cutoffs.jl:15,31      */
+    MHIP_CUTOFF_DISTANCE          = 1,   /* DistanceCutoff         cutoffs.jl:72-79      */
+    MHIP_CUTOFF_SHIFTED_POTENTIAL = 2,   /* ShiftedPotentialCutoff cutoffs.jl:100-113    */
+    MHIP_CUTOFF_SHIFTED_FORCE     = 3,   /* ShiftedForceCutoff     cutoffs.jl:133-150    */
+    MHIP_CUTOFF_CUBIC_SPLINE      = 4,   /* CubicSplineCutoff      cutoffs.jl:172-200    */
+    MHIP_CUTOFF_POLYNOMIAL        = 5    /* PolynomialCutoff       cutoffs.jl:226-253    */
+};
+
+/* src/interactions/coulomb.jl */
+enum mhip_coul_kind {
+    MHIP_COUL_NONE           = 0,
+    MHIP_COUL_PLAIN          = 1,   /* Coulomb               coulomb.jl:32-120      */
+    MHIP_COUL_REACTION_FIELD = 2,   /* CoulombReactionField  coulomb.jl:698-814     */
+    MHIP_COUL_EWALD_DIRECT   = 3    /* CoulombEwald          coulomb.jl:1320-1441   */
+};
+
+enum mhip_mem_kind { MHIP_MEM_HOST = 0, MHIP_MEM_DEVICE = 1 };
+
+/* The `pairwise_inters` tuple: LennardJones(+cutoff) and one Coulomb flavour.  Plain data so the
+ * Julia shim can fill it from the interaction structs (lennard_jones.jl:25-47, coulomb.jl). */
+typedef struct mhip_interactions {
+    int32_t lj_enabled;            /* 1 if a LennardJones is in pairwise_inters                   */
+    int32_t lj_cutoff_kind;        /* enum mhip_cutoff_kind                                       */
+    double  lj_rc;                 /* dist_cutoff                                                 */
+    double  lj_ra;                 /* dist_activation (cubic spline / polynomial)                 */
+    double  lj_weight_special;     /* weight_special, lennard_jones.jl:34 (0.5 for Amber 1-4)     */
+    int32_t coul_kind;             /* enum mhip_coul_kind                                         */
+    int32_t coul_cutoff_kind;      /* cutoff of the plain Coulomb (ignored for RF / Ewald)        */
+    double  coul_rc;               /* dist_cutoff (all flavours)                                  */
+    double  coul_ra;               /* dist_activation, plain Coulomb with spline/polynomial       */
+    double  coul_ke;               /* coulomb_const, 138.93545764 kJ mol^-1 nm (coulomb.jl:16)    */
+    double  coul_weight_special;   /* 0.8333… for Amber 1-4                                       */
+    double  rf_dielectric;         /* solvent_dielectric; +inf = conducting boundary              */
+    double  ewald_alpha;           /* α = sqrt(-log(2 tol))/rc, coulomb.jl:1332                   */
+    int32_t ewald_approx_erfc;     /* approximate_erfc (A&S 7.1.26), coulomb.jl:1384-1393         */
+    int32_t reserved;
+} mhip_interactions;
+
+typedef struct mhip_config {
+    int32_t precision;             /* 32 | 64: T of System{D,AT,T}                                */
+    int32_t device_id;             /* HIP device ordinal (one process per GPU)                    */
+    int64_t n_atoms;               /* atom capacity of this context (owned + ghost)               */
+    double  box[3];                /* CubicBoundary side lengths (spatial.jl:40); for a           */
+                                   /* non-periodic axis: extent of the local domain               */
+    double  origin[3];             /* lower corner, used on non-periodic axes only (else 0)       */
+    int32_t periodic[3];           /* 1 = periodic axis. 0 = open axis of a spatial sub-domain    */
+                                   /* whose ghost atoms the host supplies already shifted         */
+    int32_t rebuild_every;         /* neighbour rebuild cadence in steps (DistanceNeighborFinder  */
+                                   /* n_steps, neighbors.jl:385; default 10)                      */
+    double  r_list;                /* neighbour radius = dist_cutoff + dist_buffer (setup.jl:565);*/
+                                   /* +inf or <=0: every pair interacts (NoNeighborList)          */
+    mhip_interactions inter;
+} mhip_config;
+
+typedef struct mhip_stats {
+    int64_t n_atoms, n_owned, n_ghost;
+    int64_t n_rebuilds;            /* neighbour-structure rebuilds so far                         */
+    int64_t n_force_calls;
+    int64_t n_pairs_full;          /* entries of the full (both-directions) list = 2·L            */
+    int64_t n_list_slots;          /* padded slots actually streamed per force pass               */
+    int64_t n_blocks;              /* i-blocks (workgroups of the force kernel)                   */
+    int64_t tile_atoms_total;      /* Σ over blocks of LDS tile sizes                             */
+    int32_t block_atoms;           /* i-atoms per workgroup                                       */
+    int32_t j_split;               /* waves sharing one i-atom's list                             */
+    int32_t minimg_mode;           /* 1 = in-loop exact minimum image (small boxes)               */
+    int32_t max_tile_atoms;
+    double  last_rebuild_ms;       /* host wall time of the last rebuild                          */
+    int64_t lds_bytes;             /* dynamic LDS of the force kernel                             */
+    int64_t algorithmic_bytes_step;/* N(R_p+22w)+4L, SURVEY §8(d)                                 */
+} mhip_stats;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+int32_t     mhip_create(mhip_ctx** out, const mhip_config* cfg);
+int32_t     mhip_destroy(mhip_ctx* ctx);
+const char* mhip_last_error(const mhip_ctx* ctx);            /* ctx may be NULL (create errors)  */
+int32_t     mhip_device_count(int32_t* n_out);               /* visible HIP devices              */
+int32_t     mhip_set_stream(mhip_ctx* ctx, void* hip_stream);/* run on the caller's hipStream_t  */
+int32_t     mhip_synchronize(mhip_ctx* ctx);
+
+/* ---- topology / parameters ----------------------------------------------------------------- */
+/* owned atoms come first, ghosts after them; n_owned + n_ghost <= cfg.n_atoms.  Default:
+ * n_owned = cfg.n_atoms, n_ghost = 0. */
+int32_t mhip_set_atom_counts(mhip_ctx* ctx, int64_t n_owned, int64_t n_ghost);
+/* n_owned+n_ghost entries each, element type T; lambda may be NULL (λ = 1).  λ == 0 triggers the
+ * LJZeroShortcut (mixing.jl:7-11). */
+int32_t mhip_set_atoms(mhip_ctx* ctx, const void* charge, const void* sigma, const void* eps,
+                       const void* mass, const void* lambda, int32_t mem_kind);
+/* excluded (eligible == false) and special (1-4) pairs, i < j, host int32 arrays, as the
+ * GPUNeighborFinder stores them (neighbors.jl:104-115). A pair in both lists is excluded. */
+int32_t mhip_set_exceptions(mhip_ctx* ctx, const int32_t* ex_i, const int32_t* ex_j, int64_t n_ex,
+                            const int32_t* sp_i, const int32_t* sp_j, int64_t n_sp);
+
+/* specific_inter_lists (host arrays; parameters of element type T) */
+int32_t mhip_set_bonds(mhip_ctx* ctx, int64_t n, const int32_t* i, const int32_t* j,
+                       const void* k, const void* r0);                 /* HarmonicBond  harmonic_bond.jl:44-54  */
+int32_t mhip_set_angles(mhip_ctx* ctx, int64_t n, const int32_t* i, const int32_t* j,
+                        const int32_t* k, const void* kth, const void* th0); /* HarmonicAngle harmonic_angle.jl:46-67 */
+/* one entry per (torsion, Fourier term); proper and improper torsions share this list */
+int32_t mhip_set_torsions(mhip_ctx* ctx, int64_t n, const int32_t* i, const int32_t* j,
+                          const int32_t* k, const int32_t* l, const int32_t* periodicity,
+                          const void* phase, const void* kt);          /* PeriodicTorsion periodic_torsion.jl:93-142 */
+/* EwaldExclusion pairs (ewald.jl:978-1055); uses inter.ewald_alpha and inter.coul_ke */
+int32_t mhip_set_ewald_exclusions(mhip_ctx* ctx, int64_t n, const int32_t* i, const int32_t* j);
+
+/* ---- state --------------------------------------------------------------------------------- */
+/* xyz: 3·(n_owned+n_ghost) T; vel: 3·n_owned T or NULL (keep). Marks neighbour structures stale. */
+int32_t mhip_set_state(mhip_ctx* ctx, const void* xyz, const void* vel, int32_t mem_kind);
+int32_t mhip_get_state(mhip_ctx* ctx, void* xyz, void* vel, int32_t mem_kind);  /* either may be NULL */
+
+/* ---- forces / energies --------------------------------------------------------------------- */
+/* Pairwise LJ+Coulomb forces on the OWNED atoms at the current coordinates (3·n_owned T).
+ * accumulate != 0 adds into f_xyz (the contract of pairwise_forces_loop_gpu!, whose caller
+ * zeroes fs_mat, force.jl:1216); 0 overwrites.  step_n drives the rebuild cadence exactly like
+ * find_neighbors (neighbors.jl:396): rebuild when stale or step_n % rebuild_every == 0 and the
+ * step differs from the step of the last build.  virial9 must be NULL (MHIP_ERR_UNSUPPORTED). */
+int32_t mhip_forces(mhip_ctx* ctx, int64_t step_n, int32_t accumulate, void* f_xyz,
+                    void* virial9, int32_t mem_kind);
+int32_t mhip_specific_forces(mhip_ctx* ctx, int32_t accumulate, void* f_xyz, int32_t mem_kind);
+int32_t mhip_potential_energy(mhip_ctx* ctx, int64_t step_n, double* pe_out);
+int32_t mhip_specific_potential_energy(mhip_ctx* ctx, double* pe_out);
+int32_t mhip_kinetic_energy(mhip_ctx* ctx, double* ke_out);
+int32_t mhip_remove_cm(mhip_ctx* ctx);
+int32_t mhip_check_finite(mhip_ctx* ctx);          /* check_nans, simulators.jl:98-111 */
+
+/* ---- integrator ---------------------------------------------------------------------------- */
+/* Runs steps first_step+1 … first_step+n_steps of velocity Verlet entirely on the device:
+ *   v += a dt/2; x += v dt; x = wrap(x); F = forces(x); a' = F/m; v += a' dt/2;
+ *   if remove_cm_every>0 && step % remove_cm_every == 0: v -= Σmv/Σm;  neighbour rebuild when
+ *   step % rebuild_every == 0                                            (simulators.jl:589-666).
+ * Like simulate!, the call first wraps the coordinates, removes CM motion when first_step == 0,
+ * force-rebuilds the neighbour structures and recomputes the forces at first_step
+ * (simulators.jl:561-571), so chunked calls continue a run (test/simulation.jl:16-57). */
+int32_t mhip_vv_run(mhip_ctx* ctx, int64_t first_step, int64_t n_steps, double dt,
+                    int32_t remove_cm_every);
+/* The same step split at the point where a multi-GPU host exchanges ghost coordinates:
+ *   stage1: v += a dt/2; x += v dt; x = wrap(x)           (owned atoms)
+ *   stage2: F = forces(x) [+ specific]; v += a' dt/2      (owned atoms; ghosts read-only)     */
+int32_t mhip_vv_init(mhip_ctx* ctx, int64_t first_step);          /* wrap, rebuild, forces at first_step */
+int32_t mhip_vv_stage1(mhip_ctx* ctx, double dt);
+int32_t mhip_vv_stage2(mhip_ctx* ctx, int64_t step_n, double dt);
+int32_t mhip_rebuild(mhip_ctx* ctx, int64_t step_n);              /* force a neighbour rebuild now */
+
+/* ---- neighbour list export (bit-exact check) ------------------------------------------------ */
+/* Half list, each unordered pair once with i < j (0-based), special flag as neighbors.jl:411.
+ * Pair SET equals the reference's for the same-precision arithmetic; order is unspecified.
+ * capacity too small → MHIP_ERR_CAPACITY with *n_out = required entries. */
+int32_t mhip_export_neighbors(mhip_ctx* ctx, int32_t* i, int32_t* j, uint8_t* special,
+                              int64_t capacity, int64_t* n_out);
+/* Current sorted order: perm[s] = caller index of the atom stored at sorted slot s
+ * (≙ buffers.morton_seq, reorder round-trip test/gpu_optimizations.jl:220-250). */
+int32_t mhip_export_order(mhip_ctx* ctx, int32_t* perm, int64_t capacity);
+int32_t mhip_get_stats(mhip_ctx* ctx, mhip_stats* out);
+
+/* ---- multi-GPU halo helpers (device pointers; run on the context's stream) ------------------ */
+/* out[3k..3k+2] = coords[idx[k]] + shift[3k..]  (idx: caller indices of owned atoms; shift NULL ok) */
+int32_t mhip_gather_coords(mhip_ctx* ctx, const int32_t* idx_dev, const void* shift_dev,
+                           int64_t n, void* out_dev);
+/* coords[first + k] = in[3k..3k+2], k < n  (used to refresh the ghost range each step) */
+int32_t mhip_scatter_coords(mhip_ctx* ctx, int64_t first, int64_t n, const void* in_dev);
+/* out4 = {Σ m vx, Σ m vy, Σ m vz, Σ m} over owned atoms, as double[4] on the HOST */
+int32_t mhip_cm_momentum(mhip_ctx* ctx, double* out4);
+int32_t mhip_shift_velocities(mhip_ctx* ctx, const double* dv3);  /* v -= dv3 on owned atoms */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOLLYHIP_H */

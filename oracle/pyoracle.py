@@ -1,0 +1,237 @@
+"""ctypes front-end of oracle/liboracle.so — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.  It is the
+checker, never the product path.  See oracle/oracle.cpp for the reference citations.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+CUTOFFS = {"none": 0, "distance": 1, "shifted_potential": 2, "shifted_force": 3, "cubic_spline": 4, "polynomial": 5}
+COULS = {"none": 0, "plain": 1, "reaction_field": 2, "ewald_direct": 3}
+COULOMB_CONST = 138.93545764  # coulomb.jl:16
+
+
+class Interactions(C.Structure):  # == mhip_interactions (include/mollyhip.h)
+    _fields_ = [("lj_enabled", C.c_int32), ("lj_cutoff_kind", C.c_int32), ("lj_rc", C.c_double), ("lj_ra", C.c_double),
+                ("lj_weight_special", C.c_double), ("coul_kind", C.c_int32), ("coul_cutoff_kind", C.c_int32),
+                ("coul_rc", C.c_double), ("coul_ra", C.c_double), ("coul_ke", C.c_double),
+                ("coul_weight_special", C.c_double), ("rf_dielectric", C.c_double), ("ewald_alpha", C.c_double),
+                ("ewald_approx_erfc", C.c_int32), ("reserved", C.c_int32)]
+
+
+def make_interactions(d):
+    """d: dict with the field names of mhip_interactions (missing → neutral defaults)."""
+    it = Interactions()
+    it.lj_enabled = int(d.get("lj_enabled", 0))
+    it.lj_cutoff_kind = int(d.get("lj_cutoff_kind", 0))
+    it.lj_rc = float(d.get("lj_rc", 0.0)); it.lj_ra = float(d.get("lj_ra", 0.0))
+    it.lj_weight_special = float(d.get("lj_weight_special", 1.0))
+    it.coul_kind = int(d.get("coul_kind", 0)); it.coul_cutoff_kind = int(d.get("coul_cutoff_kind", 0))
+    it.coul_rc = float(d.get("coul_rc", 0.0)); it.coul_ra = float(d.get("coul_ra", 0.0))
+    it.coul_ke = float(d.get("coul_ke", COULOMB_CONST))
+    it.coul_weight_special = float(d.get("coul_weight_special", 1.0))
+    it.rf_dielectric = float(d.get("rf_dielectric", 1.0)); it.ewald_alpha = float(d.get("ewald_alpha", 0.0))
+    it.ewald_approx_erfc = int(d.get("ewald_approx_erfc", 1))
+    return it
+
+
+class OrcSystem(C.Structure):
+    _fields_ = [("n", C.c_int64), ("coords", C.c_void_p), ("vel", C.c_void_p), ("charge", C.c_void_p),
+                ("sigma", C.c_void_p), ("eps", C.c_void_p), ("mass", C.c_void_p), ("box", C.c_double * 3),
+                ("inter", Interactions), ("r_list", C.c_double), ("rebuild_every", C.c_int32), ("pad0", C.c_int32),
+                ("ex_i", C.c_void_p), ("ex_j", C.c_void_p), ("n_ex", C.c_int64),
+                ("sp_i", C.c_void_p), ("sp_j", C.c_void_p), ("n_sp", C.c_int64),
+                ("n_bonds", C.c_int64), ("b_i", C.c_void_p), ("b_j", C.c_void_p), ("b_k", C.c_void_p), ("b_r0", C.c_void_p),
+                ("n_angles", C.c_int64), ("a_i", C.c_void_p), ("a_j", C.c_void_p), ("a_k", C.c_void_p),
+                ("a_kth", C.c_void_p), ("a_th0", C.c_void_p),
+                ("n_tors", C.c_int64), ("t_i", C.c_void_p), ("t_j", C.c_void_p), ("t_k", C.c_void_p), ("t_l", C.c_void_p),
+                ("t_per", C.c_void_p), ("t_phase", C.c_void_p), ("t_k0", C.c_void_p),
+                ("n_ewx", C.c_int64), ("x_i", C.c_void_p), ("x_j", C.c_void_p)]
+
+
+def build(native=False, quiet=True):
+    target = ["native"] if native else []
+    subprocess.run(["make", "-C", _HERE] + target, check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+    return os.path.join(_HERE, "_native", "liboracle_native.so") if native else os.path.join(_HERE, "liboracle.so")
+
+
+_libs = {}
+
+
+def lib(native=False):
+    if native not in _libs:
+        path = os.path.join(_HERE, "_native", "liboracle_native.so") if native else os.path.join(_HERE, "liboracle.so")
+        if native or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(os.path.join(_HERE, "oracle.cpp")):
+            path = build(native)
+        L = C.CDLL(path)
+        L.orc_vector_1d.restype = C.c_double; L.orc_vector_1d.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double]
+        L.orc_wrap_1d.restype = C.c_double; L.orc_wrap_1d.argtypes = [C.c_int, C.c_double, C.c_double]
+        L.orc_pair.restype = None
+        L.orc_pair.argtypes = [C.c_int, C.POINTER(Interactions), C.c_void_p] + [C.c_double] * 6 + [C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_neighbors.restype = C.c_int64
+        L.orc_neighbors.argtypes = [C.c_int, C.POINTER(OrcSystem), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        L.orc_forces.restype = None
+        L.orc_forces.argtypes = [C.c_int, C.POINTER(OrcSystem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
+        L.orc_energy.restype = C.c_double
+        L.orc_energy.argtypes = [C.c_int, C.POINTER(OrcSystem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
+        L.orc_kinetic_energy.restype = C.c_double; L.orc_kinetic_energy.argtypes = [C.c_int, C.POINTER(OrcSystem)]
+        L.orc_remove_cm.restype = None; L.orc_remove_cm.argtypes = [C.c_int, C.POINTER(OrcSystem)]
+        L.orc_wrap.restype = None; L.orc_wrap.argtypes = [C.c_int, C.POINTER(OrcSystem)]
+        L.orc_vv_run.restype = None
+        L.orc_vv_run.argtypes = [C.c_int, C.POINTER(OrcSystem), C.c_int64, C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int]
+        L.orc_force_scale.restype = None
+        L.orc_force_scale.argtypes = [C.POINTER(OrcSystem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_void_p]
+        L.orc_hardware_threads.restype = C.c_int
+        _libs[native] = L
+    return _libs[native]
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class OracleSystem:
+    """A System as plain arrays in precision `dtype`, handed to the oracle.
+
+    Parameters mirror Molly's System fields (types.jl:795-979): coords (n,3), velocities (n,3),
+    atoms' charge/σ/ϵ/mass, CubicBoundary side lengths `box`, the pairwise interaction dict, the
+    neighbour radius and cadence, sparse exception pairs, and specific interaction lists.
+    """
+
+    def __init__(self, coords, box, inter, dtype=np.float64, velocities=None, charge=None, sigma=None, eps=None,
+                 mass=None, r_list=float("inf"), rebuild_every=10, excluded=None, special=None, bonds=None,
+                 angles=None, torsions=None, ewald_excl=None, native=False):
+        self.dtype = np.dtype(dtype)
+        self.prec = 32 if self.dtype == np.float32 else 64
+        T = self.dtype
+        self.n = len(coords)
+        self.coords = np.ascontiguousarray(coords, dtype=T).reshape(self.n, 3).copy()
+        self.vel = np.zeros((self.n, 3), T) if velocities is None else np.ascontiguousarray(velocities, dtype=T).copy()
+        z = np.zeros(self.n, T)
+        self.charge = z.copy() if charge is None else np.ascontiguousarray(charge, dtype=T)
+        self.sigma = z.copy() if sigma is None else np.ascontiguousarray(sigma, dtype=T)
+        self.eps = z.copy() if eps is None else np.ascontiguousarray(eps, dtype=T)
+        self.mass = np.ones(self.n, T) if mass is None else np.ascontiguousarray(mass, dtype=T)
+        self.box = np.asarray(box, dtype=np.float64).reshape(3)
+        self.inter = inter if isinstance(inter, Interactions) else make_interactions(inter)
+        self.r_list = float(r_list)
+        self.rebuild_every = int(rebuild_every)
+        self.native = native
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+
+        def pairs(p):
+            if p is None or len(p) == 0:
+                return np.zeros(0, np.int32), np.zeros(0, np.int32)
+            p = np.asarray(p, dtype=np.int64).reshape(-1, 2)
+            return i32(p[:, 0]), i32(p[:, 1])
+
+        self.ex_i, self.ex_j = pairs(excluded)
+        self.sp_i, self.sp_j = pairs(special)
+        self.x_i, self.x_j = pairs(ewald_excl)
+        self._keep = []
+        s = OrcSystem()
+        s.n = self.n
+        s.coords = _ptr(self.coords); s.vel = _ptr(self.vel); s.charge = _ptr(self.charge)
+        s.sigma = _ptr(self.sigma); s.eps = _ptr(self.eps); s.mass = _ptr(self.mass)
+        for d in range(3):
+            s.box[d] = self.box[d]
+        s.inter = self.inter
+        s.r_list = self.r_list; s.rebuild_every = self.rebuild_every
+        s.ex_i, s.ex_j, s.n_ex = _ptr(self.ex_i), _ptr(self.ex_j), len(self.ex_i)
+        s.sp_i, s.sp_j, s.n_sp = _ptr(self.sp_i), _ptr(self.sp_j), len(self.sp_i)
+        s.x_i, s.x_j, s.n_ewx = _ptr(self.x_i), _ptr(self.x_j), len(self.x_i)
+        if bonds is not None and len(bonds["i"]):
+            b = [i32(bonds["i"]), i32(bonds["j"]), np.ascontiguousarray(bonds["k"], dtype=T), np.ascontiguousarray(bonds["r0"], dtype=T)]
+            self._keep += b
+            s.n_bonds = len(b[0]); s.b_i, s.b_j, s.b_k, s.b_r0 = map(_ptr, b)
+        if angles is not None and len(angles["i"]):
+            a = [i32(angles["i"]), i32(angles["j"]), i32(angles["k"]), np.ascontiguousarray(angles["kth"], dtype=T), np.ascontiguousarray(angles["th0"], dtype=T)]
+            self._keep += a
+            s.n_angles = len(a[0]); s.a_i, s.a_j, s.a_k, s.a_kth, s.a_th0 = map(_ptr, a)
+        if torsions is not None and len(torsions["i"]):
+            t = [i32(torsions["i"]), i32(torsions["j"]), i32(torsions["k"]), i32(torsions["l"]), i32(torsions["periodicity"]),
+                 np.ascontiguousarray(torsions["phase"], dtype=T), np.ascontiguousarray(torsions["k0"], dtype=T)]
+            self._keep += t
+            s.n_tors = len(t[0]); s.t_i, s.t_j, s.t_k, s.t_l, s.t_per, s.t_phase, s.t_k0 = map(_ptr, t)
+        self.s = s
+
+    @property
+    def L(self):
+        return lib(self.native)
+
+    def neighbors(self, method="cell", nthreads=1):
+        """(i, j, special) int32/int32/uint8 arrays, 0-based, i > j as neighbors.jl:404-412."""
+        n = self.L.orc_neighbors(self.prec, C.byref(self.s), 0 if method == "brute" else 1, nthreads, None, None, None, 0)
+        i = np.empty(n, np.int32); j = np.empty(n, np.int32); sp = np.empty(n, np.uint8)
+        n2 = self.L.orc_neighbors(self.prec, C.byref(self.s), 0 if method == "brute" else 1, nthreads, _ptr(i), _ptr(j), _ptr(sp), n)
+        assert n2 == n
+        return i, j, sp
+
+    def forces(self, nl=None, nthreads=1, pairwise=True, specific=False):
+        out = np.zeros((self.n, 3), self.dtype)
+        mask = (1 if pairwise else 0) | (2 if specific else 0)
+        if nl is None:
+            self.L.orc_forces(self.prec, C.byref(self.s), None, None, None, -1, nthreads, mask, _ptr(out))
+        else:
+            i, j, sp = nl
+            self.L.orc_forces(self.prec, C.byref(self.s), _ptr(i), _ptr(j), _ptr(sp), len(i), nthreads, mask, _ptr(out))
+        return out
+
+    def potential_energy(self, nl=None, pairwise=True, specific=False):
+        mask = (1 if pairwise else 0) | (2 if specific else 0)
+        if nl is None:
+            return self.L.orc_energy(self.prec, C.byref(self.s), None, None, None, -1, mask)
+        i, j, sp = nl
+        return self.L.orc_energy(self.prec, C.byref(self.s), _ptr(i), _ptr(j), _ptr(sp), len(i), mask)
+
+    def kinetic_energy(self):
+        return self.L.orc_kinetic_energy(self.prec, C.byref(self.s))
+
+    def remove_cm(self):
+        self.L.orc_remove_cm(self.prec, C.byref(self.s))
+
+    def wrap(self):
+        self.L.orc_wrap(self.prec, C.byref(self.s))
+
+    def vv_run(self, n_steps, dt, first_step=0, remove_cm_every=1, nthreads=1, pairwise=True, specific=False):
+        mask = (1 if pairwise else 0) | (2 if specific else 0)
+        self.L.orc_vv_run(self.prec, C.byref(self.s), first_step, n_steps, float(dt), remove_cm_every, nthreads, mask)
+
+    def force_scale(self, nl=None, rel_band=2e-6):
+        """Σ_j‖f_ij‖ per atom and the summed force discontinuity of pairs within rel_band of a hard
+        cutoff (fp64 system only) — the two terms of the fp32 tolerance used in the parity tests."""
+        assert self.prec == 64
+        scale = np.zeros(self.n); jump = np.zeros(self.n)
+        if nl is None:
+            self.L.orc_force_scale(C.byref(self.s), None, None, None, -1, rel_band, _ptr(scale), _ptr(jump))
+        else:
+            i, j, sp = nl
+            self.L.orc_force_scale(C.byref(self.s), _ptr(i), _ptr(j), _ptr(sp), len(i), rel_band, _ptr(scale), _ptr(jump))
+        return scale, jump
+
+
+def vector_1d(c1, c2, L, prec=64):
+    return lib().orc_vector_1d(prec, c1, c2, L)
+
+
+def wrap_1d(c, L, prec=64):
+    return lib().orc_wrap_1d(prec, c, L)
+
+
+def pair(inter, dr, qi=0.0, qj=0.0, si=0.0, sj=0.0, ei=0.0, ej=0.0, special=False, prec=64):
+    """Force on atom j (3-vector) and pair potential energy for displacement dr = r_j - r_i."""
+    it = inter if isinstance(inter, Interactions) else make_interactions(inter)
+    d = np.ascontiguousarray(dr, dtype=np.float64)
+    f = np.zeros(3); pe = C.c_double(0)
+    lib().orc_pair(prec, C.byref(it), _ptr(d), qi, qj, si, sj, ei, ej, int(special), _ptr(f), C.byref(pe))
+    return f, pe.value
+
+
+def hardware_threads():
+    return lib().orc_hardware_threads()
