@@ -1,0 +1,119 @@
+"""ctypes binding of libmollyhip.so (include/mollyhip.h).  There is no CPU fallback: if the HIP library is
+missing or no gfx950 device is visible, calls fail loudly."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmollyhip.so")
+
+MEM_HOST, MEM_DEVICE = 0, 1
+CUTOFF_NONE, CUTOFF_DISTANCE, CUTOFF_SHIFTED_POTENTIAL, CUTOFF_SHIFTED_FORCE, CUTOFF_CUBIC_SPLINE, CUTOFF_POLYNOMIAL = range(6)
+COUL_NONE, COUL_PLAIN, COUL_REACTION_FIELD, COUL_EWALD_DIRECT = range(4)
+
+STATUS = {0: "MHIP_OK", -1: "MHIP_ERR_INVALID", -2: "MHIP_ERR_HIP", -3: "MHIP_ERR_STATE", -4: "MHIP_ERR_CAPACITY",
+          -5: "MHIP_ERR_NO_DEVICE", -6: "MHIP_ERR_UNSUPPORTED", -7: "MHIP_ERR_NAN"}
+
+
+class MollyHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{STATUS.get(code, code)}: {msg}")
+        self.code = code
+
+
+class Interactions(C.Structure):
+    _fields_ = [("lj_enabled", C.c_int32), ("lj_cutoff_kind", C.c_int32), ("lj_rc", C.c_double), ("lj_ra", C.c_double),
+                ("lj_weight_special", C.c_double), ("coul_kind", C.c_int32), ("coul_cutoff_kind", C.c_int32),
+                ("coul_rc", C.c_double), ("coul_ra", C.c_double), ("coul_ke", C.c_double),
+                ("coul_weight_special", C.c_double), ("rf_dielectric", C.c_double), ("ewald_alpha", C.c_double),
+                ("ewald_approx_erfc", C.c_int32), ("reserved", C.c_int32)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class Config(C.Structure):
+    _fields_ = [("precision", C.c_int32), ("device_id", C.c_int32), ("n_atoms", C.c_int64), ("box", C.c_double * 3),
+                ("origin", C.c_double * 3), ("periodic", C.c_int32 * 3), ("rebuild_every", C.c_int32),
+                ("r_list", C.c_double), ("inter", Interactions)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_atoms", C.c_int64), ("n_owned", C.c_int64), ("n_ghost", C.c_int64), ("n_rebuilds", C.c_int64),
+                ("n_force_calls", C.c_int64), ("n_pairs_full", C.c_int64), ("n_list_slots", C.c_int64),
+                ("n_blocks", C.c_int64), ("tile_atoms_total", C.c_int64), ("block_atoms", C.c_int32),
+                ("j_split", C.c_int32), ("minimg_mode", C.c_int32), ("max_tile_atoms", C.c_int32),
+                ("last_rebuild_ms", C.c_double), ("lds_bytes", C.c_int64), ("algorithmic_bytes_step", C.c_int64)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+# every entry point of include/mollyhip.h: name -> (restype, argtypes)
+_P, _I32, _I64, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+SIGNATURES = {
+    "mhip_create": (_I32, [C.POINTER(_P), C.POINTER(Config)]),
+    "mhip_destroy": (_I32, [_P]),
+    "mhip_last_error": (C.c_char_p, [_P]),
+    "mhip_device_count": (_I32, [C.POINTER(_I32)]),
+    "mhip_set_stream": (_I32, [_P, _P]),
+    "mhip_synchronize": (_I32, [_P]),
+    "mhip_set_atom_counts": (_I32, [_P, _I64, _I64]),
+    "mhip_set_atoms": (_I32, [_P, _P, _P, _P, _P, _P, _I32]),
+    "mhip_set_exceptions": (_I32, [_P, _P, _P, _I64, _P, _P, _I64]),
+    "mhip_set_bonds": (_I32, [_P, _I64, _P, _P, _P, _P]),
+    "mhip_set_angles": (_I32, [_P, _I64, _P, _P, _P, _P, _P]),
+    "mhip_set_torsions": (_I32, [_P, _I64, _P, _P, _P, _P, _P, _P, _P]),
+    "mhip_set_ewald_exclusions": (_I32, [_P, _I64, _P, _P]),
+    "mhip_set_state": (_I32, [_P, _P, _P, _I32]),
+    "mhip_get_state": (_I32, [_P, _P, _P, _I32]),
+    "mhip_forces": (_I32, [_P, _I64, _I32, _P, _P, _I32]),
+    "mhip_specific_forces": (_I32, [_P, _I32, _P, _I32]),
+    "mhip_potential_energy": (_I32, [_P, _I64, C.POINTER(_D)]),
+    "mhip_specific_potential_energy": (_I32, [_P, C.POINTER(_D)]),
+    "mhip_kinetic_energy": (_I32, [_P, C.POINTER(_D)]),
+    "mhip_remove_cm": (_I32, [_P]),
+    "mhip_check_finite": (_I32, [_P]),
+    "mhip_vv_run": (_I32, [_P, _I64, _I64, _D, _I32]),
+    "mhip_vv_init": (_I32, [_P, _I64]),
+    "mhip_vv_stage1": (_I32, [_P, _D]),
+    "mhip_vv_stage2": (_I32, [_P, _I64, _D]),
+    "mhip_rebuild": (_I32, [_P, _I64]),
+    "mhip_export_neighbors": (_I32, [_P, _P, _P, _P, _I64, C.POINTER(_I64)]),
+    "mhip_export_order": (_I32, [_P, _P, _I64]),
+    "mhip_get_stats": (_I32, [_P, C.POINTER(Stats)]),
+    "mhip_gather_coords": (_I32, [_P, _P, _P, _I64, _P]),
+    "mhip_scatter_coords": (_I32, [_P, _I64, _I64, _P]),
+    "mhip_cm_momentum": (_I32, [_P, C.POINTER(_D * 4)]),
+    "mhip_shift_velocities": (_I32, [_P, C.POINTER(_D * 3)]),
+}
+
+
+def build(verbose=False):
+    """Compile libmollyhip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    subprocess.run(["make", "-C", os.path.join(_HERE, "csrc")], check=True,
+                   stdout=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MollyHipError(-5, f"{LIB_PATH} is missing: build it with molly_jl_amd.build() "
+                                    "(the product path has no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)   # AttributeError if the library does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def device_count():
+    n = _I32(0)
+    lib().mhip_device_count(C.byref(n))
+    return n.value

@@ -1,0 +1,483 @@
+"""Host-side mirror of the slice of Molly.jl's API that fronts the nonbonded hot path.
+
+Julia is not available in this image, so this module stands where `MollyHIPExt.jl` stands in
+a Julia session: same names, argument meaning and error behaviour as the reference, calling the same C ABI.
+Indices are 0-based here (Python), 1-based in Julia.
+
+Reference interfaces mirrored (Molly.jl v0.23.3):
+  System                      src/types.jl:795-979
+  Atom                        src/types.jl:466-475
+  CubicBoundary               src/spatial.jl:40
+  NoCutoff … PolynomialCutoff src/cutoffs.jl:53-253
+  LennardJones                src/interactions/lennard_jones.jl:25-47
+  Coulomb / CoulombReactionField / CoulombEwald   src/interactions/coulomb.jl:32, 698, 1320
+  DistanceNeighborFinder / GPUNeighborFinder      src/neighbors.jl:104-115, 376-388
+  NeighborList                src/types.jl:611-654
+  forces / potential_energy / kinetic_energy / temperature   src/force.jl:670-720, src/energy.jl:86-248
+  find_neighbors              src/neighbors.jl:390-423
+  VelocityVerlet, simulate!   src/simulators.jl:287-300, 547-668
+  remove_CM_motion!           src/spatial.jl:901-929
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from ._lib import MollyHipError
+
+COULOMB_CONST = 138.93545764   # coulomb.jl:16, kJ mol^-1 nm e^-2
+BOLTZMANN = 8.314462618e-3     # kJ mol^-1 K^-1 (setup.jl:2007)
+
+
+# ---- cutoffs (cutoffs.jl) ---------------------------------------------------------------------------
+@dataclass(frozen=True)
+class NoCutoff:
+    kind = _lib.CUTOFF_NONE
+    dist_cutoff: float = 0.0
+    dist_activation: float = 0.0
+
+
+@dataclass(frozen=True)
+class DistanceCutoff:
+    dist_cutoff: float
+    kind = _lib.CUTOFF_DISTANCE
+    dist_activation: float = 0.0
+
+
+@dataclass(frozen=True)
+class ShiftedPotentialCutoff:
+    dist_cutoff: float
+    kind = _lib.CUTOFF_SHIFTED_POTENTIAL
+    dist_activation: float = 0.0
+
+
+@dataclass(frozen=True)
+class ShiftedForceCutoff:
+    dist_cutoff: float
+    kind = _lib.CUTOFF_SHIFTED_FORCE
+    dist_activation: float = 0.0
+
+
+class _TwoRadiusCutoff:
+    def __init__(self, dist_activation, dist_cutoff):
+        if dist_cutoff <= dist_activation:   # cutoffs.jl:180-183, 234-237
+            raise ValueError(f"the cutoff radius {dist_cutoff} must be larger than the activation radius {dist_activation}")
+        self.dist_activation, self.dist_cutoff = float(dist_activation), float(dist_cutoff)
+
+
+class CubicSplineCutoff(_TwoRadiusCutoff):
+    kind = _lib.CUTOFF_CUBIC_SPLINE
+
+
+class PolynomialCutoff(_TwoRadiusCutoff):
+    kind = _lib.CUTOFF_POLYNOMIAL
+
+
+# ---- pairwise interactions ----------------------------------------------------------------------------
+@dataclass
+class LennardJones:
+    """LennardJones(; cutoff, use_neighbors, weight_special) with Lorentz σ / geometric ϵ mixing and the
+    LJZeroShortcut (the defaults, lennard_jones.jl:29-34)."""
+    cutoff: object = field(default_factory=NoCutoff)
+    use_neighbors: bool = False
+    weight_special: float = 1.0
+
+
+@dataclass
+class Coulomb:
+    cutoff: object = field(default_factory=NoCutoff)
+    use_neighbors: bool = False
+    weight_special: float = 1.0
+    coulomb_const: float = COULOMB_CONST
+
+
+@dataclass
+class CoulombReactionField:
+    dist_cutoff: float
+    solvent_dielectric: float = 78.3   # coulomb.jl:705 crf_solvent_dielectric
+    use_neighbors: bool = False
+    weight_special: float = 1.0
+    coulomb_const: float = COULOMB_CONST
+
+
+class CoulombEwald:
+    def __init__(self, dist_cutoff, error_tol=0.0005, use_neighbors=False, weight_special=1.0,
+                 coulomb_const=COULOMB_CONST, approximate_erfc=True, dtype=np.float64):
+        self.dist_cutoff, self.error_tol = float(dist_cutoff), float(error_tol)
+        self.use_neighbors, self.weight_special, self.coulomb_const = use_neighbors, float(weight_special), float(coulomb_const)
+        self.approximate_erfc = bool(approximate_erfc)
+        T = np.dtype(dtype).type
+        # α = inv(dist_cutoff) * sqrt(-log(2 * error_tol)) evaluated in T (coulomb.jl:1332)
+        self.α = float((T(1) / T(dist_cutoff)) * np.sqrt(-np.log(T(2) * T(error_tol))))
+
+
+def use_neighbors(inter):
+    return inter.use_neighbors
+
+
+# ---- specific interaction lists (SoA form of InteractionList{2,3,4}Atoms, types.jl:236-420) ---------
+@dataclass
+class HarmonicBonds:
+    i: np.ndarray; j: np.ndarray; k: np.ndarray; r0: np.ndarray
+
+
+@dataclass
+class HarmonicAngles:
+    i: np.ndarray; j: np.ndarray; k: np.ndarray; kθ: np.ndarray; θ0: np.ndarray
+
+
+@dataclass
+class PeriodicTorsions:
+    """One entry per (torsion, Fourier term); proper and improper torsions may share one list."""
+    i: np.ndarray; j: np.ndarray; k: np.ndarray; l: np.ndarray
+    periodicity: np.ndarray; phase: np.ndarray; k0: np.ndarray
+
+
+@dataclass
+class EwaldExclusions:
+    i: np.ndarray; j: np.ndarray
+
+
+# ---- boundary / atoms / neighbour finder ------------------------------------------------------------
+class CubicBoundary:
+    def __init__(self, x, y=None, z=None):
+        if y is None:
+            sl = np.broadcast_to(np.asarray(x, dtype=np.float64), (3,)).copy()
+        else:
+            sl = np.array([x, y, z], dtype=np.float64)
+        if np.any(sl <= 0):   # spatial.jl:46-48
+            raise ValueError("CubicBoundary side lengths must be positive")
+        self.side_lengths = sl
+
+
+@dataclass
+class Atom:
+    index: int = 0
+    atom_type: int = 0
+    mass: float = 1.0
+    charge: float = 0.0
+    σ: float = 0.0
+    ϵ: float = 0.0
+    λ: float = 1.0
+
+
+class NeighborList:
+    """n entries (i, j, special), i < j, 0-based."""
+    def __init__(self, i, j, special):
+        self.i, self.j, self.special = i, j, special
+        self.n = len(i)
+
+    @property
+    def list(self):
+        return list(zip(self.i.tolist(), self.j.tolist(), self.special.astype(bool).tolist()))
+
+
+def _pairs_from(arg, name):
+    """Accepts a dense boolean matrix (as Molly's eligible/special) or an (m,2) array of pairs."""
+    if arg is None:
+        return np.zeros((0, 2), np.int32)
+    a = np.asarray(arg)
+    if a.dtype == bool and a.ndim == 2 and a.shape[0] == a.shape[1]:
+        ii, jj = np.nonzero(np.triu(a, 1) | np.triu(a.T, 1))
+        return np.stack([ii, jj], 1).astype(np.int32)
+    a = a.reshape(-1, 2).astype(np.int64)
+    if len(a) and (a.min() < 0):
+        raise ValueError(f"{name}: negative atom index")
+    lo, hi = np.minimum(a[:, 0], a[:, 1]), np.maximum(a[:, 0], a[:, 1])
+    keep = lo != hi
+    # normalize_pairs: i<j, sorted, unique (neighbors.jl:171-195)
+    u = np.unique(np.stack([lo[keep], hi[keep]], 1), axis=0) if keep.any() else np.zeros((0, 2), np.int64)
+    return u.astype(np.int32)
+
+
+class GPUNeighborFinder:
+    """GPUNeighborFinder(; eligible, dist_cutoff, special, n_steps_reorder) — neighbors.jl:104-115, 320-361.
+    `eligible`/`special` may be dense Bool matrices or sparse pair arrays (`excluded_pairs`, `special_pairs`)."""
+    def __init__(self, dist_cutoff, eligible=None, special=None, excluded_pairs=None, special_pairs=None, n_steps=10):
+        self.dist_cutoff = float(dist_cutoff)
+        self.n_steps = int(n_steps)
+        if eligible is not None:
+            el = np.asarray(eligible, dtype=bool)
+            excluded_pairs = np.argwhere(np.triu(~el | ~el.T, 1))
+        self.excluded = _pairs_from(excluded_pairs, "excluded_pairs")
+        self.special = _pairs_from(special if special is not None else special_pairs, "special_pairs")
+
+
+DistanceNeighborFinder = GPUNeighborFinder       # same contract for this engine (neighbors.jl:376-388)
+CellListMapNeighborFinder = GPUNeighborFinder    # neighbors.jl:543-590
+
+
+class NoNeighborFinder:
+    dist_cutoff = math.inf
+    n_steps = 10
+    excluded = np.zeros((0, 2), np.int32)
+    special = np.zeros((0, 2), np.int32)
+
+
+@dataclass
+class VelocityVerlet:
+    dt: float
+    coupling: object = None
+    remove_CM_motion: int = 1    # simulators.jl:293
+
+
+# ---- System --------------------------------------------------------------------------------------------
+class System:
+    """System(; atoms, coords, boundary, velocities, pairwise_inters, specific_inter_lists, neighbor_finder)
+    with array type "MI355X": every force/energy/integration call runs in libmollyhip.so."""
+
+    def __init__(self, atoms=None, coords=None, boundary=None, velocities=None, pairwise_inters=(),
+                 specific_inter_lists=(), neighbor_finder=None, dtype=np.float32, device_id=0,
+                 charge=None, sigma=None, eps=None, mass=None):
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise ValueError("dtype must be float32 or float64")
+        T = self.dtype
+        if coords is None or boundary is None:
+            raise ValueError("coords and boundary are required")
+        self.coords = np.ascontiguousarray(coords, dtype=T).reshape(-1, 3).copy()
+        n = len(self.coords)
+        if atoms is not None:
+            if len(atoms) != n:   # types.jl:914-916
+                raise ValueError(f"there are {len(atoms)} atoms but {n} coordinates")
+            charge = [a.charge for a in atoms]; sigma = [a.σ for a in atoms]; eps = [a.ϵ for a in atoms]
+            mass = [a.mass for a in atoms]; lam = [a.λ for a in atoms]
+            self.λ = np.ascontiguousarray(lam, dtype=T)
+        else:
+            self.λ = None
+        arr = lambda a, d: np.full(n, d, T) if a is None else np.ascontiguousarray(a, dtype=T).reshape(n)
+        self.charge, self.σ, self.ϵ, self.masses = arr(charge, 0), arr(sigma, 0), arr(eps, 0), arr(mass, 1)
+        if velocities is not None and len(velocities) != n:
+            raise ValueError(f"there are {n} coordinates but {len(velocities)} velocities")
+        self.velocities = np.zeros((n, 3), T) if velocities is None else np.ascontiguousarray(velocities, dtype=T).reshape(n, 3).copy()
+        self.boundary = boundary if isinstance(boundary, CubicBoundary) else CubicBoundary(boundary)
+        self.pairwise_inters = tuple(pairwise_inters)
+        self.specific_inter_lists = tuple(specific_inter_lists)
+        self.neighbor_finder = neighbor_finder if neighbor_finder is not None else NoNeighborFinder()
+        self.device_id = device_id
+        self.total_mass = float(self.masses.sum(dtype=np.float64))
+        self._ctx = None
+        self._pushed_atoms = False
+
+    def __len__(self):
+        return len(self.coords)
+
+    # -- interaction tuple → mhip_interactions ------------------------------------------------------------
+    def interactions(self):
+        it = _lib.Interactions()
+        it.lj_weight_special = 1.0; it.coul_weight_special = 1.0; it.coul_ke = COULOMB_CONST; it.rf_dielectric = 1.0
+        it.ewald_approx_erfc = 1
+        n_coul = 0
+        for inter in self.pairwise_inters:
+            if isinstance(inter, LennardJones):
+                if it.lj_enabled:
+                    raise ValueError("only one LennardJones interaction is supported per System")
+                it.lj_enabled = 1; it.lj_cutoff_kind = inter.cutoff.kind
+                it.lj_rc = inter.cutoff.dist_cutoff; it.lj_ra = inter.cutoff.dist_activation
+                it.lj_weight_special = inter.weight_special
+            elif isinstance(inter, Coulomb):
+                n_coul += 1
+                it.coul_kind = _lib.COUL_PLAIN; it.coul_cutoff_kind = inter.cutoff.kind
+                it.coul_rc = inter.cutoff.dist_cutoff; it.coul_ra = inter.cutoff.dist_activation
+                it.coul_ke = inter.coulomb_const; it.coul_weight_special = inter.weight_special
+            elif isinstance(inter, CoulombReactionField):
+                n_coul += 1
+                it.coul_kind = _lib.COUL_REACTION_FIELD; it.coul_rc = inter.dist_cutoff
+                it.rf_dielectric = inter.solvent_dielectric; it.coul_ke = inter.coulomb_const
+                it.coul_weight_special = inter.weight_special
+            elif isinstance(inter, CoulombEwald):
+                n_coul += 1
+                it.coul_kind = _lib.COUL_EWALD_DIRECT; it.coul_rc = inter.dist_cutoff; it.ewald_alpha = inter.α
+                it.ewald_approx_erfc = int(inter.approximate_erfc); it.coul_ke = inter.coulomb_const
+                it.coul_weight_special = inter.weight_special
+            else:
+                raise MollyHipError(-6, f"pairwise interaction {type(inter).__name__} is outside the hot-path scope")
+        if n_coul > 1:
+            raise ValueError("only one Coulomb-type interaction is supported per System")
+        return it
+
+    def _uses_list(self):
+        inters = self.pairwise_inters
+        return any(use_neighbors(i) for i in inters) and math.isfinite(self.neighbor_finder.dist_cutoff)
+
+    # -- engine context ----------------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise MollyHipError(rc, _lib.lib().mhip_last_error(self._ctx).decode())
+
+    def engine(self):
+        if self._ctx is not None:
+            return self._ctx
+        L = _lib.lib()
+        inters = self.pairwise_inters
+        if inters and len({bool(use_neighbors(i)) for i in inters}) > 1:
+            raise MollyHipError(-6, "mixing use_neighbors=true and false interactions is not supported")
+        cfg = _lib.Config()
+        cfg.precision = 32 if self.dtype == np.float32 else 64
+        cfg.device_id = self.device_id
+        cfg.n_atoms = len(self)
+        for d in range(3):
+            cfg.box[d] = self.boundary.side_lengths[d]; cfg.origin[d] = 0.0; cfg.periodic[d] = 1
+        cfg.rebuild_every = self.neighbor_finder.n_steps
+        cfg.r_list = self.neighbor_finder.dist_cutoff if self._uses_list() else math.inf
+        cfg.inter = self.interactions()
+        ctx = C.c_void_p()
+        rc = L.mhip_create(C.byref(ctx), C.byref(cfg))
+        if rc != 0:
+            raise MollyHipError(rc, L.mhip_last_error(None).decode())
+        self._ctx = ctx
+        self._push_atoms()
+        return ctx
+
+    def _ptr(self, a):
+        return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+    def _push_atoms(self):
+        L = _lib.lib()
+        self._check(L.mhip_set_atoms(self._ctx, self._ptr(self.charge), self._ptr(self.σ), self._ptr(self.ϵ),
+                                     self._ptr(self.masses), self._ptr(self.λ), _lib.MEM_HOST))
+        nf = self.neighbor_finder
+        if self._uses_list() or len(nf.excluded) or len(nf.special):
+            ex = np.ascontiguousarray(nf.excluded, dtype=np.int32).reshape(-1, 2)
+            sp = np.ascontiguousarray(nf.special, dtype=np.int32).reshape(-1, 2)
+            exi, exj = np.ascontiguousarray(ex[:, 0]), np.ascontiguousarray(ex[:, 1])
+            spi, spj = np.ascontiguousarray(sp[:, 0]), np.ascontiguousarray(sp[:, 1])
+            self._check(L.mhip_set_exceptions(self._ctx, self._ptr(exi), self._ptr(exj), len(exi), self._ptr(spi), self._ptr(spj), len(spi)))
+        T = self.dtype
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        f = lambda a: np.ascontiguousarray(a, dtype=T)
+        for sil in self.specific_inter_lists:
+            if isinstance(sil, HarmonicBonds):
+                a = [i32(sil.i), i32(sil.j), f(sil.k), f(sil.r0)]
+                self._check(L.mhip_set_bonds(self._ctx, len(a[0]), *map(self._ptr, a)))
+            elif isinstance(sil, HarmonicAngles):
+                a = [i32(sil.i), i32(sil.j), i32(sil.k), f(sil.kθ), f(sil.θ0)]
+                self._check(L.mhip_set_angles(self._ctx, len(a[0]), *map(self._ptr, a)))
+            elif isinstance(sil, PeriodicTorsions):
+                a = [i32(sil.i), i32(sil.j), i32(sil.k), i32(sil.l), i32(sil.periodicity), f(sil.phase), f(sil.k0)]
+                self._check(L.mhip_set_torsions(self._ctx, len(a[0]), *map(self._ptr, a)))
+            elif isinstance(sil, EwaldExclusions):
+                a = [i32(sil.i), i32(sil.j)]
+                self._check(L.mhip_set_ewald_exclusions(self._ctx, len(a[0]), *map(self._ptr, a)))
+            else:
+                raise MollyHipError(-6, f"specific interaction list {type(sil).__name__} is outside the hot-path scope")
+
+    def push_state(self, velocities=True):
+        L = _lib.lib()
+        self.engine()
+        self._check(L.mhip_set_state(self._ctx, self._ptr(self.coords), self._ptr(self.velocities) if velocities else None, _lib.MEM_HOST))
+
+    def pull_state(self):
+        L = _lib.lib()
+        self._check(L.mhip_get_state(self._ctx, self._ptr(self.coords), self._ptr(self.velocities), _lib.MEM_HOST))
+
+    def stats(self):
+        st = _lib.Stats()
+        self._check(_lib.lib().mhip_get_stats(self.engine(), C.byref(st)))
+        return st.as_dict()
+
+    def close(self):
+        if self._ctx is not None:
+            _lib.lib().mhip_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- free functions mirroring Molly's exports ---------------------------------------------------------
+def forces(sys, step_n=0, pairwise=True, specific=True):
+    """forces(sys; …): pairwise + specific interaction forces, (n,3) array (force.jl:670-720)."""
+    L = _lib.lib()
+    sys.push_state(velocities=False)
+    out = np.zeros((len(sys), 3), sys.dtype)
+    if pairwise and sys.pairwise_inters:
+        sys._check(L.mhip_forces(sys._ctx, step_n, 1, sys._ptr(out), None, _lib.MEM_HOST))
+    if specific and sys.specific_inter_lists:
+        sys._check(L.mhip_specific_forces(sys._ctx, 1, sys._ptr(out), _lib.MEM_HOST))
+    return out
+
+
+def potential_energy(sys, step_n=0, pairwise=True, specific=True):
+    """potential_energy(sys; …) (energy.jl:207-248, 409-446)."""
+    L = _lib.lib()
+    sys.push_state(velocities=False)
+    total = 0.0
+    pe = C.c_double(0)
+    if pairwise and sys.pairwise_inters:
+        sys._check(L.mhip_potential_energy(sys._ctx, step_n, C.byref(pe)))
+        total += pe.value
+    if specific and sys.specific_inter_lists:
+        sys._check(L.mhip_specific_potential_energy(sys._ctx, C.byref(pe)))
+        total += pe.value
+    return total
+
+
+def kinetic_energy(sys):
+    L = _lib.lib()
+    sys.push_state(velocities=True)
+    ke = C.c_double(0)
+    sys._check(L.mhip_kinetic_energy(sys._ctx, C.byref(ke)))
+    return ke.value
+
+
+def temperature(sys):
+    """T = 2 KE / (df k), df = 3N − 3 for a fully periodic box (energy.jl:158-175)."""
+    return 2 * kinetic_energy(sys) / ((3 * len(sys) - 3) * BOLTZMANN)
+
+
+def total_energy(sys):
+    return kinetic_energy(sys) + potential_energy(sys)
+
+
+def find_neighbors(sys, step_n=0):
+    """find_neighbors(sys, sys.neighbor_finder) → NeighborList (neighbors.jl:390-423); None without a list."""
+    if not sys._uses_list():
+        return None
+    L = _lib.lib()
+    sys.push_state(velocities=False)
+    sys._check(L.mhip_rebuild(sys._ctx, step_n))
+    n = C.c_int64(0)
+    sys._check(L.mhip_export_neighbors(sys._ctx, None, None, None, 0, C.byref(n)))
+    i = np.empty(n.value, np.int32); j = np.empty(n.value, np.int32); sp = np.empty(n.value, np.uint8)
+    if n.value:
+        sys._check(L.mhip_export_neighbors(sys._ctx, sys._ptr(i), sys._ptr(j), sys._ptr(sp), n.value, C.byref(n)))
+    return NeighborList(i, j, sp)
+
+
+def remove_CM_motion(sys):
+    """remove_CM_motion!(sys) (spatial.jl:901-929)."""
+    L = _lib.lib()
+    sys.push_state(velocities=True)
+    sys._check(L.mhip_remove_cm(sys._ctx))
+    sys.pull_state()
+    return sys
+
+
+def simulate(sys, sim, n_steps, init_step=0, check_nans=False):
+    """simulate!(sys, sim::VelocityVerlet, n_steps; init_step) — simulators.jl:547-668.  The whole loop runs on
+    the device; coordinates and velocities come back when the call returns."""
+    if not isinstance(sim, VelocityVerlet):
+        raise MollyHipError(-6, f"simulator {type(sim).__name__} is outside the hot-path scope")
+    if sim.coupling is not None:
+        raise MollyHipError(-6, "coupling is outside the hot-path scope")
+    if init_step < 0:   # check_simulate_inputs
+        raise ValueError("init_step must be non-negative")
+    L = _lib.lib()
+    sys.push_state(velocities=True)
+    sys._check(L.mhip_vv_run(sys._ctx, init_step, n_steps, float(sim.dt), int(sim.remove_CM_motion)))
+    if check_nans:
+        sys._check(L.mhip_check_finite(sys._ctx))
+    sys.pull_state()
+    return sys
+
+
+def wrap_coords(coords, boundary):
+    c = np.asarray(coords)
+    L = boundary.side_lengths.astype(c.dtype)
+    return c - np.floor(c / L) * L

@@ -1,0 +1,59 @@
+// common.h — shared types for the MI355X (gfx950) nonbonded engine.  CDNA4 only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/mollyhip.h"
+
+namespace mhip {
+
+constexpr int WAVE = 64;
+constexpr int MAX_LDS_BYTES = 160 * 1024;   // LDS per CU on gfx950 (MI355X_MICROARCH.md)
+constexpr int TILE_SLOT_MAX = 32767;        // 15-bit tile slot + 1-bit special flag per list entry
+
+template <class T> struct Vec;
+template <> struct Vec<float> { using T4 = float4; using T2 = float2; };
+template <> struct Vec<double> { using T4 = double4; using T2 = double2; };
+
+template <class T> __host__ __device__ inline typename Vec<T>::T4 make4(T x, T y, T z, T w) {
+    typename Vec<T>::T4 v; v.x = x; v.y = y; v.z = z; v.w = w; return v;
+}
+template <class T> __host__ __device__ inline typename Vec<T>::T2 make2(T x, T y) {
+    typename Vec<T>::T2 v; v.x = x; v.y = y; return v;
+}
+
+// Geometry of the (sub-)domain: orthorhombic box, cell grid of the neighbour search.
+template <class T> struct GridP {
+    T L[3], invL[3], origin[3];
+    T cs[3], inv_cs[3];        // cell size (>= r_list / stencil) and its inverse
+    int periodic[3];
+    int nc[3];                 // cells per axis
+    int stencil[3];            // cells to visit on each side (clamped so a cell is never visited twice)
+    int all_cells[3];          // 1: visit every cell of that axis (small boxes / no neighbour list)
+    int ncell;
+    T r_list, r_list2;         // +inf when every pair interacts
+    int no_list;
+};
+
+// pairwise_inters in device-friendly form (constants rounded to T on the host exactly as the
+// reference stores them inside the interaction structs)
+template <class T> struct InterP {
+    int lj, lj_cut; T lj_rc, lj_rc2, lj_ra, lj_w;
+    int coul, coul_cut; T c_rc, c_rc2, c_ra, ke, c_w;
+    T krf, crf;                // reaction-field constants for non-special pairs (coulomb.jl:764-768,799-803)
+    T alpha, two_over_sqrt_pi;
+    int approx_erfc;
+};
+
+struct HipErr { hipError_t e; const char* what; };
+#define MHIP_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) throw mhip::HipErr{_e, #expr}; } while (0)
+
+struct ApiError { int32_t code; std::string msg; };
+
+inline int cdiv(int64_t a, int64_t b) { return int((a + b - 1) / b); }
+
+}  // namespace mhip

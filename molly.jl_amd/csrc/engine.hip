@@ -1,0 +1,757 @@
+// engine.hip — host side of libmollyhip.so: context, neighbour rebuild pipeline, kernel launches and the
+// C ABI of include/mollyhip.h.  One context = one GPU = one HIP stream (one process per GPU).
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "bonded.h"
+#include "hilbert.h"
+#include "kernels.h"
+#include "sortscan.h"
+
+namespace mhip {
+
+static thread_local std::string g_create_error;
+
+template <class U> struct DBuf {
+    U* p = nullptr; size_t n = 0;
+    void reserve(size_t m) { if (m > n) { if (p) (void)hipFree(p); p = nullptr; MHIP_HIP(hipMalloc((void**)&p, std::max<size_t>(m, 1) * sizeof(U))); n = m; } }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+struct EngineBase {
+    std::string err;
+    virtual ~EngineBase() {}
+    virtual void set_stream(void* s) = 0;
+    virtual void synchronize() = 0;
+    virtual void set_atom_counts(int64_t, int64_t) = 0;
+    virtual void set_atoms(const void*, const void*, const void*, const void*, const void*, int) = 0;
+    virtual void set_exceptions(const int32_t*, const int32_t*, int64_t, const int32_t*, const int32_t*, int64_t) = 0;
+    virtual void set_bonds(int64_t, const int32_t*, const int32_t*, const void*, const void*) = 0;
+    virtual void set_angles(int64_t, const int32_t*, const int32_t*, const int32_t*, const void*, const void*) = 0;
+    virtual void set_torsions(int64_t, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const void*, const void*) = 0;
+    virtual void set_ewald_exclusions(int64_t, const int32_t*, const int32_t*) = 0;
+    virtual void set_state(const void*, const void*, int) = 0;
+    virtual void get_state(void*, void*, int) = 0;
+    virtual void forces(int64_t, int, void*, int) = 0;
+    virtual void specific_forces(int, void*, int) = 0;
+    virtual double potential_energy(int64_t) = 0;
+    virtual double specific_potential_energy() = 0;
+    virtual double kinetic_energy() = 0;
+    virtual void remove_cm() = 0;
+    virtual void check_finite() = 0;
+    virtual void vv_run(int64_t, int64_t, double, int) = 0;
+    virtual void vv_init(int64_t) = 0;
+    virtual void vv_stage1(double) = 0;
+    virtual void vv_stage2(int64_t, double) = 0;
+    virtual void rebuild_now(int64_t) = 0;
+    virtual int64_t export_neighbors(int32_t*, int32_t*, uint8_t*, int64_t) = 0;
+    virtual void export_order(int32_t*, int64_t) = 0;
+    virtual void get_stats(mhip_stats*) = 0;
+    virtual void gather_coords(const int32_t*, const void*, int64_t, void*) = 0;
+    virtual void scatter_coords(int64_t, int64_t, const void*) = 0;
+    virtual void cm_momentum(double*) = 0;
+    virtual void shift_velocities(const double*) = 0;
+};
+
+static int env_int(const char* name, int dflt) { const char* v = std::getenv(name); return v && *v ? std::atoi(v) : dflt; }
+
+template <class T> class Engine final : public EngineBase {
+    using T4 = typename Vec<T>::T4;
+    using T2 = typename Vec<T>::T2;
+
+    mhip_config cfg;
+    GridP<T> G;
+    InterP<T> I;
+    int ljm = LJ_OFF, coulm = MHIP_COUL_NONE;
+    int64_t cap, n_owned, n_ghost, n_tot;
+    hipStream_t stream = nullptr; bool own_stream = false;
+    int device = 0;
+
+    // per-atom state in sorted order, double-buffered for the re-sort
+    DBuf<T4> pos[2], vel[2], frc[2]; DBuf<T2> lj[2]; DBuf<int32_t> orig[2]; DBuf<int32_t> inv;
+    int cur = 0;
+    // sort / cells
+    DBuf<uint32_t> key_in, key_out, cell_rank; DBuf<int32_t> idx_in, perm, cell_cnt, cell_start; DBuf<unsigned char> cub_tmp;
+    bool hilbert_ok = true;
+    // exceptions (CSR over caller indices)
+    DBuf<int32_t> ex_start, ex_list, sp_start, sp_list; bool has_exc = false;
+    // blocks
+    int BI = 256, JS = 1, n_blocks = 0, T_cap = 0, R_cap = 0, max_tile = 0, max_rows = 0;
+    DBuf<int32_t> tile_idx, tile_cnt, wave_rows; DBuf<uint2> nbr; DBuf<T4> blk_center;
+    DBuf<int32_t> flags; int32_t* h_flags = nullptr;
+    int64_t total_rows = 0;
+    // reductions
+    DBuf<double> red_part, red_out; double* h_red = nullptr; DBuf<T> vcm;
+    // staging for host pointers
+    DBuf<T> stage_a, stage_b; DBuf<int32_t> stage_i;
+    // bonded
+    Bonded<T> bonded;
+
+    bool stale = true, minimg = false, cm_pending = false, params_set = false, state_set = false, frc_valid = false;
+    int64_t last_build_step = std::numeric_limits<int64_t>::min();
+    int64_t n_rebuilds = 0, n_force_calls = 0; double last_rebuild_ms = 0;
+    size_t lds_force = 0;
+
+  public:
+    explicit Engine(const mhip_config& c) : cfg(c) {
+        cap = c.n_atoms; n_owned = cap; n_ghost = 0; n_tot = cap;
+        if (cap <= 0) throw ApiError{MHIP_ERR_INVALID, "n_atoms must be positive"};
+        if (cap > (int64_t)1 << 30) throw ApiError{MHIP_ERR_INVALID, "n_atoms too large for int32 indexing"};
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw ApiError{MHIP_ERR_NO_DEVICE, "no HIP device visible (libmollyhip has no CPU fallback)"};
+        device = c.device_id;
+        if (device < 0 || device >= ndev) throw ApiError{MHIP_ERR_INVALID, "device_id out of range"};
+        MHIP_HIP(hipSetDevice(device));
+        MHIP_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); own_stream = true;
+        setup_inter(); setup_grid();
+        for (int k = 0; k < 2; ++k) { pos[k].reserve(cap); vel[k].reserve(cap); frc[k].reserve(cap); lj[k].reserve(cap); orig[k].reserve(cap); }
+        inv.reserve(cap); key_in.reserve(cap); key_out.reserve(cap); idx_in.reserve(cap); perm.reserve(cap);
+        flags.reserve(N_FLAGS); red_out.reserve(8); vcm.reserve(4);
+        MHIP_HIP(hipHostMalloc((void**)&h_flags, N_FLAGS * sizeof(int32_t)));
+        MHIP_HIP(hipHostMalloc((void**)&h_red, 8 * sizeof(double)));
+        for (int k = 0; k < 2; ++k) { MHIP_HIP(hipMemsetAsync(pos[k].p, 0, cap * sizeof(T4), stream)); MHIP_HIP(hipMemsetAsync(vel[k].p, 0, cap * sizeof(T4), stream)); MHIP_HIP(hipMemsetAsync(frc[k].p, 0, cap * sizeof(T4), stream)); MHIP_HIP(hipMemsetAsync(lj[k].p, 0, cap * sizeof(T2), stream)); }
+        std::vector<int32_t> iota(cap); for (int64_t i = 0; i < cap; ++i) iota[i] = (int32_t)i;
+        MHIP_HIP(hipMemcpyAsync(orig[0].p, iota.data(), cap * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        MHIP_HIP(hipMemcpyAsync(inv.p, iota.data(), cap * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        MHIP_HIP(hipStreamSynchronize(stream));
+        size_t tb = 0; MHIP_HIP(sort_pairs_u32(nullptr, tb, key_in.p, key_out.p, idx_in.p, perm.p, (int)cap, 32, stream));
+        size_t tb2 = 0; MHIP_HIP(exclusive_sum_i32(nullptr, tb2, cell_cnt.p, cell_start.p, 2 * G.ncell + 1, stream));
+        cub_tmp.reserve(std::max(tb, tb2) + 256);
+        choose_blocking();
+    }
+    ~Engine() override {
+        (void)hipSetDevice(device);
+        if (stream) (void)hipStreamSynchronize(stream);
+        for (int k = 0; k < 2; ++k) { pos[k].release(); vel[k].release(); frc[k].release(); lj[k].release(); orig[k].release(); }
+        inv.release(); key_in.release(); key_out.release(); cell_rank.release(); idx_in.release(); perm.release(); cell_cnt.release(); cell_start.release(); cub_tmp.release();
+        ex_start.release(); ex_list.release(); sp_start.release(); sp_list.release(); tile_idx.release(); tile_cnt.release(); wave_rows.release(); nbr.release(); blk_center.release();
+        flags.release(); red_part.release(); red_out.release(); vcm.release(); stage_a.release(); stage_b.release(); stage_i.release(); bonded.release();
+        if (h_flags) (void)hipHostFree(h_flags);
+        if (h_red) (void)hipHostFree(h_red);
+        if (own_stream && stream) (void)hipStreamDestroy(stream);
+    }
+
+  private:
+    // ---------------------------------------------------------------------------------------------
+    void setup_inter() {
+        const mhip_interactions& p = cfg.inter;
+        std::memset(&I, 0, sizeof(I));
+        I.lj = p.lj_enabled; I.lj_cut = p.lj_cutoff_kind; I.lj_rc = T(p.lj_rc); I.lj_rc2 = I.lj_rc * I.lj_rc; I.lj_ra = T(p.lj_ra); I.lj_w = T(p.lj_weight_special);
+        I.coul = p.coul_kind; I.coul_cut = p.coul_cutoff_kind; I.c_rc = T(p.coul_rc); I.c_rc2 = I.c_rc * I.c_rc; I.c_ra = T(p.coul_ra);
+        I.ke = T(p.coul_ke); I.c_w = T(p.coul_weight_special); I.alpha = T(p.ewald_alpha); I.approx_erfc = p.ewald_approx_erfc;
+        I.two_over_sqrt_pi = T(2) / std::sqrt(T(M_PI));
+        if (p.lj_cutoff_kind < 0 || p.lj_cutoff_kind > 5 || p.coul_cutoff_kind < 0 || p.coul_cutoff_kind > 5 || p.coul_kind < 0 || p.coul_kind > 3)
+            throw ApiError{MHIP_ERR_INVALID, "unknown cutoff / coulomb kind"};
+        if (p.coul_kind == MHIP_COUL_REACTION_FIELD) {   // coulomb.jl:764-768, 799-803, evaluated in T like the reference
+            T rc = I.c_rc, rc3 = rc * rc * rc, e = T(p.rf_dielectric);
+            if (std::isinf(p.rf_dielectric)) { I.krf = T(1) / (T(2) * rc3); I.crf = T(3) * (T(1) / (T(2) * rc)); }
+            else { I.krf = (T(1) / rc3) * (e - T(1)) / (T(2) * e + T(1)); I.crf = (T(1) / rc) * (T(3) * e) / (T(2) * e + T(1)); }
+        }
+        ljm = !p.lj_enabled ? LJ_OFF : (p.lj_cutoff_kind == MHIP_CUTOFF_DISTANCE ? LJ_DIST : LJ_GENERIC);
+        coulm = p.coul_kind;
+        if ((p.lj_enabled && p.lj_cutoff_kind != MHIP_CUTOFF_NONE && !(p.lj_rc > 0)) ||
+            (p.coul_kind >= MHIP_COUL_REACTION_FIELD && !(p.coul_rc > 0)))
+            throw ApiError{MHIP_ERR_INVALID, "cutoff distance must be positive"};
+    }
+
+    void setup_grid() {
+        std::memset(&G, 0, sizeof(G));
+        G.no_list = !(cfg.r_list > 0) || std::isinf(cfg.r_list);
+        G.r_list = G.no_list ? std::numeric_limits<T>::infinity() : T(cfg.r_list);
+        G.r_list2 = G.no_list ? std::numeric_limits<T>::infinity() : G.r_list * G.r_list;   // dist_cutoff^2, neighbors.jl:400
+        const int S = std::max(1, env_int("MOLLYHIP_STENCIL", 2));
+        for (int d = 0; d < 3; ++d) {
+            if (!(cfg.box[d] > 0) || std::isinf(cfg.box[d]) || std::isnan(cfg.box[d])) throw ApiError{MHIP_ERR_INVALID, "box side lengths must be positive and finite"};
+            G.L[d] = T(cfg.box[d]); G.invL[d] = T(1) / G.L[d]; G.origin[d] = cfg.periodic[d] ? T(0) : T(cfg.origin[d]); G.periodic[d] = cfg.periodic[d] ? 1 : 0;
+            int nc = 1;
+            if (!G.no_list) { nc = (int)std::floor(cfg.box[d] / (cfg.r_list / S)); nc = std::max(1, std::min(nc, 1024)); }
+            G.nc[d] = nc; G.cs[d] = T(cfg.box[d] / nc); G.inv_cs[d] = T(nc / cfg.box[d]);
+            G.stencil[d] = S; G.all_cells[d] = (G.no_list || 2 * S + 1 >= nc) ? 1 : 0;
+        }
+        // keep the cell table small: coarsen until ncell <= 2^22
+        while ((int64_t)G.nc[0] * G.nc[1] * G.nc[2] > (1 << 22)) for (int d = 0; d < 3; ++d) { G.nc[d] = std::max(1, G.nc[d] / 2); G.cs[d] = T(cfg.box[d] / G.nc[d]); G.inv_cs[d] = T(G.nc[d] / cfg.box[d]); }
+        G.ncell = G.nc[0] * G.nc[1] * G.nc[2];
+        std::vector<uint32_t> rank;
+        hilbert_ok = hilbert_cell_ranks(G.nc[0], G.nc[1], G.nc[2], rank);
+        cell_rank.reserve(G.ncell);
+        MHIP_HIP(hipMemcpy(cell_rank.p, rank.data(), (size_t)G.ncell * sizeof(uint32_t), hipMemcpyHostToDevice));
+        cell_cnt.reserve(2 * (size_t)G.ncell + 1); cell_start.reserve(2 * (size_t)G.ncell + 1);
+    }
+
+    static int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
+
+    size_t build_lds_bytes(int tcap, int bi) const {
+        return (size_t)tcap * (sizeof(T4) + 4) + (2 * MAX_BOX_CELLS + 1) * 4 + std::max<size_t>(6 * (size_t)bi * sizeof(T), (size_t)bi * 4) + 64;
+    }
+    size_t force_lds_bytes(int tlds) const {
+        size_t tile = (size_t)(tlds + 1) * (sizeof(T4) + (ljm != LJ_OFF ? sizeof(T2) : 0));
+        size_t red = (size_t)JS * 4 * BI * sizeof(T);
+        return std::max(std::max(tile, red), (size_t)BI * sizeof(double)) + 32;
+    }
+
+    void choose_blocking() {
+        // i-block size and j-split: enough waves to fill 256 CUs × 4 SIMDs even for small systems
+        int bi, js;
+        if (n_owned >= 100000) { bi = 256; js = 1; }
+        else if (n_owned >= 40000) { bi = 128; js = 2; }
+        else { bi = 64; js = 8; }
+        bi = env_int("MOLLYHIP_BLOCK_I", bi); js = env_int("MOLLYHIP_J_SPLIT", js);
+        if (bi != 64 && bi != 128 && bi != 256) throw ApiError{MHIP_ERR_INVALID, "MOLLYHIP_BLOCK_I must be 64, 128 or 256"};
+        if (js < 1 || bi * js > 1024) throw ApiError{MHIP_ERR_INVALID, "MOLLYHIP_J_SPLIT out of range (BLOCK_I*J_SPLIT <= 1024)"};
+        BI = bi; JS = js;
+        estimate_capacities();
+    }
+
+    void estimate_capacities() {
+        n_blocks = cdiv(n_owned, BI);
+        double vol = 1; for (int d = 0; d < 3; ++d) vol *= cfg.box[d];
+        double rho = (double)n_tot / vol;
+        if (G.no_list) { T_cap = (int)n_tot + 8; R_cap = cdiv(n_tot, 4) + 2; }
+        else {
+            double r = cfg.r_list * 1.001, a = std::cbrt(BI / rho);
+            double v_tile = a * a * a + 6 * a * a * r + 3 * M_PI * a * r * r + 4.0 / 3.0 * M_PI * r * r * r;
+            T_cap = (int)std::min<double>(1.4 * rho * v_tile + 64, (double)n_tot + 8);
+            R_cap = (int)std::min<double>(1.5 * rho * 4.0 / 3.0 * M_PI * r * r * r / 4 + 8, n_tot / 4.0 + 2);
+        }
+        T_cap = std::max(T_cap, 16); R_cap = std::max(R_cap, 2);
+        T_cap = std::min(T_cap, TILE_SLOT_MAX - 1);
+    }
+
+    template <class K> void set_lds_limit(K kern, size_t bytes) {
+        if (bytes > (size_t)MAX_LDS_BYTES) throw ApiError{MHIP_ERR_CAPACITY, "atom tile does not fit the 160 KiB LDS"};
+        if (bytes > 64 * 1024) MHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    }
+
+    void flush_cm() {
+        if (!cm_pending) return;
+        hipLaunchKernelGGL(k_shift_vel<T>, dim3(cdiv(n_owned, 256)), dim3(256), 0, stream, n_owned, vel[cur].p, (const T*)vcm.p);
+        cm_pending = false;
+    }
+
+    const T* to_device(const void* host_or_dev, size_t count, int mem_kind, DBuf<T>& stage) {
+        if (!host_or_dev) return nullptr;
+        if (mem_kind == MHIP_MEM_DEVICE) return (const T*)host_or_dev;
+        stage.reserve(count);
+        MHIP_HIP(hipMemcpyAsync(stage.p, host_or_dev, count * sizeof(T), hipMemcpyHostToDevice, stream));
+        return stage.p;
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // the neighbour rebuild pipeline (≙ find_neighbors + the reorder/compress/tile-search stages of
+    // ext/MollyCUDAExt.jl:845-873, redesigned O(N))
+    void rebuild(int64_t step_n) {
+        if (!params_set || !state_set) throw ApiError{MHIP_ERR_STATE, "set_atoms and set_state must be called before forces"};
+        auto t0 = std::chrono::steady_clock::now();
+        const int o = cur, n = 1 - cur;
+        const int ncell2 = 2 * G.ncell + 1;
+        MHIP_HIP(hipMemsetAsync(cell_cnt.p, 0, (size_t)ncell2 * sizeof(int32_t), stream));
+        const int nb256 = cdiv(n_tot, 256);
+        hipLaunchKernelGGL(k_cell_keys<T>, dim3(nb256), dim3(256), 0, stream, n_tot, n_owned, (const T4*)pos[o].p, (const int32_t*)orig[o].p,
+                           (const uint32_t*)cell_rank.p, key_in.p, idx_in.p, cell_cnt.p, G);
+        size_t tb = cub_tmp.n;
+        MHIP_HIP(sort_pairs_u32(cub_tmp.p, tb, key_in.p, key_out.p, idx_in.p, perm.p, (int)n_tot, ilog2(2 * G.ncell + 1) + 1 > 32 ? 32 : ilog2(2 * G.ncell + 1) + 1, stream));
+        tb = cub_tmp.n;
+        MHIP_HIP(exclusive_sum_i32(cub_tmp.p, tb, cell_cnt.p, cell_start.p, ncell2, stream));
+        hipLaunchKernelGGL(k_permute<T>, dim3(nb256), dim3(256), 0, stream, n_tot, (const int32_t*)perm.p, (const T4*)pos[o].p, (const T4*)vel[o].p,
+                           (const T4*)frc[o].p, (const T2*)lj[o].p, (const int32_t*)orig[o].p, pos[n].p, vel[n].p, frc[n].p, lj[n].p, orig[n].p, inv.p);
+        cur = n;
+        if (n_ghost > 0 && has_exc) throw ApiError{MHIP_ERR_UNSUPPORTED, "exclusion lists with ghost atoms are not supported"};
+
+        for (int attempt = 0; attempt < 12; ++attempt) {
+            n_blocks = cdiv(n_owned, BI);
+            size_t lds = build_lds_bytes(T_cap, BI);
+            if (lds > (size_t)MAX_LDS_BYTES) {
+                if (BI > 64) { BI /= 2; JS = std::min(JS * 2, 1024 / BI); estimate_capacities(); continue; }
+                throw ApiError{MHIP_ERR_CAPACITY, "neighbourhood tile of one 64-atom block does not fit the 160 KiB LDS (r_list too large for this density)"};
+            }
+            tile_idx.reserve((size_t)n_blocks * T_cap); tile_cnt.reserve(n_blocks); wave_rows.reserve((size_t)n_blocks * (BI / WAVE));
+            nbr.reserve((size_t)n_blocks * R_cap * BI); blk_center.reserve(n_blocks);
+            MHIP_HIP(hipMemsetAsync(flags.p, 0, N_FLAGS * sizeof(int32_t), stream));
+            BuildArgs<T> A;
+            A.G = G; A.n_owned = n_owned; A.n_tot = n_tot; A.BI = BI; A.T_cap = T_cap; A.R_cap = R_cap;
+            A.pos = pos[cur].p; A.orig = orig[cur].p; A.cell_start = cell_start.p; A.cell_rank = cell_rank.p;
+            A.ex_start = has_exc ? ex_start.p : nullptr; A.ex_list = ex_list.p; A.sp_start = sp_start.p; A.sp_list = sp_list.p;
+            A.tile_idx = tile_idx.p; A.tile_cnt = tile_cnt.p; A.nbr = nbr.p; A.wave_rows = wave_rows.p; A.blk_center = blk_center.p; A.flags = flags.p;
+            A.margin = G.no_list ? T(0) : G.r_list * T(1e-3);
+            set_lds_limit(k_build<T>, lds);
+            hipLaunchKernelGGL(k_build<T>, dim3(n_blocks), dim3(BI), lds, stream, A);
+            MHIP_HIP(hipGetLastError());
+            MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            MHIP_HIP(hipStreamSynchronize(stream));
+            int ovf = h_flags[FLAG_OVERFLOW];
+            if (!ovf) break;
+            if (ovf & OVF_SLOT) {
+                if (BI > 64) { BI /= 2; JS = std::min(JS * 2, 1024 / BI); estimate_capacities(); continue; }
+                throw ApiError{MHIP_ERR_CAPACITY, "more than 32766 atoms within r_list of one 64-atom block"};
+            }
+            if (ovf & OVF_BOXCELLS) {
+                if (BI > 64) { BI /= 2; JS = std::min(JS * 2, 1024 / BI); estimate_capacities(); continue; }
+                throw ApiError{MHIP_ERR_CAPACITY, "block neighbourhood spans more than 4096 cells"};
+            }
+            if (ovf & OVF_TILE) T_cap = std::min<int>(TILE_SLOT_MAX - 1, (int)(h_flags[FLAG_MAX_TILE] * 1.15) + 32);
+            if (ovf & OVF_ROWS) R_cap = (int)(h_flags[FLAG_MAX_ROWS] * 1.2) + 4;
+            if (attempt == 11) throw ApiError{MHIP_ERR_CAPACITY, "neighbour structures did not converge"};
+        }
+        minimg = h_flags[FLAG_MINIMG] != 0 || env_int("MOLLYHIP_FORCE_MINIMG", 0) != 0;
+        max_tile = h_flags[FLAG_MAX_TILE]; max_rows = h_flags[FLAG_MAX_ROWS]; total_rows = h_flags[FLAG_TOTAL_ROWS];
+        lds_force = force_lds_bytes(max_tile);
+        if (lds_force > (size_t)MAX_LDS_BYTES) throw ApiError{MHIP_ERR_CAPACITY, "force-kernel tile does not fit the 160 KiB LDS"};
+        red_part.reserve(std::max<size_t>((size_t)n_blocks, 4 * (size_t)cdiv(n_owned, 256)) + 8);
+        bonded.on_reorder();
+        stale = false; last_build_step = step_n; ++n_rebuilds;
+        last_rebuild_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+
+    void ensure_built(int64_t step_n) {
+        const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
+        if (stale || (step_n % every == 0 && step_n != last_build_step)) rebuild(step_n);
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    template <int LJM, int COULM, bool ENERGY, bool MINIMG> void launch_forces_t(const ForceArgs<T>& A) {
+        auto kern = k_forces<T, LJM, COULM, ENERGY, MINIMG>;
+        set_lds_limit(kern, lds_force);
+        hipLaunchKernelGGL(kern, dim3(A.blocks_per_xcd * 8), dim3(BI * JS), lds_force, stream, A);
+    }
+    template <int LJM, int COULM> void launch_forces_c(const ForceArgs<T>& A, bool energy) {
+        if (energy) { if (minimg) launch_forces_t<LJM, COULM, true, true>(A); else launch_forces_t<LJM, COULM, true, false>(A); }
+        else { if (minimg) launch_forces_t<LJM, COULM, false, true>(A); else launch_forces_t<LJM, COULM, false, false>(A); }
+    }
+    template <int LJM> void launch_forces_l(const ForceArgs<T>& A, bool energy) {
+        switch (coulm) {
+        case MHIP_COUL_NONE: launch_forces_c<LJM, MHIP_COUL_NONE>(A, energy); break;
+        case MHIP_COUL_PLAIN: launch_forces_c<LJM, MHIP_COUL_PLAIN>(A, energy); break;
+        case MHIP_COUL_REACTION_FIELD: launch_forces_c<LJM, MHIP_COUL_REACTION_FIELD>(A, energy); break;
+        default: launch_forces_c<LJM, MHIP_COUL_EWALD_DIRECT>(A, energy); break;
+        }
+    }
+    // pairwise forces of the current coordinates into frc[cur] (overwrites); energy → red_part[0..n_blocks)
+    void launch_pair_kernel(bool energy) {
+        ForceArgs<T> A;
+        A.G = G; A.I = I; A.n_owned = n_owned; A.BI = BI; A.BI_shift = ilog2(BI); A.JS = JS; A.T_cap = T_cap; A.T_lds = max_tile; A.R_cap = R_cap;
+        A.n_blocks = n_blocks; A.blocks_per_xcd = cdiv(n_blocks, 8);
+        A.pos = pos[cur].p; A.lj = lj[cur].p; A.tile_idx = tile_idx.p; A.tile_cnt = tile_cnt.p; A.nbr = nbr.p; A.wave_rows = wave_rows.p;
+        A.blk_center = blk_center.p; A.frc = frc[cur].p; A.pe_part = red_part.p;
+        switch (ljm) {
+        case LJ_OFF: launch_forces_l<LJ_OFF>(A, energy); break;
+        case LJ_DIST: launch_forces_l<LJ_DIST>(A, energy); break;
+        default: launch_forces_l<LJ_GENERIC>(A, energy); break;
+        }
+        MHIP_HIP(hipGetLastError());
+        ++n_force_calls;
+    }
+
+    double read_sum(int n_part) {
+        hipLaunchKernelGGL(k_sum_double, dim3(1), dim3(256), 0, stream, n_part, (const double*)red_part.p, red_out.p);
+        MHIP_HIP(hipMemcpyAsync(h_red, red_out.p, sizeof(double), hipMemcpyDeviceToHost, stream));
+        MHIP_HIP(hipStreamSynchronize(stream));
+        return h_red[0];
+    }
+
+    void export_frc(int accumulate, void* f_xyz, int mem_kind) {
+        const size_t cnt = 3 * (size_t)n_owned;
+        if (mem_kind == MHIP_MEM_DEVICE) {
+            hipLaunchKernelGGL(k_export_forces<T>, dim3(cdiv(n_owned, 256)), dim3(256), 0, stream, n_owned, (const int32_t*)orig[cur].p, (const T4*)frc[cur].p, (T*)f_xyz, accumulate);
+        } else {
+            stage_a.reserve(cnt);
+            if (accumulate) MHIP_HIP(hipMemcpyAsync(stage_a.p, f_xyz, cnt * sizeof(T), hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL(k_export_forces<T>, dim3(cdiv(n_owned, 256)), dim3(256), 0, stream, n_owned, (const int32_t*)orig[cur].p, (const T4*)frc[cur].p, stage_a.p, accumulate);
+            MHIP_HIP(hipMemcpyAsync(f_xyz, stage_a.p, cnt * sizeof(T), hipMemcpyDeviceToHost, stream));
+            MHIP_HIP(hipStreamSynchronize(stream));
+        }
+        MHIP_HIP(hipGetLastError());
+    }
+
+    // all forces of one MD step into frc[cur]: pairwise kernel overwrites, bonded kernels add
+    void step_forces() {
+        launch_pair_kernel(false);
+        bonded.launch_forces(stream, G, I, pos[cur].p, inv.p, frc[cur].p);
+        frc_valid = true;
+    }
+
+  public:
+    // ---------------------------------------------------------------------------------------------
+    void set_stream(void* s) override {
+        MHIP_HIP(hipStreamSynchronize(stream));
+        if (own_stream) { (void)hipStreamDestroy(stream); own_stream = false; }
+        stream = (hipStream_t)s;
+    }
+    void synchronize() override { MHIP_HIP(hipStreamSynchronize(stream)); }
+
+    void set_atom_counts(int64_t no, int64_t ng) override {
+        if (no <= 0 || ng < 0 || no + ng > cap) throw ApiError{MHIP_ERR_INVALID, "atom counts exceed the context capacity"};
+        n_owned = no; n_ghost = ng; n_tot = no + ng;
+        // new local atom set: restart from the identity order
+        std::vector<int32_t> iota(n_tot); for (int64_t i = 0; i < n_tot; ++i) iota[i] = (int32_t)i;
+        MHIP_HIP(hipMemcpyAsync(orig[cur].p, iota.data(), n_tot * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        MHIP_HIP(hipMemcpyAsync(inv.p, iota.data(), n_tot * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        MHIP_HIP(hipMemsetAsync(frc[cur].p, 0, n_tot * sizeof(T4), stream));
+        MHIP_HIP(hipStreamSynchronize(stream));
+        stale = true; cm_pending = false; frc_valid = false;
+        choose_blocking();
+    }
+
+    void set_atoms(const void* q, const void* sg, const void* ep, const void* ms, const void* lam, int mem_kind) override {
+        flush_cm();
+        DBuf<T> s3, s4, s5;
+        const T* dq = to_device(q, n_tot, mem_kind, stage_a);
+        const T* ds = to_device(sg, n_tot, mem_kind, stage_b);
+        const T* de = to_device(ep, n_tot, mem_kind, s3);
+        const T* dm = to_device(ms, n_tot, mem_kind, s4);
+        const T* dl = to_device(lam, n_tot, mem_kind, s5);
+        hipLaunchKernelGGL(k_scatter_params<T>, dim3(cdiv(n_tot, 256)), dim3(256), 0, stream, n_tot, (const int32_t*)inv.p, dq, ds, de, dm, dl, pos[cur].p, vel[cur].p, lj[cur].p);
+        MHIP_HIP(hipGetLastError());
+        MHIP_HIP(hipStreamSynchronize(stream));
+        s3.release(); s4.release(); s5.release();
+        params_set = true; frc_valid = false;
+    }
+
+    void set_exceptions(const int32_t* ei, const int32_t* ej, int64_t ne, const int32_t* si, const int32_t* sj, int64_t ns) override {
+        auto csr = [&](const int32_t* a, const int32_t* b, int64_t m, DBuf<int32_t>& start, DBuf<int32_t>& list) {
+            std::vector<int32_t> st(cap + 1, 0), ls(2 * (size_t)m);
+            for (int64_t k = 0; k < m; ++k) {
+                if (a[k] < 0 || b[k] < 0 || a[k] >= cap || b[k] >= cap || a[k] == b[k]) throw ApiError{MHIP_ERR_INVALID, "exception pair index out of range"};
+                st[a[k] + 1]++; st[b[k] + 1]++;
+            }
+            for (int64_t i = 0; i < cap; ++i) st[i + 1] += st[i];
+            std::vector<int32_t> fill(st.begin(), st.end() - 1);
+            for (int64_t k = 0; k < m; ++k) { ls[fill[a[k]]++] = b[k]; ls[fill[b[k]]++] = a[k]; }
+            start.reserve(cap + 1); list.reserve(std::max<size_t>(ls.size(), 1));
+            MHIP_HIP(hipMemcpy(start.p, st.data(), (cap + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+            if (!ls.empty()) MHIP_HIP(hipMemcpy(list.p, ls.data(), ls.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        };
+        MHIP_HIP(hipStreamSynchronize(stream));
+        has_exc = (ne + ns) > 0;
+        csr(ei, ej, ne, ex_start, ex_list);
+        csr(si, sj, ns, sp_start, sp_list);
+        stale = true;   // ≙ cache invalidation after append_excluded_pairs! (test/gpu_consistency.jl:494-527)
+    }
+
+    void set_bonds(int64_t n, const int32_t* i, const int32_t* j, const void* k, const void* r0) override { bonded.set_bonds(cap, n, i, j, (const T*)k, (const T*)r0); }
+    void set_angles(int64_t n, const int32_t* i, const int32_t* j, const int32_t* k, const void* kth, const void* th0) override { bonded.set_angles(cap, n, i, j, k, (const T*)kth, (const T*)th0); }
+    void set_torsions(int64_t n, const int32_t* i, const int32_t* j, const int32_t* k, const int32_t* l, const int32_t* per, const void* ph, const void* kt) override {
+        bonded.set_torsions(cap, n, i, j, k, l, per, (const T*)ph, (const T*)kt);
+    }
+    void set_ewald_exclusions(int64_t n, const int32_t* i, const int32_t* j) override { bonded.set_ewx(cap, n, i, j); }
+
+    void set_state(const void* xyz, const void* v, int mem_kind) override {
+        flush_cm();
+        const T* dx = to_device(xyz, 3 * (size_t)n_tot, mem_kind, stage_a);
+        const T* dv = to_device(v, 3 * (size_t)n_owned, mem_kind, stage_b);
+        hipLaunchKernelGGL(k_scatter_state<T>, dim3(cdiv(n_tot, 256)), dim3(256), 0, stream, n_tot, n_owned, (const int32_t*)inv.p, dx, dv, pos[cur].p, vel[cur].p, G);
+        MHIP_HIP(hipGetLastError());
+        if (mem_kind == MHIP_MEM_HOST) MHIP_HIP(hipStreamSynchronize(stream));
+        if (xyz) { stale = true; frc_valid = false; state_set = true; }
+    }
+
+    void get_state(void* xyz, void* v, int mem_kind) override {
+        flush_cm();
+        auto one = [&](void* out, int64_t n, const T4* src) {
+            if (!out) return;
+            T* d = (T*)out;
+            if (mem_kind == MHIP_MEM_HOST) { stage_a.reserve(3 * (size_t)n); d = stage_a.p; }
+            hipLaunchKernelGGL(k_gather_state<T>, dim3(cdiv(n, 256)), dim3(256), 0, stream, n, (const int32_t*)inv.p, src, d);
+            if (mem_kind == MHIP_MEM_HOST) { MHIP_HIP(hipMemcpyAsync(out, d, 3 * (size_t)n * sizeof(T), hipMemcpyDeviceToHost, stream)); MHIP_HIP(hipStreamSynchronize(stream)); }
+        };
+        one(xyz, n_tot, pos[cur].p);
+        one(v, n_owned, vel[cur].p);
+        MHIP_HIP(hipGetLastError());
+    }
+
+    void forces(int64_t step_n, int accumulate, void* f_xyz, int mem_kind) override {
+        ensure_built(step_n);
+        launch_pair_kernel(false);
+        frc_valid = false;   // frc holds the pairwise part only
+        export_frc(accumulate, f_xyz, mem_kind);
+    }
+
+    void specific_forces(int accumulate, void* f_xyz, int mem_kind) override {
+        if (!state_set) throw ApiError{MHIP_ERR_STATE, "set_state must be called before specific_forces"};
+        MHIP_HIP(hipMemsetAsync(frc[cur].p, 0, (size_t)n_tot * sizeof(T4), stream));
+        bonded.launch_forces(stream, G, I, pos[cur].p, inv.p, frc[cur].p);
+        frc_valid = false;
+        export_frc(accumulate, f_xyz, mem_kind);
+    }
+
+    double potential_energy(int64_t step_n) override {
+        ensure_built(step_n);
+        DBuf<T4> keep;   // the energy pass must not clobber the forces the integrator carries
+        keep.reserve(n_tot);
+        MHIP_HIP(hipMemcpyAsync(keep.p, frc[cur].p, (size_t)n_tot * sizeof(T4), hipMemcpyDeviceToDevice, stream));
+        launch_pair_kernel(true);
+        MHIP_HIP(hipMemcpyAsync(frc[cur].p, keep.p, (size_t)n_tot * sizeof(T4), hipMemcpyDeviceToDevice, stream));
+        double pe = read_sum(n_blocks);
+        keep.release();
+        return pe;
+    }
+
+    double specific_potential_energy() override {
+        if (!state_set) throw ApiError{MHIP_ERR_STATE, "set_state must be called before specific_potential_energy"};
+        int n_part = bonded.launch_energy(stream, G, I, pos[cur].p, inv.p, red_part);
+        if (n_part == 0) return 0.0;
+        return read_sum(n_part);
+    }
+
+    double kinetic_energy() override {
+        flush_cm();
+        int nb = cdiv(n_owned, 256);
+        red_part.reserve(nb);
+        hipLaunchKernelGGL(k_ke_partials<T>, dim3(nb), dim3(256), 0, stream, n_owned, (const T4*)vel[cur].p, red_part.p);
+        return read_sum(nb);
+    }
+
+    void cm_partials_now() {
+        int nb = cdiv(n_owned, 256);
+        red_part.reserve(4 * (size_t)nb);
+        hipLaunchKernelGGL(k_cm_partials<T>, dim3(nb), dim3(256), 0, stream, n_owned, (const T4*)vel[cur].p, cm_pending ? (const T*)vcm.p : (const T*)nullptr, red_part.p);
+    }
+
+    void remove_cm() override {
+        flush_cm();
+        cm_partials_now();
+        hipLaunchKernelGGL(k_cm_finalize<T>, dim3(1), dim3(256), 0, stream, cdiv(n_owned, 256), (const double*)red_part.p, red_out.p, vcm.p);
+        cm_pending = true; flush_cm();
+        MHIP_HIP(hipGetLastError());
+    }
+
+    void cm_momentum(double* out4) override {
+        flush_cm();
+        cm_partials_now();
+        hipLaunchKernelGGL(k_cm_finalize<T>, dim3(1), dim3(256), 0, stream, cdiv(n_owned, 256), (const double*)red_part.p, red_out.p, (T*)nullptr);
+        MHIP_HIP(hipMemcpyAsync(h_red, red_out.p, 4 * sizeof(double), hipMemcpyDeviceToHost, stream));
+        MHIP_HIP(hipStreamSynchronize(stream));
+        for (int c = 0; c < 4; ++c) out4[c] = h_red[c];
+    }
+
+    void shift_velocities(const double* dv3) override {
+        flush_cm();
+        T h[3] = {T(dv3[0]), T(dv3[1]), T(dv3[2])};
+        MHIP_HIP(hipMemcpyAsync(vcm.p, h, 3 * sizeof(T), hipMemcpyHostToDevice, stream));
+        MHIP_HIP(hipStreamSynchronize(stream));
+        cm_pending = true; flush_cm();
+    }
+
+    void check_finite() override {
+        MHIP_HIP(hipMemsetAsync(flags.p + FLAG_NAN, 0, sizeof(int32_t), stream));
+        hipLaunchKernelGGL(k_check_finite<T>, dim3(cdiv(n_owned, 256)), dim3(256), 0, stream, n_owned, (const T4*)pos[cur].p, (const T4*)vel[cur].p, (const T4*)frc[cur].p, flags.p);
+        MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        MHIP_HIP(hipStreamSynchronize(stream));
+        if (h_flags[FLAG_NAN]) throw ApiError{MHIP_ERR_NAN, "NaN or overflow found in coordinates, velocities or forces"};
+    }
+
+    // simulators.jl:561-571: wrap (done by set_state / the integrator), neighbours, forces at first_step
+    void vv_init(int64_t first_step) override {
+        if (!state_set) throw ApiError{MHIP_ERR_STATE, "set_state must be called before vv_run"};
+        rebuild(first_step);
+        step_forces();
+    }
+    void vv_stage1(double dt) override {
+        if (!frc_valid) throw ApiError{MHIP_ERR_STATE, "vv_stage1 needs forces from vv_init / vv_stage2"};
+        hipLaunchKernelGGL(k_vv1<T>, dim3(cdiv(n_owned, 256)), dim3(256), 0, stream, n_owned, pos[cur].p, vel[cur].p, (const T4*)frc[cur].p, T(dt), T(dt) / T(2),
+                           cm_pending ? (const T*)vcm.p : (const T*)nullptr, G);
+        cm_pending = false;
+    }
+    void stage2_impl(double dt, bool cm) {
+        step_forces();
+        const int nb = cdiv(n_owned, 256);
+        if (cm) {
+            red_part.reserve(4 * (size_t)nb + 8);
+            hipLaunchKernelGGL((k_vv2<T, true>), dim3(nb), dim3(256), 0, stream, n_owned, vel[cur].p, (const T4*)frc[cur].p, T(dt) / T(2), red_part.p);
+            hipLaunchKernelGGL(k_cm_finalize<T>, dim3(1), dim3(256), 0, stream, nb, (const double*)red_part.p, red_out.p, vcm.p);
+            cm_pending = true;
+        } else {
+            hipLaunchKernelGGL((k_vv2<T, false>), dim3(nb), dim3(256), 0, stream, n_owned, vel[cur].p, (const T4*)frc[cur].p, T(dt) / T(2), (double*)nullptr);
+        }
+    }
+    void vv_stage2(int64_t step_n, double dt) override {
+        (void)step_n;
+        stage2_impl(dt, false);
+        MHIP_HIP(hipGetLastError());
+    }
+    void rebuild_now(int64_t step_n) override { flush_cm(); rebuild(step_n); }
+
+    void vv_run(int64_t first_step, int64_t n_steps, double dt, int remove_cm_every) override {
+        if (!state_set || !params_set) throw ApiError{MHIP_ERR_STATE, "set_atoms and set_state must be called before vv_run"};
+        if (n_ghost > 0) throw ApiError{MHIP_ERR_STATE, "vv_run is single-domain; drive ghosted domains with vv_stage1/vv_stage2"};
+        const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
+        if (first_step == 0 && remove_cm_every != 0) remove_cm();                 // simulators.jl:563
+        vv_init(first_step);                                                      // :564-571
+        for (int64_t step = first_step + 1; step <= first_step + n_steps; ++step) {
+            vv_stage1(dt);                                                        // :594-609
+            stage2_impl(dt, remove_cm_every != 0 && step % remove_cm_every == 0); // :612-628
+            if (step % every == 0) rebuild(step);                                 // :645, neighbors.jl:396
+        }
+        flush_cm();
+        MHIP_HIP(hipGetLastError());
+        MHIP_HIP(hipStreamSynchronize(stream));
+    }
+
+    int64_t export_neighbors(int32_t* oi, int32_t* oj, uint8_t* osp, int64_t capacity) override {
+        if (stale) throw ApiError{MHIP_ERR_STATE, "no neighbour list: call forces / rebuild first"};
+        DBuf<unsigned long long> counter; counter.reserve(1);
+        MHIP_HIP(hipMemsetAsync(counter.p, 0, sizeof(unsigned long long), stream));
+        hipLaunchKernelGGL(k_export_nl<T>, dim3(n_blocks), dim3(BI), 0, stream, n_blocks, BI, T_cap, R_cap, n_owned, (const int32_t*)orig[cur].p, (const int32_t*)tile_idx.p,
+                           (const int32_t*)tile_cnt.p, (const uint2*)nbr.p, (const int32_t*)wave_rows.p, (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr, counter.p, 0ull);
+        unsigned long long n = 0;
+        MHIP_HIP(hipMemcpyAsync(&n, counter.p, sizeof(n), hipMemcpyDeviceToHost, stream));
+        MHIP_HIP(hipStreamSynchronize(stream));
+        if (oi && (int64_t)n <= capacity && n > 0) {
+            DBuf<int32_t> di, dj; DBuf<uint8_t> ds; di.reserve(n); dj.reserve(n); ds.reserve(n);
+            MHIP_HIP(hipMemsetAsync(counter.p, 0, sizeof(unsigned long long), stream));
+            hipLaunchKernelGGL(k_export_nl<T>, dim3(n_blocks), dim3(BI), 0, stream, n_blocks, BI, T_cap, R_cap, n_owned, (const int32_t*)orig[cur].p, (const int32_t*)tile_idx.p,
+                               (const int32_t*)tile_cnt.p, (const uint2*)nbr.p, (const int32_t*)wave_rows.p, di.p, dj.p, ds.p, counter.p, n);
+            MHIP_HIP(hipMemcpyAsync(oi, di.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            MHIP_HIP(hipMemcpyAsync(oj, dj.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            MHIP_HIP(hipMemcpyAsync(osp, ds.p, n * sizeof(uint8_t), hipMemcpyDeviceToHost, stream));
+            MHIP_HIP(hipStreamSynchronize(stream));
+            di.release(); dj.release(); ds.release();
+        }
+        counter.release();
+        return (int64_t)n;
+    }
+
+    void export_order(int32_t* out, int64_t capacity) override {
+        if (capacity < n_tot) throw ApiError{MHIP_ERR_CAPACITY, "export_order: buffer too small"};
+        MHIP_HIP(hipMemcpyAsync(out, orig[cur].p, n_tot * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        MHIP_HIP(hipStreamSynchronize(stream));
+    }
+
+    void get_stats(mhip_stats* s) override {
+        std::memset(s, 0, sizeof(*s));
+        s->n_atoms = n_tot; s->n_owned = n_owned; s->n_ghost = n_ghost; s->n_rebuilds = n_rebuilds; s->n_force_calls = n_force_calls;
+        s->n_blocks = n_blocks; s->block_atoms = BI; s->j_split = JS; s->minimg_mode = minimg ? 1 : 0; s->max_tile_atoms = max_tile;
+        s->last_rebuild_ms = last_rebuild_ms; s->lds_bytes = (int64_t)lds_force;
+        s->n_list_slots = total_rows * 4 * WAVE;
+        if (!stale) {
+            std::vector<int32_t> tc(n_blocks);
+            MHIP_HIP(hipMemcpy(tc.data(), tile_cnt.p, n_blocks * sizeof(int32_t), hipMemcpyDeviceToHost));
+            int64_t t = 0; for (int v : tc) t += v; s->tile_atoms_total = t;
+            s->n_pairs_full = 2 * export_neighbors(nullptr, nullptr, nullptr, 0);
+        }
+        const int64_t w = sizeof(T), Rp = (coulm != MHIP_COUL_NONE ? 6 : 4) * w;
+        s->algorithmic_bytes_step = n_owned * (Rp + 22 * w) + 4 * (s->n_pairs_full / 2);   // N(R_p + 22w) + 4L
+    }
+
+    void gather_coords(const int32_t* idx_dev, const void* shift_dev, int64_t n, void* out_dev) override {
+        if (n <= 0) return;
+        hipLaunchKernelGGL(k_gather_coords<T>, dim3(cdiv(n, 256)), dim3(256), 0, stream, n, idx_dev, (const T*)shift_dev, (const int32_t*)inv.p, (const T4*)pos[cur].p, (T*)out_dev);
+        MHIP_HIP(hipGetLastError());
+    }
+    void scatter_coords(int64_t first, int64_t n, const void* in_dev) override {
+        if (n <= 0) return;
+        if (first < 0 || first + n > n_tot) throw ApiError{MHIP_ERR_INVALID, "scatter_coords range out of bounds"};
+        hipLaunchKernelGGL(k_scatter_coords<T>, dim3(cdiv(n, 256)), dim3(256), 0, stream, first, n, (const T*)in_dev, (const int32_t*)inv.p, pos[cur].p);
+        MHIP_HIP(hipGetLastError());
+    }
+};
+
+}  // namespace mhip
+
+// ====================================================================================================
+// C ABI
+// ====================================================================================================
+struct mhip_ctx { std::unique_ptr<mhip::EngineBase> e; };
+
+namespace {
+template <class F> int32_t guard(mhip_ctx* ctx, F&& f) {
+    std::string* err = ctx && ctx->e ? &ctx->e->err : &mhip::g_create_error;
+    try { f(); err->clear(); return MHIP_OK; }
+    catch (const mhip::ApiError& a) { *err = a.msg; return a.code; }
+    catch (const mhip::HipErr& h) { *err = std::string(h.what) + ": " + hipGetErrorString(h.e); return MHIP_ERR_HIP; }
+    catch (const std::bad_alloc&) { *err = "out of host memory"; return MHIP_ERR_HIP; }
+    catch (const std::exception& x) { *err = x.what(); return MHIP_ERR_INVALID; }
+}
+#define NEED_CTX() if (!ctx || !ctx->e) { mhip::g_create_error = "null context"; return MHIP_ERR_INVALID; }
+}  // namespace
+
+extern "C" {
+
+int32_t mhip_device_count(int32_t* n_out) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    if (n_out) *n_out = n;
+    return MHIP_OK;
+}
+
+int32_t mhip_create(mhip_ctx** out, const mhip_config* cfg) {
+    if (!out || !cfg) { mhip::g_create_error = "null argument"; return MHIP_ERR_INVALID; }
+    *out = nullptr;
+    mhip_ctx* c = new (std::nothrow) mhip_ctx;
+    if (!c) { mhip::g_create_error = "out of host memory"; return MHIP_ERR_HIP; }
+    int32_t rc = guard(nullptr, [&] {
+        if (cfg->precision == 32) c->e.reset(new mhip::Engine<float>(*cfg));
+        else if (cfg->precision == 64) c->e.reset(new mhip::Engine<double>(*cfg));
+        else throw mhip::ApiError{MHIP_ERR_INVALID, "precision must be 32 or 64"};
+    });
+    if (rc != MHIP_OK) { delete c; return rc; }
+    *out = c;
+    return MHIP_OK;
+}
+
+int32_t mhip_destroy(mhip_ctx* ctx) { delete ctx; return MHIP_OK; }
+
+const char* mhip_last_error(const mhip_ctx* ctx) { return (ctx && ctx->e) ? ctx->e->err.c_str() : mhip::g_create_error.c_str(); }
+
+int32_t mhip_set_stream(mhip_ctx* ctx, void* s) { NEED_CTX(); return guard(ctx, [&] { ctx->e->set_stream(s); }); }
+int32_t mhip_synchronize(mhip_ctx* ctx) { NEED_CTX(); return guard(ctx, [&] { ctx->e->synchronize(); }); }
+int32_t mhip_set_atom_counts(mhip_ctx* ctx, int64_t no, int64_t ng) { NEED_CTX(); return guard(ctx, [&] { ctx->e->set_atom_counts(no, ng); }); }
+int32_t mhip_set_atoms(mhip_ctx* ctx, const void* q, const void* s, const void* e, const void* m, const void* l, int32_t mk) {
+    NEED_CTX(); return guard(ctx, [&] { ctx->e->set_atoms(q, s, e, m, l, mk); });
+}
+int32_t mhip_set_exceptions(mhip_ctx* ctx, const int32_t* ei, const int32_t* ej, int64_t ne, const int32_t* si, const int32_t* sj, int64_t ns) {
+    NEED_CTX(); return guard(ctx, [&] { if (ne < 0 || ns < 0) throw mhip::ApiError{MHIP_ERR_INVALID, "negative count"}; ctx->e->set_exceptions(ei, ej, ne, si, sj, ns); });
+}
+int32_t mhip_set_bonds(mhip_ctx* ctx, int64_t n, const int32_t* i, const int32_t* j, const void* k, const void* r0) { NEED_CTX(); return guard(ctx, [&] { ctx->e->set_bonds(n, i, j, k, r0); }); }
+int32_t mhip_set_angles(mhip_ctx* ctx, int64_t n, const int32_t* i, const int32_t* j, const int32_t* k, const void* kth, const void* th0) {
+    NEED_CTX(); return guard(ctx, [&] { ctx->e->set_angles(n, i, j, k, kth, th0); });
+}
+int32_t mhip_set_torsions(mhip_ctx* ctx, int64_t n, const int32_t* i, const int32_t* j, const int32_t* k, const int32_t* l, const int32_t* per, const void* ph, const void* kt) {
+    NEED_CTX(); return guard(ctx, [&] { ctx->e->set_torsions(n, i, j, k, l, per, ph, kt); });
+}
+int32_t mhip_set_ewald_exclusions(mhip_ctx* ctx, int64_t n, const int32_t* i, const int32_t* j) { NEED_CTX(); return guard(ctx, [&] { ctx->e->set_ewald_exclusions(n, i, j); }); }
+int32_t mhip_set_state(mhip_ctx* ctx, const void* x, const void* v, int32_t mk) { NEED_CTX(); return guard(ctx, [&] { ctx->e->set_state(x, v, mk); }); }
+int32_t mhip_get_state(mhip_ctx* ctx, void* x, void* v, int32_t mk) { NEED_CTX(); return guard(ctx, [&] { ctx->e->get_state(x, v, mk); }); }
+int32_t mhip_forces(mhip_ctx* ctx, int64_t step_n, int32_t acc, void* f, void* virial9, int32_t mk) {
+    NEED_CTX();
+    return guard(ctx, [&] {
+        if (virial9) throw mhip::ApiError{MHIP_ERR_UNSUPPORTED, "virial accumulation is outside the hot-path scope (SURVEY §8(f) rank 3)"};
+        if (!f) throw mhip::ApiError{MHIP_ERR_INVALID, "null force buffer"};
+        ctx->e->forces(step_n, acc, f, mk);
+    });
+}
+int32_t mhip_specific_forces(mhip_ctx* ctx, int32_t acc, void* f, int32_t mk) { NEED_CTX(); return guard(ctx, [&] { if (!f) throw mhip::ApiError{MHIP_ERR_INVALID, "null force buffer"}; ctx->e->specific_forces(acc, f, mk); }); }
+int32_t mhip_potential_energy(mhip_ctx* ctx, int64_t step_n, double* pe) { NEED_CTX(); return guard(ctx, [&] { *pe = ctx->e->potential_energy(step_n); }); }
+int32_t mhip_specific_potential_energy(mhip_ctx* ctx, double* pe) { NEED_CTX(); return guard(ctx, [&] { *pe = ctx->e->specific_potential_energy(); }); }
+int32_t mhip_kinetic_energy(mhip_ctx* ctx, double* ke) { NEED_CTX(); return guard(ctx, [&] { *ke = ctx->e->kinetic_energy(); }); }
+int32_t mhip_remove_cm(mhip_ctx* ctx) { NEED_CTX(); return guard(ctx, [&] { ctx->e->remove_cm(); }); }
+int32_t mhip_check_finite(mhip_ctx* ctx) { NEED_CTX(); return guard(ctx, [&] { ctx->e->check_finite(); }); }
+int32_t mhip_vv_run(mhip_ctx* ctx, int64_t first, int64_t n, double dt, int32_t cm) {
+    NEED_CTX(); return guard(ctx, [&] { if (n < 0 || !(dt > 0)) throw mhip::ApiError{MHIP_ERR_INVALID, "n_steps must be >= 0 and dt > 0"}; ctx->e->vv_run(first, n, dt, cm); });
+}
+int32_t mhip_vv_init(mhip_ctx* ctx, int64_t first) { NEED_CTX(); return guard(ctx, [&] { ctx->e->vv_init(first); }); }
+int32_t mhip_vv_stage1(mhip_ctx* ctx, double dt) { NEED_CTX(); return guard(ctx, [&] { ctx->e->vv_stage1(dt); }); }
+int32_t mhip_vv_stage2(mhip_ctx* ctx, int64_t step_n, double dt) { NEED_CTX(); return guard(ctx, [&] { ctx->e->vv_stage2(step_n, dt); }); }
+int32_t mhip_rebuild(mhip_ctx* ctx, int64_t step_n) { NEED_CTX(); return guard(ctx, [&] { ctx->e->rebuild_now(step_n); }); }
+int32_t mhip_export_neighbors(mhip_ctx* ctx, int32_t* i, int32_t* j, uint8_t* sp, int64_t capacity, int64_t* n_out) {
+    NEED_CTX();
+    return guard(ctx, [&] {
+        int64_t n = ctx->e->export_neighbors(i, j, sp, capacity);
+        if (n_out) *n_out = n;
+        if (i && n > capacity) throw mhip::ApiError{MHIP_ERR_CAPACITY, "export_neighbors: buffer too small"};
+    });
+}
+int32_t mhip_export_order(mhip_ctx* ctx, int32_t* perm, int64_t capacity) { NEED_CTX(); return guard(ctx, [&] { ctx->e->export_order(perm, capacity); }); }
+int32_t mhip_get_stats(mhip_ctx* ctx, mhip_stats* out) { NEED_CTX(); return guard(ctx, [&] { ctx->e->get_stats(out); }); }
+int32_t mhip_gather_coords(mhip_ctx* ctx, const int32_t* idx, const void* shift, int64_t n, void* out) { NEED_CTX(); return guard(ctx, [&] { ctx->e->gather_coords(idx, shift, n, out); }); }
+int32_t mhip_scatter_coords(mhip_ctx* ctx, int64_t first, int64_t n, const void* in) { NEED_CTX(); return guard(ctx, [&] { ctx->e->scatter_coords(first, n, in); }); }
+int32_t mhip_cm_momentum(mhip_ctx* ctx, double* out4) { NEED_CTX(); return guard(ctx, [&] { ctx->e->cm_momentum(out4); }); }
+int32_t mhip_shift_velocities(mhip_ctx* ctx, const double* dv3) { NEED_CTX(); return guard(ctx, [&] { ctx->e->shift_velocities(dv3); }); }
+
+}  // extern "C"

@@ -1,0 +1,611 @@
+// kernels.h — the gfx950 device kernels of the engine (wave64, LDS-staged atom tiles).
+//
+// Design: atoms live in HBM sorted along a generalised Hilbert curve over a fine cell
+// grid (cell ≈ r_list/2), as float4{x,y,z,q} + float2{σ,ϵ}.  A workgroup owns BI consecutive sorted atoms
+// ("i-block").  At every neighbour rebuild k_build stages the block's spatial neighbourhood ("tile": every
+// atom within r_list of the block's bounding box) in LDS, walks each i-atom's 5×5×5 cell stencil over the
+// LDS tile with the reference's exact minimum-image arithmetic, and emits a per-atom FULL neighbour list of
+// 16-bit tile slots (bit 15 = the reference's `special` flag), 4 entries per 8-byte row, interleaved so a
+// wave reads 512 contiguous bytes per row.  Every force evaluation (k_forces) re-stages the tile from the
+// current coordinates in block-local coordinates (periodic image resolved once per staged atom, not per
+// pair), then each lane streams its rows and gathers partner atoms from LDS (ds_read_b128), accumulating its
+// own force in registers: no atomics, no cross-lane reduction on the hot path, bit-reproducible forces.
+#pragma once
+#include "physics.h"
+
+namespace mhip {
+
+enum { FLAG_MINIMG = 0, FLAG_OVERFLOW = 1, FLAG_MAX_TILE = 2, FLAG_MAX_ROWS = 3, FLAG_NAN = 4, FLAG_TOTAL_ROWS = 5, N_FLAGS = 8 };
+enum { OVF_TILE = 1, OVF_ROWS = 2, OVF_BOXCELLS = 4, OVF_SLOT = 8 };
+
+constexpr int MAX_BOX_CELLS = 4096;
+
+// ---------------------------------------------------------------------------------------------------
+// small helpers
+template <class T> __device__ inline int cell_coord(T x, int d, const GridP<T>& G) {
+    // coordinates are stored wrapped into [0, L] on periodic axes (set_state / integrator wrap)
+    T rel = G.periodic[d] ? x : x - G.origin[d];
+    int c = (int)M<T>::floor(rel * G.inv_cs[d]);
+    return min(max(c, 0), G.nc[d] - 1);
+}
+
+template <class T> __device__ inline T wave_max(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { T u = __shfl_xor(v, o, 64); v = u > v ? u : v; }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// set_state / set_atoms: caller order → current sorted slots
+template <class T>
+__global__ void k_scatter_state(int64_t n_tot, int64_t n_owned, const int32_t* __restrict__ inv, const T* __restrict__ xyz,
+                                const T* __restrict__ vxyz, typename Vec<T>::T4* pos, typename Vec<T>::T4* vel, GridP<T> G) {
+    int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (o >= n_tot) return;
+    int s = inv[o];
+    if (xyz) {
+        T c[3] = {xyz[3 * o], xyz[3 * o + 1], xyz[3 * o + 2]};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) if (G.periodic[d]) c[d] = wrap_1d(c[d], G.L[d]);   // wrap_coords, simulators.jl:561
+        pos[s].x = c[0]; pos[s].y = c[1]; pos[s].z = c[2];
+    }
+    if (vxyz && o < n_owned) { vel[s].x = vxyz[3 * o]; vel[s].y = vxyz[3 * o + 1]; vel[s].z = vxyz[3 * o + 2]; }
+}
+
+template <class T>
+__global__ void k_scatter_params(int64_t n_tot, const int32_t* __restrict__ inv, const T* q, const T* sig, const T* eps,
+                                 const T* mass, const T* lam, typename Vec<T>::T4* pos, typename Vec<T>::T4* vel,
+                                 typename Vec<T>::T2* lj) {
+    int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (o >= n_tot) return;
+    int s = inv[o];
+    pos[s].w = q ? q[o] : T(0);
+    T sg = sig ? sig[o] : T(0), ep = eps ? eps[o] : T(0);
+    if (lam && lam[o] == T(0)) { sg = T(0); ep = T(0); }   // LJZeroShortcut on λ == 0 (mixing.jl:10)
+    lj[s] = make2<T>(sg, ep);
+    vel[s].w = mass ? mass[o] : T(1);
+}
+
+template <class T>
+__global__ void k_gather_state(int64_t n, const int32_t* __restrict__ inv, const typename Vec<T>::T4* __restrict__ src, T* out) {
+    int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (o >= n) return;
+    auto p = src[inv[o]];
+    out[3 * o] = p.x; out[3 * o + 1] = p.y; out[3 * o + 2] = p.z;
+}
+
+// forces: sorted → caller order (≙ reverse_reorder_forces_kernel!, kernels.jl:654-663)
+template <class T>
+__global__ void k_export_forces(int64_t n_owned, const int32_t* __restrict__ orig, const typename Vec<T>::T4* __restrict__ frc, T* out, int accumulate) {
+    int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (s >= n_owned) return;
+    int o = orig[s];
+    auto f = frc[s];
+    if (accumulate) { out[3 * o] += f.x; out[3 * o + 1] += f.y; out[3 * o + 2] += f.z; }
+    else { out[3 * o] = f.x; out[3 * o + 1] = f.y; out[3 * o + 2] = f.z; }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// rebuild step 1: sort key = Hilbert rank of the atom's cell (ghosts after all owned atoms) + histogram
+template <class T>
+__global__ void k_cell_keys(int64_t n_tot, int64_t n_owned, const typename Vec<T>::T4* __restrict__ pos, const int32_t* __restrict__ orig,
+                            const uint32_t* __restrict__ cell_rank, uint32_t* key, int32_t* idx, int32_t* cell_cnt, GridP<T> G) {
+    int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (s >= n_tot) return;
+    auto p = pos[s];
+    int cx = cell_coord(p.x, 0, G), cy = cell_coord(p.y, 1, G), cz = cell_coord(p.z, 2, G);
+    uint32_t k = cell_rank[(cz * G.nc[1] + cy) * G.nc[0] + cx];
+    if (orig[s] >= n_owned) k += (uint32_t)G.ncell;
+    key[s] = k; idx[s] = (int32_t)s;
+    atomicAdd(&cell_cnt[k], 1);
+}
+
+// rebuild step 3: apply the sort permutation to every per-atom array (≙ reorder_system_kernel!, ext:1049-1067)
+template <class T>
+__global__ void k_permute(int64_t n_tot, const int32_t* __restrict__ perm, const typename Vec<T>::T4* __restrict__ pos_o,
+                          const typename Vec<T>::T4* __restrict__ vel_o, const typename Vec<T>::T4* __restrict__ frc_o,
+                          const typename Vec<T>::T2* __restrict__ lj_o, const int32_t* __restrict__ orig_o,
+                          typename Vec<T>::T4* pos_n, typename Vec<T>::T4* vel_n, typename Vec<T>::T4* frc_n,
+                          typename Vec<T>::T2* lj_n, int32_t* orig_n, int32_t* inv) {
+    int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (s >= n_tot) return;
+    int so = perm[s];
+    pos_n[s] = pos_o[so]; vel_n[s] = vel_o[so]; frc_n[s] = frc_o[so]; lj_n[s] = lj_o[so];
+    int o = orig_o[so];
+    orig_n[s] = o; inv[o] = (int32_t)s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// rebuild step 4: tiles + neighbour lists, one workgroup (BI threads) per i-block
+template <class T> struct BuildArgs {
+    GridP<T> G;
+    int64_t n_owned, n_tot;
+    int BI, T_cap, R_cap;            // i-atoms per block, tile capacity (atoms), row capacity per block
+    const typename Vec<T>::T4* pos;
+    const int32_t* orig;
+    const int32_t* cell_start;       // 2*ncell+1: owned cells then ghost cells, in Hilbert-rank order
+    const uint32_t* cell_rank;
+    const int32_t *ex_start, *ex_list, *sp_start, *sp_list;   // CSR over caller indices (may be null)
+    int32_t* tile_idx;               // [n_blocks][T_cap] sorted slot of each tile atom
+    int32_t* tile_cnt;               // [n_blocks]
+    uint2* nbr;                      // [n_blocks][R_cap][BI] 4×uint16 entries
+    int32_t* wave_rows;              // [n_blocks][BI/64]
+    typename Vec<T>::T4* blk_center; // [n_blocks] centre (xyz) of the block's bounding box at build time
+    int32_t* flags;
+    T margin;
+};
+
+template <class T>
+__global__ void k_build(BuildArgs<T> A) {
+    using T4 = typename Vec<T>::T4;
+    extern __shared__ __align__(32) unsigned char smem[];
+    const GridP<T>& G = A.G;
+    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    // LDS carve-up
+    T4* t_pos = reinterpret_cast<T4*>(smem);
+    int32_t* t_slot = reinterpret_cast<int32_t*>(t_pos + A.T_cap);
+    int32_t* c_off = t_slot + A.T_cap;              // MAX_BOX_CELLS + 1
+    int32_t* c_cnt = c_off + (MAX_BOX_CELLS + 1);   // MAX_BOX_CELLS
+    T* red = reinterpret_cast<T*>(c_cnt + MAX_BOX_CELLS);   // 6 * nthr (bbox) / nthr ints (scan)
+    __shared__ T s_lo[3], s_hi[3];
+    __shared__ int s_boxlo[3], s_boxlen[3], s_total;
+
+    // 1. bounding box of the block's atoms
+    const int64_t si = (int64_t)b * A.BI + tid;
+    const bool valid = si < A.n_owned;
+    T4 pi = valid ? A.pos[si] : A.pos[(int64_t)b * A.BI];   // block is never empty
+    T my[3] = {pi.x, pi.y, pi.z};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { red[d * nthr + tid] = my[d]; red[(3 + d) * nthr + tid] = my[d]; }
+    __syncthreads();
+    for (int o = nthr >> 1; o > 0; o >>= 1) {
+        if (tid < o) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                T a = red[d * nthr + tid], c = red[d * nthr + tid + o]; red[d * nthr + tid] = c < a ? c : a;
+                T e = red[(3 + d) * nthr + tid], f = red[(3 + d) * nthr + tid + o]; red[(3 + d) * nthr + tid] = f > e ? f : e;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int ovf = 0, need_minimg = 0;
+        T ctr[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            T lo = red[d * nthr], hi = red[(3 + d) * nthr];
+            s_lo[d] = lo; s_hi[d] = hi; ctr[d] = (lo + hi) * T(0.5);
+            T half = (hi - lo) * T(0.5);
+            if (G.all_cells[d]) { s_boxlo[d] = 0; s_boxlen[d] = G.nc[d]; if (G.periodic[d]) need_minimg = 1; }
+            else {
+                T reach = G.r_list + A.margin;
+                T rel_lo = (G.periodic[d] ? lo : lo - G.origin[d]) - reach, rel_hi = (G.periodic[d] ? hi : hi - G.origin[d]) + reach;
+                int cl = (int)M<T>::floor(rel_lo * G.inv_cs[d]), ch = (int)M<T>::floor(rel_hi * G.inv_cs[d]);
+                if (G.periodic[d]) {
+                    int len = ch - cl + 1;
+                    if (len >= G.nc[d]) { cl = 0; len = G.nc[d]; }
+                    s_boxlo[d] = cl; s_boxlen[d] = len;
+                    // local (pre-shifted) coordinates are unambiguous only if block half-extent + reach < L/2
+                    if (!(half + reach + reach * T(0.25) < G.L[d] * T(0.5))) need_minimg = 1;
+                } else {
+                    cl = max(cl, 0); ch = min(ch, G.nc[d] - 1);
+                    s_boxlo[d] = cl; s_boxlen[d] = max(ch - cl + 1, 1);
+                }
+            }
+        }
+        if ((int64_t)s_boxlen[0] * s_boxlen[1] * s_boxlen[2] > MAX_BOX_CELLS) { ovf |= OVF_BOXCELLS; s_boxlen[0] = s_boxlen[1] = s_boxlen[2] = 1; }
+        if (ovf) atomicOr(&A.flags[FLAG_OVERFLOW], ovf);
+        if (need_minimg) atomicOr(&A.flags[FLAG_MINIMG], 1);
+        A.blk_center[b] = make4<T>(ctr[0], ctr[1], ctr[2], T(0));
+    }
+    __syncthreads();
+    const int lx = s_boxlen[0], ly = s_boxlen[1], lz = s_boxlen[2];
+    const int ncb = lx * ly * lz;
+    T lo[3] = {s_lo[0], s_lo[1], s_lo[2]}, hi[3] = {s_hi[0], s_hi[1], s_hi[2]};
+    const T reach2 = G.no_list ? G.r_list2 : (G.r_list + A.margin) * (G.r_list + A.margin);
+
+    // distance² from a point to the block's bounding box (periodic axes: nearest image)
+    auto box_dist2 = [&](const T4& p) -> T {
+        T acc = T(0);
+        T pc[3] = {p.x, p.y, p.z};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            T c = (lo[d] + hi[d]) * T(0.5), h = (hi[d] - lo[d]) * T(0.5);
+            T t = pc[d] - c;
+            if (G.periodic[d]) t -= G.L[d] * M<T>::rint(t * G.invL[d]);
+            T e = M<T>::fabs(t) - h;
+            e = e > T(0) ? e : T(0);
+            acc += e * e;
+        }
+        return acc;
+    };
+    auto cell_of_q = [&](int q, int& r_owned) {
+        int qx = q % lx, qy = (q / lx) % ly, qz = q / (lx * ly);
+        int gx = s_boxlo[0] + qx, gy = s_boxlo[1] + qy, gz = s_boxlo[2] + qz;
+        if (G.periodic[0]) { gx %= G.nc[0]; if (gx < 0) gx += G.nc[0]; }
+        if (G.periodic[1]) { gy %= G.nc[1]; if (gy < 0) gy += G.nc[1]; }
+        if (G.periodic[2]) { gz %= G.nc[2]; if (gz < 0) gz += G.nc[2]; }
+        r_owned = (int)A.cell_rank[(gz * G.nc[1] + gy) * G.nc[0] + gx];
+    };
+
+    // 2. per box cell: how many of its atoms lie within reach of the bounding box
+    for (int q = tid; q < ncb; q += nthr) {
+        int r; cell_of_q(q, r);
+        int cnt = 0;
+        for (int part = 0; part < 2; ++part) {
+            int c = r + part * G.ncell;
+            for (int s = A.cell_start[c], e = A.cell_start[c + 1]; s < e; ++s) cnt += (box_dist2(A.pos[s]) <= reach2) ? 1 : 0;
+        }
+        c_cnt[q] = cnt;
+    }
+    __syncthreads();
+    // 3. exclusive scan over the box cells (each thread scans a contiguous chunk)
+    {
+        int32_t* part = reinterpret_cast<int32_t*>(red);
+        int per = (ncb + nthr - 1) / nthr, q0 = tid * per, q1 = min(q0 + per, ncb);
+        int sum = 0;
+        for (int q = q0; q < q1; ++q) sum += c_cnt[q];
+        part[tid] = sum;
+        __syncthreads();
+        if (tid == 0) { int run = 0; for (int t = 0; t < nthr; ++t) { int v = part[t]; part[t] = run; run += v; } s_total = run; }
+        __syncthreads();
+        int run = part[tid];
+        for (int q = q0; q < q1; ++q) { c_off[q] = run; run += c_cnt[q]; }
+        if (tid == 0) c_off[ncb] = s_total;
+    }
+    __syncthreads();
+    int tile_n = s_total;
+    if (tile_n > A.T_cap || tile_n > TILE_SLOT_MAX - 1) {
+        if (tid == 0) { atomicOr(&A.flags[FLAG_OVERFLOW], tile_n > TILE_SLOT_MAX - 1 ? OVF_SLOT : OVF_TILE); atomicMax(&A.flags[FLAG_MAX_TILE], tile_n); A.tile_cnt[b] = 0; }
+        if ((tid & 63) == 0) A.wave_rows[b * (A.BI / WAVE) + tid / WAVE] = 0;
+        return;   // the host grows the capacities and rebuilds
+    }
+    // 4. stage the tile in LDS (cell-major, sorted order inside a cell: deterministic slots)
+    for (int q = tid; q < ncb; q += nthr) {
+        int r; cell_of_q(q, r);
+        int t = c_off[q];
+        for (int part = 0; part < 2; ++part) {
+            int c = r + part * G.ncell;
+            for (int s = A.cell_start[c], e = A.cell_start[c + 1]; s < e; ++s) {
+                T4 p = A.pos[s];
+                if (box_dist2(p) <= reach2) { t_pos[t] = p; t_slot[t] = s; A.tile_idx[(int64_t)b * A.T_cap + t] = s; ++t; }
+            }
+        }
+    }
+    if (tid == 0) { A.tile_cnt[b] = tile_n; atomicMax(&A.flags[FLAG_MAX_TILE], tile_n); }
+    __syncthreads();
+
+    // 5. every lane walks its cell stencil over the LDS tile with the reference's exact predicate
+    //    r2 = sum(abs2, vector(ci, cj, boundary)) <= r_list²  &&  eligible   (neighbors.jl:409-411)
+    const uint32_t SENT = (uint32_t)tile_n;
+    uint32_t pack[2] = {0, 0};
+    int cnt = 0;
+    uint2* my_rows = A.nbr + ((int64_t)b * A.R_cap) * A.BI + tid;
+    auto emit = [&](uint32_t e) {
+        int k = cnt & 3;
+        if (k == 0) { pack[0] = 0; pack[1] = 0; }
+        pack[k >> 1] |= e << (16 * (k & 1));
+        ++cnt;
+        if (k == 3) { int row = (cnt >> 2) - 1; if (row < A.R_cap) my_rows[(int64_t)row * A.BI] = make_uint2(pack[0], pack[1]); }
+    };
+    if (valid) {
+        const int oi = A.orig[si];
+        int c0[3] = {cell_coord(my[0], 0, G), cell_coord(my[1], 1, G), cell_coord(my[2], 2, G)};
+        int r0[3], rn[3];   // stencil range per axis in box-local cell coordinates
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            if (G.all_cells[d] || (G.periodic[d] && s_boxlen[d] == G.nc[d])) { r0[d] = 0; rn[d] = s_boxlen[d]; }   // whole axis
+            else if (G.periodic[d]) {
+                int rel = c0[d] - s_boxlo[d]; rel %= G.nc[d]; if (rel < 0) rel += G.nc[d];   // position of my cell inside the box
+                r0[d] = rel - G.stencil[d]; rn[d] = 2 * G.stencil[d] + 1;
+                if (r0[d] < 0) { rn[d] += r0[d]; r0[d] = 0; }                                  // box was dilated by ≥ stencil cells, so
+                if (r0[d] + rn[d] > s_boxlen[d]) rn[d] = s_boxlen[d] - r0[d];                  // clipping only drops cells out of reach
+            } else {
+                int a = max(c0[d] - G.stencil[d], s_boxlo[d]), e = min(c0[d] + G.stencil[d], s_boxlo[d] + s_boxlen[d] - 1);
+                r0[d] = a - s_boxlo[d]; rn[d] = max(e - a + 1, 0);
+            }
+        }
+        for (int qz = r0[2]; qz < r0[2] + rn[2]; ++qz)
+            for (int qy = r0[1]; qy < r0[1] + rn[1]; ++qy) {
+                int qrow = (qz * ly + qy) * lx;
+                // cells along x are contiguous in the tile: one slot range per (y,z) row
+                int t0 = c_off[qrow + r0[0]], t1 = c_off[qrow + r0[0] + rn[0]];
+                for (int t = t0; t < t1; ++t) {
+                    T4 pj = t_pos[t];
+                    T dx = G.periodic[0] ? vector_1d_exact(my[0], pj.x, G.L[0]) : M<T>::sub(pj.x, my[0]);
+                    T dy = G.periodic[1] ? vector_1d_exact(my[1], pj.y, G.L[1]) : M<T>::sub(pj.y, my[1]);
+                    T dz = G.periodic[2] ? vector_1d_exact(my[2], pj.z, G.L[2]) : M<T>::sub(pj.z, my[2]);
+                    T r2 = norm2_exact(dx, dy, dz);
+                    if (!(r2 <= G.r_list2)) continue;
+                    int sj = t_slot[t];
+                    if (sj == (int)si) continue;
+                    uint32_t sp = 0;
+                    if (A.ex_start) {
+                        int oj = A.orig[sj];
+                        bool excl = false;
+                        for (int k = A.ex_start[oi], e = A.ex_start[oi + 1]; k < e; ++k) excl |= (A.ex_list[k] == oj);
+                        if (excl) continue;
+                        for (int k = A.sp_start[oi], e = A.sp_start[oi + 1]; k < e; ++k) sp |= (A.sp_list[k] == oj) ? 1u : 0u;
+                    }
+                    emit((uint32_t)t | (sp << 15));
+                }
+            }
+    }
+    // 6. pad every lane to the wave's row count with the sentinel slot (a far-away dummy atom)
+    int rows_mine = (cnt + 3) >> 2;
+    int rows_wave = wave_max(rows_mine);
+    if (rows_wave > A.R_cap) { if ((tid & 63) == 0) { atomicOr(&A.flags[FLAG_OVERFLOW], OVF_ROWS); atomicMax(&A.flags[FLAG_MAX_ROWS], rows_wave); } rows_wave = 0; }
+    while (((cnt + 3) >> 2) < rows_wave || (cnt & 3)) emit(SENT);
+    if ((tid & 63) == 0) { A.wave_rows[b * (A.BI / WAVE) + tid / WAVE] = rows_wave; atomicMax(&A.flags[FLAG_MAX_ROWS], rows_wave); atomicAdd(&A.flags[FLAG_TOTAL_ROWS], rows_wave); }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the hot kernel: LJ + Coulomb forces (and energy) on the owned atoms from the LDS-staged tile
+template <class T> struct ForceArgs {
+    GridP<T> G;
+    InterP<T> I;
+    int64_t n_owned;
+    int BI, BI_shift, JS, T_cap, T_lds, R_cap, n_blocks, blocks_per_xcd;   // T_lds: tile capacity of the LDS carve-up
+    const typename Vec<T>::T4* pos;
+    const typename Vec<T>::T2* lj;
+    const int32_t* tile_idx;
+    const int32_t* tile_cnt;
+    const uint2* nbr;
+    const int32_t* wave_rows;
+    const typename Vec<T>::T4* blk_center;
+    typename Vec<T>::T4* frc;
+    double* pe_part;                 // [n_blocks] (ENERGY)
+};
+
+template <class T, int LJM, int COULM, bool ENERGY, bool MINIMG>
+__global__ void k_forces(ForceArgs<T> A) {
+    using T4 = typename Vec<T>::T4;
+    using T2 = typename Vec<T>::T2;
+    extern __shared__ __align__(32) unsigned char smem[];
+    const GridP<T>& G = A.G;
+    // XCD-aware mapping: hardware places workgroup w on XCD w % 8; give each XCD a contiguous run of the
+    // Hilbert-ordered blocks so that neighbouring blocks (which share most of their tiles) share an L2.
+    const int wg = blockIdx.x;
+    const int b = (wg & 7) * A.blocks_per_xcd + (wg >> 3);
+    if (b >= A.n_blocks) return;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int tile_n = A.tile_cnt[b];
+    T4* l_pos = reinterpret_cast<T4*>(smem);
+    T2* l_lj = reinterpret_cast<T2*>(l_pos + (A.T_lds + 1));
+    const T4 ctr = A.blk_center[b];
+
+    auto localise = [&](T4 p) -> T4 {
+        if constexpr (!MINIMG) {
+            p.x -= ctr.x; p.y -= ctr.y; p.z -= ctr.z;
+            if (G.periodic[0]) p.x -= G.L[0] * M<T>::rint(p.x * G.invL[0]);
+            if (G.periodic[1]) p.y -= G.L[1] * M<T>::rint(p.y * G.invL[1]);
+            if (G.periodic[2]) p.z -= G.L[2] * M<T>::rint(p.z * G.invL[2]);
+        }
+        return p;
+    };
+    // stage the tile: coalesced-ish gathers of 16 B atoms from L2 into LDS
+    const int32_t* tix = A.tile_idx + (int64_t)b * A.T_cap;
+    for (int t = tid; t < tile_n; t += nthr) {
+        int s = tix[t];
+        l_pos[t] = localise(A.pos[s]);
+        if constexpr (LJM != LJ_OFF) l_lj[t] = A.lj[s];
+    }
+    if (tid == 0) {   // sentinel: far away, no charge, no LJ
+        l_pos[tile_n] = make4<T>(T(1e4), T(1e4), T(1e4), T(0));
+        if constexpr (LJM != LJ_OFF) l_lj[tile_n] = make2<T>(T(0), T(0));
+    }
+    const int li = tid & (A.BI - 1), js = tid >> A.BI_shift;
+    const int64_t si = (int64_t)b * A.BI + li;
+    const bool valid = si < A.n_owned;
+    T4 pi = localise(A.pos[valid ? si : (int64_t)b * A.BI]);
+    T2 lji = make2<T>(T(0), T(0));
+    if constexpr (LJM != LJ_OFF) lji = A.lj[valid ? si : (int64_t)b * A.BI];
+    __syncthreads();
+
+    const int rows = A.wave_rows[b * (A.BI >> 6) + (li >> 6)];
+    const uint2* my_rows = A.nbr + ((int64_t)b * A.R_cap) * A.BI + li;
+    T fx = T(0), fy = T(0), fz = T(0), pe = T(0);
+    for (int r = js; r < rows; r += A.JS) {
+        uint2 e4 = my_rows[(int64_t)r * A.BI];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t e = ((k < 2 ? e4.x : e4.y) >> (16 * (k & 1))) & 0xffffu;
+            uint32_t slot = e & 0x7fffu;
+            bool special = (e >> 15) != 0;
+            T4 pj = l_pos[slot];
+            T2 ljj = make2<T>(T(0), T(0));
+            if constexpr (LJM != LJ_OFF) ljj = l_lj[slot];
+            T dx, dy, dz;
+            if constexpr (MINIMG) {
+                dx = G.periodic[0] ? vector_1d_exact(pi.x, pj.x, G.L[0]) : pj.x - pi.x;
+                dy = G.periodic[1] ? vector_1d_exact(pi.y, pj.y, G.L[1]) : pj.y - pi.y;
+                dz = G.periodic[2] ? vector_1d_exact(pi.z, pj.z, G.L[2]) : pj.z - pi.z;
+            } else { dx = pj.x - pi.x; dy = pj.y - pi.y; dz = pj.z - pi.z; }
+            T r2 = dx * dx + dy * dy + dz * dz;
+            T fr = pair_eval<T, LJM, COULM, ENERGY>(A.I, r2, pi.w, pj.w, lji.x, ljj.x, lji.y, ljj.y, special, pe);
+            fx -= fr * dx; fy -= fr * dy; fz -= fr * dz;   // force on i is −f (force.jl:873)
+        }
+    }
+    if (A.JS > 1) {   // deterministic reduction of the j-split partial sums through LDS
+        __syncthreads();
+        T* red = reinterpret_cast<T*>(smem);
+        red[(js * 4 + 0) * A.BI + li] = fx; red[(js * 4 + 1) * A.BI + li] = fy;
+        red[(js * 4 + 2) * A.BI + li] = fz; red[(js * 4 + 3) * A.BI + li] = pe;
+        __syncthreads();
+        if (js == 0) {
+            for (int q = 1; q < A.JS; ++q) {
+                fx += red[(q * 4 + 0) * A.BI + li]; fy += red[(q * 4 + 1) * A.BI + li];
+                fz += red[(q * 4 + 2) * A.BI + li]; pe += red[(q * 4 + 3) * A.BI + li];
+            }
+        }
+    }
+    if (js == 0 && valid) A.frc[si] = make4<T>(fx, fy, fz, T(0));
+    if constexpr (ENERGY) {
+        __syncthreads();
+        double* dred = reinterpret_cast<double*>(smem);
+        if (js == 0) dred[li] = valid ? 0.5 * (double)pe : 0.0;   // every pair is visited from both ends
+        __syncthreads();
+        if (tid == 0) { double s = 0; for (int q = 0; q < A.BI; ++q) s += dred[q]; A.pe_part[b] = s; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// neighbour list export: half list i<j in caller indices
+template <class T>
+__global__ void k_export_nl(int n_blocks, int BI, int T_cap, int R_cap, int64_t n_owned, const int32_t* __restrict__ orig,
+                            const int32_t* __restrict__ tile_idx, const int32_t* __restrict__ tile_cnt, const uint2* __restrict__ nbr,
+                            const int32_t* __restrict__ wave_rows, int32_t* out_i, int32_t* out_j, uint8_t* out_sp,
+                            unsigned long long* counter, unsigned long long capacity) {
+    int b = blockIdx.x, li = threadIdx.x;
+    int64_t si = (int64_t)b * BI + li;
+    if (si >= n_owned) return;
+    int rows = wave_rows[b * (BI >> 6) + (li >> 6)];
+    int tile_n = tile_cnt[b];
+    int oi = orig[si];
+    for (int r = 0; r < rows; ++r) {
+        uint2 e4 = nbr[((int64_t)b * R_cap + r) * BI + li];
+        for (int k = 0; k < 4; ++k) {
+            uint32_t e = ((k < 2 ? e4.x : e4.y) >> (16 * (k & 1))) & 0xffffu;
+            int slot = e & 0x7fff;
+            if (slot >= tile_n) continue;
+            int oj = orig[tile_idx[(int64_t)b * T_cap + slot]];
+            if (oi < oj) {
+                unsigned long long at = atomicAdd(counter, 1ull);
+                if (out_i && at < capacity) { out_i[at] = oi; out_j[at] = oj; out_sp[at] = (uint8_t)(e >> 15); }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// velocity Verlet (simulators.jl:589-629), owned atoms, sorted order.  vel.w carries the mass.
+template <class T>
+__global__ void k_vv1(int64_t n, typename Vec<T>::T4* pos, typename Vec<T>::T4* vel, const typename Vec<T>::T4* __restrict__ frc,
+                      T dt, T dt2, const T* __restrict__ vcm, GridP<T> G) {
+    int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    auto v = vel[s]; auto p = pos[s]; auto f = frc[s];
+    if (vcm) { v.x -= vcm[0]; v.y -= vcm[1]; v.z -= vcm[2]; }            // deferred remove_CM_motion!
+    T im = (v.w == T(0)) ? T(0) : T(1) / v.w;                              // calc_accels, force.jl:17
+    v.x += (f.x * im) * dt2; v.y += (f.y * im) * dt2; v.z += (f.z * im) * dt2;   // :594
+    p.x += v.x * dt; p.y += v.y * dt; p.z += v.z * dt;                     // :602
+    if (G.periodic[0]) p.x = wrap_1d(p.x, G.L[0]);                         // :609
+    if (G.periodic[1]) p.y = wrap_1d(p.y, G.L[1]);
+    if (G.periodic[2]) p.z = wrap_1d(p.z, G.L[2]);
+    vel[s] = v; pos[s] = p;
+}
+
+template <class T, bool CM>
+__global__ void k_vv2(int64_t n, typename Vec<T>::T4* vel, const typename Vec<T>::T4* __restrict__ frc, T dt2, double* cm_part) {
+    int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    double px = 0, py = 0, pz = 0, m = 0;
+    if (s < n) {
+        auto v = vel[s]; auto f = frc[s];
+        T im = (v.w == T(0)) ? T(0) : T(1) / v.w;
+        v.x += (f.x * im) * dt2; v.y += (f.y * im) * dt2; v.z += (f.z * im) * dt2;   // :616
+        vel[s] = v;
+        if constexpr (CM) { px = (double)v.x * v.w; py = (double)v.y * v.w; pz = (double)v.z * v.w; m = v.w; }
+    }
+    if constexpr (CM) {
+        __shared__ double sh[4][4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { px += __shfl_xor(px, o, 64); py += __shfl_xor(py, o, 64); pz += __shfl_xor(pz, o, 64); m += __shfl_xor(m, o, 64); }
+        int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { sh[w][0] = px; sh[w][1] = py; sh[w][2] = pz; sh[w][3] = m; }
+        __syncthreads();
+        if (threadIdx.x < 4) { double a = 0; for (int q = 0; q < (int)(blockDim.x >> 6); ++q) a += sh[q][threadIdx.x]; cm_part[4 * (int64_t)blockIdx.x + threadIdx.x] = a; }
+    }
+}
+
+// Σ m v and Σ m of the current velocities (for an explicit remove_CM_motion! / multi-GPU all-reduce)
+template <class T>
+__global__ void k_cm_partials(int64_t n, const typename Vec<T>::T4* __restrict__ vel, const T* __restrict__ vcm, double* cm_part) {
+    int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    double px = 0, py = 0, pz = 0, m = 0;
+    if (s < n) { auto v = vel[s]; if (vcm) { v.x -= vcm[0]; v.y -= vcm[1]; v.z -= vcm[2]; } px = (double)v.x * v.w; py = (double)v.y * v.w; pz = (double)v.z * v.w; m = v.w; }
+    __shared__ double sh[4][4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { px += __shfl_xor(px, o, 64); py += __shfl_xor(py, o, 64); pz += __shfl_xor(pz, o, 64); m += __shfl_xor(m, o, 64); }
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[w][0] = px; sh[w][1] = py; sh[w][2] = pz; sh[w][3] = m; }
+    __syncthreads();
+    if (threadIdx.x < 4) { double a = 0; for (int q = 0; q < (int)(blockDim.x >> 6); ++q) a += sh[q][threadIdx.x]; cm_part[4 * (int64_t)blockIdx.x + threadIdx.x] = a; }
+}
+
+// one block: fixed-order sum of the per-block partials → out4 = {Px,Py,Pz,M} (double) and vcm = P/M (T)
+template <class T>
+__global__ void k_cm_finalize(int n_part, const double* __restrict__ cm_part, double* out4, T* vcm) {
+    __shared__ double sh[256][4];
+    double a[4] = {0, 0, 0, 0};
+    for (int q = threadIdx.x; q < n_part; q += blockDim.x) for (int c = 0; c < 4; ++c) a[c] += cm_part[4 * (int64_t)q + c];
+    for (int c = 0; c < 4; ++c) sh[threadIdx.x][c] = a[c];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[4] = {0, 0, 0, 0};
+        for (int q = 0; q < (int)blockDim.x; ++q) for (int c = 0; c < 4; ++c) t[c] += sh[q][c];
+        for (int c = 0; c < 4; ++c) out4[c] = t[c];
+        if (vcm) for (int c = 0; c < 3; ++c) vcm[c] = (T)(t[c] / t[3]);
+    }
+}
+
+template <class T>
+__global__ void k_shift_vel(int64_t n, typename Vec<T>::T4* vel, const T* __restrict__ vcm) {
+    int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    auto v = vel[s]; v.x -= vcm[0]; v.y -= vcm[1]; v.z -= vcm[2]; vel[s] = v;
+}
+
+// kinetic energy partials: Σ (m/2) v·v  (energy.jl:56-89)
+template <class T>
+__global__ void k_ke_partials(int64_t n, const typename Vec<T>::T4* __restrict__ vel, double* part) {
+    int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    double k = 0;
+    if (s < n) { auto v = vel[s]; k = 0.5 * (double)v.w * ((double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z); }
+    __shared__ double sh[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) k += __shfl_xor(k, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = k;
+    __syncthreads();
+    if (threadIdx.x == 0) { double a = 0; for (int q = 0; q < (int)(blockDim.x >> 6); ++q) a += sh[q]; part[blockIdx.x] = a; }
+}
+
+// one block: fixed-order sum of n doubles
+__global__ void k_sum_double(int n, const double* __restrict__ part, double* out) {
+    __shared__ double sh[256];
+    double a = 0;
+    for (int q = threadIdx.x; q < n; q += blockDim.x) a += part[q];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0; for (int q = 0; q < (int)blockDim.x; ++q) t += sh[q]; *out = t; }
+}
+
+template <class T>
+__global__ void k_check_finite(int64_t n, const typename Vec<T>::T4* __restrict__ pos, const typename Vec<T>::T4* __restrict__ vel,
+                               const typename Vec<T>::T4* __restrict__ frc, int32_t* flags) {
+    int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    auto p = pos[s]; auto v = vel[s]; auto f = frc[s];
+    T t = p.x + p.y + p.z + v.x + v.y + v.z + f.x + f.y + f.z;
+    if (!(t == t) || M<T>::fabs(t) > T(1e30)) atomicOr(&flags[FLAG_NAN], 1);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// multi-GPU halo helpers
+template <class T>
+__global__ void k_gather_coords(int64_t n, const int32_t* __restrict__ idx, const T* __restrict__ shift, const int32_t* __restrict__ inv,
+                                const typename Vec<T>::T4* __restrict__ pos, T* out) {
+    int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    auto p = pos[inv[idx[k]]];
+    T sx = shift ? shift[3 * k] : T(0), sy = shift ? shift[3 * k + 1] : T(0), sz = shift ? shift[3 * k + 2] : T(0);
+    out[3 * k] = p.x + sx; out[3 * k + 1] = p.y + sy; out[3 * k + 2] = p.z + sz;
+}
+template <class T>
+__global__ void k_scatter_coords(int64_t first, int64_t n, const T* __restrict__ in, const int32_t* __restrict__ inv, typename Vec<T>::T4* pos) {
+    int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    int s = inv[first + k];
+    pos[s].x = in[3 * k]; pos[s].y = in[3 * k + 1]; pos[s].z = in[3 * k + 2];
+}
+
+}  // namespace mhip

@@ -1,0 +1,181 @@
+// physics.h — device-side pair physics: LennardJones (+6 cutoff strategies), Coulomb, CoulombReactionField,
+// CoulombEwald, and the exact compare/select minimum image.  Behavioural spec (Molly.jl v0.23.3):
+//   lennard_jones.jl:79-140, coulomb.jl:71-120, 748-814, 1384-1441, cutoffs.jl:15-253, mixing.jl:3-34,
+//   spatial.jl:491-519, 573-586.
+// Written for gfx950: fp32 uses the hardware v_rcp/v_sqrt/v_exp units (≤1 ulp) instead of the
+// multi-instruction IEEE sequences; fp64 uses the precise library forms.
+#pragma once
+#include "common.h"
+
+namespace mhip {
+
+template <class T> struct M;
+template <> struct M<float> {
+    __device__ static inline float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+    __device__ static inline float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+    __device__ static inline float exp(float x) { return __expf(x); }
+    __device__ static inline float erfc(float x) { return ::erfcf(x); }
+    __device__ static inline float erf(float x) { return ::erff(x); }
+    __device__ static inline float rint(float x) { return ::rintf(x); }
+    __device__ static inline float floor(float x) { return ::floorf(x); }
+    __device__ static inline float fabs(float x) { return ::fabsf(x); }
+    __device__ static inline float mul(float a, float b) { return __fmul_rn(a, b); }   // never contracted
+    __device__ static inline float add(float a, float b) { return __fadd_rn(a, b); }
+    __device__ static inline float sub(float a, float b) { return __fsub_rn(a, b); }
+};
+template <> struct M<double> {
+    __device__ static inline double rcp(double x) { return 1.0 / x; }
+    __device__ static inline double sqrt(double x) { return ::sqrt(x); }
+    __device__ static inline double exp(double x) { return ::exp(x); }
+    __device__ static inline double erfc(double x) { return ::erfc(x); }
+    __device__ static inline double erf(double x) { return ::erf(x); }
+    __device__ static inline double rint(double x) { return ::rint(x); }
+    __device__ static inline double floor(double x) { return ::floor(x); }
+    __device__ static inline double fabs(double x) { return ::fabs(x); }
+    __device__ static inline double mul(double a, double b) { return __dmul_rn(a, b); }
+    __device__ static inline double add(double a, double b) { return __dadd_rn(a, b); }
+    __device__ static inline double sub(double a, double b) { return __dsub_rn(a, b); }
+};
+
+// spatial.jl:491-500 vector_1D in its literal compare/select form.  With t = L - |v| both branches of the
+// reference collapse to: |v| < t ? v : copysign(t, -v)   (v + L == L - (-v) and -(v - L) == L - v exactly).
+// Non-contracted arithmetic: this is the form the bit-exact neighbour test is built on.
+template <class T> __device__ inline T vector_1d_exact(T c1, T c2, T L) {
+    T v = M<T>::sub(c2, c1);
+    T a = M<T>::fabs(v);
+    T t = M<T>::sub(L, a);
+    return (a < t) ? v : ((v > T(0)) ? -t : t);
+}
+// r2 = sum(abs2, dr) = (dx² + dy²) + dz², every operation rounded separately (neighbors.jl:409)
+template <class T> __device__ inline T norm2_exact(T dx, T dy, T dz) {
+    return M<T>::add(M<T>::add(M<T>::mul(dx, dx), M<T>::mul(dy, dy)), M<T>::mul(dz, dz));
+}
+// spatial.jl:573-579 wrap_coord_1D
+template <class T> __device__ inline T wrap_1d(T c, T L) {
+    return M<T>::sub(c, M<T>::mul(M<T>::floor(c / L), L));
+}
+
+// ---- cutoff strategies on a bare pair potential, cutoffs.jl ----------------------------------------
+template <class T> struct LJBare {   // lennard_jones.jl:106-109, 137-140; params (σ², ϵ)
+    T s2, e;
+    __device__ inline T f(T r) const { T six = s2 * M<T>::rcp(r * r); six = six * six * six; return (T(24) * e * M<T>::rcp(r)) * (T(2) * six * six - six); }
+    __device__ inline T v(T r) const { T six = s2 * M<T>::rcp(r * r); six = six * six * six; return T(4) * e * (six * six - six); }
+};
+template <class T> struct CoulBare {   // coulomb.jl:93-95, 118-120; params (ke, qi, qj)
+    T kqq;
+    __device__ inline T f(T r) const { return kqq * M<T>::rcp(r * r); }
+    __device__ inline T v(T r) const { return kqq * M<T>::rcp(r); }
+};
+
+template <class T, class P> __device__ inline T cut_force(int kind, T rc, T ra, const P& p, T r) {
+    switch (kind) {
+    case MHIP_CUTOFF_NONE: return p.f(r);
+    case MHIP_CUTOFF_DISTANCE:
+    case MHIP_CUTOFF_SHIFTED_POTENTIAL: return (r <= rc) ? p.f(r) : T(0);
+    case MHIP_CUTOFF_SHIFTED_FORCE: return (r <= rc) ? p.f(r) - p.f(rc) : T(0);
+    case MHIP_CUTOFF_CUBIC_SPLINE: {
+        if (r <= ra) return p.f(r);
+        T w = rc - ra, t = (r - ra) / w;
+        T f = -(T(6) * t * t - T(6) * t) * p.v(ra) / w - (T(3) * t * t - T(4) * t + T(1)) * (-p.f(ra));
+        return (r <= rc) ? f : T(0);
+    }
+    default: {   // MHIP_CUTOFF_POLYNOMIAL
+        if (r <= ra) return p.f(r);
+        T w = rc - ra, t = (r - ra) / w;
+        T t2 = t * t, t3 = t2 * t, t4 = t3 * t, t5 = t4 * t;
+        T S = T(1) - T(6) * t5 + T(15) * t4 - T(10) * t3;
+        T dS = (T(-30) * t4 + T(60) * t3 - T(30) * t2) / w;
+        return (r <= rc) ? S * p.f(r) - dS * p.v(r) : T(0);
+    }
+    }
+}
+template <class T, class P> __device__ inline T cut_pe(int kind, T rc, T ra, const P& p, T r) {
+    switch (kind) {
+    case MHIP_CUTOFF_NONE: return p.v(r);
+    case MHIP_CUTOFF_DISTANCE: return (r <= rc) ? p.v(r) : T(0);
+    case MHIP_CUTOFF_SHIFTED_POTENTIAL: return (r <= rc) ? p.v(r) - p.v(rc) : T(0);
+    case MHIP_CUTOFF_SHIFTED_FORCE: return (r <= rc) ? p.v(r) + (r - rc) * p.f(rc) - p.v(rc) : T(0);
+    case MHIP_CUTOFF_CUBIC_SPLINE: {
+        if (r <= ra) return p.v(r);
+        T w = rc - ra, t = (r - ra) / w, t2 = t * t, t3 = t2 * t;
+        T v = (T(2) * t3 - T(3) * t2 + T(1)) * p.v(ra) + (t3 - T(2) * t2 + t) * w * (-p.f(ra));
+        return (r <= rc) ? v : T(0);
+    }
+    default: {
+        if (r <= ra) return p.v(r);
+        T w = rc - ra, t = (r - ra) / w;
+        T t2 = t * t, t3 = t2 * t, t4 = t3 * t, t5 = t4 * t;
+        T S = T(1) - T(6) * t5 + T(15) * t4 - T(10) * t3;
+        return (r <= rc) ? S * p.v(r) : T(0);
+    }
+    }
+}
+
+// coulomb.jl:1384-1393 calc_erfc (Abramowitz & Stegun 7.1.26 when approximate_erfc)
+template <class T> __device__ inline T ewald_erfc(T ar, T e, int approx) {
+    if (approx) {
+        T t = M<T>::rcp(T(1) + T(0.3275911) * ar);
+        return (T(0.254829592) + (T(-0.284496736) + (T(1.421413741) + (T(-1.453152027) + T(1.061405429) * t) * t) * t) * t) * t * e;
+    }
+    return M<T>::erfc(ar);
+}
+
+enum { LJ_OFF = 0, LJ_DIST = 1, LJ_GENERIC = 2 };
+
+// Sum over pairwise_inters for one pair (force.jl:79-92 / kernels.jl:3-17).  Returns `fr` such that the
+// force on atom j is fr·dr (and −fr·dr on atom i, force.jl:873-874) and, if ENERGY, adds the pair energy.
+template <class T, int LJM, int COULM, bool ENERGY>
+__device__ inline T pair_eval(const InterP<T>& I, T r2, T qi, T qj, T si, T sj, T ei, T ej, bool special, T& pe) {
+    T fr = T(0);
+    T inv_r2 = M<T>::rcp(r2);
+    if constexpr (LJM != LJ_OFF) {
+        T s = (si + sj) * T(0.5);                                   // LorentzMixing
+        T e = M<T>::sqrt(ei * ej);                                  // GeometricMixing
+        e = (si == T(0) || sj == T(0)) ? T(0) : e;                  // LJZeroShortcut (ϵ == 0 already yields 0)
+        T w = special ? I.lj_w : T(1);
+        if constexpr (LJM == LJ_DIST) {
+            // DistanceCutoff: F/r = 24ϵ(2 s6² − s6)/r², zero past the cutoff (r ≤ rc ⇔ r² ≤ rc²)
+            T six = (s * s) * inv_r2; six = six * six * six;
+            bool in = r2 <= I.lj_rc2;
+            T f = T(24) * e * (T(2) * six * six - six) * inv_r2;
+            fr += in ? f * w : T(0);
+            if constexpr (ENERGY) pe += in ? T(4) * e * (six * six - six) * w : T(0);
+        } else {
+            T r = M<T>::sqrt(r2);
+            LJBare<T> p{s * s, e};
+            fr += cut_force(I.lj_cut, I.lj_rc, I.lj_ra, p, r) * M<T>::rcp(r) * w;
+            if constexpr (ENERGY) pe += cut_pe(I.lj_cut, I.lj_rc, I.lj_ra, p, r) * w;
+        }
+    }
+    if constexpr (COULM == MHIP_COUL_PLAIN) {
+        T r = M<T>::sqrt(r2);
+        CoulBare<T> p{I.ke * qi * qj};
+        T w = special ? I.c_w : T(1);
+        fr += cut_force(I.coul_cut, I.c_rc, I.c_ra, p, r) * M<T>::rcp(r) * w;
+        if constexpr (ENERGY) pe += cut_pe(I.coul_cut, I.c_rc, I.c_ra, p, r) * w;
+    } else if constexpr (COULM == MHIP_COUL_REACTION_FIELD) {
+        T inv_r = M<T>::sqrt(inv_r2);
+        T kqq = I.ke * qi * qj;
+        T krf = special ? T(0) : I.krf;                              // 1-4 pairs: no reaction field
+        T crf = special ? T(0) : I.crf;
+        T w = special ? I.c_w : T(1);
+        bool in = r2 <= I.c_rc2;
+        fr += in ? kqq * (inv_r - T(2) * krf * r2) * inv_r2 * w : T(0);
+        if constexpr (ENERGY) pe += in ? kqq * (inv_r + krf * r2 - crf) * w : T(0);
+    } else if constexpr (COULM == MHIP_COUL_EWALD_DIRECT) {
+        T inv_r = M<T>::sqrt(inv_r2);
+        T r = r2 * inv_r;
+        T ar = I.alpha * r;
+        T ex = M<T>::exp(-(ar * ar));
+        T ec = ewald_erfc(ar, ex, I.approx_erfc);
+        T kqq = I.ke * qi * qj;
+        bool in = r2 <= I.c_rc2;
+        T f3 = kqq * inv_r * inv_r2;
+        T g = special ? I.c_w : ec + I.two_over_sqrt_pi * ar * ex;   // special: plain Coulomb × weight
+        fr += in ? f3 * g : T(0);
+        if constexpr (ENERGY) pe += in ? kqq * inv_r * (special ? I.c_w : ec) : T(0);
+    }
+    return fr;
+}
+
+}  // namespace mhip

@@ -1,0 +1,79 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/mollyhip.h declares, the host
+mirror validates its inputs like the reference, and the product path fails loudly without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "mollyhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mhip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    assert os.path.exists(pkg.LIB_PATH), "libmollyhip.so not built: run python -c 'import __graft_entry__ as g; g.build()'"
+    lib = pkg.lib()
+    declared = header_symbols()
+    assert len(declared) >= 30
+    assert sorted(pkg.SIGNATURES) == declared
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_struct_layouts_match_header(pkg):
+    import ctypes as C
+    # sizes computed from the C declarations (LP64): see include/mollyhip.h
+    assert C.sizeof(pkg.Interactions) == 4 * 2 + 8 * 3 + 4 * 2 + 8 * 6 + 4 * 2
+    assert C.sizeof(pkg.Config) == 4 * 2 + 8 + 24 + 24 + 12 + 4 + 8 + C.sizeof(pkg.Interactions)
+    assert C.sizeof(pkg.Stats) == 8 * 9 + 4 * 4 + 8 * 3
+
+
+def test_product_path_fails_loudly_without_gpu(pkg):
+    if pkg.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    s = pkg.System(coords=np.random.rand(10, 3), boundary=pkg.CubicBoundary(2.0), pairwise_inters=(pkg.LennardJones(),))
+    with pytest.raises(pkg.MollyHipError) as e:
+        pkg.forces(s)
+    assert e.value.code == -5   # MHIP_ERR_NO_DEVICE: no CPU fallback exists
+
+
+def test_create_rejects_bad_config(pkg):
+    import ctypes as C
+    cfg = pkg.Config()
+    cfg.precision = 16; cfg.n_atoms = 10
+    ctx = C.c_void_p()
+    assert pkg.lib().mhip_create(C.byref(ctx), C.byref(cfg)) < 0
+    assert pkg.lib().mhip_last_error(None)
+    assert pkg.lib().mhip_forces(None, 0, 0, None, None, 0) == -1   # null context
+
+
+def test_host_mirror_validation(pkg):
+    with pytest.raises(ValueError):
+        pkg.CubicSplineCutoff(0.8, 0.6)          # cutoffs.jl:180-183
+    with pytest.raises(ValueError):
+        pkg.CubicBoundary(1.0, -1.0, 1.0)
+    with pytest.raises(ValueError):
+        pkg.System(atoms=[pkg.Atom()] * 3, coords=np.zeros((4, 3)), boundary=pkg.CubicBoundary(2.0))   # types.jl:914
+    with pytest.raises(ValueError):
+        pkg.System(coords=np.zeros((4, 3)), velocities=np.zeros((3, 3)), boundary=pkg.CubicBoundary(2.0))
+    # α = sqrt(-log(2·tol))/rc (coulomb.jl:1332): 2.6282608 for rc = 1, tol = 5e-4
+    assert pkg.CoulombEwald(dist_cutoff=1.0).α == pytest.approx(2.6282608, abs=1e-6)
+    # normalize_pairs: i<j, sorted, unique, self-pairs dropped (neighbors.jl:171-195, test/basic.jl:701-737)
+    nf = pkg.GPUNeighborFinder(dist_cutoff=1.2, excluded_pairs=[[3, 1], [1, 3], [2, 2], [0, 5]], special_pairs=[[4, 2]])
+    assert nf.excluded.tolist() == [[0, 5], [1, 3]] and nf.special.tolist() == [[2, 4]]
+    el = np.ones((4, 4), bool); el[0, 1] = el[1, 0] = False; np.fill_diagonal(el, False)
+    nf = pkg.GPUNeighborFinder(dist_cutoff=1.2, eligible=el)
+    assert nf.excluded.tolist() == [[0, 1]]
+    s = pkg.System(coords=np.zeros((4, 3)), boundary=pkg.CubicBoundary(2.0),
+                   pairwise_inters=(pkg.LennardJones(cutoff=pkg.DistanceCutoff(1.0), use_neighbors=True, weight_special=0.5),
+                                    pkg.CoulombReactionField(dist_cutoff=1.0, use_neighbors=True)))
+    it = s.interactions()
+    assert (it.lj_enabled, it.lj_cutoff_kind, it.lj_rc, it.lj_weight_special) == (1, 1, 1.0, 0.5)
+    assert (it.coul_kind, it.coul_rc, it.rf_dielectric) == (2, 1.0, 78.3)
+    with pytest.raises(pkg.MollyHipError):
+        pkg.System(coords=np.zeros((4, 3)), boundary=pkg.CubicBoundary(2.0), pairwise_inters=(object(),)).interactions()

@@ -1,0 +1,317 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Bars: neighbour pair SET bit-exact against the same-precision oracle; fp64 forces |ΔF| <= 1e-7 kJ/mol/nm
+and |ΔE| <= 1e-5 kJ/mol-scale relative (the reference's own bars, test/protein.jl:267,274;
+test/gpu_consistency.jl:44 rtol 1e-8); fp32 forces within 2e-5·Σ_j‖f_ij‖ per atom (+ the force jump of
+pairs within 2e-6 of a hard cutoff), fp32 energies within 2e-6·Σ|e_ij|.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from tests import systems as S
+
+pytestmark = pytest.mark.gpu
+
+
+def nl_keys(i, j, sp):
+    lo, hi, s = S.sorted_pairs(i, j, sp)
+    return lo, hi, s
+
+
+def assert_same_neighbors(m, case, dtype):
+    o = case.oracle(dtype)
+    oi, oj, osp = o.neighbors("cell", nthreads=4)
+    sys_ = case.system(m, dtype)
+    nl = m.find_neighbors(sys_)
+    a, b = nl_keys(oi, oj, osp), nl_keys(nl.i, nl.j, nl.special)
+    assert len(a[0]) == len(b[0]), f"{case.name}: {len(b[0])} pairs, oracle {len(a[0])}"
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    return sys_, (oi, oj, osp)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("maker", ["lj16", "lj8_small_box", "charged12", "lj20"])
+def test_neighbor_set_bit_exact(pkg, maker, dtype):
+    case = {"lj16": lambda: S.lj_fluid(16, dtype=dtype), "lj8_small_box": lambda: S.lj_fluid(8, dtype=dtype),
+            "charged12": lambda: S.charged_fluid(12, dict(kind="rf", rc=1.0), dtype=dtype),
+            "lj20": lambda: S.lj_fluid(20, seed=9, jitter=0.05, dtype=dtype)}[maker]()
+    sys_, _ = assert_same_neighbors(pkg, case, dtype)
+    st = sys_.stats()
+    assert st["n_pairs_full"] % 2 == 0
+    if maker == "lj8_small_box":
+        assert st["minimg_mode"] == 1   # box 2.9 nm < 2·(block half-extent + r_list): in-loop exact minimum image
+
+
+def test_neighbor_three_atom_toy(pkg):
+    # test/basic.jl:494-518
+    case = S.Case([[1, 1, 1], [2, 2, 2], [5, 5, 5]], 10.0, lj=dict(cutoff=("distance", 1.0)), r_list=2.0,
+                  sigma=np.full(3, 0.3), eps=np.full(3, 0.2))
+    nl = pkg.find_neighbors(case.system(pkg, np.float64))
+    assert nl.list == [(0, 1, False)]
+
+
+COULS = {
+    "plain_none": dict(kind="plain", cutoff=("none",)),
+    "plain_dist": dict(kind="plain", cutoff=("distance", 1.0), weight_special=0.8333333333333334),
+    "plain_shifted_force": dict(kind="plain", cutoff=("shifted_force", 1.0)),
+    "rf": dict(kind="rf", rc=1.0, eps_rf=78.3, weight_special=0.8333333333333334),
+    "rf_inf": dict(kind="rf", rc=1.0, eps_rf=math.inf),
+    "ewald": dict(kind="ewald", rc=1.0, weight_special=0.8333333333333334),
+    "ewald_exact_erfc": dict(kind="ewald", rc=1.0, approx=False),
+}
+
+
+@pytest.mark.parametrize("coul", sorted(COULS))
+def test_forces_and_energy_fp64(pkg, coul):
+    case = S.charged_fluid(12, COULS[coul], dtype=np.float64)
+    o = case.oracle(np.float64)
+    nl = o.neighbors("cell")
+    f_ref, e_ref = o.forces(nl), o.potential_energy(nl)
+    s = case.system(pkg, np.float64)
+    f = pkg.forces(s)
+    fmax = np.abs(f_ref).max()
+    assert np.abs(f - f_ref).max() <= 1e-9 * fmax + 1e-7
+    e = pkg.potential_energy(s)
+    assert e == pytest.approx(e_ref, rel=1e-10, abs=1e-6)
+
+
+@pytest.mark.parametrize("coul", ["rf", "ewald", "plain_dist"])
+def test_forces_and_energy_fp32(pkg, coul):
+    case = S.charged_fluid(14, COULS[coul], dtype=np.float32)
+    tol, o, nl = S.fp32_force_tolerance(case)
+    f_ref = o.forces(nl)
+    s = case.system(pkg, np.float32)
+    f = pkg.forces(s).astype(np.float64)
+    err = np.linalg.norm(f - f_ref, axis=1)
+    assert np.all(err <= tol), f"worst atom: err {err.max():.3e}, tol there {tol[err.argmax()]:.3e}"
+    rel_rms = np.sqrt((err ** 2).sum() / (np.linalg.norm(f_ref, axis=1) ** 2).sum())
+    assert rel_rms < 2e-5
+    e_ref = o.potential_energy(nl)
+    e = pkg.potential_energy(s)
+    # Σ|e_ij| scale: use the fp64 oracle energy of the absolute values via a generous proxy
+    assert e == pytest.approx(e_ref, rel=2e-5, abs=2e-6 * case.n * 500)
+
+
+@pytest.mark.parametrize("kind", ["none", "distance", "shifted_potential", "shifted_force", "cubic_spline", "polynomial"])
+def test_all_cutoffs_lj_fp64(pkg, kind):
+    # the six strategies of cutoffs.jl on a 1000-atom fluid (energy-conservation systems use them: test/energy_conservation.jl:21-26)
+    base = S.lj_fluid(10, dtype=np.float64)
+    cut = (kind,) if kind == "none" else ((kind, 1.0, 0.8) if kind in ("cubic_spline", "polynomial") else (kind, 1.0))
+    case = S.Case(base.coords, base.box, lj=dict(cutoff=cut), r_list=1.2 if kind != "none" else 1.7, sigma=base.sigma, eps=base.eps, mass=base.mass)
+    o = case.oracle(np.float64)
+    nl = o.neighbors("cell")
+    s = case.system(pkg, np.float64)
+    f_ref = o.forces(nl)
+    assert np.abs(pkg.forces(s) - f_ref).max() <= 1e-9 * np.abs(f_ref).max() + 1e-8
+    assert pkg.potential_energy(s) == pytest.approx(o.potential_energy(nl), rel=1e-10, abs=1e-8)
+
+
+def test_no_neighbor_list_path(pkg):
+    # README example shape (README.md:72-95) and test/gpu_consistency.jl:407-449: NoCutoff, no neighbour finder
+    rng = np.random.default_rng(1)
+    n = 100
+    g = np.stack(np.meshgrid(*[np.arange(5)] * 3, indexing="ij"), -1).reshape(-1, 3)[:n] * 0.4 + 0.1
+    x = g + rng.uniform(-0.03, 0.03, (n, 3))
+    case = S.Case(x, 2.0, lj=dict(cutoff=("none",)), coul=dict(kind="plain", cutoff=("none",)), sigma=np.full(n, 0.3),
+                  eps=np.full(n, 0.2), mass=np.full(n, 10.0), charge=rng.normal(size=n) * 0.1)
+    o = case.oracle(np.float64)
+    f_ref = o.forces(None)
+    s = case.system(pkg, np.float64)
+    assert np.abs(pkg.forces(s) - f_ref).max() <= 1e-9 * np.abs(f_ref).max()
+    assert pkg.potential_energy(s) == pytest.approx(o.potential_energy(None), rel=1e-10)
+    assert pkg.find_neighbors(s) is None
+
+
+def test_gpu_consistency_diagonal_33_atoms(pkg):
+    # test/gpu_consistency.jl:3-50: 33 atoms on a diagonal (0.5·i), box 20, LJ σ=1? rc 5 — partial tile
+    n = 33
+    x = np.array([[0.5 * (i + 1)] * 3 for i in range(n)])
+    case = S.Case(x, 20.0, lj=dict(cutoff=("distance", 5.0)), r_list=5.0, sigma=np.full(n, 0.3), eps=np.full(n, 0.2), mass=np.full(n, 10.0))
+    o = case.oracle(np.float64)
+    nl = o.neighbors("brute")
+    s = case.system(pkg, np.float64)
+    np.testing.assert_allclose(pkg.forces(s), o.forces(nl), rtol=1e-8, atol=1e-10)
+    assert pkg.potential_energy(s) == pytest.approx(o.potential_energy(nl), rel=1e-8, abs=1e-10)
+
+
+def test_gpu_consistency_lattice_100_atoms(pkg):
+    # test/gpu_consistency.jl:52-114: 100-atom lattice spacing 1.5, σ = 1, rc 4 (lattice distances hit exact ties)
+    g = np.stack(np.meshgrid(np.arange(5), np.arange(5), np.arange(4), indexing="ij"), -1).reshape(-1, 3).astype(float)
+    x = g * 1.5 + 0.75
+    n = len(x)
+    case = S.Case(x, 9.0, lj=dict(cutoff=("distance", 4.0)), r_list=4.0, sigma=np.full(n, 1.0), eps=np.full(n, 0.2), mass=np.full(n, 10.0))
+    for dtype in (np.float64, np.float32):
+        o = case.oracle(dtype)
+        oi, oj, osp = o.neighbors("brute")
+        s = case.system(pkg, dtype)
+        nl = pkg.find_neighbors(s)
+        a, b = nl_keys(oi, oj, osp), nl_keys(nl.i, nl.j, nl.special)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    o = case.oracle(np.float64)
+    nl = o.neighbors("brute")
+    s = case.system(pkg, np.float64)
+    np.testing.assert_allclose(pkg.forces(s), o.forces(nl), rtol=1e-8, atol=1e-9)
+
+
+def test_exclusions_and_special_pairs(pkg):
+    # test/gpu_consistency.jl:339-405: 10 atoms, excluded (1,2),(2,3), special (1,3) [1-based]
+    rng = np.random.default_rng(4)
+    x = rng.random((10, 3)) * 1.2 + 0.4
+    case = S.Case(x, 6.0, lj=dict(cutoff=("distance", 2.0), weight_special=0.5), coul=dict(kind="plain", cutoff=("distance", 2.0), weight_special=0.8),
+                  r_list=2.5, sigma=np.full(10, 0.25), eps=np.full(10, 0.3), charge=rng.normal(size=10) * 0.4,
+                  excluded=[[0, 1], [1, 2]], special=[[0, 2]])
+    o = case.oracle(np.float64)
+    oi, oj, osp = o.neighbors("brute")
+    s = case.system(pkg, np.float64)
+    nl = pkg.find_neighbors(s)
+    keys = set(zip(nl.i.tolist(), nl.j.tolist()))
+    assert (0, 1) not in keys and (1, 2) not in keys and (0, 2) in keys
+    assert dict(zip(zip(nl.i.tolist(), nl.j.tolist()), nl.special.tolist()))[(0, 2)] == 1
+    np.testing.assert_allclose(pkg.forces(s), o.forces((oi, oj, osp)), rtol=1e-8, atol=1e-9)
+    # cache invalidation after changing the exceptions (test/gpu_consistency.jl:494-527)
+    case2 = S.Case(x, 6.0, lj=case.lj, coul=case.coul, r_list=2.5, sigma=case.sigma, eps=case.eps, charge=case.charge,
+                   excluded=[[0, 1], [1, 2], [3, 4]], special=[[0, 2]])
+    s.neighbor_finder = pkg.GPUNeighborFinder(dist_cutoff=2.5, excluded_pairs=case2.excluded, special_pairs=case2.special)
+    s._push_atoms()
+    o2 = case2.oracle(np.float64)
+    np.testing.assert_allclose(pkg.forces(s), o2.forces(o2.neighbors("brute")), rtol=1e-8, atol=1e-9)
+
+
+def test_buffer_reuse_after_moving_coords(pkg):
+    # test/gpu_consistency.jl:451-492
+    case = S.lj_fluid(12, dtype=np.float64)
+    s = case.system(pkg, np.float64)
+    pkg.forces(s)
+    rng = np.random.default_rng(8)
+    x2 = case.coords + rng.normal(size=case.coords.shape) * 0.05
+    x2 = x2 - np.floor(x2 / case.box) * case.box
+    s.coords[:] = x2
+    o = case.oracle(np.float64, coords=x2)
+    f_ref = o.forces(o.neighbors("cell"))
+    assert np.abs(pkg.forces(s, step_n=1) - f_ref).max() <= 1e-9 * np.abs(f_ref).max() + 1e-8
+
+
+def test_remove_cm_motion_and_kinetic_energy(pkg):
+    # test/gpu_consistency.jl:116-157
+    case = S.charged_fluid(10, dict(kind="rf", rc=1.0), dtype=np.float64)
+    rng = np.random.default_rng(2)
+    v = rng.normal(size=(case.n, 3)) + np.array([0.3, -0.2, 0.1])
+    s = case.system(pkg, np.float64, velocities=v)
+    o = case.oracle(np.float64, velocities=v)
+    assert pkg.kinetic_energy(s) == pytest.approx(o.kinetic_energy(), rel=1e-12)
+    pkg.remove_CM_motion(s)
+    o.remove_cm()
+    np.testing.assert_allclose(s.velocities, o.vel, rtol=0, atol=1e-12)
+    assert np.abs((s.velocities * case.mass[:, None]).sum(axis=0)).max() < 1e-9
+
+
+def test_sorted_order_is_a_permutation(pkg):
+    # reorder / reverse-reorder round trip (test/gpu_optimizations.jl:220-250)
+    import ctypes as C
+    case = S.lj_fluid(12, dtype=np.float32)
+    s = case.system(pkg, np.float32)
+    f1 = pkg.forces(s)
+    perm = np.empty(case.n, np.int32)
+    s._check(pkg.lib().mhip_export_order(s.engine(), perm.ctypes.data_as(C.c_void_p), case.n))
+    assert np.array_equal(np.sort(perm), np.arange(case.n))
+    assert not np.array_equal(perm, np.arange(case.n))   # the Hilbert sort really reordered the atoms
+    s.pull_state()
+    np.testing.assert_array_equal(s.coords, case.coords.astype(np.float32))   # state round-trips bit-exactly
+    assert np.array_equal(pkg.forces(s), f1)   # and forces are bit-reproducible (no atomics on the pair path)
+
+
+def test_velocity_verlet_fp64_matches_oracle(pkg):
+    case = S.charged_fluid(10, dict(kind="rf", rc=1.0), dtype=np.float64, with_exceptions=True)
+    o = case.oracle(np.float64)
+    o.vv_run(40, 0.0005, remove_cm_every=1)
+    s = case.system(pkg, np.float64)
+    pkg.simulate(s, pkg.VelocityVerlet(dt=0.0005), 40)
+    assert np.abs(s.coords - o.coords).max() < 1e-9      # reference bar 1e-10 nm vs OpenMM over 100 steps (protein.jl:289)
+    assert np.abs(s.velocities - o.vel).max() < 1e-7
+
+
+def test_velocity_verlet_fp32_lj_tracks_fp64_oracle(pkg):
+    # test/simulation.jl:625: mean |Δx| < 5e-4 nm after 100 steps at fp32
+    case = S.lj_fluid(12, dtype=np.float32)
+    o = case.oracle(np.float64)
+    o.vv_run(100, 0.002, remove_cm_every=1)
+    s = case.system(pkg, np.float32)
+    pkg.simulate(s, pkg.VelocityVerlet(dt=0.002), 100)
+    d = s.coords.astype(np.float64) - o.coords
+    d -= np.round(d / case.box) * case.box
+    assert np.abs(d).mean() < 5e-4
+    assert np.abs((s.velocities.astype(np.float64) * case.mass[:, None]).sum(axis=0)).max() < 1e-2
+
+
+def test_chunked_continuation_is_exact(pkg):
+    # test/simulation.jl:16-57: 10 steps == 3 + 3 + 4 with init_step 3, 6 — compared with exact ==
+    case = S.lj_fluid(10, dtype=np.float32)
+    a = case.system(pkg, np.float32)
+    pkg.simulate(a, pkg.VelocityVerlet(dt=0.002), 10)
+    b = case.system(pkg, np.float32)
+    pkg.simulate(b, pkg.VelocityVerlet(dt=0.002), 3)
+    pkg.simulate(b, pkg.VelocityVerlet(dt=0.002), 3, init_step=3)
+    pkg.simulate(b, pkg.VelocityVerlet(dt=0.002), 4, init_step=6)
+    assert np.array_equal(a.coords, b.coords) and np.array_equal(a.velocities, b.velocities)
+
+
+def test_nve_energy_conservation_short(pkg):
+    # test/energy_conservation.jl:13-77 scaled down: σ = 0.05 LJ gas, T = 1 K, dt = 1 fs, no CM removal
+    rng = np.random.default_rng(0)
+    n, box = 2000, 5.0
+    g = np.stack(np.meshgrid(*[np.arange(13)] * 3, indexing="ij"), -1).reshape(-1, 3)[:n] * (box / 13) + 0.1
+    x = g + rng.uniform(-0.05, 0.05, (n, 3))
+    v = rng.normal(size=(n, 3)) * math.sqrt(8.314462618e-3 * 1.0 / 40.0)
+    case = S.Case(x, box, lj=dict(cutoff=("shifted_force", 2.0)), r_list=2.3, velocities=v, sigma=np.full(n, 0.05), eps=np.full(n, 0.2), mass=np.full(n, 40.0))
+    s = case.system(pkg, np.float64)
+    e0 = pkg.total_energy(s)
+    es = []
+    for k in range(5):
+        pkg.simulate(s, pkg.VelocityVerlet(dt=0.001, remove_CM_motion=0), 400, init_step=400 * k)
+        es.append(pkg.total_energy(s))
+    assert max(abs(e - e0) for e in es) < 5e-4
+
+
+def test_bonded_terms_match_oracle(pkg):
+    # a synthetic 60-bead chain with bonds, angles, torsions (2 Fourier terms each) and Ewald exclusions
+    rng = np.random.default_rng(6)
+    n = 60
+    x = np.cumsum(rng.normal(size=(n, 3)) * 0.09 + np.array([0.08, 0.02, 0.01]), axis=0) + 3.0
+    idx = np.arange(n)
+    bonds = dict(i=idx[:-1], j=idx[1:], k=np.full(n - 1, 250000.0), r0=np.full(n - 1, 0.15))
+    angles = dict(i=idx[:-2], j=idx[1:-1], k=idx[2:], kth=np.full(n - 2, 400.0), th0=np.full(n - 2, 1.9))
+    ti = np.repeat(idx[:-3], 2)
+    tors = dict(i=ti, j=ti + 1, k=ti + 2, l=ti + 3, periodicity=np.tile([1, 3], n - 3), phase=np.tile([0.0, math.pi], n - 3), k0=np.tile([2.5, 0.7], n - 3))
+    ewx = np.concatenate([np.stack([idx[:-1], idx[1:]], 1), np.stack([idx[:-2], idx[2:]], 1)])
+    q = rng.normal(size=n) * 0.4
+    case = S.Case(x, 8.0, coul=dict(kind="ewald", rc=1.0), r_list=1.2, charge=q, excluded=ewx, bonds=bonds, angles=angles, torsions=tors, ewald_excl=ewx)
+    for dtype, rtol in ((np.float64, 1e-9), (np.float32, 3e-4)):
+        o = case.oracle(np.float64)
+        f_ref = o.forces(None, pairwise=False, specific=True)
+        e_ref = o.potential_energy(None, pairwise=False, specific=True)
+        s = case.system(pkg, dtype)
+        f = pkg.forces(s, pairwise=False)
+        assert np.abs(f - f_ref).max() <= rtol * np.abs(f_ref).max()
+        assert pkg.potential_energy(s, pairwise=False) == pytest.approx(e_ref, rel=max(rtol, 1e-9))
+
+
+def test_full_size_256k_lj_against_oracle(pkg):
+    """BASELINE.json configs[1]: 262 144-atom LJ fluid, fp32 — direct comparison with the fp64 oracle plus the
+    size-independent properties (Newton's third law ΣF = 0, full list symmetric = 2 × half list)."""
+    case = S.lj_fluid(64, dtype=np.float32)
+    tol, o, nl = S.fp32_force_tolerance(case)
+    f_ref = o.forces(nl, nthreads=8)
+    s = case.system(pkg, np.float32)
+    f = pkg.forces(s).astype(np.float64)
+    err = np.linalg.norm(f - f_ref, axis=1)
+    assert np.all(err <= tol), f"worst err {err.max():.3e} tol {tol[err.argmax()]:.3e}"
+    assert np.abs(f.sum(axis=0)).max() < 1e-3 * np.abs(f).max()
+    st = s.stats()
+    o32 = case.oracle(np.float32)
+    n_half = len(o32.neighbors("cell", nthreads=8)[0])
+    assert st["n_pairs_full"] == 2 * n_half
+    assert st["minimg_mode"] == 0
+    e_ref = o.potential_energy(nl)
+    assert pkg.potential_energy(s) == pytest.approx(e_ref, rel=2e-5)
