@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py — ns/day (and Matom-steps/s) of the MI355X nonbonded engine on BASELINE.json's workloads.
+
+    python bench.py --gpus N --steps K --warmup W [--workload lj1m|lj256k|6mrr_pme|6mrr_rf64]
+
+One "step" = one velocity-Verlet MD step (forces + integration + amortised neighbour rebuild) of the whole
+system, state resident in HBM.  N = 1: the whole box on one GPU.  N > 1 (launched by torch.distributed.run,
+one rank per GPU): the same box cut into spatial bricks with RCCL ghost-coordinate exchange — total work is
+fixed, so scaling is "strong".  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def make_case(workload):
+    from tests import systems as S
+    if workload == "lj1m":
+        return S.lj_fluid(100, seed=4, dtype=np.float32), np.float32, 0.002
+    if workload == "lj256k":
+        return S.lj_fluid(64, seed=2, dtype=np.float32), np.float32, 0.002
+    if workload in ("6mrr_pme", "6mrr_rf64"):
+        from tests import golden6mrr
+        dtype = np.float32 if workload == "6mrr_pme" else np.float64
+        return golden6mrr.case("ewald" if workload == "6mrr_pme" else "rf", dtype=dtype, bonded=True), dtype, 0.0005
+    raise SystemExit(f"unknown workload {workload}")
+
+
+def cpu_baseline(case, dtype, dt, budget_s=20.0):
+    """The Molly-algorithm CPU restatement (oracle, kind "port") timed on this host's cores on a bounded
+    sample of the same workload: same atoms, same parameters, a handful of steps."""
+    from oracle import pyoracle as orc
+    orc.build(native=True)
+    cores = os.cpu_count() or 1
+    nthreads = min(cores, 64)
+    o = case.oracle(dtype)
+    o.native = True
+    specific = case.bonds is not None
+    t0 = time.perf_counter()
+    o.vv_run(1, dt, nthreads=nthreads, specific=specific)   # one step incl. the initial neighbour build + force pass
+    t1 = time.perf_counter() - t0
+    # steady-state sample: as many steps as fit the budget, at least one rebuild interval if affordable
+    n = int(max(2, min(20, budget_s / max(t1 / 2.0, 1e-3))))
+    t0 = time.perf_counter()
+    o.vv_run(n, dt, first_step=1, nthreads=nthreads, specific=specific)
+    t = time.perf_counter() - t0
+    steps_s = n / t
+    return {"value": steps_s * dt * 1e3 * 86400 * 1e-6, "unit": "ns/day", "cores": nthreads, "kind": "port",
+            "matom_steps_per_s": steps_s * case.n / 1e6,
+            "sample": f"{n} velocity-Verlet steps of the full {case.n}-atom system (threaded pair loop of src/force.jl:886-969 + "
+                      f"cell-list rebuild every {case.rebuild_every} steps), {nthreads} threads, -O3 -march=native"}
+
+
+def load_traffic(workload):
+    """HBM bytes per force-kernel launch from the rocprofv3 PMC passes committed under profiles/ (collected by
+    profiles/collect.sh: separate FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE×2 gfx950 correction)."""
+    p = os.path.join(ROOT, "profiles", f"traffic_{workload}.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get("hbm_bytes_per_force_launch")
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=500)
+    ap.add_argument("--workload", default=os.environ.get("MOLLYHIP_BENCH_WORKLOAD", "lj1m"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=200, help="steps of the separate hipEvent-timed pass")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N …")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+
+    import molly_loader
+    m = molly_loader.load()
+    if m.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+
+    case, dtype, dt = make_case(args.workload)
+    if world > 1:
+        from molly_jl_amd import domain   # spatial decomposition + RCCL halo exchange
+        result = domain.bench_distributed(m, case, dtype, dt, args, rank, local_rank, world)
+        if rank != 0:
+            return
+        ms_per_step, st, extra = result
+    else:
+        import ctypes as C
+        L = m.lib()
+        s = case.system(m, dtype)
+        s.push_state(velocities=True)
+        ctx = s.engine()
+        s._check(L.mhip_vv_run(ctx, 0, args.warmup, dt, 1))          # untimed warm-up (includes melting the lattice)
+        s._check(L.mhip_synchronize(ctx))
+        t0 = time.perf_counter()
+        s._check(L.mhip_vv_run(ctx, args.warmup, args.steps, dt, 1))  # timed: exactly K steps; returns after a stream sync
+        s._check(L.mhip_synchronize(ctx))
+        ms_per_step = (time.perf_counter() - t0) * 1e3 / args.steps
+        # separate pass with hipEvent stage timers on the engine's stream (never mixed into the timed region)
+        s._check(L.mhip_set_profiling(ctx, 1))
+        s._check(L.mhip_vv_run(ctx, args.warmup + args.steps, args.profile_steps, dt, 1))
+        st = s.stats()
+        s._check(L.mhip_set_profiling(ctx, 0))
+        s._check(L.mhip_check_finite(ctx))
+        extra = {}
+
+    steps_s = 1e3 / ms_per_step
+    ns_day = steps_s * (dt * 1e3) * 86400 * 1e-6        # dt [ps] → fs
+    n_atoms = case.n
+    force_ms = st["prof_ms"][0] / max(st["prof_calls"][0], 1)
+    fbytes = st["force_pass_bytes"]
+    achieved = fbytes / (force_ms * 1e-3) / 1e9 if force_ms > 0 else None
+    roofline = {"bound": "hbm", "kernel": "k_forces", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": load_traffic(args.workload),
+                "algorithmic_bytes_per_launch": fbytes, "avg_launch_ms": force_ms,
+                "step_bytes": st["algorithmic_bytes_step"],
+                "step_frac": st["algorithmic_bytes_step"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "stage_ms_per_step": {"forces": force_ms, "build_kernel": st["prof_ms"][1] / max(args.profile_steps, 1),
+                                      "integrator": st["prof_ms"][2] / max(args.profile_steps, 1),
+                                      "sort_permute": st["prof_ms"][3] / max(args.profile_steps, 1)}}
+    line = {
+        "metric": "ns_per_day", "value": ns_day, "unit": "ns/day", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32" if dtype == np.float32 else "f64", "data": "synthetic",
+        "matom_steps_per_s": steps_s * n_atoms / 1e6,
+        "config": {"workload": {"lj1m": "1M-atom LJ fluid (argon, rho=21.1/nm3), cubic PBC, DistanceCutoff 1.0 nm, r_list 1.2 nm, dt 2 fs, VelocityVerlet, remove_CM_motion=1",
+                                "lj256k": "256k-atom LJ fluid, DistanceCutoff 1.0 nm, cell-list neighbours, Float32",
+                                "6mrr_pme": "6mrr (15954 atoms) Amber99SB-ILDN/TIP3P, LJ + Ewald direct-space (PME reciprocal not in the timed path) + bonded + EwaldExclusion, Float32, dt 0.5 fs",
+                                "6mrr_rf64": "6mrr reaction-field Coulomb + LJ + bonded, Float64, dt 0.5 fs"}[args.workload],
+                   "name": args.workload, "n_atoms": n_atoms, "dt_fs": dt * 1e3, "rebuild_every": case.rebuild_every,
+                   "parallelism": "single domain" if world == 1 else extra.get("parallelism"),
+                   "block_atoms": st["block_atoms"], "j_split": st["j_split"], "pairs_half_list": st["n_pairs_full"] // 2},
+        "roofline": roofline,
+    }
+    line.update({k: v for k, v in extra.items() if k != "parallelism"})
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(case, dtype, dt)
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

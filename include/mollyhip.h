@@ -123,6 +123,11 @@ typedef struct mhip_stats {
     double  last_rebuild_ms;       /* host wall time of the last rebuild                          */
     int64_t lds_bytes;             /* dynamic LDS of the force kernel                             */
     int64_t algorithmic_bytes_step;/* N(R_p+22w)+4L, SURVEY §8(d)                                 */
+    int64_t force_pass_bytes;      /* N(R_p+3w)+4L: algorithmic bytes of ONE force-kernel launch   */
+    /* HIP-event timings, filled while profiling is on (mhip_set_profiling):                        */
+    /* stage 0 pair-force kernel, 1 tile/list build kernel, 2 integrator kernels, 3 sort+permute    */
+    double  prof_ms[4];
+    int64_t prof_calls[4];
 } mhip_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
@@ -132,6 +137,9 @@ const char* mhip_last_error(const mhip_ctx* ctx);            /* ctx may be NULL 
 int32_t     mhip_device_count(int32_t* n_out);               /* visible HIP devices              */
 int32_t     mhip_set_stream(mhip_ctx* ctx, void* hip_stream);/* run on the caller's hipStream_t  */
 int32_t     mhip_synchronize(mhip_ctx* ctx);
+/* per-stage hipEvent timers on the context's stream (≙ benchmark/gpu_profile_utils.jl:12-18); enabling
+ * resets the accumulated numbers reported by mhip_get_stats */
+int32_t     mhip_set_profiling(mhip_ctx* ctx, int32_t enable);
 
 /* ---- topology / parameters ----------------------------------------------------------------- */
 /* owned atoms come first, ghosts after them; n_owned + n_ghost <= cfg.n_atoms.  Default:

@@ -43,10 +43,13 @@ class Stats(C.Structure):
                 ("n_force_calls", C.c_int64), ("n_pairs_full", C.c_int64), ("n_list_slots", C.c_int64),
                 ("n_blocks", C.c_int64), ("tile_atoms_total", C.c_int64), ("block_atoms", C.c_int32),
                 ("j_split", C.c_int32), ("minimg_mode", C.c_int32), ("max_tile_atoms", C.c_int32),
-                ("last_rebuild_ms", C.c_double), ("lds_bytes", C.c_int64), ("algorithmic_bytes_step", C.c_int64)]
+                ("last_rebuild_ms", C.c_double), ("lds_bytes", C.c_int64), ("algorithmic_bytes_step", C.c_int64),
+                ("force_pass_bytes", C.c_int64), ("prof_ms", C.c_double * 4), ("prof_calls", C.c_int64 * 4)]
 
     def as_dict(self):
-        return {name: getattr(self, name) for name, _ in self._fields_}
+        d = {name: getattr(self, name) for name, _ in self._fields_}
+        d["prof_ms"] = list(self.prof_ms); d["prof_calls"] = list(self.prof_calls)
+        return d
 
 
 # every entry point of include/mollyhip.h: name -> (restype, argtypes)
@@ -58,6 +61,7 @@ SIGNATURES = {
     "mhip_device_count": (_I32, [C.POINTER(_I32)]),
     "mhip_set_stream": (_I32, [_P, _P]),
     "mhip_synchronize": (_I32, [_P]),
+    "mhip_set_profiling": (_I32, [_P, _I32]),
     "mhip_set_atom_counts": (_I32, [_P, _I64, _I64]),
     "mhip_set_atoms": (_I32, [_P, _P, _P, _P, _P, _P, _I32]),
     "mhip_set_exceptions": (_I32, [_P, _P, _P, _I64, _P, _P, _I64]),

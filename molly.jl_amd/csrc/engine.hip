@@ -30,6 +30,7 @@ struct EngineBase {
     virtual ~EngineBase() {}
     virtual void set_stream(void* s) = 0;
     virtual void synchronize() = 0;
+    virtual void set_profiling(bool) = 0;
     virtual void set_atom_counts(int64_t, int64_t) = 0;
     virtual void set_atoms(const void*, const void*, const void*, const void*, const void*, int) = 0;
     virtual void set_exceptions(const int32_t*, const int32_t*, int64_t, const int32_t*, const int32_t*, int64_t) = 0;
@@ -58,6 +59,35 @@ struct EngineBase {
     virtual void scatter_coords(int64_t, int64_t, const void*) = 0;
     virtual void cm_momentum(double*) = 0;
     virtual void shift_velocities(const double*) = 0;
+};
+
+// hipEvent stage timers (only active while profiling is on)
+struct Prof {
+    static constexpr int NS = 4;
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[NS];
+    size_t used[NS] = {0, 0, 0, 0};
+    double ms[NS] = {0, 0, 0, 0};
+    int64_t calls[NS] = {0, 0, 0, 0};
+    void begin(int st, hipStream_t s) {
+        if (!on) return;
+        if (used[st] == ev[st].size()) { hipEvent_t a, b; MHIP_HIP(hipEventCreate(&a)); MHIP_HIP(hipEventCreate(&b)); ev[st].push_back({a, b}); }
+        MHIP_HIP(hipEventRecord(ev[st][used[st]].first, s));
+    }
+    void end(int st, hipStream_t s) {
+        if (!on) return;
+        MHIP_HIP(hipEventRecord(ev[st][used[st]].second, s));
+        if (++used[st] >= 8192) resolve(s);
+    }
+    void resolve(hipStream_t s) {
+        MHIP_HIP(hipStreamSynchronize(s));
+        for (int st = 0; st < NS; ++st) {
+            for (size_t k = 0; k < used[st]; ++k) { float t = 0; MHIP_HIP(hipEventElapsedTime(&t, ev[st][k].first, ev[st][k].second)); ms[st] += t; ++calls[st]; }
+            used[st] = 0;
+        }
+    }
+    void reset() { for (int st = 0; st < NS; ++st) { used[st] = 0; ms[st] = 0; calls[st] = 0; } }
+    void release() { for (int st = 0; st < NS; ++st) { for (auto& e : ev[st]) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); } ev[st].clear(); } }
 };
 
 static int env_int(const char* name, int dflt) { const char* v = std::getenv(name); return v && *v ? std::atoi(v) : dflt; }
@@ -98,6 +128,7 @@ template <class T> class Engine final : public EngineBase {
     int64_t last_build_step = std::numeric_limits<int64_t>::min();
     int64_t n_rebuilds = 0, n_force_calls = 0; double last_rebuild_ms = 0;
     size_t lds_force = 0;
+    Prof prof;
 
   public:
     explicit Engine(const mhip_config& c) : cfg(c) {
@@ -133,6 +164,7 @@ template <class T> class Engine final : public EngineBase {
         inv.release(); key_in.release(); key_out.release(); cell_rank.release(); idx_in.release(); perm.release(); cell_cnt.release(); cell_start.release(); cub_tmp.release();
         ex_start.release(); ex_list.release(); sp_start.release(); sp_list.release(); tile_idx.release(); tile_cnt.release(); wave_rows.release(); nbr.release(); blk_center.release();
         flags.release(); red_part.release(); red_out.release(); vcm.release(); stage_a.release(); stage_b.release(); stage_i.release(); bonded.release();
+        prof.release();
         if (h_flags) (void)hipHostFree(h_flags);
         if (h_red) (void)hipHostFree(h_red);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -251,9 +283,10 @@ template <class T> class Engine final : public EngineBase {
         auto t0 = std::chrono::steady_clock::now();
         const int o = cur, n = 1 - cur;
         const int ncell2 = 2 * G.ncell + 1;
+        prof.begin(3, stream);
         MHIP_HIP(hipMemsetAsync(cell_cnt.p, 0, (size_t)ncell2 * sizeof(int32_t), stream));
         const int nb256 = cdiv(n_tot, 256);
-        hipLaunchKernelGGL(k_cell_keys<T>, dim3(nb256), dim3(256), 0, stream, n_tot, n_owned, (const T4*)pos[o].p, (const int32_t*)orig[o].p,
+        hipLaunchKernelGGL(k_cell_keys<T>, dim3(nb256), dim3(256), 0, stream, n_tot, n_owned, (const T4*)pos[o].p, (const int32_t*)inv.p,
                            (const uint32_t*)cell_rank.p, key_in.p, idx_in.p, cell_cnt.p, G);
         size_t tb = cub_tmp.n;
         MHIP_HIP(sort_pairs_u32(cub_tmp.p, tb, key_in.p, key_out.p, idx_in.p, perm.p, (int)n_tot, ilog2(2 * G.ncell + 1) + 1 > 32 ? 32 : ilog2(2 * G.ncell + 1) + 1, stream));
@@ -261,6 +294,7 @@ template <class T> class Engine final : public EngineBase {
         MHIP_HIP(exclusive_sum_i32(cub_tmp.p, tb, cell_cnt.p, cell_start.p, ncell2, stream));
         hipLaunchKernelGGL(k_permute<T>, dim3(nb256), dim3(256), 0, stream, n_tot, (const int32_t*)perm.p, (const T4*)pos[o].p, (const T4*)vel[o].p,
                            (const T4*)frc[o].p, (const T2*)lj[o].p, (const int32_t*)orig[o].p, pos[n].p, vel[n].p, frc[n].p, lj[n].p, orig[n].p, inv.p);
+        prof.end(3, stream);
         cur = n;
         if (n_ghost > 0 && has_exc) throw ApiError{MHIP_ERR_UNSUPPORTED, "exclusion lists with ghost atoms are not supported"};
 
@@ -281,7 +315,9 @@ template <class T> class Engine final : public EngineBase {
             A.tile_idx = tile_idx.p; A.tile_cnt = tile_cnt.p; A.nbr = nbr.p; A.wave_rows = wave_rows.p; A.blk_center = blk_center.p; A.flags = flags.p;
             A.margin = G.no_list ? T(0) : G.r_list * T(1e-3);
             set_lds_limit(k_build<T>, lds);
+            prof.begin(1, stream);
             hipLaunchKernelGGL(k_build<T>, dim3(n_blocks), dim3(BI), lds, stream, A);
+            prof.end(1, stream);
             MHIP_HIP(hipGetLastError());
             MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
             MHIP_HIP(hipStreamSynchronize(stream));
@@ -339,11 +375,13 @@ template <class T> class Engine final : public EngineBase {
         A.n_blocks = n_blocks; A.blocks_per_xcd = cdiv(n_blocks, 8);
         A.pos = pos[cur].p; A.lj = lj[cur].p; A.tile_idx = tile_idx.p; A.tile_cnt = tile_cnt.p; A.nbr = nbr.p; A.wave_rows = wave_rows.p;
         A.blk_center = blk_center.p; A.frc = frc[cur].p; A.pe_part = red_part.p;
+        prof.begin(0, stream);
         switch (ljm) {
         case LJ_OFF: launch_forces_l<LJ_OFF>(A, energy); break;
         case LJ_DIST: launch_forces_l<LJ_DIST>(A, energy); break;
         default: launch_forces_l<LJ_GENERIC>(A, energy); break;
         }
+        prof.end(0, stream);
         MHIP_HIP(hipGetLastError());
         ++n_force_calls;
     }
@@ -384,6 +422,7 @@ template <class T> class Engine final : public EngineBase {
         stream = (hipStream_t)s;
     }
     void synchronize() override { MHIP_HIP(hipStreamSynchronize(stream)); }
+    void set_profiling(bool on) override { prof.resolve(stream); if (on) prof.reset(); prof.on = on; }
 
     void set_atom_counts(int64_t no, int64_t ng) override {
         if (no <= 0 || ng < 0 || no + ng > cap) throw ApiError{MHIP_ERR_INVALID, "atom counts exceed the context capacity"};
@@ -554,13 +593,16 @@ template <class T> class Engine final : public EngineBase {
     }
     void vv_stage1(double dt) override {
         if (!frc_valid) throw ApiError{MHIP_ERR_STATE, "vv_stage1 needs forces from vv_init / vv_stage2"};
+        prof.begin(2, stream);
         hipLaunchKernelGGL(k_vv1<T>, dim3(cdiv(n_owned, 256)), dim3(256), 0, stream, n_owned, pos[cur].p, vel[cur].p, (const T4*)frc[cur].p, T(dt), T(dt) / T(2),
                            cm_pending ? (const T*)vcm.p : (const T*)nullptr, G);
+        prof.end(2, stream);
         cm_pending = false;
     }
     void stage2_impl(double dt, bool cm) {
         step_forces();
         const int nb = cdiv(n_owned, 256);
+        prof.begin(2, stream);
         if (cm) {
             red_part.reserve(4 * (size_t)nb + 8);
             hipLaunchKernelGGL((k_vv2<T, true>), dim3(nb), dim3(256), 0, stream, n_owned, vel[cur].p, (const T4*)frc[cur].p, T(dt) / T(2), red_part.p);
@@ -569,6 +611,7 @@ template <class T> class Engine final : public EngineBase {
         } else {
             hipLaunchKernelGGL((k_vv2<T, false>), dim3(nb), dim3(256), 0, stream, n_owned, vel[cur].p, (const T4*)frc[cur].p, T(dt) / T(2), (double*)nullptr);
         }
+        prof.end(2, stream);
     }
     void vv_stage2(int64_t step_n, double dt) override {
         (void)step_n;
@@ -637,6 +680,9 @@ template <class T> class Engine final : public EngineBase {
         }
         const int64_t w = sizeof(T), Rp = (coulm != MHIP_COUL_NONE ? 6 : 4) * w;
         s->algorithmic_bytes_step = n_owned * (Rp + 22 * w) + 4 * (s->n_pairs_full / 2);   // N(R_p + 22w) + 4L
+        s->force_pass_bytes = n_owned * (Rp + 3 * w) + 4 * (s->n_pairs_full / 2);          // force pass: N(R_p + 3w) + 4L
+        prof.resolve(stream);
+        for (int k = 0; k < Prof::NS; ++k) { s->prof_ms[k] = prof.ms[k]; s->prof_calls[k] = prof.calls[k]; }
     }
 
     void gather_coords(const int32_t* idx_dev, const void* shift_dev, int64_t n, void* out_dev) override {
@@ -701,6 +747,7 @@ const char* mhip_last_error(const mhip_ctx* ctx) { return (ctx && ctx->e) ? ctx-
 
 int32_t mhip_set_stream(mhip_ctx* ctx, void* s) { NEED_CTX(); return guard(ctx, [&] { ctx->e->set_stream(s); }); }
 int32_t mhip_synchronize(mhip_ctx* ctx) { NEED_CTX(); return guard(ctx, [&] { ctx->e->synchronize(); }); }
+int32_t mhip_set_profiling(mhip_ctx* ctx, int32_t on) { NEED_CTX(); return guard(ctx, [&] { ctx->e->set_profiling(on != 0); }); }
 int32_t mhip_set_atom_counts(mhip_ctx* ctx, int64_t no, int64_t ng) { NEED_CTX(); return guard(ctx, [&] { ctx->e->set_atom_counts(no, ng); }); }
 int32_t mhip_set_atoms(mhip_ctx* ctx, const void* q, const void* s, const void* e, const void* m, const void* l, int32_t mk) {
     NEED_CTX(); return guard(ctx, [&] { ctx->e->set_atoms(q, s, e, m, l, mk); });

@@ -86,17 +86,21 @@ __global__ void k_export_forces(int64_t n_owned, const int32_t* __restrict__ ori
 }
 
 // ---------------------------------------------------------------------------------------------------
-// rebuild step 1: sort key = Hilbert rank of the atom's cell (ghosts after all owned atoms) + histogram
+// rebuild step 1: sort key = Hilbert rank of the atom's cell (ghosts after all owned atoms) + histogram.
+// Threads run over CALLER indices so that the stable radix sort orders the atoms of one cell by caller
+// index: the sorted order — and with it every summation order — is a function of the coordinates alone,
+// not of the history of earlier re-sorts.
 template <class T>
-__global__ void k_cell_keys(int64_t n_tot, int64_t n_owned, const typename Vec<T>::T4* __restrict__ pos, const int32_t* __restrict__ orig,
+__global__ void k_cell_keys(int64_t n_tot, int64_t n_owned, const typename Vec<T>::T4* __restrict__ pos, const int32_t* __restrict__ inv,
                             const uint32_t* __restrict__ cell_rank, uint32_t* key, int32_t* idx, int32_t* cell_cnt, GridP<T> G) {
-    int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (s >= n_tot) return;
+    int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (o >= n_tot) return;
+    int s = inv[o];
     auto p = pos[s];
     int cx = cell_coord(p.x, 0, G), cy = cell_coord(p.y, 1, G), cz = cell_coord(p.z, 2, G);
     uint32_t k = cell_rank[(cz * G.nc[1] + cy) * G.nc[0] + cx];
-    if (orig[s] >= n_owned) k += (uint32_t)G.ncell;
-    key[s] = k; idx[s] = (int32_t)s;
+    if (o >= n_owned) k += (uint32_t)G.ncell;
+    key[o] = k; idx[o] = s;
     atomicAdd(&cell_cnt[k], 1);
 }
 

@@ -163,10 +163,14 @@ def sorted_pairs(i, j, sp):
     return lo[order], hi[order], np.asarray(sp, dtype=np.uint8)[order]
 
 
-def fp32_force_tolerance(case, coords=None, rel=2e-5):
+def fp32_force_tolerance(case, coords=None, rel=4e-5):
     """Per-atom tolerance for fp32 forces against the fp64 oracle: rel·Σ_j‖f_ij‖ plus the force jump of
-    any pair sitting within 2e-6 (relative) of a hard cutoff, where fp32 may legitimately flip `r <= rc`."""
+    any pair sitting within 2e-6 (relative) of a hard cutoff, where fp32 may legitimately flip `r <= rc`.
+    Calibration: the reference's own arithmetic evaluated in fp32 (oracle float instantiation, correctly
+    rounded libm) measures max 2.9e-5·Σ_j‖f_ij‖ and relative RMS 4.9e-6 against fp64 on the 262 144-atom
+    LJ fluid; the bar for the HIP path is max 4e-5 and relative RMS 1e-5."""
     o = case.oracle(np.float64, coords=coords)
     nl = o.neighbors("cell") if math.isfinite(case.r_list) else None
     scale, jump = o.force_scale(nl)
+    o.pair_force_scale = scale   # Σ_j‖f_ij‖ per atom, kept for property checks
     return rel * scale + 1.01 * jump + 1e-6, o, nl
