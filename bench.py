@@ -151,6 +151,8 @@ def main():
                    "parallelism": "single domain" if world == 1 else extra.get("parallelism"),
                    "block_atoms": st["block_atoms"], "j_split": st["j_split"], "pairs_half_list": st["n_pairs_full"] // 2},
         "roofline": roofline,
+        "engine": {k: st[k] for k in ("n_blocks", "block_atoms", "j_split", "max_tile_atoms", "tile_atoms_total", "lds_bytes",
+                                      "n_list_slots", "n_pairs_full", "minimg_mode", "n_rebuilds", "last_rebuild_ms")},
     }
     line.update({k: v for k, v in extra.items() if k != "parallelism"})
     if world == 1 and not args.no_cpu_baseline:

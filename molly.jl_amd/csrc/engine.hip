@@ -113,7 +113,8 @@ template <class T> class Engine final : public EngineBase {
     // exceptions (CSR over caller indices)
     DBuf<int32_t> ex_start, ex_list, sp_start, sp_list; bool has_exc = false;
     // blocks
-    int BI = 256, JS = 1, n_blocks = 0, T_cap = 0, R_cap = 0, max_tile = 0, max_rows = 0;
+    int BI = 256, JS = 1, n_blocks = 0, T_cap = 0, R_cap = 0, C_cap = 0, max_tile = 0, max_rows = 0;
+    int ljm_base = LJ_OFF;   // LJ mode implied by the interaction; ljm may be upgraded to the uniform fast path
     DBuf<int32_t> tile_idx, tile_cnt, wave_rows; DBuf<uint2> nbr; DBuf<T4> blk_center;
     DBuf<int32_t> flags; int32_t* h_flags = nullptr;
     int64_t total_rows = 0;
@@ -187,6 +188,7 @@ template <class T> class Engine final : public EngineBase {
             else { I.krf = (T(1) / rc3) * (e - T(1)) / (T(2) * e + T(1)); I.crf = (T(1) / rc) * (T(3) * e) / (T(2) * e + T(1)); }
         }
         ljm = !p.lj_enabled ? LJ_OFF : (p.lj_cutoff_kind == MHIP_CUTOFF_DISTANCE ? LJ_DIST : LJ_GENERIC);
+        ljm_base = ljm;
         coulm = p.coul_kind;
         if ((p.lj_enabled && p.lj_cutoff_kind != MHIP_CUTOFF_NONE && !(p.lj_rc > 0)) ||
             (p.coul_kind >= MHIP_COUL_REACTION_FIELD && !(p.coul_rc > 0)))
@@ -219,11 +221,14 @@ template <class T> class Engine final : public EngineBase {
 
     static int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
 
-    size_t build_lds_bytes(int tcap, int bi) const {
-        return (size_t)tcap * (sizeof(T4) + 4) + (2 * MAX_BOX_CELLS + 1) * 4 + std::max<size_t>(6 * (size_t)bi * sizeof(T), (size_t)bi * 4) + 64;
+    size_t build_lds_bytes(int tcap, int bi, int ccap) const {
+        // tile (coords + slot) | max(cell tables, per-wave candidate bit masks) | scan scratch
+        // tile (coords + slot) | cell tables | scan scratch
+        return (size_t)tcap * (sizeof(T4) + 4) + (2 * (size_t)ccap + 2) * 4 + 8 + (size_t)bi * 4 + 64;
     }
     size_t force_lds_bytes(int tlds) const {
-        size_t tile = (size_t)(tlds + 1) * (sizeof(T4) + (ljm != LJ_OFF ? sizeof(T2) : 0));
+        const bool per_atom_lj = (ljm == LJ_DIST || ljm == LJ_GENERIC);
+        size_t tile = (size_t)(tlds + 1) * (sizeof(T4) + (per_atom_lj ? sizeof(T2) : 0));
         size_t red = (size_t)JS * 4 * BI * sizeof(T);
         return std::max(std::max(tile, red), (size_t)BI * sizeof(double)) + 32;
     }
@@ -245,15 +250,18 @@ template <class T> class Engine final : public EngineBase {
         n_blocks = cdiv(n_owned, BI);
         double vol = 1; for (int d = 0; d < 3; ++d) vol *= cfg.box[d];
         double rho = (double)n_tot / vol;
-        if (G.no_list) { T_cap = (int)n_tot + 8; R_cap = cdiv(n_tot, 4) + 2; }
+        if (G.no_list) { T_cap = (int)n_tot + 8; R_cap = cdiv(n_tot, 4) + 2; C_cap = 8; }
         else {
             double r = cfg.r_list * 1.001, a = std::cbrt(BI / rho);
             double v_tile = a * a * a + 6 * a * a * r + 3 * M_PI * a * r * r + 4.0 / 3.0 * M_PI * r * r * r;
             T_cap = (int)std::min<double>(1.4 * rho * v_tile + 64, (double)n_tot + 8);
             R_cap = (int)std::min<double>(1.5 * rho * 4.0 / 3.0 * M_PI * r * r * r / 4 + 8, n_tot / 4.0 + 2);
+            double cells = 1;
+            for (int d = 0; d < 3; ++d) cells *= std::min<double>(G.nc[d], (1.3 * a + 2 * r) / (cfg.box[d] / G.nc[d]) + 2);
+            C_cap = (int)std::min<double>(cells * 1.2 + 8, MAX_BOX_CELLS);
         }
-        T_cap = std::max(T_cap, 16); R_cap = std::max(R_cap, 2);
-        T_cap = std::min(T_cap, TILE_SLOT_MAX - 1);
+        T_cap = std::max(T_cap, 16); R_cap = std::max(R_cap, 2); C_cap = std::max(C_cap, 8);
+        T_cap = std::min((T_cap + 3) & ~3, (TILE_SLOT_MAX - 1) & ~3);   // multiple of 4: keeps the LDS carve-up 8-byte aligned
     }
 
     template <class K> void set_lds_limit(K kern, size_t bytes) {
@@ -300,7 +308,7 @@ template <class T> class Engine final : public EngineBase {
 
         for (int attempt = 0; attempt < 12; ++attempt) {
             n_blocks = cdiv(n_owned, BI);
-            size_t lds = build_lds_bytes(T_cap, BI);
+            size_t lds = build_lds_bytes(T_cap, BI, C_cap);
             if (lds > (size_t)MAX_LDS_BYTES) {
                 if (BI > 64) { BI /= 2; JS = std::min(JS * 2, 1024 / BI); estimate_capacities(); continue; }
                 throw ApiError{MHIP_ERR_CAPACITY, "neighbourhood tile of one 64-atom block does not fit the 160 KiB LDS (r_list too large for this density)"};
@@ -309,14 +317,16 @@ template <class T> class Engine final : public EngineBase {
             nbr.reserve((size_t)n_blocks * R_cap * BI); blk_center.reserve(n_blocks);
             MHIP_HIP(hipMemsetAsync(flags.p, 0, N_FLAGS * sizeof(int32_t), stream));
             BuildArgs<T> A;
-            A.G = G; A.n_owned = n_owned; A.n_tot = n_tot; A.BI = BI; A.T_cap = T_cap; A.R_cap = R_cap;
+            A.G = G; A.n_owned = n_owned; A.n_tot = n_tot; A.BI = BI; A.T_cap = T_cap; A.R_cap = R_cap; A.C_cap = C_cap;
             A.pos = pos[cur].p; A.orig = orig[cur].p; A.cell_start = cell_start.p; A.cell_rank = cell_rank.p;
             A.ex_start = has_exc ? ex_start.p : nullptr; A.ex_list = ex_list.p; A.sp_start = sp_start.p; A.sp_list = sp_list.p;
             A.tile_idx = tile_idx.p; A.tile_cnt = tile_cnt.p; A.nbr = nbr.p; A.wave_rows = wave_rows.p; A.blk_center = blk_center.p; A.flags = flags.p;
             A.margin = G.no_list ? T(0) : G.r_list * T(1e-3);
+            A.debug = env_int("MOLLYHIP_BUILD_DEBUG", 0);
             set_lds_limit(k_build<T>, lds);
             prof.begin(1, stream);
             hipLaunchKernelGGL(k_build<T>, dim3(n_blocks), dim3(BI), lds, stream, A);
+            hipLaunchKernelGGL(k_build_summary, dim3(1), dim3(256), 0, stream, n_blocks, n_blocks * (BI / WAVE), R_cap, (const int32_t*)tile_cnt.p, wave_rows.p, flags.p);
             prof.end(1, stream);
             MHIP_HIP(hipGetLastError());
             MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
@@ -328,10 +338,11 @@ template <class T> class Engine final : public EngineBase {
                 throw ApiError{MHIP_ERR_CAPACITY, "more than 32766 atoms within r_list of one 64-atom block"};
             }
             if (ovf & OVF_BOXCELLS) {
+                if (h_flags[FLAG_MAX_CELLS] <= MAX_BOX_CELLS) { C_cap = std::min<int>(MAX_BOX_CELLS, (int)(h_flags[FLAG_MAX_CELLS] * 1.1) + 8); continue; }
                 if (BI > 64) { BI /= 2; JS = std::min(JS * 2, 1024 / BI); estimate_capacities(); continue; }
-                throw ApiError{MHIP_ERR_CAPACITY, "block neighbourhood spans more than 4096 cells"};
+                throw ApiError{MHIP_ERR_CAPACITY, "block neighbourhood spans more than 8192 cells"};
             }
-            if (ovf & OVF_TILE) T_cap = std::min<int>(TILE_SLOT_MAX - 1, (int)(h_flags[FLAG_MAX_TILE] * 1.15) + 32);
+            if (ovf & OVF_TILE) T_cap = std::min<int>((TILE_SLOT_MAX - 1) & ~3, (((int)(h_flags[FLAG_MAX_TILE] * 1.15) + 32) + 3) & ~3);
             if (ovf & OVF_ROWS) R_cap = (int)(h_flags[FLAG_MAX_ROWS] * 1.2) + 4;
             if (attempt == 11) throw ApiError{MHIP_ERR_CAPACITY, "neighbour structures did not converge"};
         }
@@ -379,6 +390,7 @@ template <class T> class Engine final : public EngineBase {
         switch (ljm) {
         case LJ_OFF: launch_forces_l<LJ_OFF>(A, energy); break;
         case LJ_DIST: launch_forces_l<LJ_DIST>(A, energy); break;
+        case LJ_DIST_UNIFORM: launch_forces_l<LJ_DIST_UNIFORM>(A, energy); break;
         default: launch_forces_l<LJ_GENERIC>(A, energy); break;
         }
         prof.end(0, stream);
@@ -448,6 +460,21 @@ template <class T> class Engine final : public EngineBase {
         hipLaunchKernelGGL(k_scatter_params<T>, dim3(cdiv(n_tot, 256)), dim3(256), 0, stream, n_tot, (const int32_t*)inv.p, dq, ds, de, dm, dl, pos[cur].p, vel[cur].p, lj[cur].p);
         MHIP_HIP(hipGetLastError());
         MHIP_HIP(hipStreamSynchronize(stream));
+        // one atom type (every σ, ϵ equal and non-zero, no λ = 0) + DistanceCutoff → uniform-LJ kernel variant
+        ljm = ljm_base;
+        if (ljm_base == LJ_DIST && ds && de && !(env_int("MOLLYHIP_NO_UNIFORM_LJ", 0))) {
+            std::vector<T> hs(n_tot), he(n_tot), hl;
+            MHIP_HIP(hipMemcpy(hs.data(), ds, n_tot * sizeof(T), hipMemcpyDeviceToHost));
+            MHIP_HIP(hipMemcpy(he.data(), de, n_tot * sizeof(T), hipMemcpyDeviceToHost));
+            if (dl) { hl.resize(n_tot); MHIP_HIP(hipMemcpy(hl.data(), dl, n_tot * sizeof(T), hipMemcpyDeviceToHost)); }
+            bool uni = hs[0] != T(0) && he[0] != T(0);
+            for (int64_t i = 0; i < n_tot && uni; ++i) uni = hs[i] == hs[0] && he[i] == he[0] && (hl.empty() || hl[i] != T(0));
+            if (uni) {
+                T sm = (hs[0] + hs[0]) / T(2), em = std::sqrt(he[0] * he[0]);   // the mixing rules applied to equal values
+                I.lj_s2 = sm * sm; I.lj_24e = T(24) * em; I.lj_4e = T(4) * em;
+                ljm = LJ_DIST_UNIFORM;
+            }
+        }
         s3.release(); s4.release(); s5.release();
         params_set = true; frc_valid = false;
     }

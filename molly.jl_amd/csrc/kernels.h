@@ -15,10 +15,10 @@
 
 namespace mhip {
 
-enum { FLAG_MINIMG = 0, FLAG_OVERFLOW = 1, FLAG_MAX_TILE = 2, FLAG_MAX_ROWS = 3, FLAG_NAN = 4, FLAG_TOTAL_ROWS = 5, N_FLAGS = 8 };
+enum { FLAG_MINIMG = 0, FLAG_OVERFLOW = 1, FLAG_MAX_TILE = 2, FLAG_MAX_ROWS = 3, FLAG_NAN = 4, FLAG_TOTAL_ROWS = 5, FLAG_MAX_CELLS = 6, N_FLAGS = 8 };
 enum { OVF_TILE = 1, OVF_ROWS = 2, OVF_BOXCELLS = 4, OVF_SLOT = 8 };
 
-constexpr int MAX_BOX_CELLS = 4096;
+constexpr int MAX_BOX_CELLS = 8192;
 
 // ---------------------------------------------------------------------------------------------------
 // small helpers
@@ -27,6 +27,14 @@ template <class T> __device__ inline int cell_coord(T x, int d, const GridP<T>& 
     T rel = G.periodic[d] ? x : x - G.origin[d];
     int c = (int)M<T>::floor(rel * G.inv_cs[d]);
     return min(max(c, 0), G.nc[d] - 1);
+}
+
+// value of `v` in lane `src` (wave-uniform index) broadcast to every lane through the scalar file (v_readlane_b32)
+__device__ inline float lane_bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+__device__ inline double lane_bcast(double v, int src) {
+    long long b = __double_as_longlong(v);
+    int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src), hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
 template <class T> __device__ inline T wave_max(T v) {
@@ -120,11 +128,11 @@ __global__ void k_permute(int64_t n_tot, const int32_t* __restrict__ perm, const
 }
 
 // ---------------------------------------------------------------------------------------------------
-// rebuild step 4: tiles + neighbour lists, one workgroup (BI threads) per i-block
+// rebuild step 4: tiles + neighbour lists, one workgroup (BI threads = BI/64 waves) per i-block
 template <class T> struct BuildArgs {
     GridP<T> G;
     int64_t n_owned, n_tot;
-    int BI, T_cap, R_cap;            // i-atoms per block, tile capacity (atoms), row capacity per block
+    int BI, T_cap, R_cap, C_cap;     // i-atoms per block; capacities: tile atoms, list rows per block, box cells
     const typename Vec<T>::T4* pos;
     const int32_t* orig;
     const int32_t* cell_start;       // 2*ncell+1: owned cells then ghost cells, in Hilbert-rank order
@@ -137,150 +145,200 @@ template <class T> struct BuildArgs {
     typename Vec<T>::T4* blk_center; // [n_blocks] centre (xyz) of the block's bounding box at build time
     int32_t* flags;
     T margin;
+    int debug;                       // MOLLYHIP_BUILD_DEBUG: stop after stage n (timing experiments only)
 };
+
+// exclusive prefix sum of a[0..n) in LDS, in place; a[n] receives the total.  `part` holds blockDim ints.
+__device__ inline int block_excl_scan(int32_t* a, int n, int32_t* part, int tid, int nthr) {
+    int per = (n + nthr - 1) / nthr, q0 = min(tid * per, n), q1 = min(q0 + per, n);
+    int sum = 0;
+    for (int q = q0; q < q1; ++q) sum += a[q];
+    part[tid] = sum;
+    __syncthreads();
+    if (tid < WAVE) {   // first wave scans the per-thread sums (nthr <= 256)
+        int run = 0;
+        for (int base = 0; base < nthr; base += WAVE) {
+            int v = (base + tid < nthr) ? part[base + tid] : 0, x = v;
+#pragma unroll
+            for (int o = 1; o < WAVE; o <<= 1) { int u = __shfl_up(x, o, WAVE); if (tid >= o) x += u; }
+            if (base + tid < nthr) part[base + tid] = run + x - v;
+            run += __shfl(x, WAVE - 1, WAVE);
+        }
+        if (tid == 0) a[n] = run;
+    }
+    __syncthreads();
+    int run = part[tid];
+    for (int q = q0; q < q1; ++q) { int v = a[q]; a[q] = run; run += v; }
+    __syncthreads();
+    return a[n];
+}
 
 template <class T>
 __global__ void k_build(BuildArgs<T> A) {
     using T4 = typename Vec<T>::T4;
     extern __shared__ __align__(32) unsigned char smem[];
     const GridP<T>& G = A.G;
-    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
-    // LDS carve-up
-    T4* t_pos = reinterpret_cast<T4*>(smem);
+    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, NW = nthr >> 6;
+    T4* t_pos = reinterpret_cast<T4*>(smem);                 // tile atoms: block-local coords (or wrapped coords if exact_only)
     int32_t* t_slot = reinterpret_cast<int32_t*>(t_pos + A.T_cap);
-    int32_t* c_off = t_slot + A.T_cap;              // MAX_BOX_CELLS + 1
-    int32_t* c_cnt = c_off + (MAX_BOX_CELLS + 1);   // MAX_BOX_CELLS
-    T* red = reinterpret_cast<T*>(c_cnt + MAX_BOX_CELLS);   // 6 * nthr (bbox) / nthr ints (scan)
-    __shared__ T s_lo[3], s_hi[3];
-    __shared__ int s_boxlo[3], s_boxlen[3], s_total;
+    int32_t* c_raw = t_slot + A.T_cap;                        // C_cap + 1: offsets of the cell-pruned candidate stream
+    int32_t* c_rank = c_raw + (A.C_cap + 1);                  // C_cap: Hilbert rank of each box cell
+    int32_t* part = c_rank + A.C_cap + 1;                     // nthr (8-byte aligned: the wave masks reuse c_raw/c_rank)
+    __shared__ T s_sub[4][6];                                 // per-wave bounding boxes of the i-atoms
+    __shared__ T s_ctr[3], s_half[3];
+    __shared__ int s_boxlo[3], s_boxlen[3], s_full[3], s_exact, s_wtot[4];
 
-    // 1. bounding box of the block's atoms
+    // 0. bounding boxes: one per wave of i-atoms (tight pruning for elongated blocks) and their union
     const int64_t si = (int64_t)b * A.BI + tid;
     const bool valid = si < A.n_owned;
-    T4 pi = valid ? A.pos[si] : A.pos[(int64_t)b * A.BI];   // block is never empty
+    T4 pi = A.pos[valid ? si : (int64_t)b * A.BI];            // a block is never empty
     T my[3] = {pi.x, pi.y, pi.z};
+    {
+        T mn[3] = {my[0], my[1], my[2]}, mx[3] = {my[0], my[1], my[2]};
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { red[d * nthr + tid] = my[d]; red[(3 + d) * nthr + tid] = my[d]; }
-    __syncthreads();
-    for (int o = nthr >> 1; o > 0; o >>= 1) {
-        if (tid < o) {
+        for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                T a = red[d * nthr + tid], c = red[d * nthr + tid + o]; red[d * nthr + tid] = c < a ? c : a;
-                T e = red[(3 + d) * nthr + tid], f = red[(3 + d) * nthr + tid + o]; red[(3 + d) * nthr + tid] = f > e ? f : e;
-            }
-        }
-        __syncthreads();
+            for (int d = 0; d < 3; ++d) { T u = __shfl_xor(mn[d], o, WAVE); mn[d] = u < mn[d] ? u : mn[d]; T v = __shfl_xor(mx[d], o, WAVE); mx[d] = v > mx[d] ? v : mx[d]; }
+        if (lane == 0) for (int d = 0; d < 3; ++d) { s_sub[wv][d] = mn[d]; s_sub[wv][3 + d] = mx[d]; }
     }
+    __syncthreads();
     if (tid == 0) {
-        int ovf = 0, need_minimg = 0;
-        T ctr[3];
-#pragma unroll
+        int ovf = 0, exact = 0;
         for (int d = 0; d < 3; ++d) {
-            T lo = red[d * nthr], hi = red[(3 + d) * nthr];
-            s_lo[d] = lo; s_hi[d] = hi; ctr[d] = (lo + hi) * T(0.5);
+            T lo = s_sub[0][d], hi = s_sub[0][3 + d];
+            for (int w = 1; w < NW; ++w) { lo = s_sub[w][d] < lo ? s_sub[w][d] : lo; hi = s_sub[w][3 + d] > hi ? s_sub[w][3 + d] : hi; }
             T half = (hi - lo) * T(0.5);
-            if (G.all_cells[d]) { s_boxlo[d] = 0; s_boxlen[d] = G.nc[d]; if (G.periodic[d]) need_minimg = 1; }
+            s_ctr[d] = (lo + hi) * T(0.5); s_half[d] = half;
+            s_full[d] = 0;
+            if (G.all_cells[d]) { s_boxlo[d] = 0; s_boxlen[d] = G.nc[d]; s_full[d] = 1; if (G.periodic[d]) exact = 1; }
             else {
                 T reach = G.r_list + A.margin;
                 T rel_lo = (G.periodic[d] ? lo : lo - G.origin[d]) - reach, rel_hi = (G.periodic[d] ? hi : hi - G.origin[d]) + reach;
                 int cl = (int)M<T>::floor(rel_lo * G.inv_cs[d]), ch = (int)M<T>::floor(rel_hi * G.inv_cs[d]);
                 if (G.periodic[d]) {
                     int len = ch - cl + 1;
-                    if (len >= G.nc[d]) { cl = 0; len = G.nc[d]; }
+                    if (len >= G.nc[d]) { cl = 0; len = G.nc[d]; s_full[d] = 1; }
                     s_boxlo[d] = cl; s_boxlen[d] = len;
-                    // local (pre-shifted) coordinates are unambiguous only if block half-extent + reach < L/2
-                    if (!(half + reach + reach * T(0.25) < G.L[d] * T(0.5))) need_minimg = 1;
+                    // block-local coordinates are unambiguous only if block half-extent + reach (+ drift) < L/2
+                    if (s_full[d] || !(half + reach * T(1.25) < G.L[d] * T(0.5))) exact = 1;
                 } else {
                     cl = max(cl, 0); ch = min(ch, G.nc[d] - 1);
                     s_boxlo[d] = cl; s_boxlen[d] = max(ch - cl + 1, 1);
                 }
             }
         }
-        if ((int64_t)s_boxlen[0] * s_boxlen[1] * s_boxlen[2] > MAX_BOX_CELLS) { ovf |= OVF_BOXCELLS; s_boxlen[0] = s_boxlen[1] = s_boxlen[2] = 1; }
+        if ((int64_t)s_boxlen[0] * s_boxlen[1] * s_boxlen[2] > A.C_cap) { ovf |= OVF_BOXCELLS; atomicMax(&A.flags[FLAG_MAX_CELLS], s_boxlen[0] * s_boxlen[1] * s_boxlen[2]); s_boxlen[0] = s_boxlen[1] = s_boxlen[2] = 1; }
         if (ovf) atomicOr(&A.flags[FLAG_OVERFLOW], ovf);
-        if (need_minimg) atomicOr(&A.flags[FLAG_MINIMG], 1);
-        A.blk_center[b] = make4<T>(ctr[0], ctr[1], ctr[2], T(0));
+        if (exact) atomicOr(&A.flags[FLAG_MINIMG], 1);
+        s_exact = exact;
+        A.blk_center[b] = make4<T>(s_ctr[0], s_ctr[1], s_ctr[2], T(0));
     }
     __syncthreads();
+    if (A.debug == 1) return;
     const int lx = s_boxlen[0], ly = s_boxlen[1], lz = s_boxlen[2];
     const int ncb = lx * ly * lz;
-    T lo[3] = {s_lo[0], s_lo[1], s_lo[2]}, hi[3] = {s_hi[0], s_hi[1], s_hi[2]};
-    const T reach2 = G.no_list ? G.r_list2 : (G.r_list + A.margin) * (G.r_list + A.margin);
+    const bool exact_only = s_exact != 0;
+    const T ctr[3] = {s_ctr[0], s_ctr[1], s_ctr[2]};
+    const T reach = G.no_list ? G.r_list : G.r_list + A.margin;
+    const T reach2 = G.no_list ? G.r_list2 : reach * reach;
 
-    // distance² from a point to the block's bounding box (periodic axes: nearest image)
-    auto box_dist2 = [&](const T4& p) -> T {
-        T acc = T(0);
-        T pc[3] = {p.x, p.y, p.z};
+    auto localise = [&](T x, int d) -> T {   // coordinate relative to the block centre, nearest periodic image
+        T t = x - ctr[d];
+        if (G.periodic[d]) t -= G.L[d] * M<T>::rint(t * G.invL[d]);
+        return t;
+    };
+    // squared distance from a local point to the nearest per-wave bounding box ("full" axes never prune)
+    auto sub_dist2 = [&](T lx_, T ly_, T lz_) -> T {
+        T best = T(3.0e38);
+        T pc[3] = {lx_, ly_, lz_};
+        for (int w = 0; w < NW; ++w) {
+            T acc = T(0);
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            T c = (lo[d] + hi[d]) * T(0.5), h = (hi[d] - lo[d]) * T(0.5);
-            T t = pc[d] - c;
-            if (G.periodic[d]) t -= G.L[d] * M<T>::rint(t * G.invL[d]);
-            T e = M<T>::fabs(t) - h;
-            e = e > T(0) ? e : T(0);
-            acc += e * e;
+            for (int d = 0; d < 3; ++d) {
+                if (s_full[d]) continue;
+                T lo = s_sub[w][d] - ctr[d], hi = s_sub[w][3 + d] - ctr[d];
+                T e = lo - pc[d]; T f = pc[d] - hi; e = e > f ? e : f; e = e > T(0) ? e : T(0);
+                acc += e * e;
+            }
+            best = acc < best ? acc : best;
         }
-        return acc;
-    };
-    auto cell_of_q = [&](int q, int& r_owned) {
-        int qx = q % lx, qy = (q / lx) % ly, qz = q / (lx * ly);
-        int gx = s_boxlo[0] + qx, gy = s_boxlo[1] + qy, gz = s_boxlo[2] + qz;
-        if (G.periodic[0]) { gx %= G.nc[0]; if (gx < 0) gx += G.nc[0]; }
-        if (G.periodic[1]) { gy %= G.nc[1]; if (gy < 0) gy += G.nc[1]; }
-        if (G.periodic[2]) { gz %= G.nc[2]; if (gz < 0) gz += G.nc[2]; }
-        r_owned = (int)A.cell_rank[(gz * G.nc[1] + gy) * G.nc[0] + gx];
+        return best;
     };
 
-    // 2. per box cell: how many of its atoms lie within reach of the bounding box
+    // 1. cell-level pruning: per box cell the number of candidate atoms (0 if the cell is out of reach)
     for (int q = tid; q < ncb; q += nthr) {
-        int r; cell_of_q(q, r);
-        int cnt = 0;
-        for (int part = 0; part < 2; ++part) {
-            int c = r + part * G.ncell;
-            for (int s = A.cell_start[c], e = A.cell_start[c + 1]; s < e; ++s) cnt += (box_dist2(A.pos[s]) <= reach2) ? 1 : 0;
+        int qx = q % lx, qy = (q / lx) % ly, qz = q / (lx * ly);
+        int g[3] = {s_boxlo[0] + qx, s_boxlo[1] + qy, s_boxlo[2] + qz};
+        // cell AABB in the (unwrapped) frame of the bounding boxes, tested box-against-box
+        T best = T(3.0e38);
+        for (int w = 0; w < NW; ++w) {
+            T acc = T(0);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                if (s_full[d]) continue;
+                T clo = (G.periodic[d] ? T(0) : G.origin[d]) + T(g[d]) * G.cs[d], chi = clo + G.cs[d];
+                T e = s_sub[w][d] - chi; T f = clo - s_sub[w][3 + d]; e = e > f ? e : f; e = e > T(0) ? e : T(0);
+                acc += e * e;
+            }
+            best = acc < best ? acc : best;
         }
-        c_cnt[q] = cnt;
+        int gw[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { gw[d] = g[d]; if (G.periodic[d]) { gw[d] %= G.nc[d]; if (gw[d] < 0) gw[d] += G.nc[d]; } }
+        int r = (int)A.cell_rank[(gw[2] * G.nc[1] + gw[1]) * G.nc[0] + gw[0]];
+        bool keep = best <= reach2 * T(1.0001) + T(1e-12);
+        int cnt = keep ? (A.cell_start[r + 1] - A.cell_start[r]) + (A.cell_start[G.ncell + r + 1] - A.cell_start[G.ncell + r]) : 0;
+        c_raw[q] = cnt; c_rank[q] = r;
     }
     __syncthreads();
-    // 3. exclusive scan over the box cells (each thread scans a contiguous chunk)
-    {
-        int32_t* part = reinterpret_cast<int32_t*>(red);
-        int per = (ncb + nthr - 1) / nthr, q0 = tid * per, q1 = min(q0 + per, ncb);
-        int sum = 0;
-        for (int q = q0; q < q1; ++q) sum += c_cnt[q];
-        part[tid] = sum;
+    const int nraw = block_excl_scan(c_raw, ncb, part, tid, nthr);
+    if (A.debug == 2) return;
+
+    // 2. atom-level pruning + ordered compaction into the LDS tile (cell-major, sorted order inside a cell)
+    int tile_n = 0;
+    for (int base = 0; base < nraw; base += nthr) {
+        const int t = base + tid;
+        bool keep = false; T4 p; int s = 0, q = 0;
+        if (t < nraw) {
+            int lo_q = 0, hi_q = ncb;             // largest q with c_raw[q] <= t
+            while (hi_q - lo_q > 1) { int mid = (lo_q + hi_q) >> 1; if (c_raw[mid] <= t) lo_q = mid; else hi_q = mid; }
+            q = lo_q;
+            int k = t - c_raw[q], r = c_rank[q];
+            int own = A.cell_start[r + 1] - A.cell_start[r];
+            s = k < own ? A.cell_start[r] + k : A.cell_start[G.ncell + r] + (k - own);
+            p = A.pos[s];
+            T l0 = localise(p.x, 0), l1 = localise(p.y, 1), l2 = localise(p.z, 2);
+            // exact_only blocks (small boxes): images are ambiguous, keep the whole cell-pruned set
+            keep = exact_only ? true : sub_dist2(l0, l1, l2) <= reach2;
+            if (!exact_only) { p.x = l0; p.y = l1; p.z = l2; }
+        }
+        unsigned long long m = __ballot(keep);
+        if (lane == 0) s_wtot[wv] = __popcll(m);
         __syncthreads();
-        if (tid == 0) { int run = 0; for (int t = 0; t < nthr; ++t) { int v = part[t]; part[t] = run; run += v; } s_total = run; }
+        int dst = tile_n + __popcll(m & ((1ull << lane) - 1ull));
+        int tot = 0;
+        for (int w = 0; w < NW; ++w) { if (w < wv) dst += s_wtot[w]; tot += s_wtot[w]; }
+        if (keep && dst < A.T_cap) { t_pos[dst] = p; t_slot[dst] = s; A.tile_idx[(int64_t)b * A.T_cap + dst] = s; }
+        tile_n += tot;
         __syncthreads();
-        int run = part[tid];
-        for (int q = q0; q < q1; ++q) { c_off[q] = run; run += c_cnt[q]; }
-        if (tid == 0) c_off[ncb] = s_total;
     }
-    __syncthreads();
-    int tile_n = s_total;
     if (tile_n > A.T_cap || tile_n > TILE_SLOT_MAX - 1) {
         if (tid == 0) { atomicOr(&A.flags[FLAG_OVERFLOW], tile_n > TILE_SLOT_MAX - 1 ? OVF_SLOT : OVF_TILE); atomicMax(&A.flags[FLAG_MAX_TILE], tile_n); A.tile_cnt[b] = 0; }
-        if ((tid & 63) == 0) A.wave_rows[b * (A.BI / WAVE) + tid / WAVE] = 0;
+        if (lane == 0) A.wave_rows[b * NW + wv] = 0;
         return;   // the host grows the capacities and rebuilds
     }
-    // 4. stage the tile in LDS (cell-major, sorted order inside a cell: deterministic slots)
-    for (int q = tid; q < ncb; q += nthr) {
-        int r; cell_of_q(q, r);
-        int t = c_off[q];
-        for (int part = 0; part < 2; ++part) {
-            int c = r + part * G.ncell;
-            for (int s = A.cell_start[c], e = A.cell_start[c + 1]; s < e; ++s) {
-                T4 p = A.pos[s];
-                if (box_dist2(p) <= reach2) { t_pos[t] = p; t_slot[t] = s; A.tile_idx[(int64_t)b * A.T_cap + t] = s; ++t; }
-            }
-        }
-    }
-    if (tid == 0) { A.tile_cnt[b] = tile_n; atomicMax(&A.flags[FLAG_MAX_TILE], tile_n); }
-    __syncthreads();
+    if (tid == 0) A.tile_cnt[b] = tile_n;
+    if (A.debug == 3) return;
 
-    // 5. every lane walks its cell stencil over the LDS tile with the reference's exact predicate
-    //    r2 = sum(abs2, vector(ci, cj, boundary)) <= r_list²  &&  eligible   (neighbors.jl:409-411)
+    // 3. neighbour search, transposed: the LANES hold 64 tile atoms (one coalesced LDS read per group), the wave
+    //    loops over its own i-atoms on the scalar unit (coordinates broadcast with v_readlane), and one v_cmp per
+    //    (i-atom, group) yields the 64 pair decisions as a wave mask in scalar registers, which a v_cndmask pair
+    //    drops into lane i.  After 64 iterations lane i holds the bit mask of ITS neighbours in the group.  No
+    //    divergence, no LDS latency, independent iterations.  Predicate of the reference:
+    //      r2 = sum(abs2, vector(ci, cj, boundary)) <= r_list²  &&  eligible      (neighbors.jl:409-411)
+    //    evaluated in block-local coordinates; only pairs within a 1e-4 band of r_list² — where rounding could
+    //    change the outcome — are re-evaluated with the reference's exact arithmetic, so the emitted pair SET is
+    //    bit-identical to the reference's.
     const uint32_t SENT = (uint32_t)tile_n;
     uint32_t pack[2] = {0, 0};
     int cnt = 0;
@@ -292,55 +350,107 @@ __global__ void k_build(BuildArgs<T> A) {
         ++cnt;
         if (k == 3) { int row = (cnt >> 2) - 1; if (row < A.R_cap) my_rows[(int64_t)row * A.BI] = make_uint2(pack[0], pack[1]); }
     };
-    if (valid) {
-        const int oi = A.orig[si];
-        int c0[3] = {cell_coord(my[0], 0, G), cell_coord(my[1], 1, G), cell_coord(my[2], 2, G)};
-        int r0[3], rn[3];   // stencil range per axis in box-local cell coordinates
+    __syncthreads();
+    {
+        const int oi = valid ? A.orig[si] : 0;
+        const T ml[3] = {exact_only ? my[0] : localise(my[0], 0), exact_only ? my[1] : localise(my[1], 1), exact_only ? my[2] : localise(my[2], 2)};
+        const T band_lo = G.r_list2 * T(1.0 - 1e-4), band_hi = G.r_list2 * T(1.0 + 1e-4);
+        T blo[3], bhi[3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            if (G.all_cells[d] || (G.periodic[d] && s_boxlen[d] == G.nc[d])) { r0[d] = 0; rn[d] = s_boxlen[d]; }   // whole axis
-            else if (G.periodic[d]) {
-                int rel = c0[d] - s_boxlo[d]; rel %= G.nc[d]; if (rel < 0) rel += G.nc[d];   // position of my cell inside the box
-                r0[d] = rel - G.stencil[d]; rn[d] = 2 * G.stencil[d] + 1;
-                if (r0[d] < 0) { rn[d] += r0[d]; r0[d] = 0; }                                  // box was dilated by ≥ stencil cells, so
-                if (r0[d] + rn[d] > s_boxlen[d]) rn[d] = s_boxlen[d] - r0[d];                  // clipping only drops cells out of reach
-            } else {
-                int a = max(c0[d] - G.stencil[d], s_boxlo[d]), e = min(c0[d] + G.stencil[d], s_boxlo[d] + s_boxlen[d] - 1);
-                r0[d] = a - s_boxlo[d]; rn[d] = max(e - a + 1, 0);
-            }
-        }
-        for (int qz = r0[2]; qz < r0[2] + rn[2]; ++qz)
-            for (int qy = r0[1]; qy < r0[1] + rn[1]; ++qy) {
-                int qrow = (qz * ly + qy) * lx;
-                // cells along x are contiguous in the tile: one slot range per (y,z) row
-                int t0 = c_off[qrow + r0[0]], t1 = c_off[qrow + r0[0] + rn[0]];
-                for (int t = t0; t < t1; ++t) {
-                    T4 pj = t_pos[t];
-                    T dx = G.periodic[0] ? vector_1d_exact(my[0], pj.x, G.L[0]) : M<T>::sub(pj.x, my[0]);
-                    T dy = G.periodic[1] ? vector_1d_exact(my[1], pj.y, G.L[1]) : M<T>::sub(pj.y, my[1]);
-                    T dz = G.periodic[2] ? vector_1d_exact(my[2], pj.z, G.L[2]) : M<T>::sub(pj.z, my[2]);
-                    T r2 = norm2_exact(dx, dy, dz);
-                    if (!(r2 <= G.r_list2)) continue;
-                    int sj = t_slot[t];
-                    if (sj == (int)si) continue;
-                    uint32_t sp = 0;
-                    if (A.ex_start) {
-                        int oj = A.orig[sj];
-                        bool excl = false;
-                        for (int k = A.ex_start[oi], e = A.ex_start[oi + 1]; k < e; ++k) excl |= (A.ex_list[k] == oj);
-                        if (excl) continue;
-                        for (int k = A.sp_start[oi], e = A.sp_start[oi + 1]; k < e; ++k) sp |= (A.sp_list[k] == oj) ? 1u : 0u;
-                    }
-                    emit((uint32_t)t | (sp << 15));
+        for (int d = 0; d < 3; ++d) { blo[d] = s_sub[wv][d] - ctr[d]; bhi[d] = s_sub[wv][3 + d] - ctr[d]; }
+        const unsigned long long valid_mask = __ballot(valid);
+        const int nwords = (tile_n + 63) >> 6;
+        for (int w = 0; w < nwords; ++w) {
+            const int jl = (w << 6) + lane;
+            T4 pl = make4<T>(T(0), T(0), T(0), T(0)); int sl = -1; bool near = false;
+            if (jl < tile_n) {
+                pl = t_pos[jl]; sl = t_slot[jl];
+                if (exact_only) near = true;
+                else {
+                    T pc[3] = {pl.x, pl.y, pl.z}, acc = T(0);
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) { T e = blo[d] - pc[d]; T f = pc[d] - bhi[d]; e = e > f ? e : f; e = e > T(0) ? e : T(0); acc += e * e; }
+                    near = acc <= reach2;
                 }
             }
+            if (__ballot(near) == 0ull) continue;          // the whole group is out of this wave's reach
+            int mine_lo = 0, mine_hi = 0;                  // lane i: mask of its neighbours within this group
+            if (!exact_only) {
+#pragma unroll 8
+                for (int i = 0; i < WAVE; ++i) {
+                    const T ix = lane_bcast(ml[0], i), iy = lane_bcast(ml[1], i), iz = lane_bcast(ml[2], i);
+                    T dx = pl.x - ix, dy = pl.y - iy, dz = pl.z - iz;
+                    T r2 = dx * dx + dy * dy + dz * dz;
+                    unsigned long long in = __ballot(near && r2 < band_lo);
+                    const unsigned long long maybe = __ballot(near && !(r2 < band_lo) && r2 <= band_hi);
+                    if (maybe) {   // rare: decide with the reference's exact arithmetic on the stored coordinates
+                        const T ox = lane_bcast(my[0], i), oy = lane_bcast(my[1], i), oz = lane_bcast(my[2], i);
+                        bool ok = false;
+                        if ((maybe >> lane) & 1ull) {
+                            T4 pj = A.pos[sl];
+                            T ex = G.periodic[0] ? vector_1d_exact(ox, pj.x, G.L[0]) : M<T>::sub(pj.x, ox);
+                            T ey = G.periodic[1] ? vector_1d_exact(oy, pj.y, G.L[1]) : M<T>::sub(pj.y, oy);
+                            T ez = G.periodic[2] ? vector_1d_exact(oz, pj.z, G.L[2]) : M<T>::sub(pj.z, oz);
+                            ok = norm2_exact(ex, ey, ez) <= G.r_list2;
+                        }
+                        in |= __ballot(ok);
+                    }
+                    if (lane == i) { mine_lo = (int)(uint32_t)in; mine_hi = (int)(uint32_t)(in >> 32); }   // v_cndmask ×2
+                }
+            } else {
+                for (int i = 0; i < WAVE; ++i) {
+                    const T ox = lane_bcast(my[0], i), oy = lane_bcast(my[1], i), oz = lane_bcast(my[2], i);
+                    T ex = G.periodic[0] ? vector_1d_exact(ox, pl.x, G.L[0]) : M<T>::sub(pl.x, ox);
+                    T ey = G.periodic[1] ? vector_1d_exact(oy, pl.y, G.L[1]) : M<T>::sub(pl.y, oy);
+                    T ez = G.periodic[2] ? vector_1d_exact(oz, pl.z, G.L[2]) : M<T>::sub(pl.z, oz);
+                    const unsigned long long in = __ballot(near && norm2_exact(ex, ey, ez) <= G.r_list2);
+                    if (lane == i) { mine_lo = (int)(uint32_t)in; mine_hi = (int)(uint32_t)(in >> 32); }   // v_cndmask ×2
+                }
+            }
+            // each lane unpacks its own mask (slot order = tile order: deterministic lists)
+            unsigned long long mm = ((unsigned long long)(uint32_t)mine_hi << 32) | (uint32_t)mine_lo;
+            if (!((valid_mask >> lane) & 1ull)) mm = 0;
+            while (mm) {
+                const int bit = __builtin_ctzll(mm);
+                mm &= mm - 1;
+                const uint32_t t = (uint32_t)((w << 6) + bit);
+                const int sj = t_slot[t];
+                if (sj == (int)si) continue;
+                uint32_t sp = 0;
+                if (A.ex_start) {
+                    int oj = A.orig[sj];
+                    bool excl = false;
+                    for (int k = A.ex_start[oi], e = A.ex_start[oi + 1]; k < e; ++k) excl |= (A.ex_list[k] == oj);
+                    for (int k = A.sp_start[oi], e = A.sp_start[oi + 1]; k < e; ++k) sp |= (A.sp_list[k] == oj) ? 1u : 0u;
+                    if (excl) continue;
+                }
+                emit(t | (sp << 15));
+            }
+        }
     }
-    // 6. pad every lane to the wave's row count with the sentinel slot (a far-away dummy atom)
+    if (A.debug == 4) return;
+    // 4. pad every lane to the wave's row count with the sentinel slot (a far-away dummy atom)
     int rows_mine = (cnt + 3) >> 2;
     int rows_wave = wave_max(rows_mine);
-    if (rows_wave > A.R_cap) { if ((tid & 63) == 0) { atomicOr(&A.flags[FLAG_OVERFLOW], OVF_ROWS); atomicMax(&A.flags[FLAG_MAX_ROWS], rows_wave); } rows_wave = 0; }
-    while (((cnt + 3) >> 2) < rows_wave || (cnt & 3)) emit(SENT);
-    if ((tid & 63) == 0) { A.wave_rows[b * (A.BI / WAVE) + tid / WAVE] = rows_wave; atomicMax(&A.flags[FLAG_MAX_ROWS], rows_wave); atomicAdd(&A.flags[FLAG_TOTAL_ROWS], rows_wave); }
+    if (rows_wave > A.R_cap) { if (lane == 0) atomicOr(&A.flags[FLAG_OVERFLOW], OVF_ROWS); }
+    const int rows_keep = rows_wave > A.R_cap ? 0 : rows_wave;
+    while (((cnt + 3) >> 2) < rows_keep || (cnt & 3)) emit(SENT);
+    if (lane == 0) A.wave_rows[b * NW + wv] = rows_wave;   // > R_cap reports the required capacity; k_build_summary zeroes it
+}
+
+// one block: reduce the per-block / per-wave results of k_build into the flag words the host reads
+__global__ void k_build_summary(int n_blocks, int n_waves, int R_cap, const int32_t* __restrict__ tile_cnt, int32_t* wave_rows, int32_t* flags) {
+    __shared__ int sh_t[256], sh_r[256], sh_s[256];
+    int mt = 0, mr = 0, tot = 0;
+    for (int q = threadIdx.x; q < n_blocks; q += blockDim.x) mt = max(mt, tile_cnt[q]);
+    for (int q = threadIdx.x; q < n_waves; q += blockDim.x) { int r = wave_rows[q]; mr = max(mr, r); if (r > R_cap) wave_rows[q] = 0; else tot += r; }
+    sh_t[threadIdx.x] = mt; sh_r[threadIdx.x] = mr; sh_s[threadIdx.x] = tot;
+    __syncthreads();
+    for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { sh_t[threadIdx.x] = max(sh_t[threadIdx.x], sh_t[threadIdx.x + o]); sh_r[threadIdx.x] = max(sh_r[threadIdx.x], sh_r[threadIdx.x + o]); sh_s[threadIdx.x] += sh_s[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { atomicMax(&flags[FLAG_MAX_TILE], sh_t[0]); flags[FLAG_MAX_ROWS] = sh_r[0]; flags[FLAG_TOTAL_ROWS] = sh_s[0]; }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -392,25 +502,28 @@ __global__ void k_forces(ForceArgs<T> A) {
     for (int t = tid; t < tile_n; t += nthr) {
         int s = tix[t];
         l_pos[t] = localise(A.pos[s]);
-        if constexpr (LJM != LJ_OFF) l_lj[t] = A.lj[s];
+        if constexpr (LJM == LJ_DIST || LJM == LJ_GENERIC) l_lj[t] = A.lj[s];
     }
-    if (tid == 0) {   // sentinel: far away, no charge, no LJ
+    if (tid == 0) {   // sentinel: far away (beyond every cutoff), no charge, no LJ
         l_pos[tile_n] = make4<T>(T(1e4), T(1e4), T(1e4), T(0));
-        if constexpr (LJM != LJ_OFF) l_lj[tile_n] = make2<T>(T(0), T(0));
+        if constexpr (LJM == LJ_DIST || LJM == LJ_GENERIC) l_lj[tile_n] = make2<T>(T(0), T(0));
     }
     const int li = tid & (A.BI - 1), js = tid >> A.BI_shift;
     const int64_t si = (int64_t)b * A.BI + li;
     const bool valid = si < A.n_owned;
     T4 pi = localise(A.pos[valid ? si : (int64_t)b * A.BI]);
     T2 lji = make2<T>(T(0), T(0));
-    if constexpr (LJM != LJ_OFF) lji = A.lj[valid ? si : (int64_t)b * A.BI];
+    if constexpr (LJM == LJ_DIST || LJM == LJ_GENERIC) lji = A.lj[valid ? si : (int64_t)b * A.BI];
     __syncthreads();
 
     const int rows = A.wave_rows[b * (A.BI >> 6) + (li >> 6)];
     const uint2* my_rows = A.nbr + ((int64_t)b * A.R_cap) * A.BI + li;
     T fx = T(0), fy = T(0), fz = T(0), pe = T(0);
+    // the row stream is software-pipelined: row r+JS is in flight while row r is evaluated
+    uint2 e_next = (js < rows) ? my_rows[(int64_t)js * A.BI] : make_uint2(0, 0);
     for (int r = js; r < rows; r += A.JS) {
-        uint2 e4 = my_rows[(int64_t)r * A.BI];
+        const uint2 e4 = e_next;
+        if (r + A.JS < rows) e_next = my_rows[(int64_t)(r + A.JS) * A.BI];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             uint32_t e = ((k < 2 ? e4.x : e4.y) >> (16 * (k & 1))) & 0xffffu;
@@ -418,7 +531,7 @@ __global__ void k_forces(ForceArgs<T> A) {
             bool special = (e >> 15) != 0;
             T4 pj = l_pos[slot];
             T2 ljj = make2<T>(T(0), T(0));
-            if constexpr (LJM != LJ_OFF) ljj = l_lj[slot];
+            if constexpr (LJM == LJ_DIST || LJM == LJ_GENERIC) ljj = l_lj[slot];
             T dx, dy, dz;
             if constexpr (MINIMG) {
                 dx = G.periodic[0] ? vector_1d_exact(pi.x, pj.x, G.L[0]) : pj.x - pi.x;
@@ -536,17 +649,19 @@ __global__ void k_cm_partials(int64_t n, const typename Vec<T>::T4* __restrict__
     if (threadIdx.x < 4) { double a = 0; for (int q = 0; q < (int)(blockDim.x >> 6); ++q) a += sh[q][threadIdx.x]; cm_part[4 * (int64_t)blockIdx.x + threadIdx.x] = a; }
 }
 
-// one block: fixed-order sum of the per-block partials → out4 = {Px,Py,Pz,M} (double) and vcm = P/M (T)
+// one block of 256 threads: fixed-order sum of the per-block partials → out4 = {Px,Py,Pz,M} (double), vcm = P/M (T)
 template <class T>
 __global__ void k_cm_finalize(int n_part, const double* __restrict__ cm_part, double* out4, T* vcm) {
-    __shared__ double sh[256][4];
+    __shared__ double sh[4][4];
     double a[4] = {0, 0, 0, 0};
-    for (int q = threadIdx.x; q < n_part; q += blockDim.x) for (int c = 0; c < 4; ++c) a[c] += cm_part[4 * (int64_t)q + c];
-    for (int c = 0; c < 4; ++c) sh[threadIdx.x][c] = a[c];
+    for (int q = threadIdx.x; q < n_part; q += blockDim.x) { const double* p = cm_part + 4 * (int64_t)q; a[0] += p[0]; a[1] += p[1]; a[2] += p[2]; a[3] += p[3]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) for (int c = 0; c < 4; ++c) a[c] += __shfl_xor(a[c], o, 64);
+    if ((threadIdx.x & 63) == 0) for (int c = 0; c < 4; ++c) sh[threadIdx.x >> 6][c] = a[c];
     __syncthreads();
     if (threadIdx.x == 0) {
         double t[4] = {0, 0, 0, 0};
-        for (int q = 0; q < (int)blockDim.x; ++q) for (int c = 0; c < 4; ++c) t[c] += sh[q][c];
+        for (int q = 0; q < (int)(blockDim.x >> 6); ++q) for (int c = 0; c < 4; ++c) t[c] += sh[q][c];
         for (int c = 0; c < 4; ++c) out4[c] = t[c];
         if (vcm) for (int c = 0; c < 3; ++c) vcm[c] = (T)(t[c] / t[3]);
     }

@@ -19,9 +19,20 @@ template <> struct M<float> {
     __device__ static inline float rint(float x) { return ::rintf(x); }
     __device__ static inline float floor(float x) { return ::floorf(x); }
     __device__ static inline float fabs(float x) { return ::fabsf(x); }
-    __device__ static inline float mul(float a, float b) { return __fmul_rn(a, b); }   // never contracted
-    __device__ static inline float add(float a, float b) { return __fadd_rn(a, b); }
-    __device__ static inline float sub(float a, float b) { return __fsub_rn(a, b); }
+    // individually rounded operations: hipcc's default -ffp-contract=fast would otherwise fuse a*b+c into one
+    // FMA (HIP's __fmul_rn/__fadd_rn are plain operators on AMD and do NOT prevent that)
+    __device__ static inline float mul(float a, float b) {
+#pragma clang fp contract(off)
+        return a * b;
+    }
+    __device__ static inline float add(float a, float b) {
+#pragma clang fp contract(off)
+        return a + b;
+    }
+    __device__ static inline float sub(float a, float b) {
+#pragma clang fp contract(off)
+        return a - b;
+    }
 };
 template <> struct M<double> {
     __device__ static inline double rcp(double x) { return 1.0 / x; }
@@ -32,9 +43,18 @@ template <> struct M<double> {
     __device__ static inline double rint(double x) { return ::rint(x); }
     __device__ static inline double floor(double x) { return ::floor(x); }
     __device__ static inline double fabs(double x) { return ::fabs(x); }
-    __device__ static inline double mul(double a, double b) { return __dmul_rn(a, b); }
-    __device__ static inline double add(double a, double b) { return __dadd_rn(a, b); }
-    __device__ static inline double sub(double a, double b) { return __dsub_rn(a, b); }
+    __device__ static inline double mul(double a, double b) {
+#pragma clang fp contract(off)
+        return a * b;
+    }
+    __device__ static inline double add(double a, double b) {
+#pragma clang fp contract(off)
+        return a + b;
+    }
+    __device__ static inline double sub(double a, double b) {
+#pragma clang fp contract(off)
+        return a - b;
+    }
 };
 
 // spatial.jl:491-500 vector_1D in its literal compare/select form.  With t = L - |v| both branches of the
@@ -120,7 +140,7 @@ template <class T> __device__ inline T ewald_erfc(T ar, T e, int approx) {
     return M<T>::erfc(ar);
 }
 
-enum { LJ_OFF = 0, LJ_DIST = 1, LJ_GENERIC = 2 };
+enum { LJ_OFF = 0, LJ_DIST = 1, LJ_GENERIC = 2, LJ_DIST_UNIFORM = 3 };   // UNIFORM: every atom has the same σ, ϵ
 
 // Sum over pairwise_inters for one pair (force.jl:79-92 / kernels.jl:3-17).  Returns `fr` such that the
 // force on atom j is fr·dr (and −fr·dr on atom i, force.jl:873-874) and, if ENERGY, adds the pair energy.
@@ -128,7 +148,15 @@ template <class T, int LJM, int COULM, bool ENERGY>
 __device__ inline T pair_eval(const InterP<T>& I, T r2, T qi, T qj, T si, T sj, T ei, T ej, bool special, T& pe) {
     T fr = T(0);
     T inv_r2 = M<T>::rcp(r2);
-    if constexpr (LJM != LJ_OFF) {
+    if constexpr (LJM == LJ_DIST_UNIFORM) {
+        // one atom type: σ_mix = σ, ϵ_mix = ϵ (Lorentz / geometric mixing of equal values), hoisted to the host
+        T six = I.lj_s2 * inv_r2; six = six * six * six;
+        bool in = r2 <= I.lj_rc2;
+        T w = special ? I.lj_w : T(1);
+        T f = I.lj_24e * (T(2) * six * six - six) * inv_r2;
+        fr += in ? f * w : T(0);
+        if constexpr (ENERGY) pe += in ? I.lj_4e * (six * six - six) * w : T(0);
+    } else if constexpr (LJM != LJ_OFF) {
         T s = (si + sj) * T(0.5);                                   // LorentzMixing
         T e = M<T>::sqrt(ei * ej);                                  // GeometricMixing
         e = (si == T(0) || sj == T(0)) ? T(0) : e;                  // LJZeroShortcut (ϵ == 0 already yields 0)
