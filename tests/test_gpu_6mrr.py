@@ -1,0 +1,95 @@
+"""HIP path on the solvated protein 6mrr (BASELINE.json configs[2] and [4]) against the OpenMM golden files shipped with the
+reference (fp64 bars of test/protein.jl:263-276) and against the oracle (fp32, Ewald direct space)."""
+import numpy as np
+import pytest
+
+from tests import golden6mrr as G
+from tests import systems as S
+
+pytestmark = pytest.mark.gpu
+
+
+def test_neighbor_list_is_the_references(pkg):
+    for dtype in (np.float64, np.float32):
+        case = G.case("rf", dtype, bonded=False)
+        oi, oj, osp = case.oracle(dtype).neighbors("cell", nthreads=8)
+        nl = pkg.find_neighbors(case.system(pkg, dtype))
+        a, b = S.sorted_pairs(oi, oj, osp), S.sorted_pairs(nl.i, nl.j, nl.special)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        if dtype == np.float64:
+            assert nl.n == 4602420                                                       # test/basic.jl:592-593
+            assert int(nl.special.sum()) == 3094                                          # 1-4 pairs that are not also 1-2 / 1-3
+
+
+@pytest.mark.parametrize("key,coul,lj", [("lj_only", None, True), ("coul_only", "rf", False)])
+def test_pairwise_terms_vs_openmm_fp64(pkg, key, coul, lj):
+    case = G.case(coul, np.float64, bonded=False, lj=lj)
+    s = case.system(pkg, np.float64)
+    f = pkg.forces(s)
+    assert np.linalg.norm(f - G.data()[f"openmm_forces_{key}"], axis=1).max() < 1e-7     # test/protein.jl:267
+    e = pkg.potential_energy(s) + (G.lj_dispersion_correction() if lj else 0.0)
+    assert abs(e - G.data()[f"openmm_energy_{key}"]) < 1e-4                              # 1e-5 on |E| ~ 5e3; 1e-4 on 1.2e5
+
+
+@pytest.mark.parametrize("term,key", [("bonds", "bond_only"), ("angles", "angle_only"), ("proper", "proptor_only"), ("improper", "improptor_only")])
+def test_bonded_terms_vs_openmm_fp64(pkg, term, key):
+    case = G.case(None, np.float64, lj=False, which_bonded=(term,))
+    s = case.system(pkg, np.float64)
+    f = pkg.forces(s, pairwise=False)
+    assert np.linalg.norm(f - G.data()[f"openmm_forces_{key}"], axis=1).max() < 1e-6
+    assert abs(pkg.potential_energy(s, pairwise=False) - G.data()[f"openmm_energy_{key}"]) < 1e-5
+
+
+def test_all_cutoff_interactions_vs_openmm_fp64(pkg):
+    case = G.case("rf", np.float64, bonded=True)
+    s = case.system(pkg, np.float64)
+    f = pkg.forces(s)
+    assert np.linalg.norm(f - G.data()["openmm_forces_all_cut"], axis=1).max() < 1e-6
+    e = pkg.potential_energy(s) + G.lj_dispersion_correction()
+    assert abs(e - G.data()["openmm_energy_all_cut"]) < 1e-4
+
+
+@pytest.mark.parametrize("coul", ["rf", "ewald"])
+def test_pairwise_fp32_vs_fp64_oracle(pkg, coul):
+    case = G.case(coul, np.float32, bonded=False)
+    tol, o, nl = S.fp32_force_tolerance(case)
+    f_ref = o.forces(nl, nthreads=8)
+    s = case.system(pkg, np.float32)
+    f = pkg.forces(s).astype(np.float64)
+    err = np.linalg.norm(f - f_ref, axis=1)
+    assert np.all(err <= tol), f"worst err {err.max():.3e} tol {tol[err.argmax()]:.3e}"
+    assert np.sqrt((err ** 2).sum() / (np.linalg.norm(f_ref, axis=1) ** 2).sum()) < 1e-5
+    assert pkg.potential_energy(s) == pytest.approx(o.potential_energy(nl), rel=1e-5)
+
+
+def test_ewald_direct_plus_exclusions_fp64(pkg):
+    # CoulombEwald + LJ over the list, bonded terms and the EwaldExclusion list (setup.jl:1877-1913), exact erfc
+    case = G.case("ewald", np.float64, bonded=True, approx_erfc=False)
+    o = case.oracle(np.float64)
+    nl = o.neighbors("cell", nthreads=8)
+    f_ref = o.forces(nl, nthreads=8, specific=True)
+    s = case.system(pkg, np.float64)
+    f = pkg.forces(s)
+    assert np.linalg.norm(f - f_ref, axis=1).max() < 1e-6
+    assert pkg.potential_energy(s) == pytest.approx(o.potential_energy(nl, specific=True), rel=1e-11)
+    # the same in fp32 with the A&S erfc polynomial (the configuration bench.py times)
+    case32 = G.case("ewald", np.float32, bonded=True)
+    tol, o32, nl32 = S.fp32_force_tolerance(case32)
+    f_ref = o32.forces(nl32, nthreads=8, specific=True)
+    bonded_scale = np.linalg.norm(o32.forces(None, pairwise=False, specific=True), axis=1)
+    f = pkg.forces(case32.system(pkg, np.float32)).astype(np.float64)
+    assert np.all(np.linalg.norm(f - f_ref, axis=1) <= tol + 2e-5 * bonded_scale + 2e-3)
+
+
+def test_velocity_verlet_rf_fp64_tracks_oracle_and_conserves_energy(pkg):
+    # BASELINE.json configs[4]: reaction-field Coulomb, Float64, NVE (remove_CM_motion = 0), dt = 0.5 fs
+    case = G.case("rf", np.float64, bonded=True)
+    o = case.oracle(np.float64)
+    o.vv_run(20, 0.0005, remove_cm_every=0, nthreads=8, specific=True)
+    s = case.system(pkg, np.float64)
+    e0 = pkg.total_energy(s)
+    pkg.simulate(s, pkg.VelocityVerlet(dt=0.0005, remove_CM_motion=0), 20)
+    assert np.abs(s.coords - o.coords).max() < 1e-9 and np.abs(s.velocities - o.vel).max() < 1e-7
+    pkg.simulate(s, pkg.VelocityVerlet(dt=0.0005, remove_CM_motion=0), 180, init_step=20)
+    e1 = pkg.total_energy(s)
+    assert abs(e1 - e0) < 2e-4 * abs(pkg.kinetic_energy(s))     # 0.1 ps: no secular blow-up (RF has a force jump at rc)
