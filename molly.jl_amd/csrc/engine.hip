@@ -128,7 +128,7 @@ template <class T> class Engine final : public EngineBase {
     bool stale = true, minimg = false, cm_pending = false, params_set = false, state_set = false, frc_valid = false;
     int64_t last_build_step = std::numeric_limits<int64_t>::min();
     int64_t n_rebuilds = 0, n_force_calls = 0; double last_rebuild_ms = 0;
-    size_t lds_force = 0;
+    size_t lds_force = 0; int tile_lds = 0; bool segmented = false;
     Prof prof;
 
   public:
@@ -348,8 +348,18 @@ template <class T> class Engine final : public EngineBase {
         }
         minimg = h_flags[FLAG_MINIMG] != 0 || env_int("MOLLYHIP_FORCE_MINIMG", 0) != 0;
         max_tile = h_flags[FLAG_MAX_TILE]; max_rows = h_flags[FLAG_MAX_ROWS]; total_rows = h_flags[FLAG_TOTAL_ROWS];
-        lds_force = force_lds_bytes(max_tile);
-        if (lds_force > (size_t)MAX_LDS_BYTES) throw ApiError{MHIP_ERR_CAPACITY, "force-kernel tile does not fit the 160 KiB LDS"};
+        {   // LDS carve-up of the force kernel: the whole tile if it fits the budget, else segments of the budget's size
+            const size_t budget = std::min<size_t>((size_t)env_int("MOLLYHIP_LDS_BUDGET_KB", 160) * 1024, MAX_LDS_BYTES);
+            const bool per_atom_lj = (ljm == LJ_DIST || ljm == LJ_GENERIC);
+            const size_t per_atom = sizeof(T4) + (per_atom_lj ? sizeof(T2) : 0);
+            const size_t fixed = std::max((size_t)JS * 4 * BI * sizeof(T), (size_t)BI * sizeof(double)) + 64;
+            int fit = (int)((budget > fixed + 2 * per_atom ? budget - fixed : 2 * per_atom) / per_atom) - 1;
+            fit = std::max(fit & ~1, 2);
+            segmented = max_tile > fit;
+            tile_lds = segmented ? fit : max_tile;
+            lds_force = force_lds_bytes(tile_lds);
+            if (lds_force > (size_t)MAX_LDS_BYTES) throw ApiError{MHIP_ERR_CAPACITY, "force-kernel LDS carve-up exceeds 160 KiB"};
+        }
         red_part.reserve(std::max<size_t>((size_t)n_blocks, 4 * (size_t)cdiv(n_owned, 256)) + 8);
         bonded.on_reorder();
         stale = false; last_build_step = step_n; ++n_rebuilds;
@@ -363,9 +373,15 @@ template <class T> class Engine final : public EngineBase {
 
     // ---------------------------------------------------------------------------------------------
     template <int LJM, int COULM, bool ENERGY, bool MINIMG> void launch_forces_t(const ForceArgs<T>& A) {
-        auto kern = k_forces<T, LJM, COULM, ENERGY, MINIMG>;
-        set_lds_limit(kern, lds_force);
-        hipLaunchKernelGGL(kern, dim3(A.blocks_per_xcd * 8), dim3(BI * JS), lds_force, stream, A);
+        if (segmented) {
+            auto kern = k_forces<T, LJM, COULM, ENERGY, MINIMG, true>;
+            set_lds_limit(kern, lds_force);
+            hipLaunchKernelGGL(kern, dim3(A.blocks_per_xcd * 8), dim3(BI * JS), lds_force, stream, A);
+        } else {
+            auto kern = k_forces<T, LJM, COULM, ENERGY, MINIMG, false>;
+            set_lds_limit(kern, lds_force);
+            hipLaunchKernelGGL(kern, dim3(A.blocks_per_xcd * 8), dim3(BI * JS), lds_force, stream, A);
+        }
     }
     template <int LJM, int COULM> void launch_forces_c(const ForceArgs<T>& A, bool energy) {
         if (energy) { if (minimg) launch_forces_t<LJM, COULM, true, true>(A); else launch_forces_t<LJM, COULM, true, false>(A); }
@@ -382,7 +398,7 @@ template <class T> class Engine final : public EngineBase {
     // pairwise forces of the current coordinates into frc[cur] (overwrites); energy → red_part[0..n_blocks)
     void launch_pair_kernel(bool energy) {
         ForceArgs<T> A;
-        A.G = G; A.I = I; A.n_owned = n_owned; A.BI = BI; A.BI_shift = ilog2(BI); A.JS = JS; A.T_cap = T_cap; A.T_lds = max_tile; A.R_cap = R_cap;
+        A.G = G; A.I = I; A.n_owned = n_owned; A.BI = BI; A.BI_shift = ilog2(BI); A.JS = JS; A.T_cap = T_cap; A.T_lds = tile_lds; A.R_cap = R_cap;
         A.n_blocks = n_blocks; A.blocks_per_xcd = cdiv(n_blocks, 8);
         A.pos = pos[cur].p; A.lj = lj[cur].p; A.tile_idx = tile_idx.p; A.tile_cnt = tile_cnt.p; A.nbr = nbr.p; A.wave_rows = wave_rows.p;
         A.blk_center = blk_center.p; A.frc = frc[cur].p; A.pe_part = red_part.p;

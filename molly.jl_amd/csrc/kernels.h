@@ -471,10 +471,11 @@ template <class T> struct ForceArgs {
     double* pe_part;                 // [n_blocks] (ENERGY)
 };
 
-template <class T, int LJM, int COULM, bool ENERGY, bool MINIMG>
+template <class T, int LJM, int COULM, bool ENERGY, bool MINIMG, bool SEG>
 __global__ void k_forces(ForceArgs<T> A) {
     using T4 = typename Vec<T>::T4;
     using T2 = typename Vec<T>::T2;
+    constexpr bool PER_ATOM_LJ = (LJM == LJ_DIST || LJM == LJ_GENERIC);
     extern __shared__ __align__(32) unsigned char smem[];
     const GridP<T>& G = A.G;
     // XCD-aware mapping: hardware places workgroup w on XCD w % 8; give each XCD a contiguous run of the
@@ -497,50 +498,58 @@ __global__ void k_forces(ForceArgs<T> A) {
         }
         return p;
     };
-    // stage the tile: coalesced-ish gathers of 16 B atoms from L2 into LDS
-    const int32_t* tix = A.tile_idx + (int64_t)b * A.T_cap;
-    for (int t = tid; t < tile_n; t += nthr) {
-        int s = tix[t];
-        l_pos[t] = localise(A.pos[s]);
-        if constexpr (LJM == LJ_DIST || LJM == LJ_GENERIC) l_lj[t] = A.lj[s];
-    }
-    if (tid == 0) {   // sentinel: far away (beyond every cutoff), no charge, no LJ
-        l_pos[tile_n] = make4<T>(T(1e4), T(1e4), T(1e4), T(0));
-        if constexpr (LJM == LJ_DIST || LJM == LJ_GENERIC) l_lj[tile_n] = make2<T>(T(0), T(0));
-    }
     const int li = tid & (A.BI - 1), js = tid >> A.BI_shift;
     const int64_t si = (int64_t)b * A.BI + li;
     const bool valid = si < A.n_owned;
     T4 pi = localise(A.pos[valid ? si : (int64_t)b * A.BI]);
     T2 lji = make2<T>(T(0), T(0));
-    if constexpr (LJM == LJ_DIST || LJM == LJ_GENERIC) lji = A.lj[valid ? si : (int64_t)b * A.BI];
-    __syncthreads();
-
+    if constexpr (PER_ATOM_LJ) lji = A.lj[valid ? si : (int64_t)b * A.BI];
     const int rows = A.wave_rows[b * (A.BI >> 6) + (li >> 6)];
     const uint2* my_rows = A.nbr + ((int64_t)b * A.R_cap) * A.BI + li;
+    const int32_t* tix = A.tile_idx + (int64_t)b * A.T_cap;
     T fx = T(0), fy = T(0), fz = T(0), pe = T(0);
-    // the row stream is software-pipelined: row r+JS is in flight while row r is evaluated
-    uint2 e_next = (js < rows) ? my_rows[(int64_t)js * A.BI] : make_uint2(0, 0);
-    for (int r = js; r < rows; r += A.JS) {
-        const uint2 e4 = e_next;
-        if (r + A.JS < rows) e_next = my_rows[(int64_t)(r + A.JS) * A.BI];
+
+    // The tile normally fits the LDS carve-up in one piece.  SEG: a tile larger than the LDS budget is
+    // processed in segments; every segment re-walks the row stream and treats slots outside it as sentinels.
+    const int seg_cap = A.T_lds;
+    for (int seg_lo = 0; seg_lo < (SEG ? tile_n : 1); seg_lo += seg_cap) {
+        const int n_here = SEG ? min(seg_cap, tile_n - seg_lo) : tile_n;
+        if (SEG && seg_lo > 0) __syncthreads();
+        // stage the tile: gathers of 16 B atoms (mostly L2 hits) into LDS, periodic image resolved once per atom
+        for (int t = tid; t < n_here; t += nthr) {
+            int s = tix[seg_lo + t];
+            l_pos[t] = localise(A.pos[s]);
+            if constexpr (PER_ATOM_LJ) l_lj[t] = A.lj[s];
+        }
+        if (tid == 0) {   // sentinel: far away (beyond every cutoff), no charge, no LJ
+            l_pos[n_here] = make4<T>(T(1e4), T(1e4), T(1e4), T(0));
+            if constexpr (PER_ATOM_LJ) l_lj[n_here] = make2<T>(T(0), T(0));
+        }
+        __syncthreads();
+        // the row stream is software-pipelined: row r+JS is in flight while row r is evaluated
+        uint2 e_next = (js < rows) ? my_rows[(int64_t)js * A.BI] : make_uint2(0, 0);
+        for (int r = js; r < rows; r += A.JS) {
+            const uint2 e4 = e_next;
+            if (r + A.JS < rows) e_next = my_rows[(int64_t)(r + A.JS) * A.BI];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            uint32_t e = ((k < 2 ? e4.x : e4.y) >> (16 * (k & 1))) & 0xffffu;
-            uint32_t slot = e & 0x7fffu;
-            bool special = (e >> 15) != 0;
-            T4 pj = l_pos[slot];
-            T2 ljj = make2<T>(T(0), T(0));
-            if constexpr (LJM == LJ_DIST || LJM == LJ_GENERIC) ljj = l_lj[slot];
-            T dx, dy, dz;
-            if constexpr (MINIMG) {
-                dx = G.periodic[0] ? vector_1d_exact(pi.x, pj.x, G.L[0]) : pj.x - pi.x;
-                dy = G.periodic[1] ? vector_1d_exact(pi.y, pj.y, G.L[1]) : pj.y - pi.y;
-                dz = G.periodic[2] ? vector_1d_exact(pi.z, pj.z, G.L[2]) : pj.z - pi.z;
-            } else { dx = pj.x - pi.x; dy = pj.y - pi.y; dz = pj.z - pi.z; }
-            T r2 = dx * dx + dy * dy + dz * dz;
-            T fr = pair_eval<T, LJM, COULM, ENERGY>(A.I, r2, pi.w, pj.w, lji.x, ljj.x, lji.y, ljj.y, special, pe);
-            fx -= fr * dx; fy -= fr * dy; fz -= fr * dz;   // force on i is −f (force.jl:873)
+            for (int k = 0; k < 4; ++k) {
+                uint32_t e = ((k < 2 ? e4.x : e4.y) >> (16 * (k & 1))) & 0xffffu;
+                uint32_t slot = e & 0x7fffu;
+                if constexpr (SEG) { slot -= (uint32_t)seg_lo; slot = slot < (uint32_t)n_here ? slot : (uint32_t)n_here; }
+                bool special = (e >> 15) != 0;
+                T4 pj = l_pos[slot];
+                T2 ljj = make2<T>(T(0), T(0));
+                if constexpr (PER_ATOM_LJ) ljj = l_lj[slot];
+                T dx, dy, dz;
+                if constexpr (MINIMG) {
+                    dx = G.periodic[0] ? vector_1d_exact(pi.x, pj.x, G.L[0]) : pj.x - pi.x;
+                    dy = G.periodic[1] ? vector_1d_exact(pi.y, pj.y, G.L[1]) : pj.y - pi.y;
+                    dz = G.periodic[2] ? vector_1d_exact(pi.z, pj.z, G.L[2]) : pj.z - pi.z;
+                } else { dx = pj.x - pi.x; dy = pj.y - pi.y; dz = pj.z - pi.z; }
+                T r2 = dx * dx + dy * dy + dz * dz;
+                T fr = pair_eval<T, LJM, COULM, ENERGY>(A.I, r2, pi.w, pj.w, lji.x, ljj.x, lji.y, ljj.y, special, pe);
+                fx -= fr * dx; fy -= fr * dy; fz -= fr * dz;   // force on i is −f (force.jl:873)
+            }
         }
     }
     if (A.JS > 1) {   // deterministic reduction of the j-split partial sums through LDS

@@ -174,3 +174,17 @@ def fp32_force_tolerance(case, coords=None, rel=4e-5):
     scale, jump = o.force_scale(nl)
     o.pair_force_scale = scale   # Σ_j‖f_ij‖ per atom, kept for property checks
     return rel * scale + 1.01 * jump + 1e-6, o, nl
+
+
+def rel_rms(err, f_ref):
+    return float(np.sqrt((err ** 2).sum() / (np.linalg.norm(f_ref, axis=1) ** 2).sum()))
+
+
+def fp32_reference_rms(case, f_ref64, coords=None, specific=False, nthreads=8):
+    """Relative RMS force error of the REFERENCE's arithmetic evaluated in fp32 (oracle float instantiation, correctly
+    rounded libm, list order summation) against fp64 on the same inputs: the yardstick for the fp32 HIP path, which
+    must be no worse than 1.5x this (or 5e-6, whichever is larger)."""
+    o32 = case.oracle(np.float32, coords=coords)
+    nl32 = o32.neighbors("cell", nthreads=nthreads) if math.isfinite(case.r_list) else None
+    f32 = o32.forces(nl32, nthreads=1, specific=specific).astype(np.float64)
+    return rel_rms(np.linalg.norm(f32 - f_ref64, axis=1), f_ref64)

@@ -3,8 +3,8 @@
 Bars: neighbour pair SET bit-exact against the same-precision oracle; fp64 forces |ΔF| <= 1e-7 kJ/mol/nm
 and |ΔE| <= 1e-5 kJ/mol-scale relative (the reference's own bars, test/protein.jl:267,274;
 test/gpu_consistency.jl:44 rtol 1e-8); fp32 forces within 4e-5·Σ_j‖f_ij‖ per atom (+ the force jump of
-pairs within 2e-6 of a hard cutoff) and relative RMS 1e-5 (tests/systems.py:fp32_force_tolerance has the
-calibration against the reference arithmetic evaluated in fp32), fp32 energies within 2e-5 relative.
+pairs within 2e-6 of a hard cutoff) and a relative RMS force error no worse than 1.5x that of the reference's own
+arithmetic evaluated in fp32 (tests/systems.py:fp32_reference_rms), fp32 energies within 2e-5 relative.
 """
 import math
 
@@ -87,8 +87,7 @@ def test_forces_and_energy_fp32(pkg, coul):
     f = pkg.forces(s).astype(np.float64)
     err = np.linalg.norm(f - f_ref, axis=1)
     assert np.all(err <= tol), f"worst atom: err {err.max():.3e}, tol there {tol[err.argmax()]:.3e}"
-    rel_rms = np.sqrt((err ** 2).sum() / (np.linalg.norm(f_ref, axis=1) ** 2).sum())
-    assert rel_rms < 1e-5
+    assert S.rel_rms(err, f_ref) <= max(1.5 * S.fp32_reference_rms(case, f_ref), 5e-6)
     e_ref = o.potential_energy(nl)
     e = pkg.potential_energy(s)
     # Σ|e_ij| scale: use the fp64 oracle energy of the absolute values via a generous proxy
@@ -325,7 +324,7 @@ def test_full_size_256k_lj_against_oracle(pkg):
     f = pkg.forces(s).astype(np.float64)
     err = np.linalg.norm(f - f_ref, axis=1)
     assert np.all(err <= tol), f"worst err {err.max():.3e} tol {tol[err.argmax()]:.3e}"
-    assert np.sqrt((err ** 2).sum() / (np.linalg.norm(f_ref, axis=1) ** 2).sum()) < 1e-5
+    assert S.rel_rms(err, f_ref) <= max(1.5 * S.fp32_reference_rms(case, f_ref), 5e-6)
     # Newton's third law: both directions of a pair are evaluated independently in fp32, so ΣF vanishes to rounding
     assert np.abs(f.sum(axis=0)).max() < 1e-6 * o.pair_force_scale.sum()
     st = s.stats()
