@@ -224,6 +224,10 @@ int32_t mhip_scatter_coords(mhip_ctx* ctx, int64_t first, int64_t n, const void*
 /* out4 = {Σ m vx, Σ m vy, Σ m vz, Σ m} over owned atoms, as double[4] on the HOST */
 int32_t mhip_cm_momentum(mhip_ctx* ctx, double* out4);
 int32_t mhip_shift_velocities(mhip_ctx* ctx, const double* dv3);  /* v -= dv3 on owned atoms */
+/* The same without a host round trip: out4_dev (device double[4]) receives this domain's {Σ m v, Σ m}; after the
+ * host all-reduced it over the domains (RCCL), mhip_remove_cm_dev subtracts P/M of the device-resident total. */
+int32_t mhip_cm_momentum_dev(mhip_ctx* ctx, double* out4_dev);
+int32_t mhip_remove_cm_dev(mhip_ctx* ctx, const double* total4_dev);
 
 #ifdef __cplusplus
 }

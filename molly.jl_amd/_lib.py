@@ -90,6 +90,8 @@ SIGNATURES = {
     "mhip_scatter_coords": (_I32, [_P, _I64, _I64, _P]),
     "mhip_cm_momentum": (_I32, [_P, C.POINTER(_D * 4)]),
     "mhip_shift_velocities": (_I32, [_P, C.POINTER(_D * 3)]),
+    "mhip_cm_momentum_dev": (_I32, [_P, _P]),
+    "mhip_remove_cm_dev": (_I32, [_P, _P]),
 }
 
 

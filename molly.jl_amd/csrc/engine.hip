@@ -59,6 +59,8 @@ struct EngineBase {
     virtual void scatter_coords(int64_t, int64_t, const void*) = 0;
     virtual void cm_momentum(double*) = 0;
     virtual void shift_velocities(const double*) = 0;
+    virtual void cm_momentum_dev(double*) = 0;
+    virtual void remove_cm_dev(const double*) = 0;
 };
 
 // hipEvent stage timers (only active while profiling is on)
@@ -620,6 +622,19 @@ template <class T> class Engine final : public EngineBase {
         cm_pending = true; flush_cm();
     }
 
+    void cm_momentum_dev(double* out4_dev) override {
+        flush_cm();
+        cm_partials_now();
+        hipLaunchKernelGGL(k_cm_finalize<T>, dim3(1), dim3(256), 0, stream, cdiv(n_owned, 256), (const double*)red_part.p, out4_dev, (T*)nullptr);
+        MHIP_HIP(hipGetLastError());
+    }
+    void remove_cm_dev(const double* total4_dev) override {
+        flush_cm();
+        hipLaunchKernelGGL(k_vcm_from_total<T>, dim3(1), dim3(64), 0, stream, total4_dev, vcm.p);
+        cm_pending = true;   // subtracted by the next vv_stage1 (or flushed by any state read)
+        MHIP_HIP(hipGetLastError());
+    }
+
     void check_finite() override {
         MHIP_HIP(hipMemsetAsync(flags.p + FLAG_NAN, 0, sizeof(int32_t), stream));
         hipLaunchKernelGGL(k_check_finite<T>, dim3(cdiv(n_owned, 256)), dim3(256), 0, stream, n_owned, (const T4*)pos[cur].p, (const T4*)vel[cur].p, (const T4*)frc[cur].p, flags.p);
@@ -843,5 +858,7 @@ int32_t mhip_gather_coords(mhip_ctx* ctx, const int32_t* idx, const void* shift,
 int32_t mhip_scatter_coords(mhip_ctx* ctx, int64_t first, int64_t n, const void* in) { NEED_CTX(); return guard(ctx, [&] { ctx->e->scatter_coords(first, n, in); }); }
 int32_t mhip_cm_momentum(mhip_ctx* ctx, double* out4) { NEED_CTX(); return guard(ctx, [&] { ctx->e->cm_momentum(out4); }); }
 int32_t mhip_shift_velocities(mhip_ctx* ctx, const double* dv3) { NEED_CTX(); return guard(ctx, [&] { ctx->e->shift_velocities(dv3); }); }
+int32_t mhip_cm_momentum_dev(mhip_ctx* ctx, double* out4) { NEED_CTX(); return guard(ctx, [&] { ctx->e->cm_momentum_dev(out4); }); }
+int32_t mhip_remove_cm_dev(mhip_ctx* ctx, const double* t4) { NEED_CTX(); return guard(ctx, [&] { ctx->e->remove_cm_dev(t4); }); }
 
 }  // extern "C"

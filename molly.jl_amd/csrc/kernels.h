@@ -676,6 +676,12 @@ __global__ void k_cm_finalize(int n_part, const double* __restrict__ cm_part, do
     }
 }
 
+// vcm = P/M from a device-resident {Px,Py,Pz,M} (the all-reduced total of a multi-GPU run)
+template <class T>
+__global__ void k_vcm_from_total(const double* __restrict__ total4, T* vcm) {
+    if (threadIdx.x < 3) vcm[threadIdx.x] = (T)(total4[threadIdx.x] / total4[3]);
+}
+
 template <class T>
 __global__ void k_shift_vel(int64_t n, typename Vec<T>::T4* vel, const T* __restrict__ vcm) {
     int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;

@@ -1,0 +1,407 @@
+"""Spatial domain decomposition of one periodic box over the GPUs of a node — one process per GPU, ghost-atom
+coordinates exchanged with torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+The reference has no multi-device path at all (README.md:54; docs/src/documentation.md:1826,1837): this module is new
+design, following SURVEY.md §8(e).  The box is cut into gx×gy×gz bricks; a rank owns the atoms whose wrapped
+coordinate lies in its brick and keeps, as ghosts, a full shell of width r_list of its neighbours' atoms, already
+shifted by the periodic image that places them next to the brick.  Every pair that touches an owned atom is evaluated
+by the owner (full shell, no ghost-force return), so one exchange of ghost COORDINATES per force evaluation is the only
+data-path communication; migration and the ghost plan are redone at the neighbour-rebuild cadence.
+
+Per step and rank:   stage1 (kick, drift) → pack ghosts (HIP gather kernel) → all_to_all_single → unpack (scatter kernel)
+                     → stage2 (forces, kick) → [all_reduce of 32 B for remove_CM_motion]
+Axes that are not cut (g = 1) stay periodic inside the engine and need no ghosts.
+"""
+import ctypes as C
+import itertools
+import math
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+def choose_grid(world, box):
+    """Factor `world` into gx·gy·gz with the most cubic bricks (1, 2×1×1, 2×2×1, 2×2×2 for a cubic box)."""
+    best, best_score = (world, 1, 1), None
+    for gx in range(1, world + 1):
+        if world % gx:
+            continue
+        for gy in range(1, world // gx + 1):
+            if (world // gx) % gy:
+                continue
+            gz = world // gx // gy
+            b = (box[0] / gx, box[1] / gy, box[2] / gz)
+            score = (max(b) / min(b), -gx, -gy)   # aspect ratio first, then prefer cutting x, y before z
+            if best_score is None or score < best_score:
+                best, best_score = (gx, gy, gz), score
+    return best
+
+
+class BrickGrid:
+    """Geometry of the decomposition: brick of rank r, neighbour directions and their periodic shifts."""
+
+    def __init__(self, box, grid, rank, r_ghost):
+        self.box = np.asarray(box, dtype=np.float64)
+        self.grid = tuple(int(g) for g in grid)
+        self.world = self.grid[0] * self.grid[1] * self.grid[2]
+        self.rank = rank
+        self.r_ghost = float(r_ghost)
+        self.brick = self.box / np.array(self.grid)
+        self.coord = self.coords_of(rank)
+        self.lo = self.brick * np.array(self.coord)
+        self.hi = self.lo + self.brick
+        for d in range(3):
+            if self.grid[d] > 1 and self.brick[d] < self.r_ghost:
+                raise ValueError(f"brick of {self.brick[d]:.3f} nm along axis {d} is narrower than the ghost reach {self.r_ghost:.3f} nm")
+        # the 3^k − 1 neighbour directions over the cut axes, each mapped to (peer rank, coordinate shift of the ghosts)
+        comps = [(-1, 0, 1) if g > 1 else (0,) for g in self.grid]
+        dirs = []
+        for dvec in itertools.product(*comps):
+            if dvec == (0, 0, 0):
+                continue
+            peer_c, shift = [], []
+            for d in range(3):
+                c = self.coord[d] + dvec[d]
+                s = 0.0
+                if c < 0:
+                    c += self.grid[d]; s = +self.box[d]      # my atom appears beyond the peer's upper face
+                elif c >= self.grid[d]:
+                    c -= self.grid[d]; s = -self.box[d]
+                peer_c.append(c); shift.append(s)
+            dirs.append((self.rank_of(tuple(peer_c)), dvec, tuple(shift)))
+        dirs.sort(key=lambda t: (t[0], t[1]))                 # all_to_all wants the segments grouped by peer
+        self.dirs = dirs
+
+    def rank_of(self, c):
+        return (c[2] * self.grid[1] + c[1]) * self.grid[0] + c[0]
+
+    def coords_of(self, r):
+        return (r % self.grid[0], (r // self.grid[0]) % self.grid[1], r // (self.grid[0] * self.grid[1]))
+
+    def owner_of(self, x):
+        """rank owning each wrapped coordinate (n,3) tensor"""
+        r = torch.zeros(x.shape[0], dtype=torch.int64, device=x.device)
+        mul = 1
+        for d in range(3):
+            c = torch.clamp(torch.floor(x[:, d] / self.brick[d]).to(torch.int64), 0, self.grid[d] - 1)
+            r += c * mul
+            mul *= self.grid[d]
+        return r
+
+    def engine_box(self, pad):
+        """(box, origin, periodic) of the local engine: cut axes are open and cover brick + ghost shell + pad"""
+        box, origin, periodic = [], [], []
+        for d in range(3):
+            if self.grid[d] == 1:
+                box.append(self.box[d]); origin.append(0.0); periodic.append(1)
+            else:
+                box.append(self.brick[d] + 2 * (self.r_ghost + pad)); origin.append(self.lo[d] - self.r_ghost - pad); periodic.append(0)
+        return box, origin, periodic
+
+
+class HipDomainEngine:
+    """The per-rank libmollyhip context driven through device pointers of torch tensors."""
+
+    def __init__(self, inter, dtype, capacity, box, origin, periodic, r_list, rebuild_every, device_id):
+        L = _lib.lib()
+        cfg = _lib.Config()
+        cfg.precision = 32 if np.dtype(dtype) == np.float32 else 64
+        cfg.device_id = device_id
+        cfg.n_atoms = capacity
+        for d in range(3):
+            cfg.box[d], cfg.origin[d], cfg.periodic[d] = box[d], origin[d], periodic[d]
+        cfg.rebuild_every = rebuild_every
+        cfg.r_list = r_list
+        cfg.inter = inter
+        self.ctx = C.c_void_p()
+        rc = L.mhip_create(C.byref(self.ctx), C.byref(cfg))
+        if rc != 0:
+            raise _lib.MollyHipError(rc, L.mhip_last_error(None).decode())
+        self.L = L
+        self.capacity = capacity
+        self._chk(L.mhip_set_stream(self.ctx, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise _lib.MollyHipError(rc, self.L.mhip_last_error(self.ctx).decode())
+
+    @staticmethod
+    def _p(t):
+        return None if t is None else C.c_void_p(t.data_ptr())
+
+    def set_local(self, n_owned, n_ghost, q, sigma, eps, mass, x_all, v_owned):
+        if n_owned + n_ghost > self.capacity:
+            raise _lib.MollyHipError(-4, f"domain holds {n_owned}+{n_ghost} atoms, engine capacity is {self.capacity}")
+        self._chk(self.L.mhip_set_atom_counts(self.ctx, n_owned, n_ghost))
+        self._keep = (q.contiguous(), sigma.contiguous(), eps.contiguous(), mass.contiguous(), x_all.contiguous(), v_owned.contiguous())
+        self._chk(self.L.mhip_set_atoms(self.ctx, *[self._p(t) for t in self._keep[:4]], None, _lib.MEM_DEVICE))
+        self._chk(self.L.mhip_set_state(self.ctx, self._p(self._keep[4]), self._p(self._keep[5]), _lib.MEM_DEVICE))
+
+    def gather(self, idx_i32, shift, out):
+        self._chk(self.L.mhip_gather_coords(self.ctx, self._p(idx_i32), self._p(shift), idx_i32.numel(), self._p(out)))
+
+    def scatter(self, first, n, buf):
+        self._chk(self.L.mhip_scatter_coords(self.ctx, first, n, self._p(buf)))
+
+    def vv_init(self, step):
+        self._chk(self.L.mhip_vv_init(self.ctx, step))
+
+    def stage1(self, dt):
+        self._chk(self.L.mhip_vv_stage1(self.ctx, dt))
+
+    def stage2(self, step, dt):
+        self._chk(self.L.mhip_vv_stage2(self.ctx, step, dt))
+
+    def get_state(self, x_all, v_owned):
+        self._chk(self.L.mhip_get_state(self.ctx, self._p(x_all), self._p(v_owned), _lib.MEM_DEVICE))
+
+    def cm_momentum(self, out4):          # device double[4]
+        self._chk(self.L.mhip_cm_momentum_dev(self.ctx, self._p(out4)))
+
+    def remove_cm(self, total4):
+        self._chk(self.L.mhip_remove_cm_dev(self.ctx, self._p(total4)))
+
+    def synchronize(self):
+        self._chk(self.L.mhip_synchronize(self.ctx))
+
+    def set_profiling(self, on):
+        self._chk(self.L.mhip_set_profiling(self.ctx, int(on)))
+
+    def stats(self):
+        st = _lib.Stats()
+        self._chk(self.L.mhip_get_stats(self.ctx, C.byref(st)))
+        return st.as_dict()
+
+    def close(self):
+        if self.ctx:
+            self.L.mhip_destroy(self.ctx)
+            self.ctx = None
+
+
+class DomainRun:
+    """One rank's share of a velocity-Verlet run.  `engine` implements set_local / gather / scatter / vv_init / stage1 /
+    stage2 / get_state / cm_momentum / remove_cm (HipDomainEngine on the GPU, an oracle-backed stand-in in the CPU tests)."""
+
+    def __init__(self, grid: BrickGrid, engine, tdtype, device, rebuild_every, group=None):
+        self.g, self.e = grid, engine
+        self.tdtype, self.device = tdtype, device
+        self.every = rebuild_every
+        self.group = group
+        self.world, self.rank = grid.world, grid.rank
+        self.boxt = torch.tensor(grid.box, dtype=tdtype, device=device)
+        self.n_owned = self.n_ghost = 0
+        self.cm_buf = torch.zeros(4, dtype=torch.float64, device=device)
+        self.stats = {"exchange_calls": 0, "ghost_atoms": 0, "migrated": 0}
+        # gloo cannot move device memory: stage through the host (used by the multi-process tests that share ONE GPU;
+        # the production path is backend "nccl" = RCCL, device buffers end to end)
+        self.stage_host = torch.device(device).type == "cuda" and dist.get_backend(group) == "gloo"
+
+    def _a2a(self, recv, send, rc=None, sc=None):
+        if self.stage_host:
+            r = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_to_all_single(r, send.cpu(), rc, sc, group=self.group)
+            recv.copy_(r)
+        else:
+            dist.all_to_all_single(recv, send, rc, sc, group=self.group)
+
+    def _all_reduce(self, t):
+        if self.stage_host:
+            c = t.cpu(); dist.all_reduce(c, group=self.group); t.copy_(c)
+        else:
+            dist.all_reduce(t, group=self.group)
+
+    def _all_gather(self, t):
+        if self.stage_host:
+            out = [torch.empty(t.shape, dtype=t.dtype) for _ in range(self.world)]
+            dist.all_gather(out, t.cpu(), group=self.group)
+            return out
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t, group=self.group)
+        return out
+
+    # -- setup from the full system (every rank generates the same synthetic system and keeps its atoms) -------------
+    def setup_from_global(self, coords, velocities, charge, sigma, eps, mass, step=0):
+        x = torch.as_tensor(np.asarray(coords), dtype=self.tdtype, device=self.device)
+        x = x - torch.floor(x / self.boxt) * self.boxt
+        mine = self.g.owner_of(x) == self.rank
+        idx = torch.nonzero(mine).squeeze(1)
+        tt = lambda a: torch.as_tensor(np.asarray(a), dtype=self.tdtype, device=self.device)[idx].contiguous()
+        self.gid = idx.to(torch.int64)
+        self.x, self.v = x[idx].contiguous(), tt(velocities)
+        self.par = torch.stack([tt(charge), tt(sigma), tt(eps), tt(mass)], dim=1).contiguous()
+        self._plan_and_load(step)
+
+    # -- ghost plan: which of my atoms go to which neighbour, with which periodic shift -------------------------------
+    def _plan_and_load(self, step):
+        g = self.g
+        n = self.x.shape[0]
+        rg = g.r_ghost
+        near = []   # per axis: [3, n] rows = near lower face, always, near upper face
+        for d in range(3):
+            xd = self.x[:, d]
+            lo = xd < (g.lo[d] + rg)
+            hi = xd >= (g.hi[d] - rg)
+            near.append(torch.stack([lo, torch.ones_like(lo), hi]))
+        if g.dirs:
+            sel = torch.stack([near[0][dv[0] + 1] & near[1][dv[1] + 1] & near[2][dv[2] + 1] for (_, dv, _) in g.dirs])   # [ndir, n]
+            pairs = torch.nonzero(sel)                      # sorted by direction, then atom
+            self.send_idx = pairs[:, 1].to(torch.int32).contiguous()
+            per_dir = torch.bincount(pairs[:, 0], minlength=len(g.dirs))
+            shifts = torch.tensor([s for (_, _, s) in g.dirs], dtype=self.tdtype, device=self.device)
+            self.send_shift = shifts[pairs[:, 0]].contiguous()
+            peer_of_dir = torch.tensor([p for (p, _, _) in g.dirs], dtype=torch.int64, device=self.device)
+            send_counts = torch.zeros(self.world, dtype=torch.int64, device=self.device).index_add_(0, peer_of_dir, per_dir)
+        else:
+            self.send_idx = torch.zeros(0, dtype=torch.int32, device=self.device)
+            self.send_shift = torch.zeros((0, 3), dtype=self.tdtype, device=self.device)
+            send_counts = torch.zeros(self.world, dtype=torch.int64, device=self.device)
+        recv_counts = torch.empty_like(send_counts)
+        self._a2a(recv_counts, send_counts)
+        self.send_counts, self.recv_counts = send_counts.tolist(), recv_counts.tolist()     # one host sync per rebuild
+        self.n_owned, self.n_ghost = n, int(sum(self.recv_counts))
+        # ghost parameters (charge, σ, ϵ, mass) and first ghost coordinates
+        send_par = self.par[self.send_idx.long()].contiguous()
+        recv_par = torch.empty((self.n_ghost, 4), dtype=self.tdtype, device=self.device)
+        self._a2a_rows(recv_par, send_par)
+        send_x = (self.x[self.send_idx.long()] + self.send_shift).contiguous()
+        self.recv_x = torch.empty((self.n_ghost, 3), dtype=self.tdtype, device=self.device)
+        self._a2a_rows(self.recv_x, send_x)
+        self.send_buf = torch.empty((self.send_idx.numel(), 3), dtype=self.tdtype, device=self.device)
+        par_all = torch.cat([self.par, recv_par], dim=0)
+        x_all = torch.cat([self.x, self.recv_x], dim=0).contiguous()
+        self.e.set_local(self.n_owned, self.n_ghost, par_all[:, 0], par_all[:, 1], par_all[:, 2], par_all[:, 3], x_all, self.v)
+        self.e.vv_init(step)                                 # neighbour structures + forces at this step
+        self.stats["ghost_atoms"] = self.n_ghost
+
+    def _a2a_rows(self, recv, send):
+        w = recv.shape[1]
+        self._a2a(recv.view(-1), send.view(-1), [c * w for c in self.recv_counts], [c * w for c in self.send_counts])
+
+    # -- one MD step ------------------------------------------------------------------------------------------------
+    def exchange_ghosts(self):
+        if self.world == 1 or not self.g.dirs:
+            return
+        self.e.gather(self.send_idx, self.send_shift, self.send_buf)
+        self._a2a_rows(self.recv_x, self.send_buf)
+        self.e.scatter(self.n_owned, self.n_ghost, self.recv_x)
+        self.stats["exchange_calls"] += 1
+
+    def step(self, step_n, dt, remove_cm_every=1):
+        self.e.stage1(dt)
+        self.exchange_ghosts()
+        self.e.stage2(step_n, dt)
+        if remove_cm_every and step_n % remove_cm_every == 0:
+            self.e.cm_momentum(self.cm_buf)
+            self._all_reduce(self.cm_buf)
+            self.e.remove_cm(self.cm_buf)
+        if step_n % self.every == 0:
+            self.migrate(step_n)
+
+    def run(self, first_step, n_steps, dt, remove_cm_every=1):
+        for s in range(first_step + 1, first_step + n_steps + 1):
+            self.step(s, dt, remove_cm_every)
+
+    # -- migration at the rebuild cadence -------------------------------------------------------------------------------
+    def pull(self):
+        x_all = torch.empty((self.n_owned + self.n_ghost, 3), dtype=self.tdtype, device=self.device)
+        self.e.get_state(x_all, self.v)
+        self.x = x_all[: self.n_owned].contiguous()
+
+    def migrate(self, step):
+        self.pull()
+        x = self.x - torch.floor(self.x / self.boxt) * self.boxt      # wrap the cut (open) axes too
+        dest = self.g.owner_of(x)
+        order = torch.argsort(dest, stable=True)
+        send_counts = torch.bincount(dest, minlength=self.world)
+        recv_counts = torch.empty_like(send_counts)
+        self._a2a(recv_counts, send_counts)
+        sc, rc = send_counts.tolist(), recv_counts.tolist()
+        payload = torch.cat([x, self.v, self.par], dim=1)[order].contiguous()         # 10 reals per atom
+        gid = self.gid[order].contiguous()
+        n_new = int(sum(rc))
+        rp = torch.empty((n_new, 10), dtype=self.tdtype, device=self.device)
+        rg = torch.empty(n_new, dtype=torch.int64, device=self.device)
+        self._a2a(rp.view(-1), payload.view(-1), [c * 10 for c in rc], [c * 10 for c in sc])
+        self._a2a(rg, gid, rc, sc)
+        self.stats["migrated"] += int(self.n_owned - sc[self.rank])
+        o = torch.argsort(rg)                                          # deterministic local order: by global atom id
+        self.gid = rg[o].contiguous()
+        rp = rp[o]
+        self.x, self.v, self.par = rp[:, 0:3].contiguous(), rp[:, 3:6].contiguous(), rp[:, 6:10].contiguous()
+        self._plan_and_load(step)
+
+    # -- gather the whole system on every rank (tests / final state) ------------------------------------------------------
+    def gather_global(self, n_total):
+        self.pull()
+        counts = [int(c.item()) for c in self._all_gather(torch.tensor([self.n_owned], dtype=torch.int64, device=self.device))]
+        mx = max(counts)
+        pack = torch.zeros((mx, 7), dtype=torch.float64, device=self.device)
+        pack[: self.n_owned, 0] = self.gid.to(torch.float64)
+        pack[: self.n_owned, 1:4] = self.x.to(torch.float64)
+        pack[: self.n_owned, 4:7] = self.v.to(torch.float64)
+        out = self._all_gather(pack)
+        xs = np.zeros((n_total, 3)); vs = np.zeros((n_total, 3))
+        for r, t in enumerate(out):
+            t = t[: counts[r]].cpu().numpy()
+            ids = t[:, 0].astype(np.int64)
+            xs[ids], vs[ids] = t[:, 1:4], t[:, 4:7]
+        return xs, vs
+
+
+def make_interactions(case, dtype):
+    """mhip_interactions of a tests.systems.Case-like description (lj / coul dicts) without building a System."""
+    it = _lib.Interactions()
+    d = case.inter_dict(dtype)
+    it.lj_weight_special = 1.0; it.coul_weight_special = 1.0; it.coul_ke = 138.93545764; it.rf_dielectric = 1.0; it.ewald_approx_erfc = 1
+    for k, v in d.items():
+        setattr(it, k, v)
+    return it
+
+
+def bench_distributed(m, case, dtype, dt, args, rank, local_rank, world):
+    """bench.py body for N > 1: strong scaling of one box over `world` GPUs.  Returns (ms_per_step, stats, extra) on rank 0."""
+    if case.excluded is not None or case.bonds is not None:
+        raise SystemExit("the multi-GPU path covers exception-free systems (LJ fluids); 6mrr runs as replicas only (SURVEY §8(e))")
+    torch.cuda.set_device(local_rank)
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    tdtype = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
+    grid = choose_grid(world, case.box)
+    bg = BrickGrid(case.box, grid, rank, case.r_list)
+    box, origin, periodic = bg.engine_box(pad=0.3)
+    vol_frac = np.prod([b / L for b, L in zip(box, case.box)])
+    capacity = int(case.n * min(1.0, vol_frac) * 1.25) + 4096
+    eng = HipDomainEngine(make_interactions(case, dtype), dtype, capacity, box, origin, periodic, case.r_list, case.rebuild_every, local_rank)
+    run = DomainRun(bg, eng, tdtype, device, case.rebuild_every)
+    run.setup_from_global(case.coords, case.velocities, np.zeros(case.n) if case.charge is None else case.charge, case.sigma, case.eps, case.mass)
+    run.run(0, args.warmup, dt)
+    torch.cuda.synchronize(); dist.barrier()
+    t0 = time.perf_counter()
+    run.run(args.warmup, args.steps, dt)
+    torch.cuda.synchronize(); dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    ms_per_step = float(el.item()) * 1e3 / args.steps
+    eng.set_profiling(True)
+    run.run(args.warmup + args.steps, args.profile_steps, dt)
+    torch.cuda.synchronize()
+    st = eng.stats()
+    eng.set_profiling(False)
+    # whole-job figures for the roofline block: pairs and bytes summed over the ranks
+    tot = torch.tensor([st["n_pairs_full"], st["force_pass_bytes"], st["algorithmic_bytes_step"], run.n_ghost, run.n_owned], dtype=torch.float64, device=device)
+    per_rank = [torch.zeros_like(tot) for _ in range(world)]
+    dist.all_gather(per_rank, tot)
+    dist.barrier()
+    if rank != 0:
+        return None
+    agg = torch.stack(per_rank).sum(0).tolist()
+    st["n_pairs_full"] = int(agg[0])
+    extra = {"parallelism": f"spatial bricks {grid[0]}x{grid[1]}x{grid[2]}, full-shell ghost coordinates via all_to_all_single (RCCL), "
+                            f"{int(agg[3] / world)} ghosts / {int(agg[4] / world)} owned atoms per GPU",
+             "per_gpu_force_pass_bytes": st["force_pass_bytes"], "ghost_fraction": agg[3] / max(agg[4], 1)}
+    return ms_per_step, st, extra
