@@ -111,6 +111,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise MollyHipError(-5, f"{LIB_PATH} is missing: build it with molly_jl_amd.build() "
                                     "(the product path has no CPU fallback)")
+        # PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 with the same SONAMEs as /opt/rocm's.  The
+        # first one loaded serves the whole process, and torch cannot initialise on top of the system copies — so when
+        # torch is installed it is imported FIRST and libmollyhip.so binds to the runtime torch brought (one HIP runtime
+        # per process: device pointers, the null stream and RCCL all live in it).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)   # AttributeError if the library does not export a declared symbol

@@ -366,9 +366,17 @@ def bench_distributed(m, case, dtype, dt, args, rank, local_rank, world):
     """bench.py body for N > 1: strong scaling of one box over `world` GPUs.  Returns (ms_per_step, stats, extra) on rank 0."""
     if case.excluded is not None or case.bonds is not None:
         raise SystemExit("the multi-GPU path covers exception-free systems (LJ fluids); 6mrr runs as replicas only (SURVEY §8(e))")
+    import os
+    # test hooks: several ranks on ONE GPU (the single-GPU box) with gloo + host staging; production = one GPU per rank, RCCL
+    backend = os.environ.get("MOLLYHIP_DIST_BACKEND", "nccl")
+    if "MOLLYHIP_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["MOLLYHIP_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     if not dist.is_initialized():
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     device = torch.device("cuda", local_rank)
     tdtype = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
     grid = choose_grid(world, case.box)
@@ -384,7 +392,7 @@ def bench_distributed(m, case, dtype, dt, args, rank, local_rank, world):
     t0 = time.perf_counter()
     run.run(args.warmup, args.steps, dt)
     torch.cuda.synchronize(); dist.barrier()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     ms_per_step = float(el.item()) * 1e3 / args.steps
     eng.set_profiling(True)
@@ -393,7 +401,8 @@ def bench_distributed(m, case, dtype, dt, args, rank, local_rank, world):
     st = eng.stats()
     eng.set_profiling(False)
     # whole-job figures for the roofline block: pairs and bytes summed over the ranks
-    tot = torch.tensor([st["n_pairs_full"], st["force_pass_bytes"], st["algorithmic_bytes_step"], run.n_ghost, run.n_owned], dtype=torch.float64, device=device)
+    tot = torch.tensor([st["n_pairs_full"], st["force_pass_bytes"], st["algorithmic_bytes_step"], run.n_ghost, run.n_owned], dtype=torch.float64,
+                       device=device if backend == "nccl" else "cpu")
     per_rank = [torch.zeros_like(tot) for _ in range(world)]
     dist.all_gather(per_rank, tot)
     dist.barrier()
