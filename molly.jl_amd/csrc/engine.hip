@@ -113,7 +113,8 @@ template <class T> class Engine final : public EngineBase {
     DBuf<uint32_t> key_in, key_out, cell_rank; DBuf<int32_t> idx_in, perm, cell_cnt, cell_start; DBuf<unsigned char> cub_tmp;
     bool hilbert_ok = true;
     // exceptions (CSR over caller indices)
-    DBuf<int32_t> ex_start, ex_list, sp_start, sp_list; bool has_exc = false;
+    DBuf<int32_t> xl_start; DBuf<uint32_t> xl_list; bool has_exc = false; int xl_span = 0;
+    static constexpr int X_CAP = 32;
     // blocks
     int BI = 256, JS = 1, n_blocks = 0, T_cap = 0, R_cap = 0, C_cap = 0, max_tile = 0, max_rows = 0;
     int ljm_base = LJ_OFF;   // LJ mode implied by the interaction; ljm may be upgraded to the uniform fast path
@@ -165,7 +166,7 @@ template <class T> class Engine final : public EngineBase {
         if (stream) (void)hipStreamSynchronize(stream);
         for (int k = 0; k < 2; ++k) { pos[k].release(); vel[k].release(); frc[k].release(); lj[k].release(); orig[k].release(); }
         inv.release(); key_in.release(); key_out.release(); cell_rank.release(); idx_in.release(); perm.release(); cell_cnt.release(); cell_start.release(); cub_tmp.release();
-        ex_start.release(); ex_list.release(); sp_start.release(); sp_list.release(); tile_idx.release(); tile_cnt.release(); wave_rows.release(); nbr.release(); blk_center.release();
+        xl_start.release(); xl_list.release(); tile_idx.release(); tile_cnt.release(); wave_rows.release(); nbr.release(); blk_center.release();
         flags.release(); red_part.release(); red_out.release(); vcm.release(); stage_a.release(); stage_b.release(); stage_i.release(); bonded.release();
         prof.release();
         if (h_flags) (void)hipHostFree(h_flags);
@@ -225,8 +226,8 @@ template <class T> class Engine final : public EngineBase {
 
     size_t build_lds_bytes(int tcap, int bi, int ccap) const {
         // tile (coords + slot) | max(cell tables, per-wave candidate bit masks) | scan scratch
-        // tile (coords + slot) | cell tables | scan scratch
-        return (size_t)tcap * (sizeof(T4) + 4) + (2 * (size_t)ccap + 2) * 4 + 8 + (size_t)bi * 4 + 64;
+        // tile (coords + caller index) | cell tables | scan scratch | per-lane exception lists
+        return (size_t)tcap * (sizeof(float4) + 4) + (2 * (size_t)ccap + 2) * 4 + 8 + (size_t)bi * JS * 4 + (has_exc ? (size_t)X_CAP * bi * 4 : 0) + 64;
     }
     size_t force_lds_bytes(int tlds) const {
         const bool per_atom_lj = (ljm == LJ_DIST || ljm == LJ_GENERIC);
@@ -238,7 +239,7 @@ template <class T> class Engine final : public EngineBase {
     void choose_blocking() {
         // i-block size and j-split: enough waves to fill 256 CUs × 4 SIMDs even for small systems
         int bi, js;
-        if (n_owned >= 100000) { bi = 256; js = 1; }
+        if (n_owned >= 100000) { bi = 256; js = 2; }
         else if (n_owned >= 40000) { bi = 128; js = 2; }
         else { bi = 64; js = 8; }
         bi = env_int("MOLLYHIP_BLOCK_I", bi); js = env_int("MOLLYHIP_J_SPLIT", js);
@@ -257,7 +258,7 @@ template <class T> class Engine final : public EngineBase {
             double r = cfg.r_list * 1.001, a = std::cbrt(BI / rho);
             double v_tile = a * a * a + 6 * a * a * r + 3 * M_PI * a * r * r + 4.0 / 3.0 * M_PI * r * r * r;
             T_cap = (int)std::min<double>(1.4 * rho * v_tile + 64, (double)n_tot + 8);
-            R_cap = (int)std::min<double>(1.5 * rho * 4.0 / 3.0 * M_PI * r * r * r / 4 + 8, n_tot / 4.0 + 2);
+            R_cap = (int)std::min<double>(1.5 * rho * 4.0 / 3.0 * M_PI * r * r * r / 4 / JS + 8, n_tot / 4.0 + 2);
             double cells = 1;
             for (int d = 0; d < 3; ++d) cells *= std::min<double>(G.nc[d], (1.3 * a + 2 * r) / (cfg.box[d] / G.nc[d]) + 2);
             C_cap = (int)std::min<double>(cells * 1.2 + 8, MAX_BOX_CELLS);
@@ -315,20 +316,20 @@ template <class T> class Engine final : public EngineBase {
                 if (BI > 64) { BI /= 2; JS = std::min(JS * 2, 1024 / BI); estimate_capacities(); continue; }
                 throw ApiError{MHIP_ERR_CAPACITY, "neighbourhood tile of one 64-atom block does not fit the 160 KiB LDS (r_list too large for this density)"};
             }
-            tile_idx.reserve((size_t)n_blocks * T_cap); tile_cnt.reserve(n_blocks); wave_rows.reserve((size_t)n_blocks * (BI / WAVE));
-            nbr.reserve((size_t)n_blocks * R_cap * BI); blk_center.reserve(n_blocks);
+            tile_idx.reserve((size_t)n_blocks * T_cap); tile_cnt.reserve(n_blocks); wave_rows.reserve((size_t)n_blocks * JS * (BI / WAVE));
+            nbr.reserve((size_t)n_blocks * JS * R_cap * BI); blk_center.reserve(n_blocks);
             MHIP_HIP(hipMemsetAsync(flags.p, 0, N_FLAGS * sizeof(int32_t), stream));
             BuildArgs<T> A;
-            A.G = G; A.n_owned = n_owned; A.n_tot = n_tot; A.BI = BI; A.T_cap = T_cap; A.R_cap = R_cap; A.C_cap = C_cap;
+            A.G = G; A.n_owned = n_owned; A.n_tot = n_tot; A.BI = BI; A.BI_shift = ilog2(BI); A.JS = JS; A.T_cap = T_cap; A.R_cap = R_cap; A.C_cap = C_cap;
             A.pos = pos[cur].p; A.orig = orig[cur].p; A.cell_start = cell_start.p; A.cell_rank = cell_rank.p;
-            A.ex_start = has_exc ? ex_start.p : nullptr; A.ex_list = ex_list.p; A.sp_start = sp_start.p; A.sp_list = sp_list.p;
+            A.xl_start = has_exc ? xl_start.p : nullptr; A.xl_list = xl_list.p; A.xl_span = xl_span; A.X_cap = X_CAP;
             A.tile_idx = tile_idx.p; A.tile_cnt = tile_cnt.p; A.nbr = nbr.p; A.wave_rows = wave_rows.p; A.blk_center = blk_center.p; A.flags = flags.p;
             A.margin = G.no_list ? T(0) : G.r_list * T(1e-3);
             A.debug = env_int("MOLLYHIP_BUILD_DEBUG", 0);
             set_lds_limit(k_build<T>, lds);
             prof.begin(1, stream);
-            hipLaunchKernelGGL(k_build<T>, dim3(n_blocks), dim3(BI), lds, stream, A);
-            hipLaunchKernelGGL(k_build_summary, dim3(1), dim3(256), 0, stream, n_blocks, n_blocks * (BI / WAVE), R_cap, (const int32_t*)tile_cnt.p, wave_rows.p, flags.p);
+            hipLaunchKernelGGL(k_build<T>, dim3(n_blocks), dim3(BI * JS), lds, stream, A);
+            hipLaunchKernelGGL(k_build_summary, dim3(1), dim3(256), 0, stream, n_blocks, n_blocks * JS * (BI / WAVE), R_cap, (const int32_t*)tile_cnt.p, wave_rows.p, flags.p);
             prof.end(1, stream);
             MHIP_HIP(hipGetLastError());
             MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
@@ -498,23 +499,33 @@ template <class T> class Engine final : public EngineBase {
     }
 
     void set_exceptions(const int32_t* ei, const int32_t* ej, int64_t ne, const int32_t* si, const int32_t* sj, int64_t ns) override {
-        auto csr = [&](const int32_t* a, const int32_t* b, int64_t m, DBuf<int32_t>& start, DBuf<int32_t>& list) {
-            std::vector<int32_t> st(cap + 1, 0), ls(2 * (size_t)m);
+        // one CSR over caller indices holding both kinds; excluded beats special (neighbors.jl:410-411 tests eligible first)
+        std::vector<std::vector<uint32_t>> adj(cap);
+        int span = 0;
+        auto add = [&](const int32_t* a, const int32_t* b, int64_t m, uint32_t flag) {
             for (int64_t k = 0; k < m; ++k) {
                 if (a[k] < 0 || b[k] < 0 || a[k] >= cap || b[k] >= cap || a[k] == b[k]) throw ApiError{MHIP_ERR_INVALID, "exception pair index out of range"};
-                st[a[k] + 1]++; st[b[k] + 1]++;
+                for (int dir = 0; dir < 2; ++dir) {
+                    uint32_t me = dir ? b[k] : a[k], other = dir ? a[k] : b[k];
+                    bool found = false;
+                    for (auto& e : adj[me]) if ((e & XL_INDEX) == other) { e |= flag; found = true; }
+                    if (!found) adj[me].push_back(other | flag);
+                }
+                span = std::max(span, std::abs(a[k] - b[k]));
             }
-            for (int64_t i = 0; i < cap; ++i) st[i + 1] += st[i];
-            std::vector<int32_t> fill(st.begin(), st.end() - 1);
-            for (int64_t k = 0; k < m; ++k) { ls[fill[a[k]]++] = b[k]; ls[fill[b[k]]++] = a[k]; }
-            start.reserve(cap + 1); list.reserve(std::max<size_t>(ls.size(), 1));
-            MHIP_HIP(hipMemcpy(start.p, st.data(), (cap + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
-            if (!ls.empty()) MHIP_HIP(hipMemcpy(list.p, ls.data(), ls.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         };
+        add(ei, ej, ne, XL_EXCLUDED);
+        add(si, sj, ns, XL_SPECIAL);
+        std::vector<int32_t> st(cap + 1, 0);
+        for (int64_t i = 0; i < cap; ++i) st[i + 1] = st[i] + (int32_t)adj[i].size();
+        std::vector<uint32_t> ls((size_t)st[cap]);
+        for (int64_t i = 0; i < cap; ++i) std::copy(adj[i].begin(), adj[i].end(), ls.begin() + st[i]);
         MHIP_HIP(hipStreamSynchronize(stream));
         has_exc = (ne + ns) > 0;
-        csr(ei, ej, ne, ex_start, ex_list);
-        csr(si, sj, ns, sp_start, sp_list);
+        xl_span = span;
+        xl_start.reserve(cap + 1); xl_list.reserve(std::max<size_t>(ls.size(), 1));
+        MHIP_HIP(hipMemcpy(xl_start.p, st.data(), (cap + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+        if (!ls.empty()) MHIP_HIP(hipMemcpy(xl_list.p, ls.data(), ls.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         stale = true;   // ≙ cache invalidation after append_excluded_pairs! (test/gpu_consistency.jl:494-527)
     }
 
@@ -698,7 +709,7 @@ template <class T> class Engine final : public EngineBase {
         if (stale) throw ApiError{MHIP_ERR_STATE, "no neighbour list: call forces / rebuild first"};
         DBuf<unsigned long long> counter; counter.reserve(1);
         MHIP_HIP(hipMemsetAsync(counter.p, 0, sizeof(unsigned long long), stream));
-        hipLaunchKernelGGL(k_export_nl<T>, dim3(n_blocks), dim3(BI), 0, stream, n_blocks, BI, T_cap, R_cap, n_owned, (const int32_t*)orig[cur].p, (const int32_t*)tile_idx.p,
+        hipLaunchKernelGGL(k_export_nl<T>, dim3(n_blocks), dim3(BI), 0, stream, n_blocks, BI, JS, T_cap, R_cap, n_owned, (const int32_t*)orig[cur].p, (const int32_t*)tile_idx.p,
                            (const int32_t*)tile_cnt.p, (const uint2*)nbr.p, (const int32_t*)wave_rows.p, (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr, counter.p, 0ull);
         unsigned long long n = 0;
         MHIP_HIP(hipMemcpyAsync(&n, counter.p, sizeof(n), hipMemcpyDeviceToHost, stream));
@@ -706,7 +717,7 @@ template <class T> class Engine final : public EngineBase {
         if (oi && (int64_t)n <= capacity && n > 0) {
             DBuf<int32_t> di, dj; DBuf<uint8_t> ds; di.reserve(n); dj.reserve(n); ds.reserve(n);
             MHIP_HIP(hipMemsetAsync(counter.p, 0, sizeof(unsigned long long), stream));
-            hipLaunchKernelGGL(k_export_nl<T>, dim3(n_blocks), dim3(BI), 0, stream, n_blocks, BI, T_cap, R_cap, n_owned, (const int32_t*)orig[cur].p, (const int32_t*)tile_idx.p,
+            hipLaunchKernelGGL(k_export_nl<T>, dim3(n_blocks), dim3(BI), 0, stream, n_blocks, BI, JS, T_cap, R_cap, n_owned, (const int32_t*)orig[cur].p, (const int32_t*)tile_idx.p,
                                (const int32_t*)tile_cnt.p, (const uint2*)nbr.p, (const int32_t*)wave_rows.p, di.p, dj.p, ds.p, counter.p, n);
             MHIP_HIP(hipMemcpyAsync(oi, di.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
             MHIP_HIP(hipMemcpyAsync(oj, dj.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));

@@ -19,6 +19,7 @@ enum { FLAG_MINIMG = 0, FLAG_OVERFLOW = 1, FLAG_MAX_TILE = 2, FLAG_MAX_ROWS = 3,
 enum { OVF_TILE = 1, OVF_ROWS = 2, OVF_BOXCELLS = 4, OVF_SLOT = 8 };
 
 constexpr int MAX_BOX_CELLS = 8192;
+constexpr uint32_t XL_EXCLUDED = 1u << 30, XL_SPECIAL = 1u << 31, XL_INDEX = (1u << 30) - 1u;
 
 // ---------------------------------------------------------------------------------------------------
 // small helpers
@@ -132,16 +133,20 @@ __global__ void k_permute(int64_t n_tot, const int32_t* __restrict__ perm, const
 template <class T> struct BuildArgs {
     GridP<T> G;
     int64_t n_owned, n_tot;
-    int BI, T_cap, R_cap, C_cap;     // i-atoms per block; capacities: tile atoms, list rows per block, box cells
+    int BI, BI_shift, JS;            // i-atoms per block; waves sharing one i-atom (each takes every JS-th group of 64 tile atoms)
+    int T_cap, R_cap, C_cap;         // capacities: tile atoms, list rows per (block, j-split), box cells
     const typename Vec<T>::T4* pos;
     const int32_t* orig;
     const int32_t* cell_start;       // 2*ncell+1: owned cells then ghost cells, in Hilbert-rank order
     const uint32_t* cell_rank;
-    const int32_t *ex_start, *ex_list, *sp_start, *sp_list;   // CSR over caller indices (may be null)
+    const int32_t* xl_start;         // exceptions, CSR over caller indices (null: none). Entry = partner caller index
+    const uint32_t* xl_list;         //   | XL_EXCLUDED (bit 30) | XL_SPECIAL (bit 31); a pair in both lists is excluded
+    int xl_span;                     // max |i - j| over all exception pairs: candidates further apart in caller index skip the scan
+    int X_cap;                       // per-lane LDS capacity of the exception list
     int32_t* tile_idx;               // [n_blocks][T_cap] sorted slot of each tile atom
     int32_t* tile_cnt;               // [n_blocks]
-    uint2* nbr;                      // [n_blocks][R_cap][BI] 4×uint16 entries
-    int32_t* wave_rows;              // [n_blocks][BI/64]
+    uint2* nbr;                      // [n_blocks][JS][R_cap][BI] 4×uint16 entries
+    int32_t* wave_rows;              // [n_blocks][JS][BI/64]
     typename Vec<T>::T4* blk_center; // [n_blocks] centre (xyz) of the block's bounding box at build time
     int32_t* flags;
     T margin;
@@ -178,18 +183,23 @@ __global__ void k_build(BuildArgs<T> A) {
     using T4 = typename Vec<T>::T4;
     extern __shared__ __align__(32) unsigned char smem[];
     const GridP<T>& G = A.G;
-    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, NW = nthr >> 6;
-    T4* t_pos = reinterpret_cast<T4*>(smem);                 // tile atoms: block-local coords (or wrapped coords if exact_only)
-    int32_t* t_slot = reinterpret_cast<int32_t*>(t_pos + A.T_cap);
-    int32_t* c_raw = t_slot + A.T_cap;                        // C_cap + 1: offsets of the cell-pruned candidate stream
+    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv_all = tid >> 6, NW_ALL = nthr >> 6;
+    const int li = tid & (A.BI - 1), js = tid >> A.BI_shift;   // thread = (j-split, i-atom); every j-split group sees the same i-atoms
+    const int wv = li >> 6, NW = A.BI >> 6;                    // i-wave of my atom, i-waves per block
+    // tile atoms in block-local coordinates, ALWAYS fp32: the search only needs them for the cheap pre-test, whose
+    // 1e-4 band absorbs the rounding; decisions inside the band use the stored T coordinates from HBM
+    float4* t_pos = reinterpret_cast<float4*>(smem);
+    int32_t* t_orig = reinterpret_cast<int32_t*>(t_pos + A.T_cap);   // caller index of each tile atom
+    int32_t* c_raw = t_orig + A.T_cap;                        // C_cap + 1: offsets of the cell-pruned candidate stream
     int32_t* c_rank = c_raw + (A.C_cap + 1);                  // C_cap: Hilbert rank of each box cell
-    int32_t* part = c_rank + A.C_cap + 1;                     // nthr (8-byte aligned: the wave masks reuse c_raw/c_rank)
+    int32_t* part = c_rank + A.C_cap + 1;                     // nthr
+    uint32_t* x_part = reinterpret_cast<uint32_t*>(part + nthr);   // [X_cap][BI] per-atom exception lists (only if xl_start)
     __shared__ T s_sub[4][6];                                 // per-wave bounding boxes of the i-atoms
     __shared__ T s_ctr[3], s_half[3];
-    __shared__ int s_boxlo[3], s_boxlen[3], s_full[3], s_exact, s_wtot[4];
+    __shared__ int s_boxlo[3], s_boxlen[3], s_full[3], s_exact, s_wtot[16];
 
     // 0. bounding boxes: one per wave of i-atoms (tight pruning for elongated blocks) and their union
-    const int64_t si = (int64_t)b * A.BI + tid;
+    const int64_t si = (int64_t)b * A.BI + li;
     const bool valid = si < A.n_owned;
     T4 pi = A.pos[valid ? si : (int64_t)b * A.BI];            // a block is never empty
     T my[3] = {pi.x, pi.y, pi.z};
@@ -199,7 +209,7 @@ __global__ void k_build(BuildArgs<T> A) {
         for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
             for (int d = 0; d < 3; ++d) { T u = __shfl_xor(mn[d], o, WAVE); mn[d] = u < mn[d] ? u : mn[d]; T v = __shfl_xor(mx[d], o, WAVE); mx[d] = v > mx[d] ? v : mx[d]; }
-        if (lane == 0) for (int d = 0; d < 3; ++d) { s_sub[wv][d] = mn[d]; s_sub[wv][3 + d] = mx[d]; }
+        if (lane == 0 && js == 0) for (int d = 0; d < 3; ++d) { s_sub[wv][d] = mn[d]; s_sub[wv][3 + d] = mx[d]; }
     }
     __syncthreads();
     if (tid == 0) {
@@ -310,21 +320,21 @@ __global__ void k_build(BuildArgs<T> A) {
             T l0 = localise(p.x, 0), l1 = localise(p.y, 1), l2 = localise(p.z, 2);
             // exact_only blocks (small boxes): images are ambiguous, keep the whole cell-pruned set
             keep = exact_only ? true : sub_dist2(l0, l1, l2) <= reach2;
-            if (!exact_only) { p.x = l0; p.y = l1; p.z = l2; }
+            p.x = l0; p.y = l1; p.z = l2;
         }
         unsigned long long m = __ballot(keep);
-        if (lane == 0) s_wtot[wv] = __popcll(m);
+        if (lane == 0) s_wtot[wv_all] = __popcll(m);
         __syncthreads();
         int dst = tile_n + __popcll(m & ((1ull << lane) - 1ull));
         int tot = 0;
-        for (int w = 0; w < NW; ++w) { if (w < wv) dst += s_wtot[w]; tot += s_wtot[w]; }
-        if (keep && dst < A.T_cap) { t_pos[dst] = p; t_slot[dst] = s; A.tile_idx[(int64_t)b * A.T_cap + dst] = s; }
+        for (int w = 0; w < NW_ALL; ++w) { if (w < wv_all) dst += s_wtot[w]; tot += s_wtot[w]; }
+        if (keep && dst < A.T_cap) { t_pos[dst] = make_float4((float)p.x, (float)p.y, (float)p.z, 0.f); t_orig[dst] = A.orig[s]; A.tile_idx[(int64_t)b * A.T_cap + dst] = s; }
         tile_n += tot;
         __syncthreads();
     }
     if (tile_n > A.T_cap || tile_n > TILE_SLOT_MAX - 1) {
         if (tid == 0) { atomicOr(&A.flags[FLAG_OVERFLOW], tile_n > TILE_SLOT_MAX - 1 ? OVF_SLOT : OVF_TILE); atomicMax(&A.flags[FLAG_MAX_TILE], tile_n); A.tile_cnt[b] = 0; }
-        if (lane == 0) A.wave_rows[b * NW + wv] = 0;
+        if (lane == 0) A.wave_rows[(b * A.JS + js) * NW + wv] = 0;
         return;   // the host grows the capacities and rebuilds
     }
     if (tid == 0) A.tile_cnt[b] = tile_n;
@@ -342,7 +352,7 @@ __global__ void k_build(BuildArgs<T> A) {
     const uint32_t SENT = (uint32_t)tile_n;
     uint32_t pack[2] = {0, 0};
     int cnt = 0;
-    uint2* my_rows = A.nbr + ((int64_t)b * A.R_cap) * A.BI + tid;
+    uint2* my_rows = A.nbr + (((int64_t)b * A.JS + js) * A.R_cap) * A.BI + li;
     auto emit = [&](uint32_t e) {
         int k = cnt & 3;
         if (k == 0) { pack[0] = 0; pack[1] = 0; }
@@ -352,42 +362,51 @@ __global__ void k_build(BuildArgs<T> A) {
     };
     __syncthreads();
     {
-        const int oi = valid ? A.orig[si] : 0;
-        const T ml[3] = {exact_only ? my[0] : localise(my[0], 0), exact_only ? my[1] : localise(my[1], 1), exact_only ? my[2] : localise(my[2], 2)};
-        const T band_lo = G.r_list2 * T(1.0 - 1e-4), band_hi = G.r_list2 * T(1.0 + 1e-4);
-        T blo[3], bhi[3];
+        const int oi = valid ? A.orig[si] : -1;
+        int xl0 = 0, nxl = 0;
+        if (A.xl_start && valid) {   // my exception list: into LDS once (shared by the j-split group), scanned only for
+            xl0 = A.xl_start[oi]; nxl = A.xl_start[oi + 1] - xl0;   // candidates close in caller index
+            if (js == 0) for (int k = 0; k < min(nxl, A.X_cap); ++k) x_part[k * A.BI + li] = A.xl_list[xl0 + k];
+        }
+        if (A.xl_start) __syncthreads();
+        const float ml[3] = {(float)localise(my[0], 0), (float)localise(my[1], 1), (float)localise(my[2], 2)};
+        const float rl2 = G.no_list ? 3.0e38f : (float)G.r_list2;
+        const float band_lo = rl2 * (1.0f - 1e-4f), band_hi = G.no_list ? 3.0e38f : rl2 * (1.0f + 1e-4f);
+        const float reach2f = G.no_list ? 3.0e38f : (float)reach2;
+        float blo[3], bhi[3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { blo[d] = s_sub[wv][d] - ctr[d]; bhi[d] = s_sub[wv][3 + d] - ctr[d]; }
+        for (int d = 0; d < 3; ++d) { blo[d] = (float)(s_sub[wv][d] - ctr[d]); bhi[d] = (float)(s_sub[wv][3 + d] - ctr[d]); }
         const unsigned long long valid_mask = __ballot(valid);
         const int nwords = (tile_n + 63) >> 6;
-        for (int w = 0; w < nwords; ++w) {
+        for (int w = js; w < nwords; w += A.JS) {    // this wave's share of the tile: every JS-th group of 64 atoms
             const int jl = (w << 6) + lane;
-            T4 pl = make4<T>(T(0), T(0), T(0), T(0)); int sl = -1; bool near = false;
+            float4 pl = make_float4(0.f, 0.f, 0.f, 0.f); bool near = false;
+            T4 px = make4<T>(T(0), T(0), T(0), T(0));      // stored coordinates of my candidate (exact_only blocks)
             if (jl < tile_n) {
-                pl = t_pos[jl]; sl = t_slot[jl];
-                if (exact_only) near = true;
+                pl = t_pos[jl];
+                if (exact_only) { near = true; px = A.pos[A.tile_idx[(int64_t)b * A.T_cap + jl]]; }
                 else {
-                    T pc[3] = {pl.x, pl.y, pl.z}, acc = T(0);
+                    float pc[3] = {pl.x, pl.y, pl.z}, acc = 0.f;
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) { T e = blo[d] - pc[d]; T f = pc[d] - bhi[d]; e = e > f ? e : f; e = e > T(0) ? e : T(0); acc += e * e; }
-                    near = acc <= reach2;
+                    for (int d = 0; d < 3; ++d) { float e = blo[d] - pc[d]; float f = pc[d] - bhi[d]; e = e > f ? e : f; e = e > 0.f ? e : 0.f; acc += e * e; }
+                    near = acc <= reach2f;
                 }
             }
-            if (__ballot(near) == 0ull) continue;          // the whole group is out of this wave's reach
+            if (__ballot(near) == 0ull || A.debug == 8) continue;          // the whole group is out of this wave's reach
             int mine_lo = 0, mine_hi = 0;                  // lane i: mask of its neighbours within this group
             if (!exact_only) {
 #pragma unroll 8
                 for (int i = 0; i < WAVE; ++i) {
-                    const T ix = lane_bcast(ml[0], i), iy = lane_bcast(ml[1], i), iz = lane_bcast(ml[2], i);
-                    T dx = pl.x - ix, dy = pl.y - iy, dz = pl.z - iz;
-                    T r2 = dx * dx + dy * dy + dz * dz;
+                    const float ix = lane_bcast(ml[0], i), iy = lane_bcast(ml[1], i), iz = lane_bcast(ml[2], i);
+                    float dx = pl.x - ix, dy = pl.y - iy, dz = pl.z - iz;
+                    float r2 = dx * dx + dy * dy + dz * dz;
                     unsigned long long in = __ballot(near && r2 < band_lo);
                     const unsigned long long maybe = __ballot(near && !(r2 < band_lo) && r2 <= band_hi);
                     if (maybe) {   // rare: decide with the reference's exact arithmetic on the stored coordinates
                         const T ox = lane_bcast(my[0], i), oy = lane_bcast(my[1], i), oz = lane_bcast(my[2], i);
                         bool ok = false;
                         if ((maybe >> lane) & 1ull) {
-                            T4 pj = A.pos[sl];
+                            T4 pj = A.pos[A.tile_idx[(int64_t)b * A.T_cap + jl]];
                             T ex = G.periodic[0] ? vector_1d_exact(ox, pj.x, G.L[0]) : M<T>::sub(pj.x, ox);
                             T ey = G.periodic[1] ? vector_1d_exact(oy, pj.y, G.L[1]) : M<T>::sub(pj.y, oy);
                             T ez = G.periodic[2] ? vector_1d_exact(oz, pj.z, G.L[2]) : M<T>::sub(pj.z, oz);
@@ -400,29 +419,31 @@ __global__ void k_build(BuildArgs<T> A) {
             } else {
                 for (int i = 0; i < WAVE; ++i) {
                     const T ox = lane_bcast(my[0], i), oy = lane_bcast(my[1], i), oz = lane_bcast(my[2], i);
-                    T ex = G.periodic[0] ? vector_1d_exact(ox, pl.x, G.L[0]) : M<T>::sub(pl.x, ox);
-                    T ey = G.periodic[1] ? vector_1d_exact(oy, pl.y, G.L[1]) : M<T>::sub(pl.y, oy);
-                    T ez = G.periodic[2] ? vector_1d_exact(oz, pl.z, G.L[2]) : M<T>::sub(pl.z, oz);
+                    T ex = G.periodic[0] ? vector_1d_exact(ox, px.x, G.L[0]) : M<T>::sub(px.x, ox);
+                    T ey = G.periodic[1] ? vector_1d_exact(oy, px.y, G.L[1]) : M<T>::sub(px.y, oy);
+                    T ez = G.periodic[2] ? vector_1d_exact(oz, px.z, G.L[2]) : M<T>::sub(px.z, oz);
                     const unsigned long long in = __ballot(near && norm2_exact(ex, ey, ez) <= G.r_list2);
                     if (lane == i) { mine_lo = (int)(uint32_t)in; mine_hi = (int)(uint32_t)(in >> 32); }   // v_cndmask ×2
                 }
             }
             // each lane unpacks its own mask (slot order = tile order: deterministic lists)
             unsigned long long mm = ((unsigned long long)(uint32_t)mine_hi << 32) | (uint32_t)mine_lo;
-            if (!((valid_mask >> lane) & 1ull)) mm = 0;
+            if (!((valid_mask >> lane) & 1ull) || A.debug == 7) mm = 0;
             while (mm) {
                 const int bit = __builtin_ctzll(mm);
                 mm &= mm - 1;
                 const uint32_t t = (uint32_t)((w << 6) + bit);
-                const int sj = t_slot[t];
-                if (sj == (int)si) continue;
+                const int oj = t_orig[t];
+                if (oj == oi) continue;
                 uint32_t sp = 0;
-                if (A.ex_start) {
-                    int oj = A.orig[sj];
-                    bool excl = false;
-                    for (int k = A.ex_start[oi], e = A.ex_start[oi + 1]; k < e; ++k) excl |= (A.ex_list[k] == oj);
-                    for (int k = A.sp_start[oi], e = A.sp_start[oi + 1]; k < e; ++k) sp |= (A.sp_list[k] == oj) ? 1u : 0u;
-                    if (excl) continue;
+                if (nxl > 0 && (unsigned)(oj - oi + A.xl_span) <= (unsigned)(2 * A.xl_span)) {
+                    uint32_t hit = 0;
+                    for (int k = 0; k < nxl; ++k) {
+                        uint32_t e = k < A.X_cap ? x_part[k * A.BI + li] : A.xl_list[xl0 + k];
+                        hit = ((e & XL_INDEX) == (uint32_t)oj) ? e : hit;
+                    }
+                    if (hit & XL_EXCLUDED) continue;
+                    sp = hit >> 31;
                 }
                 emit(t | (sp << 15));
             }
@@ -435,7 +456,7 @@ __global__ void k_build(BuildArgs<T> A) {
     if (rows_wave > A.R_cap) { if (lane == 0) atomicOr(&A.flags[FLAG_OVERFLOW], OVF_ROWS); }
     const int rows_keep = rows_wave > A.R_cap ? 0 : rows_wave;
     while (((cnt + 3) >> 2) < rows_keep || (cnt & 3)) emit(SENT);
-    if (lane == 0) A.wave_rows[b * NW + wv] = rows_wave;   // > R_cap reports the required capacity; k_build_summary zeroes it
+    if (lane == 0) A.wave_rows[(b * A.JS + js) * NW + wv] = rows_wave;   // > R_cap reports the required capacity; k_build_summary zeroes it
 }
 
 // one block: reduce the per-block / per-wave results of k_build into the flag words the host reads
@@ -504,8 +525,8 @@ __global__ void k_forces(ForceArgs<T> A) {
     T4 pi = localise(A.pos[valid ? si : (int64_t)b * A.BI]);
     T2 lji = make2<T>(T(0), T(0));
     if constexpr (PER_ATOM_LJ) lji = A.lj[valid ? si : (int64_t)b * A.BI];
-    const int rows = A.wave_rows[b * (A.BI >> 6) + (li >> 6)];
-    const uint2* my_rows = A.nbr + ((int64_t)b * A.R_cap) * A.BI + li;
+    const int rows = A.wave_rows[(b * A.JS + js) * (A.BI >> 6) + (li >> 6)];               // this wave's own sub-list: the
+    const uint2* my_rows = A.nbr + (((int64_t)b * A.JS + js) * A.R_cap) * A.BI + li;       // j-split was done by k_build
     const int32_t* tix = A.tile_idx + (int64_t)b * A.T_cap;
     T fx = T(0), fy = T(0), fz = T(0), pe = T(0);
 
@@ -526,11 +547,11 @@ __global__ void k_forces(ForceArgs<T> A) {
             if constexpr (PER_ATOM_LJ) l_lj[n_here] = make2<T>(T(0), T(0));
         }
         __syncthreads();
-        // the row stream is software-pipelined: row r+JS is in flight while row r is evaluated
-        uint2 e_next = (js < rows) ? my_rows[(int64_t)js * A.BI] : make_uint2(0, 0);
-        for (int r = js; r < rows; r += A.JS) {
+        // the row stream is software-pipelined: row r+1 is in flight while row r is evaluated
+        uint2 e_next = (0 < rows) ? my_rows[0] : make_uint2(0, 0);
+        for (int r = 0; r < rows; ++r) {
             const uint2 e4 = e_next;
-            if (r + A.JS < rows) e_next = my_rows[(int64_t)(r + A.JS) * A.BI];
+            if (r + 1 < rows) e_next = my_rows[(int64_t)(r + 1) * A.BI];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 uint32_t e = ((k < 2 ? e4.x : e4.y) >> (16 * (k & 1))) & 0xffffu;
@@ -578,26 +599,28 @@ __global__ void k_forces(ForceArgs<T> A) {
 // ---------------------------------------------------------------------------------------------------
 // neighbour list export: half list i<j in caller indices
 template <class T>
-__global__ void k_export_nl(int n_blocks, int BI, int T_cap, int R_cap, int64_t n_owned, const int32_t* __restrict__ orig,
+__global__ void k_export_nl(int n_blocks, int BI, int JS, int T_cap, int R_cap, int64_t n_owned, const int32_t* __restrict__ orig,
                             const int32_t* __restrict__ tile_idx, const int32_t* __restrict__ tile_cnt, const uint2* __restrict__ nbr,
                             const int32_t* __restrict__ wave_rows, int32_t* out_i, int32_t* out_j, uint8_t* out_sp,
                             unsigned long long* counter, unsigned long long capacity) {
     int b = blockIdx.x, li = threadIdx.x;
     int64_t si = (int64_t)b * BI + li;
     if (si >= n_owned) return;
-    int rows = wave_rows[b * (BI >> 6) + (li >> 6)];
     int tile_n = tile_cnt[b];
     int oi = orig[si];
-    for (int r = 0; r < rows; ++r) {
-        uint2 e4 = nbr[((int64_t)b * R_cap + r) * BI + li];
-        for (int k = 0; k < 4; ++k) {
-            uint32_t e = ((k < 2 ? e4.x : e4.y) >> (16 * (k & 1))) & 0xffffu;
-            int slot = e & 0x7fff;
-            if (slot >= tile_n) continue;
-            int oj = orig[tile_idx[(int64_t)b * T_cap + slot]];
-            if (oi < oj) {
-                unsigned long long at = atomicAdd(counter, 1ull);
-                if (out_i && at < capacity) { out_i[at] = oi; out_j[at] = oj; out_sp[at] = (uint8_t)(e >> 15); }
+    for (int js = 0; js < JS; ++js) {
+        int rows = wave_rows[(b * JS + js) * (BI >> 6) + (li >> 6)];
+        for (int r = 0; r < rows; ++r) {
+            uint2 e4 = nbr[(((int64_t)b * JS + js) * R_cap + r) * BI + li];
+            for (int k = 0; k < 4; ++k) {
+                uint32_t e = ((k < 2 ? e4.x : e4.y) >> (16 * (k & 1))) & 0xffffu;
+                int slot = e & 0x7fff;
+                if (slot >= tile_n) continue;
+                int oj = orig[tile_idx[(int64_t)b * T_cap + slot]];
+                if (oi < oj) {
+                    unsigned long long at = atomicAdd(counter, 1ull);
+                    if (out_i && at < capacity) { out_i[at] = oi; out_j[at] = oj; out_sp[at] = (uint8_t)(e >> 15); }
+                }
             }
         }
     }

@@ -2,8 +2,12 @@ import sys, os, ctypes as C, numpy as np, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import molly_loader; m = molly_loader.load()
 from tests import systems as S
-n_side = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-case = S.lj_fluid(n_side, dtype=np.float32)
+arg = sys.argv[1] if len(sys.argv) > 1 else "64"
+if arg == "6mrr":
+    from tests import golden6mrr
+    case = golden6mrr.case("ewald", np.float32, bonded=False)
+else:
+    case = S.lj_fluid(int(arg), dtype=np.float32)
 s = case.system(m, np.float32)
 s.push_state()
 L = m.lib(); ctx = s.engine()
