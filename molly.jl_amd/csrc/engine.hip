@@ -239,9 +239,9 @@ template <class T> class Engine final : public EngineBase {
     void choose_blocking() {
         // i-block size and j-split: enough waves to fill 256 CUs × 4 SIMDs even for small systems
         int bi, js;
-        if (n_owned >= 100000) { bi = 256; js = 2; }
-        else if (n_owned >= 40000) { bi = 128; js = 2; }
-        else { bi = 64; js = 8; }
+        if (n_owned >= 100000) { bi = 256; js = 2; }        // measured on MI355X: lj1m 256x2, 6mrr 64x16 (profiles/)
+        else if (n_owned >= 40000) { bi = 128; js = 4; }
+        else { bi = 64; js = 16; }
         bi = env_int("MOLLYHIP_BLOCK_I", bi); js = env_int("MOLLYHIP_J_SPLIT", js);
         if (bi != 64 && bi != 128 && bi != 256) throw ApiError{MHIP_ERR_INVALID, "MOLLYHIP_BLOCK_I must be 64, 128 or 256"};
         if (js < 1 || bi * js > 1024) throw ApiError{MHIP_ERR_INVALID, "MOLLYHIP_J_SPLIT out of range (BLOCK_I*J_SPLIT <= 1024)"};

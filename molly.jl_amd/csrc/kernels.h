@@ -377,9 +377,11 @@ __global__ void k_build(BuildArgs<T> A) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) { blo[d] = (float)(s_sub[wv][d] - ctr[d]); bhi[d] = (float)(s_sub[wv][3 + d] - ctr[d]); }
         const unsigned long long valid_mask = __ballot(valid);
-        const int nwords = (tile_n + 63) >> 6;
-        for (int w = js; w < nwords; w += A.JS) {    // this wave's share of the tile: every JS-th group of 64 atoms
-            const int jl = (w << 6) + lane;
+        // this wave's share of the tile: the atoms t ≡ js (mod JS), a uniform sample in tile order, so that the JS
+        // sub-lists of an i-atom come out equally long (little sentinel padding)
+        const int nwords = (tile_n + 64 * A.JS - 1) / (64 * A.JS);
+        for (int w = 0; w < nwords; ++w) {
+            const int jl = ((w << 6) + lane) * A.JS + js;
             float4 pl = make_float4(0.f, 0.f, 0.f, 0.f); bool near = false;
             T4 px = make4<T>(T(0), T(0), T(0), T(0));      // stored coordinates of my candidate (exact_only blocks)
             if (jl < tile_n) {
@@ -432,7 +434,7 @@ __global__ void k_build(BuildArgs<T> A) {
             while (mm) {
                 const int bit = __builtin_ctzll(mm);
                 mm &= mm - 1;
-                const uint32_t t = (uint32_t)((w << 6) + bit);
+                const uint32_t t = (uint32_t)(((w << 6) + bit) * A.JS + js);
                 const int oj = t_orig[t];
                 if (oj == oi) continue;
                 uint32_t sp = 0;
