@@ -17,3 +17,4 @@ for kern in ('k_build','k_forces'):
     if kern in s['pmc']:
         print(kern, {c: round(v['per_launch']) for c,v in sorted(s['pmc'][kern].items())})
 PY
+rm -rf "$OUT/trace" "$OUT/pmc_sq" "$OUT/pmc_sq2"
