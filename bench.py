@@ -136,8 +136,10 @@ def main():
                 "step_bytes": st["algorithmic_bytes_step"],
                 "step_frac": st["algorithmic_bytes_step"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "stage_ms_per_step": {"forces": force_ms, "build_kernel": st["prof_ms"][1] / max(args.profile_steps, 1),
+                                      "list_filter": st["prof_ms"][4] / max(args.profile_steps, 1),
                                       "integrator": st["prof_ms"][2] / max(args.profile_steps, 1),
-                                      "sort_permute": st["prof_ms"][3] / max(args.profile_steps, 1)}}
+                                      "sort_permute": st["prof_ms"][3] / max(args.profile_steps, 1)},
+                "stage_ms_per_call": {"build_kernel": st["prof_ms"][1] / max(st["prof_calls"][1], 1), "list_filter": st["prof_ms"][4] / max(st["prof_calls"][4], 1)}}
     line = {
         "metric": "ns_per_day", "value": ns_day, "unit": "ns/day", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -152,7 +154,7 @@ def main():
                    "block_atoms": st["block_atoms"], "j_split": st["j_split"], "pairs_half_list": st["n_pairs_full"] // 2},
         "roofline": roofline,
         "engine": {k: st[k] for k in ("n_blocks", "block_atoms", "j_split", "max_tile_atoms", "tile_atoms_total", "lds_bytes",
-                                      "n_list_slots", "n_pairs_full", "minimg_mode", "n_rebuilds", "last_rebuild_ms")},
+                                      "n_list_slots", "n_pairs_full", "minimg_mode", "n_rebuilds", "n_outer_builds", "n_filter_passes", "last_rebuild_ms")},
     }
     line.update({k: v for k, v in extra.items() if k != "parallelism"})
     if world == 1 and not args.no_cpu_baseline:

@@ -125,9 +125,12 @@ typedef struct mhip_stats {
     int64_t algorithmic_bytes_step;/* N(R_p+22w)+4L, SURVEY §8(d)                                 */
     int64_t force_pass_bytes;      /* N(R_p+3w)+4L: algorithmic bytes of ONE force-kernel launch   */
     /* HIP-event timings, filled while profiling is on (mhip_set_profiling):                        */
-    /* stage 0 pair-force kernel, 1 tile/list build kernel, 2 integrator kernels, 3 sort+permute    */
-    double  prof_ms[4];
-    int64_t prof_calls[4];
+    /* stage 0 pair-force kernel, 1 tile/list build kernel (outer search), 2 integrator kernels,    */
+    /* 3 sort+permute, 4 list filter (inner list of the dual pair list), 5 bonded kernels           */
+    double  prof_ms[6];
+    int64_t prof_calls[6];
+    int64_t n_outer_builds;        /* searches with the outer radius (dual pair list)             */
+    int64_t n_filter_passes;
 } mhip_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */

@@ -65,12 +65,12 @@ struct EngineBase {
 
 // hipEvent stage timers (only active while profiling is on)
 struct Prof {
-    static constexpr int NS = 4;
+    static constexpr int NS = 6;
     bool on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[NS];
-    size_t used[NS] = {0, 0, 0, 0};
-    double ms[NS] = {0, 0, 0, 0};
-    int64_t calls[NS] = {0, 0, 0, 0};
+    size_t used[NS] = {};
+    double ms[NS] = {};
+    int64_t calls[NS] = {};
     void begin(int st, hipStream_t s) {
         if (!on) return;
         if (used[st] == ev[st].size()) { hipEvent_t a, b; MHIP_HIP(hipEventCreate(&a)); MHIP_HIP(hipEventCreate(&b)); ev[st].push_back({a, b}); }
@@ -119,6 +119,9 @@ template <class T> class Engine final : public EngineBase {
     int BI = 256, JS = 1, n_blocks = 0, T_cap = 0, R_cap = 0, C_cap = 0, max_tile = 0, max_rows = 0;
     int ljm_base = LJ_OFF;   // LJ mode implied by the interaction; ljm may be upgraded to the uniform fast path
     DBuf<int32_t> tile_idx, tile_cnt, wave_rows; DBuf<uint2> nbr; DBuf<T4> blk_center;
+    // dual pair list: outer list (nbr / wave_rows, radius r_list + margin) and the inner list filtered from it
+    DBuf<int32_t> wave_rows_in, tile_idx_in, tile_cnt_in; DBuf<uint2> nbr_in; DBuf<T4> pos_snap; DBuf<float> blk_disp2; int max_tile_in = 0;
+    bool dual = false, dual_disabled = false; int early_outer = 0; double outer_margin = 0; int outer_every = 1; int64_t last_outer_step = 0, n_outer = 0, n_filters = 0; T r_in = 0, r_in2 = 0;
     DBuf<int32_t> flags; int32_t* h_flags = nullptr;
     int64_t total_rows = 0;
     // reductions
@@ -166,6 +169,7 @@ template <class T> class Engine final : public EngineBase {
         if (stream) (void)hipStreamSynchronize(stream);
         for (int k = 0; k < 2; ++k) { pos[k].release(); vel[k].release(); frc[k].release(); lj[k].release(); orig[k].release(); }
         inv.release(); key_in.release(); key_out.release(); cell_rank.release(); idx_in.release(); perm.release(); cell_cnt.release(); cell_start.release(); cub_tmp.release();
+        wave_rows_in.release(); nbr_in.release(); pos_snap.release(); blk_disp2.release(); tile_idx_in.release(); tile_cnt_in.release();
         xl_start.release(); xl_list.release(); tile_idx.release(); tile_cnt.release(); wave_rows.release(); nbr.release(); blk_center.release();
         flags.release(); red_part.release(); red_out.release(); vcm.release(); stage_a.release(); stage_b.release(); stage_i.release(); bonded.release();
         prof.release();
@@ -201,14 +205,23 @@ template <class T> class Engine final : public EngineBase {
     void setup_grid() {
         std::memset(&G, 0, sizeof(G));
         G.no_list = !(cfg.r_list > 0) || std::isinf(cfg.r_list);
-        G.r_list = G.no_list ? std::numeric_limits<T>::infinity() : T(cfg.r_list);
-        G.r_list2 = G.no_list ? std::numeric_limits<T>::infinity() : G.r_list * G.r_list;   // dist_cutoff^2, neighbors.jl:400
+        r_in = G.no_list ? std::numeric_limits<T>::infinity() : T(cfg.r_list);
+        r_in2 = G.no_list ? std::numeric_limits<T>::infinity() : r_in * r_in;                 // dist_cutoff^2, neighbors.jl:400
+        // dual pair list: search with r_list + margin every `outer_every` rebuild intervals, filter to exactly r_list at
+        // every rebuild step (MOLLYHIP_OUTER_MARGIN_PM in picometres, 0 disables; MOLLYHIP_OUTER_EVERY)
+        outer_margin = (G.no_list || dual_disabled) ? 0.0 : env_int("MOLLYHIP_OUTER_MARGIN_PM", 200) * 1e-3;
+        outer_every = std::max(1, env_int("MOLLYHIP_OUTER_EVERY", 10));
+        for (int d = 0; d < 3; ++d) if (cfg.periodic[d] && cfg.r_list + outer_margin > 0.5 * cfg.box[d]) outer_margin = 0;   // keep r_outer <= L/2
+        dual = outer_margin > 0 && outer_every > 1 && n_ghost == 0;   // ghosted sub-domains are re-planned by the host at every rebuild step
+        const double r_search = G.no_list ? 0.0 : cfg.r_list + (dual ? outer_margin : 0.0);
+        G.r_list = G.no_list ? std::numeric_limits<T>::infinity() : T(r_search);
+        G.r_list2 = G.no_list ? std::numeric_limits<T>::infinity() : (dual ? G.r_list * G.r_list : r_in2);
         const int S = std::max(1, env_int("MOLLYHIP_STENCIL", 2));
         for (int d = 0; d < 3; ++d) {
             if (!(cfg.box[d] > 0) || std::isinf(cfg.box[d]) || std::isnan(cfg.box[d])) throw ApiError{MHIP_ERR_INVALID, "box side lengths must be positive and finite"};
             G.L[d] = T(cfg.box[d]); G.invL[d] = T(1) / G.L[d]; G.origin[d] = cfg.periodic[d] ? T(0) : T(cfg.origin[d]); G.periodic[d] = cfg.periodic[d] ? 1 : 0;
             int nc = 1;
-            if (!G.no_list) { nc = (int)std::floor(cfg.box[d] / (cfg.r_list / S)); nc = std::max(1, std::min(nc, 1024)); }
+            if (!G.no_list) { nc = (int)std::floor(cfg.box[d] / (r_search / S)); nc = std::max(1, std::min(nc, 1024)); }
             G.nc[d] = nc; G.cs[d] = T(cfg.box[d] / nc); G.inv_cs[d] = T(nc / cfg.box[d]);
             G.stencil[d] = S; G.all_cells[d] = (G.no_list || 2 * S + 1 >= nc) ? 1 : 0;
         }
@@ -255,7 +268,7 @@ template <class T> class Engine final : public EngineBase {
         double rho = (double)n_tot / vol;
         if (G.no_list) { T_cap = (int)n_tot + 8; R_cap = cdiv(n_tot, 4) + 2; C_cap = 8; }
         else {
-            double r = cfg.r_list * 1.001, a = std::cbrt(BI / rho);
+            double r = (cfg.r_list + (dual ? outer_margin : 0.0)) * 1.001, a = std::cbrt(BI / rho);
             double v_tile = a * a * a + 6 * a * a * r + 3 * M_PI * a * r * r + 4.0 / 3.0 * M_PI * r * r * r;
             T_cap = (int)std::min<double>(1.4 * rho * v_tile + 64, (double)n_tot + 8);
             R_cap = (int)std::min<double>(1.5 * rho * 4.0 / 3.0 * M_PI * r * r * r / 4 / JS + 8, n_tot / 4.0 + 2);
@@ -289,7 +302,17 @@ template <class T> class Engine final : public EngineBase {
     // ---------------------------------------------------------------------------------------------
     // the neighbour rebuild pipeline (≙ find_neighbors + the reorder/compress/tile-search stages of
     // ext/MollyCUDAExt.jl:845-873, redesigned O(N))
+    // a search that does not fit the LDS with the outer radius falls back to the plain single-radius list
     void rebuild(int64_t step_n) {
+        try { rebuild_impl(step_n); }
+        catch (const ApiError& e) {
+            if (e.code != MHIP_ERR_CAPACITY || !dual) throw;
+            dual_disabled = true; setup_grid(); choose_blocking(); stale = true;
+            rebuild_impl(step_n);
+        }
+    }
+
+    void rebuild_impl(int64_t step_n) {
         if (!params_set || !state_set) throw ApiError{MHIP_ERR_STATE, "set_atoms and set_state must be called before forces"};
         auto t0 = std::chrono::steady_clock::now();
         const int o = cur, n = 1 - cur;
@@ -329,7 +352,7 @@ template <class T> class Engine final : public EngineBase {
             set_lds_limit(k_build<T>, lds);
             prof.begin(1, stream);
             hipLaunchKernelGGL(k_build<T>, dim3(n_blocks), dim3(BI * JS), lds, stream, A);
-            hipLaunchKernelGGL(k_build_summary, dim3(1), dim3(256), 0, stream, n_blocks, n_blocks * JS * (BI / WAVE), R_cap, (const int32_t*)tile_cnt.p, wave_rows.p, flags.p);
+            hipLaunchKernelGGL(k_build_summary, dim3(std::min(64, cdiv(n_blocks * JS * (BI / WAVE), 256))), dim3(256), 0, stream, n_blocks, n_blocks * JS * (BI / WAVE), R_cap, (const int32_t*)tile_cnt.p, wave_rows.p, (const float*)nullptr, flags.p);
             prof.end(1, stream);
             MHIP_HIP(hipGetLastError());
             MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
@@ -351,27 +374,85 @@ template <class T> class Engine final : public EngineBase {
         }
         minimg = h_flags[FLAG_MINIMG] != 0 || env_int("MOLLYHIP_FORCE_MINIMG", 0) != 0;
         max_tile = h_flags[FLAG_MAX_TILE]; max_rows = h_flags[FLAG_MAX_ROWS]; total_rows = h_flags[FLAG_TOTAL_ROWS];
-        {   // LDS carve-up of the force kernel: the whole tile if it fits the budget, else segments of the budget's size
-            const size_t budget = std::min<size_t>((size_t)env_int("MOLLYHIP_LDS_BUDGET_KB", 160) * 1024, MAX_LDS_BYTES);
-            const bool per_atom_lj = (ljm == LJ_DIST || ljm == LJ_GENERIC);
-            const size_t per_atom = sizeof(T4) + (per_atom_lj ? sizeof(T2) : 0);
-            const size_t fixed = std::max((size_t)JS * 4 * BI * sizeof(T), (size_t)BI * sizeof(double)) + 64;
-            int fit = (int)((budget > fixed + 2 * per_atom ? budget - fixed : 2 * per_atom) / per_atom) - 1;
-            fit = std::max(fit & ~1, 2);
-            segmented = max_tile > fit;
-            tile_lds = segmented ? fit : max_tile;
-            lds_force = force_lds_bytes(tile_lds);
-            if (lds_force > (size_t)MAX_LDS_BYTES) throw ApiError{MHIP_ERR_CAPACITY, "force-kernel LDS carve-up exceeds 160 KiB"};
-        }
+        carve_force_lds(max_tile);
         red_part.reserve(std::max<size_t>((size_t)n_blocks, 4 * (size_t)cdiv(n_owned, 256)) + 8);
         bonded.on_reorder();
+        ++n_outer; last_outer_step = step_n;
+        if (dual) {
+            pos_snap.reserve(cap);
+            MHIP_HIP(hipMemcpyAsync(pos_snap.p, pos[cur].p, (size_t)n_tot * sizeof(T4), hipMemcpyDeviceToDevice, stream));
+            launch_filter();
+            MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            MHIP_HIP(hipStreamSynchronize(stream));
+            total_rows = h_flags[FLAG_TOTAL_ROWS]; max_tile_in = h_flags[FLAG_MAX_TILE];
+            carve_force_lds(max_tile_in);
+        }
         stale = false; last_build_step = step_n; ++n_rebuilds;
         last_rebuild_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
 
+    // LDS carve-up of the force kernel: the whole tile if it fits the budget, else segments of the budget's size
+    void carve_force_lds(int tile_max) {
+        const size_t budget = std::min<size_t>((size_t)env_int("MOLLYHIP_LDS_BUDGET_KB", 160) * 1024, MAX_LDS_BYTES);
+        const bool per_atom_lj = (ljm == LJ_DIST || ljm == LJ_GENERIC);
+        const size_t per_atom = sizeof(T4) + (per_atom_lj ? sizeof(T2) : 0);
+        const size_t fixed = std::max((size_t)JS * 4 * BI * sizeof(T), (size_t)BI * sizeof(double)) + 64;
+        int fit = (int)((budget > fixed + 2 * per_atom ? budget - fixed : 2 * per_atom) / per_atom) - 1;
+        fit = std::max(fit & ~1, 2);
+        segmented = tile_max > fit;
+        tile_lds = segmented ? fit : std::max(tile_max, 1);
+        lds_force = force_lds_bytes(tile_lds);
+        if (lds_force > (size_t)MAX_LDS_BYTES) throw ApiError{MHIP_ERR_CAPACITY, "force-kernel LDS carve-up exceeds 160 KiB"};
+    }
+
+    // inner list := outer entries with r2 <= r_list² at the current coordinates (+ max displacement since the outer build)
+    void launch_filter() {
+        wave_rows_in.reserve((size_t)n_blocks * JS * (BI / WAVE)); nbr_in.reserve((size_t)n_blocks * JS * R_cap * BI);
+        tile_idx_in.reserve((size_t)n_blocks * T_cap); tile_cnt_in.reserve(n_blocks);
+        MHIP_HIP(hipMemsetAsync(flags.p, 0, N_FLAGS * sizeof(int32_t), stream));
+        blk_disp2.reserve(n_blocks);
+        FilterArgs<T> F;
+        F.G = G; F.n_owned = n_owned; F.BI = BI; F.BI_shift = ilog2(BI); F.JS = JS; F.T_cap = T_cap; F.R_cap = R_cap; F.n_blocks = n_blocks;
+        F.pos = pos[cur].p; F.pos_snap = pos_snap.p; F.tile_idx = tile_idx.p; F.tile_cnt = tile_cnt.p; F.nbr_out = nbr.p; F.rows_out = wave_rows.p;
+        F.nbr_in = nbr_in.p; F.rows_in = wave_rows_in.p; F.tile_idx_in = tile_idx_in.p; F.tile_cnt_in = tile_cnt_in.p; F.blk_center = blk_center.p; F.blk_disp2 = blk_disp2.p; F.flags = flags.p; F.r_in = r_in; F.r_in2 = r_in2; F.exact_all = minimg ? 1 : 0;
+        F.T_lds = std::min<int>(max_tile, (MAX_LDS_BYTES - 256) / (int)sizeof(float4));
+        F.T_lds = minimg ? 0 : F.T_lds;
+        size_t lds = (size_t)F.T_lds * sizeof(float4) + ((size_t)(T_cap + 31) / 32 + 1) * 4 + (size_t)((T_cap + 2) & ~1) * 2 + (size_t)BI * JS * 4 + 64;
+        set_lds_limit(k_filter<T>, lds);
+        prof.begin(4, stream);
+        hipLaunchKernelGGL(k_filter<T>, dim3(n_blocks), dim3(BI * JS), lds, stream, F);
+        hipLaunchKernelGGL(k_build_summary, dim3(std::min(64, cdiv(n_blocks * JS * (BI / WAVE), 256))), dim3(256), 0, stream, n_blocks, n_blocks * JS * (BI / WAVE), R_cap,
+                           (const int32_t*)tile_cnt_in.p, wave_rows_in.p, (const float*)blk_disp2.p, flags.p);
+        prof.end(4, stream);
+        MHIP_HIP(hipGetLastError());
+        ++n_filters;
+    }
+
+    // rebuild step of the cadence (find_neighbors at step_n % n_steps == 0): a fresh search, or — with the dual list —
+    // a filter pass, falling back to the search when it is due or an atom moved more than half the margin
+    void refresh(int64_t step_n) {
+        const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
+        if (!dual || stale || (step_n - last_outer_step) >= (int64_t)outer_every * every || step_n < last_outer_step) { rebuild(step_n); return; }
+        launch_filter();
+        MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        MHIP_HIP(hipStreamSynchronize(stream));
+        float d2; std::memcpy(&d2, &h_flags[FLAG_MAX_DISP2], sizeof(float));
+        if (2.0 * std::sqrt((double)d2) > outer_margin * 0.98) {
+            // atoms outran the margin.  If that keeps happening before the outer list has paid for itself (fast light atoms,
+            // small time step), the dual list is a loss: fall back to a fresh search at every rebuild step.
+            if (step_n - last_outer_step <= 2 * (int64_t)every) { if (++early_outer >= 3) { dual_disabled = true; setup_grid(); choose_blocking(); stale = true; } }
+            else early_outer = 0;
+            rebuild(step_n); return;
+        }
+        total_rows = h_flags[FLAG_TOTAL_ROWS]; max_tile_in = h_flags[FLAG_MAX_TILE];
+        carve_force_lds(max_tile_in);
+        last_build_step = step_n; ++n_rebuilds;
+    }
+
     void ensure_built(int64_t step_n) {
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
-        if (stale || (step_n % every == 0 && step_n != last_build_step)) rebuild(step_n);
+        if (stale) rebuild(step_n);
+        else if (step_n % every == 0 && step_n != last_build_step) refresh(step_n);
     }
 
     // ---------------------------------------------------------------------------------------------
@@ -403,7 +484,7 @@ template <class T> class Engine final : public EngineBase {
         ForceArgs<T> A;
         A.G = G; A.I = I; A.n_owned = n_owned; A.BI = BI; A.BI_shift = ilog2(BI); A.JS = JS; A.T_cap = T_cap; A.T_lds = tile_lds; A.R_cap = R_cap;
         A.n_blocks = n_blocks; A.blocks_per_xcd = cdiv(n_blocks, 8);
-        A.pos = pos[cur].p; A.lj = lj[cur].p; A.tile_idx = tile_idx.p; A.tile_cnt = tile_cnt.p; A.nbr = nbr.p; A.wave_rows = wave_rows.p;
+        A.pos = pos[cur].p; A.lj = lj[cur].p; A.tile_idx = dual ? tile_idx_in.p : tile_idx.p; A.tile_cnt = dual ? tile_cnt_in.p : tile_cnt.p; A.nbr = dual ? nbr_in.p : nbr.p; A.wave_rows = dual ? wave_rows_in.p : wave_rows.p;
         A.blk_center = blk_center.p; A.frc = frc[cur].p; A.pe_part = red_part.p;
         prof.begin(0, stream);
         switch (ljm) {
@@ -465,6 +546,7 @@ template <class T> class Engine final : public EngineBase {
         MHIP_HIP(hipMemsetAsync(frc[cur].p, 0, n_tot * sizeof(T4), stream));
         MHIP_HIP(hipStreamSynchronize(stream));
         stale = true; cm_pending = false; frc_valid = false;
+        setup_grid();          // the dual pair list is a single-domain feature: the search radius depends on n_ghost
         choose_blocking();
     }
 
@@ -687,7 +769,7 @@ template <class T> class Engine final : public EngineBase {
         stage2_impl(dt, false);
         MHIP_HIP(hipGetLastError());
     }
-    void rebuild_now(int64_t step_n) override { flush_cm(); rebuild(step_n); }
+    void rebuild_now(int64_t step_n) override { flush_cm(); if (stale) rebuild(step_n); else refresh(step_n); }
 
     void vv_run(int64_t first_step, int64_t n_steps, double dt, int remove_cm_every) override {
         if (!state_set || !params_set) throw ApiError{MHIP_ERR_STATE, "set_atoms and set_state must be called before vv_run"};
@@ -698,7 +780,7 @@ template <class T> class Engine final : public EngineBase {
         for (int64_t step = first_step + 1; step <= first_step + n_steps; ++step) {
             vv_stage1(dt);                                                        // :594-609
             stage2_impl(dt, remove_cm_every != 0 && step % remove_cm_every == 0); // :612-628
-            if (step % every == 0) rebuild(step);                                 // :645, neighbors.jl:396
+            if (step % every == 0) refresh(step);                                 // :645, neighbors.jl:396
         }
         flush_cm();
         MHIP_HIP(hipGetLastError());
@@ -709,16 +791,16 @@ template <class T> class Engine final : public EngineBase {
         if (stale) throw ApiError{MHIP_ERR_STATE, "no neighbour list: call forces / rebuild first"};
         DBuf<unsigned long long> counter; counter.reserve(1);
         MHIP_HIP(hipMemsetAsync(counter.p, 0, sizeof(unsigned long long), stream));
-        hipLaunchKernelGGL(k_export_nl<T>, dim3(n_blocks), dim3(BI), 0, stream, n_blocks, BI, JS, T_cap, R_cap, n_owned, (const int32_t*)orig[cur].p, (const int32_t*)tile_idx.p,
-                           (const int32_t*)tile_cnt.p, (const uint2*)nbr.p, (const int32_t*)wave_rows.p, (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr, counter.p, 0ull);
+        hipLaunchKernelGGL(k_export_nl<T>, dim3(n_blocks), dim3(BI), 0, stream, n_blocks, BI, JS, T_cap, R_cap, n_owned, (const int32_t*)orig[cur].p, (const int32_t*)(dual ? tile_idx_in.p : tile_idx.p),
+                           (const int32_t*)(dual ? tile_cnt_in.p : tile_cnt.p), (const uint2*)(dual ? nbr_in.p : nbr.p), (const int32_t*)(dual ? wave_rows_in.p : wave_rows.p), (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr, counter.p, 0ull);
         unsigned long long n = 0;
         MHIP_HIP(hipMemcpyAsync(&n, counter.p, sizeof(n), hipMemcpyDeviceToHost, stream));
         MHIP_HIP(hipStreamSynchronize(stream));
         if (oi && (int64_t)n <= capacity && n > 0) {
             DBuf<int32_t> di, dj; DBuf<uint8_t> ds; di.reserve(n); dj.reserve(n); ds.reserve(n);
             MHIP_HIP(hipMemsetAsync(counter.p, 0, sizeof(unsigned long long), stream));
-            hipLaunchKernelGGL(k_export_nl<T>, dim3(n_blocks), dim3(BI), 0, stream, n_blocks, BI, JS, T_cap, R_cap, n_owned, (const int32_t*)orig[cur].p, (const int32_t*)tile_idx.p,
-                               (const int32_t*)tile_cnt.p, (const uint2*)nbr.p, (const int32_t*)wave_rows.p, di.p, dj.p, ds.p, counter.p, n);
+            hipLaunchKernelGGL(k_export_nl<T>, dim3(n_blocks), dim3(BI), 0, stream, n_blocks, BI, JS, T_cap, R_cap, n_owned, (const int32_t*)orig[cur].p, (const int32_t*)(dual ? tile_idx_in.p : tile_idx.p),
+                               (const int32_t*)(dual ? tile_cnt_in.p : tile_cnt.p), (const uint2*)(dual ? nbr_in.p : nbr.p), (const int32_t*)(dual ? wave_rows_in.p : wave_rows.p), di.p, dj.p, ds.p, counter.p, n);
             MHIP_HIP(hipMemcpyAsync(oi, di.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
             MHIP_HIP(hipMemcpyAsync(oj, dj.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
             MHIP_HIP(hipMemcpyAsync(osp, ds.p, n * sizeof(uint8_t), hipMemcpyDeviceToHost, stream));
@@ -738,12 +820,12 @@ template <class T> class Engine final : public EngineBase {
     void get_stats(mhip_stats* s) override {
         std::memset(s, 0, sizeof(*s));
         s->n_atoms = n_tot; s->n_owned = n_owned; s->n_ghost = n_ghost; s->n_rebuilds = n_rebuilds; s->n_force_calls = n_force_calls;
-        s->n_blocks = n_blocks; s->block_atoms = BI; s->j_split = JS; s->minimg_mode = minimg ? 1 : 0; s->max_tile_atoms = max_tile;
+        s->n_blocks = n_blocks; s->block_atoms = BI; s->j_split = JS; s->minimg_mode = minimg ? 1 : 0; s->max_tile_atoms = dual ? max_tile_in : max_tile;
         s->last_rebuild_ms = last_rebuild_ms; s->lds_bytes = (int64_t)lds_force;
         s->n_list_slots = total_rows * 4 * WAVE;
         if (!stale) {
             std::vector<int32_t> tc(n_blocks);
-            MHIP_HIP(hipMemcpy(tc.data(), tile_cnt.p, n_blocks * sizeof(int32_t), hipMemcpyDeviceToHost));
+            MHIP_HIP(hipMemcpy(tc.data(), dual ? tile_cnt_in.p : tile_cnt.p, n_blocks * sizeof(int32_t), hipMemcpyDeviceToHost));
             int64_t t = 0; for (int v : tc) t += v; s->tile_atoms_total = t;
             s->n_pairs_full = 2 * export_neighbors(nullptr, nullptr, nullptr, 0);
         }
@@ -752,6 +834,7 @@ template <class T> class Engine final : public EngineBase {
         s->force_pass_bytes = n_owned * (Rp + 3 * w) + 4 * (s->n_pairs_full / 2);          // force pass: N(R_p + 3w) + 4L
         prof.resolve(stream);
         for (int k = 0; k < Prof::NS; ++k) { s->prof_ms[k] = prof.ms[k]; s->prof_calls[k] = prof.calls[k]; }
+        s->n_outer_builds = n_outer; s->n_filter_passes = n_filters;
     }
 
     void gather_coords(const int32_t* idx_dev, const void* shift_dev, int64_t n, void* out_dev) override {

@@ -15,7 +15,7 @@
 
 namespace mhip {
 
-enum { FLAG_MINIMG = 0, FLAG_OVERFLOW = 1, FLAG_MAX_TILE = 2, FLAG_MAX_ROWS = 3, FLAG_NAN = 4, FLAG_TOTAL_ROWS = 5, FLAG_MAX_CELLS = 6, N_FLAGS = 8 };
+enum { FLAG_MINIMG = 0, FLAG_OVERFLOW = 1, FLAG_MAX_TILE = 2, FLAG_MAX_ROWS = 3, FLAG_NAN = 4, FLAG_TOTAL_ROWS = 5, FLAG_MAX_CELLS = 6, FLAG_MAX_DISP2 = 7, N_FLAGS = 8 };
 enum { OVF_TILE = 1, OVF_ROWS = 2, OVF_BOXCELLS = 4, OVF_SLOT = 8 };
 
 constexpr int MAX_BOX_CELLS = 8192;
@@ -397,8 +397,21 @@ __global__ void k_build(BuildArgs<T> A) {
             if (__ballot(near) == 0ull || A.debug == 8) continue;          // the whole group is out of this wave's reach
             int mine_lo = 0, mine_hi = 0;                  // lane i: mask of its neighbours within this group
             if (!exact_only) {
-#pragma unroll 8
-                for (int i = 0; i < WAVE; ++i) {
+                // which of my wave's i-atoms can reach this group at all?  bounding box of the group's near atoms
+                // (wave min/max), every lane tests ITS i-atom against it; the scalar loop then visits only those.
+                float gmn[3] = {near ? pl.x : 3.0e38f, near ? pl.y : 3.0e38f, near ? pl.z : 3.0e38f};
+                float gmx[3] = {near ? pl.x : -3.0e38f, near ? pl.y : -3.0e38f, near ? pl.z : -3.0e38f};
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) { gmn[d] = fminf(gmn[d], __shfl_xor(gmn[d], o, WAVE)); gmx[d] = fmaxf(gmx[d], __shfl_xor(gmx[d], o, WAVE)); }
+                float acc = 0.f;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { float e = gmn[d] - ml[d]; float f = ml[d] - gmx[d]; e = e > f ? e : f; e = e > 0.f ? e : 0.f; acc += e * e; }
+                unsigned long long im = __ballot(valid && acc <= reach2f);
+                while (im) {
+                    const int i = __builtin_ctzll(im);
+                    im &= im - 1;
                     const float ix = lane_bcast(ml[0], i), iy = lane_bcast(ml[1], i), iz = lane_bcast(ml[2], i);
                     float dx = pl.x - ix, dy = pl.y - iy, dz = pl.z - iz;
                     float r2 = dx * dx + dy * dy + dz * dz;
@@ -461,19 +474,184 @@ __global__ void k_build(BuildArgs<T> A) {
     if (lane == 0) A.wave_rows[(b * A.JS + js) * NW + wv] = rows_wave;   // > R_cap reports the required capacity; k_build_summary zeroes it
 }
 
-// one block: reduce the per-block / per-wave results of k_build into the flag words the host reads
-__global__ void k_build_summary(int n_blocks, int n_waves, int R_cap, const int32_t* __restrict__ tile_cnt, int32_t* wave_rows, int32_t* flags) {
-    __shared__ int sh_t[256], sh_r[256], sh_s[256];
-    int mt = 0, mr = 0, tot = 0;
-    for (int q = threadIdx.x; q < n_blocks; q += blockDim.x) mt = max(mt, tile_cnt[q]);
-    for (int q = threadIdx.x; q < n_waves; q += blockDim.x) { int r = wave_rows[q]; mr = max(mr, r); if (r > R_cap) wave_rows[q] = 0; else tot += r; }
-    sh_t[threadIdx.x] = mt; sh_r[threadIdx.x] = mr; sh_s[threadIdx.x] = tot;
+// reduce the per-block / per-wave results of k_build or k_filter into the flag words the host reads (flags zeroed before)
+__global__ void k_build_summary(int n_blocks, int n_waves, int R_cap, const int32_t* __restrict__ tile_cnt, int32_t* wave_rows,
+                                const float* __restrict__ blk_disp2, int32_t* flags) {
+    __shared__ int sh_t[256], sh_r[256], sh_s[256]; __shared__ float sh_d[256];
+    int mt = 0, mr = 0, tot = 0; float md = 0.f;
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x, gn = gridDim.x * blockDim.x;
+    for (int q = gt; q < n_blocks; q += gn) { mt = max(mt, tile_cnt[q]); if (blk_disp2) md = fmaxf(md, blk_disp2[q]); }
+    for (int q = gt; q < n_waves; q += gn) { int r = wave_rows[q]; mr = max(mr, r); if (r > R_cap) wave_rows[q] = 0; else tot += r; }
+    sh_t[threadIdx.x] = mt; sh_r[threadIdx.x] = mr; sh_s[threadIdx.x] = tot; sh_d[threadIdx.x] = md;
     __syncthreads();
     for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) { sh_t[threadIdx.x] = max(sh_t[threadIdx.x], sh_t[threadIdx.x + o]); sh_r[threadIdx.x] = max(sh_r[threadIdx.x], sh_r[threadIdx.x + o]); sh_s[threadIdx.x] += sh_s[threadIdx.x + o]; }
+        if ((int)threadIdx.x < o) {
+            sh_t[threadIdx.x] = max(sh_t[threadIdx.x], sh_t[threadIdx.x + o]); sh_r[threadIdx.x] = max(sh_r[threadIdx.x], sh_r[threadIdx.x + o]);
+            sh_s[threadIdx.x] += sh_s[threadIdx.x + o]; sh_d[threadIdx.x] = fmaxf(sh_d[threadIdx.x], sh_d[threadIdx.x + o]);
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { atomicMax(&flags[FLAG_MAX_TILE], sh_t[0]); flags[FLAG_MAX_ROWS] = sh_r[0]; flags[FLAG_TOTAL_ROWS] = sh_s[0]; }
+    if (threadIdx.x == 0) {
+        atomicMax(&flags[FLAG_MAX_TILE], sh_t[0]); atomicMax(&flags[FLAG_MAX_ROWS], sh_r[0]); atomicAdd(&flags[FLAG_TOTAL_ROWS], sh_s[0]);
+        atomicMax(reinterpret_cast<unsigned int*>(&flags[FLAG_MAX_DISP2]), __float_as_uint(sh_d[0]));   // d2 >= 0: uint order = float order
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Dual pair list ("dynamic pruning"): k_build searches with the OUTER radius r_list + Δ only every few rebuild
+// intervals; at every rebuild step k_filter re-tests the outer entries at the current coordinates and keeps exactly
+// the pairs with r2 <= r_list² (reference predicate, exact arithmetic inside the ±1e-4 band).  As long as no atom
+// moved more than Δ/2 since the outer build — checked here, max displacement² goes to flags — the kept set is
+// bit-identical to a fresh search.  Same tile, same slots, same row layout as the outer list.
+template <class T> struct FilterArgs {
+    GridP<T> G;
+    int64_t n_owned;
+    int BI, BI_shift, JS, T_cap, T_lds, R_cap, n_blocks;
+    const typename Vec<T>::T4* pos;
+    const typename Vec<T>::T4* pos_snap;      // coordinates at the outer build (same sorted order)
+    const int32_t* tile_idx;
+    const int32_t* tile_cnt;
+    const uint2* nbr_out; const int32_t* rows_out;
+    uint2* nbr_in; int32_t* rows_in;
+    int32_t* tile_idx_in; int32_t* tile_cnt_in;   // compacted tile: only the atoms the inner list references
+    const typename Vec<T>::T4* blk_center;
+    float* blk_disp2;                         // [n_blocks] max displacement² of the block's atoms since the outer build
+    int32_t* flags;
+    T r_in, r_in2;                            // r_list and r_list² as the reference forms them (dist_cutoff ^ 2)
+    int exact_all;                            // small boxes: block-local coordinates are ambiguous, decide every pair exactly
+};
+
+template <class T>
+__global__ void k_filter(FilterArgs<T> A) {
+    using T4 = typename Vec<T>::T4;
+    extern __shared__ __align__(32) unsigned char smem[];
+    const GridP<T>& G = A.G;
+    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
+    const int li = tid & (A.BI - 1), js = tid >> A.BI_shift;
+    const int tile_n = A.tile_cnt[b];
+    float4* l_pos = reinterpret_cast<float4*>(smem);
+    uint32_t* l_used = reinterpret_cast<uint32_t*>(l_pos + A.T_lds);          // bit t: tile atom t is referenced by the inner list
+    uint16_t* l_new = reinterpret_cast<uint16_t*>(l_used + (A.T_cap + 31) / 32 + 1);   // its slot in the compacted tile
+    int32_t* l_part = reinterpret_cast<int32_t*>(l_new + ((A.T_cap + 2) & ~1));  // nthr scan scratch
+    const T4 ctr = A.blk_center[b];
+    const bool use_lds = !A.exact_all && tile_n <= A.T_lds;
+    auto localise = [&](T4 p) -> float4 {
+        T x = p.x - ctr.x, y = p.y - ctr.y, z = p.z - ctr.z;
+        if (G.periodic[0]) x -= G.L[0] * M<T>::rint(x * G.invL[0]);
+        if (G.periodic[1]) y -= G.L[1] * M<T>::rint(y * G.invL[1]);
+        if (G.periodic[2]) z -= G.L[2] * M<T>::rint(z * G.invL[2]);
+        return make_float4((float)x, (float)y, (float)z, 0.f);
+    };
+    const int32_t* tix = A.tile_idx + (int64_t)b * A.T_cap;
+    if (use_lds) for (int t = tid; t < tile_n; t += nthr) l_pos[t] = localise(A.pos[tix[t]]);
+    const int nuw = (tile_n + 31) >> 5;
+    for (int w = tid; w < nuw; w += nthr) l_used[w] = 0u;
+    const int64_t si = (int64_t)b * A.BI + li;
+    const bool valid = si < A.n_owned;
+    const T4 pi = A.pos[valid ? si : (int64_t)b * A.BI];
+    const float4 pil = localise(pi);
+    // displacement of my atom since the outer build (nearest image): the host re-searches when 2·max > Δ
+    __shared__ float s_d2[16];
+    {
+        float d2 = 0.f;
+        if (valid && js == 0) {
+            T4 q = A.pos_snap[si];
+            T dx = pi.x - q.x, dy = pi.y - q.y, dz = pi.z - q.z;
+            if (G.periodic[0]) dx -= G.L[0] * M<T>::rint(dx * G.invL[0]);
+            if (G.periodic[1]) dy -= G.L[1] * M<T>::rint(dy * G.invL[1]);
+            if (G.periodic[2]) dz -= G.L[2] * M<T>::rint(dz * G.invL[2]);
+            d2 = (float)(dx * dx + dy * dy + dz * dz);
+        }
+        d2 = wave_max(d2);
+        if (lane == 0) s_d2[tid >> 6] = d2;
+    }
+    __syncthreads();
+    if (tid == 0) { float m = 0.f; for (int w = 0; w < (nthr >> 6); ++w) m = fmaxf(m, s_d2[w]); A.blk_disp2[b] = m; }
+    const int wslot = (b * A.JS + js) * (A.BI >> 6) + (li >> 6);
+    const int rows = A.rows_out[wslot];
+    const uint2* src = A.nbr_out + (((int64_t)b * A.JS + js) * A.R_cap) * A.BI + li;
+    uint2* dst = A.nbr_in + (((int64_t)b * A.JS + js) * A.R_cap) * A.BI + li;
+    const float rl2 = (float)A.r_in2, band_lo = rl2 * (1.0f - 1e-4f), band_hi = rl2 * (1.0f + 1e-4f);
+    const uint32_t SENT = (uint32_t)tile_n;
+    uint32_t pack[2] = {0, 0};
+    int cnt = 0;
+    auto emit = [&](uint32_t e) {
+        int k = cnt & 3;
+        if (k == 0) { pack[0] = 0; pack[1] = 0; }
+        pack[k >> 1] |= e << (16 * (k & 1));
+        ++cnt;
+        if (k == 3) dst[(int64_t)((cnt >> 2) - 1) * A.BI] = make_uint2(pack[0], pack[1]);
+    };
+    uint2 e_next = (0 < rows) ? src[0] : make_uint2(0, 0);
+    for (int r = 0; r < rows; ++r) {
+        const uint2 e4 = e_next;
+        if (r + 1 < rows) e_next = src[(int64_t)(r + 1) * A.BI];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t e = ((k < 2 ? e4.x : e4.y) >> (16 * (k & 1))) & 0xffffu;
+            uint32_t slot = e & 0x7fffu;
+            if (slot >= SENT || !valid) continue;
+            bool in = false, maybe = true;
+            if (use_lds) {
+                float4 pj = l_pos[slot];
+                float dx = pj.x - pil.x, dy = pj.y - pil.y, dz = pj.z - pil.z;
+                float r2 = dx * dx + dy * dy + dz * dz;
+                in = r2 < band_lo; maybe = !in && r2 <= band_hi;
+            }
+            if (maybe) {
+                T4 pj = A.pos[tix[slot]];
+                T ex = G.periodic[0] ? vector_1d_exact(pi.x, pj.x, G.L[0]) : M<T>::sub(pj.x, pi.x);
+                T ey = G.periodic[1] ? vector_1d_exact(pi.y, pj.y, G.L[1]) : M<T>::sub(pj.y, pi.y);
+                T ez = G.periodic[2] ? vector_1d_exact(pi.z, pj.z, G.L[2]) : M<T>::sub(pj.z, pi.z);
+                in = norm2_exact(ex, ey, ez) <= A.r_in2;
+            }
+            if (in) { emit(e); atomicOr(&l_used[slot >> 5], 1u << (slot & 31)); }
+        }
+    }
+    int rows_mine = (cnt + 3) >> 2;
+    int rows_wave = wave_max(rows_mine);
+    while (((cnt + 3) >> 2) < rows_wave || (cnt & 3)) emit(SENT);
+    if (lane == 0) A.rows_in[wslot] = rows_wave;
+    // compact the tile to the referenced atoms: rank of every used slot (ordered), new tile list, rows rewritten in place
+    __syncthreads();
+    {
+        int per = (nuw + nthr - 1) / nthr, w0 = min(tid * per, nuw), w1 = min(w0 + per, nuw);
+        int sum = 0;
+        for (int w = w0; w < w1; ++w) sum += __popc(l_used[w]);
+        l_part[tid] = sum;
+        __syncthreads();
+        if (tid < WAVE) {
+            int run = 0;
+            for (int base = 0; base < nthr; base += WAVE) {
+                int v = (base + tid < nthr) ? l_part[base + tid] : 0, x = v;
+#pragma unroll
+                for (int o = 1; o < WAVE; o <<= 1) { int u = __shfl_up(x, o, WAVE); if (tid >= o) x += u; }
+                if (base + tid < nthr) l_part[base + tid] = run + x - v;
+                run += __shfl(x, WAVE - 1, WAVE);
+            }
+            if (tid == 0) A.tile_cnt_in[b] = run;
+        }
+        __syncthreads();
+        int run = l_part[tid];
+        for (int w = w0; w < w1; ++w) {
+            uint32_t m = l_used[w];
+            while (m) { int bit = __builtin_ctz(m); m &= m - 1; int t = (w << 5) + bit; l_new[t] = (uint16_t)run; A.tile_idx_in[(int64_t)b * A.T_cap + run] = tix[t]; ++run; }
+        }
+    }
+    __syncthreads();
+    const uint32_t n_in = (uint32_t)A.tile_cnt_in[b];   // written by thread 0 before the barriers above
+    for (int r = 0; r < rows_wave; ++r) {
+        uint2 e4 = dst[(int64_t)r * A.BI];
+        uint32_t out[2] = {0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t e = ((k < 2 ? e4.x : e4.y) >> (16 * (k & 1))) & 0xffffu;
+            uint32_t slot = e & 0x7fffu;
+            uint32_t ns = slot >= SENT ? n_in : (uint32_t)l_new[slot];
+            out[k >> 1] |= (ns | (e & 0x8000u)) << (16 * (k & 1));
+        }
+        dst[(int64_t)r * A.BI] = make_uint2(out[0], out[1]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------

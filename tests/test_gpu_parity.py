@@ -334,3 +334,25 @@ def test_full_size_256k_lj_against_oracle(pkg):
     assert st["minimg_mode"] == 0
     e_ref = o.potential_energy(nl)
     assert pkg.potential_energy(s) == pytest.approx(e_ref, rel=2e-5)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_dual_pair_list_stays_bit_exact_during_a_run(pkg, dtype):
+    """The engine searches with r_list + 0.1 nm every 5th rebuild interval and FILTERS that outer list to exactly r_list at
+    every rebuild step.  After 30 steps (filter passes at 10, 20, 30) the list it is using must equal a fresh reference
+    search on the coordinates it holds — same pair set, same special flags."""
+    import ctypes as C
+    case = S.charged_fluid(12, dict(kind="rf", rc=1.0), dtype=dtype)
+    s = case.system(pkg, dtype)
+    pkg.simulate(s, pkg.VelocityVerlet(dt=0.001), 30)
+    L = pkg.lib()
+    n = C.c_int64(0)
+    s._check(L.mhip_export_neighbors(s.engine(), None, None, None, 0, C.byref(n)))
+    i = np.empty(n.value, np.int32); j = np.empty(n.value, np.int32); sp = np.empty(n.value, np.uint8)
+    s._check(L.mhip_export_neighbors(s.engine(), s._ptr(i), s._ptr(j), s._ptr(sp), n.value, C.byref(n)))
+    st = s.stats()
+    o = case.oracle(dtype, coords=s.coords.astype(np.float64))
+    oi, oj, osp = o.neighbors("cell", nthreads=4)
+    a, b = nl_keys(oi, oj, osp), nl_keys(i, j, sp)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert st["n_rebuilds"] >= 4
