@@ -33,10 +33,8 @@ __device__ inline void block_sum_to(double v, double* part) {
 }
 
 template <class T, bool ENERGY>
-__global__ void k_bonds(int64_t n, const int32_t* __restrict__ bi, const int32_t* __restrict__ bj, const T* __restrict__ bk, const T* __restrict__ br0,
-                        const int32_t* __restrict__ inv, const typename Vec<T>::T4* __restrict__ pos, typename Vec<T>::T4* frc, double* part, GridP<T> G) {
-    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    double e = 0;
+__device__ inline void d_bonds(int64_t t, int64_t n, const int32_t* __restrict__ bi, const int32_t* __restrict__ bj, const T* __restrict__ bk, const T* __restrict__ br0,
+                        const int32_t* __restrict__ inv, const typename Vec<T>::T4* __restrict__ pos, typename Vec<T>::T4* frc, double& e, const GridP<T>& G) {
     if (t < n) {
         int i = inv[bi[t]], j = inv[bj[t]];
         T ab[3]; min_image<T>(pos[i], pos[j], G, ab);
@@ -45,15 +43,12 @@ __global__ void k_bonds(int64_t n, const int32_t* __restrict__ bi, const int32_t
         if constexpr (ENERGY) e = (double)((bk[t] / T(2)) * dr * dr);
         else { T c = bk[t] * dr / r; add_force<T>(frc, i, c * ab[0], c * ab[1], c * ab[2]); add_force<T>(frc, j, -c * ab[0], -c * ab[1], -c * ab[2]); }
     }
-    if constexpr (ENERGY) block_sum_to(e, part);
 }
 
 template <class T, bool ENERGY>
-__global__ void k_angles(int64_t n, const int32_t* __restrict__ ai, const int32_t* __restrict__ aj, const int32_t* __restrict__ ak, const T* __restrict__ kth,
+__device__ inline void d_angles(int64_t t, int64_t n, const int32_t* __restrict__ ai, const int32_t* __restrict__ aj, const int32_t* __restrict__ ak, const T* __restrict__ kth,
                          const T* __restrict__ th0, const int32_t* __restrict__ inv, const typename Vec<T>::T4* __restrict__ pos, typename Vec<T>::T4* frc,
-                         double* part, GridP<T> G) {
-    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    double e = 0;
+                         double& e, const GridP<T>& G) {
     if (t < n) {
         int i = inv[ai[t]], j = inv[aj[t]], k = inv[ak[t]];
         T ba[3], bc[3], cr[3];
@@ -77,15 +72,12 @@ __global__ void k_angles(int64_t n, const int32_t* __restrict__ ai, const int32_
             }
         }
     }
-    if constexpr (ENERGY) block_sum_to(e, part);
 }
 
 template <class T, bool ENERGY>
-__global__ void k_torsions(int64_t n, const int32_t* __restrict__ ti, const int32_t* __restrict__ tj, const int32_t* __restrict__ tk, const int32_t* __restrict__ tl,
+__device__ inline void d_torsions(int64_t t, int64_t n, const int32_t* __restrict__ ti, const int32_t* __restrict__ tj, const int32_t* __restrict__ tk, const int32_t* __restrict__ tl,
                            const int32_t* __restrict__ per, const T* __restrict__ phase, const T* __restrict__ k0, const int32_t* __restrict__ inv,
-                           const typename Vec<T>::T4* __restrict__ pos, typename Vec<T>::T4* frc, double* part, GridP<T> G) {
-    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    double e = 0;
+                           const typename Vec<T>::T4* __restrict__ pos, typename Vec<T>::T4* frc, double& e, const GridP<T>& G) {
     if (t < n) {
         int i = inv[ti[t]], j = inv[tj[t]], k = inv[tk[t]], l = inv[tl[t]];
         T ab[3], bc[3], cd[3], c1[3], c2[3], c12[3];
@@ -108,14 +100,11 @@ __global__ void k_torsions(int64_t n, const int32_t* __restrict__ ti, const int3
             add_force<T>(frc, l, fl[0], fl[1], fl[2]);
         }
     }
-    if constexpr (ENERGY) block_sum_to(e, part);
 }
 
 template <class T, bool ENERGY>
-__global__ void k_ewald_excl(int64_t n, const int32_t* __restrict__ xi, const int32_t* __restrict__ xj, const int32_t* __restrict__ inv,
-                             const typename Vec<T>::T4* __restrict__ pos, typename Vec<T>::T4* frc, double* part, GridP<T> G, InterP<T> I) {
-    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    double e = 0;
+__device__ inline void d_ewald_excl(int64_t t, int64_t n, const int32_t* __restrict__ xi, const int32_t* __restrict__ xj, const int32_t* __restrict__ inv,
+                             const typename Vec<T>::T4* __restrict__ pos, typename Vec<T>::T4* frc, double& e, const GridP<T>& G, const InterP<T>& I) {
     if (t < n) {
         int i = inv[xi[t]], j = inv[xj[t]];
         auto pi = pos[i], pj = pos[j];
@@ -132,7 +121,30 @@ __global__ void k_ewald_excl(int64_t n, const int32_t* __restrict__ xi, const in
             add_force<T>(frc, j, -dE * d[0], -dE * d[1], -dE * d[2]);
         }
     }
-    if constexpr (ENERGY) block_sum_to(e, part);
+}
+
+// All specific interaction lists in ONE launch: consecutive block ranges serve bonds, angles, torsion terms and Ewald
+// exclusions, so the (latency-bound, few-thousand-thread) lists overlap instead of queueing behind each other.
+template <class T> struct BondedArgs {
+    int64_t n_b, n_a, n_t, n_x;
+    int blk_b, blk_a, blk_t;          // first block of the angle / torsion / exclusion ranges are the running sums
+    const int32_t *b_i, *b_j; const T *b_k, *b_r0;
+    const int32_t *a_i, *a_j, *a_k; const T *a_kth, *a_th0;
+    const int32_t *t_i, *t_j, *t_k, *t_l, *t_per; const T *t_phase, *t_k0;
+    const int32_t *x_i, *x_j;
+    const int32_t* inv; const typename Vec<T>::T4* pos; typename Vec<T>::T4* frc; double* part;
+    GridP<T> G; InterP<T> I;
+};
+
+template <class T, bool ENERGY>
+__global__ void k_bonded(BondedArgs<T> A) {
+    const int blk = blockIdx.x;
+    double e = 0;
+    if (blk < A.blk_b) d_bonds<T, ENERGY>((int64_t)blk * blockDim.x + threadIdx.x, A.n_b, A.b_i, A.b_j, A.b_k, A.b_r0, A.inv, A.pos, A.frc, e, A.G);
+    else if (blk < A.blk_b + A.blk_a) d_angles<T, ENERGY>((int64_t)(blk - A.blk_b) * blockDim.x + threadIdx.x, A.n_a, A.a_i, A.a_j, A.a_k, A.a_kth, A.a_th0, A.inv, A.pos, A.frc, e, A.G);
+    else if (blk < A.blk_b + A.blk_a + A.blk_t) d_torsions<T, ENERGY>((int64_t)(blk - A.blk_b - A.blk_a) * blockDim.x + threadIdx.x, A.n_t, A.t_i, A.t_j, A.t_k, A.t_l, A.t_per, A.t_phase, A.t_k0, A.inv, A.pos, A.frc, e, A.G);
+    else d_ewald_excl<T, ENERGY>((int64_t)(blk - A.blk_b - A.blk_a - A.blk_t) * blockDim.x + threadIdx.x, A.n_x, A.x_i, A.x_j, A.inv, A.pos, A.frc, e, A.G, A.I);
+    if constexpr (ENERGY) block_sum_to(e, A.part);
 }
 
 template <class U> struct HBuf {   // device array filled from a host array once
@@ -166,29 +178,33 @@ template <class T> struct Bonded {
     bool any() const { return b_i.n || a_i.n || t_i.n || x_i.n; }
     void release() { for (auto* h : {&b_i, &b_j, &a_i, &a_j, &a_k, &t_i, &t_j, &t_k, &t_l, &t_per, &x_i, &x_j}) h->release(); for (auto* h : {&b_k, &b_r0, &a_kth, &a_th0, &t_phase, &t_k0}) h->release(); }
 
+    static constexpr int BT = 64;   // one wave per block: thousands of short, latency-bound terms spread over all CUs
+    BondedArgs<T> args(const GridP<T>& G, const InterP<T>& I, const T4* pos, const int32_t* inv, T4* frc, double* part) const {
+        BondedArgs<T> A;
+        A.n_b = b_i.n; A.n_a = a_i.n; A.n_t = t_i.n; A.n_x = x_i.n;
+        A.blk_b = cdiv(b_i.n, BT); A.blk_a = cdiv(a_i.n, BT); A.blk_t = cdiv(t_i.n, BT);
+        A.b_i = b_i.p; A.b_j = b_j.p; A.b_k = b_k.p; A.b_r0 = b_r0.p;
+        A.a_i = a_i.p; A.a_j = a_j.p; A.a_k = a_k.p; A.a_kth = a_kth.p; A.a_th0 = a_th0.p;
+        A.t_i = t_i.p; A.t_j = t_j.p; A.t_k = t_k.p; A.t_l = t_l.p; A.t_per = t_per.p; A.t_phase = t_phase.p; A.t_k0 = t_k0.p;
+        A.x_i = x_i.p; A.x_j = x_j.p; A.inv = inv; A.pos = pos; A.frc = frc; A.part = part; A.G = G; A.I = I;
+        return A;
+    }
+    int n_blocks() const { return cdiv(b_i.n, BT) + cdiv(a_i.n, BT) + cdiv(t_i.n, BT) + cdiv(x_i.n, BT); }
+
     void launch_forces(hipStream_t s, const GridP<T>& G, const InterP<T>& I, const T4* pos, const int32_t* inv, T4* frc) {
-        if (b_i.n) hipLaunchKernelGGL((k_bonds<T, false>), dim3(cdiv(b_i.n, 256)), dim3(256), 0, s, (int64_t)b_i.n, b_i.p, b_j.p, b_k.p, b_r0.p, inv, pos, frc, (double*)nullptr, G);
-        if (a_i.n) hipLaunchKernelGGL((k_angles<T, false>), dim3(cdiv(a_i.n, 256)), dim3(256), 0, s, (int64_t)a_i.n, a_i.p, a_j.p, a_k.p, a_kth.p, a_th0.p, inv, pos, frc, (double*)nullptr, G);
-        if (t_i.n) hipLaunchKernelGGL((k_torsions<T, false>), dim3(cdiv(t_i.n, 256)), dim3(256), 0, s, (int64_t)t_i.n, t_i.p, t_j.p, t_k.p, t_l.p, t_per.p, t_phase.p, t_k0.p, inv, pos, frc, (double*)nullptr, G);
-        if (x_i.n) hipLaunchKernelGGL((k_ewald_excl<T, false>), dim3(cdiv(x_i.n, 256)), dim3(256), 0, s, (int64_t)x_i.n, x_i.p, x_j.p, inv, pos, frc, (double*)nullptr, G, I);
+        int nb = n_blocks();
+        if (!nb) return;
+        hipLaunchKernelGGL((k_bonded<T, false>), dim3(nb), dim3(BT), 0, s, args(G, I, pos, inv, frc, nullptr));
         MHIP_HIP(hipGetLastError());
     }
-    // writes per-block partial energies consecutively into part (grown as needed); returns their count
+    // writes per-block partial energies into part (grown as needed); returns their count
     template <class DB> int launch_energy(hipStream_t s, const GridP<T>& G, const InterP<T>& I, const T4* pos, const int32_t* inv, DB& part) {
-        int nb = cdiv(b_i.n, 256), na = cdiv(a_i.n, 256), nt = cdiv(t_i.n, 256), nx = cdiv(x_i.n, 256);
-        int total = nb + na + nt + nx;
-        if (!total) return 0;
-        part.reserve(total);
-        double* p = part.p;
-        if (nb) hipLaunchKernelGGL((k_bonds<T, true>), dim3(nb), dim3(256), 0, s, (int64_t)b_i.n, b_i.p, b_j.p, b_k.p, b_r0.p, inv, pos, (T4*)nullptr, p, G);
-        p += nb;
-        if (na) hipLaunchKernelGGL((k_angles<T, true>), dim3(na), dim3(256), 0, s, (int64_t)a_i.n, a_i.p, a_j.p, a_k.p, a_kth.p, a_th0.p, inv, pos, (T4*)nullptr, p, G);
-        p += na;
-        if (nt) hipLaunchKernelGGL((k_torsions<T, true>), dim3(nt), dim3(256), 0, s, (int64_t)t_i.n, t_i.p, t_j.p, t_k.p, t_l.p, t_per.p, t_phase.p, t_k0.p, inv, pos, (T4*)nullptr, p, G);
-        p += nt;
-        if (nx) hipLaunchKernelGGL((k_ewald_excl<T, true>), dim3(nx), dim3(256), 0, s, (int64_t)x_i.n, x_i.p, x_j.p, inv, pos, (T4*)nullptr, p, G, I);
+        int nb = n_blocks();
+        if (!nb) return 0;
+        part.reserve(nb);
+        hipLaunchKernelGGL((k_bonded<T, true>), dim3(nb), dim3(BT), 0, s, args(G, I, pos, inv, (T4*)nullptr, part.p));
         MHIP_HIP(hipGetLastError());
-        return total;
+        return nb;
     }
 };
 

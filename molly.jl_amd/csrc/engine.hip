@@ -125,13 +125,14 @@ template <class T> class Engine final : public EngineBase {
     DBuf<int32_t> flags; int32_t* h_flags = nullptr;
     int64_t total_rows = 0;
     // reductions
-    DBuf<double> red_part, red_out; double* h_red = nullptr; DBuf<T> vcm;
+    DBuf<double> red_part, red_out, cm_step; double* h_red = nullptr; DBuf<T> vcm;
+    int n_cm_step = 0;   // cm_pending == 2: v_cm still lives as the per-block partials of the last k_vv2 (cm_step[0..4*n_cm_step))
     // staging for host pointers
     DBuf<T> stage_a, stage_b; DBuf<int32_t> stage_i;
     // bonded
     Bonded<T> bonded;
 
-    bool stale = true, minimg = false, cm_pending = false, params_set = false, state_set = false, frc_valid = false;
+    int cm_pending = 0; bool stale = true, minimg = false, params_set = false, state_set = false, frc_valid = false;
     int64_t last_build_step = std::numeric_limits<int64_t>::min();
     int64_t n_rebuilds = 0, n_force_calls = 0; double last_rebuild_ms = 0;
     size_t lds_force = 0; int tile_lds = 0; bool segmented = false;
@@ -151,7 +152,7 @@ template <class T> class Engine final : public EngineBase {
         setup_inter(); setup_grid();
         for (int k = 0; k < 2; ++k) { pos[k].reserve(cap); vel[k].reserve(cap); frc[k].reserve(cap); lj[k].reserve(cap); orig[k].reserve(cap); }
         inv.reserve(cap); key_in.reserve(cap); key_out.reserve(cap); idx_in.reserve(cap); perm.reserve(cap);
-        flags.reserve(N_FLAGS); red_out.reserve(8); vcm.reserve(4);
+        flags.reserve(N_FLAGS); red_out.reserve(8); vcm.reserve(4); cm_step.reserve(4 * 1024);
         MHIP_HIP(hipHostMalloc((void**)&h_flags, N_FLAGS * sizeof(int32_t)));
         MHIP_HIP(hipHostMalloc((void**)&h_red, 8 * sizeof(double)));
         for (int k = 0; k < 2; ++k) { MHIP_HIP(hipMemsetAsync(pos[k].p, 0, cap * sizeof(T4), stream)); MHIP_HIP(hipMemsetAsync(vel[k].p, 0, cap * sizeof(T4), stream)); MHIP_HIP(hipMemsetAsync(frc[k].p, 0, cap * sizeof(T4), stream)); MHIP_HIP(hipMemsetAsync(lj[k].p, 0, cap * sizeof(T2), stream)); }
@@ -171,7 +172,7 @@ template <class T> class Engine final : public EngineBase {
         inv.release(); key_in.release(); key_out.release(); cell_rank.release(); idx_in.release(); perm.release(); cell_cnt.release(); cell_start.release(); cub_tmp.release();
         wave_rows_in.release(); nbr_in.release(); pos_snap.release(); blk_disp2.release(); tile_idx_in.release(); tile_cnt_in.release();
         xl_start.release(); xl_list.release(); tile_idx.release(); tile_cnt.release(); wave_rows.release(); nbr.release(); blk_center.release();
-        flags.release(); red_part.release(); red_out.release(); vcm.release(); stage_a.release(); stage_b.release(); stage_i.release(); bonded.release();
+        flags.release(); red_part.release(); red_out.release(); cm_step.release(); vcm.release(); stage_a.release(); stage_b.release(); stage_i.release(); bonded.release();
         prof.release();
         if (h_flags) (void)hipHostFree(h_flags);
         if (h_red) (void)hipHostFree(h_red);
@@ -287,8 +288,9 @@ template <class T> class Engine final : public EngineBase {
 
     void flush_cm() {
         if (!cm_pending) return;
-        hipLaunchKernelGGL(k_shift_vel<T>, dim3(cdiv(n_owned, 256)), dim3(256), 0, stream, n_owned, vel[cur].p, (const T*)vcm.p);
-        cm_pending = false;
+        hipLaunchKernelGGL(k_shift_vel<T>, dim3(std::min(cdiv(n_owned, 256), 1024)), dim3(256), 0, stream, n_owned, vel[cur].p, (const T*)vcm.p,
+                           cm_pending == 2 ? (const double*)cm_step.p : (const double*)nullptr, n_cm_step);
+        cm_pending = 0;
     }
 
     const T* to_device(const void* host_or_dev, size_t count, int mem_kind, DBuf<T>& stage) {
@@ -545,7 +547,7 @@ template <class T> class Engine final : public EngineBase {
         MHIP_HIP(hipMemcpyAsync(inv.p, iota.data(), n_tot * sizeof(int32_t), hipMemcpyHostToDevice, stream));
         MHIP_HIP(hipMemsetAsync(frc[cur].p, 0, n_tot * sizeof(T4), stream));
         MHIP_HIP(hipStreamSynchronize(stream));
-        stale = true; cm_pending = false; frc_valid = false;
+        stale = true; cm_pending = 0; frc_valid = false;
         setup_grid();          // the dual pair list is a single-domain feature: the search radius depends on n_ghost
         choose_blocking();
     }
@@ -687,14 +689,14 @@ template <class T> class Engine final : public EngineBase {
     void cm_partials_now() {
         int nb = cdiv(n_owned, 256);
         red_part.reserve(4 * (size_t)nb);
-        hipLaunchKernelGGL(k_cm_partials<T>, dim3(nb), dim3(256), 0, stream, n_owned, (const T4*)vel[cur].p, cm_pending ? (const T*)vcm.p : (const T*)nullptr, red_part.p);
+        hipLaunchKernelGGL(k_cm_partials<T>, dim3(nb), dim3(256), 0, stream, n_owned, (const T4*)vel[cur].p, (const T*)nullptr, red_part.p);   // callers flush_cm() first
     }
 
     void remove_cm() override {
         flush_cm();
         cm_partials_now();
         hipLaunchKernelGGL(k_cm_finalize<T>, dim3(1), dim3(256), 0, stream, cdiv(n_owned, 256), (const double*)red_part.p, red_out.p, vcm.p);
-        cm_pending = true; flush_cm();
+        cm_pending = 1; flush_cm();
         MHIP_HIP(hipGetLastError());
     }
 
@@ -712,7 +714,7 @@ template <class T> class Engine final : public EngineBase {
         T h[3] = {T(dv3[0]), T(dv3[1]), T(dv3[2])};
         MHIP_HIP(hipMemcpyAsync(vcm.p, h, 3 * sizeof(T), hipMemcpyHostToDevice, stream));
         MHIP_HIP(hipStreamSynchronize(stream));
-        cm_pending = true; flush_cm();
+        cm_pending = 1; flush_cm();
     }
 
     void cm_momentum_dev(double* out4_dev) override {
@@ -724,7 +726,7 @@ template <class T> class Engine final : public EngineBase {
     void remove_cm_dev(const double* total4_dev) override {
         flush_cm();
         hipLaunchKernelGGL(k_vcm_from_total<T>, dim3(1), dim3(64), 0, stream, total4_dev, vcm.p);
-        cm_pending = true;   // subtracted by the next vv_stage1 (or flushed by any state read)
+        cm_pending = 1;   // subtracted by the next vv_stage1 (or flushed by any state read)
         MHIP_HIP(hipGetLastError());
     }
 
@@ -745,20 +747,18 @@ template <class T> class Engine final : public EngineBase {
     void vv_stage1(double dt) override {
         if (!frc_valid) throw ApiError{MHIP_ERR_STATE, "vv_stage1 needs forces from vv_init / vv_stage2"};
         prof.begin(2, stream);
-        hipLaunchKernelGGL(k_vv1<T>, dim3(cdiv(n_owned, 256)), dim3(256), 0, stream, n_owned, pos[cur].p, vel[cur].p, (const T4*)frc[cur].p, T(dt), T(dt) / T(2),
-                           cm_pending ? (const T*)vcm.p : (const T*)nullptr, G);
+        hipLaunchKernelGGL(k_vv1<T>, dim3(std::min(cdiv(n_owned, 256), 1024)), dim3(256), 0, stream, n_owned, pos[cur].p, vel[cur].p, (const T4*)frc[cur].p, T(dt), T(dt) / T(2),
+                           cm_pending == 1 ? (const T*)vcm.p : (const T*)nullptr, cm_pending == 2 ? (const double*)cm_step.p : (const double*)nullptr, n_cm_step, G);
         prof.end(2, stream);
-        cm_pending = false;
+        cm_pending = 0;
     }
     void stage2_impl(double dt, bool cm) {
         step_forces();
-        const int nb = cdiv(n_owned, 256);
+        const int nb = std::min(cdiv(n_owned, 256), 1024);
         prof.begin(2, stream);
         if (cm) {
-            red_part.reserve(4 * (size_t)nb + 8);
-            hipLaunchKernelGGL((k_vv2<T, true>), dim3(nb), dim3(256), 0, stream, n_owned, vel[cur].p, (const T4*)frc[cur].p, T(dt) / T(2), red_part.p);
-            hipLaunchKernelGGL(k_cm_finalize<T>, dim3(1), dim3(256), 0, stream, nb, (const double*)red_part.p, red_out.p, vcm.p);
-            cm_pending = true;
+            hipLaunchKernelGGL((k_vv2<T, true>), dim3(nb), dim3(256), 0, stream, n_owned, vel[cur].p, (const T4*)frc[cur].p, T(dt) / T(2), cm_step.p);
+            cm_pending = 2; n_cm_step = nb;   // the next k_vv1 (or any flush) re-sums the partials: no finalize launch
         } else {
             hipLaunchKernelGGL((k_vv2<T, false>), dim3(nb), dim3(256), 0, stream, n_owned, vel[cur].p, (const T4*)frc[cur].p, T(dt) / T(2), (double*)nullptr);
         }

@@ -808,32 +808,51 @@ __global__ void k_export_nl(int n_blocks, int BI, int JS, int T_cap, int R_cap, 
 
 // ---------------------------------------------------------------------------------------------------
 // velocity Verlet (simulators.jl:589-629), owned atoms, sorted order.  vel.w carries the mass.
+// v_cm = Σ(m v) / Σ m from the per-block partials of k_vv2, re-summed by EVERY block in the same fixed order (n_part <= 1024,
+// 32 KB of L2 reads per block): no separate finalize launch between the second kick and the next first kick.
+template <class T>
+__device__ inline void block_vcm(const double* __restrict__ part, int n_part, T* vcm3) {
+    __shared__ double sh_cm[4][4];
+    double a[4] = {0, 0, 0, 0};
+    for (int q = threadIdx.x; q < n_part; q += blockDim.x) { const double* p = part + 4 * (int64_t)q; a[0] += p[0]; a[1] += p[1]; a[2] += p[2]; a[3] += p[3]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) for (int c = 0; c < 4; ++c) a[c] += __shfl_xor(a[c], o, 64);
+    if ((threadIdx.x & 63) == 0) for (int c = 0; c < 4; ++c) sh_cm[threadIdx.x >> 6][c] = a[c];
+    __syncthreads();
+    double t[4] = {0, 0, 0, 0};
+    for (int q = 0; q < (int)(blockDim.x >> 6); ++q) for (int c = 0; c < 4; ++c) t[c] += sh_cm[q][c];
+    for (int c = 0; c < 3; ++c) vcm3[c] = (T)(t[c] / t[3]);
+}
+
 template <class T>
 __global__ void k_vv1(int64_t n, typename Vec<T>::T4* pos, typename Vec<T>::T4* vel, const typename Vec<T>::T4* __restrict__ frc,
-                      T dt, T dt2, const T* __restrict__ vcm, GridP<T> G) {
-    int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (s >= n) return;
-    auto v = vel[s]; auto p = pos[s]; auto f = frc[s];
-    if (vcm) { v.x -= vcm[0]; v.y -= vcm[1]; v.z -= vcm[2]; }            // deferred remove_CM_motion!
-    T im = (v.w == T(0)) ? T(0) : T(1) / v.w;                              // calc_accels, force.jl:17
-    v.x += (f.x * im) * dt2; v.y += (f.y * im) * dt2; v.z += (f.z * im) * dt2;   // :594
-    p.x += v.x * dt; p.y += v.y * dt; p.z += v.z * dt;                     // :602
-    if (G.periodic[0]) p.x = wrap_1d(p.x, G.L[0]);                         // :609
-    if (G.periodic[1]) p.y = wrap_1d(p.y, G.L[1]);
-    if (G.periodic[2]) p.z = wrap_1d(p.z, G.L[2]);
-    vel[s] = v; pos[s] = p;
+                      T dt, T dt2, const T* __restrict__ vcm, const double* __restrict__ cm_part, int n_cm_part, GridP<T> G) {
+    T vc[3] = {T(0), T(0), T(0)};
+    const bool sub = vcm != nullptr || cm_part != nullptr;
+    if (cm_part) block_vcm<T>(cm_part, n_cm_part, vc);
+    else if (vcm) { vc[0] = vcm[0]; vc[1] = vcm[1]; vc[2] = vcm[2]; }
+    for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
+        auto v = vel[s]; auto p = pos[s]; auto f = frc[s];
+        if (sub) { v.x -= vc[0]; v.y -= vc[1]; v.z -= vc[2]; }                // deferred remove_CM_motion!
+        T im = (v.w == T(0)) ? T(0) : T(1) / v.w;                              // calc_accels, force.jl:17
+        v.x += (f.x * im) * dt2; v.y += (f.y * im) * dt2; v.z += (f.z * im) * dt2;   // :594
+        p.x += v.x * dt; p.y += v.y * dt; p.z += v.z * dt;                     // :602
+        if (G.periodic[0]) p.x = wrap_1d(p.x, G.L[0]);                         // :609
+        if (G.periodic[1]) p.y = wrap_1d(p.y, G.L[1]);
+        if (G.periodic[2]) p.z = wrap_1d(p.z, G.L[2]);
+        vel[s] = v; pos[s] = p;
+    }
 }
 
 template <class T, bool CM>
 __global__ void k_vv2(int64_t n, typename Vec<T>::T4* vel, const typename Vec<T>::T4* __restrict__ frc, T dt2, double* cm_part) {
-    int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     double px = 0, py = 0, pz = 0, m = 0;
-    if (s < n) {
+    for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
         auto v = vel[s]; auto f = frc[s];
         T im = (v.w == T(0)) ? T(0) : T(1) / v.w;
         v.x += (f.x * im) * dt2; v.y += (f.y * im) * dt2; v.z += (f.z * im) * dt2;   // :616
         vel[s] = v;
-        if constexpr (CM) { px = (double)v.x * v.w; py = (double)v.y * v.w; pz = (double)v.z * v.w; m = v.w; }
+        if constexpr (CM) { px += (double)v.x * v.w; py += (double)v.y * v.w; pz += (double)v.z * v.w; m += v.w; }
     }
     if constexpr (CM) {
         __shared__ double sh[4][4];
@@ -886,10 +905,13 @@ __global__ void k_vcm_from_total(const double* __restrict__ total4, T* vcm) {
 }
 
 template <class T>
-__global__ void k_shift_vel(int64_t n, typename Vec<T>::T4* vel, const T* __restrict__ vcm) {
-    int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (s >= n) return;
-    auto v = vel[s]; v.x -= vcm[0]; v.y -= vcm[1]; v.z -= vcm[2]; vel[s] = v;
+__global__ void k_shift_vel(int64_t n, typename Vec<T>::T4* vel, const T* __restrict__ vcm, const double* __restrict__ cm_part, int n_cm_part) {
+    T vc[3];
+    if (cm_part) block_vcm<T>(cm_part, n_cm_part, vc);
+    else { vc[0] = vcm[0]; vc[1] = vcm[1]; vc[2] = vcm[2]; }
+    for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
+        auto v = vel[s]; v.x -= vc[0]; v.y -= vc[1]; v.z -= vc[2]; vel[s] = v;
+    }
 }
 
 // kinetic energy partials: Σ (m/2) v·v  (energy.jl:56-89)
