@@ -120,7 +120,8 @@ template <class T> class Engine final : public EngineBase {
     int ljm_base = LJ_OFF;   // LJ mode implied by the interaction; ljm may be upgraded to the uniform fast path
     DBuf<int32_t> tile_idx, tile_cnt, wave_rows; DBuf<uint2> nbr; DBuf<T4> blk_center;
     // dual pair list: outer list (nbr / wave_rows, radius r_list + margin) and the inner list filtered from it
-    DBuf<int32_t> wave_rows_in, tile_idx_in, tile_cnt_in; DBuf<uint2> nbr_in; DBuf<T4> pos_snap; DBuf<float> blk_disp2; int max_tile_in = 0;
+    DBuf<int32_t> wave_rows_in, tile_idx_in, tile_cnt_in, rows_x; DBuf<uint2> nbr_in, nbr_x; DBuf<T4> pos_snap; DBuf<float> blk_disp2; int max_tile_in = 0;
+    bool inner_valid = false, prune_disp_exceeded = false;
     bool dual = false, dual_disabled = false; int early_outer = 0; double outer_margin = 0; int outer_every = 1; int64_t last_outer_step = 0, n_outer = 0, n_filters = 0; T r_in = 0, r_in2 = 0;
     DBuf<int32_t> flags; int32_t* h_flags = nullptr;
     int64_t total_rows = 0;
@@ -170,7 +171,7 @@ template <class T> class Engine final : public EngineBase {
         if (stream) (void)hipStreamSynchronize(stream);
         for (int k = 0; k < 2; ++k) { pos[k].release(); vel[k].release(); frc[k].release(); lj[k].release(); orig[k].release(); }
         inv.release(); key_in.release(); key_out.release(); cell_rank.release(); idx_in.release(); perm.release(); cell_cnt.release(); cell_start.release(); cub_tmp.release();
-        wave_rows_in.release(); nbr_in.release(); pos_snap.release(); blk_disp2.release(); tile_idx_in.release(); tile_cnt_in.release();
+        wave_rows_in.release(); nbr_in.release(); pos_snap.release(); blk_disp2.release(); tile_idx_in.release(); tile_cnt_in.release(); rows_x.release(); nbr_x.release();
         xl_start.release(); xl_list.release(); tile_idx.release(); tile_cnt.release(); wave_rows.release(); nbr.release(); blk_center.release();
         flags.release(); red_part.release(); red_out.release(); cm_step.release(); vcm.release(); stage_a.release(); stage_b.release(); stage_i.release(); bonded.release();
         prof.release();
@@ -213,7 +214,12 @@ template <class T> class Engine final : public EngineBase {
         outer_margin = (G.no_list || dual_disabled) ? 0.0 : env_int("MOLLYHIP_OUTER_MARGIN_PM", 200) * 1e-3;
         outer_every = std::max(1, env_int("MOLLYHIP_OUTER_EVERY", 10));
         for (int d = 0; d < 3; ++d) if (cfg.periodic[d] && cfg.r_list + outer_margin > 0.5 * cfg.box[d]) outer_margin = 0;   // keep r_outer <= L/2
-        dual = outer_margin > 0 && outer_every > 1 && n_ghost == 0;   // ghosted sub-domains are re-planned by the host at every rebuild step
+        // walking the outer list is only equivalent to walking the reference's list if every interaction vanishes beyond a
+        // cutoff <= r_list; a NoCutoff interaction summed over a neighbour list depends on list membership itself
+        const mhip_interactions& ip = cfg.inter;
+        const bool lj_cut_ok = !ip.lj_enabled || (ip.lj_cutoff_kind != MHIP_CUTOFF_NONE && ip.lj_rc <= cfg.r_list);
+        const bool coul_cut_ok = ip.coul_kind == MHIP_COUL_NONE || (ip.coul_kind == MHIP_COUL_PLAIN ? (ip.coul_cutoff_kind != MHIP_CUTOFF_NONE && ip.coul_rc <= cfg.r_list) : ip.coul_rc <= cfg.r_list);
+        dual = outer_margin > 0 && outer_every > 1 && n_ghost == 0 && lj_cut_ok && coul_cut_ok;   // ghosted sub-domains are re-planned by the host
         const double r_search = G.no_list ? 0.0 : cfg.r_list + (dual ? outer_margin : 0.0);
         G.r_list = G.no_list ? std::numeric_limits<T>::infinity() : T(r_search);
         G.r_list2 = G.no_list ? std::numeric_limits<T>::infinity() : (dual ? G.r_list * G.r_list : r_in2);
@@ -380,14 +386,10 @@ template <class T> class Engine final : public EngineBase {
         red_part.reserve(std::max<size_t>((size_t)n_blocks, 4 * (size_t)cdiv(n_owned, 256)) + 8);
         bonded.on_reorder();
         ++n_outer; last_outer_step = step_n;
-        if (dual) {
+        if (dual) {   // remember where everybody was; the next force pass prunes the outer list into the inner one
             pos_snap.reserve(cap);
             MHIP_HIP(hipMemcpyAsync(pos_snap.p, pos[cur].p, (size_t)n_tot * sizeof(T4), hipMemcpyDeviceToDevice, stream));
-            launch_filter();
-            MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-            MHIP_HIP(hipStreamSynchronize(stream));
-            total_rows = h_flags[FLAG_TOTAL_ROWS]; max_tile_in = h_flags[FLAG_MAX_TILE];
-            carve_force_lds(max_tile_in);
+            inner_valid = false; prune_disp_exceeded = false;
         }
         stale = false; last_build_step = step_n; ++n_rebuilds;
         last_rebuild_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -409,25 +411,24 @@ template <class T> class Engine final : public EngineBase {
 
     // inner list := outer entries with r2 <= r_list² at the current coordinates (+ max displacement since the outer build)
     void launch_filter() {
-        wave_rows_in.reserve((size_t)n_blocks * JS * (BI / WAVE)); nbr_in.reserve((size_t)n_blocks * JS * R_cap * BI);
+        rows_x.reserve((size_t)n_blocks * JS * (BI / WAVE)); nbr_x.reserve((size_t)n_blocks * JS * R_cap * BI);
         tile_idx_in.reserve((size_t)n_blocks * T_cap); tile_cnt_in.reserve(n_blocks);
         MHIP_HIP(hipMemsetAsync(flags.p, 0, N_FLAGS * sizeof(int32_t), stream));
         blk_disp2.reserve(n_blocks);
         FilterArgs<T> F;
         F.G = G; F.n_owned = n_owned; F.BI = BI; F.BI_shift = ilog2(BI); F.JS = JS; F.T_cap = T_cap; F.R_cap = R_cap; F.n_blocks = n_blocks;
         F.pos = pos[cur].p; F.pos_snap = pos_snap.p; F.tile_idx = tile_idx.p; F.tile_cnt = tile_cnt.p; F.nbr_out = nbr.p; F.rows_out = wave_rows.p;
-        F.nbr_in = nbr_in.p; F.rows_in = wave_rows_in.p; F.tile_idx_in = tile_idx_in.p; F.tile_cnt_in = tile_cnt_in.p; F.blk_center = blk_center.p; F.blk_disp2 = blk_disp2.p; F.flags = flags.p; F.r_in = r_in; F.r_in2 = r_in2; F.exact_all = minimg ? 1 : 0;
+        F.nbr_in = nbr_x.p; F.rows_in = rows_x.p; F.tile_idx_in = tile_idx_in.p; F.tile_cnt_in = tile_cnt_in.p; F.blk_center = blk_center.p; F.blk_disp2 = blk_disp2.p; F.flags = flags.p; F.r_in = r_in; F.r_in2 = r_in2; F.exact_all = minimg ? 1 : 0;
         F.T_lds = std::min<int>(max_tile, (MAX_LDS_BYTES - 256) / (int)sizeof(float4));
         F.T_lds = minimg ? 0 : F.T_lds;
-        size_t lds = (size_t)F.T_lds * sizeof(float4) + ((size_t)(T_cap + 31) / 32 + 1) * 4 + (size_t)((T_cap + 2) & ~1) * 2 + (size_t)BI * JS * 4 + 64;
+        size_t lds = (size_t)F.T_lds * sizeof(float4) + (size_t)((T_cap + 8) & ~7) + (size_t)((T_cap + 2) & ~1) * 2 + (size_t)BI * JS * 4 + 64;
         set_lds_limit(k_filter<T>, lds);
         prof.begin(4, stream);
         hipLaunchKernelGGL(k_filter<T>, dim3(n_blocks), dim3(BI * JS), lds, stream, F);
         hipLaunchKernelGGL(k_build_summary, dim3(std::min(64, cdiv(n_blocks * JS * (BI / WAVE), 256))), dim3(256), 0, stream, n_blocks, n_blocks * JS * (BI / WAVE), R_cap,
-                           (const int32_t*)tile_cnt_in.p, wave_rows_in.p, (const float*)blk_disp2.p, flags.p);
+                           (const int32_t*)tile_cnt_in.p, rows_x.p, (const float*)blk_disp2.p, flags.p);
         prof.end(4, stream);
         MHIP_HIP(hipGetLastError());
-        ++n_filters;
     }
 
     // rebuild step of the cadence (find_neighbors at step_n % n_steps == 0): a fresh search, or — with the dual list —
@@ -435,20 +436,20 @@ template <class T> class Engine final : public EngineBase {
     void refresh(int64_t step_n) {
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         if (!dual || stale || (step_n - last_outer_step) >= (int64_t)outer_every * every || step_n < last_outer_step) { rebuild(step_n); return; }
-        launch_filter();
-        MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-        MHIP_HIP(hipStreamSynchronize(stream));
-        float d2; std::memcpy(&d2, &h_flags[FLAG_MAX_DISP2], sizeof(float));
-        if (2.0 * std::sqrt((double)d2) > outer_margin * 0.98) {
-            // atoms outran the margin.  If that keeps happening before the outer list has paid for itself (fast light atoms,
-            // small time step), the dual list is a loss: fall back to a fresh search at every rebuild step.
-            if (step_n - last_outer_step <= 2 * (int64_t)every) { if (++early_outer >= 3) { dual_disabled = true; setup_grid(); choose_blocking(); stale = true; } }
-            else early_outer = 0;
-            rebuild(step_n); return;
-        }
-        total_rows = h_flags[FLAG_TOTAL_ROWS]; max_tile_in = h_flags[FLAG_MAX_TILE];
-        carve_force_lds(max_tile_in);
+        inner_valid = false;                      // the next force pass re-prunes the outer list at the then-current coordinates
         last_build_step = step_n; ++n_rebuilds;
+    }
+
+    // after a force pass that pruned: if an atom outran half the margin the outer list can no longer vouch for the inner one
+    void after_forces(int64_t step_n) {
+        if (!prune_disp_exceeded) return;
+        prune_disp_exceeded = false;
+        const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
+        // If that keeps happening before the outer list has paid for itself (fast light atoms, small time step), the dual list
+        // is a loss: fall back to a fresh search at every rebuild step.
+        if (step_n - last_outer_step <= 2 * (int64_t)every) { if (++early_outer >= 3) { dual_disabled = true; setup_grid(); choose_blocking(); stale = true; } }
+        else early_outer = 0;
+        rebuild(step_n);
     }
 
     void ensure_built(int64_t step_n) {
@@ -458,16 +459,17 @@ template <class T> class Engine final : public EngineBase {
     }
 
     // ---------------------------------------------------------------------------------------------
+    template <int LJM, int COULM, bool ENERGY, bool MINIMG, bool SEGM, bool PRUNE> void launch_forces_k(const ForceArgs<T>& A) {
+        auto kern = k_forces<T, LJM, COULM, ENERGY, MINIMG, SEGM, PRUNE>;
+        set_lds_limit(kern, lds_force);
+        hipLaunchKernelGGL(kern, dim3(A.blocks_per_xcd * 8), dim3(BI * JS), lds_force, stream, A);
+    }
     template <int LJM, int COULM, bool ENERGY, bool MINIMG> void launch_forces_t(const ForceArgs<T>& A) {
-        if (segmented) {
-            auto kern = k_forces<T, LJM, COULM, ENERGY, MINIMG, true>;
-            set_lds_limit(kern, lds_force);
-            hipLaunchKernelGGL(kern, dim3(A.blocks_per_xcd * 8), dim3(BI * JS), lds_force, stream, A);
-        } else {
-            auto kern = k_forces<T, LJM, COULM, ENERGY, MINIMG, false>;
-            set_lds_limit(kern, lds_force);
-            hipLaunchKernelGGL(kern, dim3(A.blocks_per_xcd * 8), dim3(BI * JS), lds_force, stream, A);
+        const bool prune = A.nbr_dst != nullptr;
+        if constexpr (!ENERGY) {
+            if (prune) { if (segmented) launch_forces_k<LJM, COULM, false, MINIMG, true, true>(A); else launch_forces_k<LJM, COULM, false, MINIMG, false, true>(A); return; }
         }
+        if (segmented) launch_forces_k<LJM, COULM, ENERGY, MINIMG, true, false>(A); else launch_forces_k<LJM, COULM, ENERGY, MINIMG, false, false>(A);
     }
     template <int LJM, int COULM> void launch_forces_c(const ForceArgs<T>& A, bool energy) {
         if (energy) { if (minimg) launch_forces_t<LJM, COULM, true, true>(A); else launch_forces_t<LJM, COULM, true, false>(A); }
@@ -486,7 +488,18 @@ template <class T> class Engine final : public EngineBase {
         ForceArgs<T> A;
         A.G = G; A.I = I; A.n_owned = n_owned; A.BI = BI; A.BI_shift = ilog2(BI); A.JS = JS; A.T_cap = T_cap; A.T_lds = tile_lds; A.R_cap = R_cap;
         A.n_blocks = n_blocks; A.blocks_per_xcd = cdiv(n_blocks, 8);
-        A.pos = pos[cur].p; A.lj = lj[cur].p; A.tile_idx = dual ? tile_idx_in.p : tile_idx.p; A.tile_cnt = dual ? tile_cnt_in.p : tile_cnt.p; A.nbr = dual ? nbr_in.p : nbr.p; A.wave_rows = dual ? wave_rows_in.p : wave_rows.p;
+        A.pos = pos[cur].p; A.lj = lj[cur].p; A.tile_idx = tile_idx.p; A.tile_cnt = tile_cnt.p;
+        // dual pair list: a force pass whose inner list is stale walks the OUTER list (always a valid superset — the cutoff is
+        // applied per pair) and, if it is a plain force call, prunes it into the inner list on the way
+        const bool use_inner = dual && inner_valid;
+        const bool prune = dual && !inner_valid && !energy;
+        A.nbr = use_inner ? nbr_in.p : nbr.p; A.wave_rows = use_inner ? wave_rows_in.p : wave_rows.p;
+        A.nbr_dst = nullptr; A.rows_dst = nullptr; A.pos_snap = nullptr; A.blk_disp2 = nullptr; A.r_prune2 = r_in2;
+        if (prune) {
+            wave_rows_in.reserve((size_t)n_blocks * JS * (BI / WAVE)); nbr_in.reserve((size_t)n_blocks * JS * R_cap * BI); blk_disp2.reserve(n_blocks);
+            MHIP_HIP(hipMemsetAsync(blk_disp2.p, 0, (size_t)n_blocks * sizeof(float), stream));
+            A.nbr_dst = nbr_in.p; A.rows_dst = wave_rows_in.p; A.pos_snap = pos_snap.p; A.blk_disp2 = blk_disp2.p;
+        }
         A.blk_center = blk_center.p; A.frc = frc[cur].p; A.pe_part = red_part.p;
         prof.begin(0, stream);
         switch (ljm) {
@@ -498,6 +511,18 @@ template <class T> class Engine final : public EngineBase {
         prof.end(0, stream);
         MHIP_HIP(hipGetLastError());
         ++n_force_calls;
+        if (prune) {   // validity of the pruned list: nobody moved more than half the margin since the outer search
+            MHIP_HIP(hipMemsetAsync(flags.p, 0, N_FLAGS * sizeof(int32_t), stream));
+            hipLaunchKernelGGL(k_build_summary, dim3(std::min(64, cdiv(n_blocks * JS * (BI / WAVE), 256))), dim3(256), 0, stream, n_blocks, n_blocks * JS * (BI / WAVE), R_cap,
+                               (const int32_t*)tile_cnt.p, wave_rows_in.p, (const float*)blk_disp2.p, flags.p);
+            MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            MHIP_HIP(hipStreamSynchronize(stream));
+            float d2; std::memcpy(&d2, &h_flags[FLAG_MAX_DISP2], sizeof(float));
+            total_rows = h_flags[FLAG_TOTAL_ROWS];
+            ++n_filters;
+            inner_valid = true; prune_disp_exceeded = 2.0 * std::sqrt((double)d2) > outer_margin * 0.98;
+            if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] prune: max disp %.5f nm (margin %.3f) rows %lld exceeded %d calls %lld\n", std::sqrt((double)d2), outer_margin, (long long)total_rows, (int)prune_disp_exceeded, (long long)n_force_calls);
+        }
     }
 
     double read_sum(int n_part) {
@@ -522,8 +547,12 @@ template <class T> class Engine final : public EngineBase {
     }
 
     // all forces of one MD step into frc[cur]: pairwise kernel overwrites, bonded kernels add
-    void step_forces() {
+    void step_forces(int64_t step_n) {
         launch_pair_kernel(false);
+        if (prune_disp_exceeded) {   // the outer list could not vouch for this pass: search again and redo it on the fresh list
+            after_forces(step_n);
+            launch_pair_kernel(false);
+        }
         bonded.launch_forces(stream, G, I, pos[cur].p, inv.p, frc[cur].p);
         frc_valid = true;
     }
@@ -648,6 +677,7 @@ template <class T> class Engine final : public EngineBase {
         ensure_built(step_n);
         launch_pair_kernel(false);
         frc_valid = false;   // frc holds the pairwise part only
+        if (prune_disp_exceeded) { after_forces(step_n); launch_pair_kernel(false); }
         export_frc(accumulate, f_xyz, mem_kind);
     }
 
@@ -742,7 +772,7 @@ template <class T> class Engine final : public EngineBase {
     void vv_init(int64_t first_step) override {
         if (!state_set) throw ApiError{MHIP_ERR_STATE, "set_state must be called before vv_run"};
         rebuild(first_step);
-        step_forces();
+        step_forces(first_step);
     }
     void vv_stage1(double dt) override {
         if (!frc_valid) throw ApiError{MHIP_ERR_STATE, "vv_stage1 needs forces from vv_init / vv_stage2"};
@@ -752,8 +782,8 @@ template <class T> class Engine final : public EngineBase {
         prof.end(2, stream);
         cm_pending = 0;
     }
-    void stage2_impl(double dt, bool cm) {
-        step_forces();
+    void stage2_impl(int64_t step_n, double dt, bool cm) {
+        step_forces(step_n);
         const int nb = std::min(cdiv(n_owned, 256), 1024);
         prof.begin(2, stream);
         if (cm) {
@@ -765,8 +795,7 @@ template <class T> class Engine final : public EngineBase {
         prof.end(2, stream);
     }
     void vv_stage2(int64_t step_n, double dt) override {
-        (void)step_n;
-        stage2_impl(dt, false);
+        stage2_impl(step_n, dt, false);
         MHIP_HIP(hipGetLastError());
     }
     void rebuild_now(int64_t step_n) override { flush_cm(); if (stale) rebuild(step_n); else refresh(step_n); }
@@ -779,8 +808,13 @@ template <class T> class Engine final : public EngineBase {
         vv_init(first_step);                                                      // :564-571
         for (int64_t step = first_step + 1; step <= first_step + n_steps; ++step) {
             vv_stage1(dt);                                                        // :594-609
-            stage2_impl(dt, remove_cm_every != 0 && step % remove_cm_every == 0); // :612-628
-            if (step % every == 0) refresh(step);                                 // :645, neighbors.jl:396
+            // find_neighbors at step % n_steps == 0 (:645, neighbors.jl:396) builds the list from the coordinates of THIS step; it is
+            // scheduled before the force pass so that, with the dual pair list, that pass can prune the outer list on the way.
+            // Forces are unaffected: the pass walks a superset of the old list and every interaction has a cutoff <= r_list.
+            const bool pre = dual;                                                // without the dual list: the reference's order
+            if (pre && step % every == 0) refresh(step);
+            stage2_impl(step, dt, remove_cm_every != 0 && step % remove_cm_every == 0); // :612-628
+            if (!pre && step % every == 0) refresh(step);
         }
         flush_cm();
         MHIP_HIP(hipGetLastError());
@@ -789,18 +823,34 @@ template <class T> class Engine final : public EngineBase {
 
     int64_t export_neighbors(int32_t* oi, int32_t* oj, uint8_t* osp, int64_t capacity) override {
         if (stale) throw ApiError{MHIP_ERR_STATE, "no neighbour list: call forces / rebuild first"};
+        const int32_t *x_tidx = tile_idx.p, *x_tcnt = tile_cnt.p, *x_rows = wave_rows.p; const uint2* x_nbr = nbr.p;
+        if (dual) {
+            // the reference's list at the current coordinates = the outer list filtered with the exact predicate; valid as long as
+            // nobody moved more than half the margin since the outer search, else search again first
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                launch_filter();
+                MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+                MHIP_HIP(hipStreamSynchronize(stream));
+                float d2; std::memcpy(&d2, &h_flags[FLAG_MAX_DISP2], sizeof(float));
+                if (2.0 * std::sqrt((double)d2) <= outer_margin * 0.98) break;
+                flush_cm(); rebuild(last_build_step);
+                if (!dual) break;
+            }
+            if (dual) { x_tidx = tile_idx_in.p; x_tcnt = tile_cnt_in.p; x_rows = rows_x.p; x_nbr = nbr_x.p; }
+            else { x_tidx = tile_idx.p; x_tcnt = tile_cnt.p; x_rows = wave_rows.p; x_nbr = nbr.p; }
+        }
         DBuf<unsigned long long> counter; counter.reserve(1);
         MHIP_HIP(hipMemsetAsync(counter.p, 0, sizeof(unsigned long long), stream));
-        hipLaunchKernelGGL(k_export_nl<T>, dim3(n_blocks), dim3(BI), 0, stream, n_blocks, BI, JS, T_cap, R_cap, n_owned, (const int32_t*)orig[cur].p, (const int32_t*)(dual ? tile_idx_in.p : tile_idx.p),
-                           (const int32_t*)(dual ? tile_cnt_in.p : tile_cnt.p), (const uint2*)(dual ? nbr_in.p : nbr.p), (const int32_t*)(dual ? wave_rows_in.p : wave_rows.p), (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr, counter.p, 0ull);
+        hipLaunchKernelGGL(k_export_nl<T>, dim3(n_blocks), dim3(BI), 0, stream, n_blocks, BI, JS, T_cap, R_cap, n_owned, (const int32_t*)orig[cur].p, x_tidx, x_tcnt, x_nbr, x_rows,
+                           (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr, counter.p, 0ull);
         unsigned long long n = 0;
         MHIP_HIP(hipMemcpyAsync(&n, counter.p, sizeof(n), hipMemcpyDeviceToHost, stream));
         MHIP_HIP(hipStreamSynchronize(stream));
         if (oi && (int64_t)n <= capacity && n > 0) {
             DBuf<int32_t> di, dj; DBuf<uint8_t> ds; di.reserve(n); dj.reserve(n); ds.reserve(n);
             MHIP_HIP(hipMemsetAsync(counter.p, 0, sizeof(unsigned long long), stream));
-            hipLaunchKernelGGL(k_export_nl<T>, dim3(n_blocks), dim3(BI), 0, stream, n_blocks, BI, JS, T_cap, R_cap, n_owned, (const int32_t*)orig[cur].p, (const int32_t*)(dual ? tile_idx_in.p : tile_idx.p),
-                               (const int32_t*)(dual ? tile_cnt_in.p : tile_cnt.p), (const uint2*)(dual ? nbr_in.p : nbr.p), (const int32_t*)(dual ? wave_rows_in.p : wave_rows.p), di.p, dj.p, ds.p, counter.p, n);
+            hipLaunchKernelGGL(k_export_nl<T>, dim3(n_blocks), dim3(BI), 0, stream, n_blocks, BI, JS, T_cap, R_cap, n_owned, (const int32_t*)orig[cur].p, x_tidx, x_tcnt, x_nbr, x_rows,
+                               di.p, dj.p, ds.p, counter.p, n);
             MHIP_HIP(hipMemcpyAsync(oi, di.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
             MHIP_HIP(hipMemcpyAsync(oj, dj.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
             MHIP_HIP(hipMemcpyAsync(osp, ds.p, n * sizeof(uint8_t), hipMemcpyDeviceToHost, stream));
@@ -820,12 +870,12 @@ template <class T> class Engine final : public EngineBase {
     void get_stats(mhip_stats* s) override {
         std::memset(s, 0, sizeof(*s));
         s->n_atoms = n_tot; s->n_owned = n_owned; s->n_ghost = n_ghost; s->n_rebuilds = n_rebuilds; s->n_force_calls = n_force_calls;
-        s->n_blocks = n_blocks; s->block_atoms = BI; s->j_split = JS; s->minimg_mode = minimg ? 1 : 0; s->max_tile_atoms = dual ? max_tile_in : max_tile;
+        s->n_blocks = n_blocks; s->block_atoms = BI; s->j_split = JS; s->minimg_mode = minimg ? 1 : 0; s->max_tile_atoms = max_tile;
         s->last_rebuild_ms = last_rebuild_ms; s->lds_bytes = (int64_t)lds_force;
         s->n_list_slots = total_rows * 4 * WAVE;
         if (!stale) {
             std::vector<int32_t> tc(n_blocks);
-            MHIP_HIP(hipMemcpy(tc.data(), dual ? tile_cnt_in.p : tile_cnt.p, n_blocks * sizeof(int32_t), hipMemcpyDeviceToHost));
+            MHIP_HIP(hipMemcpy(tc.data(), tile_cnt.p, n_blocks * sizeof(int32_t), hipMemcpyDeviceToHost));
             int64_t t = 0; for (int v : tc) t += v; s->tile_atoms_total = t;
             s->n_pairs_full = 2 * export_neighbors(nullptr, nullptr, nullptr, 0);
         }

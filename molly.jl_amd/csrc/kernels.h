@@ -530,8 +530,8 @@ __global__ void k_filter(FilterArgs<T> A) {
     const int li = tid & (A.BI - 1), js = tid >> A.BI_shift;
     const int tile_n = A.tile_cnt[b];
     float4* l_pos = reinterpret_cast<float4*>(smem);
-    uint32_t* l_used = reinterpret_cast<uint32_t*>(l_pos + A.T_lds);          // bit t: tile atom t is referenced by the inner list
-    uint16_t* l_new = reinterpret_cast<uint16_t*>(l_used + (A.T_cap + 31) / 32 + 1);   // its slot in the compacted tile
+    uint8_t* l_used = reinterpret_cast<uint8_t*>(l_pos + A.T_lds);            // byte t != 0: tile atom t is referenced by the inner list
+    uint16_t* l_new = reinterpret_cast<uint16_t*>(l_used + ((A.T_cap + 8) & ~7));    // its slot in the compacted tile
     int32_t* l_part = reinterpret_cast<int32_t*>(l_new + ((A.T_cap + 2) & ~1));  // nthr scan scratch
     const T4 ctr = A.blk_center[b];
     const bool use_lds = !A.exact_all && tile_n <= A.T_lds;
@@ -544,8 +544,8 @@ __global__ void k_filter(FilterArgs<T> A) {
     };
     const int32_t* tix = A.tile_idx + (int64_t)b * A.T_cap;
     if (use_lds) for (int t = tid; t < tile_n; t += nthr) l_pos[t] = localise(A.pos[tix[t]]);
-    const int nuw = (tile_n + 31) >> 5;
-    for (int w = tid; w < nuw; w += nthr) l_used[w] = 0u;
+    const int nuw = (tile_n + 3) >> 2;      // marks handled four at a time (32-bit words)
+    for (int w = tid; w < nuw; w += nthr) reinterpret_cast<uint32_t*>(l_used)[w] = 0u;
     const int64_t si = (int64_t)b * A.BI + li;
     const bool valid = si < A.n_owned;
     const T4 pi = A.pos[valid ? si : (int64_t)b * A.BI];
@@ -605,7 +605,7 @@ __global__ void k_filter(FilterArgs<T> A) {
                 T ez = G.periodic[2] ? vector_1d_exact(pi.z, pj.z, G.L[2]) : M<T>::sub(pj.z, pi.z);
                 in = norm2_exact(ex, ey, ez) <= A.r_in2;
             }
-            if (in) { emit(e); atomicOr(&l_used[slot >> 5], 1u << (slot & 31)); }
+            if (in) { emit(e); l_used[slot] = 1; }   // benign race: every writer stores the same byte
         }
     }
     int rows_mine = (cnt + 3) >> 2;
@@ -616,8 +616,9 @@ __global__ void k_filter(FilterArgs<T> A) {
     __syncthreads();
     {
         int per = (nuw + nthr - 1) / nthr, w0 = min(tid * per, nuw), w1 = min(w0 + per, nuw);
+        const uint32_t* uw = reinterpret_cast<const uint32_t*>(l_used);
         int sum = 0;
-        for (int w = w0; w < w1; ++w) sum += __popc(l_used[w]);
+        for (int w = w0; w < w1; ++w) sum += __popc(uw[w] & 0x01010101u);
         l_part[tid] = sum;
         __syncthreads();
         if (tid < WAVE) {
@@ -634,8 +635,9 @@ __global__ void k_filter(FilterArgs<T> A) {
         __syncthreads();
         int run = l_part[tid];
         for (int w = w0; w < w1; ++w) {
-            uint32_t m = l_used[w];
-            while (m) { int bit = __builtin_ctz(m); m &= m - 1; int t = (w << 5) + bit; l_new[t] = (uint16_t)run; A.tile_idx_in[(int64_t)b * A.T_cap + run] = tix[t]; ++run; }
+            uint32_t m = uw[w];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if ((m >> (8 * q)) & 1u) { int t = (w << 2) + q; l_new[t] = (uint16_t)run; A.tile_idx_in[(int64_t)b * A.T_cap + run] = tix[t]; ++run; }
         }
     }
     __syncthreads();
@@ -670,9 +672,12 @@ template <class T> struct ForceArgs {
     const typename Vec<T>::T4* blk_center;
     typename Vec<T>::T4* frc;
     double* pe_part;                 // [n_blocks] (ENERGY)
+    // PRUNE pass of the dual pair list: the rows read above are the OUTER list; entries with r² <= r_prune2 are re-emitted as
+    // the inner list, and the displacement of the block's atoms since the outer build is recorded for the host's validity check
+    uint2* nbr_dst; int32_t* rows_dst; const typename Vec<T>::T4* pos_snap; float* blk_disp2; T r_prune2;
 };
 
-template <class T, int LJM, int COULM, bool ENERGY, bool MINIMG, bool SEG>
+template <class T, int LJM, int COULM, bool ENERGY, bool MINIMG, bool SEG, bool PRUNE>
 __global__ void k_forces(ForceArgs<T> A) {
     using T4 = typename Vec<T>::T4;
     using T2 = typename Vec<T>::T2;
@@ -709,6 +714,18 @@ __global__ void k_forces(ForceArgs<T> A) {
     const uint2* my_rows = A.nbr + (((int64_t)b * A.JS + js) * A.R_cap) * A.BI + li;       // j-split was done by k_build
     const int32_t* tix = A.tile_idx + (int64_t)b * A.T_cap;
     T fx = T(0), fy = T(0), fz = T(0), pe = T(0);
+    // PRUNE: inner-list emission state (same row format as k_build)
+    uint32_t pk[2] = {0, 0};
+    int kept = 0;
+    uint2* out_rows = nullptr;
+    if constexpr (PRUNE) out_rows = A.nbr_dst + (((int64_t)b * A.JS + js) * A.R_cap) * A.BI + li;
+    auto emit = [&](uint32_t e) {
+        int k = kept & 3;
+        if (k == 0) { pk[0] = 0; pk[1] = 0; }
+        pk[k >> 1] |= e << (16 * (k & 1));
+        ++kept;
+        if (k == 3) out_rows[(int64_t)((kept >> 2) - 1) * A.BI] = make_uint2(pk[0], pk[1]);
+    };
 
     // The tile normally fits the LDS carve-up in one piece.  SEG: a tile larger than the LDS budget is
     // processed in segments; every segment re-walks the row stream and treats slots outside it as sentinels.
@@ -736,6 +753,7 @@ __global__ void k_forces(ForceArgs<T> A) {
             for (int k = 0; k < 4; ++k) {
                 uint32_t e = ((k < 2 ? e4.x : e4.y) >> (16 * (k & 1))) & 0xffffu;
                 uint32_t slot = e & 0x7fffu;
+                [[maybe_unused]] const bool real = SEG ? (slot - (uint32_t)seg_lo) < (uint32_t)n_here : slot < (uint32_t)tile_n;   // not a sentinel / other segment
                 if constexpr (SEG) { slot -= (uint32_t)seg_lo; slot = slot < (uint32_t)n_here ? slot : (uint32_t)n_here; }
                 bool special = (e >> 15) != 0;
                 T4 pj = l_pos[slot];
@@ -748,10 +766,30 @@ __global__ void k_forces(ForceArgs<T> A) {
                     dz = G.periodic[2] ? vector_1d_exact(pi.z, pj.z, G.L[2]) : pj.z - pi.z;
                 } else { dx = pj.x - pi.x; dy = pj.y - pi.y; dz = pj.z - pi.z; }
                 T r2 = dx * dx + dy * dy + dz * dz;
+                if constexpr (PRUNE) { if (real && valid && r2 <= A.r_prune2) emit(e); }
                 T fr = pair_eval<T, LJM, COULM, ENERGY>(A.I, r2, pi.w, pj.w, lji.x, ljj.x, lji.y, ljj.y, special, pe);
                 fx -= fr * dx; fy -= fr * dy; fz -= fr * dz;   // force on i is −f (force.jl:873)
             }
         }
+    }
+    if constexpr (PRUNE) {
+        // finish the inner list: pad to the wave's row count; record how far the block's atoms moved since the outer build
+        const uint32_t SENTP = (uint32_t)tile_n;
+        int rows_mine = (kept + 3) >> 2;
+        int rows_wave = wave_max(rows_mine);
+        while (((kept + 3) >> 2) < rows_wave || (kept & 3)) emit(SENTP);
+        if ((tid & 63) == 0) A.rows_dst[(b * A.JS + js) * (A.BI >> 6) + (li >> 6)] = rows_wave;
+        float d2 = 0.f;
+        if (valid && js == 0) {
+            T4 q = A.pos_snap[si], p0 = A.pos[si];
+            T ex = p0.x - q.x, ey = p0.y - q.y, ez = p0.z - q.z;
+            if (G.periodic[0]) ex -= G.L[0] * M<T>::rint(ex * G.invL[0]);
+            if (G.periodic[1]) ey -= G.L[1] * M<T>::rint(ey * G.invL[1]);
+            if (G.periodic[2]) ez -= G.L[2] * M<T>::rint(ez * G.invL[2]);
+            d2 = (float)(ex * ex + ey * ey + ez * ez);
+        }
+        d2 = wave_max(d2);
+        if (js == 0 && (tid & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(A.blk_disp2 + b), __float_as_uint(d2));   // <= 4 waves per block
     }
     if (A.JS > 1) {   // deterministic reduction of the j-split partial sums through LDS
         __syncthreads();

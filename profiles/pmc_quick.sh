@@ -13,7 +13,7 @@ python - "$OUT/summary.json" <<'PY'
 import json,sys
 s=json.load(open(sys.argv[1]))
 for k,v in sorted(s['kernels'].items(), key=lambda kv:-kv[1]['total_ns'])[:8]: print(k, v['calls'], round(v['avg_us'],1))
-for kern in ('k_build','k_forces'):
+for kern in ('k_build','k_forces','k_filter'):
     if kern in s['pmc']:
         print(kern, {c: round(v['per_launch']) for c,v in sorted(s['pmc'][kern].items())})
 PY

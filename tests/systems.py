@@ -128,9 +128,11 @@ def lj_fluid(n_side, seed=2, temperature=85.0, jitter=0.02, r_cut=1.0, r_list=1.
                 name=f"lj{n}")
 
 
-def charged_fluid(n_side, coul, seed=5, spacing=0.31, r_list=1.2, dtype=np.float32, with_exceptions=True):
+def charged_fluid(n_side, coul, seed=5, spacing=0.31, r_list=1.2, dtype=np.float32, with_exceptions=True, stable=False):
     """A water-like-density mixed LJ + Coulomb fluid with per-atom σ, ϵ, q (two species + some LJ-less
-    'hydrogens' with ϵ = 0) and random excluded / special pairs between close atoms."""
+    'hydrogens' with ϵ = 0) and random excluded / special pairs between close atoms.  The ϵ = 0 species exercises the
+    LJZeroShortcut in force tests but, being free point charges, collapses onto opposite charges within a few dozen steps;
+    dynamics tests pass stable=True, which gives it a small repulsive core."""
     n = n_side ** 3
     rng = np.random.default_rng(seed)
     g = np.stack(np.meshgrid(*[np.arange(n_side)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float64)
@@ -140,7 +142,7 @@ def charged_fluid(n_side, coul, seed=5, spacing=0.31, r_list=1.2, dtype=np.float
     x = x.astype(dtype).astype(np.float64)
     x = np.where(x >= np.float64(dtype(box)), 0.0, x)
     kind = rng.integers(0, 3, n)
-    sigma = np.choose(kind, [0.315, 0.25, 0.1]); eps = np.choose(kind, [0.65, 0.3, 0.0])
+    sigma = np.choose(kind, [0.315, 0.25, 0.2 if stable else 0.1]); eps = np.choose(kind, [0.65, 0.3, 0.2 if stable else 0.0])
     q = np.choose(kind, [-0.8, 0.35, 0.45]) * rng.uniform(0.9, 1.1, n)
     q -= q.mean()
     excluded = special = None

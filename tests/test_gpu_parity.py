@@ -223,7 +223,7 @@ def test_sorted_order_is_a_permutation(pkg):
 
 
 def test_velocity_verlet_fp64_matches_oracle(pkg):
-    case = S.charged_fluid(10, dict(kind="rf", rc=1.0), dtype=np.float64, with_exceptions=True)
+    case = S.charged_fluid(10, dict(kind="rf", rc=1.0), dtype=np.float64, with_exceptions=True, stable=True)
     o = case.oracle(np.float64)
     o.vv_run(40, 0.0005, remove_cm_every=1)
     s = case.system(pkg, np.float64)
@@ -342,7 +342,7 @@ def test_dual_pair_list_stays_bit_exact_during_a_run(pkg, dtype):
     every rebuild step.  After 30 steps (filter passes at 10, 20, 30) the list it is using must equal a fresh reference
     search on the coordinates it holds — same pair set, same special flags."""
     import ctypes as C
-    case = S.charged_fluid(12, dict(kind="rf", rc=1.0), dtype=dtype)
+    case = S.charged_fluid(12, dict(kind="rf", rc=1.0), dtype=dtype, stable=True)
     s = case.system(pkg, dtype)
     pkg.simulate(s, pkg.VelocityVerlet(dt=0.001), 30)
     L = pkg.lib()
