@@ -122,6 +122,9 @@ template <class T> class Engine final : public EngineBase {
     // dual pair list: outer list (nbr / wave_rows, radius r_list + margin) and the inner list filtered from it
     DBuf<int32_t> wave_rows_in, tile_idx_in, tile_cnt_in, rows_x; DBuf<uint2> nbr_in, nbr_x; DBuf<T4> pos_snap; DBuf<float> blk_disp2; int max_tile_in = 0;
     bool inner_valid = false, prune_disp_exceeded = false;
+    int64_t last_prune_step = 0;
+    DBuf<T4> pos_snap_in;        // coordinates at the last prune (validity of the inner list: 2·displacement <= skin)
+    double skin = 0; bool strict_cadence = false; int64_t n_disp_checks = 0;
     bool dual = false, dual_disabled = false; int early_outer = 0; double outer_margin = 0; int outer_every = 1; int64_t last_outer_step = 0, n_outer = 0, n_filters = 0; T r_in = 0, r_in2 = 0;
     DBuf<int32_t> flags; int32_t* h_flags = nullptr;
     int64_t total_rows = 0;
@@ -171,6 +174,7 @@ template <class T> class Engine final : public EngineBase {
         if (stream) (void)hipStreamSynchronize(stream);
         for (int k = 0; k < 2; ++k) { pos[k].release(); vel[k].release(); frc[k].release(); lj[k].release(); orig[k].release(); }
         inv.release(); key_in.release(); key_out.release(); cell_rank.release(); idx_in.release(); perm.release(); cell_cnt.release(); cell_start.release(); cub_tmp.release();
+        pos_snap_in.release();
         wave_rows_in.release(); nbr_in.release(); pos_snap.release(); blk_disp2.release(); tile_idx_in.release(); tile_cnt_in.release(); rows_x.release(); nbr_x.release();
         xl_start.release(); xl_list.release(); tile_idx.release(); tile_cnt.release(); wave_rows.release(); nbr.release(); blk_center.release();
         flags.release(); red_part.release(); red_out.release(); cm_step.release(); vcm.release(); stage_a.release(); stage_b.release(); stage_i.release(); bonded.release();
@@ -212,14 +216,21 @@ template <class T> class Engine final : public EngineBase {
         // dual pair list: search with r_list + margin every `outer_every` rebuild intervals, filter to exactly r_list at
         // every rebuild step (MOLLYHIP_OUTER_MARGIN_PM in picometres, 0 disables; MOLLYHIP_OUTER_EVERY)
         outer_margin = (G.no_list || dual_disabled) ? 0.0 : env_int("MOLLYHIP_OUTER_MARGIN_PM", 200) * 1e-3;
-        outer_every = std::max(1, env_int("MOLLYHIP_OUTER_EVERY", 10));
+        outer_every = std::max(1, env_int("MOLLYHIP_OUTER_EVERY", 1000));   // upper bound only: the outer list is re-searched when displacement says so
+        strict_cadence = env_int("MOLLYHIP_STRICT_CADENCE", 0) != 0;         // 1: re-prune at every rebuild step, whatever the displacement
         for (int d = 0; d < 3; ++d) if (cfg.periodic[d] && cfg.r_list + outer_margin > 0.5 * cfg.box[d]) outer_margin = 0;   // keep r_outer <= L/2
         // walking the outer list is only equivalent to walking the reference's list if every interaction vanishes beyond a
         // cutoff <= r_list; a NoCutoff interaction summed over a neighbour list depends on list membership itself
         const mhip_interactions& ip = cfg.inter;
         const bool lj_cut_ok = !ip.lj_enabled || (ip.lj_cutoff_kind != MHIP_CUTOFF_NONE && ip.lj_rc <= cfg.r_list);
         const bool coul_cut_ok = ip.coul_kind == MHIP_COUL_NONE || (ip.coul_kind == MHIP_COUL_PLAIN ? (ip.coul_cutoff_kind != MHIP_CUTOFF_NONE && ip.coul_rc <= cfg.r_list) : ip.coul_rc <= cfg.r_list);
-        dual = outer_margin > 0 && outer_every > 1 && n_ghost == 0 && lj_cut_ok && coul_cut_ok;   // ghosted sub-domains are re-planned by the host
+        {   // skin = r_list − largest cutoff: how far a pair may close in before the inner list must be re-pruned
+            double rc_max = 0;
+            if (ip.lj_enabled) rc_max = std::max(rc_max, ip.lj_rc);
+            if (ip.coul_kind != MHIP_COUL_NONE) rc_max = std::max(rc_max, ip.coul_rc);
+            skin = G.no_list ? 0.0 : cfg.r_list - rc_max;
+        }
+        dual = outer_margin > 0 && outer_every > 1 && n_ghost == 0 && lj_cut_ok && coul_cut_ok && skin > 0;   // ghosted sub-domains are re-planned by the host
         const double r_search = G.no_list ? 0.0 : cfg.r_list + (dual ? outer_margin : 0.0);
         G.r_list = G.no_list ? std::numeric_limits<T>::infinity() : T(r_search);
         G.r_list2 = G.no_list ? std::numeric_limits<T>::infinity() : (dual ? G.r_list * G.r_list : r_in2);
@@ -436,7 +447,22 @@ template <class T> class Engine final : public EngineBase {
     void refresh(int64_t step_n) {
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         if (!dual || stale || (step_n - last_outer_step) >= (int64_t)outer_every * every || step_n < last_outer_step) { rebuild(step_n); return; }
-        inner_valid = false;                      // the next force pass re-prunes the outer list at the then-current coordinates
+        // The inner list (pairs within r_list when it was pruned) provably contains every pair within the cutoffs as long as no atom
+        // moved more than skin/2 since then — the condition the reference's fixed cadence only assumes.  Check it; re-prune (inside
+        // the next force pass) only when it is about to fail.  mhip_export_neighbors always returns the exact list of NOW.
+        bool reprune = strict_cadence || !inner_valid;
+        if (!reprune) {
+            MHIP_HIP(hipMemsetAsync(flags.p + FLAG_MAX_DISP2, 0, sizeof(int32_t), stream));
+            hipLaunchKernelGGL(k_max_disp<T>, dim3(std::min(cdiv(n_owned, 256), 1024)), dim3(256), 0, stream, n_owned, (const T4*)pos[cur].p, (const T4*)pos_snap_in.p, flags.p, G);
+            MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            MHIP_HIP(hipStreamSynchronize(stream));
+            float d2; std::memcpy(&d2, &h_flags[FLAG_MAX_DISP2], sizeof(float));
+            ++n_disp_checks;
+            // headroom for the drift until the next check: the displacement so far, extrapolated one more interval
+            const double d = std::sqrt((double)d2), checks = std::max<int64_t>(1, (step_n - last_prune_step) / every);
+            reprune = 2.0 * d * (checks + 1.0) / checks > skin * 0.98;
+        }
+        if (reprune) inner_valid = false;         // the next force pass re-prunes the outer list at the then-current coordinates
         last_build_step = step_n; ++n_rebuilds;
     }
 
@@ -493,32 +519,44 @@ template <class T> class Engine final : public EngineBase {
         // applied per pair) and, if it is a plain force call, prunes it into the inner list on the way
         const bool use_inner = dual && inner_valid;
         const bool prune = dual && !inner_valid && !energy;
+        carve_force_lds(use_inner ? max_tile_in : max_tile);
+        A.T_lds = tile_lds;
+        if (use_inner) { A.tile_idx = tile_idx_in.p; A.tile_cnt = tile_cnt_in.p; }
         A.nbr = use_inner ? nbr_in.p : nbr.p; A.wave_rows = use_inner ? wave_rows_in.p : wave_rows.p;
         A.nbr_dst = nullptr; A.rows_dst = nullptr; A.pos_snap = nullptr; A.blk_disp2 = nullptr; A.r_prune2 = r_in2;
+        A.tile_idx_dst = nullptr; A.tile_cnt_dst = nullptr; A.mark_off = 0;
         if (prune) {
             wave_rows_in.reserve((size_t)n_blocks * JS * (BI / WAVE)); nbr_in.reserve((size_t)n_blocks * JS * R_cap * BI); blk_disp2.reserve(n_blocks);
             MHIP_HIP(hipMemsetAsync(blk_disp2.p, 0, (size_t)n_blocks * sizeof(float), stream));
             A.nbr_dst = nbr_in.p; A.rows_dst = wave_rows_in.p; A.pos_snap = pos_snap.p; A.blk_disp2 = blk_disp2.p;
+            pos_snap_in.reserve(cap);
+            MHIP_HIP(hipMemcpyAsync(pos_snap_in.p, pos[cur].p, (size_t)n_tot * sizeof(T4), hipMemcpyDeviceToDevice, stream));
+            last_prune_step = last_build_step;
+            tile_idx_in.reserve((size_t)n_blocks * T_cap); tile_cnt_in.reserve(n_blocks);
+            A.tile_idx_dst = tile_idx_in.p; A.tile_cnt_dst = tile_cnt_in.p;
+            A.mark_off = (int)((lds_force + 15) & ~(size_t)15);
+            lds_force = (size_t)A.mark_off + (size_t)((T_cap + 8) & ~7) + ((size_t)BI * JS + 2) * 4 + 16;   // + marks + scan scratch
+            if (lds_force > (size_t)MAX_LDS_BYTES) throw ApiError{MHIP_ERR_CAPACITY, "prune pass LDS carve-up exceeds 160 KiB"};
         }
         A.blk_center = blk_center.p; A.frc = frc[cur].p; A.pe_part = red_part.p;
-        prof.begin(0, stream);
+        prof.begin(prune ? 4 : 0, stream);   // stage 4 = force passes that also prune the outer list
         switch (ljm) {
         case LJ_OFF: launch_forces_l<LJ_OFF>(A, energy); break;
         case LJ_DIST: launch_forces_l<LJ_DIST>(A, energy); break;
         case LJ_DIST_UNIFORM: launch_forces_l<LJ_DIST_UNIFORM>(A, energy); break;
         default: launch_forces_l<LJ_GENERIC>(A, energy); break;
         }
-        prof.end(0, stream);
+        prof.end(prune ? 4 : 0, stream);
         MHIP_HIP(hipGetLastError());
         ++n_force_calls;
         if (prune) {   // validity of the pruned list: nobody moved more than half the margin since the outer search
             MHIP_HIP(hipMemsetAsync(flags.p, 0, N_FLAGS * sizeof(int32_t), stream));
             hipLaunchKernelGGL(k_build_summary, dim3(std::min(64, cdiv(n_blocks * JS * (BI / WAVE), 256))), dim3(256), 0, stream, n_blocks, n_blocks * JS * (BI / WAVE), R_cap,
-                               (const int32_t*)tile_cnt.p, wave_rows_in.p, (const float*)blk_disp2.p, flags.p);
+                               (const int32_t*)tile_cnt_in.p, wave_rows_in.p, (const float*)blk_disp2.p, flags.p);
             MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
             MHIP_HIP(hipStreamSynchronize(stream));
             float d2; std::memcpy(&d2, &h_flags[FLAG_MAX_DISP2], sizeof(float));
-            total_rows = h_flags[FLAG_TOTAL_ROWS];
+            total_rows = h_flags[FLAG_TOTAL_ROWS]; max_tile_in = h_flags[FLAG_MAX_TILE];
             ++n_filters;
             inner_valid = true; prune_disp_exceeded = 2.0 * std::sqrt((double)d2) > outer_margin * 0.98;
             if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] prune: max disp %.5f nm (margin %.3f) rows %lld exceeded %d calls %lld\n", std::sqrt((double)d2), outer_margin, (long long)total_rows, (int)prune_disp_exceeded, (long long)n_force_calls);

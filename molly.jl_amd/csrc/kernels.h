@@ -498,6 +498,26 @@ __global__ void k_build_summary(int n_blocks, int n_waves, int R_cap, const int3
 }
 
 // ---------------------------------------------------------------------------------------------------
+// max over the owned atoms of |x - x_snap|² (nearest image) → flags[FLAG_MAX_DISP2] (float bits; d² >= 0 so uint order works)
+template <class T>
+__global__ void k_max_disp(int64_t n, const typename Vec<T>::T4* __restrict__ pos, const typename Vec<T>::T4* __restrict__ snap, int32_t* flags, GridP<T> G) {
+    float d2 = 0.f;
+    for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
+        auto p = pos[s]; auto q = snap[s];
+        T ex = p.x - q.x, ey = p.y - q.y, ez = p.z - q.z;
+        if (G.periodic[0]) ex -= G.L[0] * M<T>::rint(ex * G.invL[0]);
+        if (G.periodic[1]) ey -= G.L[1] * M<T>::rint(ey * G.invL[1]);
+        if (G.periodic[2]) ez -= G.L[2] * M<T>::rint(ez * G.invL[2]);
+        d2 = fmaxf(d2, (float)(ex * ex + ey * ey + ez * ez));
+    }
+    d2 = wave_max(d2);
+    __shared__ float sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = d2;
+    __syncthreads();
+    if (threadIdx.x == 0) { float m = 0.f; for (int q = 0; q < (int)(blockDim.x >> 6); ++q) m = fmaxf(m, sh[q]); atomicMax(reinterpret_cast<unsigned int*>(&flags[FLAG_MAX_DISP2]), __float_as_uint(m)); }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Dual pair list ("dynamic pruning"): k_build searches with the OUTER radius r_list + Δ only every few rebuild
 // intervals; at every rebuild step k_filter re-tests the outer entries at the current coordinates and keeps exactly
 // the pairs with r2 <= r_list² (reference predicate, exact arithmetic inside the ±1e-4 band).  As long as no atom
@@ -675,6 +695,8 @@ template <class T> struct ForceArgs {
     // PRUNE pass of the dual pair list: the rows read above are the OUTER list; entries with r² <= r_prune2 are re-emitted as
     // the inner list, and the displacement of the block's atoms since the outer build is recorded for the host's validity check
     uint2* nbr_dst; int32_t* rows_dst; const typename Vec<T>::T4* pos_snap; float* blk_disp2; T r_prune2;
+    // … and the tile is compacted to the atoms the inner list references (slots renumbered in the emitted rows)
+    int32_t* tile_idx_dst; int32_t* tile_cnt_dst; int mark_off;   // byte offset of the mark array in dynamic LDS
 };
 
 template <class T, int LJM, int COULM, bool ENERGY, bool MINIMG, bool SEG, bool PRUNE>
@@ -719,6 +741,11 @@ __global__ void k_forces(ForceArgs<T> A) {
     int kept = 0;
     uint2* out_rows = nullptr;
     if constexpr (PRUNE) out_rows = A.nbr_dst + (((int64_t)b * A.JS + js) * A.R_cap) * A.BI + li;
+    [[maybe_unused]] uint8_t* l_mark = nullptr;
+    if constexpr (PRUNE) {
+        l_mark = smem + A.mark_off;
+        for (int w = tid; w < ((tile_n + 3) >> 2); w += nthr) reinterpret_cast<uint32_t*>(l_mark)[w] = 0u;   // ordered before the marks by the staging barrier
+    }
     auto emit = [&](uint32_t e) {
         int k = kept & 3;
         if (k == 0) { pk[0] = 0; pk[1] = 0; }
@@ -766,7 +793,7 @@ __global__ void k_forces(ForceArgs<T> A) {
                     dz = G.periodic[2] ? vector_1d_exact(pi.z, pj.z, G.L[2]) : pj.z - pi.z;
                 } else { dx = pj.x - pi.x; dy = pj.y - pi.y; dz = pj.z - pi.z; }
                 T r2 = dx * dx + dy * dy + dz * dz;
-                if constexpr (PRUNE) { if (real && valid && r2 <= A.r_prune2) emit(e); }
+                if constexpr (PRUNE) { if (real && valid && r2 <= A.r_prune2) { emit(e); l_mark[e & 0x7fffu] = 1; } }   // benign race: same byte value
                 T fr = pair_eval<T, LJM, COULM, ENERGY>(A.I, r2, pi.w, pj.w, lji.x, ljj.x, lji.y, ljj.y, special, pe);
                 fx -= fr * dx; fy -= fr * dy; fz -= fr * dz;   // force on i is −f (force.jl:873)
             }
@@ -790,6 +817,52 @@ __global__ void k_forces(ForceArgs<T> A) {
         }
         d2 = wave_max(d2);
         if (js == 0 && (tid & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(A.blk_disp2 + b), __float_as_uint(d2));   // <= 4 waves per block
+        // compact the tile to the referenced atoms: ordered rank of every marked slot, new tile list, own rows renumbered
+        __syncthreads();
+        uint16_t* l_new = reinterpret_cast<uint16_t*>(smem);                       // the staged tile is dead now
+        int32_t* l_scan = reinterpret_cast<int32_t*>(l_mark + ((A.T_cap + 8) & ~7));
+        const uint32_t* uw = reinterpret_cast<const uint32_t*>(l_mark);
+        const int nuw = (tile_n + 3) >> 2;
+        int per = (nuw + nthr - 1) / nthr, w0 = min(tid * per, nuw), w1 = min(w0 + per, nuw);
+        int sum = 0;
+        for (int w = w0; w < w1; ++w) sum += __popc(uw[w] & 0x01010101u);
+        l_scan[tid] = sum;
+        __syncthreads();
+        if (tid < WAVE) {
+            int run = 0;
+            for (int base = 0; base < nthr; base += WAVE) {
+                int v = (base + tid < nthr) ? l_scan[base + tid] : 0, x = v;
+#pragma unroll
+                for (int o = 1; o < WAVE; o <<= 1) { int u = __shfl_up(x, o, WAVE); if (tid >= o) x += u; }
+                if (base + tid < nthr) l_scan[base + tid] = run + x - v;
+                run += __shfl(x, WAVE - 1, WAVE);
+            }
+            if (tid == 0) { A.tile_cnt_dst[b] = run; l_scan[nthr] = run; }
+        }
+        __syncthreads();
+        {
+            int run = l_scan[tid];
+            for (int w = w0; w < w1; ++w) {
+                uint32_t m = uw[w];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if ((m >> (8 * q)) & 1u) { int t = (w << 2) + q; l_new[t] = (uint16_t)run; A.tile_idx_dst[(int64_t)b * A.T_cap + run] = tix[t]; ++run; }
+            }
+        }
+        __syncthreads();
+        const uint32_t n_in = (uint32_t)l_scan[nthr];
+        for (int r = 0; r < rows_wave; ++r) {
+            uint2 e4 = out_rows[(int64_t)r * A.BI];
+            uint32_t o2[2] = {0, 0};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t e = ((k < 2 ? e4.x : e4.y) >> (16 * (k & 1))) & 0xffffu;
+                uint32_t slot = e & 0x7fffu;
+                uint32_t ns = slot >= SENTP ? n_in : (uint32_t)l_new[slot];
+                o2[k >> 1] |= (ns | (e & 0x8000u)) << (16 * (k & 1));
+            }
+            out_rows[(int64_t)r * A.BI] = make_uint2(o2[0], o2[1]);
+        }
+        __syncthreads();   // l_new overlays the region the j-split reduction is about to use
     }
     if (A.JS > 1) {   // deterministic reduction of the j-split partial sums through LDS
         __syncthreads();
