@@ -204,7 +204,7 @@ int32_t mhip_vv_run(mhip_ctx* ctx, int64_t first_step, int64_t n_steps, double d
  *   stage2: F = forces(x) [+ specific]; v += a' dt/2      (owned atoms; ghosts read-only)     */
 int32_t mhip_vv_init(mhip_ctx* ctx, int64_t first_step);          /* wrap, rebuild, forces at first_step */
 int32_t mhip_vv_stage1(mhip_ctx* ctx, double dt);
-int32_t mhip_vv_stage2(mhip_ctx* ctx, int64_t step_n, double dt);
+int32_t mhip_vv_stage2(mhip_ctx* ctx, int64_t step_n, double dt);   /* incl. find_neighbors when step_n % rebuild_every == 0 */
 int32_t mhip_rebuild(mhip_ctx* ctx, int64_t step_n);              /* force a neighbour rebuild now */
 
 /* ---- neighbour list export (bit-exact check) ------------------------------------------------ */
@@ -230,7 +230,25 @@ int32_t mhip_shift_velocities(mhip_ctx* ctx, const double* dv3);  /* v -= dv3 on
 /* The same without a host round trip: out4_dev (device double[4]) receives this domain's {Σ m v, Σ m}; after the
  * host all-reduced it over the domains (RCCL), mhip_remove_cm_dev subtracts P/M of the device-resident total. */
 int32_t mhip_cm_momentum_dev(mhip_ctx* ctx, double* out4_dev);
+/* total4_dev is read by the next vv_stage1 / vv_halo_begin (or any state read): keep it untouched until then. */
 int32_t mhip_remove_cm_dev(mhip_ctx* ctx, const double* total4_dev);
+/* Long-lived ghost plans (no reference equivalent).  A host that hands over a ghost shell of width
+ * r_list + margin calls mhip_set_ghost_margin(margin) BEFORE mhip_set_atom_counts.  The sub-domain then searches an
+ * outer list of radius r_list + margin once per plan and re-prunes it to the reference's r_list list at the
+ * find_neighbors cadence (steps % rebuild_every == 0, inside vv_stage2 / vv_halo_end), exactly like the single-domain
+ * engine.  The plan (ownership, ghost set, outer list) stays valid while no owned or ghost atom moved more than margin/2:
+ * mhip_plan_disp2_dev writes max |x - x_plan|^2 as ONE float into device memory (MAX-all-reduce it over the ranks,
+ * re-plan when 2 sqrt(d2) nears margin).  +inf means "re-plan at every rebuild step" (margin 0, or an interaction
+ * without a cutoff <= r_list).  A force pass that finds the margin already exceeded fails with MHIP_ERR_STATE. */
+int32_t mhip_set_ghost_margin(mhip_ctx* ctx, double margin);
+int32_t mhip_plan_disp2_dev(mhip_ctx* ctx, float* out_dev);
+/* One MD step of a ghosted sub-domain in two launches-batches around the ghost exchange:
+ *   vv_halo_begin = vv_stage1 + gather_coords;   vv_halo_end = scatter_coords + vv_stage2 (+ this rank's
+ *   {Σ m v, Σ m} into cm_out4_dev when non-NULL, to be all-reduced and handed back through mhip_remove_cm_dev). */
+int32_t mhip_vv_halo_begin(mhip_ctx* ctx, double dt, const int32_t* idx_dev, const void* shift_dev,
+                           int64_t n_send, void* send_dev);
+int32_t mhip_vv_halo_end(mhip_ctx* ctx, int64_t step_n, double dt, int64_t first_ghost, int64_t n_ghost,
+                         const void* recv_dev, double* cm_out4_dev);
 
 #ifdef __cplusplus
 }

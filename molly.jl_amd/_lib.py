@@ -93,6 +93,10 @@ SIGNATURES = {
     "mhip_shift_velocities": (_I32, [_P, C.POINTER(_D * 3)]),
     "mhip_cm_momentum_dev": (_I32, [_P, _P]),
     "mhip_remove_cm_dev": (_I32, [_P, _P]),
+    "mhip_set_ghost_margin": (_I32, [_P, _D]),
+    "mhip_plan_disp2_dev": (_I32, [_P, _P]),
+    "mhip_vv_halo_begin": (_I32, [_P, _D, _P, _P, _I64, _P]),
+    "mhip_vv_halo_end": (_I32, [_P, _I64, _D, _I64, _I64, _P, _P]),
 }
 
 

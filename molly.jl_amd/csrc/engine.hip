@@ -61,6 +61,10 @@ struct EngineBase {
     virtual void shift_velocities(const double*) = 0;
     virtual void cm_momentum_dev(double*) = 0;
     virtual void remove_cm_dev(const double*) = 0;
+    virtual void set_ghost_margin(double) = 0;
+    virtual void plan_disp2_dev(float*) = 0;
+    virtual void halo_begin(double, const int32_t*, const void*, int64_t, void*) = 0;
+    virtual void halo_end(int64_t, double, int64_t, int64_t, const void*, double*) = 0;
 };
 
 // hipEvent stage timers (only active while profiling is on)
@@ -125,6 +129,9 @@ template <class T> class Engine final : public EngineBase {
     int64_t last_prune_step = 0;
     DBuf<T4> pos_snap_in;        // coordinates at the last prune (validity of the inner list: 2·displacement <= skin)
     double skin = 0; bool strict_cadence = false; int64_t n_disp_checks = 0;
+    // ghosted sub-domain whose ghost shell reaches r_list + ghost_margin: the ghost PLAN then lives as long as an outer list
+    // (until some atom moved ghost_margin/2), so the dual list works here too and the host re-plans only when mhip_plan_disp2_dev says so
+    double ghost_margin = 0; const double* cm_ext = nullptr;
     bool dual = false, dual_disabled = false; int early_outer = 0; double outer_margin = 0; int outer_every = 1; int64_t last_outer_step = 0, n_outer = 0, n_filters = 0; T r_in = 0, r_in2 = 0;
     DBuf<int32_t> flags; int32_t* h_flags = nullptr;
     int64_t total_rows = 0;
@@ -216,6 +223,7 @@ template <class T> class Engine final : public EngineBase {
         // dual pair list: search with r_list + margin every `outer_every` rebuild intervals, filter to exactly r_list at
         // every rebuild step (MOLLYHIP_OUTER_MARGIN_PM in picometres, 0 disables; MOLLYHIP_OUTER_EVERY)
         outer_margin = (G.no_list || dual_disabled) ? 0.0 : env_int("MOLLYHIP_OUTER_MARGIN_PM", 200) * 1e-3;
+        if (n_ghost > 0) outer_margin = std::min(outer_margin, ghost_margin);   // the shell handed over must cover the outer radius
         outer_every = std::max(1, env_int("MOLLYHIP_OUTER_EVERY", 1000));   // upper bound only: the outer list is re-searched when displacement says so
         strict_cadence = env_int("MOLLYHIP_STRICT_CADENCE", 0) != 0;         // 1: re-prune at every rebuild step, whatever the displacement
         for (int d = 0; d < 3; ++d) if (cfg.periodic[d] && cfg.r_list + outer_margin > 0.5 * cfg.box[d]) outer_margin = 0;   // keep r_outer <= L/2
@@ -230,7 +238,7 @@ template <class T> class Engine final : public EngineBase {
             if (ip.coul_kind != MHIP_COUL_NONE) rc_max = std::max(rc_max, ip.coul_rc);
             skin = G.no_list ? 0.0 : cfg.r_list - rc_max;
         }
-        dual = outer_margin > 0 && outer_every > 1 && n_ghost == 0 && lj_cut_ok && coul_cut_ok && skin > 0;   // ghosted sub-domains are re-planned by the host
+        dual = outer_margin > 0 && outer_every > 1 && lj_cut_ok && coul_cut_ok && skin > 0;   // ghosted: only with a ghost margin (else re-planned every rebuild)
         const double r_search = G.no_list ? 0.0 : cfg.r_list + (dual ? outer_margin : 0.0);
         G.r_list = G.no_list ? std::numeric_limits<T>::infinity() : T(r_search);
         G.r_list2 = G.no_list ? std::numeric_limits<T>::infinity() : (dual ? G.r_list * G.r_list : r_in2);
@@ -303,11 +311,12 @@ template <class T> class Engine final : public EngineBase {
         if (bytes > 64 * 1024) MHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     }
 
+    const double* cm_src() const { return cm_ext ? cm_ext : (const double*)cm_step.p; }
     void flush_cm() {
         if (!cm_pending) return;
         hipLaunchKernelGGL(k_shift_vel<T>, dim3(std::min(cdiv(n_owned, 256), 1024)), dim3(256), 0, stream, n_owned, vel[cur].p, (const T*)vcm.p,
-                           cm_pending == 2 ? (const double*)cm_step.p : (const double*)nullptr, n_cm_step);
-        cm_pending = 0;
+                           cm_pending == 2 ? cm_src() : (const double*)nullptr, n_cm_step);
+        cm_pending = 0; cm_ext = nullptr;
     }
 
     const T* to_device(const void* host_or_dev, size_t count, int mem_kind, DBuf<T>& stage) {
@@ -368,6 +377,7 @@ template <class T> class Engine final : public EngineBase {
             A.tile_idx = tile_idx.p; A.tile_cnt = tile_cnt.p; A.nbr = nbr.p; A.wave_rows = wave_rows.p; A.blk_center = blk_center.p; A.flags = flags.p;
             A.margin = G.no_list ? T(0) : G.r_list * T(1e-3);
             A.debug = env_int("MOLLYHIP_BUILD_DEBUG", 0);
+            A.approx = dual && !env_int("MOLLYHIP_EXACT_OUTER", 0) ? 1 : 0;
             set_lds_limit(k_build<T>, lds);
             prof.begin(1, stream);
             hipLaunchKernelGGL(k_build<T>, dim3(n_blocks), dim3(BI * JS), lds, stream, A);
@@ -446,14 +456,15 @@ template <class T> class Engine final : public EngineBase {
     // a filter pass, falling back to the search when it is due or an atom moved more than half the margin
     void refresh(int64_t step_n) {
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
-        if (!dual || stale || (step_n - last_outer_step) >= (int64_t)outer_every * every || step_n < last_outer_step) { rebuild(step_n); return; }
+        if (!dual || stale || (n_ghost == 0 && ((step_n - last_outer_step) >= (int64_t)outer_every * every || step_n < last_outer_step))) { rebuild(step_n); return; }
         // The inner list (pairs within r_list when it was pruned) provably contains every pair within the cutoffs as long as no atom
         // moved more than skin/2 since then — the condition the reference's fixed cadence only assumes.  Check it; re-prune (inside
         // the next force pass) only when it is about to fail.  mhip_export_neighbors always returns the exact list of NOW.
         bool reprune = strict_cadence || !inner_valid;
         if (!reprune) {
             MHIP_HIP(hipMemsetAsync(flags.p + FLAG_MAX_DISP2, 0, sizeof(int32_t), stream));
-            hipLaunchKernelGGL(k_max_disp<T>, dim3(std::min(cdiv(n_owned, 256), 1024)), dim3(256), 0, stream, n_owned, (const T4*)pos[cur].p, (const T4*)pos_snap_in.p, flags.p, G);
+            hipLaunchKernelGGL(k_max_disp<T>, dim3(std::min(cdiv(n_tot, 256), 1024)), dim3(256), 0, stream, n_tot, (const T4*)pos[cur].p, (const T4*)pos_snap_in.p,
+                               reinterpret_cast<unsigned int*>(flags.p + FLAG_MAX_DISP2), G);
             MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
             MHIP_HIP(hipStreamSynchronize(stream));
             float d2; std::memcpy(&d2, &h_flags[FLAG_MAX_DISP2], sizeof(float));
@@ -470,6 +481,7 @@ template <class T> class Engine final : public EngineBase {
     void after_forces(int64_t step_n) {
         if (!prune_disp_exceeded) return;
         prune_disp_exceeded = false;
+        if (n_ghost > 0) throw ApiError{MHIP_ERR_STATE, "an atom moved more than half the ghost margin since the ghost plan: re-plan earlier (mhip_plan_disp2_dev)"};
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         // If that keeps happening before the outer list has paid for itself (fast light atoms, small time step), the dual list
         // is a loss: fall back to a fresh search at every rebuild step.
@@ -551,6 +563,9 @@ template <class T> class Engine final : public EngineBase {
         ++n_force_calls;
         if (prune) {   // validity of the pruned list: nobody moved more than half the margin since the outer search
             MHIP_HIP(hipMemsetAsync(flags.p, 0, N_FLAGS * sizeof(int32_t), stream));
+            if (n_ghost > 0)   // the blocks record the displacement of the owned atoms; the ghosts' comes on top
+                hipLaunchKernelGGL(k_max_disp<T>, dim3(std::min(cdiv(n_ghost, 256), 1024)), dim3(256), 0, stream, n_ghost, (const T4*)pos[cur].p + n_owned, (const T4*)pos_snap.p + n_owned,
+                                   reinterpret_cast<unsigned int*>(flags.p + FLAG_MAX_DISP2), G);
             hipLaunchKernelGGL(k_build_summary, dim3(std::min(64, cdiv(n_blocks * JS * (BI / WAVE), 256))), dim3(256), 0, stream, n_blocks, n_blocks * JS * (BI / WAVE), R_cap,
                                (const int32_t*)tile_cnt_in.p, wave_rows_in.p, (const float*)blk_disp2.p, flags.p);
             MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
@@ -614,8 +629,8 @@ template <class T> class Engine final : public EngineBase {
         MHIP_HIP(hipMemcpyAsync(inv.p, iota.data(), n_tot * sizeof(int32_t), hipMemcpyHostToDevice, stream));
         MHIP_HIP(hipMemsetAsync(frc[cur].p, 0, n_tot * sizeof(T4), stream));
         MHIP_HIP(hipStreamSynchronize(stream));
-        stale = true; cm_pending = 0; frc_valid = false;
-        setup_grid();          // the dual pair list is a single-domain feature: the search radius depends on n_ghost
+        stale = true; cm_pending = 0; cm_ext = nullptr; frc_valid = false;
+        setup_grid();          // the search radius depends on n_ghost / the ghost margin
         choose_blocking();
     }
 
@@ -793,9 +808,8 @@ template <class T> class Engine final : public EngineBase {
     }
     void remove_cm_dev(const double* total4_dev) override {
         flush_cm();
-        hipLaunchKernelGGL(k_vcm_from_total<T>, dim3(1), dim3(64), 0, stream, total4_dev, vcm.p);
-        cm_pending = 1;   // subtracted by the next vv_stage1 (or flushed by any state read)
-        MHIP_HIP(hipGetLastError());
+        // {ΣPx, ΣPy, ΣPz, ΣM} is read as ONE partial by the next k_vv1 (or any state read): total4_dev must stay untouched until then
+        cm_ext = total4_dev; n_cm_step = 1; cm_pending = 2;
     }
 
     void check_finite() override {
@@ -816,9 +830,9 @@ template <class T> class Engine final : public EngineBase {
         if (!frc_valid) throw ApiError{MHIP_ERR_STATE, "vv_stage1 needs forces from vv_init / vv_stage2"};
         prof.begin(2, stream);
         hipLaunchKernelGGL(k_vv1<T>, dim3(std::min(cdiv(n_owned, 256), 1024)), dim3(256), 0, stream, n_owned, pos[cur].p, vel[cur].p, (const T4*)frc[cur].p, T(dt), T(dt) / T(2),
-                           cm_pending == 1 ? (const T*)vcm.p : (const T*)nullptr, cm_pending == 2 ? (const double*)cm_step.p : (const double*)nullptr, n_cm_step, G);
+                           cm_pending == 1 ? (const T*)vcm.p : (const T*)nullptr, cm_pending == 2 ? cm_src() : (const double*)nullptr, n_cm_step, G);
         prof.end(2, stream);
-        cm_pending = 0;
+        cm_pending = 0; cm_ext = nullptr;
     }
     void stage2_impl(int64_t step_n, double dt, bool cm) {
         step_forces(step_n);
@@ -832,8 +846,45 @@ template <class T> class Engine final : public EngineBase {
         }
         prof.end(2, stream);
     }
+    // the neighbour cadence of a stepwise-driven run: as in vv_run.  A ghosted sub-domain without the dual list is re-planned
+    // (set_atom_counts / set_state → stale) by the host at every rebuild step instead.
+    void stage2_cadenced(int64_t step_n, double dt, bool cm) {
+        const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
+        const bool due = step_n % every == 0 && step_n != last_build_step && (n_ghost == 0 || dual);
+        if (due && dual) refresh(step_n);
+        stage2_impl(step_n, dt, cm);
+        if (due && !dual) refresh(step_n);
+    }
     void vv_stage2(int64_t step_n, double dt) override {
-        stage2_impl(step_n, dt, false);
+        stage2_cadenced(step_n, dt, false);
+        MHIP_HIP(hipGetLastError());
+    }
+
+    void set_ghost_margin(double m) override {
+        if (!(m >= 0) || std::isinf(m)) throw ApiError{MHIP_ERR_INVALID, "ghost margin must be finite and >= 0"};
+        ghost_margin = m; stale = true;
+        if (n_ghost > 0) { setup_grid(); choose_blocking(); }
+    }
+    // max |x − x_plan|² over owned and ghost atoms since the outer search of the current ghost plan, as a float in device memory
+    // (ready for a MAX all-reduce over the ranks); +inf when this sub-domain has to be re-planned at every rebuild step anyway
+    void plan_disp2_dev(float* out_dev) override {
+        if (!dual || stale) { const uint32_t inf_bits = 0x7f800000u; MHIP_HIP(hipMemsetD32Async((hipDeviceptr_t)out_dev, (int)inf_bits, 1, stream)); return; }
+        MHIP_HIP(hipMemsetAsync(out_dev, 0, sizeof(float), stream));
+        hipLaunchKernelGGL(k_max_disp<T>, dim3(std::min(cdiv(n_tot, 256), 1024)), dim3(256), 0, stream, n_tot, (const T4*)pos[cur].p, (const T4*)pos_snap.p, reinterpret_cast<unsigned int*>(out_dev), G);
+        MHIP_HIP(hipGetLastError());
+    }
+    // one MD step of a ghosted sub-domain in two calls around the ghost exchange
+    void halo_begin(double dt, const int32_t* idx_dev, const void* shift_dev, int64_t n, void* out_dev) override {
+        vv_stage1(dt);
+        gather_coords(idx_dev, shift_dev, n, out_dev);
+    }
+    void halo_end(int64_t step_n, double dt, int64_t first, int64_t n, const void* in_dev, double* cm_out4_dev) override {
+        scatter_coords(first, n, in_dev);
+        stage2_cadenced(step_n, dt, cm_out4_dev != nullptr);
+        if (cm_out4_dev) {   // this rank's {ΣPx, ΣPy, ΣPz, ΣM} for the all-reduce; nothing pending locally: the TOTAL comes back via remove_cm_dev
+            hipLaunchKernelGGL(k_cm_finalize<T>, dim3(1), dim3(256), 0, stream, n_cm_step, (const double*)cm_step.p, cm_out4_dev, (T*)nullptr);
+            cm_pending = 0;
+        }
         MHIP_HIP(hipGetLastError());
     }
     void rebuild_now(int64_t step_n) override { flush_cm(); if (stale) rebuild(step_n); else refresh(step_n); }
@@ -1042,5 +1093,11 @@ int32_t mhip_cm_momentum(mhip_ctx* ctx, double* out4) { NEED_CTX(); return guard
 int32_t mhip_shift_velocities(mhip_ctx* ctx, const double* dv3) { NEED_CTX(); return guard(ctx, [&] { ctx->e->shift_velocities(dv3); }); }
 int32_t mhip_cm_momentum_dev(mhip_ctx* ctx, double* out4) { NEED_CTX(); return guard(ctx, [&] { ctx->e->cm_momentum_dev(out4); }); }
 int32_t mhip_remove_cm_dev(mhip_ctx* ctx, const double* t4) { NEED_CTX(); return guard(ctx, [&] { ctx->e->remove_cm_dev(t4); }); }
+int32_t mhip_set_ghost_margin(mhip_ctx* ctx, double m) { NEED_CTX(); return guard(ctx, [&] { ctx->e->set_ghost_margin(m); }); }
+int32_t mhip_plan_disp2_dev(mhip_ctx* ctx, float* out) { NEED_CTX(); return guard(ctx, [&] { if (!out) throw mhip::ApiError{MHIP_ERR_INVALID, "null output"}; ctx->e->plan_disp2_dev(out); }); }
+int32_t mhip_vv_halo_begin(mhip_ctx* ctx, double dt, const int32_t* idx, const void* shift, int64_t n, void* out) { NEED_CTX(); return guard(ctx, [&] { ctx->e->halo_begin(dt, idx, shift, n, out); }); }
+int32_t mhip_vv_halo_end(mhip_ctx* ctx, int64_t step_n, double dt, int64_t first, int64_t n, const void* in, double* cm_out4) {
+    NEED_CTX(); return guard(ctx, [&] { ctx->e->halo_end(step_n, dt, first, n, in, cm_out4); });
+}
 
 }  // extern "C"

@@ -31,6 +31,15 @@ template <class T> __device__ inline int cell_coord(T x, int d, const GridP<T>& 
 }
 
 // value of `v` in lane `src` (wave-uniform index) broadcast to every lane through the scalar file (v_readlane_b32)
+// lane `dst` (wave-uniform) of lo/hi := the two halves of a wave mask held in scalar registers (v_writelane_b32; the lane
+// select goes through m0 because a VOP3 may read only one ordinary SGPR on gfx9)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ inline void mask_to_lane(int& lo, int& hi, unsigned long long mask, int dst) {
+    const int mlo = (int)(uint32_t)mask, mhi = (int)(uint32_t)(mask >> 32);
+    asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0" : "+v"(lo), "+v"(hi) : "s"(mlo), "s"(mhi), "s"(dst) : "m0");
+}
+#pragma clang diagnostic pop
 __device__ inline float lane_bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 __device__ inline double lane_bcast(double v, int src) {
     long long b = __double_as_longlong(v);
@@ -151,6 +160,7 @@ template <class T> struct BuildArgs {
     int32_t* flags;
     T margin;
     int debug;                       // MOLLYHIP_BUILD_DEBUG: stop after stage n (timing experiments only)
+    int approx;                      // outer list of the dual scheme: any superset of r_list will do, skip the exact band test
 };
 
 // exclusive prefix sum of a[0..n) in LDS, in place; a[n] receives the total.  `part` holds blockDim ints.
@@ -409,27 +419,37 @@ __global__ void k_build(BuildArgs<T> A) {
 #pragma unroll
                 for (int d = 0; d < 3; ++d) { float e = gmn[d] - ml[d]; float f = ml[d] - gmx[d]; e = e > f ? e : f; e = e > 0.f ? e : 0.f; acc += e * e; }
                 unsigned long long im = __ballot(valid && acc <= reach2f);
-                while (im) {
-                    const int i = __builtin_ctzll(im);
-                    im &= im - 1;
-                    const float ix = lane_bcast(ml[0], i), iy = lane_bcast(ml[1], i), iz = lane_bcast(ml[2], i);
-                    float dx = pl.x - ix, dy = pl.y - iy, dz = pl.z - iz;
-                    float r2 = dx * dx + dy * dy + dz * dz;
-                    unsigned long long in = __ballot(near && r2 < band_lo);
-                    const unsigned long long maybe = __ballot(near && !(r2 < band_lo) && r2 <= band_hi);
-                    if (maybe) {   // rare: decide with the reference's exact arithmetic on the stored coordinates
-                        const T ox = lane_bcast(my[0], i), oy = lane_bcast(my[1], i), oz = lane_bcast(my[2], i);
-                        bool ok = false;
-                        if ((maybe >> lane) & 1ull) {
-                            T4 pj = A.pos[A.tile_idx[(int64_t)b * A.T_cap + jl]];
-                            T ex = G.periodic[0] ? vector_1d_exact(ox, pj.x, G.L[0]) : M<T>::sub(pj.x, ox);
-                            T ey = G.periodic[1] ? vector_1d_exact(oy, pj.y, G.L[1]) : M<T>::sub(pj.y, oy);
-                            T ez = G.periodic[2] ? vector_1d_exact(oz, pj.z, G.L[2]) : M<T>::sub(pj.z, oz);
-                            ok = norm2_exact(ex, ey, ez) <= G.r_list2;
-                        }
-                        in |= __ballot(ok);
+                // candidates out of reach (or past the tile's end) are parked at infinity: no lane mask in the loop
+                const float qx = near ? pl.x : __builtin_inff();
+                if (A.approx) {
+                    while (im) {
+                        const int i = __builtin_ctzll(im);
+                        im &= im - 1;
+                        const float dx = qx - lane_bcast(ml[0], i), dy = pl.y - lane_bcast(ml[1], i), dz = pl.z - lane_bcast(ml[2], i);
+                        mask_to_lane(mine_lo, mine_hi, __ballot(dx * dx + dy * dy + dz * dz <= band_hi), i);
                     }
-                    if (lane == i) { mine_lo = (int)(uint32_t)in; mine_hi = (int)(uint32_t)(in >> 32); }   // v_cndmask ×2
+                } else {
+                    while (im) {
+                        const int i = __builtin_ctzll(im);
+                        im &= im - 1;
+                        const float dx = qx - lane_bcast(ml[0], i), dy = pl.y - lane_bcast(ml[1], i), dz = pl.z - lane_bcast(ml[2], i);
+                        const float r2 = dx * dx + dy * dy + dz * dz;
+                        unsigned long long in = __ballot(r2 < band_lo);
+                        const unsigned long long maybe = __ballot(r2 <= band_hi) & ~in;
+                        if (maybe) {   // rare: decide with the reference's exact arithmetic on the stored coordinates
+                            const T ox = lane_bcast(my[0], i), oy = lane_bcast(my[1], i), oz = lane_bcast(my[2], i);
+                            bool ok = false;
+                            if ((maybe >> lane) & 1ull) {
+                                T4 pj = A.pos[A.tile_idx[(int64_t)b * A.T_cap + jl]];
+                                T ex = G.periodic[0] ? vector_1d_exact(ox, pj.x, G.L[0]) : M<T>::sub(pj.x, ox);
+                                T ey = G.periodic[1] ? vector_1d_exact(oy, pj.y, G.L[1]) : M<T>::sub(pj.y, oy);
+                                T ez = G.periodic[2] ? vector_1d_exact(oz, pj.z, G.L[2]) : M<T>::sub(pj.z, oz);
+                                ok = norm2_exact(ex, ey, ez) <= G.r_list2;
+                            }
+                            in |= __ballot(ok);
+                        }
+                        mask_to_lane(mine_lo, mine_hi, in, i);
+                    }
                 }
             } else {
                 for (int i = 0; i < WAVE; ++i) {
@@ -498,9 +518,9 @@ __global__ void k_build_summary(int n_blocks, int n_waves, int R_cap, const int3
 }
 
 // ---------------------------------------------------------------------------------------------------
-// max over the owned atoms of |x - x_snap|² (nearest image) → flags[FLAG_MAX_DISP2] (float bits; d² >= 0 so uint order works)
+// max over n atoms of |x - x_snap|² (nearest image) → atomicMax into *out_word (float bits; d² >= 0 so uint order works)
 template <class T>
-__global__ void k_max_disp(int64_t n, const typename Vec<T>::T4* __restrict__ pos, const typename Vec<T>::T4* __restrict__ snap, int32_t* flags, GridP<T> G) {
+__global__ void k_max_disp(int64_t n, const typename Vec<T>::T4* __restrict__ pos, const typename Vec<T>::T4* __restrict__ snap, unsigned int* out_word, GridP<T> G) {
     float d2 = 0.f;
     for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
         auto p = pos[s]; auto q = snap[s];
@@ -514,7 +534,7 @@ __global__ void k_max_disp(int64_t n, const typename Vec<T>::T4* __restrict__ po
     __shared__ float sh[4];
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = d2;
     __syncthreads();
-    if (threadIdx.x == 0) { float m = 0.f; for (int q = 0; q < (int)(blockDim.x >> 6); ++q) m = fmaxf(m, sh[q]); atomicMax(reinterpret_cast<unsigned int*>(&flags[FLAG_MAX_DISP2]), __float_as_uint(m)); }
+    if (threadIdx.x == 0) { float m = 0.f; for (int q = 0; q < (int)(blockDim.x >> 6); ++q) m = fmaxf(m, sh[q]); atomicMax(out_word, __float_as_uint(m)); }
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -6,11 +6,17 @@ design, following SURVEY.md §8(e).  The box is cut into gx×gy×gz bricks; a ra
 coordinate lies in its brick and keeps, as ghosts, a full shell of width r_list of its neighbours' atoms, already
 shifted by the periodic image that places them next to the brick.  Every pair that touches an owned atom is evaluated
 by the owner (full shell, no ghost-force return), so one exchange of ghost COORDINATES per force evaluation is the only
-data-path communication; migration and the ghost plan are redone at the neighbour-rebuild cadence.
+data-path communication.
 
-Per step and rank:   stage1 (kick, drift) → pack ghosts (HIP gather kernel) → all_to_all_single → unpack (scatter kernel)
-                     → stage2 (forces, kick) → [all_reduce of 32 B for remove_CM_motion]
+Per step and rank:   halo_begin (kick, drift, pack ghosts) → all_to_all_single → halo_end (unpack, forces, kick, Σmv)
+                     → [all_reduce of 32 B for remove_CM_motion]
 Axes that are not cut (g = 1) stay periodic inside the engine and need no ghosts.
+
+Ghost plan lifetime.  With ghost_margin = 0 ownership and the ghost plan are redone at every neighbour-rebuild step.
+With ghost_margin = Δ > 0 the shell is r_list + Δ wide and the plan (ownership, ghost set, the engine's outer pair list)
+is kept until some atom has moved Δ/2 since it was made: until then every atom within r_list of an owned atom is
+provably in the local set, the engine re-prunes its outer list to the reference's r_list list at the rebuild cadence,
+and the ranks agree on the re-plan step through one MAX all-reduce of a float per rebuild interval.
 """
 import ctypes as C
 import itertools
@@ -106,7 +112,7 @@ class BrickGrid:
 class HipDomainEngine:
     """The per-rank libmollyhip context driven through device pointers of torch tensors."""
 
-    def __init__(self, inter, dtype, capacity, box, origin, periodic, r_list, rebuild_every, device_id):
+    def __init__(self, inter, dtype, capacity, box, origin, periodic, r_list, rebuild_every, device_id, ghost_margin=0.0):
         L = _lib.lib()
         cfg = _lib.Config()
         cfg.precision = 32 if np.dtype(dtype) == np.float32 else 64
@@ -124,6 +130,7 @@ class HipDomainEngine:
         self.L = L
         self.capacity = capacity
         self._chk(L.mhip_set_stream(self.ctx, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        self._chk(L.mhip_set_ghost_margin(self.ctx, float(ghost_margin)))
 
     def _chk(self, rc):
         if rc != 0:
@@ -156,6 +163,15 @@ class HipDomainEngine:
     def stage2(self, step, dt):
         self._chk(self.L.mhip_vv_stage2(self.ctx, step, dt))
 
+    def halo_begin(self, dt, idx_i32, shift, out):
+        self._chk(self.L.mhip_vv_halo_begin(self.ctx, dt, self._p(idx_i32), self._p(shift), idx_i32.numel(), self._p(out)))
+
+    def halo_end(self, step, dt, first, n, buf, cm_out4):
+        self._chk(self.L.mhip_vv_halo_end(self.ctx, step, dt, first, n, self._p(buf), self._p(cm_out4)))
+
+    def plan_disp2(self, out1_f32):       # device float[1]
+        self._chk(self.L.mhip_plan_disp2_dev(self.ctx, self._p(out1_f32)))
+
     def get_state(self, x_all, v_owned):
         self._chk(self.L.mhip_get_state(self.ctx, self._p(x_all), self._p(v_owned), _lib.MEM_DEVICE))
 
@@ -183,11 +199,14 @@ class HipDomainEngine:
 
 
 class DomainRun:
-    """One rank's share of a velocity-Verlet run.  `engine` implements set_local / gather / scatter / vv_init / stage1 /
-    stage2 / get_state / cm_momentum / remove_cm (HipDomainEngine on the GPU, an oracle-backed stand-in in the CPU tests)."""
+    """One rank's share of a velocity-Verlet run.  `engine` implements set_local / vv_init / halo_begin / halo_end /
+    plan_disp2 / get_state / remove_cm (HipDomainEngine on the GPU, an oracle-backed stand-in in the CPU tests).
+    `grid.r_ghost` must be r_list + ghost_margin."""
 
-    def __init__(self, grid: BrickGrid, engine, tdtype, device, rebuild_every, group=None):
+    def __init__(self, grid: BrickGrid, engine, tdtype, device, rebuild_every, group=None, ghost_margin=0.0):
         self.g, self.e = grid, engine
+        self.gm = float(ghost_margin)
+        self.plan_step = 0
         self.tdtype, self.device = tdtype, device
         self.every = rebuild_every
         self.group = group
@@ -195,7 +214,8 @@ class DomainRun:
         self.boxt = torch.tensor(grid.box, dtype=tdtype, device=device)
         self.n_owned = self.n_ghost = 0
         self.cm_buf = torch.zeros(4, dtype=torch.float64, device=device)
-        self.stats = {"exchange_calls": 0, "ghost_atoms": 0, "migrated": 0}
+        self.d2_buf = torch.zeros(1, dtype=torch.float32, device=device)
+        self.stats = {"exchange_calls": 0, "ghost_atoms": 0, "migrated": 0, "plans": 0, "plan_checks": 0}
         # gloo cannot move device memory: stage through the host (used by the multi-process tests that share ONE GPU;
         # the production path is backend "nccl" = RCCL, device buffers end to end)
         self.stage_host = torch.device(device).type == "cuda" and dist.get_backend(group) == "gloo"
@@ -208,11 +228,11 @@ class DomainRun:
         else:
             dist.all_to_all_single(recv, send, rc, sc, group=self.group)
 
-    def _all_reduce(self, t):
+    def _all_reduce(self, t, op=dist.ReduceOp.SUM):
         if self.stage_host:
-            c = t.cpu(); dist.all_reduce(c, group=self.group); t.copy_(c)
+            c = t.cpu(); dist.all_reduce(c, op=op, group=self.group); t.copy_(c)
         else:
-            dist.all_reduce(t, group=self.group)
+            dist.all_reduce(t, op=op, group=self.group)
 
     def _all_gather(self, t):
         if self.stage_host:
@@ -261,7 +281,8 @@ class DomainRun:
             send_counts = torch.zeros(self.world, dtype=torch.int64, device=self.device)
         recv_counts = torch.empty_like(send_counts)
         self._a2a(recv_counts, send_counts)
-        self.send_counts, self.recv_counts = send_counts.tolist(), recv_counts.tolist()     # one host sync per rebuild
+        self.send_counts, self.recv_counts = send_counts.tolist(), recv_counts.tolist()     # one host sync per plan
+        self._sc3, self._rc3 = [c * 3 for c in self.send_counts], [c * 3 for c in self.recv_counts]
         self.n_owned, self.n_ghost = n, int(sum(self.recv_counts))
         # ghost parameters (charge, σ, ϵ, mass) and first ghost coordinates
         send_par = self.par[self.send_idx.long()].contiguous()
@@ -276,29 +297,45 @@ class DomainRun:
         self.e.set_local(self.n_owned, self.n_ghost, par_all[:, 0], par_all[:, 1], par_all[:, 2], par_all[:, 3], x_all, self.v)
         self.e.vv_init(step)                                 # neighbour structures + forces at this step
         self.stats["ghost_atoms"] = self.n_ghost
+        self.stats["plans"] += 1
+        self.plan_step = step
 
     def _a2a_rows(self, recv, send):
         w = recv.shape[1]
         self._a2a(recv.view(-1), send.view(-1), [c * w for c in self.recv_counts], [c * w for c in self.send_counts])
 
     # -- one MD step ------------------------------------------------------------------------------------------------
-    def exchange_ghosts(self):
-        if self.world == 1 or not self.g.dirs:
-            return
-        self.e.gather(self.send_idx, self.send_shift, self.send_buf)
-        self._a2a_rows(self.recv_x, self.send_buf)
-        self.e.scatter(self.n_owned, self.n_ghost, self.recv_x)
-        self.stats["exchange_calls"] += 1
-
     def step(self, step_n, dt, remove_cm_every=1):
-        self.e.stage1(dt)
-        self.exchange_ghosts()
-        self.e.stage2(step_n, dt)
-        if remove_cm_every and step_n % remove_cm_every == 0:
-            self.e.cm_momentum(self.cm_buf)
+        cm = bool(remove_cm_every) and step_n % remove_cm_every == 0
+        self.e.halo_begin(dt, self.send_idx, self.send_shift, self.send_buf)      # kick, drift, pack my atoms the peers need
+        if self.world > 1 and self.g.dirs:
+            self._a2a(self.recv_x.view(-1), self.send_buf.view(-1), self._rc3, self._sc3)
+            self.stats["exchange_calls"] += 1
+        self.e.halo_end(step_n, dt, self.n_owned, self.n_ghost, self.recv_x, self.cm_buf if cm else None)   # unpack, forces, kick
+        if cm:
             self._all_reduce(self.cm_buf)
-            self.e.remove_cm(self.cm_buf)
+            self.e.remove_cm(self.cm_buf)              # applied by the next halo_begin
         if step_n % self.every == 0:
+            self.replan_if_due(step_n)
+
+    def replan_if_due(self, step_n):
+        """Collective decision at the rebuild cadence: keep the ghost plan while no atom anywhere moved ghost_margin/2."""
+        if self.gm <= 0:
+            self.migrate(step_n)
+            return
+        self.e.plan_disp2(self.d2_buf)
+        self._all_reduce(self.d2_buf, dist.ReduceOp.MAX)
+        d2 = float(self.d2_buf.item())                  # the one host sync per rebuild interval
+        self.stats["plan_checks"] += 1
+        if math.isinf(d2):
+            self.migrate(step_n)
+            return
+        moved = 2.0 * math.sqrt(d2)
+        if moved > self.gm:
+            raise RuntimeError(f"an atom moved {moved / 2:.4f} nm since the ghost plan of step {self.plan_step}: more than half the "
+                               f"ghost margin {self.gm:.3f} nm — the margin is too small for this rebuild interval")
+        k = max(1, (step_n - self.plan_step) // self.every)
+        if moved * (k + 1) / k > 0.9 * self.gm:        # would not survive another interval at this drift rate
             self.migrate(step_n)
 
     def run(self, first_step, n_steps, dt, remove_cm_every=1):
@@ -380,12 +417,16 @@ def bench_distributed(m, case, dtype, dt, args, rank, local_rank, world):
     device = torch.device("cuda", local_rank)
     tdtype = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
     grid = choose_grid(world, case.box)
-    bg = BrickGrid(case.box, grid, rank, case.r_list)
+    gm = float(os.environ.get("MOLLYHIP_GHOST_MARGIN_PM", "200")) * 1e-3
+    brick_min = min(b / g for b, g in zip(case.box, grid) if g > 1)
+    if case.r_list + gm > brick_min:
+        gm = 0.0                                            # bricks too thin for a margin: re-plan at every rebuild step
+    bg = BrickGrid(case.box, grid, rank, case.r_list + gm)
     box, origin, periodic = bg.engine_box(pad=0.3)
     vol_frac = np.prod([b / L for b, L in zip(box, case.box)])
     capacity = int(case.n * min(1.0, vol_frac) * 1.25) + 4096
-    eng = HipDomainEngine(make_interactions(case, dtype), dtype, capacity, box, origin, periodic, case.r_list, case.rebuild_every, local_rank)
-    run = DomainRun(bg, eng, tdtype, device, case.rebuild_every)
+    eng = HipDomainEngine(make_interactions(case, dtype), dtype, capacity, box, origin, periodic, case.r_list, case.rebuild_every, local_rank, ghost_margin=gm)
+    run = DomainRun(bg, eng, tdtype, device, case.rebuild_every, ghost_margin=gm)
     run.setup_from_global(case.coords, case.velocities, np.zeros(case.n) if case.charge is None else case.charge, case.sigma, case.eps, case.mass)
     run.run(0, args.warmup, dt)
     torch.cuda.synchronize(); dist.barrier()
@@ -411,6 +452,7 @@ def bench_distributed(m, case, dtype, dt, args, rank, local_rank, world):
     agg = torch.stack(per_rank).sum(0).tolist()
     st["n_pairs_full"] = int(agg[0])
     extra = {"parallelism": f"spatial bricks {grid[0]}x{grid[1]}x{grid[2]}, full-shell ghost coordinates via all_to_all_single (RCCL), "
-                            f"{int(agg[3] / world)} ghosts / {int(agg[4] / world)} owned atoms per GPU",
+                            f"{int(agg[3] / world)} ghosts / {int(agg[4] / world)} owned atoms per GPU, ghost margin {gm:.2f} nm "
+                            f"({run.stats['plans']} ghost plans in {run.stats['plan_checks']} checks)",
              "per_gpu_force_pass_bytes": st["force_pass_bytes"], "ghost_fraction": agg[3] / max(agg[4], 1)}
     return ms_per_step, st, extra

@@ -19,6 +19,7 @@ class OracleDomainEngine:
         f = lambda t: t.detach().cpu().numpy().astype(np.float64).copy()
         self.q, self.sigma, self.eps, self.mass = f(q), f(sigma), f(eps), f(mass)
         self.x, self.v = f(x_all), f(v_owned)
+        self.x_plan = self.x.copy()
         self.f = None
 
     def _forces(self):
@@ -48,6 +49,26 @@ class OracleDomainEngine:
     def stage2(self, step, dt):
         self._forces()
         self.v += self.f / self.mass[: self.n_owned, None] * (dt / 2)
+
+    # the fused per-step entry points of HipDomainEngine
+    def halo_begin(self, dt, idx, shift, out):
+        self.stage1(dt)
+        if idx.numel():
+            self.gather(idx, shift, out)
+
+    def halo_end(self, step, dt, first, n, buf, cm_out4):
+        if n:
+            self.scatter(first, n, buf)
+        self.stage2(step, dt)
+        if cm_out4 is not None:
+            self.cm_momentum(cm_out4)
+
+    def plan_disp2(self, out1):
+        d = self.x - self.x_plan
+        for k in range(3):
+            if self.periodic[k]:
+                d[:, k] -= np.round(d[:, k] / self.box[k]) * self.box[k]
+        out1[0] = float((d * d).sum(axis=1).max())
 
     def get_state(self, x_all, v_owned):
         x_all.copy_(torch.from_numpy(self.x).to(x_all.dtype)); v_owned.copy_(torch.from_numpy(self.v).to(v_owned.dtype))

@@ -14,6 +14,7 @@ L = m.lib(); ctx = s.engine()
 s._check(L.mhip_rebuild(ctx, 0))
 s._check(L.mhip_set_profiling(ctx, 1))
 for k in range(10):
+    s.push_state()                       # marks the list stale: every call is a full (outer) search
     s._check(L.mhip_rebuild(ctx, k + 1))
 st = s.stats()
 print("debug", os.environ.get("MOLLYHIP_BUILD_DEBUG", "0"), "build kernel ms", st["prof_ms"][1] / max(st["prof_calls"][1], 1), "sort ms", st["prof_ms"][3] / max(st["prof_calls"][3], 1),
