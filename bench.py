@@ -98,7 +98,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
 
     case, dtype, dt = make_case(args.workload)
-    if world > 1:
+    if world > 1 or os.environ.get("MOLLYHIP_FORCE_DOMAIN"):   # the env hook drives the N = 1 box through the multi-GPU host loop (overhead checks)
         from molly_jl_amd import domain   # spatial decomposition + RCCL halo exchange
         result = domain.bench_distributed(m, case, dtype, dt, args, rank, local_rank, world)
         if rank != 0:

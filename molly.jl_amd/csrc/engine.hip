@@ -132,6 +132,8 @@ template <class T> class Engine final : public EngineBase {
     // ghosted sub-domain whose ghost shell reaches r_list + ghost_margin: the ghost PLAN then lives as long as an outer list
     // (until some atom moved ghost_margin/2), so the dual list works here too and the host re-plans only when mhip_plan_disp2_dev says so
     double ghost_margin = 0; const double* cm_ext = nullptr;
+    // single list, same idea: a rebuild step whose displacement check shows the list still covers every cutoff sphere is skipped
+    bool lazy_single = false; int64_t n_skipped = 0;
     bool dual = false, dual_disabled = false; int early_outer = 0; double outer_margin = 0; int outer_every = 1; int64_t last_outer_step = 0, n_outer = 0, n_filters = 0; T r_in = 0, r_in2 = 0;
     DBuf<int32_t> flags; int32_t* h_flags = nullptr;
     int64_t total_rows = 0;
@@ -239,6 +241,8 @@ template <class T> class Engine final : public EngineBase {
             skin = G.no_list ? 0.0 : cfg.r_list - rc_max;
         }
         dual = outer_margin > 0 && outer_every > 1 && lj_cut_ok && coul_cut_ok && skin > 0;   // ghosted: only with a ghost margin (else re-planned every rebuild)
+        lazy_single = !dual && !G.no_list && lj_cut_ok && coul_cut_ok && skin > 0 && n_ghost == 0 && !strict_cadence;
+        if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] grid: dual %d margin %.3f skin %.3f lj_ok %d coul_ok %d ghosts %lld\n", (int)dual, outer_margin, skin, (int)lj_cut_ok, (int)coul_cut_ok, (long long)n_ghost);
         const double r_search = G.no_list ? 0.0 : cfg.r_list + (dual ? outer_margin : 0.0);
         G.r_list = G.no_list ? std::numeric_limits<T>::infinity() : T(r_search);
         G.r_list2 = G.no_list ? std::numeric_limits<T>::infinity() : (dual ? G.r_list * G.r_list : r_in2);
@@ -335,6 +339,7 @@ template <class T> class Engine final : public EngineBase {
         try { rebuild_impl(step_n); }
         catch (const ApiError& e) {
             if (e.code != MHIP_ERR_CAPACITY || !dual) throw;
+            if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] dual list off (capacity): %s\n", e.msg.c_str());
             dual_disabled = true; setup_grid(); choose_blocking(); stale = true;
             rebuild_impl(step_n);
         }
@@ -365,7 +370,8 @@ template <class T> class Engine final : public EngineBase {
             size_t lds = build_lds_bytes(T_cap, BI, C_cap);
             if (lds > (size_t)MAX_LDS_BYTES) {
                 if (BI > 64) { BI /= 2; JS = std::min(JS * 2, 1024 / BI); estimate_capacities(); continue; }
-                throw ApiError{MHIP_ERR_CAPACITY, "neighbourhood tile of one 64-atom block does not fit the 160 KiB LDS (r_list too large for this density)"};
+                throw ApiError{MHIP_ERR_CAPACITY, "neighbourhood tile of one 64-atom block does not fit the 160 KiB LDS (r_list too large for this density): T_cap " + std::to_string(T_cap) +
+                               " C_cap " + std::to_string(C_cap) + " bytes " + std::to_string(lds)};
             }
             tile_idx.reserve((size_t)n_blocks * T_cap); tile_cnt.reserve(n_blocks); wave_rows.reserve((size_t)n_blocks * JS * (BI / WAVE));
             nbr.reserve((size_t)n_blocks * JS * R_cap * BI); blk_center.reserve(n_blocks);
@@ -412,6 +418,11 @@ template <class T> class Engine final : public EngineBase {
             MHIP_HIP(hipMemcpyAsync(pos_snap.p, pos[cur].p, (size_t)n_tot * sizeof(T4), hipMemcpyDeviceToDevice, stream));
             inner_valid = false; prune_disp_exceeded = false;
         }
+        if (lazy_single) {
+            pos_snap_in.reserve(cap);
+            MHIP_HIP(hipMemcpyAsync(pos_snap_in.p, pos[cur].p, (size_t)n_tot * sizeof(T4), hipMemcpyDeviceToDevice, stream));
+            last_prune_step = step_n;
+        }
         stale = false; last_build_step = step_n; ++n_rebuilds;
         last_rebuild_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
@@ -452,23 +463,35 @@ template <class T> class Engine final : public EngineBase {
         MHIP_HIP(hipGetLastError());
     }
 
+    // max |x − x_snap|² over all local atoms (one small kernel + one host sync)
+    float max_disp2_since(const DBuf<T4>& snap) {
+        MHIP_HIP(hipMemsetAsync(flags.p + FLAG_MAX_DISP2, 0, sizeof(int32_t), stream));
+        hipLaunchKernelGGL(k_max_disp<T>, dim3(std::min(cdiv(n_tot, 256), 1024)), dim3(256), 0, stream, n_tot, (const T4*)pos[cur].p, (const T4*)snap.p,
+                           reinterpret_cast<unsigned int*>(flags.p + FLAG_MAX_DISP2), G);
+        MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        MHIP_HIP(hipStreamSynchronize(stream));
+        float d2; std::memcpy(&d2, &h_flags[FLAG_MAX_DISP2], sizeof(float));
+        ++n_disp_checks;
+        return d2;
+    }
+
     // rebuild step of the cadence (find_neighbors at step_n % n_steps == 0): a fresh search, or — with the dual list —
     // a filter pass, falling back to the search when it is due or an atom moved more than half the margin
     void refresh(int64_t step_n) {
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
+        if (!dual && lazy_single && !stale && step_n > last_prune_step) {
+            // single list built with r_list at step last_prune_step: it still holds every pair within the cutoffs unless somebody moved skin/2
+            const double d = std::sqrt((double)max_disp2_since(pos_snap_in)), checks = std::max<int64_t>(1, (step_n - last_prune_step) / every);
+            if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] step %lld: max disp %.5f nm since the build of step %lld (skin %.3f)\n", (long long)step_n, d, (long long)last_prune_step, skin);
+            if (2.0 * d * (checks + 1.0) / checks <= skin * 0.98) { last_build_step = step_n; ++n_skipped; return; }
+        }
         if (!dual || stale || (n_ghost == 0 && ((step_n - last_outer_step) >= (int64_t)outer_every * every || step_n < last_outer_step))) { rebuild(step_n); return; }
         // The inner list (pairs within r_list when it was pruned) provably contains every pair within the cutoffs as long as no atom
         // moved more than skin/2 since then — the condition the reference's fixed cadence only assumes.  Check it; re-prune (inside
         // the next force pass) only when it is about to fail.  mhip_export_neighbors always returns the exact list of NOW.
         bool reprune = strict_cadence || !inner_valid;
         if (!reprune) {
-            MHIP_HIP(hipMemsetAsync(flags.p + FLAG_MAX_DISP2, 0, sizeof(int32_t), stream));
-            hipLaunchKernelGGL(k_max_disp<T>, dim3(std::min(cdiv(n_tot, 256), 1024)), dim3(256), 0, stream, n_tot, (const T4*)pos[cur].p, (const T4*)pos_snap_in.p,
-                               reinterpret_cast<unsigned int*>(flags.p + FLAG_MAX_DISP2), G);
-            MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-            MHIP_HIP(hipStreamSynchronize(stream));
-            float d2; std::memcpy(&d2, &h_flags[FLAG_MAX_DISP2], sizeof(float));
-            ++n_disp_checks;
+            const float d2 = max_disp2_since(pos_snap_in);
             // headroom for the drift until the next check: the displacement so far, extrapolated one more interval
             const double d = std::sqrt((double)d2), checks = std::max<int64_t>(1, (step_n - last_prune_step) / every);
             reprune = 2.0 * d * (checks + 1.0) / checks > skin * 0.98;
@@ -485,7 +508,7 @@ template <class T> class Engine final : public EngineBase {
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         // If that keeps happening before the outer list has paid for itself (fast light atoms, small time step), the dual list
         // is a loss: fall back to a fresh search at every rebuild step.
-        if (step_n - last_outer_step <= 2 * (int64_t)every) { if (++early_outer >= 3) { dual_disabled = true; setup_grid(); choose_blocking(); stale = true; } }
+        if (step_n - last_outer_step <= 2 * (int64_t)every) { if (++early_outer >= 3) { if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] dual list off (outer list outrun 3x)\n"); dual_disabled = true; setup_grid(); choose_blocking(); stale = true; } }
         else early_outer = 0;
         rebuild(step_n);
     }
@@ -912,6 +935,7 @@ template <class T> class Engine final : public EngineBase {
 
     int64_t export_neighbors(int32_t* oi, int32_t* oj, uint8_t* osp, int64_t capacity) override {
         if (stale) throw ApiError{MHIP_ERR_STATE, "no neighbour list: call forces / rebuild first"};
+        if (lazy_single && last_build_step != last_prune_step) { flush_cm(); rebuild(last_build_step); }   // skipped rebuilds: hand out the list of NOW
         const int32_t *x_tidx = tile_idx.p, *x_tcnt = tile_cnt.p, *x_rows = wave_rows.p; const uint2* x_nbr = nbr.p;
         if (dual) {
             // the reference's list at the current coordinates = the outer list filtered with the exact predicate; valid as long as

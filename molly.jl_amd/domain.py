@@ -418,7 +418,7 @@ def bench_distributed(m, case, dtype, dt, args, rank, local_rank, world):
     tdtype = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
     grid = choose_grid(world, case.box)
     gm = float(os.environ.get("MOLLYHIP_GHOST_MARGIN_PM", "200")) * 1e-3
-    brick_min = min(b / g for b, g in zip(case.box, grid) if g > 1)
+    brick_min = min([b / g for b, g in zip(case.box, grid) if g > 1], default=math.inf)
     if case.r_list + gm > brick_min:
         gm = 0.0                                            # bricks too thin for a margin: re-plan at every rebuild step
     bg = BrickGrid(case.box, grid, rank, case.r_list + gm)
