@@ -30,10 +30,10 @@ def make_case(workload):
         return S.lj_fluid(100, seed=4, dtype=np.float32), np.float32, 0.002
     if workload == "lj256k":
         return S.lj_fluid(64, seed=2, dtype=np.float32), np.float32, 0.002
-    if workload in ("6mrr_pme", "6mrr_rf64"):
+    if workload in ("6mrr_pme", "6mrr_direct", "6mrr_rf64"):
         from tests import golden6mrr
-        dtype = np.float32 if workload == "6mrr_pme" else np.float64
-        return golden6mrr.case("ewald" if workload == "6mrr_pme" else "rf", dtype=dtype, bonded=True), dtype, 0.0005
+        dtype = np.float64 if workload == "6mrr_rf64" else np.float32
+        return golden6mrr.case("rf" if workload == "6mrr_rf64" else "ewald", dtype=dtype, bonded=True, pme=(workload == "6mrr_pme")), dtype, 0.0005
     raise SystemExit(f"unknown workload {workload}")
 
 
@@ -47,19 +47,20 @@ def cpu_baseline(case, dtype, dt, budget_s=20.0):
     o = case.oracle(dtype)
     o.native = True
     specific = case.bonds is not None
+    general = case.pme is not None
     t0 = time.perf_counter()
-    o.vv_run(1, dt, nthreads=nthreads, specific=specific)   # one step incl. the initial neighbour build + force pass
+    o.vv_run(1, dt, nthreads=nthreads, specific=specific, general=general)   # one step incl. the initial neighbour build + force pass
     t1 = time.perf_counter() - t0
     # steady-state sample: as many steps as fit the budget, at least one rebuild interval if affordable
     n = int(max(2, min(20, budget_s / max(t1 / 2.0, 1e-3))))
     t0 = time.perf_counter()
-    o.vv_run(n, dt, first_step=1, nthreads=nthreads, specific=specific)
+    o.vv_run(n, dt, first_step=1, nthreads=nthreads, specific=specific, general=general)
     t = time.perf_counter() - t0
     steps_s = n / t
     return {"value": steps_s * dt * 1e3 * 86400 * 1e-6, "unit": "ns/day", "cores": nthreads, "kind": "port",
             "matom_steps_per_s": steps_s * case.n / 1e6,
             "sample": f"{n} velocity-Verlet steps of the full {case.n}-atom system (threaded pair loop of src/force.jl:886-969 + "
-                      f"cell-list rebuild every {case.rebuild_every} steps), {nthreads} threads, -O3 -march=native"}
+                      f"cell-list rebuild every {case.rebuild_every} steps" + (", serial PME reciprocal space" if general else "") + f"), {nthreads} threads, -O3 -march=native"}
 
 
 def load_traffic(workload):
@@ -138,7 +139,9 @@ def main():
                 "stage_ms_per_step": {"forces": force_ms, "build_kernel": st["prof_ms"][1] / max(args.profile_steps, 1),
                                       "list_filter": st["prof_ms"][4] / max(args.profile_steps, 1),
                                       "integrator": st["prof_ms"][2] / max(args.profile_steps, 1),
-                                      "sort_permute": st["prof_ms"][3] / max(args.profile_steps, 1)},
+                                      "sort_permute": st["prof_ms"][3] / max(args.profile_steps, 1),
+                                      "bonded": st["prof_ms"][5] / max(args.profile_steps, 1),
+                                      "pme_reciprocal": st["prof_ms"][6] / max(args.profile_steps, 1)},
                 "stage_ms_per_call": {"build_kernel": st["prof_ms"][1] / max(st["prof_calls"][1], 1), "list_filter": st["prof_ms"][4] / max(st["prof_calls"][4], 1)}}
     line = {
         "metric": "ns_per_day", "value": ns_day, "unit": "ns/day", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -147,7 +150,8 @@ def main():
         "matom_steps_per_s": steps_s * n_atoms / 1e6,
         "config": {"workload": {"lj1m": "1M-atom LJ fluid (argon, rho=21.1/nm3), cubic PBC, DistanceCutoff 1.0 nm, r_list 1.2 nm, dt 2 fs, VelocityVerlet, remove_CM_motion=1",
                                 "lj256k": "256k-atom LJ fluid, DistanceCutoff 1.0 nm, cell-list neighbours, Float32",
-                                "6mrr_pme": "6mrr (15954 atoms) Amber99SB-ILDN/TIP3P, LJ + Ewald direct-space (PME reciprocal not in the timed path) + bonded + EwaldExclusion, Float32, dt 0.5 fs",
+                                "6mrr_pme": "6mrr (15954 atoms) Amber99SB-ILDN/TIP3P, LJ + Ewald direct space + PME reciprocal space (order 5, mesh 46x46x51, every step) + bonded + EwaldExclusion, Float32, dt 0.5 fs",
+                                "6mrr_direct": "6mrr (15954 atoms) Amber99SB-ILDN/TIP3P, LJ + Ewald direct space only (no reciprocal PME) + bonded + EwaldExclusion, Float32, dt 0.5 fs",
                                 "6mrr_rf64": "6mrr reaction-field Coulomb + LJ + bonded, Float64, dt 0.5 fs"}[args.workload],
                    "name": args.workload, "n_atoms": n_atoms, "dt_fs": dt * 1e3, "rebuild_every": case.rebuild_every,
                    "parallelism": "single domain" if world == 1 else extra.get("parallelism"),

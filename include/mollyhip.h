@@ -11,6 +11,8 @@
  *   mhip_potential_energy     ≙ Molly.pairwise_pe_loop_gpu!       ext/MollyCUDAExt.jl:936, src/kernels.jl:393,
  *                                                                  caller src/energy.jl:427
  *   mhip_specific_potential_energy ≙ specific_pe_gpu!             src/kernels.jl:430-567, caller src/energy.jl:431
+ *   mhip_general_forces / mhip_general_potential_energy ≙ AtomsCalculators.forces! / potential_energy of the PME general
+ *                               interaction, src/interactions/ewald.jl:873-944, callers src/force.jl:792-795, src/energy.jl:239-245
  *   mhip_kinetic_energy       ≙ kinetic_energy                    src/energy.jl:56-89
  *   mhip_remove_cm            ≙ Molly.remove_CM_motion!           ext/MollyCUDAExt.jl:2373, src/spatial.jl:901-929
  *   mhip_vv_run               ≙ simulate!(sys, ::VelocityVerlet)  src/simulators.jl:547-668 (loop 589-666)
@@ -126,9 +128,9 @@ typedef struct mhip_stats {
     int64_t force_pass_bytes;      /* N(R_p+3w)+4L: algorithmic bytes of ONE force-kernel launch   */
     /* HIP-event timings, filled while profiling is on (mhip_set_profiling):                        */
     /* stage 0 pair-force kernel, 1 tile/list build kernel (outer search), 2 integrator kernels,    */
-    /* 3 sort+permute, 4 list filter (inner list of the dual pair list), 5 bonded kernels           */
-    double  prof_ms[6];
-    int64_t prof_calls[6];
+    /* 3 sort+permute, 4 force passes that prune the outer list, 5 bonded kernels, 6 PME reciprocal */
+    double  prof_ms[8];
+    int64_t prof_calls[8];
     int64_t n_outer_builds;        /* searches with the outer radius (dual pair list)             */
     int64_t n_filter_passes;
 } mhip_stats;
@@ -185,6 +187,18 @@ int32_t mhip_forces(mhip_ctx* ctx, int64_t step_n, int32_t accumulate, void* f_x
 int32_t mhip_specific_forces(mhip_ctx* ctx, int32_t accumulate, void* f_xyz, int32_t mem_kind);
 int32_t mhip_potential_energy(mhip_ctx* ctx, int64_t step_n, double* pe_out);
 int32_t mhip_specific_potential_energy(mhip_ctx* ctx, double* pe_out);
+/* ---- general interaction: particle-mesh Ewald, reciprocal space ------------
+ * ≙ PME(dist_cutoff, atoms, boundary; error_tol, order, ϵr) (ewald.jl:361-421).  The caller passes what that constructor
+ * derives: B-spline `order` (4, 5 or 6; 0 switches PME off), mesh = pme_params.(box_sides, α, error_tol) (ewald.jl:479-482),
+ * α = sqrt(-log(2 error_tol)) / dist_cutoff, ϵr; the Coulomb constant is inter.coul_ke.  Charges are the ones of mhip_set_atoms.
+ * Once set, mhip_vv_run / vv_stage2 add the reciprocal-space forces after the specific interactions (force.jl:792-795).
+ * Pairs with coul_kind = MHIP_COUL_EWALD_DIRECT (direct space) and mhip_set_ewald_exclusions (excluded-pair correction).
+ * Single domain, fully periodic box only (MHIP_ERR_UNSUPPORTED otherwise). */
+int32_t mhip_set_pme(mhip_ctx* ctx, int32_t order, const int32_t* mesh3, double alpha, double eps_r);
+/* reciprocal-space forces, added to (accumulate != 0) or written into f_xyz   (ewald_pe_forces!, ewald.jl:873-916) */
+int32_t mhip_general_forces(mhip_ctx* ctx, int32_t accumulate, void* f_xyz, int32_t mem_kind);
+/* E_recip + E_self + E_net-charge                                           (ewald.jl:898-928) */
+int32_t mhip_general_potential_energy(mhip_ctx* ctx, double* pe_out);
 int32_t mhip_kinetic_energy(mhip_ctx* ctx, double* ke_out);
 int32_t mhip_remove_cm(mhip_ctx* ctx);
 int32_t mhip_check_finite(mhip_ctx* ctx);          /* check_nans, simulators.jl:98-111 */

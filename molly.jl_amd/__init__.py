@@ -8,7 +8,7 @@ from .api import (  # noqa: F401
     Atom, BOLTZMANN, COULOMB_CONST, CellListMapNeighborFinder, Coulomb, CoulombEwald, CoulombReactionField,
     CubicBoundary, CubicSplineCutoff, DistanceCutoff, DistanceNeighborFinder, EwaldExclusions, GPUNeighborFinder,
     HarmonicAngles, HarmonicBonds, LennardJones, NeighborList, NoCutoff, NoNeighborFinder, PeriodicTorsions,
-    PolynomialCutoff, ShiftedForceCutoff, ShiftedPotentialCutoff, System, VelocityVerlet, find_neighbors, forces,
+    PME, PolynomialCutoff, ShiftedForceCutoff, ShiftedPotentialCutoff, System, VelocityVerlet, find_neighbors, forces,
     kinetic_energy, potential_energy, remove_CM_motion, simulate, temperature, total_energy, use_neighbors,
     wrap_coords,
 )

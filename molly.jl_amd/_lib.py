@@ -44,7 +44,7 @@ class Stats(C.Structure):
                 ("n_blocks", C.c_int64), ("tile_atoms_total", C.c_int64), ("block_atoms", C.c_int32),
                 ("j_split", C.c_int32), ("minimg_mode", C.c_int32), ("max_tile_atoms", C.c_int32),
                 ("last_rebuild_ms", C.c_double), ("lds_bytes", C.c_int64), ("algorithmic_bytes_step", C.c_int64),
-                ("force_pass_bytes", C.c_int64), ("prof_ms", C.c_double * 6), ("prof_calls", C.c_int64 * 6),
+                ("force_pass_bytes", C.c_int64), ("prof_ms", C.c_double * 8), ("prof_calls", C.c_int64 * 8),
                 ("n_outer_builds", C.c_int64), ("n_filter_passes", C.c_int64)]
 
     def as_dict(self):
@@ -93,6 +93,9 @@ SIGNATURES = {
     "mhip_shift_velocities": (_I32, [_P, C.POINTER(_D * 3)]),
     "mhip_cm_momentum_dev": (_I32, [_P, _P]),
     "mhip_remove_cm_dev": (_I32, [_P, _P]),
+    "mhip_set_pme": (_I32, [_P, _I32, _P, _D, _D]),
+    "mhip_general_forces": (_I32, [_P, _I32, _P, _I32]),
+    "mhip_general_potential_energy": (_I32, [_P, C.POINTER(_D)]),
     "mhip_set_ghost_margin": (_I32, [_P, _D]),
     "mhip_plan_disp2_dev": (_I32, [_P, _P]),
     "mhip_vv_halo_begin": (_I32, [_P, _D, _P, _P, _I64, _P]),

@@ -117,6 +117,21 @@ def use_neighbors(inter):
     return inter.use_neighbors
 
 
+class PME:
+    """PME(dist_cutoff, atoms, boundary; error_tol=0.0005, order=5, ϵr=1.0): reciprocal-space part of the particle-mesh Ewald
+    sum, a general interaction (ewald.jl:361-421).  α and the mesh are derived as the reference does (:368-369, :479-482)."""
+
+    def __init__(self, dist_cutoff, atoms=None, boundary=None, error_tol=0.0005, order=5, ϵr=1.0, dtype=np.float64):
+        if boundary is None:
+            raise ValueError("PME needs the boundary")
+        T = np.dtype(dtype).type
+        self.dist_cutoff, self.error_tol, self.order, self.ϵr = float(dist_cutoff), float(error_tol), int(order), float(ϵr)
+        self.α = float((T(1) / T(dist_cutoff)) * np.sqrt(-np.log(T(2) * T(error_tol))))
+        sides = boundary.side_lengths if isinstance(boundary, CubicBoundary) else tuple(boundary)
+        tol = T(error_tol)
+        self.mesh_dims = tuple(max(int(np.ceil(T(2) * T(self.α) * T(L) / (T(3) * tol ** T(0.2)))), 6) for L in sides)   # pme_params
+
+
 # ---- specific interaction lists (SoA form of InteractionList{2,3,4}Atoms, types.jl:236-420) ---------
 @dataclass
 class HarmonicBonds:
@@ -230,7 +245,7 @@ class System:
 
     def __init__(self, atoms=None, coords=None, boundary=None, velocities=None, pairwise_inters=(),
                  specific_inter_lists=(), neighbor_finder=None, dtype=np.float32, device_id=0,
-                 charge=None, sigma=None, eps=None, mass=None):
+                 charge=None, sigma=None, eps=None, mass=None, general_inters=()):
         self.dtype = np.dtype(dtype)
         if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
             raise ValueError("dtype must be float32 or float64")
@@ -255,6 +270,7 @@ class System:
         self.boundary = boundary if isinstance(boundary, CubicBoundary) else CubicBoundary(boundary)
         self.pairwise_inters = tuple(pairwise_inters)
         self.specific_inter_lists = tuple(specific_inter_lists)
+        self.general_inters = tuple(general_inters)
         self.neighbor_finder = neighbor_finder if neighbor_finder is not None else NoNeighborFinder()
         self.device_id = device_id
         self.total_mass = float(self.masses.sum(dtype=np.float64))
@@ -363,6 +379,12 @@ class System:
                 self._check(L.mhip_set_ewald_exclusions(self._ctx, len(a[0]), *map(self._ptr, a)))
             else:
                 raise MollyHipError(-6, f"specific interaction list {type(sil).__name__} is outside the hot-path scope")
+        for gi in self.general_inters:
+            if isinstance(gi, PME):
+                mesh = (C.c_int32 * 3)(*gi.mesh_dims)
+                self._check(L.mhip_set_pme(self._ctx, gi.order, mesh, gi.α, gi.ϵr))
+            else:
+                raise MollyHipError(-6, f"general interaction {type(gi).__name__} is outside the hot-path scope")
 
     def push_state(self, velocities=True):
         L = _lib.lib()
@@ -391,8 +413,8 @@ class System:
 
 
 # ---- free functions mirroring Molly's exports ---------------------------------------------------------
-def forces(sys, step_n=0, pairwise=True, specific=True):
-    """forces(sys; …): pairwise + specific interaction forces, (n,3) array (force.jl:670-720)."""
+def forces(sys, step_n=0, pairwise=True, specific=True, general=True):
+    """forces(sys; …): pairwise + specific + general interaction forces, (n,3) array (force.jl:670-720, 792-795)."""
     L = _lib.lib()
     sys.push_state(velocities=False)
     out = np.zeros((len(sys), 3), sys.dtype)
@@ -400,10 +422,12 @@ def forces(sys, step_n=0, pairwise=True, specific=True):
         sys._check(L.mhip_forces(sys._ctx, step_n, 1, sys._ptr(out), None, _lib.MEM_HOST))
     if specific and sys.specific_inter_lists:
         sys._check(L.mhip_specific_forces(sys._ctx, 1, sys._ptr(out), _lib.MEM_HOST))
+    if general and sys.general_inters:
+        sys._check(L.mhip_general_forces(sys._ctx, 1, sys._ptr(out), _lib.MEM_HOST))
     return out
 
 
-def potential_energy(sys, step_n=0, pairwise=True, specific=True):
+def potential_energy(sys, step_n=0, pairwise=True, specific=True, general=True):
     """potential_energy(sys; …) (energy.jl:207-248, 409-446)."""
     L = _lib.lib()
     sys.push_state(velocities=False)
@@ -414,6 +438,9 @@ def potential_energy(sys, step_n=0, pairwise=True, specific=True):
         total += pe.value
     if specific and sys.specific_inter_lists:
         sys._check(L.mhip_specific_potential_energy(sys._ctx, C.byref(pe)))
+        total += pe.value
+    if general and sys.general_inters:
+        sys._check(L.mhip_general_potential_energy(sys._ctx, C.byref(pe)))
         total += pe.value
     return total
 

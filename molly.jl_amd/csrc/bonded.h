@@ -4,6 +4,7 @@
 // Behavioural spec: harmonic_bond.jl:44-54, harmonic_angle.jl:46-67, periodic_torsion.jl:93-142,
 // spatial.jl:834-894, ewald.jl:1019-1055.
 #pragma once
+#include <cstdlib>
 #include <vector>
 
 #include "physics.h"
@@ -194,6 +195,20 @@ template <class T> struct Bonded {
     void launch_forces(hipStream_t s, const GridP<T>& G, const InterP<T>& I, const T4* pos, const int32_t* inv, T4* frc) {
         int nb = n_blocks();
         if (!nb) return;
+        static const bool split = [] { const char* v = std::getenv("MOLLYHIP_BONDED_SPLIT"); return v && *v && std::atoi(v) != 0; }();
+        if (split) {   // timing experiments: one launch per interaction type (blocks of the other types see empty lists)
+            for (int k = 0; k < 4; ++k) {
+                BondedArgs<T> A = args(G, I, pos, inv, frc, nullptr);
+                if (k != 0) { A.n_b = 0; A.blk_b = 0; }
+                if (k != 1) { A.n_a = 0; A.blk_a = 0; }
+                if (k != 2) { A.n_t = 0; A.blk_t = 0; }
+                if (k != 3) A.n_x = 0;
+                const int g = k == 0 ? A.blk_b : k == 1 ? A.blk_a : k == 2 ? A.blk_t : cdiv(A.n_x, (int64_t)BT);
+                if (g > 0) hipLaunchKernelGGL((k_bonded<T, false>), dim3(g), dim3(BT), 0, s, A);
+            }
+            MHIP_HIP(hipGetLastError());
+            return;
+        }
         hipLaunchKernelGGL((k_bonded<T, false>), dim3(nb), dim3(BT), 0, s, args(G, I, pos, inv, frc, nullptr));
         MHIP_HIP(hipGetLastError());
     }

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "bonded.h"
+#include "pme.h"
 #include "hilbert.h"
 #include "kernels.h"
 #include "sortscan.h"
@@ -61,6 +62,9 @@ struct EngineBase {
     virtual void shift_velocities(const double*) = 0;
     virtual void cm_momentum_dev(double*) = 0;
     virtual void remove_cm_dev(const double*) = 0;
+    virtual void set_pme(int32_t, const int32_t*, double, double) = 0;
+    virtual void general_forces(int, void*, int) = 0;
+    virtual double general_potential_energy() = 0;
     virtual void set_ghost_margin(double) = 0;
     virtual void plan_disp2_dev(float*) = 0;
     virtual void halo_begin(double, const int32_t*, const void*, int64_t, void*) = 0;
@@ -69,7 +73,7 @@ struct EngineBase {
 
 // hipEvent stage timers (only active while profiling is on)
 struct Prof {
-    static constexpr int NS = 6;
+    static constexpr int NS = 8;
     bool on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[NS];
     size_t used[NS] = {};
@@ -88,7 +92,7 @@ struct Prof {
     void resolve(hipStream_t s) {
         MHIP_HIP(hipStreamSynchronize(s));
         for (int st = 0; st < NS; ++st) {
-            for (size_t k = 0; k < used[st]; ++k) { float t = 0; MHIP_HIP(hipEventElapsedTime(&t, ev[st][k].first, ev[st][k].second)); ms[st] += t; ++calls[st]; }
+            for (size_t k = 0; k < used[st]; ++k) { float t = 0; MHIP_HIP(hipEventSynchronize(ev[st][k].second)); MHIP_HIP(hipEventElapsedTime(&t, ev[st][k].first, ev[st][k].second)); ms[st] += t; ++calls[st]; }
             used[st] = 0;
         }
     }
@@ -144,6 +148,12 @@ template <class T> class Engine final : public EngineBase {
     DBuf<T> stage_a, stage_b; DBuf<int32_t> stage_i;
     // bonded
     Bonded<T> bonded;
+    // general interaction: PME reciprocal space (ewald.jl:361-929)
+    Pme<T> pme; double pc_sum = 0, pc_abs2_sum = 0;
+    // bonded terms and PME run on side streams while the pair kernel runs on the main one; their forces land in frc_side[] and
+    // are folded in by the second kick
+    hipStream_t side[2] = {nullptr, nullptr}; hipEvent_t ev_pos = nullptr, ev_side[2] = {nullptr, nullptr};
+    DBuf<T4> frc_side[2]; const T4* pend_a = nullptr; const T4* pend_b = nullptr; bool overlap = true;
 
     int cm_pending = 0; bool stale = true, minimg = false, params_set = false, state_set = false, frc_valid = false;
     int64_t last_build_step = std::numeric_limits<int64_t>::min();
@@ -162,6 +172,9 @@ template <class T> class Engine final : public EngineBase {
         if (device < 0 || device >= ndev) throw ApiError{MHIP_ERR_INVALID, "device_id out of range"};
         MHIP_HIP(hipSetDevice(device));
         MHIP_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); own_stream = true;
+        overlap = env_int("MOLLYHIP_OVERLAP", 0) != 0;   // measured on MI355X (6mrr): side streams gain nothing, the small kernels do not co-run profitably
+        for (int k = 0; k < 2; ++k) { MHIP_HIP(hipStreamCreateWithFlags(&side[k], hipStreamNonBlocking)); MHIP_HIP(hipEventCreateWithFlags(&ev_side[k], hipEventDisableTiming)); }
+        MHIP_HIP(hipEventCreateWithFlags(&ev_pos, hipEventDisableTiming));
         setup_inter(); setup_grid();
         for (int k = 0; k < 2; ++k) { pos[k].reserve(cap); vel[k].reserve(cap); frc[k].reserve(cap); lj[k].reserve(cap); orig[k].reserve(cap); }
         inv.reserve(cap); key_in.reserve(cap); key_out.reserve(cap); idx_in.reserve(cap); perm.reserve(cap);
@@ -186,8 +199,10 @@ template <class T> class Engine final : public EngineBase {
         pos_snap_in.release();
         wave_rows_in.release(); nbr_in.release(); pos_snap.release(); blk_disp2.release(); tile_idx_in.release(); tile_cnt_in.release(); rows_x.release(); nbr_x.release();
         xl_start.release(); xl_list.release(); tile_idx.release(); tile_cnt.release(); wave_rows.release(); nbr.release(); blk_center.release();
-        flags.release(); red_part.release(); red_out.release(); cm_step.release(); vcm.release(); stage_a.release(); stage_b.release(); stage_i.release(); bonded.release();
+        flags.release(); red_part.release(); red_out.release(); cm_step.release(); vcm.release(); stage_a.release(); stage_b.release(); stage_i.release(); bonded.release(); pme.release();
         prof.release();
+        for (int k = 0; k < 2; ++k) { if (side[k]) { (void)hipStreamSynchronize(side[k]); (void)hipStreamDestroy(side[k]); } if (ev_side[k]) (void)hipEventDestroy(ev_side[k]); frc_side[k].release(); }
+        if (ev_pos) (void)hipEventDestroy(ev_pos);
         if (h_flags) (void)hipHostFree(h_flags);
         if (h_red) (void)hipHostFree(h_red);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -622,15 +637,52 @@ template <class T> class Engine final : public EngineBase {
         MHIP_HIP(hipGetLastError());
     }
 
-    // all forces of one MD step into frc[cur]: pairwise kernel overwrites, bonded kernels add
+    // all forces of one MD step: the pair kernel overwrites frc[cur] on the main stream while the bonded terms and the PME
+    // reciprocal part — independent, latency-bound chains of small kernels — run next to it on the side streams into
+    // frc_side[]; the consumer (second kick, or fold_side_forces) adds them
     void step_forces(int64_t step_n) {
+        const bool side_b = overlap && bonded.any(), side_p = overlap && pme.on();
+        if (side_p && n_ghost > 0) throw ApiError{MHIP_ERR_UNSUPPORTED, "PME runs on a single domain (SURVEY §8(e): 6mrr-size systems are replicas only)"};
+        if (side_b || side_p) MHIP_HIP(hipEventRecord(ev_pos, stream));
+        for (int k = 0; k < 2; ++k) {
+            if (!(k == 0 ? side_b : side_p)) continue;
+            frc_side[k].reserve(cap);
+            MHIP_HIP(hipStreamWaitEvent(side[k], ev_pos, 0));
+            MHIP_HIP(hipMemsetAsync(frc_side[k].p, 0, (size_t)n_owned * sizeof(T4), side[k]));
+            prof.begin(k == 0 ? 5 : 6, side[k]);
+            if (k == 0) bonded.launch_forces(side[k], G, I, pos[cur].p, inv.p, frc_side[k].p);
+            else pme.run(side[k], n_owned, pos[cur].p, frc_side[k].p, nullptr);
+            prof.end(k == 0 ? 5 : 6, side[k]);
+            MHIP_HIP(hipEventRecord(ev_side[k], side[k]));
+        }
         launch_pair_kernel(false);
+        bool redo = false;
         if (prune_disp_exceeded) {   // the outer list could not vouch for this pass: search again and redo it on the fresh list
+            for (int k = 0; k < 2; ++k) if (k == 0 ? side_b : side_p) MHIP_HIP(hipStreamWaitEvent(stream, ev_side[k], 0));   // they read the old order
             after_forces(step_n);
             launch_pair_kernel(false);
+            redo = true;
         }
-        bonded.launch_forces(stream, G, I, pos[cur].p, inv.p, frc[cur].p);
+        pend_a = pend_b = nullptr;
+        if (redo || !side_b) { if (bonded.any()) { prof.begin(5, stream); bonded.launch_forces(stream, G, I, pos[cur].p, inv.p, frc[cur].p); prof.end(5, stream); } }
+        else { MHIP_HIP(hipStreamWaitEvent(stream, ev_side[0], 0)); pend_a = frc_side[0].p; }
+        if (redo || !side_p) launch_pme_forces();
+        else { MHIP_HIP(hipStreamWaitEvent(stream, ev_side[1], 0)); pend_b = frc_side[1].p; }
         frc_valid = true;
+    }
+    // frc[cur] += the side-stream contributions, for consumers other than the second kick
+    void fold_side_forces() {
+        if (!pend_a && !pend_b) return;
+        hipLaunchKernelGGL(k_add_forces<T>, dim3(std::min(cdiv(n_owned, 256), 1024)), dim3(256), 0, stream, n_owned, frc[cur].p, pend_a, pend_b);
+        pend_a = pend_b = nullptr;
+    }
+
+    void launch_pme_forces() {
+        if (!pme.on()) return;
+        if (n_ghost > 0) throw ApiError{MHIP_ERR_UNSUPPORTED, "PME runs on a single domain (SURVEY §8(e): 6mrr-size systems are replicas only)"};
+        prof.begin(6, stream);
+        pme.run(stream, n_owned, pos[cur].p, frc[cur].p, nullptr);
+        prof.end(6, stream);
     }
 
   public:
@@ -682,6 +734,12 @@ template <class T> class Engine final : public EngineBase {
                 I.lj_s2 = sm * sm; I.lj_24e = T(24) * em; I.lj_4e = T(4) * em;
                 ljm = LJ_DIST_UNIFORM;
             }
+        }
+        pc_sum = 0; pc_abs2_sum = 0;
+        if (dq) {   // Σq and Σq² of the PME self / net-charge terms (ewald.jl:917-924)
+            std::vector<T> hq(n_owned);
+            MHIP_HIP(hipMemcpy(hq.data(), dq, n_owned * sizeof(T), hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < n_owned; ++i) { pc_sum += (double)hq[i]; pc_abs2_sum += (double)hq[i] * (double)hq[i]; }
         }
         s3.release(); s4.release(); s5.release();
         params_set = true; frc_valid = false;
@@ -784,6 +842,30 @@ template <class T> class Engine final : public EngineBase {
         return read_sum(n_part);
     }
 
+    void set_pme(int32_t order, const int32_t* mesh, double alpha, double eps_r) override {
+        MHIP_HIP(hipStreamSynchronize(stream));
+        int32_t none[3] = {0, 0, 0};
+        pme.setup(order, order ? mesh : none, alpha, cfg.inter.coul_ke, eps_r, cfg.box, cfg.periodic);
+        frc_valid = false;
+    }
+    // ≙ AtomsCalculators.forces! of the general interaction (force.jl:792-795): forces added to / written into f_xyz
+    void general_forces(int accumulate, void* f_xyz, int mem_kind) override {
+        if (!state_set) throw ApiError{MHIP_ERR_STATE, "set_state must be called before general_forces"};
+        MHIP_HIP(hipMemsetAsync(frc[cur].p, 0, (size_t)n_tot * sizeof(T4), stream));
+        launch_pme_forces();
+        frc_valid = false;
+        export_frc(accumulate, f_xyz, mem_kind);
+    }
+    double general_potential_energy() override {
+        if (!state_set) throw ApiError{MHIP_ERR_STATE, "set_state must be called before general_potential_energy"};
+        if (!pme.on()) return 0.0;
+        if (n_ghost > 0) throw ApiError{MHIP_ERR_UNSUPPORTED, "PME runs on a single domain"};
+        const int nb = pme.dft_blocks(0);
+        red_part.reserve(nb);
+        pme.run(stream, n_owned, pos[cur].p, (T4*)nullptr, red_part.p);
+        return 0.5 * read_sum(nb) + pme.self_factor * pc_abs2_sum + pme.charge_factor * pc_sum * pc_sum;   // ewald.jl:917-928
+    }
+
     double kinetic_energy() override {
         flush_cm();
         int nb = cdiv(n_owned, 256);
@@ -848,6 +930,7 @@ template <class T> class Engine final : public EngineBase {
         if (!state_set) throw ApiError{MHIP_ERR_STATE, "set_state must be called before vv_run"};
         rebuild(first_step);
         step_forces(first_step);
+        fold_side_forces();
     }
     void vv_stage1(double dt) override {
         if (!frc_valid) throw ApiError{MHIP_ERR_STATE, "vv_stage1 needs forces from vv_init / vv_stage2"};
@@ -862,12 +945,13 @@ template <class T> class Engine final : public EngineBase {
         const int nb = std::min(cdiv(n_owned, 256), 1024);
         prof.begin(2, stream);
         if (cm) {
-            hipLaunchKernelGGL((k_vv2<T, true>), dim3(nb), dim3(256), 0, stream, n_owned, vel[cur].p, (const T4*)frc[cur].p, T(dt) / T(2), cm_step.p);
+            hipLaunchKernelGGL((k_vv2<T, true>), dim3(nb), dim3(256), 0, stream, n_owned, vel[cur].p, frc[cur].p, T(dt) / T(2), cm_step.p, pend_a, pend_b);
             cm_pending = 2; n_cm_step = nb;   // the next k_vv1 (or any flush) re-sums the partials: no finalize launch
         } else {
-            hipLaunchKernelGGL((k_vv2<T, false>), dim3(nb), dim3(256), 0, stream, n_owned, vel[cur].p, (const T4*)frc[cur].p, T(dt) / T(2), (double*)nullptr);
+            hipLaunchKernelGGL((k_vv2<T, false>), dim3(nb), dim3(256), 0, stream, n_owned, vel[cur].p, frc[cur].p, T(dt) / T(2), (double*)nullptr, pend_a, pend_b);
         }
         prof.end(2, stream);
+        pend_a = pend_b = nullptr;    // the kick wrote the total back into frc[cur]
     }
     // the neighbour cadence of a stepwise-driven run: as in vv_run.  A ghosted sub-domain without the dual list is re-planned
     // (set_atom_counts / set_state → stale) by the host at every rebuild step instead.
@@ -1117,6 +1201,11 @@ int32_t mhip_cm_momentum(mhip_ctx* ctx, double* out4) { NEED_CTX(); return guard
 int32_t mhip_shift_velocities(mhip_ctx* ctx, const double* dv3) { NEED_CTX(); return guard(ctx, [&] { ctx->e->shift_velocities(dv3); }); }
 int32_t mhip_cm_momentum_dev(mhip_ctx* ctx, double* out4) { NEED_CTX(); return guard(ctx, [&] { ctx->e->cm_momentum_dev(out4); }); }
 int32_t mhip_remove_cm_dev(mhip_ctx* ctx, const double* t4) { NEED_CTX(); return guard(ctx, [&] { ctx->e->remove_cm_dev(t4); }); }
+int32_t mhip_set_pme(mhip_ctx* ctx, int32_t order, const int32_t* mesh, double alpha, double eps_r) {
+    NEED_CTX(); return guard(ctx, [&] { if (order != 0 && !mesh) throw mhip::ApiError{MHIP_ERR_INVALID, "null mesh"}; ctx->e->set_pme(order, mesh, alpha, eps_r); });
+}
+int32_t mhip_general_forces(mhip_ctx* ctx, int32_t acc, void* f, int32_t mk) { NEED_CTX(); return guard(ctx, [&] { if (!f) throw mhip::ApiError{MHIP_ERR_INVALID, "null force buffer"}; ctx->e->general_forces(acc, f, mk); }); }
+int32_t mhip_general_potential_energy(mhip_ctx* ctx, double* pe) { NEED_CTX(); return guard(ctx, [&] { *pe = ctx->e->general_potential_energy(); }); }
 int32_t mhip_set_ghost_margin(mhip_ctx* ctx, double m) { NEED_CTX(); return guard(ctx, [&] { ctx->e->set_ghost_margin(m); }); }
 int32_t mhip_plan_disp2_dev(mhip_ctx* ctx, float* out) { NEED_CTX(); return guard(ctx, [&] { if (!out) throw mhip::ApiError{MHIP_ERR_INVALID, "null output"}; ctx->e->plan_disp2_dev(out); }); }
 int32_t mhip_vv_halo_begin(mhip_ctx* ctx, double dt, const int32_t* idx, const void* shift, int64_t n, void* out) { NEED_CTX(); return guard(ctx, [&] { ctx->e->halo_begin(dt, idx, shift, n, out); }); }

@@ -975,11 +975,17 @@ __global__ void k_vv1(int64_t n, typename Vec<T>::T4* pos, typename Vec<T>::T4* 
     }
 }
 
+// fa / fb (nullable): force contributions computed concurrently on the side streams (bonded terms, PME reciprocal space); they are
+// folded in here and the total is written back so that the next first kick sees it
 template <class T, bool CM>
-__global__ void k_vv2(int64_t n, typename Vec<T>::T4* vel, const typename Vec<T>::T4* __restrict__ frc, T dt2, double* cm_part) {
+__global__ void k_vv2(int64_t n, typename Vec<T>::T4* vel, typename Vec<T>::T4* frc, T dt2, double* cm_part,
+                      const typename Vec<T>::T4* __restrict__ fa, const typename Vec<T>::T4* __restrict__ fb) {
     double px = 0, py = 0, pz = 0, m = 0;
     for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
         auto v = vel[s]; auto f = frc[s];
+        if (fa) { const auto g = fa[s]; f.x += g.x; f.y += g.y; f.z += g.z; }
+        if (fb) { const auto g = fb[s]; f.x += g.x; f.y += g.y; f.z += g.z; }
+        if (fa || fb) frc[s] = f;
         T im = (v.w == T(0)) ? T(0) : T(1) / v.w;
         v.x += (f.x * im) * dt2; v.y += (f.y * im) * dt2; v.z += (f.z * im) * dt2;   // :616
         vel[s] = v;
@@ -993,6 +999,17 @@ __global__ void k_vv2(int64_t n, typename Vec<T>::T4* vel, const typename Vec<T>
         if ((threadIdx.x & 63) == 0) { sh[w][0] = px; sh[w][1] = py; sh[w][2] = pz; sh[w][3] = m; }
         __syncthreads();
         if (threadIdx.x < 4) { double a = 0; for (int q = 0; q < (int)(blockDim.x >> 6); ++q) a += sh[q][threadIdx.x]; cm_part[4 * (int64_t)blockIdx.x + threadIdx.x] = a; }
+    }
+}
+
+// frc += fa (+ fb): the same fold outside the integrator
+template <class T>
+__global__ void k_add_forces(int64_t n, typename Vec<T>::T4* frc, const typename Vec<T>::T4* __restrict__ fa, const typename Vec<T>::T4* __restrict__ fb) {
+    for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
+        auto f = frc[s];
+        if (fa) { const auto g = fa[s]; f.x += g.x; f.y += g.y; f.z += g.z; }
+        if (fb) { const auto g = fb[s]; f.x += g.x; f.y += g.y; f.z += g.z; }
+        frc[s] = f;
     }
 }
 

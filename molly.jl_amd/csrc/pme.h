@@ -1,0 +1,415 @@
+// pme.h — smooth particle-mesh Ewald, reciprocal-space term, single domain, CubicBoundary.
+// Behavioural spec: src/interactions/ewald.jl — pme_bspline_moduli :311-358, grid_placement_inner! :484-493,
+// update_bsplines_inner! :518-556, spread_charge_inner! :598-621, recip_conv_inner! :676-725,
+// interpolate_force_inner! :805-840, ewald_pe_forces! :873-929.
+//
+// gfx950 design.  The reference's meshes are whatever pme_params (:479-482) yields — 46×46×51 for 6mrr, factors 23 and 17 —
+// and are tiny (≈10⁵ points, < 1 MB: L2-resident), so the transform is latency-, not bandwidth- or flop-bound.  Instead of a
+// library FFT (Bluestein chains of many small launches for such sizes) the three axis transforms are direct DFTs on
+// LDS-staged line tiles: any n, one launch per axis, and the x pass does forward-x · influence function · backward-x in
+// one kernel, so a whole reciprocal evaluation is 7 launches:
+//   spread (float atomics into one real mesh per XCD, 32 lanes per atom) → z (sums the copies) → y → x·conv·x⁻¹ → y⁻¹ → z⁻¹
+//   → gather (32 lanes per atom).
+// Grid layout: complex<T> at ((x·ny + y)·nz + z), z fastest (the reference's charge_grid[z, y, x]).
+#pragma once
+#include <vector>
+
+#include "physics.h"
+
+namespace mhip {
+
+template <class T> struct PmeP {
+    int n[3];
+    T invL[3], n_over_L[3];
+    T f_div_er, factor, pi_V;        // ke/ϵr, π²/α², π·V
+    int debug;                       // MOLLYHIP_PME_DEBUG: timing experiments only
+};
+
+// update_bsplines_inner! (:518-556) for one fractional offset: θ and dθ/du of the ORDER B-spline weights
+template <class T, int ORDER> __device__ inline void pme_bspline(T dr, T* b, T* db) {
+#pragma unroll
+    for (int k = 0; k < ORDER; ++k) b[k] = T(0);
+    b[1] = dr; b[0] = T(1) - dr;
+#pragma unroll
+    for (int k = 3; k <= ORDER - 1; ++k) {
+        const T dv = T(1) / T(k - 1);
+        b[k - 1] = dv * dr * b[k - 2];
+#pragma unroll
+        for (int l = 1; l <= k - 2; ++l) b[k - l - 1] = dv * ((dr + T(l)) * b[k - l - 2] + (T(k - l) - dr) * b[k - l - 1]);
+        b[0] *= dv * (T(1) - dr);
+    }
+    db[0] = -b[0];
+#pragma unroll
+    for (int k = 1; k <= ORDER - 1; ++k) db[k] = b[k - 1] - b[k];
+    const T dv = T(1) / T(ORDER - 1);
+    b[ORDER - 1] = dv * dr * b[ORDER - 2];
+#pragma unroll
+    for (int l = 1; l <= ORDER - 2; ++l) b[ORDER - l - 1] = dv * ((dr + T(l)) * b[ORDER - l - 2] + (T(ORDER - l) - dr) * b[ORDER - l - 1]);
+    b[0] *= dv * (T(1) - dr);
+}
+// grid_placement_inner! (:484-493): first mesh index and fractional offset along one axis
+template <class T> __device__ inline void pme_place(T c, T invL, int n, int& idx, T& dr) {
+    T t = c * invL;
+    t = (t - M<T>::floor(t)) * T(n);
+    const int ti = (int)M<T>::floor(t);
+    dr = t - T(ti);
+    idx = ti % n;
+}
+template <class T, int ORDER> __device__ inline T pick(const T* a, int i) {   // a[i] of a register array, no scratch
+    T v = a[0];
+#pragma unroll
+    for (int k = 1; k < ORDER; ++k) v = (k == i) ? a[k] : v;
+    return v;
+}
+
+// XCD the calling wave runs on (0..7): HW_REG_XCC_ID, bits 3:0
+__device__ inline int xcc_id() { return (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 7u); }
+constexpr int PME_COPIES = 8;
+constexpr int PME_AB = 64;       // atoms per block and round of the spread / gather kernels
+
+// Phase 1 of spread and gather: ONE lane per atom evaluates grid_placement_inner! and update_bsplines_inner! (the recursion is
+// serial and identical for every mesh point of the atom) and parks first index, charge and the 3·ORDER weights (and
+// derivatives) in LDS, [value][atom] so that both the writes (lanes = atoms) and the later reads are conflict-free.
+template <class T, int ORDER, bool DERIV>
+__device__ inline void pme_atom_tables(int64_t a0, int64_t n_atoms, const typename Vec<T>::T4* __restrict__ pos, const PmeP<T>& P, T* l_w, int* l_i, T* l_q) {
+    const int t = threadIdx.x;
+    if (t < PME_AB) {
+        const int64_t a = a0 + t;
+        T q = T(0); int i0[3] = {0, 0, 0};
+        T th[ORDER], dth[ORDER], dr;
+        if (a < n_atoms) {
+            const auto p = pos[a];
+            q = p.w;
+            const T c[3] = {p.x, p.y, p.z};
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                pme_place<T>(c[d], P.invL[d], P.n[d], i0[d], dr);
+                pme_bspline<T, ORDER>(dr, th, dth);
+#pragma unroll
+                for (int k = 0; k < ORDER; ++k) { l_w[((d * ORDER + k) * (DERIV ? 2 : 1)) * PME_AB + t] = th[k]; if constexpr (DERIV) l_w[((d * ORDER + k) * 2 + 1) * PME_AB + t] = dth[k]; }
+            }
+        }
+        l_q[t] = q; l_i[t] = i0[0]; l_i[PME_AB + t] = i0[1]; l_i[2 * PME_AB + t] = i0[2];
+    }
+}
+
+// spread_charge_inner! (:598-621).  Phase 2: a 32-lane half-wave per atom, lane ↔ (iy, iz), loop over ix: the ORDER² lanes of an
+// atom touch ORDER rows of ORDER contiguous z points per instruction (few cache lines).
+// Float atomics resolve in the L2 of the XCD that issues them; each XCD accumulates into its OWN real mesh (selected by the
+// hardware XCC id, so correctness does not depend on how workgroups are dealt out) and the first transform pass sums the copies.
+template <class T, int ORDER>
+__global__ void __launch_bounds__(256) k_pme_spread(int64_t n_atoms, const typename Vec<T>::T4* __restrict__ pos, T* rgrid, PmeP<T> P) {
+    __shared__ T l_w[3 * ORDER * PME_AB]; __shared__ int l_i[3 * PME_AB]; __shared__ T l_q[PME_AB];
+    const int tid = threadIdx.x, sub = tid & 31, hw = tid >> 5;
+    T* mesh = rgrid + (int64_t)xcc_id() * P.n[0] * P.n[1] * P.n[2];
+    for (int64_t a0 = (int64_t)blockIdx.x * PME_AB; a0 < n_atoms; a0 += (int64_t)gridDim.x * PME_AB) {
+        __syncthreads();
+        pme_atom_tables<T, ORDER, false>(a0, n_atoms, pos, P, l_w, l_i, l_q);
+        __syncthreads();
+        for (int t = hw; t < PME_AB; t += 8) {
+            const T q = l_q[t];
+            if (q == T(0)) continue;                                   // also the atoms past the end
+            const int i0x = l_i[t], i0y = l_i[PME_AB + t], i0z = l_i[2 * PME_AB + t];
+            for (int pr = sub; pr < ORDER * ORDER; pr += 32) {
+                const int iy = pr / ORDER, iz = pr - iy * ORDER;
+                int yi = i0y + iy; yi -= yi >= P.n[1] ? P.n[1] : 0;
+                int zi = i0z + iz; zi -= zi >= P.n[2] ? P.n[2] : 0;
+                const T qyz = (q * l_w[(ORDER + iy) * PME_AB + t]) * l_w[(2 * ORDER + iz) * PME_AB + t];
+                T* col = mesh + (int64_t)yi * P.n[2] + zi;
+#pragma unroll
+                for (int ix = 0; ix < ORDER; ++ix) {
+                    int xi = i0x + ix; xi -= xi >= P.n[0] ? P.n[0] : 0;
+                    atomicAdd(col + (int64_t)xi * P.n[1] * P.n[2], l_w[ix * PME_AB + t] * qyz);
+                }
+            }
+        }
+    }
+}
+
+// interpolate_force_inner! (:805-840): Fs[i] -= q (∂θ/∂r ⊗ θ ⊗ θ) · φ, same two phases, shuffle reduction inside the half-wave
+template <class T, int ORDER>
+__global__ void __launch_bounds__(256) k_pme_gather(int64_t n_atoms, const typename Vec<T>::T4* __restrict__ pos, const typename Vec<T>::T2* __restrict__ grid,
+                                                    typename Vec<T>::T4* frc, PmeP<T> P) {
+    __shared__ T l_w[6 * ORDER * PME_AB]; __shared__ int l_i[3 * PME_AB]; __shared__ T l_q[PME_AB];
+    const int tid = threadIdx.x, sub = tid & 31, hw = tid >> 5;
+    for (int64_t a0 = (int64_t)blockIdx.x * PME_AB; a0 < n_atoms; a0 += (int64_t)gridDim.x * PME_AB) {
+        __syncthreads();
+        pme_atom_tables<T, ORDER, true>(a0, n_atoms, pos, P, l_w, l_i, l_q);
+        __syncthreads();
+        for (int t = hw; t < PME_AB; t += 8) {                          // both halves of a wave run all 8 rounds (shuffles)
+            const T q = l_q[t];
+            const int i0x = l_i[t], i0y = l_i[PME_AB + t], i0z = l_i[2 * PME_AB + t];
+            T fx = T(0), fy = T(0), fz = T(0);
+            if (q != T(0)) {
+                for (int pr = sub; pr < ORDER * ORDER; pr += 32) {
+                    const int iy = pr / ORDER, iz = pr - iy * ORDER;
+                    int yi = i0y + iy; yi -= yi >= P.n[1] ? P.n[1] : 0;
+                    int zi = i0z + iz; zi -= zi >= P.n[2] ? P.n[2] : 0;
+                    const T ty = l_w[((ORDER + iy) * 2) * PME_AB + t], dty = l_w[((ORDER + iy) * 2 + 1) * PME_AB + t];
+                    const T tz = l_w[((2 * ORDER + iz) * 2) * PME_AB + t], dtz = l_w[((2 * ORDER + iz) * 2 + 1) * PME_AB + t];
+                    const T tyz = ty * tz, dty_tz = dty * tz, ty_dtz = ty * dtz;
+                    const auto* col = grid + (int64_t)yi * P.n[2] + zi;
+                    T g[ORDER];
+#pragma unroll
+                    for (int ix = 0; ix < ORDER; ++ix) {
+                        int xi = i0x + ix; xi -= xi >= P.n[0] ? P.n[0] : 0;
+                        g[ix] = (P.debug & 1) ? T(1) : col[(int64_t)xi * P.n[1] * P.n[2]].x;
+                    }
+#pragma unroll
+                    for (int ix = 0; ix < ORDER; ++ix) {
+                        const T tx = l_w[(ix * 2) * PME_AB + t], dtx = l_w[(ix * 2 + 1) * PME_AB + t];
+                        fx += dtx * tyz * g[ix]; fy += tx * dty_tz * g[ix]; fz += tx * ty_dtz * g[ix];
+                    }
+                }
+            }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) { fx += __shfl_xor(fx, o, 64); fy += __shfl_xor(fy, o, 64); fz += __shfl_xor(fz, o, 64); }   // stays inside the 32-lane half
+            if (sub == 0 && q != T(0)) {
+                auto f = frc[a0 + t];
+                f.x -= q * (fx * P.n_over_L[0]); f.y -= q * (fy * P.n_over_L[1]); f.z -= q * (fz * P.n_over_L[2]);
+                frc[a0 + t] = f;
+            }
+        }
+    }
+}
+
+// One axis of the 3-D transform as a direct DFT: a block stages C = 256/n whole lines in LDS ([j][c], c = line within the
+// tile) and every thread owns ONE output (k, c), so a pass is ~n·n_lines/64 short, independent waves — enough of them to hide
+// the LDS latency of the n-term sums.
+//   axis 2 (z): lines are contiguous, line q starts at q·nz            (q = x·ny + y)
+//   axis 1 (y): line q = x·nz + z starts at x·ny·nz + z, stride nz
+//   axis 0 (x): line q = y·nz + z starts at q, stride ny·nz
+// MODE 0: plain complex pass.  MODE 1 (axis 2, forward): the input is the sum of the PME_COPIES real charge meshes.
+// MODE 2 (axis 0): forward transform, multiply by the influence function of recip_conv_inner! (:676-725), transform back —
+// the other two inverse passes follow as plain launches with sign +1.
+constexpr int PME_THREADS = 256;
+
+template <class T> struct DftArgs {
+    typename Vec<T>::T2* grid;
+    const T* rgrid;                       // MODE 1: [PME_COPIES][nx·ny·nz] real charge meshes
+    const typename Vec<T>::T2* tw;        // [n] e^{-2πi m/n} of this axis
+    const T* mh[3];                       // [n_d] signed frequency / L_d
+    const T* bsm[3];                      // [n_d] B-spline moduli
+    double* e_part;                       // MODE 2 && ENERGY: per-block Σ eterm·|S|²
+    PmeP<T> P;
+    int axis, sign, C;                    // sign −1: forward (plan_fft!), +1: backward (plan_bfft!), both unnormalised
+};
+
+template <class T, int MODE, bool ENERGY>
+__global__ void __launch_bounds__(PME_THREADS) k_pme_dft(DftArgs<T> A) {
+    using T2 = typename Vec<T>::T2;
+    extern __shared__ __align__(16) unsigned char pme_smem[];
+    const int n = A.P.n[A.axis], nx = A.P.n[0], ny = A.P.n[1], nz = A.P.n[2], C = A.C;
+    T2* l_tw = reinterpret_cast<T2*>(pme_smem);
+    T2* l_a = l_tw + n;
+    [[maybe_unused]] T2* l_b = l_a + n * C;
+    const int tid = threadIdx.x;
+    const int64_t n_mesh = (int64_t)nx * ny * nz, n_lines = n_mesh / n, q0 = (int64_t)blockIdx.x * C;
+    const int n_here = (int)min((int64_t)C, n_lines - q0);
+    const int64_t stride = A.axis == 2 ? 1 : (A.axis == 1 ? nz : (int64_t)ny * nz);
+    auto line_base = [&](int64_t q) -> int64_t {
+        if (A.axis == 2) return q * nz;
+        if (A.axis == 1) { const int64_t x = q / nz; return x * ny * nz + (q - x * nz); }
+        return q;
+    };
+    for (int m = tid; m < n; m += PME_THREADS) { T2 w = A.tw[m]; if (A.sign > 0 && MODE != 2) w.y = -w.y; l_tw[m] = w; }
+    for (int e = tid; e < n * C; e += PME_THREADS) {
+        int j, c;
+        if (A.axis == 2) { c = e / n; j = e - c * n; } else { j = e / C; c = e - j * C; }
+        T2 v; v.x = T(0); v.y = T(0);
+        if (c < n_here) {
+            const int64_t at = line_base(q0 + c) + j * stride;
+            if constexpr (MODE == 1) {
+#pragma unroll
+                for (int k = 0; k < PME_COPIES; ++k) v.x += A.rgrid[k * n_mesh + at];
+            } else v = A.grid[at];
+        }
+        l_a[j * C + c] = v;
+    }
+    __syncthreads();
+    // output (k, c) = Σ_j src[j][c] · w^(jk); four terms in flight per iteration
+    auto dft_one = [&](const T2* src, bool conj, int k, int c, T& re, T& im) {
+        T r0 = T(0), i0 = T(0), r1 = T(0), i1 = T(0);
+        const T sg = conj ? T(-1) : T(1);
+        int m = 0, j = 0;
+        for (; j + 1 < n; j += 2) {
+            const T2 v0 = src[j * C + c], w0 = l_tw[m];
+            m += k; m -= m >= n ? n : 0;
+            const T2 v1 = src[(j + 1) * C + c], w1 = l_tw[m];
+            m += k; m -= m >= n ? n : 0;
+            const T w0y = w0.y * sg, w1y = w1.y * sg;
+            r0 += v0.x * w0.x - v0.y * w0y; i0 += v0.x * w0y + v0.y * w0.x;
+            r1 += v1.x * w1.x - v1.y * w1y; i1 += v1.x * w1y + v1.y * w1.x;
+        }
+        if (j < n) {
+            const T2 v0 = src[j * C + c], w0 = l_tw[m];
+            const T w0y = w0.y * sg;
+            r0 += v0.x * w0.x - v0.y * w0y; i0 += v0.x * w0y + v0.y * w0.x;
+        }
+        re = r0 + r1; im = i0 + i1;
+    };
+    [[maybe_unused]] double e_loc = 0;
+    for (int o = tid; o < n * C; o += PME_THREADS) {       // one round unless n > 256
+        const int c = o / n, k = o - c * n;
+        T re, im;
+        dft_one(l_a, false, k, c, re, im);
+        if constexpr (MODE != 2) {
+            if (c < n_here) { T2 v; v.x = re; v.y = im; A.grid[line_base(q0 + c) + k * stride] = v; }
+        } else {
+            T2 v; v.x = T(0); v.y = T(0);
+            if (c < n_here) {
+                const int kx = k; const int64_t q = q0 + c; const int ky = (int)(q / nz), kz = (int)(q - (int64_t)ky * nz);
+                if (kx | ky | kz) {
+                    const T mhx = A.mh[0][kx], mhy = A.mh[1][ky], mhz = A.mh[2][kz];
+                    const T m2 = mhx * mhx + mhy * mhy + mhz * mhz;
+                    const T denom = m2 * (A.P.pi_V * A.bsm[0][kx]) * A.bsm[1][ky] * A.bsm[2][kz];
+                    const T eterm = A.P.f_div_er * M<T>::exp(-A.P.factor * m2) / denom;
+                    if constexpr (ENERGY) e_loc += (double)(eterm * (re * re + im * im));
+                    v.x = re * eterm; v.y = im * eterm;
+                }
+                // k = 0: the reference leaves the DC term of the charge grid untouched (:681-683); it only adds a constant to the
+                // potential mesh, which the B-spline derivative weights (Σ dθ = 0) remove from every force — zero it instead
+            }
+            l_b[k * C + c] = v;
+        }
+    }
+    if constexpr (MODE == 2) {
+        __syncthreads();
+        for (int o = tid; o < n * C; o += PME_THREADS) {
+            const int c = o / n, k = o - c * n;
+            T re, im;
+            dft_one(l_b, true, k, c, re, im);
+            if (c < n_here) { T2 v; v.x = re; v.y = im; A.grid[line_base(q0 + c) + k * stride] = v; }
+        }
+        if constexpr (ENERGY) {
+            __shared__ double sh_e[PME_THREADS / 64];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) e_loc += __shfl_xor(e_loc, o, 64);
+            if ((tid & 63) == 0) sh_e[tid >> 6] = e_loc;
+            __syncthreads();
+            if (tid == 0) { double s = 0; for (int w = 0; w < PME_THREADS / 64; ++w) s += sh_e[w]; A.e_part[blockIdx.x] = s; }
+        }
+    }
+}
+
+template <class U> struct PBuf {
+    U* p = nullptr; size_t n = 0;
+    void set(const std::vector<U>& h) { release(); n = h.size(); if (n) { MHIP_HIP(hipMalloc((void**)&p, n * sizeof(U))); MHIP_HIP(hipMemcpy(p, h.data(), n * sizeof(U), hipMemcpyHostToDevice)); } }
+    void alloc(size_t m) { release(); n = m; if (n) MHIP_HIP(hipMalloc((void**)&p, n * sizeof(U))); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+template <class T> struct Pme {
+    using T4 = typename Vec<T>::T4;
+    using T2 = typename Vec<T>::T2;
+    int order = 0;
+    PmeP<T> P;
+    PBuf<T2> grid, tw[3];
+    PBuf<T> mh[3], bsm[3], rgrid;      // rgrid: PME_COPIES real charge meshes, one per XCD
+    double self_factor = 0, charge_factor = 0;   // E_self = −f/ϵr·α/√π·Σq²  and  E_charge = −f/ϵr·π/(2Vα²)·(Σq)²   (:917-927)
+
+    bool on() const { return order > 0; }
+    void release() { grid.release(); rgrid.release(); for (int d = 0; d < 3; ++d) { tw[d].release(); mh[d].release(); bsm[d].release(); } order = 0; }
+
+    // pme_bspline_moduli (:311-358), in T like the reference
+    static void moduli(int ord, const int* n, std::vector<T>* out) {
+        const int nmax = std::max(n[0], std::max(n[1], n[2]));
+        std::vector<T> data(ord, T(0)), bd(nmax + ord + 1, T(0));
+        data[0] = T(1);
+        for (int k = 3; k <= ord - 1; ++k) {
+            T d = T(1) / (T(k) - T(1));
+            data[k - 1] = T(0);
+            for (int l = 1; l <= k - 2; ++l) data[k - l - 1] = d * (T(l) * data[k - l - 2] + T(k - l) * data[k - l - 1]);
+            data[0] *= d;
+        }
+        T d = T(1) / (T(ord) - T(1));
+        data[ord - 1] = T(0);
+        for (int l = 1; l <= ord - 2; ++l) data[ord - l - 1] = d * (T(l) * data[ord - l - 2] + T(ord - l) * data[ord - l - 1]);
+        data[0] *= d;
+        for (int i = 1; i <= ord; ++i) bd[i] = data[i - 1];
+        for (int dd = 0; dd < 3; ++dd) {
+            const int nd = n[dd];
+            out[dd].assign(nd, T(0));
+            for (int i = 1; i <= nd; ++i) {
+                T sc = T(0), ss = T(0);
+                for (int j = 1; j <= nd; ++j) { T arg = T(2) * T(M_PI) * T(i - 1) * T(j - 1) / T(nd); sc += bd[j - 1] * std::cos(arg); ss += bd[j - 1] * std::sin(arg); }
+                out[dd][i - 1] = sc * sc + ss * ss;
+            }
+            for (int i = 1; i <= nd; ++i) if (out[dd][i - 1] < T(1e-7)) out[dd][i - 1] = (out[dd][(i - 2 + nd) % nd] + out[dd][i % nd]) / T(2);
+        }
+    }
+
+    void setup(int ord, const int32_t* mesh, double alpha, double ke, double eps_r, const double* box, const int* periodic) {
+        release();
+        if (ord == 0) return;
+        if (ord != 4 && ord != 5 && ord != 6) throw ApiError{MHIP_ERR_UNSUPPORTED, "PME B-spline order must be 4, 5 or 6"};
+        if (!(alpha > 0) || !(eps_r > 0)) throw ApiError{MHIP_ERR_INVALID, "PME needs alpha > 0 and eps_r > 0"};
+        for (int d = 0; d < 3; ++d) {
+            if (!periodic[d]) throw ApiError{MHIP_ERR_UNSUPPORTED, "PME needs a fully periodic box"};
+            if (mesh[d] < ord || mesh[d] > 4096) throw ApiError{MHIP_ERR_INVALID, "PME mesh size out of range (order .. 4096 per axis)"};
+        }
+        if ((int64_t)mesh[0] * mesh[1] * mesh[2] > ((int64_t)1 << 28)) throw ApiError{MHIP_ERR_CAPACITY, "PME mesh too large"};
+        order = ord;
+        const T a = T(alpha);
+        T V = T(1);
+        for (int d = 0; d < 3; ++d) { P.n[d] = mesh[d]; P.invL[d] = T(1) / T(box[d]); P.n_over_L[d] = T(mesh[d]) * (T(1) / T(box[d])); V *= T(box[d]); }
+        { const char* v = std::getenv("MOLLYHIP_PME_DEBUG"); P.debug = v && *v ? std::atoi(v) : 0; }
+        P.f_div_er = T(ke) / T(eps_r); P.factor = T(M_PI) * T(M_PI) / (a * a); P.pi_V = T(M_PI) * V;
+        self_factor = -(double)P.f_div_er * (double)a / std::sqrt(M_PI);
+        charge_factor = -(double)P.f_div_er * M_PI / (2.0 * (double)V * (double)a * (double)a);
+        std::vector<T> bm[3];
+        moduli(ord, P.n, bm);
+        for (int d = 0; d < 3; ++d) {
+            const int nd = P.n[d];
+            std::vector<T2> w(nd); std::vector<T> m(nd);
+            const T maxk = T(0.5) * T(nd + 1);
+            for (int k = 0; k < nd; ++k) {
+                const double ang = -2.0 * M_PI * k / nd;
+                w[k].x = (T)std::cos(ang); w[k].y = (T)std::sin(ang);
+                m[k] = (T(k) < maxk ? T(k) : T(k - nd)) * P.invL[d];
+            }
+            tw[d].set(w); mh[d].set(m); bsm[d].set(bm[d]);
+        }
+        grid.alloc((size_t)P.n[0] * P.n[1] * P.n[2]);
+        rgrid.alloc((size_t)PME_COPIES * P.n[0] * P.n[1] * P.n[2]);
+    }
+
+    int lines_per_block(int axis) const { return std::max(1, PME_THREADS / P.n[axis]); }
+    DftArgs<T> dft_args(int axis, int sign, double* e_part) const {
+        DftArgs<T> A;
+        A.grid = grid.p; A.rgrid = rgrid.p; A.tw = tw[axis].p; for (int d = 0; d < 3; ++d) { A.mh[d] = mh[d].p; A.bsm[d] = bsm[d].p; }
+        A.e_part = e_part; A.P = P; A.axis = axis; A.sign = sign; A.C = lines_per_block(axis);
+        return A;
+    }
+    int dft_blocks(int axis) const { return (int)cdiv((int64_t)P.n[0] * P.n[1] * P.n[2] / P.n[axis], (int64_t)lines_per_block(axis)); }
+    size_t dft_lds(int axis, bool conv) const { return (size_t)P.n[axis] * sizeof(T2) * (1 + lines_per_block(axis) * (conv ? 2 : 1)); }
+
+    // PME_AB atoms per 256-thread block and round; at most 2048 blocks (each then loops over its atom batches)
+    static unsigned atom_blocks(int64_t n) { return (unsigned)std::min<int64_t>(cdiv(n, (int64_t)PME_AB), 2048); }
+    template <int ORDER> void spread_t(hipStream_t s, int64_t n, const T4* pos) { hipLaunchKernelGGL((k_pme_spread<T, ORDER>), dim3(atom_blocks(n)), dim3(256), 0, s, n, pos, rgrid.p, P); }
+    template <int ORDER> void gather_t(hipStream_t s, int64_t n, const T4* pos, T4* frc) { hipLaunchKernelGGL((k_pme_gather<T, ORDER>), dim3(atom_blocks(n)), dim3(256), 0, s, n, pos, (const T2*)grid.p, frc, P); }
+    template <int MODE, bool EN> void dft(hipStream_t s, int axis, int sign, double* e_part) {
+        auto kern = k_pme_dft<T, MODE, EN>;
+        const size_t lds = dft_lds(axis, MODE == 2);
+        if (lds > 64 * 1024) MHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(dft_blocks(axis)), dim3(PME_THREADS), lds, s, dft_args(axis, sign, e_part));
+    }
+
+    // ewald_pe_forces! (:873-929) on the sorted arrays: frc (nullable) gets the reciprocal-space forces ADDED; e_part (nullable)
+    // receives dft_blocks(0) partial sums of Σ eterm·|S|² (the caller halves them and adds the self terms).
+    void run(hipStream_t s, int64_t n_atoms, const T4* pos, T4* frc, double* e_part) {
+        MHIP_HIP(hipMemsetAsync(rgrid.p, 0, rgrid.n * sizeof(T), s));
+        if (order == 4) spread_t<4>(s, n_atoms, pos); else if (order == 5) spread_t<5>(s, n_atoms, pos); else spread_t<6>(s, n_atoms, pos);
+        dft<1, false>(s, 2, -1, nullptr);
+        dft<0, false>(s, 1, -1, nullptr);
+        if (e_part) dft<2, true>(s, 0, -1, e_part); else dft<2, false>(s, 0, -1, nullptr);
+        if (frc) {
+            dft<0, false>(s, 1, +1, nullptr);
+            dft<0, false>(s, 2, +1, nullptr);
+            if (order == 4) gather_t<4>(s, n_atoms, pos, frc); else if (order == 5) gather_t<5>(s, n_atoms, pos, frc); else gather_t<6>(s, n_atoms, pos, frc);
+        }
+        MHIP_HIP(hipGetLastError());
+    }
+};
+
+}  // namespace mhip

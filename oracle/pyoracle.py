@@ -51,7 +51,8 @@ class OrcSystem(C.Structure):
                 ("a_kth", C.c_void_p), ("a_th0", C.c_void_p),
                 ("n_tors", C.c_int64), ("t_i", C.c_void_p), ("t_j", C.c_void_p), ("t_k", C.c_void_p), ("t_l", C.c_void_p),
                 ("t_per", C.c_void_p), ("t_phase", C.c_void_p), ("t_k0", C.c_void_p),
-                ("n_ewx", C.c_int64), ("x_i", C.c_void_p), ("x_j", C.c_void_p)]
+                ("n_ewx", C.c_int64), ("x_i", C.c_void_p), ("x_j", C.c_void_p),
+                ("pme_order", C.c_int32), ("pme_mesh", C.c_int32 * 3), ("pme_eps_r", C.c_double)]
 
 
 def build(native=False, quiet=True):
@@ -67,7 +68,8 @@ _libs = {}
 def lib(native=False):
     if native not in _libs:
         path = os.path.join(_HERE, "_native", "liboracle_native.so") if native else os.path.join(_HERE, "liboracle.so")
-        if native or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(os.path.join(_HERE, "oracle.cpp")):
+        src_time = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("oracle.cpp", "pme.h"))
+        if native or not os.path.exists(path) or os.path.getmtime(path) < src_time:
             path = build(native)
         L = C.CDLL(path)
         L.orc_vector_1d.restype = C.c_double; L.orc_vector_1d.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double]
@@ -106,7 +108,7 @@ class OracleSystem:
 
     def __init__(self, coords, box, inter, dtype=np.float64, velocities=None, charge=None, sigma=None, eps=None,
                  mass=None, r_list=float("inf"), rebuild_every=10, excluded=None, special=None, bonds=None,
-                 angles=None, torsions=None, ewald_excl=None, native=False):
+                 angles=None, torsions=None, ewald_excl=None, native=False, pme=None):
         self.dtype = np.dtype(dtype)
         self.prec = 32 if self.dtype == np.float32 else 64
         T = self.dtype
@@ -159,6 +161,10 @@ class OracleSystem:
                  np.ascontiguousarray(torsions["phase"], dtype=T), np.ascontiguousarray(torsions["k0"], dtype=T)]
             self._keep += t
             s.n_tors = len(t[0]); s.t_i, s.t_j, s.t_k, s.t_l, s.t_per, s.t_phase, s.t_k0 = map(_ptr, t)
+        if pme is not None:   # general interaction PME: dict(order=5, mesh=(nx, ny, nz), eps_r=1.0); α and ke come from `inter`
+            s.pme_order = int(pme.get("order", 5)); s.pme_eps_r = float(pme.get("eps_r", 1.0))
+            for d in range(3):
+                s.pme_mesh[d] = int(pme["mesh"][d])
         self.s = s
 
     @property
@@ -173,9 +179,9 @@ class OracleSystem:
         assert n2 == n
         return i, j, sp
 
-    def forces(self, nl=None, nthreads=1, pairwise=True, specific=False):
+    def forces(self, nl=None, nthreads=1, pairwise=True, specific=False, general=False):
         out = np.zeros((self.n, 3), self.dtype)
-        mask = (1 if pairwise else 0) | (2 if specific else 0)
+        mask = (1 if pairwise else 0) | (2 if specific else 0) | (4 if general else 0)
         if nl is None:
             self.L.orc_forces(self.prec, C.byref(self.s), None, None, None, -1, nthreads, mask, _ptr(out))
         else:
@@ -183,8 +189,8 @@ class OracleSystem:
             self.L.orc_forces(self.prec, C.byref(self.s), _ptr(i), _ptr(j), _ptr(sp), len(i), nthreads, mask, _ptr(out))
         return out
 
-    def potential_energy(self, nl=None, pairwise=True, specific=False):
-        mask = (1 if pairwise else 0) | (2 if specific else 0)
+    def potential_energy(self, nl=None, pairwise=True, specific=False, general=False):
+        mask = (1 if pairwise else 0) | (2 if specific else 0) | (4 if general else 0)
         if nl is None:
             return self.L.orc_energy(self.prec, C.byref(self.s), None, None, None, -1, mask)
         i, j, sp = nl
@@ -199,8 +205,8 @@ class OracleSystem:
     def wrap(self):
         self.L.orc_wrap(self.prec, C.byref(self.s))
 
-    def vv_run(self, n_steps, dt, first_step=0, remove_cm_every=1, nthreads=1, pairwise=True, specific=False):
-        mask = (1 if pairwise else 0) | (2 if specific else 0)
+    def vv_run(self, n_steps, dt, first_step=0, remove_cm_every=1, nthreads=1, pairwise=True, specific=False, general=False):
+        mask = (1 if pairwise else 0) | (2 if specific else 0) | (4 if general else 0)
         self.L.orc_vv_run(self.prec, C.byref(self.s), first_step, n_steps, float(dt), remove_cm_every, nthreads, mask)
 
     def force_scale(self, nl=None, rel_band=2e-6):
@@ -214,6 +220,16 @@ class OracleSystem:
             i, j, sp = nl
             self.L.orc_force_scale(C.byref(self.s), _ptr(i), _ptr(j), _ptr(sp), len(i), rel_band, _ptr(scale), _ptr(jump))
         return scale, jump
+
+
+def pme_mesh(box, alpha, error_tol=0.0005):
+    """pme_params (ewald.jl:479-482): mesh points per axis, max(ceil(2 α L / (3 tol^0.2)), 6)"""
+    return tuple(max(int(np.ceil(2.0 * alpha * float(L) / (3.0 * error_tol ** 0.2))), 6) for L in box)
+
+
+def ewald_alpha(dist_cutoff, error_tol=0.0005):
+    """α = sqrt(−log(2 tol)) / r_c (ewald.jl:368, coulomb.jl:1332)"""
+    return float(np.sqrt(-np.log(2.0 * error_tol)) / dist_cutoff)
 
 
 def vector_1d(c1, c2, L, prec=64):

@@ -17,7 +17,7 @@ def data():
 
 
 def case(coulomb="rf", dtype=np.float64, bonded=True, lj=True, which_bonded=("bonds", "angles", "proper", "improper"), r_list=1.2,
-         approx_erfc=True, rebuild_every=10):
+         approx_erfc=True, rebuild_every=10, pme=False):
     """coulomb: None | "rf" (CoulombReactionField rc 1.0, ε 78.3 — OpenMM CutoffPeriodic) | "ewald" (CoulombEwald rc 1.0,
     tol 5e-4 + EwaldExclusion list), as setup.jl:1852-1913 wires them for nonbonded_method :cutoff / :pme."""
     d = data()
@@ -43,7 +43,8 @@ def case(coulomb="rf", dtype=np.float64, bonded=True, lj=True, which_bonded=("bo
             kw["ewald_excl"] = d["ewald_excl"]
     return S.Case(coords, box, lj=dict(cutoff=("distance", 1.0), weight_special=float(d["weight_14_lj"])) if lj else None, coul=coul,
                   r_list=r_list, rebuild_every=rebuild_every, velocities=r(d["velocities_300K"]), charge=r(d["charge"]), sigma=r(d["sigma"]),
-                  eps=r(d["eps"]), mass=r(d["mass"]), excluded=d["excluded"], special=d["special"], name="6mrr", **kw)
+                  eps=r(d["eps"]), mass=r(d["mass"]), excluded=d["excluded"], special=d["special"], name="6mrr",
+                  pme=dict(order=5, error_tol=5e-4, eps_r=1.0) if (pme and coulomb == "ewald") else None, **kw)
 
 
 def lj_dispersion_correction(d=None, rc=1.0):

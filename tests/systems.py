@@ -12,7 +12,7 @@ CUT = {"none": 0, "distance": 1, "shifted_potential": 2, "shifted_force": 3, "cu
 class Case:
     def __init__(self, coords, box, lj=None, coul=None, r_list=math.inf, rebuild_every=10, velocities=None, charge=None,
                  sigma=None, eps=None, mass=None, excluded=None, special=None, bonds=None, angles=None, torsions=None,
-                 ewald_excl=None, name="case"):
+                 ewald_excl=None, name="case", pme=None):
         """lj: None | dict(cutoff=(kind, rc[, ra]), weight_special=1.0)
         coul: None | dict(kind="plain"|"rf"|"ewald", cutoff=(kind, rc[, ra]) (plain), rc=…, eps_rf=78.3, tol=5e-4,
                           approx=True, weight_special=1.0)"""
@@ -26,6 +26,15 @@ class Case:
         self.excluded, self.special = excluded, special
         self.bonds, self.angles, self.torsions, self.ewald_excl = bonds, angles, torsions, ewald_excl
         self.name = name
+        self.pme = pme       # None | dict(order=5, error_tol=5e-4, eps_r=1.0[, mesh=(nx, ny, nz)]): general interaction PME (needs coul kind "ewald")
+
+    def pme_params(self, dtype):
+        """order, mesh, ϵr of the PME general interaction as Molly's constructor derives them (ewald.jl:361-372, 479-482)"""
+        if self.pme is None:
+            return None
+        alpha = self.inter_dict(dtype)["ewald_alpha"]
+        mesh = self.pme.get("mesh") or orc.pme_mesh(self.box, alpha, self.pme.get("error_tol", self.coul.get("tol", 5e-4)))
+        return dict(order=self.pme.get("order", 5), mesh=tuple(int(v) for v in mesh), eps_r=self.pme.get("eps_r", 1.0))
 
     # -- interaction dict for the oracle (field names of mhip_interactions) ---------------------------------
     def inter_dict(self, dtype):
@@ -60,7 +69,8 @@ class Case:
                                 velocities=self.velocities if velocities is None else velocities,
                                 charge=self.charge, sigma=self.sigma, eps=self.eps, mass=self.mass, r_list=self.r_list,
                                 rebuild_every=self.rebuild_every, excluded=self.excluded, special=self.special,
-                                bonds=self.bonds, angles=self.angles, torsions=self._tors(), ewald_excl=self.ewald_excl)
+                                bonds=self.bonds, angles=self.angles, torsions=self._tors(), ewald_excl=self.ewald_excl,
+                                pme=self.pme_params(dtype))
 
     def system(self, m, dtype=np.float32, coords=None, velocities=None):
         """Product System with the reference-style constructors (m = the molly_jl_amd module)."""
@@ -97,10 +107,15 @@ class Case:
             sils.append(m.EwaldExclusions(e[:, 0], e[:, 1]))
         nf = m.GPUNeighborFinder(dist_cutoff=self.r_list, excluded_pairs=self.excluded, special_pairs=self.special,
                                  n_steps=self.rebuild_every) if use_nl or self.excluded is not None or self.special is not None else None
+        gis = []
+        if self.pme is not None:
+            gis.append(m.PME(self.coul["rc"], boundary=m.CubicBoundary(*self.box), error_tol=self.pme.get("error_tol", self.coul.get("tol", 5e-4)),
+                             order=self.pme.get("order", 5), ϵr=self.pme.get("eps_r", 1.0), dtype=dtype))
+            gis[-1].mesh_dims = self.pme_params(dtype)["mesh"]      # the oracle and the product always see the same mesh
         return m.System(coords=self.coords if coords is None else coords, boundary=m.CubicBoundary(*self.box),
                         velocities=self.velocities if velocities is None else velocities, pairwise_inters=tuple(inters),
                         specific_inter_lists=tuple(sils), neighbor_finder=nf, dtype=dtype, charge=self.charge,
-                        sigma=self.sigma, eps=self.eps, mass=self.mass)
+                        sigma=self.sigma, eps=self.eps, mass=self.mass, general_inters=tuple(gis))
 
 
 # ---- SURVEY §8(d) synthetic LJ fluid (argon at 1400 kg/m³, benchmark/benchmark_gpu_tiles.jl:18-25) ------
@@ -128,7 +143,7 @@ def lj_fluid(n_side, seed=2, temperature=85.0, jitter=0.02, r_cut=1.0, r_list=1.
                 name=f"lj{n}")
 
 
-def charged_fluid(n_side, coul, seed=5, spacing=0.31, r_list=1.2, dtype=np.float32, with_exceptions=True, stable=False):
+def charged_fluid(n_side, coul, seed=5, spacing=0.31, r_list=1.2, dtype=np.float32, with_exceptions=True, stable=False, pme=None, box_scale=(1.0, 1.0, 1.0)):
     """A water-like-density mixed LJ + Coulomb fluid with per-atom σ, ϵ, q (two species + some LJ-less
     'hydrogens' with ϵ = 0) and random excluded / special pairs between close atoms.  The ϵ = 0 species exercises the
     LJZeroShortcut in force tests but, being free point charges, collapses onto opposite charges within a few dozen steps;
@@ -153,10 +168,11 @@ def charged_fluid(n_side, coul, seed=5, spacing=0.31, r_list=1.2, dtype=np.float
         special = np.stack([idx[idx % 3 == 1], idx[idx % 3 == 1] + 2], 1)
     v = rng.normal(size=(n, 3)) * 0.3
     v -= v.mean(axis=0)
-    return Case(x, float(dtype(box)), lj=dict(cutoff=("distance", 1.0), weight_special=0.5), coul=coul, r_list=r_list,
+    boxv = np.array([float(dtype(box * sc)) for sc in box_scale])     # box_scale > 1 stretches the box (orthorhombic cases), atoms stay put
+    return Case(x, boxv, lj=dict(cutoff=("distance", 1.0), weight_special=0.5), coul=coul, r_list=r_list,
                 velocities=v.astype(dtype).astype(np.float64), charge=q.astype(dtype).astype(np.float64),
                 sigma=sigma, eps=eps, mass=np.choose(kind, [15.999, 12.011, 1.008]), excluded=excluded, special=special,
-                name=f"charged{n}")
+                name=f"charged{n}", pme=pme)
 
 
 def sorted_pairs(i, j, sp):

@@ -1,0 +1,74 @@
+"""HIP PME reciprocal space (csrc/pme.h) against the oracle restatement and the OpenMM fixtures of the reference
+(test/protein.jl:208-299)."""
+import numpy as np
+import pytest
+
+from tests import golden6mrr as G
+from tests import systems as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype,order,box_scale,mesh", [(np.float64, 5, (1.0, 1.0, 1.0), None), (np.float64, 4, (1.0, 1.15, 1.3), (14, 17, 21)),
+                                                       (np.float64, 6, (1.0, 1.0, 1.0), (16, 12, 15)), (np.float32, 5, (1.0, 1.1, 1.0), None)])
+def test_reciprocal_forces_and_energy_vs_oracle(pkg, dtype, order, box_scale, mesh):
+    pme = dict(order=order, error_tol=5e-4)
+    if mesh:
+        pme["mesh"] = mesh
+    case = S.charged_fluid(10, dict(kind="ewald", rc=1.0, tol=5e-4), dtype=dtype, pme=pme, box_scale=box_scale, with_exceptions=False)
+    o = case.oracle(np.float64)
+    f_ref = o.forces(None, pairwise=False, specific=False, general=True)
+    e_ref = o.potential_energy(None, pairwise=False, general=True)
+    s = case.system(pkg, dtype)
+    f = pkg.forces(s, pairwise=False, specific=False).astype(np.float64)
+    e = pkg.potential_energy(s, pairwise=False, specific=False)
+    scale = np.linalg.norm(f_ref, axis=1).max()
+    rel_f, rel_e = (1e-10, 1e-11) if dtype == np.float64 else (2e-4, 2e-5)     # fp32: spread atomics + 50-term DFT sums in single precision
+    assert np.linalg.norm(f - f_ref, axis=1).max() < rel_f * scale
+    assert abs(e - e_ref) < rel_e * abs(e_ref)
+
+
+def test_6mrr_reciprocal_fp32_vs_fp64_oracle(pkg):
+    case = G.case("ewald", np.float32, bonded=False, lj=False, pme=True)
+    o = case.oracle(np.float64)
+    f_ref = o.forces(None, pairwise=False, specific=False, general=True)
+    s = case.system(pkg, np.float32)
+    f = pkg.forces(s, pairwise=False, specific=False).astype(np.float64)
+    err = np.linalg.norm(f - f_ref, axis=1)
+    assert err.max() < 2e-4 * np.linalg.norm(f_ref, axis=1).max()
+    assert np.sqrt((err ** 2).mean()) < 2e-5 * np.sqrt((f_ref ** 2).sum(axis=1).mean())
+    e_ref = o.potential_energy(None, pairwise=False, general=True)
+    assert abs(pkg.potential_energy(s, pairwise=False, specific=False) - e_ref) < 2e-5 * abs(e_ref)
+
+
+@pytest.mark.parametrize("exact,ftol,etol", [(True, 1e-6, 1e-4), (False, 1e-3, 0.2)])
+def test_all_pme_vs_openmm_fp64(pkg, exact, ftol, etol):
+    """the reference's bars (test/protein.jl:267, 274): 1e-7 / 1e-5 with exact erfc, 1e-3 / 0.2 with the A&S approximation; the
+    exact case is held to 1e-6 / 1e-4 here (other summation orders than OpenMM's, forces of 1e4 kJ/mol/nm)"""
+    d = G.data()
+    case = G.case("ewald", np.float64, bonded=True, approx_erfc=not exact, pme=True)
+    s = case.system(pkg, np.float64)
+    key = "all_pme_exact" if exact else "all_pme"
+    f = pkg.forces(s)
+    assert np.linalg.norm(f - d[f"openmm_forces_{key}"], axis=1).max() < ftol
+    e = pkg.potential_energy(s) + G.lj_dispersion_correction(d)
+    assert abs(e - float(d[f"openmm_energy_{key}"])) < etol
+
+
+def test_100_step_pme_trajectory_vs_openmm_fp64(pkg):
+    """test/protein.jl:278-299 on the device: the complete MD step (pair + bonded + PME + integrator)"""
+    d = G.data()
+    case = G.case("ewald", np.float64, bonded=True, approx_erfc=False, pme=True)
+    s = case.system(pkg, np.float64)
+    pkg.simulate(s, pkg.VelocityVerlet(dt=0.0005), 100)
+    xo = d["openmm_coordinates_100steps"]; box = case.box
+    dx = s.coords - (xo - np.floor(xo / box) * box)
+    dx -= np.round(dx / box) * box
+    assert np.linalg.norm(dx, axis=1).max() < 1e-9                                            # reference bar 1e-10 (same summation order as OpenMM's CPU platform)
+    assert np.linalg.norm(s.velocities - d["openmm_velocities_100steps"], axis=1).max() < 1e-7
+
+
+def test_pme_rejects_what_it_does_not_cover(pkg):
+    case = S.charged_fluid(6, dict(kind="ewald", rc=0.9, tol=5e-4), dtype=np.float32, pme=dict(order=7), r_list=0.9, with_exceptions=False)
+    with pytest.raises(pkg.MollyHipError):
+        pkg.forces(case.system(pkg, np.float32), pairwise=False)

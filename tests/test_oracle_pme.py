@@ -1,0 +1,55 @@
+"""The oracle's PME reciprocal-space restatement (oracle/pme.h ≙ src/interactions/ewald.jl:311-929) pinned to the reference's
+own OpenMM fixtures for 6mrr (test/protein.jl:208-299): total forces and energy with `nonbonded_method=:pme`, exact and
+approximate erfc, and the 100-step velocity-Verlet trajectory."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+from tests import golden6mrr as G
+
+
+def test_mesh_and_alpha_match_the_reference_constructor():
+    case = G.case("ewald", np.float64, pme=True)
+    p = case.pme_params(np.float64)
+    assert p["mesh"] == (46, 46, 51) and p["order"] == 5                     # pme_params, ewald.jl:479-482
+    assert case.inter_dict(np.float64)["ewald_alpha"] == pytest.approx(2.6283, abs(1e-4))
+    assert orc.pme_mesh([0.5, 0.5, 0.5], 2.6283) == (6, 6, 6)                # max(s, 6)
+
+
+@pytest.mark.parametrize("exact,ftol,etol", [(True, 1e-7, 1e-5), (False, 1e-3, 0.2)])           # test/protein.jl:267, 274
+def test_all_pme_forces_and_energy_vs_openmm(exact, ftol, etol):
+    d = G.data()
+    case = G.case("ewald", np.float64, bonded=True, approx_erfc=not exact, pme=True)
+    o = case.oracle(np.float64)
+    nl = o.neighbors("cell", nthreads=8)
+    f = o.forces(nl, nthreads=8, pairwise=True, specific=True, general=True)
+    key = "all_pme_exact" if exact else "all_pme"
+    assert np.linalg.norm(f - d[f"openmm_forces_{key}"], axis=1).max() < ftol
+    e = o.potential_energy(nl, pairwise=True, specific=True, general=True) + G.lj_dispersion_correction(d)
+    assert abs(e - float(d[f"openmm_energy_{key}"])) < etol
+
+
+def test_pme_reciprocal_forces_sum_to_zero_and_energy_is_translation_invariant():
+    case = G.case("ewald", np.float64, bonded=False, lj=False, pme=True)
+    o = case.oracle(np.float64)
+    f = o.forces(None, pairwise=False, specific=False, general=True)
+    assert np.abs(f.sum(axis=0)).max() < 2e-2 * np.abs(f).max()            # mesh forces conserve momentum only to PME accuracy
+    e0 = o.potential_energy(None, pairwise=False, general=True)
+    o2 = case.oracle(np.float64, coords=case.coords + np.array([0.123, -0.4, 0.05]))
+    o2.wrap()
+    e1 = o2.potential_energy(None, pairwise=False, general=True)
+    assert abs(e1 - e0) < 5e-4 * abs(e0)                                     # mesh discretisation only
+
+
+def test_100_step_pme_trajectory_vs_openmm():
+    """test/protein.jl:278-299: 100 velocity-Verlet steps of 0.5 fs with every interaction incl. PME"""
+    d = G.data()
+    case = G.case("ewald", np.float64, bonded=True, approx_erfc=False, pme=True)
+    o = case.oracle(np.float64)
+    assert o.kinetic_energy() == pytest.approx(65521.87288132431, rel=1e-9)                 # :284
+    o.vv_run(100, 0.0005, remove_cm_every=1, nthreads=min(orc.hardware_threads(), 32), specific=True, general=True)
+    xo = d["openmm_coordinates_100steps"]; box = case.box
+    dx = o.coords - (xo - np.floor(xo / box) * box)
+    dx -= np.round(dx / box) * box
+    assert np.linalg.norm(dx, axis=1).max() < 1e-10                                           # :297
+    assert np.linalg.norm(o.vel - d["openmm_velocities_100steps"], axis=1).max() < 1e-7       # :298
