@@ -30,7 +30,7 @@ def test_struct_layouts_match_header(pkg):
     # sizes computed from the C declarations (LP64): see include/mollyhip.h
     assert C.sizeof(pkg.Interactions) == 4 * 2 + 8 * 3 + 4 * 2 + 8 * 6 + 4 * 2
     assert C.sizeof(pkg.Config) == 4 * 2 + 8 + 24 + 24 + 12 + 4 + 8 + C.sizeof(pkg.Interactions)
-    assert C.sizeof(pkg.Stats) == 8 * 9 + 4 * 4 + 8 * 3 + 8 + 8 * 6 + 8 * 6 + 16
+    assert C.sizeof(pkg.Stats) == 8 * 9 + 4 * 4 + 8 * 3 + 8 + 8 * 8 + 8 * 8 + 16
 
 
 def test_product_path_fails_loudly_without_gpu(pkg):
