@@ -93,6 +93,12 @@ def main():
             raise SystemExit("--gpus N>1 must be launched with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N …")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
 
+    # stdout carries exactly ONE line, the JSON record: libraries that print on their own (RCCL's version banner comes out of the
+    # C stdio buffer at exit, i.e. after anything printed here) are pointed at stderr for the whole run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import molly_loader
     m = molly_loader.load()
     if m.device_count() < 1:
@@ -163,7 +169,7 @@ def main():
     line.update({k: v for k, v in extra.items() if k != "parallelism"})
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(case, dtype, dt)
-    print(json.dumps(line))
+    os.write(json_fd, (json.dumps(line) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -447,6 +447,8 @@ def bench_distributed(m, case, dtype, dt, args, rank, local_rank, world):
     per_rank = [torch.zeros_like(tot) for _ in range(world)]
     dist.all_gather(per_rank, tot)
     dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
     if rank != 0:
         return None
     agg = torch.stack(per_rank).sum(0).tolist()

@@ -11,6 +11,13 @@ from collections import defaultdict
 
 
 def short(name):
+    m = re.search(r"k_forces<([^>]*)>", name)
+    if m:   # the PRUNE instantiation (last template flag) is a different kernel: it also writes the inner pair list
+        return "k_forces_prune" if m.group(1).split(",")[-1].strip() == "true" else "k_forces"
+    m = re.search(r"k_pme_dft<([^>]*)>", name)
+    if m:
+        mode = m.group(1).split(",")[1].strip()
+        return {"0": "k_pme_dft", "1": "k_pme_dft_zfwd", "2": "k_pme_dft_xconv"}.get(mode, "k_pme_dft")
     m = re.search(r"(k_[a-z0-9_]+)", name)
     if m:
         return m.group(1)
