@@ -121,7 +121,7 @@ template <class T> class Engine final : public EngineBase {
     DBuf<uint32_t> key_in, key_out, cell_rank; DBuf<int32_t> idx_in, perm, cell_cnt, cell_start; DBuf<unsigned char> cub_tmp;
     bool hilbert_ok = true;
     // exceptions (CSR over caller indices)
-    DBuf<int32_t> xl_start; DBuf<uint32_t> xl_list; bool has_exc = false; int xl_span = 0;
+    DBuf<int32_t> xl_start; DBuf<uint32_t> xl_list; bool has_exc = false; int xl_span = 0; int64_t n_special = 0;
     static constexpr int X_CAP = 32;
     // blocks
     int BI = 256, JS = 1, n_blocks = 0, T_cap = 0, R_cap = 0, C_cap = 0, max_tile = 0, max_rows = 0;
@@ -574,7 +574,7 @@ template <class T> class Engine final : public EngineBase {
         if (use_inner) { A.tile_idx = tile_idx_in.p; A.tile_cnt = tile_cnt_in.p; }
         A.nbr = use_inner ? nbr_in.p : nbr.p; A.wave_rows = use_inner ? wave_rows_in.p : wave_rows.p;
         A.nbr_dst = nullptr; A.rows_dst = nullptr; A.pos_snap = nullptr; A.blk_disp2 = nullptr; A.r_prune2 = r_in2;
-        A.tile_idx_dst = nullptr; A.tile_cnt_dst = nullptr; A.mark_off = 0;
+        A.tile_idx_dst = nullptr; A.tile_cnt_dst = nullptr; A.mark_off = 0; A.any_special = n_special > 0 ? 1 : 0;
         if (prune) {
             wave_rows_in.reserve((size_t)n_blocks * JS * (BI / WAVE)); nbr_in.reserve((size_t)n_blocks * JS * R_cap * BI); blk_disp2.reserve(n_blocks);
             MHIP_HIP(hipMemsetAsync(blk_disp2.p, 0, (size_t)n_blocks * sizeof(float), stream));
@@ -768,7 +768,7 @@ template <class T> class Engine final : public EngineBase {
         std::vector<uint32_t> ls((size_t)st[cap]);
         for (int64_t i = 0; i < cap; ++i) std::copy(adj[i].begin(), adj[i].end(), ls.begin() + st[i]);
         MHIP_HIP(hipStreamSynchronize(stream));
-        has_exc = (ne + ns) > 0;
+        has_exc = (ne + ns) > 0; n_special = ns;
         xl_span = span;
         xl_start.reserve(cap + 1); xl_list.reserve(std::max<size_t>(ls.size(), 1));
         MHIP_HIP(hipMemcpy(xl_start.p, st.data(), (cap + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -860,7 +860,7 @@ template <class T> class Engine final : public EngineBase {
         if (!state_set) throw ApiError{MHIP_ERR_STATE, "set_state must be called before general_potential_energy"};
         if (!pme.on()) return 0.0;
         if (n_ghost > 0) throw ApiError{MHIP_ERR_UNSUPPORTED, "PME runs on a single domain"};
-        const int nb = pme.dft_blocks(0);
+        const int nb = pme.conv_blocks();
         red_part.reserve(nb);
         pme.run(stream, n_owned, pos[cur].p, (T4*)nullptr, red_part.p);
         return 0.5 * read_sum(nb) + pme.self_factor * pc_abs2_sum + pme.charge_factor * pc_sum * pc_sum;   // ewald.jl:917-928

@@ -11,6 +11,7 @@
 // pair), then each lane streams its rows and gathers partner atoms from LDS (ds_read_b128), accumulating its
 // own force in registers: no atomics, no cross-lane reduction on the hot path, bit-reproducible forces.
 #pragma once
+#include <type_traits>
 #include "physics.h"
 
 namespace mhip {
@@ -717,6 +718,7 @@ template <class T> struct ForceArgs {
     uint2* nbr_dst; int32_t* rows_dst; const typename Vec<T>::T4* pos_snap; float* blk_disp2; T r_prune2;
     // … and the tile is compacted to the atoms the inner list references (slots renumbered in the emitted rows)
     int32_t* tile_idx_dst; int32_t* tile_cnt_dst; int mark_off;   // byte offset of the mark array in dynamic LDS
+    int any_special;                 // 0: no special (1-4) pair exists, the per-entry weight select is compiled out (uniform-LJ fluids)
 };
 
 template <class T, int LJM, int COULM, bool ENERGY, bool MINIMG, bool SEG, bool PRUNE>
@@ -792,32 +794,39 @@ __global__ void k_forces(ForceArgs<T> A) {
         }
         __syncthreads();
         // the row stream is software-pipelined: row r+1 is in flight while row r is evaluated
-        uint2 e_next = (0 < rows) ? my_rows[0] : make_uint2(0, 0);
-        for (int r = 0; r < rows; ++r) {
-            const uint2 e4 = e_next;
-            if (r + 1 < rows) e_next = my_rows[(int64_t)(r + 1) * A.BI];
+        auto walk_rows = [&](auto spec_tag) {
+            constexpr bool SPEC = decltype(spec_tag)::value;
+            uint2 e_next = (0 < rows) ? my_rows[0] : make_uint2(0, 0);
+            for (int r = 0; r < rows; ++r) {
+                const uint2 e4 = e_next;
+                if (r + 1 < rows) e_next = my_rows[(int64_t)(r + 1) * A.BI];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                uint32_t e = ((k < 2 ? e4.x : e4.y) >> (16 * (k & 1))) & 0xffffu;
-                uint32_t slot = e & 0x7fffu;
-                [[maybe_unused]] const bool real = SEG ? (slot - (uint32_t)seg_lo) < (uint32_t)n_here : slot < (uint32_t)tile_n;   // not a sentinel / other segment
-                if constexpr (SEG) { slot -= (uint32_t)seg_lo; slot = slot < (uint32_t)n_here ? slot : (uint32_t)n_here; }
-                bool special = (e >> 15) != 0;
-                T4 pj = l_pos[slot];
-                T2 ljj = make2<T>(T(0), T(0));
-                if constexpr (PER_ATOM_LJ) ljj = l_lj[slot];
-                T dx, dy, dz;
-                if constexpr (MINIMG) {
-                    dx = G.periodic[0] ? vector_1d_exact(pi.x, pj.x, G.L[0]) : pj.x - pi.x;
-                    dy = G.periodic[1] ? vector_1d_exact(pi.y, pj.y, G.L[1]) : pj.y - pi.y;
-                    dz = G.periodic[2] ? vector_1d_exact(pi.z, pj.z, G.L[2]) : pj.z - pi.z;
-                } else { dx = pj.x - pi.x; dy = pj.y - pi.y; dz = pj.z - pi.z; }
-                T r2 = dx * dx + dy * dy + dz * dz;
-                if constexpr (PRUNE) { if (real && valid && r2 <= A.r_prune2) { emit(e); l_mark[e & 0x7fffu] = 1; } }   // benign race: same byte value
-                T fr = pair_eval<T, LJM, COULM, ENERGY>(A.I, r2, pi.w, pj.w, lji.x, ljj.x, lji.y, ljj.y, special, pe);
-                fx -= fr * dx; fy -= fr * dy; fz -= fr * dz;   // force on i is −f (force.jl:873)
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t e = ((k < 2 ? e4.x : e4.y) >> (16 * (k & 1))) & 0xffffu;
+                    uint32_t slot = e & 0x7fffu;
+                    [[maybe_unused]] const bool real = SEG ? (slot - (uint32_t)seg_lo) < (uint32_t)n_here : slot < (uint32_t)tile_n;   // not a sentinel / other segment
+                    if constexpr (SEG) { slot -= (uint32_t)seg_lo; slot = slot < (uint32_t)n_here ? slot : (uint32_t)n_here; }
+                    const bool special = SPEC ? (e >> 15) != 0 : false;
+                    T4 pj = l_pos[slot];
+                    T2 ljj = make2<T>(T(0), T(0));
+                    if constexpr (PER_ATOM_LJ) ljj = l_lj[slot];
+                    T dx, dy, dz;
+                    if constexpr (MINIMG) {
+                        dx = G.periodic[0] ? vector_1d_exact(pi.x, pj.x, G.L[0]) : pj.x - pi.x;
+                        dy = G.periodic[1] ? vector_1d_exact(pi.y, pj.y, G.L[1]) : pj.y - pi.y;
+                        dz = G.periodic[2] ? vector_1d_exact(pi.z, pj.z, G.L[2]) : pj.z - pi.z;
+                    } else { dx = pj.x - pi.x; dy = pj.y - pi.y; dz = pj.z - pi.z; }
+                    T r2 = dx * dx + dy * dy + dz * dz;
+                    if constexpr (PRUNE) { if (real && valid && r2 <= A.r_prune2) { emit(e); l_mark[e & 0x7fffu] = 1; } }   // benign race: same byte value
+                    T fr = pair_eval<T, LJM, COULM, ENERGY>(A.I, r2, pi.w, pj.w, lji.x, ljj.x, lji.y, ljj.y, special, pe);
+                    fx -= fr * dx; fy -= fr * dy; fz -= fr * dz;   // force on i is −f (force.jl:873)
+                }
             }
-        }
+        };
+        // one-type LJ fluids normally have no special pairs at all: a second copy of the loop without the weight selects
+        if constexpr (LJM == LJ_DIST_UNIFORM && COULM == MHIP_COUL_NONE && !ENERGY) {
+            if (A.any_special) walk_rows(std::true_type{}); else walk_rows(std::false_type{});
+        } else walk_rows(std::true_type{});
     }
     if constexpr (PRUNE) {
         // finish the inner list: pad to the wave's row count; record how far the block's atoms moved since the outer build

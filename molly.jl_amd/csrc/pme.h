@@ -93,34 +93,110 @@ __device__ inline void pme_atom_tables(int64_t a0, int64_t n_atoms, const typena
     }
 }
 
-// spread_charge_inner! (:598-621).  Phase 2: a 32-lane half-wave per atom, lane ↔ (iy, iz), loop over ix: the ORDER² lanes of an
-// atom touch ORDER rows of ORDER contiguous z points per instruction (few cache lines).
-// Float atomics resolve in the L2 of the XCD that issues them; each XCD accumulates into its OWN real mesh (selected by the
-// hardware XCC id, so correctness does not depend on how workgroups are dealt out) and the first transform pass sums the copies.
-template <class T, int ORDER>
+// spread_charge_inner! (:598-621).  A block takes PME_SB consecutive (Hilbert-sorted, hence spatially compact) atoms.
+// Phase 1: one lane per atom (tables above).  Phase 2: a 32-lane half-wave per atom, lane ↔ (iy, iz), loop over ix, adds the
+// ORDER³ weights into an LDS sub-mesh that covers the batch's bounding box (ds_add_f32; relative mesh indices, so the box may
+// straddle the periodic boundary).  Phase 3: the sub-mesh is flushed with ONE global float atomic per touched mesh point —
+// several times fewer than one per (atom, point).  A batch whose box does not fit the LDS sub-mesh (a jump of the curve) falls
+// back to direct global atomics.  Global atomics resolve in the L2 of the issuing XCD; each XCD accumulates into its OWN real
+// mesh (selected by the hardware XCC id) and the first transform pass sums the copies.
+constexpr int PME_BOX_BYTES = 24 * 1024;   // LDS sub-mesh
+
+template <class T, int ORDER, int PME_SB>
 __global__ void __launch_bounds__(256) k_pme_spread(int64_t n_atoms, const typename Vec<T>::T4* __restrict__ pos, T* rgrid, PmeP<T> P) {
-    __shared__ T l_w[3 * ORDER * PME_AB]; __shared__ int l_i[3 * PME_AB]; __shared__ T l_q[PME_AB];
+    __shared__ T l_w[3 * ORDER * PME_SB]; __shared__ int l_i[3 * PME_SB]; __shared__ T l_q[PME_SB];
+    constexpr int PME_BOX = PME_BOX_BYTES / (int)sizeof(T);
+    __shared__ T l_box[PME_BOX]; __shared__ int l_lo[3], l_hi[3];
     const int tid = threadIdx.x, sub = tid & 31, hw = tid >> 5;
     T* mesh = rgrid + (int64_t)xcc_id() * P.n[0] * P.n[1] * P.n[2];
-    for (int64_t a0 = (int64_t)blockIdx.x * PME_AB; a0 < n_atoms; a0 += (int64_t)gridDim.x * PME_AB) {
+    for (int64_t a0 = (int64_t)blockIdx.x * PME_SB; a0 < n_atoms; a0 += (int64_t)gridDim.x * PME_SB) {
         __syncthreads();
-        pme_atom_tables<T, ORDER, false>(a0, n_atoms, pos, P, l_w, l_i, l_q);
-        __syncthreads();
-        for (int t = hw; t < PME_AB; t += 8) {
-            const T q = l_q[t];
-            if (q == T(0)) continue;                                   // also the atoms past the end
-            const int i0x = l_i[t], i0y = l_i[PME_AB + t], i0z = l_i[2 * PME_AB + t];
-            for (int pr = sub; pr < ORDER * ORDER; pr += 32) {
-                const int iy = pr / ORDER, iz = pr - iy * ORDER;
-                int yi = i0y + iy; yi -= yi >= P.n[1] ? P.n[1] : 0;
-                int zi = i0z + iz; zi -= zi >= P.n[2] ? P.n[2] : 0;
-                const T qyz = (q * l_w[(ORDER + iy) * PME_AB + t]) * l_w[(2 * ORDER + iz) * PME_AB + t];
-                T* col = mesh + (int64_t)yi * P.n[2] + zi;
+        // phase 1 (one thread per atom)
+        if (tid < PME_SB) {
+            const int64_t a = a0 + tid;
+            T q = T(0); int i0[3] = {0, 0, 0};
+            if (a < n_atoms) {
+                const auto p = pos[a];
+                q = p.w;
+                const T c[3] = {p.x, p.y, p.z};
+                T th[ORDER], dth[ORDER], dr;
 #pragma unroll
-                for (int ix = 0; ix < ORDER; ++ix) {
-                    int xi = i0x + ix; xi -= xi >= P.n[0] ? P.n[0] : 0;
-                    atomicAdd(col + (int64_t)xi * P.n[1] * P.n[2], l_w[ix * PME_AB + t] * qyz);
+                for (int d = 0; d < 3; ++d) {
+                    pme_place<T>(c[d], P.invL[d], P.n[d], i0[d], dr);
+                    pme_bspline<T, ORDER>(dr, th, dth);
+#pragma unroll
+                    for (int k = 0; k < ORDER; ++k) l_w[(d * ORDER + k) * PME_SB + tid] = th[k];
                 }
+            }
+            l_q[tid] = q; l_i[tid] = i0[0]; l_i[PME_SB + tid] = i0[1]; l_i[2 * PME_SB + tid] = i0[2];
+        }
+        if (tid < 3) { l_lo[tid] = 1 << 30; l_hi[tid] = -(1 << 30); }
+        __syncthreads();
+        // bounding box of the first indices, relative to the batch's first atom and folded into [−n/2, n/2)
+        const int ref[3] = {l_i[0], l_i[PME_SB], l_i[2 * PME_SB]};
+        int rel[3];
+        const int ta = tid < PME_SB ? tid : 0;
+        const bool mine = tid < PME_SB && l_q[ta] != T(0);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            int r = l_i[d * PME_SB + ta] - ref[d];
+            const int n = P.n[d], h = n >> 1;
+            r += r < -h ? n : 0; r -= r >= n - h ? n : 0;
+            rel[d] = r;
+            int lo = mine ? r : (1 << 30), hi = mine ? r : -(1 << 30);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+            if ((tid & 63) == 0) { atomicMin(&l_lo[d], lo); atomicMax(&l_hi[d], hi); }
+        }
+        __syncthreads();
+        const int lo3[3] = {l_lo[0], l_lo[1], l_lo[2]};
+        const bool empty = l_hi[0] < lo3[0];
+        const int ex = l_hi[0] - lo3[0] + ORDER, ey = l_hi[1] - lo3[1] + ORDER, ez = l_hi[2] - lo3[2] + ORDER;
+        const bool fits = !empty && ex <= P.n[0] && ey <= P.n[1] && ez <= P.n[2] && (int64_t)ex * ey * ez <= PME_BOX;
+        if (fits) {   // the atoms' offsets inside the box replace their absolute first indices (everybody has read `ref` by now)
+            for (int c = tid; c < ex * ey * ez; c += 256) l_box[c] = T(0);
+            if (tid < PME_SB) { l_i[tid] = rel[0] - lo3[0]; l_i[PME_SB + tid] = rel[1] - lo3[1]; l_i[2 * PME_SB + tid] = rel[2] - lo3[2]; }
+        }
+        __syncthreads();
+        if (!empty) {
+            for (int t = hw; t < PME_SB; t += 8) {
+                const T q = l_q[t];
+                if (q == T(0)) continue;                                   // also the atoms past the end
+                const int bx = l_i[t], by = l_i[PME_SB + t], bz = l_i[2 * PME_SB + t];
+                for (int pr = sub; pr < ORDER * ORDER; pr += 32) {
+                    const int iy = pr / ORDER, iz = pr - iy * ORDER;
+                    const T qyz = (q * l_w[(ORDER + iy) * PME_SB + t]) * l_w[(2 * ORDER + iz) * PME_SB + t];
+                    if (fits) {
+                        T* col = l_box + (by + iy) * ez + (bz + iz);
+#pragma unroll
+                        for (int ix = 0; ix < ORDER; ++ix) atomicAdd(col + (bx + ix) * ey * ez, l_w[ix * PME_SB + t] * qyz);
+                    } else {
+                        int yi = by + iy; yi -= yi >= P.n[1] ? P.n[1] : 0;
+                        int zi = bz + iz; zi -= zi >= P.n[2] ? P.n[2] : 0;
+                        T* col = mesh + (int64_t)yi * P.n[2] + zi;
+#pragma unroll
+                        for (int ix = 0; ix < ORDER; ++ix) {
+                            int xi = bx + ix; xi -= xi >= P.n[0] ? P.n[0] : 0;
+                            atomicAdd(col + (int64_t)xi * P.n[1] * P.n[2], l_w[ix * PME_SB + t] * qyz);
+                        }
+                    }
+                }
+            }
+        }
+        if (fits) {
+            __syncthreads();
+            // phase 3: box cell (cx, cy, cz) is mesh point (first index of the batch's first atom + l_lo + c) mod n
+            int base[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { int v = (ref[d] + lo3[d]) % P.n[d]; base[d] = v < 0 ? v + P.n[d] : v; }
+            for (int c = tid; c < ex * ey * ez; c += 256) {
+                const T v = l_box[c];
+                if (v == T(0)) continue;
+                const int cx = c / (ey * ez), r = c - cx * ey * ez, cy = r / ez, cz = r - cy * ez;
+                int xi = base[0] + cx; xi -= xi >= P.n[0] ? P.n[0] : 0;
+                int yi = base[1] + cy; yi -= yi >= P.n[1] ? P.n[1] : 0;
+                int zi = base[2] + cz; zi -= zi >= P.n[2] ? P.n[2] : 0;
+                atomicAdd(mesh + ((int64_t)xi * P.n[1] + yi) * P.n[2] + zi, v);
             }
         }
     }
@@ -128,7 +204,7 @@ __global__ void __launch_bounds__(256) k_pme_spread(int64_t n_atoms, const typen
 
 // interpolate_force_inner! (:805-840): Fs[i] -= q (∂θ/∂r ⊗ θ ⊗ θ) · φ, same two phases, shuffle reduction inside the half-wave
 template <class T, int ORDER>
-__global__ void __launch_bounds__(256) k_pme_gather(int64_t n_atoms, const typename Vec<T>::T4* __restrict__ pos, const typename Vec<T>::T2* __restrict__ grid,
+__global__ void __launch_bounds__(256) k_pme_gather(int64_t n_atoms, const typename Vec<T>::T4* __restrict__ pos, const T* __restrict__ grid,
                                                     typename Vec<T>::T4* frc, PmeP<T> P) {
     __shared__ T l_w[6 * ORDER * PME_AB]; __shared__ int l_i[3 * PME_AB]; __shared__ T l_q[PME_AB];
     const int tid = threadIdx.x, sub = tid & 31, hw = tid >> 5;
@@ -153,7 +229,7 @@ __global__ void __launch_bounds__(256) k_pme_gather(int64_t n_atoms, const typen
 #pragma unroll
                     for (int ix = 0; ix < ORDER; ++ix) {
                         int xi = i0x + ix; xi -= xi >= P.n[0] ? P.n[0] : 0;
-                        g[ix] = (P.debug & 1) ? T(1) : col[(int64_t)xi * P.n[1] * P.n[2]].x;
+                        g[ix] = (P.debug & 1) ? T(1) : col[(int64_t)xi * P.n[1] * P.n[2]];
                     }
 #pragma unroll
                     for (int ix = 0; ix < ORDER; ++ix) {
@@ -173,61 +249,127 @@ __global__ void __launch_bounds__(256) k_pme_gather(int64_t n_atoms, const typen
     }
 }
 
-// One axis of the 3-D transform as a direct DFT: a block stages C = 256/n whole lines in LDS ([j][c], c = line within the
-// tile) and every thread owns ONE output (k, c), so a pass is ~n·n_lines/64 short, independent waves — enough of them to hide
-// the LDS latency of the n-term sums.
-//   axis 2 (z): lines are contiguous, line q starts at q·nz            (q = x·ny + y)
-//   axis 1 (y): line q = x·nz + z starts at x·ny·nz + z, stride nz
-//   axis 0 (x): line q = y·nz + z starts at q, stride ny·nz
-// MODE 0: plain complex pass.  MODE 1 (axis 2, forward): the input is the sum of the PME_COPIES real charge meshes.
-// MODE 2 (axis 0): forward transform, multiply by the influence function of recip_conv_inner! (:676-725), transform back —
-// the other two inverse passes follow as plain launches with sign +1.
+// The 3-D transform, one launch per axis, as direct DFTs on LDS-staged line tiles: a block stages C whole lines ([j][c],
+// c = line within the tile) and every thread owns ONE output (k, c), so a pass is many short, independent waves.
+// The charge mesh is real, so only the half spectrum kz = 0 … nz/2 is carried (Hermitian symmetry halves every pass):
+//   k_pme_z_r2c   real lines (sum of the per-XCD meshes) → nzh = nz/2+1 complex outputs per line
+//   k_pme_dft     y, then x, on the half grid (nx, ny, nzh); the x pass (CONV) does forward · influence function · backward
+//   k_pme_z_c2r   Hermitian half lines → real potential mesh, φ[z] = Re X₀ + 2 Σ_{0<k<nz/2} Re(X_k w^{kz}) (+ Nyquist term)
+// Half-grid layout: complex<T> at ((x·ny + y)·nzh + kz).  Line q of the y pass = x·nzh + kz (start x·ny·nzh + kz, stride nzh),
+// of the x pass = y·nzh + kz (start q, stride ny·nzh).
 constexpr int PME_THREADS = 256;
 
 template <class T> struct DftArgs {
-    typename Vec<T>::T2* grid;
-    const T* rgrid;                       // MODE 1: [PME_COPIES][nx·ny·nz] real charge meshes
+    typename Vec<T>::T2* grid;            // half grid
+    T* rgrid;                             // r2c: [PME_COPIES][nx·ny·nz] real charge meshes (read, then zeroed for the next spread)
+    T* phi;                               // c2r: [nx·ny·nz] real potential mesh
     const typename Vec<T>::T2* tw;        // [n] e^{-2πi m/n} of this axis
     const T* mh[3];                       // [n_d] signed frequency / L_d
     const T* bsm[3];                      // [n_d] B-spline moduli
-    double* e_part;                       // MODE 2 && ENERGY: per-block Σ eterm·|S|²
+    double* e_part;                       // CONV && ENERGY: per-block Σ w·eterm·|S|² over the half spectrum (w = 2 off the symmetry planes)
     PmeP<T> P;
-    int axis, sign, C;                    // sign −1: forward (plan_fft!), +1: backward (plan_bfft!), both unnormalised
+    int axis, sign, C, nzh;               // sign −1: forward (plan_fft!), +1: backward (plan_bfft!), both unnormalised
 };
 
-template <class T, int MODE, bool ENERGY>
-__global__ void __launch_bounds__(PME_THREADS) k_pme_dft(DftArgs<T> A) {
+template <class T>
+__global__ void __launch_bounds__(PME_THREADS) k_pme_z_r2c(DftArgs<T> A) {
     using T2 = typename Vec<T>::T2;
     extern __shared__ __align__(16) unsigned char pme_smem[];
-    const int n = A.P.n[A.axis], nx = A.P.n[0], ny = A.P.n[1], nz = A.P.n[2], C = A.C;
+    const int nz = A.P.n[2], nzh = A.nzh, C = A.C, tid = threadIdx.x;
     T2* l_tw = reinterpret_cast<T2*>(pme_smem);
-    T2* l_a = l_tw + n;
-    [[maybe_unused]] T2* l_b = l_a + n * C;
-    const int tid = threadIdx.x;
-    const int64_t n_mesh = (int64_t)nx * ny * nz, n_lines = n_mesh / n, q0 = (int64_t)blockIdx.x * C;
+    T* l_a = reinterpret_cast<T*>(l_tw + nz);                          // [j][c] real
+    const int64_t n_mesh = (int64_t)A.P.n[0] * A.P.n[1] * nz, n_lines = n_mesh / nz, q0 = (int64_t)blockIdx.x * C;
     const int n_here = (int)min((int64_t)C, n_lines - q0);
-    const int64_t stride = A.axis == 2 ? 1 : (A.axis == 1 ? nz : (int64_t)ny * nz);
-    auto line_base = [&](int64_t q) -> int64_t {
-        if (A.axis == 2) return q * nz;
-        if (A.axis == 1) { const int64_t x = q / nz; return x * ny * nz + (q - x * nz); }
-        return q;
-    };
-    for (int m = tid; m < n; m += PME_THREADS) { T2 w = A.tw[m]; if (A.sign > 0 && MODE != 2) w.y = -w.y; l_tw[m] = w; }
-    for (int e = tid; e < n * C; e += PME_THREADS) {
-        int j, c;
-        if (A.axis == 2) { c = e / n; j = e - c * n; } else { j = e / C; c = e - j * C; }
-        T2 v; v.x = T(0); v.y = T(0);
+    for (int m = tid; m < nz; m += PME_THREADS) l_tw[m] = A.tw[m];
+    for (int e = tid; e < nz * C; e += PME_THREADS) {
+        const int c = e / nz, j = e - c * nz;
+        T v = T(0);
         if (c < n_here) {
-            const int64_t at = line_base(q0 + c) + j * stride;
-            if constexpr (MODE == 1) {
+            const int64_t at = (q0 + c) * nz + j;
 #pragma unroll
-                for (int k = 0; k < PME_COPIES; ++k) v.x += A.rgrid[k * n_mesh + at];
-            } else v = A.grid[at];
+            for (int k = 0; k < PME_COPIES; ++k) { v += A.rgrid[k * n_mesh + at]; A.rgrid[k * n_mesh + at] = T(0); }
         }
         l_a[j * C + c] = v;
     }
     __syncthreads();
-    // output (k, c) = Σ_j src[j][c] · w^(jk); four terms in flight per iteration
+    for (int o = tid; o < nzh * C; o += PME_THREADS) {
+        const int c = o / nzh, k = o - c * nzh;
+        T r0 = T(0), i0 = T(0), r1 = T(0), i1 = T(0);
+        int m = 0, j = 0;
+        for (; j + 1 < nz; j += 2) {
+            const T v0 = l_a[j * C + c]; const T2 w0 = l_tw[m];
+            m += k; m -= m >= nz ? nz : 0;
+            const T v1 = l_a[(j + 1) * C + c]; const T2 w1 = l_tw[m];
+            m += k; m -= m >= nz ? nz : 0;
+            r0 += v0 * w0.x; i0 += v0 * w0.y; r1 += v1 * w1.x; i1 += v1 * w1.y;
+        }
+        if (j < nz) { const T v0 = l_a[j * C + c]; const T2 w0 = l_tw[m]; r0 += v0 * w0.x; i0 += v0 * w0.y; }
+        if (c < n_here) { T2 v; v.x = r0 + r1; v.y = i0 + i1; A.grid[(q0 + c) * nzh + k] = v; }
+    }
+}
+
+template <class T>
+__global__ void __launch_bounds__(PME_THREADS) k_pme_z_c2r(DftArgs<T> A) {
+    using T2 = typename Vec<T>::T2;
+    extern __shared__ __align__(16) unsigned char pme_smem[];
+    const int nz = A.P.n[2], nzh = A.nzh, C = A.C, tid = threadIdx.x;
+    T2* l_tw = reinterpret_cast<T2*>(pme_smem);
+    T2* l_a = l_tw + nz;                                               // [k][c] complex, k < nzh
+    const int64_t n_lines = (int64_t)A.P.n[0] * A.P.n[1], q0 = (int64_t)blockIdx.x * C;
+    const int n_here = (int)min((int64_t)C, n_lines - q0);
+    for (int m = tid; m < nz; m += PME_THREADS) { T2 w = A.tw[m]; w.y = -w.y; l_tw[m] = w; }      // e^{+2πi m/n}
+    for (int e = tid; e < nzh * C; e += PME_THREADS) {
+        const int c = e / nzh, k = e - c * nzh;
+        T2 v; v.x = T(0); v.y = T(0);
+        if (c < n_here) {
+            v = A.grid[(q0 + c) * nzh + k];
+            const bool plane = k == 0 || 2 * k == nz;                   // self-conjugate terms count once, the others stand for k and nz − k
+            if (!plane) { v.x += v.x; v.y += v.y; }
+        }
+        l_a[k * C + c] = v;
+    }
+    __syncthreads();
+    for (int o = tid; o < nz * C; o += PME_THREADS) {
+        const int c = o / nz, z = o - c * nz;
+        T r0 = T(0), r1 = T(0);
+        int m = 0, k = 0;
+        for (; k + 1 < nzh; k += 2) {
+            const T2 v0 = l_a[k * C + c], w0 = l_tw[m];
+            m += z; m -= m >= nz ? nz : 0;
+            const T2 v1 = l_a[(k + 1) * C + c], w1 = l_tw[m];
+            m += z; m -= m >= nz ? nz : 0;
+            r0 += v0.x * w0.x - v0.y * w0.y; r1 += v1.x * w1.x - v1.y * w1.y;
+        }
+        if (k < nzh) { const T2 v0 = l_a[k * C + c], w0 = l_tw[m]; r0 += v0.x * w0.x - v0.y * w0.y; }
+        if (c < n_here) A.phi[(q0 + c) * nz + z] = r0 + r1;
+    }
+}
+
+template <class T, bool CONV, bool ENERGY>
+__global__ void __launch_bounds__(PME_THREADS) k_pme_dft(DftArgs<T> A) {
+    using T2 = typename Vec<T>::T2;
+    extern __shared__ __align__(16) unsigned char pme_smem[];
+    const int n = A.P.n[A.axis], nx = A.P.n[0], ny = A.P.n[1], nz = A.P.n[2], nzh = A.nzh, C = A.C;
+    T2* l_tw = reinterpret_cast<T2*>(pme_smem);
+    T2* l_a = l_tw + n;
+    [[maybe_unused]] T2* l_b = l_a + n * C;
+    const int tid = threadIdx.x;
+    const int64_t n_lines = (int64_t)nx * ny * nzh / n, q0 = (int64_t)blockIdx.x * C;
+    const int n_here = (int)min((int64_t)C, n_lines - q0);
+    const int64_t stride = A.axis == 1 ? nzh : (int64_t)ny * nzh;
+    auto line_base = [&](int64_t q) -> int64_t {
+        if (A.axis == 1) { const int64_t x = q / nzh; return x * ny * nzh + (q - x * nzh); }
+        return q;
+    };
+    for (int m = tid; m < n; m += PME_THREADS) { T2 w = A.tw[m]; if (A.sign > 0 && !CONV) w.y = -w.y; l_tw[m] = w; }
+    for (int e = tid; e < n * C; e += PME_THREADS) {
+        const int j = e / C, c = e - j * C;
+        T2 v; v.x = T(0); v.y = T(0);
+        if (c < n_here) v = A.grid[line_base(q0 + c) + j * stride];
+        l_a[j * C + c] = v;
+    }
+    __syncthreads();
+    // output (k, c) = Σ_j src[j][c] · w^(jk), two terms in flight per iteration
     auto dft_one = [&](const T2* src, bool conj, int k, int c, T& re, T& im) {
         T r0 = T(0), i0 = T(0), r1 = T(0), i1 = T(0);
         const T sg = conj ? T(-1) : T(1);
@@ -253,18 +395,18 @@ __global__ void __launch_bounds__(PME_THREADS) k_pme_dft(DftArgs<T> A) {
         const int c = o / n, k = o - c * n;
         T re, im;
         dft_one(l_a, false, k, c, re, im);
-        if constexpr (MODE != 2) {
+        if constexpr (!CONV) {
             if (c < n_here) { T2 v; v.x = re; v.y = im; A.grid[line_base(q0 + c) + k * stride] = v; }
         } else {
             T2 v; v.x = T(0); v.y = T(0);
             if (c < n_here) {
-                const int kx = k; const int64_t q = q0 + c; const int ky = (int)(q / nz), kz = (int)(q - (int64_t)ky * nz);
+                const int kx = k; const int64_t q = q0 + c; const int ky = (int)(q / nzh), kz = (int)(q - (int64_t)ky * nzh);
                 if (kx | ky | kz) {
                     const T mhx = A.mh[0][kx], mhy = A.mh[1][ky], mhz = A.mh[2][kz];
                     const T m2 = mhx * mhx + mhy * mhy + mhz * mhz;
                     const T denom = m2 * (A.P.pi_V * A.bsm[0][kx]) * A.bsm[1][ky] * A.bsm[2][kz];
                     const T eterm = A.P.f_div_er * M<T>::exp(-A.P.factor * m2) / denom;
-                    if constexpr (ENERGY) e_loc += (double)(eterm * (re * re + im * im));
+                    if constexpr (ENERGY) e_loc += (double)(eterm * (re * re + im * im)) * ((kz == 0 || 2 * kz == nz) ? 1.0 : 2.0);
                     v.x = re * eterm; v.y = im * eterm;
                 }
                 // k = 0: the reference leaves the DC term of the charge grid untouched (:681-683); it only adds a constant to the
@@ -273,7 +415,7 @@ __global__ void __launch_bounds__(PME_THREADS) k_pme_dft(DftArgs<T> A) {
             l_b[k * C + c] = v;
         }
     }
-    if constexpr (MODE == 2) {
+    if constexpr (CONV) {
         __syncthreads();
         for (int o = tid; o < n * C; o += PME_THREADS) {
             const int c = o / n, k = o - c * n;
@@ -305,11 +447,12 @@ template <class T> struct Pme {
     int order = 0;
     PmeP<T> P;
     PBuf<T2> grid, tw[3];
-    PBuf<T> mh[3], bsm[3], rgrid;      // rgrid: PME_COPIES real charge meshes, one per XCD
+    PBuf<T> mh[3], bsm[3], rgrid, phi; // rgrid: PME_COPIES real charge meshes, one per XCD; phi: real potential mesh
+    int nzh = 0;                       // half-spectrum length along z
     double self_factor = 0, charge_factor = 0;   // E_self = −f/ϵr·α/√π·Σq²  and  E_charge = −f/ϵr·π/(2Vα²)·(Σq)²   (:917-927)
 
     bool on() const { return order > 0; }
-    void release() { grid.release(); rgrid.release(); for (int d = 0; d < 3; ++d) { tw[d].release(); mh[d].release(); bsm[d].release(); } order = 0; }
+    void release() { grid.release(); rgrid.release(); phi.release(); for (int d = 0; d < 3; ++d) { tw[d].release(); mh[d].release(); bsm[d].release(); } order = 0; }
 
     // pme_bspline_moduli (:311-358), in T like the reference
     static void moduli(int ord, const int* n, std::vector<T>* out) {
@@ -370,42 +513,68 @@ template <class T> struct Pme {
             }
             tw[d].set(w); mh[d].set(m); bsm[d].set(bm[d]);
         }
-        grid.alloc((size_t)P.n[0] * P.n[1] * P.n[2]);
+        nzh = P.n[2] / 2 + 1;
+        grid.alloc((size_t)P.n[0] * P.n[1] * nzh);
         rgrid.alloc((size_t)PME_COPIES * P.n[0] * P.n[1] * P.n[2]);
+        MHIP_HIP(hipMemset(rgrid.p, 0, rgrid.n * sizeof(T)));     // from here on k_pme_z_r2c leaves the meshes zeroed behind it
+        phi.alloc((size_t)P.n[0] * P.n[1] * P.n[2]);
     }
 
-    int lines_per_block(int axis) const { return std::max(1, PME_THREADS / P.n[axis]); }
-    DftArgs<T> dft_args(int axis, int sign, double* e_part) const {
+    DftArgs<T> dft_args(int axis, int sign, int C, double* e_part) const {
         DftArgs<T> A;
-        A.grid = grid.p; A.rgrid = rgrid.p; A.tw = tw[axis].p; for (int d = 0; d < 3; ++d) { A.mh[d] = mh[d].p; A.bsm[d] = bsm[d].p; }
-        A.e_part = e_part; A.P = P; A.axis = axis; A.sign = sign; A.C = lines_per_block(axis);
+        A.grid = grid.p; A.rgrid = rgrid.p; A.phi = phi.p; A.tw = tw[axis].p; for (int d = 0; d < 3; ++d) { A.mh[d] = mh[d].p; A.bsm[d] = bsm[d].p; }
+        A.e_part = e_part; A.P = P; A.axis = axis; A.sign = sign; A.C = C; A.nzh = nzh;
         return A;
     }
-    int dft_blocks(int axis) const { return (int)cdiv((int64_t)P.n[0] * P.n[1] * P.n[2] / P.n[axis], (int64_t)lines_per_block(axis)); }
-    size_t dft_lds(int axis, bool conv) const { return (size_t)P.n[axis] * sizeof(T2) * (1 + lines_per_block(axis) * (conv ? 2 : 1)); }
+    // lines per block: one output per thread
+    int c_r2c() const { return std::max(1, PME_THREADS / nzh); }
+    int c_c2r() const { return std::max(1, PME_THREADS / P.n[2]); }
+    int c_xy(int axis) const { return std::max(1, PME_THREADS / P.n[axis]); }
+    int conv_blocks() const { return (int)cdiv((int64_t)P.n[1] * nzh, (int64_t)c_xy(0)); }
 
     // PME_AB atoms per 256-thread block and round; at most 2048 blocks (each then loops over its atom batches)
     static unsigned atom_blocks(int64_t n) { return (unsigned)std::min<int64_t>(cdiv(n, (int64_t)PME_AB), 2048); }
-    template <int ORDER> void spread_t(hipStream_t s, int64_t n, const T4* pos) { hipLaunchKernelGGL((k_pme_spread<T, ORDER>), dim3(atom_blocks(n)), dim3(256), 0, s, n, pos, rgrid.p, P); }
-    template <int ORDER> void gather_t(hipStream_t s, int64_t n, const T4* pos, T4* frc) { hipLaunchKernelGGL((k_pme_gather<T, ORDER>), dim3(atom_blocks(n)), dim3(256), 0, s, n, pos, (const T2*)grid.p, frc, P); }
-    template <int MODE, bool EN> void dft(hipStream_t s, int axis, int sign, double* e_part) {
-        auto kern = k_pme_dft<T, MODE, EN>;
-        const size_t lds = dft_lds(axis, MODE == 2);
+    template <int ORDER> void spread_t(hipStream_t s, int64_t n, const T4* pos) {
+        static const int sb = [] { const char* v = std::getenv("MOLLYHIP_PME_SPREAD_BATCH"); return v && *v ? std::atoi(v) : 64; }();
+        if (sb >= 128) hipLaunchKernelGGL((k_pme_spread<T, ORDER, 128>), dim3((unsigned)std::min<int64_t>(cdiv(n, (int64_t)128), 2048)), dim3(256), 0, s, n, pos, rgrid.p, P);
+        else if (sb <= 32) hipLaunchKernelGGL((k_pme_spread<T, ORDER, 32>), dim3((unsigned)std::min<int64_t>(cdiv(n, (int64_t)32), 4096)), dim3(256), 0, s, n, pos, rgrid.p, P);
+        else hipLaunchKernelGGL((k_pme_spread<T, ORDER, 64>), dim3((unsigned)std::min<int64_t>(cdiv(n, (int64_t)64), 2048)), dim3(256), 0, s, n, pos, rgrid.p, P);
+    }
+    template <int ORDER> void gather_t(hipStream_t s, int64_t n, const T4* pos, T4* frc) { hipLaunchKernelGGL((k_pme_gather<T, ORDER>), dim3(atom_blocks(n)), dim3(256), 0, s, n, pos, (const T*)phi.p, frc, P); }
+    template <class K> static void big_lds(K kern, size_t lds) {
         if (lds > 64 * 1024) MHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(dft_blocks(axis)), dim3(PME_THREADS), lds, s, dft_args(axis, sign, e_part));
+    }
+    template <bool CONV, bool EN> void dft_xy(hipStream_t s, int axis, int sign, double* e_part) {
+        auto kern = k_pme_dft<T, CONV, EN>;
+        const int C = c_xy(axis);
+        const size_t lds = (size_t)P.n[axis] * sizeof(T2) * (1 + C * (CONV ? 2 : 1));
+        big_lds(kern, lds);
+        const int64_t n_lines = (int64_t)P.n[0] * P.n[1] * nzh / P.n[axis];
+        hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(n_lines, (int64_t)C)), dim3(PME_THREADS), lds, s, dft_args(axis, sign, C, e_part));
+    }
+    void z_r2c(hipStream_t s) {
+        const int C = c_r2c();
+        const size_t lds = (size_t)P.n[2] * sizeof(T2) + (size_t)P.n[2] * C * sizeof(T);
+        big_lds(k_pme_z_r2c<T>, lds);
+        hipLaunchKernelGGL(k_pme_z_r2c<T>, dim3((unsigned)cdiv((int64_t)P.n[0] * P.n[1], (int64_t)C)), dim3(PME_THREADS), lds, s, dft_args(2, -1, C, nullptr));
+    }
+    void z_c2r(hipStream_t s) {
+        const int C = c_c2r();
+        const size_t lds = (size_t)P.n[2] * sizeof(T2) + (size_t)nzh * C * sizeof(T2);
+        big_lds(k_pme_z_c2r<T>, lds);
+        hipLaunchKernelGGL(k_pme_z_c2r<T>, dim3((unsigned)cdiv((int64_t)P.n[0] * P.n[1], (int64_t)C)), dim3(PME_THREADS), lds, s, dft_args(2, +1, C, nullptr));
     }
 
     // ewald_pe_forces! (:873-929) on the sorted arrays: frc (nullable) gets the reciprocal-space forces ADDED; e_part (nullable)
-    // receives dft_blocks(0) partial sums of Σ eterm·|S|² (the caller halves them and adds the self terms).
+    // receives conv_blocks() partial sums of Σ eterm·|S|² (the caller halves them and adds the self terms).
     void run(hipStream_t s, int64_t n_atoms, const T4* pos, T4* frc, double* e_part) {
-        MHIP_HIP(hipMemsetAsync(rgrid.p, 0, rgrid.n * sizeof(T), s));
         if (order == 4) spread_t<4>(s, n_atoms, pos); else if (order == 5) spread_t<5>(s, n_atoms, pos); else spread_t<6>(s, n_atoms, pos);
-        dft<1, false>(s, 2, -1, nullptr);
-        dft<0, false>(s, 1, -1, nullptr);
-        if (e_part) dft<2, true>(s, 0, -1, e_part); else dft<2, false>(s, 0, -1, nullptr);
+        z_r2c(s);
+        dft_xy<false, false>(s, 1, -1, nullptr);
+        if (e_part) dft_xy<true, true>(s, 0, -1, e_part); else dft_xy<true, false>(s, 0, -1, nullptr);
         if (frc) {
-            dft<0, false>(s, 1, +1, nullptr);
-            dft<0, false>(s, 2, +1, nullptr);
+            dft_xy<false, false>(s, 1, +1, nullptr);
+            z_c2r(s);
             if (order == 4) gather_t<4>(s, n_atoms, pos, frc); else if (order == 5) gather_t<5>(s, n_atoms, pos, frc); else gather_t<6>(s, n_atoms, pos, frc);
         }
         MHIP_HIP(hipGetLastError());
