@@ -102,6 +102,8 @@ struct Prof {
 
 static int env_int(const char* name, int dflt) { const char* v = std::getenv(name); return v && *v ? std::atoi(v) : dflt; }
 
+void launch_forces_uniform_f32(const ForceArgs<float>& A, bool seg, bool prune, size_t lds, unsigned threads, hipStream_t stream);
+
 template <class T> class Engine final : public EngineBase {
     using T4 = typename Vec<T>::T4;
     using T2 = typename Vec<T>::T2;
@@ -536,6 +538,10 @@ template <class T> class Engine final : public EngineBase {
 
     // ---------------------------------------------------------------------------------------------
     template <int LJM, int COULM, bool ENERGY, bool MINIMG, bool SEGM, bool PRUNE> void launch_forces_k(const ForceArgs<T>& A) {
+        if constexpr (std::is_same<T, float>::value && LJM == LJ_DIST_UNIFORM && COULM == MHIP_COUL_NONE && !ENERGY && !MINIMG) {
+            launch_forces_uniform_f32(A, SEGM, PRUNE, lds_force, (unsigned)(BI * JS), stream);   // compiled in forces_uniform.hip
+            return;
+        }
         auto kern = k_forces<T, LJM, COULM, ENERGY, MINIMG, SEGM, PRUNE>;
         set_lds_limit(kern, lds_force);
         hipLaunchKernelGGL(kern, dim3(A.blocks_per_xcd * 8), dim3(BI * JS), lds_force, stream, A);

@@ -496,7 +496,7 @@ __global__ void k_build(BuildArgs<T> A) {
 }
 
 // reduce the per-block / per-wave results of k_build or k_filter into the flag words the host reads (flags zeroed before)
-__global__ void k_build_summary(int n_blocks, int n_waves, int R_cap, const int32_t* __restrict__ tile_cnt, int32_t* wave_rows,
+[[maybe_unused]] static __global__ void k_build_summary(int n_blocks, int n_waves, int R_cap, const int32_t* __restrict__ tile_cnt, int32_t* wave_rows,
                                 const float* __restrict__ blk_disp2, int32_t* flags) {
     __shared__ int sh_t[256], sh_r[256], sh_s[256]; __shared__ float sh_d[256];
     int mt = 0, mr = 0, tot = 0; float md = 0.f;
@@ -797,6 +797,45 @@ __global__ void k_forces(ForceArgs<T> A) {
         auto walk_rows = [&](auto spec_tag) {
             constexpr bool SPEC = decltype(spec_tag)::value;
             uint2 e_next = (0 < rows) ? my_rows[0] : make_uint2(0, 0);
+            // One-type fp32 LJ fluid without special pairs (the 1M-atom benchmark): the pair arithmetic written on float2 values —
+            // (x, y) of one partner as they come out of ds_read_b96, then the radial part of two partners side by side — so that it
+            // maps onto v_pk_{add,mul,fma}_f32 without the register shuffles of the auto-vectorised generic loop (forces_uniform.hip
+            // is compiled with the SLP vectoriser off).  Same operation order per pair as pair_eval.
+            if constexpr (std::is_same<T, float>::value && LJM == LJ_DIST_UNIFORM && COULM == MHIP_COUL_NONE && !ENERGY && !MINIMG && !SEG && !SPEC) {
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                const v2f pixy = {(float)pi.x, (float)pi.y};   // (casts: the branch must also parse for T = double)
+                const float piz = (float)pi.z, s2 = (float)A.I.lj_s2, c24 = (float)A.I.lj_24e, rc2 = (float)A.I.lj_rc2, rp2 = (float)A.r_prune2;
+                float fzf = (float)fz;
+                v2f fxy = {(float)fx, (float)fy};
+                for (int r = 0; r < rows; ++r) {
+                    const uint2 e4 = e_next;
+                    if (r + 1 < rows) e_next = my_rows[(int64_t)(r + 1) * A.BI];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t w = h ? e4.y : e4.x;
+                        const uint32_t sa = w & 0x7fffu, sb = (w >> 16) & 0x7fffu;
+                        const T4 pa = l_pos[sa], pb = l_pos[sb];
+                        const v2f da = (v2f){(float)pa.x, (float)pa.y} - pixy, db = (v2f){(float)pb.x, (float)pb.y} - pixy;
+                        const float dza = (float)pa.z - piz, dzb = (float)pb.z - piz;
+                        const v2f qa = da * da, qb = db * db;
+                        v2f r2;
+                        r2.x = __builtin_fmaf(dza, dza, qa.x) + qa.y;
+                        r2.y = __builtin_fmaf(dzb, dzb, qb.x) + qb.y;
+                        if constexpr (PRUNE) {
+                            if (sa < (uint32_t)tile_n && valid && r2.x <= rp2) { emit(w & 0xffffu); l_mark[sa] = 1; }
+                            if (sb < (uint32_t)tile_n && valid && r2.y <= rp2) { emit(w >> 16); l_mark[sb] = 1; }
+                        }
+                        const v2f inv = {__builtin_amdgcn_rcpf(r2.x), __builtin_amdgcn_rcpf(r2.y)};
+                        v2f six = inv * s2; six = six * six * six;
+                        v2f f = (six * (six + six - 1.0f)) * inv * c24;
+                        f.x = r2.x <= rc2 ? f.x : 0.f; f.y = r2.y <= rc2 ? f.y : 0.f;
+                        fxy -= da * f.x; fxy -= db * f.y;
+                        fzf -= dza * f.x; fzf -= dzb * f.y;
+                    }
+                }
+                fx = (T)fxy.x; fy = (T)fxy.y; fz = (T)fzf;
+                return;
+            }
             for (int r = 0; r < rows; ++r) {
                 const uint2 e4 = e_next;
                 if (r + 1 < rows) e_next = my_rows[(int64_t)(r + 1) * A.BI];
@@ -1086,7 +1125,7 @@ __global__ void k_ke_partials(int64_t n, const typename Vec<T>::T4* __restrict__
 }
 
 // one block: fixed-order sum of n doubles
-__global__ void k_sum_double(int n, const double* __restrict__ part, double* out) {
+[[maybe_unused]] static __global__ void k_sum_double(int n, const double* __restrict__ part, double* out) {
     __shared__ double sh[256];
     double a = 0;
     for (int q = threadIdx.x; q < n; q += blockDim.x) a += part[q];
