@@ -164,10 +164,21 @@ class HipDomainEngine:
         self._chk(self.L.mhip_vv_stage2(self.ctx, step, dt))
 
     def halo_begin(self, dt, idx_i32, shift, out):
-        self._chk(self.L.mhip_vv_halo_begin(self.ctx, dt, self._p(idx_i32), self._p(shift), idx_i32.numel(), self._p(out)))
+        # the buffers of a ghost plan do not change between re-plans: their ctypes pointers are built once per plan
+        key = (idx_i32.data_ptr(), shift.data_ptr(), out.data_ptr(), idx_i32.numel())
+        if getattr(self, "_hb_key", None) != key:
+            self._hb_key, self._hb = key, (self._p(idx_i32), self._p(shift), C.c_int64(idx_i32.numel()), self._p(out))
+        rc = self.L.mhip_vv_halo_begin(self.ctx, dt, *self._hb)
+        if rc != 0:
+            self._chk(rc)
 
     def halo_end(self, step, dt, first, n, buf, cm_out4):
-        self._chk(self.L.mhip_vv_halo_end(self.ctx, step, dt, first, n, self._p(buf), self._p(cm_out4)))
+        key = (buf.data_ptr(), None if cm_out4 is None else cm_out4.data_ptr())
+        if getattr(self, "_he_key", None) != key:
+            self._he_key, self._he = key, (self._p(buf), self._p(cm_out4))
+        rc = self.L.mhip_vv_halo_end(self.ctx, step, dt, first, n, *self._he)
+        if rc != 0:
+            self._chk(rc)
 
     def plan_disp2(self, out1_f32):       # device float[1]
         self._chk(self.L.mhip_plan_disp2_dev(self.ctx, self._p(out1_f32)))
