@@ -208,6 +208,7 @@ __global__ void k_build(BuildArgs<T> A) {
     __shared__ T s_sub[4][6];                                 // per-wave bounding boxes of the i-atoms
     __shared__ T s_ctr[3], s_half[3];
     __shared__ int s_boxlo[3], s_boxlen[3], s_full[3], s_exact, s_wtot[16];
+    __shared__ int s_self[256];                                // tile slot of each i-atom itself (BI <= 256)
 
     // 0. bounding boxes: one per wave of i-atoms (tight pruning for elongated blocks) and their union
     const int64_t si = (int64_t)b * A.BI + li;
@@ -339,7 +340,11 @@ __global__ void k_build(BuildArgs<T> A) {
         int dst = tile_n + __popcll(m & ((1ull << lane) - 1ull));
         int tot = 0;
         for (int w = 0; w < NW_ALL; ++w) { if (w < wv_all) dst += s_wtot[w]; tot += s_wtot[w]; }
-        if (keep && dst < A.T_cap) { t_pos[dst] = make_float4((float)p.x, (float)p.y, (float)p.z, 0.f); t_orig[dst] = A.orig[s]; A.tile_idx[(int64_t)b * A.T_cap + dst] = s; }
+        if (keep && dst < A.T_cap) {
+            t_pos[dst] = make_float4((float)p.x, (float)p.y, (float)p.z, 0.f); t_orig[dst] = A.orig[s]; A.tile_idx[(int64_t)b * A.T_cap + dst] = s;
+            const int64_t rel = (int64_t)s - (int64_t)b * A.BI;
+            if (rel >= 0 && rel < A.BI) s_self[rel] = dst;     // an i-atom always survives the pruning of its own block
+        }
         tile_n += tot;
         __syncthreads();
     }
@@ -388,6 +393,7 @@ __global__ void k_build(BuildArgs<T> A) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) { blo[d] = (float)(s_sub[wv][d] - ctr[d]); bhi[d] = (float)(s_sub[wv][3 + d] - ctr[d]); }
         const unsigned long long valid_mask = __ballot(valid);
+        const uint32_t self_t = valid ? (uint32_t)s_self[li] : 0xffffffffu;
         // this wave's share of the tile: the atoms t ≡ js (mod JS), a uniform sample in tile order, so that the JS
         // sub-lists of an i-atom come out equally long (little sentinel padding)
         const int nwords = (tile_n + 64 * A.JS - 1) / (64 * A.JS);
@@ -469,9 +475,9 @@ __global__ void k_build(BuildArgs<T> A) {
                 const int bit = __builtin_ctzll(mm);
                 mm &= mm - 1;
                 const uint32_t t = (uint32_t)(((w << 6) + bit) * A.JS + js);
-                const int oj = t_orig[t];
-                if (oj == oi) continue;
+                if (t == self_t) continue;                       // the atom itself (no LDS lookup on the common path)
                 uint32_t sp = 0;
+                const int oj = nxl > 0 ? t_orig[t] : 0;
                 if (nxl > 0 && (unsigned)(oj - oi + A.xl_span) <= (unsigned)(2 * A.xl_span)) {
                     uint32_t hit = 0;
                     for (int k = 0; k < nxl; ++k) {
