@@ -72,3 +72,19 @@ def test_pme_rejects_what_it_does_not_cover(pkg):
     case = S.charged_fluid(6, dict(kind="ewald", rc=0.9, tol=5e-4), dtype=np.float32, pme=dict(order=7), r_list=0.9, with_exceptions=False)
     with pytest.raises(pkg.MollyHipError):
         pkg.forces(case.system(pkg, np.float32), pairwise=False)
+
+
+def test_complete_pme_step_conserves_energy_fp64(pkg):
+    """NVE with every interaction incl. reciprocal PME (Float64, dt 0.5 fs, remove_CM_motion = 0): forces and energies of the
+    direct, reciprocal and exclusion parts belong to one Hamiltonian — the total energy stays bounded and returns at equal phase of
+    the O-H ringing (same bars as the reaction-field run of test_gpu_6mrr.py)."""
+    case = G.case("ewald", np.float64, bonded=True, approx_erfc=False, pme=True)
+    s = case.system(pkg, np.float64)
+    e0 = pkg.total_energy(s)
+    assert e0 + G.lj_dispersion_correction() == pytest.approx(96522.24858589929, abs=1e-3)     # test/protein.jl:285
+    es = [e0]
+    for k in range(10):
+        pkg.simulate(s, pkg.VelocityVerlet(dt=0.0005, remove_CM_motion=0), 20, init_step=20 * k)
+        es.append(pkg.total_energy(s))
+    assert max(abs(e - e0) for e in es) < 0.06 * abs(e0)
+    assert abs(es[5] - e0) < 2e-3 * abs(e0) and abs(es[-1] - e0) < 5e-3 * abs(e0)
