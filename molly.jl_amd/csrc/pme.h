@@ -65,7 +65,7 @@ template <class T, int ORDER> __device__ inline T pick(const T* a, int i) {   //
 // XCD the calling wave runs on (0..7): HW_REG_XCC_ID, bits 3:0
 __device__ inline int xcc_id() { return (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 7u); }
 constexpr int PME_COPIES = 8;
-constexpr int PME_AB = 64;       // atoms per block and round of the spread / gather kernels
+constexpr int PME_AB = 16;       // atoms per block and round of the gather kernel (small batches: many short blocks; 64 -> 16 halved its time)
 
 // Phase 1 of spread and gather: ONE lane per atom evaluates grid_placement_inner! and update_bsplines_inner! (the recursion is
 // serial and identical for every mesh point of the atom) and parks first index, charge and the 3·ORDER weights (and
