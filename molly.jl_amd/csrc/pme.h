@@ -8,8 +8,8 @@
 // library FFT (Bluestein chains of many small launches for such sizes) the three axis transforms are direct DFTs on
 // LDS-staged line tiles: any n, one launch per axis, and the x pass does forward-x · influence function · backward-x in
 // one kernel, so a whole reciprocal evaluation is 7 launches:
-//   spread (float atomics into one real mesh per XCD, 32 lanes per atom) → z (sums the copies) → y → x·conv·x⁻¹ → y⁻¹ → z⁻¹
-//   → gather (32 lanes per atom).
+//   spread (LDS sub-mesh per atom batch, one float atomic per touched mesh point) → z real-to-complex → y → x·conv·x⁻¹ → y⁻¹
+//   → z complex-to-real → gather (32 lanes per atom).
 // Grid layout: complex<T> at ((x·ny + y)·nz + z), z fastest (the reference's charge_grid[z, y, x]).
 #pragma once
 #include <vector>
@@ -62,9 +62,6 @@ template <class T, int ORDER> __device__ inline T pick(const T* a, int i) {   //
     return v;
 }
 
-// XCD the calling wave runs on (0..7): HW_REG_XCC_ID, bits 3:0
-__device__ inline int xcc_id() { return (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 7u); }
-constexpr int PME_COPIES = 8;
 constexpr int PME_AB = 16;       // atoms per block and round of the gather kernel (small batches: many short blocks; 64 -> 16 halved its time)
 
 // Phase 1 of spread and gather: ONE lane per atom evaluates grid_placement_inner! and update_bsplines_inner! (the recursion is
@@ -98,8 +95,8 @@ __device__ inline void pme_atom_tables(int64_t a0, int64_t n_atoms, const typena
 // ORDER³ weights into an LDS sub-mesh that covers the batch's bounding box (ds_add_f32; relative mesh indices, so the box may
 // straddle the periodic boundary).  Phase 3: the sub-mesh is flushed with ONE global float atomic per touched mesh point —
 // several times fewer than one per (atom, point).  A batch whose box does not fit the LDS sub-mesh (a jump of the curve) falls
-// back to direct global atomics.  Global atomics resolve in the L2 of the issuing XCD; each XCD accumulates into its OWN real
-// mesh (selected by the hardware XCC id) and the first transform pass sums the copies.
+// back to direct global atomics.  (One mesh per XCD, selected by the hardware XCC id, was measured too: the spread did not get
+// faster and the first transform pass paid for summing and re-zeroing eight copies.)
 constexpr int PME_BOX_BYTES = 24 * 1024;   // LDS sub-mesh
 
 template <class T, int ORDER, int PME_SB>
@@ -108,7 +105,7 @@ __global__ void __launch_bounds__(256) k_pme_spread(int64_t n_atoms, const typen
     constexpr int PME_BOX = PME_BOX_BYTES / (int)sizeof(T);
     __shared__ T l_box[PME_BOX]; __shared__ int l_lo[3], l_hi[3];
     const int tid = threadIdx.x, sub = tid & 31, hw = tid >> 5;
-    T* mesh = rgrid + (int64_t)xcc_id() * P.n[0] * P.n[1] * P.n[2];
+    T* mesh = rgrid;
     for (int64_t a0 = (int64_t)blockIdx.x * PME_SB; a0 < n_atoms; a0 += (int64_t)gridDim.x * PME_SB) {
         __syncthreads();
         // phase 1 (one thread per atom)
@@ -252,7 +249,7 @@ __global__ void __launch_bounds__(256) k_pme_gather(int64_t n_atoms, const typen
 // The 3-D transform, one launch per axis, as direct DFTs on LDS-staged line tiles: a block stages C whole lines ([j][c],
 // c = line within the tile) and every thread owns ONE output (k, c), so a pass is many short, independent waves.
 // The charge mesh is real, so only the half spectrum kz = 0 … nz/2 is carried (Hermitian symmetry halves every pass):
-//   k_pme_z_r2c   real lines (sum of the per-XCD meshes) → nzh = nz/2+1 complex outputs per line
+//   k_pme_z_r2c   real lines → nzh = nz/2+1 complex outputs per line (and zeroes the charge mesh behind it)
 //   k_pme_dft     y, then x, on the half grid (nx, ny, nzh); the x pass (CONV) does forward · influence function · backward
 //   k_pme_z_c2r   Hermitian half lines → real potential mesh, φ[z] = Re X₀ + 2 Σ_{0<k<nz/2} Re(X_k w^{kz}) (+ Nyquist term)
 // Half-grid layout: complex<T> at ((x·ny + y)·nzh + kz).  Line q of the y pass = x·nzh + kz (start x·ny·nzh + kz, stride nzh),
@@ -261,7 +258,7 @@ constexpr int PME_THREADS = 256;
 
 template <class T> struct DftArgs {
     typename Vec<T>::T2* grid;            // half grid
-    T* rgrid;                             // r2c: [PME_COPIES][nx·ny·nz] real charge meshes (read, then zeroed for the next spread)
+    T* rgrid;                             // r2c: [nx·ny·nz] real charge mesh (read, then zeroed for the next spread)
     T* phi;                               // c2r: [nx·ny·nz] real potential mesh
     const typename Vec<T>::T2* tw;        // [n] e^{-2πi m/n} of this axis
     const T* mh[3];                       // [n_d] signed frequency / L_d
@@ -286,8 +283,7 @@ __global__ void __launch_bounds__(PME_THREADS) k_pme_z_r2c(DftArgs<T> A) {
         T v = T(0);
         if (c < n_here) {
             const int64_t at = (q0 + c) * nz + j;
-#pragma unroll
-            for (int k = 0; k < PME_COPIES; ++k) { v += A.rgrid[k * n_mesh + at]; A.rgrid[k * n_mesh + at] = T(0); }
+            v = A.rgrid[at]; A.rgrid[at] = T(0);
         }
         l_a[j * C + c] = v;
     }
@@ -447,7 +443,7 @@ template <class T> struct Pme {
     int order = 0;
     PmeP<T> P;
     PBuf<T2> grid, tw[3];
-    PBuf<T> mh[3], bsm[3], rgrid, phi; // rgrid: PME_COPIES real charge meshes, one per XCD; phi: real potential mesh
+    PBuf<T> mh[3], bsm[3], rgrid, phi; // rgrid: real charge mesh; phi: real potential mesh
     int nzh = 0;                       // half-spectrum length along z
     double self_factor = 0, charge_factor = 0;   // E_self = −f/ϵr·α/√π·Σq²  and  E_charge = −f/ϵr·π/(2Vα²)·(Σq)²   (:917-927)
 
@@ -515,7 +511,7 @@ template <class T> struct Pme {
         }
         nzh = P.n[2] / 2 + 1;
         grid.alloc((size_t)P.n[0] * P.n[1] * nzh);
-        rgrid.alloc((size_t)PME_COPIES * P.n[0] * P.n[1] * P.n[2]);
+        rgrid.alloc((size_t)P.n[0] * P.n[1] * P.n[2]);
         MHIP_HIP(hipMemset(rgrid.p, 0, rgrid.n * sizeof(T)));     // from here on k_pme_z_r2c leaves the meshes zeroed behind it
         phi.alloc((size_t)P.n[0] * P.n[1] * P.n[2]);
     }
