@@ -656,7 +656,7 @@ template <class T> class Engine final : public EngineBase {
             MHIP_HIP(hipStreamWaitEvent(side[k], ev_pos, 0));
             MHIP_HIP(hipMemsetAsync(frc_side[k].p, 0, (size_t)n_owned * sizeof(T4), side[k]));
             prof.begin(k == 0 ? 5 : 6, side[k]);
-            if (k == 0) bonded.launch_forces(side[k], G, I, pos[cur].p, inv.p, frc_side[k].p);
+            if (k == 0) bonded.launch_forces(side[k], G, I, pos[cur].p, inv.p, frc_side[k].p, orig[cur].p, n_owned, cap);
             else pme.run(side[k], n_owned, pos[cur].p, frc_side[k].p, nullptr);
             prof.end(k == 0 ? 5 : 6, side[k]);
             MHIP_HIP(hipEventRecord(ev_side[k], side[k]));
@@ -670,7 +670,7 @@ template <class T> class Engine final : public EngineBase {
             redo = true;
         }
         pend_a = pend_b = nullptr;
-        if (redo || !side_b) { if (bonded.any()) { prof.begin(5, stream); bonded.launch_forces(stream, G, I, pos[cur].p, inv.p, frc[cur].p); prof.end(5, stream); } }
+        if (redo || !side_b) { if (bonded.any()) { prof.begin(5, stream); bonded.launch_forces(stream, G, I, pos[cur].p, inv.p, frc[cur].p, orig[cur].p, n_owned, cap); prof.end(5, stream); } }
         else { MHIP_HIP(hipStreamWaitEvent(stream, ev_side[0], 0)); pend_a = frc_side[0].p; }
         if (redo || !side_p) launch_pme_forces();
         else { MHIP_HIP(hipStreamWaitEvent(stream, ev_side[1], 0)); pend_b = frc_side[1].p; }
@@ -824,7 +824,7 @@ template <class T> class Engine final : public EngineBase {
     void specific_forces(int accumulate, void* f_xyz, int mem_kind) override {
         if (!state_set) throw ApiError{MHIP_ERR_STATE, "set_state must be called before specific_forces"};
         MHIP_HIP(hipMemsetAsync(frc[cur].p, 0, (size_t)n_tot * sizeof(T4), stream));
-        bonded.launch_forces(stream, G, I, pos[cur].p, inv.p, frc[cur].p);
+        bonded.launch_forces(stream, G, I, pos[cur].p, inv.p, frc[cur].p, orig[cur].p, n_owned, cap);
         frc_valid = false;
         export_frc(accumulate, f_xyz, mem_kind);
     }
