@@ -156,17 +156,22 @@ __global__ void __launch_bounds__(256) k_pme_spread(int64_t n_atoms, const typen
         }
         __syncthreads();
         if (!empty) {
-            for (int t = hw; t < PME_SB; t += 8) {
+            // the two half-waves of a wave take atoms half a batch apart: neighbours in the sorted order overlap in the sub-mesh and
+            // their ds_add_f32 would hit the same addresses in the same instruction
+            for (int t = (hw >> 1) + (hw & 1) * (PME_SB / 2), k = 0; k < PME_SB / 8; ++k, t += 4) {
                 const T q = l_q[t];
                 if (q == T(0)) continue;                                   // also the atoms past the end
                 const int bx = l_i[t], by = l_i[PME_SB + t], bz = l_i[2 * PME_SB + t];
                 for (int pr = sub; pr < ORDER * ORDER; pr += 32) {
                     const int iy = pr / ORDER, iz = pr - iy * ORDER;
                     const T qyz = (q * l_w[(ORDER + iy) * PME_SB + t]) * l_w[(2 * ORDER + iz) * PME_SB + t];
+                    T wx[ORDER];                       // all x weights first: the adds below then issue back to back
+#pragma unroll
+                    for (int ix = 0; ix < ORDER; ++ix) wx[ix] = l_w[ix * PME_SB + t] * qyz;
                     if (fits) {
                         T* col = l_box + (by + iy) * ez + (bz + iz);
 #pragma unroll
-                        for (int ix = 0; ix < ORDER; ++ix) atomicAdd(col + (bx + ix) * ey * ez, l_w[ix * PME_SB + t] * qyz);
+                        for (int ix = 0; ix < ORDER; ++ix) atomicAdd(col + (bx + ix) * ey * ez, wx[ix]);
                     } else {
                         int yi = by + iy; yi -= yi >= P.n[1] ? P.n[1] : 0;
                         int zi = bz + iz; zi -= zi >= P.n[2] ? P.n[2] : 0;
@@ -174,7 +179,7 @@ __global__ void __launch_bounds__(256) k_pme_spread(int64_t n_atoms, const typen
 #pragma unroll
                         for (int ix = 0; ix < ORDER; ++ix) {
                             int xi = bx + ix; xi -= xi >= P.n[0] ? P.n[0] : 0;
-                            atomicAdd(col + (int64_t)xi * P.n[1] * P.n[2], l_w[ix * PME_SB + t] * qyz);
+                            atomicAdd(col + (int64_t)xi * P.n[1] * P.n[2], wx[ix]);
                         }
                     }
                 }
