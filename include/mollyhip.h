@@ -255,7 +255,12 @@ int32_t mhip_remove_cm_dev(mhip_ctx* ctx, const double* total4_dev);
  * re-plan when 2 sqrt(d2) nears margin).  +inf means "re-plan at every rebuild step" (margin 0, or an interaction
  * without a cutoff <= r_list).  A force pass that finds the margin already exceeded fails with MHIP_ERR_STATE. */
 int32_t mhip_set_ghost_margin(mhip_ctx* ctx, double margin);
+/* out_dev: float[2] = { max |x - x_plan|^2 since the plan's outer search, max |x - x_prune|^2 since the inner list was last pruned }.
+ * With a ghost margin the HOST schedules the prunes (all ranks at the same step): when 2 sqrt(out[1]) is about to use up the skin
+ * r_list - max cutoff it either calls mhip_request_prune — the next force pass then re-prunes the outer list, which needs
+ * 2 sqrt(out[0]) <= margin at that moment — or re-plans. */
 int32_t mhip_plan_disp2_dev(mhip_ctx* ctx, float* out_dev);
+int32_t mhip_request_prune(mhip_ctx* ctx);
 /* One MD step of a ghosted sub-domain in two launches-batches around the ghost exchange:
  *   vv_halo_begin = vv_stage1 + gather_coords;   vv_halo_end = scatter_coords + vv_stage2 (+ this rank's
  *   {Σ m v, Σ m} into cm_out4_dev when non-NULL, to be all-reduced and handed back through mhip_remove_cm_dev). */
@@ -263,6 +268,12 @@ int32_t mhip_vv_halo_begin(mhip_ctx* ctx, double dt, const int32_t* idx_dev, con
                            int64_t n_send, void* send_dev);
 int32_t mhip_vv_halo_end(mhip_ctx* ctx, int64_t step_n, double dt, int64_t first_ghost, int64_t n_ghost,
                          const void* recv_dev, double* cm_out4_dev);
+/* The same without the finalize launch: cm_parts_dev receives n_parts (<= 1024) per-block partials {Σ m vx, Σ m vy, Σ m vz, Σ m}
+ * (double[4·n_parts], unused ones zero).  The host SUM-all-reduces the whole array over the ranks and hands it back through
+ * mhip_remove_cm_parts_dev; the next first kick re-sums it in fixed order.  The array must stay untouched until then. */
+int32_t mhip_vv_halo_end_parts(mhip_ctx* ctx, int64_t step_n, double dt, int64_t first_ghost, int64_t n_ghost,
+                               const void* recv_dev, double* cm_parts_dev, int32_t n_parts);
+int32_t mhip_remove_cm_parts_dev(mhip_ctx* ctx, const double* total_parts_dev, int32_t n_parts);
 
 #ifdef __cplusplus
 }

@@ -98,8 +98,11 @@ SIGNATURES = {
     "mhip_general_potential_energy": (_I32, [_P, C.POINTER(_D)]),
     "mhip_set_ghost_margin": (_I32, [_P, _D]),
     "mhip_plan_disp2_dev": (_I32, [_P, _P]),
+    "mhip_request_prune": (_I32, [_P]),
     "mhip_vv_halo_begin": (_I32, [_P, _D, _P, _P, _I64, _P]),
     "mhip_vv_halo_end": (_I32, [_P, _I64, _D, _I64, _I64, _P, _P]),
+    "mhip_vv_halo_end_parts": (_I32, [_P, _I64, _D, _I64, _I64, _P, _P, _I32]),
+    "mhip_remove_cm_parts_dev": (_I32, [_P, _P, _I32]),
 }
 
 

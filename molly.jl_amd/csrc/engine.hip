@@ -67,8 +67,11 @@ struct EngineBase {
     virtual double general_potential_energy() = 0;
     virtual void set_ghost_margin(double) = 0;
     virtual void plan_disp2_dev(float*) = 0;
+    virtual void request_prune() = 0;
     virtual void halo_begin(double, const int32_t*, const void*, int64_t, void*) = 0;
     virtual void halo_end(int64_t, double, int64_t, int64_t, const void*, double*) = 0;
+    virtual void halo_end_parts(int64_t, double, int64_t, int64_t, const void*, double*, int32_t) = 0;
+    virtual void remove_cm_parts_dev(const double*, int32_t) = 0;
 };
 
 // hipEvent stage timers (only active while profiling is on)
@@ -138,6 +141,7 @@ template <class T> class Engine final : public EngineBase {
     // ghosted sub-domain whose ghost shell reaches r_list + ghost_margin: the ghost PLAN then lives as long as an outer list
     // (until some atom moved ghost_margin/2), so the dual list works here too and the host re-plans only when mhip_plan_disp2_dev says so
     double ghost_margin = 0; const double* cm_ext = nullptr;
+    bool host_prune = false;     // ghost plans: the HOST decides, collectively over the ranks, when the inner list is re-pruned (mhip_request_prune)
     // single list, same idea: a rebuild step whose displacement check shows the list still covers every cutoff sphere is skipped
     bool lazy_single = false; int64_t n_skipped = 0;
     bool dual = false, dual_disabled = false; int early_outer = 0; double outer_margin = 0; int outer_every = 1; int64_t last_outer_step = 0, n_outer = 0, n_filters = 0; T r_in = 0, r_in2 = 0;
@@ -506,6 +510,7 @@ template <class T> class Engine final : public EngineBase {
         // The inner list (pairs within r_list when it was pruned) provably contains every pair within the cutoffs as long as no atom
         // moved more than skin/2 since then — the condition the reference's fixed cadence only assumes.  Check it; re-prune (inside
         // the next force pass) only when it is about to fail.  mhip_export_neighbors always returns the exact list of NOW.
+        if (host_prune && inner_valid && !strict_cadence) { last_build_step = step_n; ++n_rebuilds; return; }   // the host calls mhip_request_prune
         bool reprune = strict_cadence || !inner_valid;
         if (!reprune) {
             const float d2 = max_disp2_since(pos_snap_in);
@@ -729,14 +734,17 @@ template <class T> class Engine final : public EngineBase {
         // one atom type (every σ, ϵ equal and non-zero, no λ = 0) + DistanceCutoff → uniform-LJ kernel variant
         ljm = ljm_base;
         if (ljm_base == LJ_DIST && ds && de && !(env_int("MOLLYHIP_NO_UNIFORM_LJ", 0))) {
-            std::vector<T> hs(n_tot), he(n_tot), hl;
-            MHIP_HIP(hipMemcpy(hs.data(), ds, n_tot * sizeof(T), hipMemcpyDeviceToHost));
-            MHIP_HIP(hipMemcpy(he.data(), de, n_tot * sizeof(T), hipMemcpyDeviceToHost));
-            if (dl) { hl.resize(n_tot); MHIP_HIP(hipMemcpy(hl.data(), dl, n_tot * sizeof(T), hipMemcpyDeviceToHost)); }
-            bool uni = hs[0] != T(0) && he[0] != T(0);
-            for (int64_t i = 0; i < n_tot && uni; ++i) uni = hs[i] == hs[0] && he[i] == he[0] && (hl.empty() || hl[i] != T(0));
+            // decided on the device (a sub-domain hands its parameters over at every re-plan): flag ≠ 0 if some σ, ϵ differs from atom 0's or a λ is 0
+            MHIP_HIP(hipMemsetAsync(flags.p, 0, N_FLAGS * sizeof(int32_t), stream));
+            hipLaunchKernelGGL(k_uniform_check<T>, dim3(std::min(cdiv(n_tot, 256), 1024)), dim3(256), 0, stream, n_tot, ds, de, dl, flags.p);
+            T h2[2] = {T(0), T(0)};
+            MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            MHIP_HIP(hipMemcpyAsync(&h2[0], ds, sizeof(T), hipMemcpyDeviceToHost, stream));
+            MHIP_HIP(hipMemcpyAsync(&h2[1], de, sizeof(T), hipMemcpyDeviceToHost, stream));
+            MHIP_HIP(hipStreamSynchronize(stream));
+            const bool uni = h_flags[FLAG_NAN] == 0 && h2[0] != T(0) && h2[1] != T(0);
             if (uni) {
-                T sm = (hs[0] + hs[0]) / T(2), em = std::sqrt(he[0] * he[0]);   // the mixing rules applied to equal values
+                T sm = (h2[0] + h2[0]) / T(2), em = std::sqrt(h2[1] * h2[1]);   // the mixing rules applied to equal values
                 I.lj_s2 = sm * sm; I.lj_24e = T(24) * em; I.lj_4e = T(4) * em;
                 ljm = LJ_DIST_UNIFORM;
             }
@@ -946,12 +954,13 @@ template <class T> class Engine final : public EngineBase {
         prof.end(2, stream);
         cm_pending = 0; cm_ext = nullptr;
     }
-    void stage2_impl(int64_t step_n, double dt, bool cm) {
+    void stage2_impl(int64_t step_n, double dt, bool cm, double* cm_parts_ext = nullptr, int n_parts_ext = 0) {
         step_forces(step_n);
-        const int nb = std::min(cdiv(n_owned, 256), 1024);
+        // with an external partial buffer every one of its n_parts_ext slots gets a block (blocks without atoms write zeros)
+        const int nb = cm_parts_ext ? n_parts_ext : std::min(cdiv(n_owned, 256), 1024);
         prof.begin(2, stream);
         if (cm) {
-            hipLaunchKernelGGL((k_vv2<T, true>), dim3(nb), dim3(256), 0, stream, n_owned, vel[cur].p, frc[cur].p, T(dt) / T(2), cm_step.p, pend_a, pend_b);
+            hipLaunchKernelGGL((k_vv2<T, true>), dim3(nb), dim3(256), 0, stream, n_owned, vel[cur].p, frc[cur].p, T(dt) / T(2), cm_parts_ext ? cm_parts_ext : cm_step.p, pend_a, pend_b);
             cm_pending = 2; n_cm_step = nb;   // the next k_vv1 (or any flush) re-sums the partials: no finalize launch
         } else {
             hipLaunchKernelGGL((k_vv2<T, false>), dim3(nb), dim3(256), 0, stream, n_owned, vel[cur].p, frc[cur].p, T(dt) / T(2), (double*)nullptr, pend_a, pend_b);
@@ -961,11 +970,11 @@ template <class T> class Engine final : public EngineBase {
     }
     // the neighbour cadence of a stepwise-driven run: as in vv_run.  A ghosted sub-domain without the dual list is re-planned
     // (set_atom_counts / set_state → stale) by the host at every rebuild step instead.
-    void stage2_cadenced(int64_t step_n, double dt, bool cm) {
+    void stage2_cadenced(int64_t step_n, double dt, bool cm, double* cm_parts_ext = nullptr, int n_parts_ext = 0) {
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         const bool due = step_n % every == 0 && step_n != last_build_step && (n_ghost == 0 || dual);
         if (due && dual) refresh(step_n);
-        stage2_impl(step_n, dt, cm);
+        stage2_impl(step_n, dt, cm, cm_parts_ext, n_parts_ext);
         if (due && !dual) refresh(step_n);
     }
     void vv_stage2(int64_t step_n, double dt) override {
@@ -973,19 +982,42 @@ template <class T> class Engine final : public EngineBase {
         MHIP_HIP(hipGetLastError());
     }
 
+    // the same with this rank's Σ m v left as n_parts per-block partials {Px, Py, Pz, M} in cm_parts_dev (no finalize launch): the
+    // host all-reduces the whole array and hands it back through remove_cm_parts_dev, where the next first kick re-sums it
+    void halo_end_parts(int64_t step_n, double dt, int64_t first, int64_t n, const void* in_dev, double* cm_parts_dev, int32_t n_parts) override {
+        if (cm_parts_dev && (n_parts < 1 || n_parts > 1024)) throw ApiError{MHIP_ERR_INVALID, "n_parts must be 1..1024"};
+        scatter_coords(first, n, in_dev);
+        stage2_cadenced(step_n, dt, cm_parts_dev != nullptr, cm_parts_dev, n_parts);
+        if (cm_parts_dev) { cm_pending = 0; cm_ext = nullptr; }
+        MHIP_HIP(hipGetLastError());
+    }
+    void remove_cm_parts_dev(const double* total_parts_dev, int32_t n_parts) override {
+        if (n_parts < 1 || n_parts > 1024) throw ApiError{MHIP_ERR_INVALID, "n_parts must be 1..1024"};
+        flush_cm();
+        cm_ext = total_parts_dev; n_cm_step = n_parts; cm_pending = 2;
+    }
+
     void set_ghost_margin(double m) override {
         if (!(m >= 0) || std::isinf(m)) throw ApiError{MHIP_ERR_INVALID, "ghost margin must be finite and >= 0"};
-        ghost_margin = m; stale = true;
+        ghost_margin = m; stale = true; host_prune = m > 0;
         if (n_ghost > 0) { setup_grid(); choose_blocking(); }
     }
     // max |x − x_plan|² over owned and ghost atoms since the outer search of the current ghost plan, as a float in device memory
     // (ready for a MAX all-reduce over the ranks); +inf when this sub-domain has to be re-planned at every rebuild step anyway
+    // out[0] = max |x − x_plan|² over owned and ghost atoms since the outer search of the current ghost plan, out[1] = the same since
+    // the last prune of the inner list — floats in device memory, ready for a MAX all-reduce over the ranks.  +inf in out[0] when this
+    // sub-domain has to be re-planned at every rebuild step anyway.
     void plan_disp2_dev(float* out_dev) override {
-        if (!dual || stale) { const uint32_t inf_bits = 0x7f800000u; MHIP_HIP(hipMemsetD32Async((hipDeviceptr_t)out_dev, (int)inf_bits, 1, stream)); return; }
-        MHIP_HIP(hipMemsetAsync(out_dev, 0, sizeof(float), stream));
-        hipLaunchKernelGGL(k_max_disp<T>, dim3(std::min(cdiv(n_tot, 256), 1024)), dim3(256), 0, stream, n_tot, (const T4*)pos[cur].p, (const T4*)pos_snap.p, reinterpret_cast<unsigned int*>(out_dev), G);
+        const uint32_t inf_bits = 0x7f800000u;
+        if (!dual || stale) { MHIP_HIP(hipMemsetD32Async((hipDeviceptr_t)out_dev, (int)inf_bits, 2, stream)); return; }
+        MHIP_HIP(hipMemsetAsync(out_dev, 0, 2 * sizeof(float), stream));
+        const dim3 g(std::min(cdiv(n_tot, 256), 1024));
+        hipLaunchKernelGGL(k_max_disp<T>, g, dim3(256), 0, stream, n_tot, (const T4*)pos[cur].p, (const T4*)pos_snap.p, reinterpret_cast<unsigned int*>(out_dev), G);
+        if (inner_valid) hipLaunchKernelGGL(k_max_disp<T>, g, dim3(256), 0, stream, n_tot, (const T4*)pos[cur].p, (const T4*)pos_snap_in.p, reinterpret_cast<unsigned int*>(out_dev) + 1, G);
+        else MHIP_HIP(hipMemsetD32Async((hipDeviceptr_t)(out_dev + 1), (int)inf_bits, 1, stream));
         MHIP_HIP(hipGetLastError());
     }
+    void request_prune() override { inner_valid = false; }
     // one MD step of a ghosted sub-domain in two calls around the ghost exchange
     void halo_begin(double dt, const int32_t* idx_dev, const void* shift_dev, int64_t n, void* out_dev) override {
         vv_stage1(dt);
@@ -1212,8 +1244,13 @@ int32_t mhip_set_pme(mhip_ctx* ctx, int32_t order, const int32_t* mesh, double a
 }
 int32_t mhip_general_forces(mhip_ctx* ctx, int32_t acc, void* f, int32_t mk) { NEED_CTX(); return guard(ctx, [&] { if (!f) throw mhip::ApiError{MHIP_ERR_INVALID, "null force buffer"}; ctx->e->general_forces(acc, f, mk); }); }
 int32_t mhip_general_potential_energy(mhip_ctx* ctx, double* pe) { NEED_CTX(); return guard(ctx, [&] { *pe = ctx->e->general_potential_energy(); }); }
+int32_t mhip_vv_halo_end_parts(mhip_ctx* ctx, int64_t step_n, double dt, int64_t first, int64_t n, const void* in, double* cm_parts, int32_t n_parts) {
+    NEED_CTX(); return guard(ctx, [&] { ctx->e->halo_end_parts(step_n, dt, first, n, in, cm_parts, n_parts); });
+}
+int32_t mhip_remove_cm_parts_dev(mhip_ctx* ctx, const double* parts, int32_t n_parts) { NEED_CTX(); return guard(ctx, [&] { if (!parts) throw mhip::ApiError{MHIP_ERR_INVALID, "null partials"}; ctx->e->remove_cm_parts_dev(parts, n_parts); }); }
 int32_t mhip_set_ghost_margin(mhip_ctx* ctx, double m) { NEED_CTX(); return guard(ctx, [&] { ctx->e->set_ghost_margin(m); }); }
 int32_t mhip_plan_disp2_dev(mhip_ctx* ctx, float* out) { NEED_CTX(); return guard(ctx, [&] { if (!out) throw mhip::ApiError{MHIP_ERR_INVALID, "null output"}; ctx->e->plan_disp2_dev(out); }); }
+int32_t mhip_request_prune(mhip_ctx* ctx) { NEED_CTX(); return guard(ctx, [&] { ctx->e->request_prune(); }); }
 int32_t mhip_vv_halo_begin(mhip_ctx* ctx, double dt, const int32_t* idx, const void* shift, int64_t n, void* out) { NEED_CTX(); return guard(ctx, [&] { ctx->e->halo_begin(dt, idx, shift, n, out); }); }
 int32_t mhip_vv_halo_end(mhip_ctx* ctx, int64_t step_n, double dt, int64_t first, int64_t n, const void* in, double* cm_out4) {
     NEED_CTX(); return guard(ctx, [&] { ctx->e->halo_end(step_n, dt, first, n, in, cm_out4); });

@@ -501,6 +501,16 @@ __global__ void k_build(BuildArgs<T> A) {
     if (lane == 0) A.wave_rows[(b * A.JS + js) * NW + wv] = rows_wave;   // > R_cap reports the required capacity; k_build_summary zeroes it
 }
 
+// flags[FLAG_NAN] != 0 unless every σ equals σ[0], every ϵ equals ϵ[0] and no λ is 0 (one-type system → uniform-LJ kernels)
+template <class T>
+__global__ void k_uniform_check(int64_t n, const T* __restrict__ sig, const T* __restrict__ eps, const T* __restrict__ lam, int32_t* flags) {
+    const T s0 = sig[0], e0 = eps[0];
+    bool bad = false;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        bad = bad || sig[i] != s0 || eps[i] != e0 || (lam && lam[i] == T(0));
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&flags[FLAG_NAN], 1);
+}
+
 // reduce the per-block / per-wave results of k_build or k_filter into the flag words the host reads (flags zeroed before)
 [[maybe_unused]] static __global__ void k_build_summary(int n_blocks, int n_waves, int R_cap, const int32_t* __restrict__ tile_cnt, int32_t* wave_rows,
                                 const float* __restrict__ blk_disp2, int32_t* flags) {

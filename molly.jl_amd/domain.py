@@ -13,10 +13,11 @@ Per step and rank:   halo_begin (kick, drift, pack ghosts) → all_to_all_single
 Axes that are not cut (g = 1) stay periodic inside the engine and need no ghosts.
 
 Ghost plan lifetime.  With ghost_margin = 0 ownership and the ghost plan are redone at every neighbour-rebuild step.
-With ghost_margin = Δ > 0 the shell is r_list + Δ wide and the plan (ownership, ghost set, the engine's outer pair list)
-is kept until some atom has moved Δ/2 since it was made: until then every atom within r_list of an owned atom is
-provably in the local set, the engine re-prunes its outer list to the reference's r_list list at the rebuild cadence,
-and the ranks agree on the re-plan step through one MAX all-reduce of a float per rebuild interval.
+With ghost_margin = Δ > 0 the shell is r_list + Δ wide.  A plan (ownership, ghost set, the engine's outer pair list) can
+vouch for a prune of the inner lists as long as no atom has moved Δ/2 since it was made: until then every atom within
+r_list of an owned atom is provably in the local set.  Between prunes only the skin criterion has to hold (2·displacement
+since the prune ≤ r_list − cutoff), as in the single-domain engine.  The ranks agree on prune and re-plan steps through one
+MAX all-reduce of two floats per rebuild interval (DomainRun.replan_if_due).
 """
 import ctypes as C
 import itertools
@@ -45,6 +46,9 @@ def choose_grid(world, box):
             if best_score is None or score < best_score:
                 best, best_score = (gx, gy, gz), score
     return best
+
+
+CM_PARTS = 256   # per-rank partial sums of the centre-of-mass momentum carried by the all-reduce (8 KB)
 
 
 class BrickGrid:
@@ -172,16 +176,20 @@ class HipDomainEngine:
         if rc != 0:
             self._chk(rc)
 
-    def halo_end(self, step, dt, first, n, buf, cm_out4):
-        key = (buf.data_ptr(), None if cm_out4 is None else cm_out4.data_ptr())
+    def halo_end(self, step, dt, first, n, buf, cm_parts):
+        """cm_parts: None, or a device double tensor of 4·k entries (k per-block partials of Σ m v, Σ m — see CM_PARTS)"""
+        key = (buf.data_ptr(), None if cm_parts is None else cm_parts.data_ptr())
         if getattr(self, "_he_key", None) != key:
-            self._he_key, self._he = key, (self._p(buf), self._p(cm_out4))
-        rc = self.L.mhip_vv_halo_end(self.ctx, step, dt, first, n, *self._he)
+            self._he_key, self._he = key, (self._p(buf), self._p(cm_parts), 0 if cm_parts is None else cm_parts.numel() // 4)
+        rc = self.L.mhip_vv_halo_end_parts(self.ctx, step, dt, first, n, *self._he)
         if rc != 0:
             self._chk(rc)
 
-    def plan_disp2(self, out1_f32):       # device float[1]
-        self._chk(self.L.mhip_plan_disp2_dev(self.ctx, self._p(out1_f32)))
+    def plan_disp2(self, out2_f32):       # device float[2]: max displacement² since the plan / since the last prune
+        self._chk(self.L.mhip_plan_disp2_dev(self.ctx, self._p(out2_f32)))
+
+    def request_prune(self):
+        self._chk(self.L.mhip_request_prune(self.ctx))
 
     def get_state(self, x_all, v_owned):
         self._chk(self.L.mhip_get_state(self.ctx, self._p(x_all), self._p(v_owned), _lib.MEM_DEVICE))
@@ -189,8 +197,8 @@ class HipDomainEngine:
     def cm_momentum(self, out4):          # device double[4]
         self._chk(self.L.mhip_cm_momentum_dev(self.ctx, self._p(out4)))
 
-    def remove_cm(self, total4):
-        self._chk(self.L.mhip_remove_cm_dev(self.ctx, self._p(total4)))
+    def remove_cm(self, total_parts):
+        self._chk(self.L.mhip_remove_cm_parts_dev(self.ctx, self._p(total_parts), total_parts.numel() // 4))
 
     def synchronize(self):
         self._chk(self.L.mhip_synchronize(self.ctx))
@@ -214,19 +222,21 @@ class DomainRun:
     plan_disp2 / get_state / remove_cm (HipDomainEngine on the GPU, an oracle-backed stand-in in the CPU tests).
     `grid.r_ghost` must be r_list + ghost_margin."""
 
-    def __init__(self, grid: BrickGrid, engine, tdtype, device, rebuild_every, group=None, ghost_margin=0.0):
+    def __init__(self, grid: BrickGrid, engine, tdtype, device, rebuild_every, group=None, ghost_margin=0.0, skin=0.0):
         self.g, self.e = grid, engine
         self.gm = float(ghost_margin)
-        self.plan_step = 0
+        self.skin = float(skin)              # r_list − largest cutoff: how far pairs may close in before the inner list must be re-pruned
+        self.plan_step = self.prune_step = 0
         self.tdtype, self.device = tdtype, device
         self.every = rebuild_every
         self.group = group
         self.world, self.rank = grid.world, grid.rank
         self.boxt = torch.tensor(grid.box, dtype=tdtype, device=device)
         self.n_owned = self.n_ghost = 0
-        self.cm_buf = torch.zeros(4, dtype=torch.float64, device=device)
-        self.d2_buf = torch.zeros(1, dtype=torch.float32, device=device)
-        self.stats = {"exchange_calls": 0, "ghost_atoms": 0, "migrated": 0, "plans": 0, "plan_checks": 0}
+        # Σ m v travels as per-block partials (no finalize launch on the device): CM_PARTS × {Px, Py, Pz, M}, summed over the ranks
+        self.cm_buf = torch.zeros(4 * CM_PARTS, dtype=torch.float64, device=device)
+        self.d2_buf = torch.zeros(2, dtype=torch.float32, device=device)
+        self.stats = {"exchange_calls": 0, "ghost_atoms": 0, "migrated": 0, "plans": 0, "plan_checks": 0, "prunes": 0}
         # gloo cannot move device memory: stage through the host (used by the multi-process tests that share ONE GPU;
         # the production path is backend "nccl" = RCCL, device buffers end to end)
         self.stage_host = torch.device(device).type == "cuda" and dist.get_backend(group) == "gloo"
@@ -309,7 +319,7 @@ class DomainRun:
         self.e.vv_init(step)                                 # neighbour structures + forces at this step
         self.stats["ghost_atoms"] = self.n_ghost
         self.stats["plans"] += 1
-        self.plan_step = step
+        self.plan_step = self.prune_step = step
 
     def _a2a_rows(self, recv, send):
         w = recv.shape[1]
@@ -330,24 +340,31 @@ class DomainRun:
             self.replan_if_due(step_n)
 
     def replan_if_due(self, step_n):
-        """Collective decision at the rebuild cadence: keep the ghost plan while no atom anywhere moved ghost_margin/2."""
+        """Collective decision at the rebuild cadence (one MAX all-reduce of two floats, one host sync).  The inner pair lists are
+        re-pruned — on every rank at the same step — when the displacement since the last prune is about to use up the skin.  A
+        prune needs the ghost plan to be valid at that moment (nobody moved more than ghost_margin/2 since it was made): if it
+        is not, ownership, ghosts and outer lists are redone instead.  In between, nothing needs to hold but the skin criterion,
+        exactly as in the single-domain engine."""
         if self.gm <= 0:
             self.migrate(step_n)
             return
         self.e.plan_disp2(self.d2_buf)
         self._all_reduce(self.d2_buf, dist.ReduceOp.MAX)
-        d2 = float(self.d2_buf.item())                  # the one host sync per rebuild interval
+        d2_plan, d2_prune = (float(v) for v in self.d2_buf.tolist())      # the one host sync per rebuild interval
         self.stats["plan_checks"] += 1
-        if math.isinf(d2):
+        if math.isinf(d2_plan):
             self.migrate(step_n)
             return
-        moved = 2.0 * math.sqrt(d2)
-        if moved > self.gm:
-            raise RuntimeError(f"an atom moved {moved / 2:.4f} nm since the ghost plan of step {self.plan_step}: more than half the "
-                               f"ghost margin {self.gm:.3f} nm — the margin is too small for this rebuild interval")
-        k = max(1, (step_n - self.plan_step) // self.every)
-        if moved * (k + 1) / k > 0.9 * self.gm:        # would not survive another interval at this drift rate
+        k = max(1, (step_n - self.prune_step) // self.every)
+        prune_due = math.isinf(d2_prune) or 2.0 * math.sqrt(d2_prune) * (k + 1) / k > 0.98 * self.skin
+        if not prune_due:
+            return
+        if 2.0 * math.sqrt(d2_plan) > 0.95 * self.gm:       # the plan cannot vouch for a prune any more
             self.migrate(step_n)
+        else:
+            self.e.request_prune()                           # the next force pass walks the outer list and prunes
+            self.prune_step = step_n
+            self.stats["prunes"] += 1
 
     def run(self, first_step, n_steps, dt, remove_cm_every=1):
         for s in range(first_step + 1, first_step + n_steps + 1):
@@ -437,7 +454,8 @@ def bench_distributed(m, case, dtype, dt, args, rank, local_rank, world):
     vol_frac = np.prod([b / L for b, L in zip(box, case.box)])
     capacity = int(case.n * min(1.0, vol_frac) * 1.25) + 4096
     eng = HipDomainEngine(make_interactions(case, dtype), dtype, capacity, box, origin, periodic, case.r_list, case.rebuild_every, local_rank, ghost_margin=gm)
-    run = DomainRun(bg, eng, tdtype, device, case.rebuild_every, ghost_margin=gm)
+    rc_max = max([c[1] for c in ([case.lj.get("cutoff", ("none", 0.0))] if case.lj else []) if len(c) > 1] + ([case.coul.get("rc", 0.0)] if case.coul else []) + [0.0])
+    run = DomainRun(bg, eng, tdtype, device, case.rebuild_every, ghost_margin=gm, skin=case.r_list - rc_max)
     run.setup_from_global(case.coords, case.velocities, np.zeros(case.n) if case.charge is None else case.charge, case.sigma, case.eps, case.mass)
     run.run(0, args.warmup, dt)
     torch.cuda.synchronize(); dist.barrier()
@@ -466,6 +484,6 @@ def bench_distributed(m, case, dtype, dt, args, rank, local_rank, world):
     st["n_pairs_full"] = int(agg[0])
     extra = {"parallelism": f"spatial bricks {grid[0]}x{grid[1]}x{grid[2]}, full-shell ghost coordinates via all_to_all_single (RCCL), "
                             f"{int(agg[3] / world)} ghosts / {int(agg[4] / world)} owned atoms per GPU, ghost margin {gm:.2f} nm "
-                            f"({run.stats['plans']} ghost plans in {run.stats['plan_checks']} checks)",
+                            f"({run.stats['plans']} ghost plans, {run.stats['prunes']} prunes in {run.stats['plan_checks']} checks)",
              "per_gpu_force_pass_bytes": st["force_pass_bytes"], "ghost_fraction": agg[3] / max(agg[4], 1)}
     return ms_per_step, st, extra

@@ -9,8 +9,9 @@ from oracle import pyoracle as orc
 
 
 class OracleDomainEngine:
-    def __init__(self, inter_dict, box, periodic, r_list, dtype=np.float64):
+    def __init__(self, inter_dict, box, periodic, r_list, dtype=np.float64, ghost_margin=0.0):
         self.inter, self.r_list, self.dtype = inter_dict, r_list, dtype
+        self.ghost_margin, self.n_prunes = ghost_margin, 0
         self.box = np.array([b if p else math.inf for b, p in zip(box, periodic)])   # open axes: no minimum image
         self.periodic = periodic
 
@@ -19,7 +20,7 @@ class OracleDomainEngine:
         f = lambda t: t.detach().cpu().numpy().astype(np.float64).copy()
         self.q, self.sigma, self.eps, self.mass = f(q), f(sigma), f(eps), f(mass)
         self.x, self.v = f(x_all), f(v_owned)
-        self.x_plan = self.x.copy()
+        self.x_plan = self.x.copy(); self.x_prune = self.x.copy()
         self.f = None
 
     def _forces(self):
@@ -63,19 +64,31 @@ class OracleDomainEngine:
         if cm_out4 is not None:
             self.cm_momentum(cm_out4)
 
-    def plan_disp2(self, out1):
-        d = self.x - self.x_plan
+    def _disp2(self, ref):
+        d = self.x - ref
         for k in range(3):
             if self.periodic[k]:
                 d[:, k] -= np.round(d[:, k] / self.box[k]) * self.box[k]
-        out1[0] = float((d * d).sum(axis=1).max())
+        return float((d * d).sum(axis=1).max())
+
+    def plan_disp2(self, out2):
+        out2[0] = self._disp2(self.x_plan); out2[1] = self._disp2(self.x_prune)
+
+    def request_prune(self):
+        # this stand-in searches its neighbours at every force call; what it checks is that a prune is only asked for while the
+        # ghost shell still covers r_list around every owned atom — i.e. while the plan is valid
+        assert 2.0 * np.sqrt(self._disp2(self.x_plan)) <= self.ghost_margin + 1e-12
+        self.x_prune = self.x.copy()
+        self.n_prunes += 1
 
     def get_state(self, x_all, v_owned):
         x_all.copy_(torch.from_numpy(self.x).to(x_all.dtype)); v_owned.copy_(torch.from_numpy(self.v).to(v_owned.dtype))
 
-    def cm_momentum(self, out4):
+    def cm_momentum(self, out):            # out: 4·k doubles, k partials; this stand-in fills the first one
         m = self.mass[: self.n_owned]
-        out4[:3] = torch.from_numpy((self.v * m[:, None]).sum(axis=0)); out4[3] = float(m.sum())
+        out.zero_()
+        out[:3] = torch.from_numpy((self.v * m[:, None]).sum(axis=0)); out[3] = float(m.sum())
 
-    def remove_cm(self, total4):
-        self.v -= (total4[:3] / total4[3]).numpy()
+    def remove_cm(self, total):
+        t = total.view(-1, 4).sum(dim=0)
+        self.v -= (t[:3] / t[3]).numpy()

@@ -20,7 +20,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, n_side, n_steps, dtype_name, out_dir, gm=0.0):
+def _worker(rank, world, port, n_side, n_steps, dtype_name, out_dir, gm=0.0, host_skin=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import molly_loader
@@ -35,14 +35,14 @@ def _worker(rank, world, port, n_side, n_steps, dtype_name, out_dir, gm=0.0):
     bg = domain.BrickGrid(case.box, grid, rank, case.r_list + gm)
     box, origin, periodic = bg.engine_box(pad=0.3)
     eng = domain.HipDomainEngine(domain.make_interactions(case, dtype), dtype, case.n, box, origin, periodic, case.r_list, case.rebuild_every, 0, ghost_margin=gm)
-    run = domain.DomainRun(bg, eng, tdtype, dev, case.rebuild_every, ghost_margin=gm)
+    run = domain.DomainRun(bg, eng, tdtype, dev, case.rebuild_every, ghost_margin=gm, skin=(case.r_list - 1.0) if host_skin is None else host_skin)
     run.setup_from_global(case.coords, case.velocities, np.zeros(case.n), case.sigma, case.eps, case.mass)
     run.run(0, n_steps, 0.002, remove_cm_every=1)
     xs, vs = run.gather_global(case.n)
     if rank == 0:
         st = eng.stats()
         np.savez(os.path.join(out_dir, "result.npz"), x=xs, v=vs, ghosts=run.n_ghost, migrated=run.stats["migrated"], plans=run.stats["plans"],
-                 checks=run.stats["plan_checks"], outer=st["n_outer_builds"], prunes=st["n_filter_passes"])
+                 checks=run.stats["plan_checks"], outer=st["n_outer_builds"], prunes=st["n_filter_passes"], host_prunes=run.stats["prunes"])
     dist.barrier()
     eng.close()
     dist.destroy_process_group()
@@ -66,12 +66,14 @@ def test_hip_domains_match_single_domain_oracle(world, dtype_name, tmp_path):
     assert int(res["ghosts"]) > 0
 
 
-@pytest.mark.parametrize("world,dtype_name,gm,n_steps", [(2, "f64", 0.2, 60), (8, "f64", 0.2, 40), (4, "f32", 0.2, 40), (2, "f64", 0.03, 60)])
-def test_long_lived_ghost_plans_with_dual_list(world, dtype_name, gm, n_steps, tmp_path):
-    """ghost shell r_list + margin: ownership, ghost set and the engine's outer pair list live until an atom moved margin/2;
-    in between the sub-domain engines only re-prune (dual pair list with ghosts)"""
+@pytest.mark.parametrize("world,dtype_name,gm,n_steps,host_skin", [(2, "f64", 0.2, 60, None), (8, "f64", 0.2, 40, None), (4, "f32", 0.2, 40, None),
+                                                                    (2, "f64", 0.2, 60, 0.03), (2, "f64", 0.03, 60, 0.02)])
+def test_long_lived_ghost_plans_with_dual_list(world, dtype_name, gm, n_steps, host_skin, tmp_path):
+    """ghost shell r_list + margin: ownership, ghost set and the engine's outer pair list live until a prune comes due after an
+    atom moved margin/2; the prunes (dual pair list with ghosts) are scheduled by the host, collectively.  host_skin shrinks the
+    skin the HOST schedules with (the engine's real skin is 0.2 nm) to force prunes and re-plans within a short run."""
     n_side = 16                       # bricks 2.9 nm >= 1.2 + 0.2
-    mp.spawn(_worker, args=(world, _free_port(), n_side, n_steps, dtype_name, str(tmp_path), gm), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n_side, n_steps, dtype_name, str(tmp_path), gm, host_skin), nprocs=world, join=True)
     res = np.load(os.path.join(tmp_path, "result.npz"))
     dtype = np.float32 if dtype_name == "f32" else np.float64
     case = S.lj_fluid(n_side, dtype=dtype, rebuild_every=10)
@@ -84,7 +86,10 @@ def test_long_lived_ghost_plans_with_dual_list(world, dtype_name, gm, n_steps, t
     else:
         assert np.abs(d).mean() < 1e-5 and np.abs(d).max() < 2e-3
     assert int(res["checks"]) == n_steps // 10
-    if gm >= 0.2:
-        assert int(res["plans"]) == 1 and int(res["outer"]) == 1 and int(res["prunes"]) >= 1     # one plan, one outer search, only prunes
+    if host_skin is None:
+        assert int(res["plans"]) == 1 and int(res["outer"]) == 1 and int(res["prunes"]) == 1 and int(res["host_prunes"]) == 0   # one plan, one search, its first prune
+    elif gm >= 0.2:
+        assert int(res["plans"]) == 1 and int(res["outer"]) == 1 and int(res["host_prunes"]) >= 2
+        assert int(res["host_prunes"]) <= int(res["prunes"]) <= 1 + int(res["host_prunes"])   # (a prune requested after the last step is never run)
     else:
-        assert int(res["plans"]) > 1                                                              # small margin: re-planned on the way
+        assert int(res["plans"]) > 1 and int(res["host_prunes"]) >= 1                                                            # a due prune finds the plan stale
