@@ -141,6 +141,7 @@ template <class T> class Engine final : public EngineBase {
     // ghosted sub-domain whose ghost shell reaches r_list + ghost_margin: the ghost PLAN then lives as long as an outer list
     // (until some atom moved ghost_margin/2), so the dual list works here too and the host re-plans only when mhip_plan_disp2_dev says so
     double ghost_margin = 0; const double* cm_ext = nullptr;
+    long long grid_key = -1;
     bool host_prune = false;     // ghost plans: the HOST decides, collectively over the ranks, when the inner list is re-pruned (mhip_request_prune)
     // single list, same idea: a rebuild step whose displacement check shows the list still covers every cutoff sphere is skipped
     bool lazy_single = false; int64_t n_skipped = 0;
@@ -155,7 +156,7 @@ template <class T> class Engine final : public EngineBase {
     // bonded
     Bonded<T> bonded;
     // general interaction: PME reciprocal space (ewald.jl:361-929)
-    Pme<T> pme; double pc_sum = 0, pc_abs2_sum = 0;
+    Pme<T> pme; double pc_sum = 0, pc_abs2_sum = 0; bool pc_valid = false;
     // bonded terms and PME run on side streams while the pair kernel runs on the main one; their forces land in frc_side[] and
     // are folded in by the second kick
     hipStream_t side[2] = {nullptr, nullptr}; hipEvent_t ev_pos = nullptr, ev_side[2] = {nullptr, nullptr};
@@ -710,14 +711,15 @@ template <class T> class Engine final : public EngineBase {
         if (no <= 0 || ng < 0 || no + ng > cap) throw ApiError{MHIP_ERR_INVALID, "atom counts exceed the context capacity"};
         n_owned = no; n_ghost = ng; n_tot = no + ng;
         // new local atom set: restart from the identity order
-        std::vector<int32_t> iota(n_tot); for (int64_t i = 0; i < n_tot; ++i) iota[i] = (int32_t)i;
-        MHIP_HIP(hipMemcpyAsync(orig[cur].p, iota.data(), n_tot * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-        MHIP_HIP(hipMemcpyAsync(inv.p, iota.data(), n_tot * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(k_iota2, dim3(std::min(cdiv(n_tot, 256), 1024)), dim3(256), 0, stream, n_tot, orig[cur].p, inv.p);
         MHIP_HIP(hipMemsetAsync(frc[cur].p, 0, n_tot * sizeof(T4), stream));
-        MHIP_HIP(hipStreamSynchronize(stream));
+        MHIP_HIP(hipGetLastError());
         stale = true; cm_pending = 0; cm_ext = nullptr; frc_valid = false;
-        setup_grid();          // the search radius depends on n_ghost / the ghost margin
-        choose_blocking();
+        // the search radius depends on whether there are ghosts and on the ghost margin, the blocking on the size class: a re-plan
+        // that changes neither keeps the grid, its Hilbert table and the (already adapted) capacities
+        const int size_class = n_owned >= 100000 ? 2 : (n_owned >= 40000 ? 1 : 0);
+        const long long key = (n_ghost > 0 ? 1 : 0) | (dual_disabled ? 2 : 0) | (size_class << 2) | ((long long)std::llround(ghost_margin * 1e6) << 8);
+        if (key != grid_key) { setup_grid(); choose_blocking(); grid_key = key; }
     }
 
     void set_atoms(const void* q, const void* sg, const void* ep, const void* ms, const void* lam, int mem_kind) override {
@@ -749,12 +751,7 @@ template <class T> class Engine final : public EngineBase {
                 ljm = LJ_DIST_UNIFORM;
             }
         }
-        pc_sum = 0; pc_abs2_sum = 0;
-        if (dq) {   // Σq and Σq² of the PME self / net-charge terms (ewald.jl:917-924)
-            std::vector<T> hq(n_owned);
-            MHIP_HIP(hipMemcpy(hq.data(), dq, n_owned * sizeof(T), hipMemcpyDeviceToHost));
-            for (int64_t i = 0; i < n_owned; ++i) { pc_sum += (double)hq[i]; pc_abs2_sum += (double)hq[i] * (double)hq[i]; }
-        }
+        pc_valid = false;   // Σq, Σq² of the PME self / net-charge terms are read back only when an energy asks for them
         s3.release(); s4.release(); s5.release();
         params_set = true; frc_valid = false;
     }
@@ -874,6 +871,14 @@ template <class T> class Engine final : public EngineBase {
         if (!state_set) throw ApiError{MHIP_ERR_STATE, "set_state must be called before general_potential_energy"};
         if (!pme.on()) return 0.0;
         if (n_ghost > 0) throw ApiError{MHIP_ERR_UNSUPPORTED, "PME runs on a single domain"};
+        if (!pc_valid) {   // Σq and Σq² (ewald.jl:917-924) from the charges kept in pos.w
+            std::vector<T4> hp(n_owned);
+            MHIP_HIP(hipStreamSynchronize(stream));
+            MHIP_HIP(hipMemcpy(hp.data(), pos[cur].p, n_owned * sizeof(T4), hipMemcpyDeviceToHost));
+            pc_sum = 0; pc_abs2_sum = 0;
+            for (int64_t i = 0; i < n_owned; ++i) { pc_sum += (double)hp[i].w; pc_abs2_sum += (double)hp[i].w * (double)hp[i].w; }
+            pc_valid = true;
+        }
         const int nb = pme.conv_blocks();
         red_part.reserve(nb);
         pme.run(stream, n_owned, pos[cur].p, (T4*)nullptr, red_part.p);

@@ -501,6 +501,11 @@ __global__ void k_build(BuildArgs<T> A) {
     if (lane == 0) A.wave_rows[(b * A.JS + js) * NW + wv] = rows_wave;   // > R_cap reports the required capacity; k_build_summary zeroes it
 }
 
+// a[i] = b[i] = i
+[[maybe_unused]] static __global__ void k_iota2(int64_t n, int32_t* a, int32_t* b) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { a[i] = (int32_t)i; b[i] = (int32_t)i; }
+}
+
 // flags[FLAG_NAN] != 0 unless every σ equals σ[0], every ϵ equals ϵ[0] and no λ is 0 (one-type system → uniform-LJ kernels)
 template <class T>
 __global__ void k_uniform_check(int64_t n, const T* __restrict__ sig, const T* __restrict__ eps, const T* __restrict__ lam, int32_t* flags) {
