@@ -180,8 +180,10 @@ template <class T> class Engine final : public EngineBase {
         MHIP_HIP(hipSetDevice(device));
         MHIP_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); own_stream = true;
         overlap = env_int("MOLLYHIP_OVERLAP", 0) != 0;   // measured on MI355X (6mrr): side streams gain nothing, the small kernels do not co-run profitably
-        for (int k = 0; k < 2; ++k) { MHIP_HIP(hipStreamCreateWithFlags(&side[k], hipStreamNonBlocking)); MHIP_HIP(hipEventCreateWithFlags(&ev_side[k], hipEventDisableTiming)); }
-        MHIP_HIP(hipEventCreateWithFlags(&ev_pos, hipEventDisableTiming));
+        if (overlap) {   // side streams only when asked for: every extra stream is a hardware queue
+            for (int k = 0; k < 2; ++k) { MHIP_HIP(hipStreamCreateWithFlags(&side[k], hipStreamNonBlocking)); MHIP_HIP(hipEventCreateWithFlags(&ev_side[k], hipEventDisableTiming)); }
+            MHIP_HIP(hipEventCreateWithFlags(&ev_pos, hipEventDisableTiming));
+        }
         setup_inter(); setup_grid();
         for (int k = 0; k < 2; ++k) { pos[k].reserve(cap); vel[k].reserve(cap); frc[k].reserve(cap); lj[k].reserve(cap); orig[k].reserve(cap); }
         inv.reserve(cap); key_in.reserve(cap); key_out.reserve(cap); idx_in.reserve(cap); perm.reserve(cap);

@@ -48,7 +48,8 @@ def choose_grid(world, box):
     return best
 
 
-CM_PARTS = 256   # per-rank partial sums of the centre-of-mass momentum carried by the all-reduce (8 KB)
+import os as _os
+CM_PARTS = int(_os.environ.get("MOLLYHIP_CM_PARTS", "256"))   # per-rank partial sums of the centre-of-mass momentum carried by the all-reduce (8 KB)
 
 
 class BrickGrid:
