@@ -50,7 +50,7 @@ enum mhip_status {
     MHIP_ERR_STATE        = -3,   /* call order violated (e.g. forces before set_state)    */
     MHIP_ERR_CAPACITY     = -4,   /* caller buffer too small (export_neighbors)            */
     MHIP_ERR_NO_DEVICE    = -5,   /* no gfx950 device visible: the product path never falls back to CPU */
-    MHIP_ERR_UNSUPPORTED  = -6,   /* feature outside the hot-path scope (e.g. virial)      */
+    MHIP_ERR_UNSUPPORTED  = -6,   /* feature outside the hot-path scope                    */
     MHIP_ERR_NAN          = -7    /* NaN detected by mhip_check_finite                     */
 };
 
@@ -181,7 +181,9 @@ int32_t mhip_get_state(mhip_ctx* ctx, void* xyz, void* vel, int32_t mem_kind);  
  * accumulate != 0 adds into f_xyz (the contract of pairwise_forces_loop_gpu!, whose caller
  * zeroes fs_mat, force.jl:1216); 0 overwrites.  step_n drives the rebuild cadence exactly like
  * find_neighbors (neighbors.jl:396): rebuild when stale or step_n % rebuild_every == 0 and the
- * step differs from the step of the last build.  virial9 must be NULL (MHIP_ERR_UNSUPPORTED). */
+ * step differs from the step of the last build.  virial9 (nullable): 9 HOST doubles, row-major 3x3, to which the pairwise
+ * virial Σ dr ⊗ f over the pair list is ADDED (≙ needs_vir, force.jl:848-852, 877-880; buffers.virial_nounits).  The virial of the
+ * specific and general interactions is not computed by this library. */
 int32_t mhip_forces(mhip_ctx* ctx, int64_t step_n, int32_t accumulate, void* f_xyz,
                     void* virial9, int32_t mem_kind);
 int32_t mhip_specific_forces(mhip_ctx* ctx, int32_t accumulate, void* f_xyz, int32_t mem_kind);

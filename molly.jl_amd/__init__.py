@@ -9,6 +9,6 @@ from .api import (  # noqa: F401
     CubicBoundary, CubicSplineCutoff, DistanceCutoff, DistanceNeighborFinder, EwaldExclusions, GPUNeighborFinder,
     HarmonicAngles, HarmonicBonds, LennardJones, NeighborList, NoCutoff, NoNeighborFinder, PeriodicTorsions,
     PME, PolynomialCutoff, ShiftedForceCutoff, ShiftedPotentialCutoff, System, VelocityVerlet, find_neighbors, forces,
-    kinetic_energy, potential_energy, remove_CM_motion, simulate, temperature, total_energy, use_neighbors,
+    kinetic_energy, potential_energy, remove_CM_motion, scalar_virial, simulate, temperature, total_energy, use_neighbors, virial,
     wrap_coords,
 )

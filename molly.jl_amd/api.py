@@ -427,6 +427,24 @@ def forces(sys, step_n=0, pairwise=True, specific=True, general=True):
     return out
 
 
+def virial(sys, step_n=0):
+    """virial(sys): 3×3 tensor Σ dr ⊗ f over the neighbour pairs of the pairwise interactions (force.jl:848-852, energy.jl:116-131).
+    The specific and general interactions' virial is outside the scope of the engine."""
+    if sys.specific_inter_lists or sys.general_inters:
+        raise MollyHipError(-6, "the virial of specific / general interactions is outside the hot-path scope")
+    L = _lib.lib()
+    sys.push_state(velocities=False)
+    out = np.zeros((len(sys), 3), sys.dtype)
+    v = np.zeros(9, np.float64)
+    sys._check(L.mhip_forces(sys._ctx, step_n, 0, sys._ptr(out), v.ctypes.data_as(C.c_void_p), _lib.MEM_HOST))
+    return v.reshape(3, 3)
+
+
+def scalar_virial(sys, step_n=0):
+    """scalar_virial(sys) = tr(virial(sys)) (energy.jl:148-151)"""
+    return float(np.trace(virial(sys, step_n)))
+
+
 def potential_energy(sys, step_n=0, pairwise=True, specific=True, general=True):
     """potential_energy(sys; …) (energy.jl:207-248, 409-446)."""
     L = _lib.lib()

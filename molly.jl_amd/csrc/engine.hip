@@ -62,6 +62,7 @@ struct EngineBase {
     virtual void shift_velocities(const double*) = 0;
     virtual void cm_momentum_dev(double*) = 0;
     virtual void remove_cm_dev(const double*) = 0;
+    virtual void pairwise_virial(int64_t, double*) = 0;
     virtual void set_pme(int32_t, const int32_t*, double, double) = 0;
     virtual void general_forces(int, void*, int) = 0;
     virtual double general_potential_energy() = 0;
@@ -434,7 +435,7 @@ template <class T> class Engine final : public EngineBase {
         minimg = h_flags[FLAG_MINIMG] != 0 || env_int("MOLLYHIP_FORCE_MINIMG", 0) != 0;
         max_tile = h_flags[FLAG_MAX_TILE]; max_rows = h_flags[FLAG_MAX_ROWS]; total_rows = h_flags[FLAG_TOTAL_ROWS];
         carve_force_lds(max_tile);
-        red_part.reserve(std::max<size_t>((size_t)n_blocks, 4 * (size_t)cdiv(n_owned, 256)) + 8);
+        red_part.reserve(std::max<size_t>(7 * (size_t)n_blocks, 4 * (size_t)cdiv(n_owned, 256)) + 8);
         bonded.on_reorder();
         ++n_outer; last_outer_step = step_n;
         if (dual) {   // remember where everybody was; the next force pass prunes the outer list into the inner one
@@ -848,6 +849,27 @@ template <class T> class Engine final : public EngineBase {
         return pe;
     }
 
+    // Σ over the pair list of dr ⊗ f (force.jl:848-852, 877-880), ADDED to out9 (row-major 3x3, host doubles).  Runs the energy variant
+    // of the pair kernel, whose forces are discarded like those of potential_energy.
+    void pairwise_virial(int64_t step_n, double* out9) override {
+        ensure_built(step_n);
+        DBuf<T4> keep;
+        keep.reserve(n_tot);
+        MHIP_HIP(hipMemcpyAsync(keep.p, frc[cur].p, (size_t)n_tot * sizeof(T4), hipMemcpyDeviceToDevice, stream));
+        launch_pair_kernel(true);
+        MHIP_HIP(hipMemcpyAsync(frc[cur].p, keep.p, (size_t)n_tot * sizeof(T4), hipMemcpyDeviceToDevice, stream));
+        double v[6];
+        for (int c = 0; c < 6; ++c) {
+            hipLaunchKernelGGL(k_sum_double, dim3(1), dim3(256), 0, stream, n_blocks, (const double*)red_part.p + (size_t)(c + 1) * n_blocks, red_out.p);
+            MHIP_HIP(hipMemcpyAsync(h_red, red_out.p, sizeof(double), hipMemcpyDeviceToHost, stream));
+            MHIP_HIP(hipStreamSynchronize(stream));
+            v[c] = h_red[0];
+        }
+        keep.release();
+        out9[0] += v[0]; out9[4] += v[1]; out9[8] += v[2];
+        out9[1] += v[3]; out9[3] += v[3]; out9[2] += v[4]; out9[6] += v[4]; out9[5] += v[5]; out9[7] += v[5];
+    }
+
     double specific_potential_energy() override {
         if (!state_set) throw ApiError{MHIP_ERR_STATE, "set_state must be called before specific_potential_energy"};
         int n_part = bonded.launch_energy(stream, G, I, pos[cur].p, inv.p, red_part);
@@ -1212,9 +1234,9 @@ int32_t mhip_get_state(mhip_ctx* ctx, void* x, void* v, int32_t mk) { NEED_CTX()
 int32_t mhip_forces(mhip_ctx* ctx, int64_t step_n, int32_t acc, void* f, void* virial9, int32_t mk) {
     NEED_CTX();
     return guard(ctx, [&] {
-        if (virial9) throw mhip::ApiError{MHIP_ERR_UNSUPPORTED, "virial accumulation is outside the hot-path scope (SURVEY §8(f) rank 3)"};
         if (!f) throw mhip::ApiError{MHIP_ERR_INVALID, "null force buffer"};
         ctx->e->forces(step_n, acc, f, mk);
+        if (virial9) ctx->e->pairwise_virial(step_n, static_cast<double*>(virial9));
     });
 }
 int32_t mhip_specific_forces(mhip_ctx* ctx, int32_t acc, void* f, int32_t mk) { NEED_CTX(); return guard(ctx, [&] { if (!f) throw mhip::ApiError{MHIP_ERR_INVALID, "null force buffer"}; ctx->e->specific_forces(acc, f, mk); }); }

@@ -779,6 +779,7 @@ __global__ void k_forces(ForceArgs<T> A) {
     const uint2* my_rows = A.nbr + (((int64_t)b * A.JS + js) * A.R_cap) * A.BI + li;       // j-split was done by k_build
     const int32_t* tix = A.tile_idx + (int64_t)b * A.T_cap;
     T fx = T(0), fy = T(0), fz = T(0), pe = T(0);
+    [[maybe_unused]] T vir[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};   // ENERGY: Σ fr·(dx², dy², dz², dx·dy, dx·dz, dy·dz), the pair virial dr ⊗ f (force.jl:848-852)
     // PRUNE: inner-list emission state (same row format as k_build)
     uint32_t pk[2] = {0, 0};
     int kept = 0;
@@ -889,6 +890,10 @@ __global__ void k_forces(ForceArgs<T> A) {
                     if constexpr (PRUNE) { if (real && valid && r2 <= A.r_prune2) { emit(e); l_mark[e & 0x7fffu] = 1; } }   // benign race: same byte value
                     T fr = pair_eval<T, LJM, COULM, ENERGY>(A.I, r2, pi.w, pj.w, lji.x, ljj.x, lji.y, ljj.y, special, pe);
                     fx -= fr * dx; fy -= fr * dy; fz -= fr * dz;   // force on i is −f (force.jl:873)
+                    if constexpr (ENERGY) {
+                        vir[0] += fr * dx * dx; vir[1] += fr * dy * dy; vir[2] += fr * dz * dz;
+                        vir[3] += fr * dx * dy; vir[4] += fr * dx * dz; vir[5] += fr * dy * dz;
+                    }
                 }
             }
         };
@@ -977,11 +982,27 @@ __global__ void k_forces(ForceArgs<T> A) {
     }
     if (js == 0 && valid) A.frc[si] = make4<T>(fx, fy, fz, T(0));
     if constexpr (ENERGY) {
+        if (A.JS > 1) {   // j-split partial sums of the virial, two rounds through the same four LDS slots
+            T* red = reinterpret_cast<T*>(smem);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < 3; ++c) red[(js * 4 + c) * A.BI + li] = vir[3 * half + c];
+                __syncthreads();
+                if (js == 0) for (int q = 1; q < A.JS; ++q) for (int c = 0; c < 3; ++c) vir[3 * half + c] += red[(q * 4 + c) * A.BI + li];
+            }
+        }
+        // block sums of the energy and the six virial components, each halved (every pair is visited from both ends);
+        // pe_part is component-major: [0, n_blocks) energy, then xx, yy, zz, xy, xz, yz
         __syncthreads();
         double* dred = reinterpret_cast<double*>(smem);
-        if (js == 0) dred[li] = valid ? 0.5 * (double)pe : 0.0;   // every pair is visited from both ends
-        __syncthreads();
-        if (tid == 0) { double s = 0; for (int q = 0; q < A.BI; ++q) s += dred[q]; A.pe_part[b] = s; }
+        for (int c = 0; c < 7; ++c) {
+            if (js == 0) dred[li] = valid ? 0.5 * (double)(c == 0 ? pe : vir[c - 1]) : 0.0;
+            __syncthreads();
+            if (tid == 0) { double s = 0; for (int q = 0; q < A.BI; ++q) s += dred[q]; A.pe_part[(int64_t)c * A.n_blocks + b] = s; }
+            __syncthreads();
+        }
     }
 }
 

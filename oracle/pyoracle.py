@@ -83,6 +83,8 @@ def lib(native=False):
         L.orc_energy.restype = C.c_double
         L.orc_energy.argtypes = [C.c_int, C.POINTER(OrcSystem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
         L.orc_kinetic_energy.restype = C.c_double; L.orc_kinetic_energy.argtypes = [C.c_int, C.POINTER(OrcSystem)]
+        L.orc_virial.restype = None
+        L.orc_virial.argtypes = [C.c_int, C.POINTER(OrcSystem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.orc_remove_cm.restype = None; L.orc_remove_cm.argtypes = [C.c_int, C.POINTER(OrcSystem)]
         L.orc_wrap.restype = None; L.orc_wrap.argtypes = [C.c_int, C.POINTER(OrcSystem)]
         L.orc_vv_run.restype = None
@@ -195,6 +197,16 @@ class OracleSystem:
             return self.L.orc_energy(self.prec, C.byref(self.s), None, None, None, -1, mask)
         i, j, sp = nl
         return self.L.orc_energy(self.prec, C.byref(self.s), _ptr(i), _ptr(j), _ptr(sp), len(i), mask)
+
+    def virial(self, nl=None):
+        """3x3 virial tensor of the pairwise interactions, Σ dr ⊗ f over the list (force.jl:848-852)"""
+        out = np.zeros(9)
+        if nl is None:
+            self.L.orc_virial(self.prec, C.byref(self.s), None, None, None, -1, _ptr(out))
+        else:
+            i, j, sp = nl
+            self.L.orc_virial(self.prec, C.byref(self.s), _ptr(i), _ptr(j), _ptr(sp), len(i), _ptr(out))
+        return out.reshape(3, 3)
 
     def kinetic_energy(self):
         return self.L.orc_kinetic_energy(self.prec, C.byref(self.s))

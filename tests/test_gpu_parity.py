@@ -356,3 +356,23 @@ def test_dual_pair_list_stays_bit_exact_during_a_run(pkg, dtype):
     a, b = nl_keys(oi, oj, osp), nl_keys(i, j, sp)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     assert st["n_rebuilds"] >= 4
+
+
+@pytest.mark.parametrize("kind,dtype", [("lj", np.float64), ("lj", np.float32), ("rf", np.float64), ("ewald", np.float32)])
+def test_pairwise_virial_vs_oracle(pkg, kind, dtype):
+    """mhip_forces(virial9): Σ dr ⊗ f over the pair list (≙ needs_vir, force.jl:848-852, 877-880), against the oracle, whose trace
+    satisfies tr W = −dE/dλ under uniform scaling (tests/test_oracle_golden.py)"""
+    if kind == "lj":
+        case = S.lj_fluid(12, dtype=dtype)
+    else:
+        case = S.charged_fluid(10, dict(kind=kind, rc=1.0, weight_special=0.8333333333333334), dtype=dtype, stable=True)
+    o = case.oracle(np.float64)
+    w_ref = o.virial(o.neighbors("cell"))
+    s = case.system(pkg, dtype)
+    w = pkg.virial(s)
+    scale = np.abs(w_ref).max()
+    assert np.abs(w - w_ref).max() < (1e-10 if dtype == np.float64 else 2e-4) * scale
+    assert np.abs(w - w.T).max() == 0.0
+    assert pkg.scalar_virial(s) == pytest.approx(np.trace(w), rel=1e-12)
+    f = pkg.forces(s)                                   # the virial call left the engine's forces untouched
+    assert np.isfinite(f).all()

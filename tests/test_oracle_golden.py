@@ -205,3 +205,22 @@ def test_velocity_verlet_chunked_continuation_is_exact():
     assert np.array_equal(a.coords, b.coords) and np.array_equal(a.vel, b.vel)
     # momentum stays removed (remove_CM_motion=1, simulators.jl:293)
     assert np.abs((a.vel * 10.0).sum(axis=0)).max() < 1e-10
+
+
+def test_pairwise_virial_obeys_the_scaling_identity():
+    """force.jl:848-852: vir += dr ⊗ f.  For a smooth pair potential tr W = Σ dr·f = −dE/dλ under x → λx, L → λL, r_c → λ r_c... here
+    with the cutoff fixed and a ShiftedForceCutoff (force and energy continuous at r_c), so the identity holds to O(h²)."""
+    from tests import systems as S
+    case = S.lj_fluid(6, dtype=np.float64)
+    case.lj = dict(cutoff=("shifted_force", 1.0))
+    o = case.oracle(np.float64)
+    w = o.virial(o.neighbors("cell"))
+    assert np.abs(w - w.T).max() < 1e-9 * np.abs(w).max()
+
+    def energy(lam):
+        c2 = S.Case(case.coords * lam, case.box * lam, lj=case.lj, r_list=case.r_list, sigma=case.sigma, eps=case.eps, mass=case.mass)
+        o2 = c2.oracle(np.float64)
+        return o2.potential_energy(o2.neighbors("cell"))
+
+    h = 1e-6
+    assert np.trace(w) == pytest.approx(-(energy(1 + h) - energy(1 - h)) / (2 * h), rel=1e-7)
