@@ -182,11 +182,12 @@ int32_t mhip_get_state(mhip_ctx* ctx, void* xyz, void* vel, int32_t mem_kind);  
  * zeroes fs_mat, force.jl:1216); 0 overwrites.  step_n drives the rebuild cadence exactly like
  * find_neighbors (neighbors.jl:396): rebuild when stale or step_n % rebuild_every == 0 and the
  * step differs from the step of the last build.  virial9 (nullable): 9 HOST doubles, row-major 3x3, to which the pairwise
- * virial Σ dr ⊗ f over the pair list is ADDED (≙ needs_vir, force.jl:848-852, 877-880; buffers.virial_nounits).  The virial of the
- * specific and general interactions is not computed by this library. */
+ * virial Σ dr ⊗ f over the pair list is ADDED (≙ needs_vir, force.jl:848-852, 877-880; buffers.virial_nounits). */
 int32_t mhip_forces(mhip_ctx* ctx, int64_t step_n, int32_t accumulate, void* f_xyz,
                     void* virial9, int32_t mem_kind);
 int32_t mhip_specific_forces(mhip_ctx* ctx, int32_t accumulate, void* f_xyz, int32_t mem_kind);
+/* virial of the specific interactions, Σ r ⊗ f per term (≙ needs_vir in specific_force!, force.jl:991-1060), ADDED to 9 host doubles */
+int32_t mhip_specific_virial(mhip_ctx* ctx, double* virial9);
 int32_t mhip_potential_energy(mhip_ctx* ctx, int64_t step_n, double* pe_out);
 int32_t mhip_specific_potential_energy(mhip_ctx* ctx, double* pe_out);
 /* ---- general interaction: particle-mesh Ewald, reciprocal space ------------
@@ -201,6 +202,8 @@ int32_t mhip_set_pme(mhip_ctx* ctx, int32_t order, const int32_t* mesh3, double 
 int32_t mhip_general_forces(mhip_ctx* ctx, int32_t accumulate, void* f_xyz, int32_t mem_kind);
 /* E_recip + E_self + E_net-charge                                           (ewald.jl:898-928) */
 int32_t mhip_general_potential_energy(mhip_ctx* ctx, double* pe_out);
+/* reciprocal-space virial (recip_conv_inner!, ewald.jl:701-723, 747-750) + the net-charge term (:925-927), ADDED to 9 host doubles */
+int32_t mhip_general_virial(mhip_ctx* ctx, double* virial9);
 int32_t mhip_kinetic_energy(mhip_ctx* ctx, double* ke_out);
 int32_t mhip_remove_cm(mhip_ctx* ctx);
 int32_t mhip_check_finite(mhip_ctx* ctx);          /* check_nans, simulators.jl:98-111 */

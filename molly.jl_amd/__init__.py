@@ -9,6 +9,6 @@ from .api import (  # noqa: F401
     CubicBoundary, CubicSplineCutoff, DistanceCutoff, DistanceNeighborFinder, EwaldExclusions, GPUNeighborFinder,
     HarmonicAngles, HarmonicBonds, LennardJones, NeighborList, NoCutoff, NoNeighborFinder, PeriodicTorsions,
     PME, PolynomialCutoff, ShiftedForceCutoff, ShiftedPotentialCutoff, System, VelocityVerlet, find_neighbors, forces,
-    kinetic_energy, potential_energy, remove_CM_motion, scalar_virial, simulate, temperature, total_energy, use_neighbors, virial,
+    kinetic_energy, potential_energy, pressure, scalar_pressure, remove_CM_motion, scalar_virial, simulate, temperature, total_energy, use_neighbors, virial,
     wrap_coords,
 )

@@ -93,6 +93,8 @@ SIGNATURES = {
     "mhip_shift_velocities": (_I32, [_P, C.POINTER(_D * 3)]),
     "mhip_cm_momentum_dev": (_I32, [_P, _P]),
     "mhip_remove_cm_dev": (_I32, [_P, _P]),
+    "mhip_specific_virial": (_I32, [_P, _P]),
+    "mhip_general_virial": (_I32, [_P, _P]),
     "mhip_set_pme": (_I32, [_P, _I32, _P, _D, _D]),
     "mhip_general_forces": (_I32, [_P, _I32, _P, _I32]),
     "mhip_general_potential_energy": (_I32, [_P, C.POINTER(_D)]),

@@ -427,22 +427,38 @@ def forces(sys, step_n=0, pairwise=True, specific=True, general=True):
     return out
 
 
-def virial(sys, step_n=0):
-    """virial(sys): 3×3 tensor Σ dr ⊗ f over the neighbour pairs of the pairwise interactions (force.jl:848-852, energy.jl:116-131).
-    The specific and general interactions' virial is outside the scope of the engine."""
-    if sys.specific_inter_lists or sys.general_inters:
-        raise MollyHipError(-6, "the virial of specific / general interactions is outside the hot-path scope")
+def virial(sys, step_n=0, pairwise=True, specific=True, general=True):
+    """virial(sys): 3×3 tensor Σ r ⊗ f of the pairwise (over the neighbour pairs, force.jl:848-852), specific (force.jl:991-1060) and
+    general (PME reciprocal space, ewald.jl:701-723, 925-927) interactions (energy.jl:116-131)."""
     L = _lib.lib()
     sys.push_state(velocities=False)
-    out = np.zeros((len(sys), 3), sys.dtype)
     v = np.zeros(9, np.float64)
-    sys._check(L.mhip_forces(sys._ctx, step_n, 0, sys._ptr(out), v.ctypes.data_as(C.c_void_p), _lib.MEM_HOST))
+    vp = v.ctypes.data_as(C.c_void_p)
+    if pairwise and sys.pairwise_inters:
+        out = np.zeros((len(sys), 3), sys.dtype)
+        sys._check(L.mhip_forces(sys._ctx, step_n, 0, sys._ptr(out), vp, _lib.MEM_HOST))
+    if specific and sys.specific_inter_lists:
+        sys._check(L.mhip_specific_virial(sys._ctx, vp))
+    if general and sys.general_inters:
+        sys._check(L.mhip_general_virial(sys._ctx, vp))
     return v.reshape(3, 3)
 
 
 def scalar_virial(sys, step_n=0):
     """scalar_virial(sys) = tr(virial(sys)) (energy.jl:148-151)"""
     return float(np.trace(virial(sys, step_n)))
+
+
+def pressure(sys, step_n=0):
+    """pressure(sys) = (2K + W) / V with K = ½ Σ m v ⊗ v (spatial.jl:930-982), in kJ mol⁻¹ nm⁻³ (1 kJ mol⁻¹ nm⁻³ = 16.6054 bar)"""
+    w = virial(sys, step_n)
+    v = np.asarray(sys.velocities, dtype=np.float64); m = np.asarray(sys.masses, dtype=np.float64)
+    k = 0.5 * np.einsum("i,ia,ib->ab", m, v, v)
+    return (2.0 * k + w) / float(np.prod(sys.boundary.side_lengths))
+
+
+def scalar_pressure(sys, step_n=0):
+    return float(np.trace(pressure(sys, step_n))) / 3.0
 
 
 def potential_energy(sys, step_n=0, pairwise=True, specific=True, general=True):

@@ -47,6 +47,21 @@ template <class T> struct SlotSink {     // slot = first slot of the term + role
     __device__ inline void operator()(int, int role, T fx, T fy, T fz) const { out[first + role] = make4<T>(fx, fy, fz, T(0)); }
 };
 
+// Σ over the atoms of a term of (r_atom − r_first) ⊗ f_atom.  The reference takes the SECOND atom as the origin (force.jl:991-1060);
+// a term's forces add up to zero, so the tensor does not depend on the origin (to rounding).
+template <class T> struct VirialSink {
+    const typename Vec<T>::T4* pos; const GridP<T>* G; double* v; typename Vec<T>::T4 p0;
+    __device__ inline void operator()(int s, int role, T fx, T fy, T fz) {
+        if (role == 0) { p0 = pos[s]; return; }
+        T d[3]; min_image<T>(p0, pos[s], *G, d);
+        const T f[3] = {fx, fy, fz};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) v[3 * a + b] += (double)(d[a] * f[b]);
+    }
+};
+
 template <class T, bool ENERGY, class Sink>
 __device__ inline void d_bonds(int64_t t, int64_t n, const int32_t* __restrict__ bi, const int32_t* __restrict__ bj, const T* __restrict__ bk, const T* __restrict__ br0,
                         const int32_t* __restrict__ inv, const typename Vec<T>::T4* __restrict__ pos, Sink&& sink, double& e, const GridP<T>& G) {
@@ -168,6 +183,19 @@ __global__ void k_bonded(BondedArgs<T> A) {
     if constexpr (ENERGY) block_sum_to(e, A.part);
 }
 
+// the specific interactions' virial: per-block partial sums of the nine components, component-major in A.part
+template <class T>
+__global__ void k_bonded_virial(BondedArgs<T> A, int n_blocks_total) {
+    const int blk = blockIdx.x;
+    double e = 0, v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    VirialSink<T> sink{A.pos, &A.G, v, make4<T>(T(0), T(0), T(0), T(0))};
+    if (blk < A.blk_b) d_bonds<T, false>((int64_t)blk * blockDim.x + threadIdx.x, A.n_b, A.b_i, A.b_j, A.b_k, A.b_r0, A.inv, A.pos, sink, e, A.G);
+    else if (blk < A.blk_b + A.blk_a) d_angles<T, false>((int64_t)(blk - A.blk_b) * blockDim.x + threadIdx.x, A.n_a, A.a_i, A.a_j, A.a_k, A.a_kth, A.a_th0, A.inv, A.pos, sink, e, A.G);
+    else if (blk < A.blk_b + A.blk_a + A.blk_t) d_torsions<T, false>((int64_t)(blk - A.blk_b - A.blk_a) * blockDim.x + threadIdx.x, A.n_t, A.t_i, A.t_j, A.t_k, A.t_l, A.t_per, A.t_phase, A.t_k0, A.inv, A.pos, sink, e, A.G);
+    else d_ewald_excl<T, false>((int64_t)(blk - A.blk_b - A.blk_a - A.blk_t) * blockDim.x + threadIdx.x, A.n_x, A.x_i, A.x_j, A.inv, A.pos, sink, e, A.G, A.I);
+    for (int c = 0; c < 9; ++c) { block_sum_to(v[c], A.part + (int64_t)c * n_blocks_total); __syncthreads(); }
+}
+
 // frc[s] += Σ slots of the terms atom orig[s] takes part in.  Eight lanes share an atom (lane l takes slots l, l+8, … and a fixed
 // shuffle tree adds them): a backbone atom sits in dozens of torsion terms, and one lane walking them serially set the kernel's
 // duration.  Fixed order → bit-reproducible.
@@ -279,6 +307,15 @@ template <class T> struct Bonded {
         hipLaunchKernelGGL((k_bonded<T, false, true>), dim3(nb), dim3(BT), 0, s, args(G, I, pos, inv, slots, nullptr));
         hipLaunchKernelGGL(k_bonded_collect<T>, dim3((unsigned)cdiv(n_owned * COLLECT_LANES, (int64_t)256)), dim3(256), 0, s, n_owned, orig, (const int32_t*)role_start.p, (const int32_t*)role_slot.p, (const T4*)slots, frc);
         MHIP_HIP(hipGetLastError());
+    }
+    // nine component-major runs of per-block partial sums of the specific interactions' virial; returns the run length
+    template <class DB> int launch_virial(hipStream_t s, const GridP<T>& G, const InterP<T>& I, const T4* pos, const int32_t* inv, DB& part) {
+        int nb = n_blocks();
+        if (!nb) return 0;
+        part.reserve(9 * (size_t)nb);
+        hipLaunchKernelGGL(k_bonded_virial<T>, dim3(nb), dim3(BT), 0, s, args(G, I, pos, inv, (T4*)nullptr, part.p), nb);
+        MHIP_HIP(hipGetLastError());
+        return nb;
     }
     // writes per-block partial energies into part (grown as needed); returns their count
     template <class DB> int launch_energy(hipStream_t s, const GridP<T>& G, const InterP<T>& I, const T4* pos, const int32_t* inv, DB& part) {

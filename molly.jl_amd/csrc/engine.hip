@@ -63,6 +63,8 @@ struct EngineBase {
     virtual void cm_momentum_dev(double*) = 0;
     virtual void remove_cm_dev(const double*) = 0;
     virtual void pairwise_virial(int64_t, double*) = 0;
+    virtual void specific_virial(double*) = 0;
+    virtual void general_virial(double*) = 0;
     virtual void set_pme(int32_t, const int32_t*, double, double) = 0;
     virtual void general_forces(int, void*, int) = 0;
     virtual double general_potential_energy() = 0;
@@ -870,6 +872,33 @@ template <class T> class Engine final : public EngineBase {
         out9[1] += v[3]; out9[3] += v[3]; out9[2] += v[4]; out9[6] += v[4]; out9[5] += v[5]; out9[7] += v[5];
     }
 
+    double sum_run(const double* part, int n) {
+        hipLaunchKernelGGL(k_sum_double, dim3(1), dim3(256), 0, stream, n, part, red_out.p);
+        MHIP_HIP(hipMemcpyAsync(h_red, red_out.p, sizeof(double), hipMemcpyDeviceToHost, stream));
+        MHIP_HIP(hipStreamSynchronize(stream));
+        return h_red[0];
+    }
+    // Σ over the specific interactions of r ⊗ f (force.jl:991-1060), ADDED to out9
+    void specific_virial(double* out9) override {
+        if (!state_set) throw ApiError{MHIP_ERR_STATE, "set_state must be called before specific_virial"};
+        const int nb = bonded.launch_virial(stream, G, I, pos[cur].p, inv.p, red_part);
+        if (!nb) return;
+        for (int c = 0; c < 9; ++c) out9[c] += sum_run((const double*)red_part.p + (size_t)c * nb, nb);
+    }
+    // reciprocal-space PME virial (recip_conv_inner! ewald.jl:701-723, halved :747-750) + the net-charge term charge_E·I (:925-927), ADDED to out9
+    void general_virial(double* out9) override {
+        if (!state_set) throw ApiError{MHIP_ERR_STATE, "set_state must be called before general_virial"};
+        if (!pme.on()) return;
+        const double e = general_potential_energy();           // fills red_part with the 7 component-major runs (and Σq)
+        (void)e;
+        const int nb = pme.conv_blocks();
+        double v[6];
+        for (int c = 0; c < 6; ++c) v[c] = 0.5 * sum_run((const double*)red_part.p + (size_t)(c + 1) * nb, nb);
+        const double charge_E = pme.charge_factor * pc_sum * pc_sum;
+        out9[0] += v[0] + charge_E; out9[4] += v[1] + charge_E; out9[8] += v[2] + charge_E;
+        out9[1] += v[3]; out9[3] += v[3]; out9[2] += v[4]; out9[6] += v[4]; out9[5] += v[5]; out9[7] += v[5];
+    }
+
     double specific_potential_energy() override {
         if (!state_set) throw ApiError{MHIP_ERR_STATE, "set_state must be called before specific_potential_energy"};
         int n_part = bonded.launch_energy(stream, G, I, pos[cur].p, inv.p, red_part);
@@ -904,7 +933,7 @@ template <class T> class Engine final : public EngineBase {
             pc_valid = true;
         }
         const int nb = pme.conv_blocks();
-        red_part.reserve(nb);
+        red_part.reserve(7 * (size_t)nb);
         pme.run(stream, n_owned, pos[cur].p, (T4*)nullptr, red_part.p);
         return 0.5 * read_sum(nb) + pme.self_factor * pc_abs2_sum + pme.charge_factor * pc_sum * pc_sum;   // ewald.jl:917-928
     }
@@ -1268,6 +1297,8 @@ int32_t mhip_cm_momentum(mhip_ctx* ctx, double* out4) { NEED_CTX(); return guard
 int32_t mhip_shift_velocities(mhip_ctx* ctx, const double* dv3) { NEED_CTX(); return guard(ctx, [&] { ctx->e->shift_velocities(dv3); }); }
 int32_t mhip_cm_momentum_dev(mhip_ctx* ctx, double* out4) { NEED_CTX(); return guard(ctx, [&] { ctx->e->cm_momentum_dev(out4); }); }
 int32_t mhip_remove_cm_dev(mhip_ctx* ctx, const double* t4) { NEED_CTX(); return guard(ctx, [&] { ctx->e->remove_cm_dev(t4); }); }
+int32_t mhip_specific_virial(mhip_ctx* ctx, double* out9) { NEED_CTX(); return guard(ctx, [&] { if (!out9) throw mhip::ApiError{MHIP_ERR_INVALID, "null output"}; ctx->e->specific_virial(out9); }); }
+int32_t mhip_general_virial(mhip_ctx* ctx, double* out9) { NEED_CTX(); return guard(ctx, [&] { if (!out9) throw mhip::ApiError{MHIP_ERR_INVALID, "null output"}; ctx->e->general_virial(out9); }); }
 int32_t mhip_set_pme(mhip_ctx* ctx, int32_t order, const int32_t* mesh, double alpha, double eps_r) {
     NEED_CTX(); return guard(ctx, [&] { if (order != 0 && !mesh) throw mhip::ApiError{MHIP_ERR_INVALID, "null mesh"}; ctx->e->set_pme(order, mesh, alpha, eps_r); });
 }

@@ -391,7 +391,7 @@ __global__ void __launch_bounds__(PME_THREADS) k_pme_dft(DftArgs<T> A) {
         }
         re = r0 + r1; im = i0 + i1;
     };
-    [[maybe_unused]] double e_loc = 0;
+    [[maybe_unused]] double e_loc = 0, v_loc[6] = {0, 0, 0, 0, 0, 0};
     for (int o = tid; o < n * C; o += PME_THREADS) {       // one round unless n > 256
         const int c = o / n, k = o - c * n;
         T re, im;
@@ -407,7 +407,20 @@ __global__ void __launch_bounds__(PME_THREADS) k_pme_dft(DftArgs<T> A) {
                     const T m2 = mhx * mhx + mhy * mhy + mhz * mhz;
                     const T denom = m2 * (A.P.pi_V * A.bsm[0][kx]) * A.bsm[1][ky] * A.bsm[2][kz];
                     const T eterm = A.P.f_div_er * M<T>::exp(-A.P.factor * m2) / denom;
-                    if constexpr (ENERGY) e_loc += (double)(eterm * (re * re + im * im)) * ((kz == 0 || 2 * kz == nz) ? 1.0 : 2.0);
+                    if constexpr (ENERGY) {
+                        const bool twice = !(kz == 0 || 2 * kz == nz);           // stands for k and its mirror −k of the full mesh
+                        const double Ek = (double)(eterm * (re * re + im * im)) * (twice ? 2.0 : 1.0);
+                        e_loc += Ek;
+                        // V·P_k = E_k [I − 2(1 + factor·m²)(m ⊗ m)/m²]  (recip_conv_inner! :701-723), six independent components.
+                        // The reference visits k and −k separately and an even mesh's Nyquist index keeps its sign of m under the mirror
+                        // (:685-693), so there the mixed term of a Nyquist axis and a regular one cancels between the two.
+                        const double coeff = 2.0 * (1.0 + (double)A.P.factor * (double)m2) / (double)m2;
+                        const bool nqx = twice && 2 * kx == nx, nqy = twice && 2 * ky == ny;
+                        v_loc[0] += Ek * (1.0 - coeff * mhx * mhx); v_loc[1] += Ek * (1.0 - coeff * mhy * mhy); v_loc[2] += Ek * (1.0 - coeff * mhz * mhz);
+                        if (nqx == nqy) v_loc[3] -= Ek * coeff * mhx * mhy;
+                        if (!nqx) v_loc[4] -= Ek * coeff * mhx * mhz;
+                        if (!nqy) v_loc[5] -= Ek * coeff * mhy * mhz;
+                    }
                     v.x = re * eterm; v.y = im * eterm;
                 }
                 // k = 0: the reference leaves the DC term of the charge grid untouched (:681-683); it only adds a constant to the
@@ -424,13 +437,17 @@ __global__ void __launch_bounds__(PME_THREADS) k_pme_dft(DftArgs<T> A) {
             dft_one(l_b, true, k, c, re, im);
             if (c < n_here) { T2 v; v.x = re; v.y = im; A.grid[line_base(q0 + c) + k * stride] = v; }
         }
-        if constexpr (ENERGY) {
+        if constexpr (ENERGY) {   // per-block sums, component-major in e_part: energy, then xx yy zz xy xz yz of the virial
             __shared__ double sh_e[PME_THREADS / 64];
+            for (int c = 0; c < 7; ++c) {
+                double val = c == 0 ? e_loc : v_loc[c - 1];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) e_loc += __shfl_xor(e_loc, o, 64);
-            if ((tid & 63) == 0) sh_e[tid >> 6] = e_loc;
-            __syncthreads();
-            if (tid == 0) { double s = 0; for (int w = 0; w < PME_THREADS / 64; ++w) s += sh_e[w]; A.e_part[blockIdx.x] = s; }
+                for (int o = 32; o > 0; o >>= 1) val += __shfl_xor(val, o, 64);
+                if ((tid & 63) == 0) sh_e[tid >> 6] = val;
+                __syncthreads();
+                if (tid == 0) { double s = 0; for (int w = 0; w < PME_THREADS / 64; ++w) s += sh_e[w]; A.e_part[(int64_t)c * gridDim.x + blockIdx.x] = s; }
+                __syncthreads();
+            }
         }
     }
 }
@@ -567,7 +584,8 @@ template <class T> struct Pme {
     }
 
     // ewald_pe_forces! (:873-929) on the sorted arrays: frc (nullable) gets the reciprocal-space forces ADDED; e_part (nullable)
-    // receives conv_blocks() partial sums of Σ eterm·|S|² (the caller halves them and adds the self terms).
+    // receives 7·conv_blocks() partial sums, component-major: Σ eterm·|S|² and the six components of the reciprocal virial (the caller halves
+    // them and adds the self / net-charge terms).
     void run(hipStream_t s, int64_t n_atoms, const T4* pos, T4* frc, double* e_part) {
         if (order == 4) spread_t<4>(s, n_atoms, pos); else if (order == 5) spread_t<5>(s, n_atoms, pos); else spread_t<6>(s, n_atoms, pos);
         z_r2c(s);

@@ -113,7 +113,9 @@ template <class T> struct Pme {
     }
 
     // ewald_pe_forces! :873-929.  x: 3n coords, q: n charges; fs (nullable): 3n forces, the PME force is ADDED (Fs[i] -= f, :838)
-    T run(int64_t natoms, const T* x, const T* q, T* fs) const {
+    // vir (nullable, 9 entries, ADDED): reciprocal-space virial of recip_conv_inner! (:701-723), halved like the energy (:747-750), plus the
+    // net-charge term charge_E·I (:925-927)
+    T run(int64_t natoms, const T* x, const T* q, T* fs, T* vir = nullptr) const {
         const int nx = n[0], ny = n[1], nz = n[2];
         std::vector<std::complex<T>> grid((size_t)nx * ny * nz, std::complex<T>(0, 0));
         std::vector<int> idx(3 * (size_t)natoms);
@@ -150,6 +152,10 @@ template <class T> struct Pme {
             T eterm = f_div_er * std::exp(-factor * m2) / denom;
             gv = std::complex<T>(d1 * eterm, d2 * eterm);
             esum += eterm * (d1 * d1 + d2 * d2);
+            if (vir) {   // V·P_k = E_k [I − 2(1 + factor·m²)(m ⊗ m)/m²]
+                const T Ek = eterm * (d1 * d1 + d2 * d2), coeff = T(2) * (T(1) + factor * m2) / m2, mh[3] = {mhx, mhy, mhz};
+                for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) vir[3 * a + b] += (Ek * ((a == b ? T(1) : T(0)) - coeff * mh[a] * mh[b])) / T(2);
+            }
         }
         const T recip_E = esum / T(2);
         dft3(grid, +1);
@@ -178,6 +184,7 @@ template <class T> struct Pme {
         for (int64_t i = 0; i < natoms; ++i) { pc_sum += q[i]; pc_abs2 += q[i] * q[i]; }
         const T charge_E = -f_div_er * T(M_PI) * pc_sum * pc_sum / (T(2) * V * alpha * alpha);
         const T self_E = f_div_er * -pc_abs2 * alpha / std::sqrt(T(M_PI)) + charge_E;
+        if (vir) for (int a = 0; a < 3; ++a) vir[4 * a] += charge_E;
         return recip_E + self_E;
     }
 };

@@ -84,7 +84,7 @@ def lib(native=False):
         L.orc_energy.argtypes = [C.c_int, C.POINTER(OrcSystem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
         L.orc_kinetic_energy.restype = C.c_double; L.orc_kinetic_energy.argtypes = [C.c_int, C.POINTER(OrcSystem)]
         L.orc_virial.restype = None
-        L.orc_virial.argtypes = [C.c_int, C.POINTER(OrcSystem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.orc_virial.argtypes = [C.c_int, C.POINTER(OrcSystem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         L.orc_remove_cm.restype = None; L.orc_remove_cm.argtypes = [C.c_int, C.POINTER(OrcSystem)]
         L.orc_wrap.restype = None; L.orc_wrap.argtypes = [C.c_int, C.POINTER(OrcSystem)]
         L.orc_vv_run.restype = None
@@ -198,14 +198,16 @@ class OracleSystem:
         i, j, sp = nl
         return self.L.orc_energy(self.prec, C.byref(self.s), _ptr(i), _ptr(j), _ptr(sp), len(i), mask)
 
-    def virial(self, nl=None):
-        """3x3 virial tensor of the pairwise interactions, Σ dr ⊗ f over the list (force.jl:848-852)"""
+    def virial(self, nl=None, pairwise=True, specific=False, general=False):
+        """3x3 virial tensor: Σ dr ⊗ f over the pair list (force.jl:848-852), the specific interactions (force.jl:991-1060) and
+        the PME reciprocal-space part (ewald.jl:701-723, 925-927)"""
         out = np.zeros(9)
+        mask = (1 if pairwise else 0) | (2 if specific else 0) | (4 if general else 0)
         if nl is None:
-            self.L.orc_virial(self.prec, C.byref(self.s), None, None, None, -1, _ptr(out))
+            self.L.orc_virial(self.prec, C.byref(self.s), None, None, None, -1, mask, _ptr(out))
         else:
             i, j, sp = nl
-            self.L.orc_virial(self.prec, C.byref(self.s), _ptr(i), _ptr(j), _ptr(sp), len(i), _ptr(out))
+            self.L.orc_virial(self.prec, C.byref(self.s), _ptr(i), _ptr(j), _ptr(sp), len(i), mask, _ptr(out))
         return out.reshape(3, 3)
 
     def kinetic_energy(self):

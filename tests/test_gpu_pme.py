@@ -88,3 +88,24 @@ def test_complete_pme_step_conserves_energy_fp64(pkg):
         es.append(pkg.total_energy(s))
     assert max(abs(e - e0) for e in es) < 0.06 * abs(e0)
     assert abs(es[5] - e0) < 2e-3 * abs(e0) and abs(es[-1] - e0) < 5e-3 * abs(e0)
+
+
+@pytest.mark.parametrize("dtype,rel", [(np.float64, 1e-9), (np.float32, 3e-4)])
+def test_total_virial_and_pressure_6mrr_vs_oracle(pkg, dtype, rel):
+    """virial(sys) = pairwise + specific + PME parts (energy.jl:116-131), each against the oracle; test/protein.jl:168-171:
+    scalar_virial = tr(virial), scalar_pressure = tr(pressure) / 3"""
+    case = G.case("ewald", dtype, bonded=True, approx_erfc=False, pme=True)
+    o = case.oracle(np.float64)
+    nl = o.neighbors("cell", nthreads=8)
+    s = case.system(pkg, dtype)
+    for kw in (dict(pairwise=True, specific=False, general=False), dict(pairwise=False, specific=True, general=False), dict(pairwise=False, specific=False, general=True)):
+        w_ref = o.virial(nl, **kw)
+        w = pkg.virial(s, **kw)
+        assert np.abs(w - w_ref).max() < rel * np.abs(w_ref).max(), kw
+    w = pkg.virial(s)
+    assert np.abs(w - o.virial(nl, pairwise=True, specific=True, general=True)).max() < rel * np.abs(w).max()
+    assert pkg.scalar_virial(s) == pytest.approx(np.trace(w), rel=rel)        # recomputed: the spread's atomics reorder the mesh sums
+    p = pkg.pressure(s)
+    k = 0.5 * np.einsum("i,ia,ib->ab", case.mass, case.velocities, case.velocities)
+    assert np.abs(p - (2 * k + w) / np.prod(case.box)).max() < rel * np.abs(p).max()
+    assert pkg.scalar_pressure(s) == pytest.approx(np.trace(p) / 3, rel=rel)

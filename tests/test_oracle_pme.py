@@ -53,3 +53,33 @@ def test_100_step_pme_trajectory_vs_openmm():
     dx -= np.round(dx / box) * box
     assert np.linalg.norm(dx, axis=1).max() < 1e-10                                           # :297
     assert np.linalg.norm(o.vel - d["openmm_velocities_100steps"], axis=1).max() < 1e-7       # :298
+
+
+def test_specific_and_pme_virial_obey_the_scaling_identity():
+    """tr W = −dE/dλ under x → λx, L → λL for the specific interactions (force.jl:991-1060) and for the PME reciprocal part with α and
+    the mesh fixed (ewald.jl:701-723, 925-927); both tensors symmetric."""
+    from tests import systems as S
+    case = G.case(None, np.float64, lj=False, bonded=True)
+    w = case.oracle(np.float64).virial(None, pairwise=False, specific=True)
+
+    def e_spec(lam):
+        c2 = G.case(None, np.float64, lj=False, bonded=True)
+        c2.coords = case.coords * lam; c2.box = case.box * lam
+        return c2.oracle(np.float64).potential_energy(None, pairwise=False, specific=True)
+
+    h = 1e-7
+    assert np.trace(w) == pytest.approx(-(e_spec(1 + h) - e_spec(1 - h)) / (2 * h), rel=1e-7)
+    assert np.abs(w - w.T).max() < 1e-9 * np.abs(w).max()
+
+    mk = lambda: S.charged_fluid(8, dict(kind="ewald", rc=0.9, tol=5e-4), dtype=np.float64, with_exceptions=False, r_list=1.0, pme=dict(order=5, mesh=(14, 14, 14)))
+    cp = mk()
+    wp = cp.oracle(np.float64).virial(None, pairwise=False, general=True)
+
+    def e_pme(lam):
+        c2 = mk()
+        c2.coords = cp.coords * lam; c2.box = cp.box * lam
+        return c2.oracle(np.float64).potential_energy(None, pairwise=False, general=True)
+
+    h = 1e-6
+    assert np.trace(wp) == pytest.approx(-(e_pme(1 + h) - e_pme(1 - h)) / (2 * h), rel=1e-7)
+    assert np.abs(wp - wp.T).max() < 1e-10 * np.abs(wp).max()
