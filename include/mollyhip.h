@@ -226,6 +226,25 @@ int32_t mhip_vv_stage1(mhip_ctx* ctx, double dt);
 int32_t mhip_vv_stage2(mhip_ctx* ctx, int64_t step_n, double dt);   /* incl. find_neighbors when step_n % rebuild_every == 0 */
 int32_t mhip_rebuild(mhip_ctx* ctx, int64_t step_n);              /* force a neighbour rebuild now */
 
+/* ---- stochastic dynamics ------------------------------------------------ */
+/* All noise is Philox4x32-10 keyed by (key, ctr1) with the 1-based caller index of the atom as ctr0 (kernels.jl:688-741): results do
+ * not depend on the internal atom order.  kT = k·temperature in kJ/mol.
+ * simulate!(sys, ::Langevin, n_steps) (simulators.jl:1099-1220): per step
+ *   F = forces(x); v += (F/m) dt; x += v dt/2; v = exp(−γ dt) v + sqrt(1 − exp(−2 γ dt)) sqrt(kT/m) ξ; x += v dt/2; x = wrap(x);
+ *   CM removal and neighbour cadence as mhip_vv_run.  Step first_step + s (s = 1 …) uses ctr1 + s − 1 (:1189-1190). */
+int32_t mhip_langevin_run(mhip_ctx* ctx, int64_t first_step, int64_t n_steps, double dt, double kT, double friction,
+                          int32_t remove_cm_every, uint64_t philox_key, uint64_t philox_ctr1);
+/* random_velocities!(sys, temp) (spatial.jl:803-831, random_velocities_kernel! kernels.jl:688-704): v_i = sqrt(kT/m_i) ξ_i */
+int32_t mhip_random_velocities(mhip_ctx* ctx, double kT, uint64_t philox_key, uint64_t philox_ctr1);
+/* One application of AndersenThermostat (coupling.jl:196-211, apply_andersen_coupling_kernel! kernels.jl:706-723): each atom is
+ * re-drawn with probability prob = dt / coupling_const (clamped to [0, prevfloat(1)]). */
+int32_t mhip_andersen(mhip_ctx* ctx, double kT, double prob, uint64_t philox_key, uint64_t philox_ctr1);
+/* The same thermostat as the `coupling` of mhip_vv_run / mhip_langevin_run: applied after every step's CM removal (simulators.jl:630,
+ * 1208); the per-step (ctr1, key) are words of philox(step, 0; seed).  prob <= 0 switches it off. */
+int32_t mhip_set_andersen(mhip_ctx* ctx, double kT, double prob, uint64_t seed);
+/* the raw generator on the device (known-answer tests): out4 = philox4x32_10(ctr4, key2) */
+int32_t mhip_philox4x32_10(const uint32_t* ctr4, const uint32_t* key2, uint32_t* out4);
+
 /* ---- neighbour list export (bit-exact check) ------------------------------------------------ */
 /* Half list, each unordered pair once with i < j (0-based), special flag as neighbors.jl:411.
  * Pair SET equals the reference's for the same-precision arithmetic; order is unspecified.

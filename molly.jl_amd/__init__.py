@@ -5,10 +5,10 @@ libmollyhip.so) and the host-side mirror of the reference interface (`api.py`, `
 """
 from ._lib import MollyHipError, build, device_count, lib, LIB_PATH, SIGNATURES, Stats, Config, Interactions  # noqa: F401
 from .api import (  # noqa: F401
-    Atom, BOLTZMANN, COULOMB_CONST, CellListMapNeighborFinder, Coulomb, CoulombEwald, CoulombReactionField,
+    AndersenThermostat, Atom, BOLTZMANN, COULOMB_CONST, CellListMapNeighborFinder, Coulomb, CoulombEwald, CoulombReactionField,
     CubicBoundary, CubicSplineCutoff, DistanceCutoff, DistanceNeighborFinder, EwaldExclusions, GPUNeighborFinder,
-    HarmonicAngles, HarmonicBonds, LennardJones, NeighborList, NoCutoff, NoNeighborFinder, PeriodicTorsions,
+    HarmonicAngles, HarmonicBonds, Langevin, LennardJones, NeighborList, NoCutoff, NoNeighborFinder, PeriodicTorsions,
     PME, PolynomialCutoff, ShiftedForceCutoff, ShiftedPotentialCutoff, System, VelocityVerlet, find_neighbors, forces,
-    kinetic_energy, potential_energy, pressure, scalar_pressure, remove_CM_motion, scalar_virial, simulate, temperature, total_energy, use_neighbors, virial,
+    kinetic_energy, potential_energy, pressure, scalar_pressure, random_velocities, apply_coupling, remove_CM_motion, scalar_virial, simulate, temperature, total_energy, use_neighbors, virial,
     wrap_coords,
 )

@@ -93,6 +93,11 @@ SIGNATURES = {
     "mhip_shift_velocities": (_I32, [_P, C.POINTER(_D * 3)]),
     "mhip_cm_momentum_dev": (_I32, [_P, _P]),
     "mhip_remove_cm_dev": (_I32, [_P, _P]),
+    "mhip_langevin_run": (_I32, [_P, _I64, _I64, _D, _D, _D, _I32, C.c_uint64, C.c_uint64]),
+    "mhip_random_velocities": (_I32, [_P, _D, C.c_uint64, C.c_uint64]),
+    "mhip_andersen": (_I32, [_P, _D, _D, C.c_uint64, C.c_uint64]),
+    "mhip_set_andersen": (_I32, [_P, _D, _D, C.c_uint64]),
+    "mhip_philox4x32_10": (_I32, [_P, _P, _P]),
     "mhip_specific_virial": (_I32, [_P, _P]),
     "mhip_general_virial": (_I32, [_P, _P]),
     "mhip_set_pme": (_I32, [_P, _I32, _P, _D, _D]),

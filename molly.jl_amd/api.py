@@ -238,6 +238,33 @@ class VelocityVerlet:
     remove_CM_motion: int = 1    # simulators.jl:293
 
 
+@dataclass
+class AndersenThermostat:
+    """AndersenThermostat(temperature, coupling_const) (coupling.jl:188-211): every step each atom's velocity is re-drawn from the
+    Maxwell-Boltzmann distribution with probability dt / coupling_const."""
+    temperature: float
+    coupling_const: float
+
+
+class Langevin:
+    """Langevin(; dt, temperature, friction, coupling=nothing, remove_CM_motion=1) — the Langevin middle integrator
+    (simulators.jl:1065-1097): vel_scale = exp(−dt·friction), noise_scale = sqrt(1 − vel_scale²)."""
+
+    def __init__(self, dt, temperature, friction, coupling=None, remove_CM_motion=1):
+        self.dt, self.temperature, self.friction = float(dt), float(temperature), float(friction)
+        self.coupling, self.remove_CM_motion = coupling, int(remove_CM_motion)
+        self.vel_scale = float(np.exp(-self.dt * self.friction))
+        self.noise_scale = float(np.sqrt(1.0 - self.vel_scale ** 2))
+
+
+def _rng(rng):
+    return rng if isinstance(rng, np.random.Generator) else np.random.default_rng(rng)
+
+
+def _rand_u64(rng):
+    return int(rng.integers(0, 2 ** 64, dtype=np.uint64))          # rand(rng, UInt64)
+
+
 # ---- System --------------------------------------------------------------------------------------------
 class System:
     """System(; atoms, coords, boundary, velocities, pairwise_inters, specific_inter_lists, neighbor_finder)
@@ -520,22 +547,60 @@ def remove_CM_motion(sys):
     return sys
 
 
-def simulate(sys, sim, n_steps, init_step=0, check_nans=False):
-    """simulate!(sys, sim::VelocityVerlet, n_steps; init_step) — simulators.jl:547-668.  The whole loop runs on
-    the device; coordinates and velocities come back when the call returns."""
-    if not isinstance(sim, VelocityVerlet):
+def simulate(sys, sim, n_steps, init_step=0, check_nans=False, rng=None):
+    """simulate!(sys, sim, n_steps; init_step, rng) for VelocityVerlet (simulators.jl:547-668) and Langevin (:1099-1220), with
+    coupling nothing or AndersenThermostat.  The whole loop runs on the device; coordinates and velocities come back when the
+    call returns.  rng: a numpy Generator or a seed; as in the reference it only supplies the Philox key / counter words."""
+    if not isinstance(sim, (VelocityVerlet, Langevin)):
         raise MollyHipError(-6, f"simulator {type(sim).__name__} is outside the hot-path scope")
-    if sim.coupling is not None:
-        raise MollyHipError(-6, "coupling is outside the hot-path scope")
+    if sim.coupling is not None and not isinstance(sim.coupling, AndersenThermostat):
+        raise MollyHipError(-6, f"coupling {type(sim.coupling).__name__} is outside the hot-path scope")
     if init_step < 0:   # check_simulate_inputs
         raise ValueError("init_step must be non-negative")
     L = _lib.lib()
+    rng = _rng(rng)
     sys.push_state(velocities=True)
-    sys._check(L.mhip_vv_run(sys._ctx, init_step, n_steps, float(sim.dt), int(sim.remove_CM_motion)))
+    thermostat = sim.coupling
+    if thermostat is not None:
+        sys._check(L.mhip_set_andersen(sys._ctx, BOLTZMANN * float(thermostat.temperature), float(sim.dt) / float(thermostat.coupling_const), _rand_u64(rng)))
+    try:
+        if isinstance(sim, Langevin):
+            key, ctr1 = _rand_u64(rng), _rand_u64(rng)             # simulators.jl:1149-1150
+            sys._check(L.mhip_langevin_run(sys._ctx, init_step, n_steps, sim.dt, BOLTZMANN * sim.temperature, sim.friction,
+                                           int(sim.remove_CM_motion), key, ctr1))
+        else:
+            sys._check(L.mhip_vv_run(sys._ctx, init_step, n_steps, float(sim.dt), int(sim.remove_CM_motion)))
+    finally:
+        if thermostat is not None:
+            sys._check(L.mhip_set_andersen(sys._ctx, 0.0, 0.0, 0))
     if check_nans:
         sys._check(L.mhip_check_finite(sys._ctx))
     sys.pull_state()
     return sys
+
+
+def random_velocities(sys, temp, rng=None):
+    """random_velocities!(sys, temp; rng) (spatial.jl:803-831): Maxwell-Boltzmann velocities at temperature temp (K), drawn on the device"""
+    L = _lib.lib()
+    rng = _rng(rng)
+    sys.push_state(velocities=True)
+    ctr1, key = _rand_u64(rng), _rand_u64(rng)
+    sys._check(L.mhip_random_velocities(sys._ctx, BOLTZMANN * float(temp), key, ctr1))
+    sys.pull_state()
+    return sys
+
+
+def apply_coupling(sys, thermostat, sim, rng=None):
+    """apply_coupling!(sys, buffers, ::AndersenThermostat, sim) (coupling.jl:196-211): one application; returns False (no force recompute)"""
+    if not isinstance(thermostat, AndersenThermostat):
+        raise MollyHipError(-6, f"coupling {type(thermostat).__name__} is outside the hot-path scope")
+    L = _lib.lib()
+    rng = _rng(rng)
+    sys.push_state(velocities=True)
+    ctr1, key = _rand_u64(rng), _rand_u64(rng)
+    sys._check(L.mhip_andersen(sys._ctx, BOLTZMANN * float(thermostat.temperature), float(sim.dt) / float(thermostat.coupling_const), key, ctr1))
+    sys.pull_state()
+    return False
 
 
 def wrap_coords(coords, boundary):

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "bonded.h"
+#include "stochastic.h"
 #include "pme.h"
 #include "hilbert.h"
 #include "kernels.h"
@@ -50,6 +51,9 @@ struct EngineBase {
     virtual void check_finite() = 0;
     virtual void vv_run(int64_t, int64_t, double, int) = 0;
     virtual void vv_init(int64_t) = 0;
+    virtual void langevin_run(int64_t, int64_t, double, double, double, int, uint64_t, uint64_t) = 0;
+    virtual void redraw_velocities(int, double, double, uint64_t, uint64_t) = 0;
+    virtual void set_andersen(double, double, uint64_t) = 0;
     virtual void vv_stage1(double) = 0;
     virtual void vv_stage2(int64_t, double) = 0;
     virtual void rebuild_now(int64_t) = 0;
@@ -1106,7 +1110,72 @@ template <class T> class Engine final : public EngineBase {
             const bool pre = dual;                                                // without the dual list: the reference's order
             if (pre && step % every == 0) refresh(step);
             stage2_impl(step, dt, remove_cm_every != 0 && step % remove_cm_every == 0); // :612-628
+            apply_coupling(step);                                                 // :630
             if (!pre && step % every == 0) refresh(step);
+        }
+        flush_cm();
+        MHIP_HIP(hipGetLastError());
+        MHIP_HIP(hipStreamSynchronize(stream));
+    }
+
+    // ---- stochastic dynamics (kernels in stochastic.hip) ------------------------------------------------------
+    StochP<T> stoch_params(double kT, uint64_t key, uint64_t ctr1) const {
+        StochP<T> P{};
+        P.noise_kt = std::sqrt(kT); P.key = key; P.ctr1 = ctr1; P.natoms = (uint64_t)cfg.n_atoms;
+        return P;
+    }
+    // mode 0: one application of the Andersen thermostat with per-atom probability `prob` (coupling.jl:196-211);
+    // mode 1: random_velocities! (spatial.jl:803-831).  Velocities only: positions, forces and the pair list stay valid.
+    void redraw_velocities(int mode, double kT, double prob, uint64_t key, uint64_t ctr1) override {
+        if (!state_set || !params_set) throw ApiError{MHIP_ERR_STATE, "set_atoms and set_state must be called before drawing velocities"};
+        if (n_ghost > 0) throw ApiError{MHIP_ERR_UNSUPPORTED, "velocity draws are single-domain"};
+        if (!(kT >= 0)) throw ApiError{MHIP_ERR_INVALID, "kT must be non-negative"};
+        StochP<T> P = stoch_params(kT, key, ctr1);
+        const double pc = std::min(std::max(prob, 0.0), std::nextafter(1.0, 0.0));          // clamp(…, 0, prevfloat(1.0))
+        P.prob_u64 = (uint64_t)std::nearbyint(std::ldexp(pc, 64));                            // round(UInt64, prob·2⁶⁴) ≤ 2⁶⁴ − 2¹¹
+        launch_redraw<T>(stream, mode, n_owned, vel[cur].p, orig[cur].p, P, cm_pending == 1 ? (const T*)vcm.p : (const T*)nullptr,
+                         cm_pending == 2 ? cm_src() : (const double*)nullptr, n_cm_step);
+        cm_pending = 0; cm_ext = nullptr;
+        MHIP_HIP(hipGetLastError());
+    }
+    // AndersenThermostat as the coupling of vv_run / langevin_run: applied after every step's CM removal (simulators.jl:630, 1209);
+    // the reference draws (ctr1, key) from the host rng per step — here they are the words of philox(step, 0; seed)
+    double andersen_kT = 0, andersen_prob = 0; uint64_t andersen_seed = 0;
+    void set_andersen(double kT, double prob, uint64_t seed) override { andersen_kT = kT; andersen_prob = prob; andersen_seed = seed; }
+    void apply_coupling(int64_t step) {
+        if (!(andersen_prob > 0)) return;
+        uint32_t w[4]; philox_host((uint64_t)step, 0, andersen_seed, w);
+        redraw_velocities(0, andersen_kT, andersen_prob, ((uint64_t)w[3] << 32) | w[2], ((uint64_t)w[1] << 32) | w[0]);
+    }
+
+    // simulate!(sys, ::Langevin, n_steps) (simulators.jl:1099-1220) without constraints: per step the forces of the current
+    // coordinates, ONE fused update launch (kick, half drift, O-step, half drift, wrap, Σ m v partials), the neighbour cadence.
+    // ctr1 advances by one per step (:1190) from ctr1_0 + (first_step's offset), so chunked continuation reproduces one long run.
+    void langevin_run(int64_t first_step, int64_t n_steps, double dt, double kT, double friction, int remove_cm_every, uint64_t key, uint64_t ctr1_0) override {
+        if (!state_set || !params_set) throw ApiError{MHIP_ERR_STATE, "set_atoms and set_state must be called before langevin_run"};
+        if (n_ghost > 0) throw ApiError{MHIP_ERR_STATE, "langevin_run is single-domain"};
+        if (!(kT >= 0) || !(friction >= 0)) throw ApiError{MHIP_ERR_INVALID, "temperature and friction must be non-negative"};
+        const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
+        if (first_step == 0 && remove_cm_every != 0) remove_cm();                 // :1115
+        rebuild(first_step);                                                      // :1116
+        const double vs = std::exp(-dt * friction);                               // :1091-1092
+        StochP<T> P = stoch_params(kT, key, ctr1_0);
+        P.dt = T(dt); P.dt_half = T(dt) / T(2); P.vel_scale = T(vs); P.noise_kt = std::sqrt(1.0 - vs * vs) * std::sqrt(kT);
+        const int nb = std::min(cdiv(n_owned, 256), 1024);
+        for (int64_t step = first_step + 1; step <= first_step + n_steps; ++step) {
+            step_forces(step);                                                    // :1173
+            fold_side_forces();
+            const bool cm = remove_cm_every != 0 && step % remove_cm_every == 0;
+            P.ctr1 = ctr1_0 + (uint64_t)(step - first_step - 1);
+            prof.begin(2, stream);
+            launch_langevin<T>(stream, nb, n_owned, pos[cur].p, vel[cur].p, (const T4*)frc[cur].p, orig[cur].p, P,
+                               cm_pending == 1 ? (const T*)vcm.p : (const T*)nullptr, cm_pending == 2 ? cm_src() : (const double*)nullptr, n_cm_step,
+                               cm ? cm_step.p : (double*)nullptr, G);
+            prof.end(2, stream);
+            cm_pending = 0; cm_ext = nullptr; frc_valid = false;
+            if (cm) { cm_pending = 2; n_cm_step = nb; }                           // :1204-1206, subtracted by the next consumer
+            apply_coupling(step);                                                 // :1208
+            if (step % every == 0) refresh(step);                                 // :1211 — the next force pass prunes the fresh outer list
         }
         flush_cm();
         MHIP_HIP(hipGetLastError());
@@ -1297,6 +1366,23 @@ int32_t mhip_cm_momentum(mhip_ctx* ctx, double* out4) { NEED_CTX(); return guard
 int32_t mhip_shift_velocities(mhip_ctx* ctx, const double* dv3) { NEED_CTX(); return guard(ctx, [&] { ctx->e->shift_velocities(dv3); }); }
 int32_t mhip_cm_momentum_dev(mhip_ctx* ctx, double* out4) { NEED_CTX(); return guard(ctx, [&] { ctx->e->cm_momentum_dev(out4); }); }
 int32_t mhip_remove_cm_dev(mhip_ctx* ctx, const double* t4) { NEED_CTX(); return guard(ctx, [&] { ctx->e->remove_cm_dev(t4); }); }
+int32_t mhip_langevin_run(mhip_ctx* ctx, int64_t first, int64_t n, double dt, double kT, double friction, int32_t cm_every, uint64_t key, uint64_t ctr1) {
+    NEED_CTX(); return guard(ctx, [&] {
+        if (first < 0 || n < 0 || !(dt > 0)) throw mhip::ApiError{MHIP_ERR_INVALID, "first_step and n_steps must be non-negative, dt positive"};
+        ctx->e->langevin_run(first, n, dt, kT, friction, cm_every, key, ctr1); });
+}
+int32_t mhip_random_velocities(mhip_ctx* ctx, double kT, uint64_t key, uint64_t ctr1) { NEED_CTX(); return guard(ctx, [&] { ctx->e->redraw_velocities(1, kT, 1.0, key, ctr1); }); }
+int32_t mhip_andersen(mhip_ctx* ctx, double kT, double prob, uint64_t key, uint64_t ctr1) { NEED_CTX(); return guard(ctx, [&] { ctx->e->redraw_velocities(0, kT, prob, key, ctr1); }); }
+int32_t mhip_set_andersen(mhip_ctx* ctx, double kT, double prob, uint64_t seed) { NEED_CTX(); return guard(ctx, [&] { ctx->e->set_andersen(kT, prob, seed); }); }
+int32_t mhip_philox4x32_10(const uint32_t* ctr4, const uint32_t* key2, uint32_t* out4) {
+    if (!ctr4 || !key2 || !out4) return MHIP_ERR_INVALID;
+    uint32_t *in = nullptr, *out = nullptr, h[6] = {ctr4[0], ctr4[1], ctr4[2], ctr4[3], key2[0], key2[1]};
+    if (hipMalloc((void**)&in, sizeof(h)) != hipSuccess || hipMalloc((void**)&out, 4 * sizeof(uint32_t)) != hipSuccess) { (void)hipFree(in); return MHIP_ERR_HIP; }
+    bool ok = hipMemcpy(in, h, sizeof(h), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) { mhip::launch_philox_probe(nullptr, in, out); ok = hipMemcpy(out4, out, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess; }
+    (void)hipFree(in); (void)hipFree(out);
+    return ok ? MHIP_OK : MHIP_ERR_HIP;
+}
 int32_t mhip_specific_virial(mhip_ctx* ctx, double* out9) { NEED_CTX(); return guard(ctx, [&] { if (!out9) throw mhip::ApiError{MHIP_ERR_INVALID, "null output"}; ctx->e->specific_virial(out9); }); }
 int32_t mhip_general_virial(mhip_ctx* ctx, double* out9) { NEED_CTX(); return guard(ctx, [&] { if (!out9) throw mhip::ApiError{MHIP_ERR_INVALID, "null output"}; ctx->e->general_virial(out9); }); }
 int32_t mhip_set_pme(mhip_ctx* ctx, int32_t order, const int32_t* mesh, double alpha, double eps_r) {

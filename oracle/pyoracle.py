@@ -52,7 +52,8 @@ class OrcSystem(C.Structure):
                 ("n_tors", C.c_int64), ("t_i", C.c_void_p), ("t_j", C.c_void_p), ("t_k", C.c_void_p), ("t_l", C.c_void_p),
                 ("t_per", C.c_void_p), ("t_phase", C.c_void_p), ("t_k0", C.c_void_p),
                 ("n_ewx", C.c_int64), ("x_i", C.c_void_p), ("x_j", C.c_void_p),
-                ("pme_order", C.c_int32), ("pme_mesh", C.c_int32 * 3), ("pme_eps_r", C.c_double)]
+                ("pme_order", C.c_int32), ("pme_mesh", C.c_int32 * 3), ("pme_eps_r", C.c_double),
+                ("andersen_kT", C.c_double), ("andersen_prob", C.c_double), ("andersen_seed", C.c_uint64)]
 
 
 def build(native=False, quiet=True):
@@ -68,7 +69,7 @@ _libs = {}
 def lib(native=False):
     if native not in _libs:
         path = os.path.join(_HERE, "_native", "liboracle_native.so") if native else os.path.join(_HERE, "liboracle.so")
-        src_time = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("oracle.cpp", "pme.h"))
+        src_time = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("oracle.cpp", "pme.h", "stochastic.h"))
         if native or not os.path.exists(path) or os.path.getmtime(path) < src_time:
             path = build(native)
         L = C.CDLL(path)
@@ -87,6 +88,13 @@ def lib(native=False):
         L.orc_virial.argtypes = [C.c_int, C.POINTER(OrcSystem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         L.orc_remove_cm.restype = None; L.orc_remove_cm.argtypes = [C.c_int, C.POINTER(OrcSystem)]
         L.orc_wrap.restype = None; L.orc_wrap.argtypes = [C.c_int, C.POINTER(OrcSystem)]
+        L.orc_langevin_run.restype = None
+        L.orc_langevin_run.argtypes = [C.c_int, C.POINTER(OrcSystem), C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int,
+                                       C.c_uint64, C.c_uint64, C.c_int, C.c_int]
+        L.orc_redraw.restype = None
+        L.orc_redraw.argtypes = [C.c_int, C.POINTER(OrcSystem), C.c_int, C.c_double, C.c_double, C.c_uint64, C.c_uint64]
+        L.orc_philox4x32_10.restype = None; L.orc_philox4x32_10.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_randn3.restype = None; L.orc_randn3.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p]
         L.orc_vv_run.restype = None
         L.orc_vv_run.argtypes = [C.c_int, C.POINTER(OrcSystem), C.c_int64, C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int]
         L.orc_force_scale.restype = None
@@ -223,6 +231,26 @@ class OracleSystem:
         mask = (1 if pairwise else 0) | (2 if specific else 0) | (4 if general else 0)
         self.L.orc_vv_run(self.prec, C.byref(self.s), first_step, n_steps, float(dt), remove_cm_every, nthreads, mask)
 
+    def set_andersen(self, kT, prob, seed):
+        """AndersenThermostat as the coupling of vv_run / langevin_run (coupling.jl:196-211); prob = dt / coupling_const, <= 0: off"""
+        self.s.andersen_kT = float(kT); self.s.andersen_prob = float(prob); self.s.andersen_seed = int(seed)
+
+    def langevin_run(self, n_steps, dt, kT, friction, key, ctr1, first_step=0, remove_cm_every=1, nthreads=1, pairwise=True, specific=False, general=False):
+        mask = (1 if pairwise else 0) | (2 if specific else 0) | (4 if general else 0)
+        self.L.orc_langevin_run(self.prec, C.byref(self.s), first_step, n_steps, float(dt), float(kT), float(friction), remove_cm_every,
+                                int(key), int(ctr1), nthreads, mask)
+
+    def random_velocities(self, kT, key, ctr1):
+        self.L.orc_redraw(self.prec, C.byref(self.s), 1, float(kT), 1.0, int(key), int(ctr1))
+
+    def andersen(self, kT, prob, key, ctr1):
+        self.L.orc_redraw(self.prec, C.byref(self.s), 0, float(kT), float(prob), int(key), int(ctr1))
+
+    def randn3(self, i, key, ctr1):
+        out = np.zeros(3)
+        self.L.orc_randn3(self.prec, int(i), self.n, int(key), int(ctr1), _ptr(out))
+        return out
+
     def force_scale(self, nl=None, rel_band=2e-6):
         """Σ_j‖f_ij‖ per atom and the summed force discontinuity of pairs within rel_band of a hard
         cutoff (fp64 system only) — the two terms of the fp32 tolerance used in the parity tests."""
@@ -265,3 +293,10 @@ def pair(inter, dr, qi=0.0, qj=0.0, si=0.0, sj=0.0, ei=0.0, ej=0.0, special=Fals
 
 def hardware_threads():
     return lib().orc_hardware_threads()
+
+
+def philox4x32_10(ctr4, key2):
+    """the raw generator (Random123 known-answer vectors pin it)"""
+    c = np.asarray(ctr4, np.uint32); k = np.asarray(key2, np.uint32); out = np.zeros(4, np.uint32)
+    lib().orc_philox4x32_10(_ptr(c), _ptr(k), _ptr(out))
+    return out

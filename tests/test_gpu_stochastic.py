@@ -1,0 +1,122 @@
+"""Langevin integrator, Andersen thermostat and random velocities on the MI355X (csrc/stochastic.hip) against the oracle's restatement
+(oracle/stochastic.h) with the same Philox keys and counters, plus the known-answer vectors of the generator on the device."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import systems as S
+from tests.test_oracle_stochastic import KB, PHILOX_KAT, ideal_gas
+
+pytestmark = pytest.mark.gpu
+
+
+def draws(seed, n):
+    """the uint64 words simulate(..., rng=seed) draws, in its order"""
+    rng = np.random.default_rng(seed)
+    return [int(rng.integers(0, 2 ** 64, dtype=np.uint64)) for _ in range(n)]
+
+
+@pytest.mark.parametrize("ctr,key,out", PHILOX_KAT)
+def test_device_philox_known_answers(pkg, ctr, key, out):
+    c = np.asarray(ctr, np.uint32); k = np.asarray(key, np.uint32); o = np.zeros(4, np.uint32)
+    rc = pkg.lib().mhip_philox4x32_10(c.ctypes.data_as(C.c_void_p), k.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.c_void_p))
+    assert rc == 0 and [int(x) for x in o] == out
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-13), (np.float32, 2e-6)])
+def test_random_velocities_and_andersen_match_the_oracle(pkg, dtype, tol):
+    """same counters → same normals (device log / sincos against libm: a few ulp), and EXACTLY the same atoms picked by the thermostat"""
+    n = 20000
+    mass = np.where(np.arange(n) % 3 == 0, 1.008, 15.999); mass[11] = 0.0
+    case = ideal_gas(n, dtype, mass=mass)
+    ctr1, key = draws(7, 2)
+    o = case.oracle(dtype); o.random_velocities(KB * 300.0, key=key, ctr1=ctr1)
+    s = case.system(pkg, dtype)
+    pkg.random_velocities(s, 300.0, rng=7)
+    scale = np.sqrt(KB * 300.0 / 1.008)
+    assert np.abs(s.velocities.astype(np.float64) - o.vel).max() < 6 * tol * scale
+    assert np.all(s.velocities[11] == 0)
+    v0 = s.velocities.copy()
+    sim = pkg.VelocityVerlet(dt=0.002)
+    assert pkg.apply_coupling(s, pkg.AndersenThermostat(250.0, 0.01), sim, rng=8) is False
+    ctr1, key = draws(8, 2)
+    v0_ref = o.vel.copy()
+    o.andersen(KB * 250.0, 0.2, key=key, ctr1=ctr1)
+    hit, hit_ref = np.any(s.velocities != v0, axis=1), np.any(o.vel != v0_ref, axis=1)
+    assert np.array_equal(hit, hit_ref) and 0.17 < hit.mean() < 0.23
+    assert np.abs(s.velocities.astype(np.float64) - o.vel).max() < 6 * tol * scale
+    assert np.array_equal(s.velocities[~hit], v0[~hit])
+
+
+def test_langevin_fp64_matches_oracle(pkg):
+    """simulate!(sys, ::Langevin, n) (simulators.jl:1099-1220) on the charged fluid with exceptions, CM removal every step: 30 steps
+    against the oracle with the same key / counter"""
+    case = S.charged_fluid(10, dict(kind="rf", rc=1.0), dtype=np.float64, with_exceptions=True, stable=True)
+    key, ctr1 = draws(21, 2)
+    o = case.oracle(np.float64)
+    o.langevin_run(30, 0.0005, KB * 300.0, 5.0, key=key, ctr1=ctr1, remove_cm_every=1, nthreads=4)
+    s = case.system(pkg, np.float64)
+    pkg.simulate(s, pkg.Langevin(dt=0.0005, temperature=300.0, friction=5.0), 30, rng=21)
+    assert np.abs(s.coords - o.coords).max() < 1e-9
+    assert np.abs(s.velocities - o.vel).max() < 1e-7
+    assert np.abs((s.velocities * case.mass[:, None]).sum(axis=0)).max() < 1e-9       # remove_CM_motion! after the last step
+
+
+def test_langevin_fp32_6mrr_pme_tracks_fp32_oracle(pkg):
+    """the complete 6mrr step (pair list + bonded + PME) under the Langevin integrator over 10 steps.  The fp32 noise is its own stream
+    (one Philox block per atom, single-precision Box-Muller), so the partner is the oracle's fp32 instance."""
+    from tests import golden6mrr as G
+    case = G.case("ewald", np.float32, bonded=True, pme=True)
+    key, ctr1 = draws(5, 2)
+    o = case.oracle(np.float32)
+    o.langevin_run(10, 0.0005, KB * 300.0, 1.0, key=key, ctr1=ctr1, remove_cm_every=1, nthreads=8, specific=True, general=True)
+    s = case.system(pkg, np.float32)
+    pkg.simulate(s, pkg.Langevin(dt=0.0005, temperature=300.0, friction=1.0), 10, rng=5)
+    d = s.coords.astype(np.float64) - o.coords
+    d -= np.round(d / case.box) * case.box
+    print("6mrr langevin fp32: max |dx|", np.abs(d).max(), "max |dv|", np.abs(s.velocities - o.vel).max())
+    assert np.abs(d).max() < 2e-5 and np.abs(s.velocities - o.vel).max() < 5e-3
+
+
+def test_langevin_is_reproducible_and_chunks_continue(pkg):
+    """counter-based noise: two runs with the same rng are bit-identical in fp64 coordinates up to summation order (none here: no
+    atomics on the pair path), and different seeds decorrelate"""
+    case = S.lj_fluid(10, dtype=np.float32)
+    sim = pkg.Langevin(dt=0.002, temperature=85.0, friction=2.0)
+    a = case.system(pkg, np.float32); pkg.simulate(a, sim, 25, rng=3)
+    b = case.system(pkg, np.float32); pkg.simulate(b, sim, 25, rng=3)
+    assert np.array_equal(a.coords, b.coords) and np.array_equal(a.velocities, b.velocities)
+    c = case.system(pkg, np.float32); pkg.simulate(c, sim, 25, rng=4)
+    assert np.abs(a.velocities - c.velocities).max() > 1e-3
+
+
+def test_langevin_thermalises_the_lj_fluid(pkg):
+    """test/simulation.jl: Langevin runs are judged by their temperature; 85 K argon driven to 140 K within ~10 relaxation times"""
+    case = S.lj_fluid(16, dtype=np.float32)
+    s = case.system(pkg, np.float32)
+    pkg.simulate(s, pkg.Langevin(dt=0.002, temperature=140.0, friction=5.0), 1000, rng=1)
+    ts = []
+    for k in range(10):
+        pkg.simulate(s, pkg.Langevin(dt=0.002, temperature=140.0, friction=5.0), 50, init_step=1000 + 50 * k, rng=100 + k)
+        ts.append(pkg.temperature(s))
+    assert abs(np.mean(ts) - 140.0) < 0.04 * 140.0
+    assert np.isfinite(s.coords).all()
+
+
+def test_velocity_verlet_with_andersen_coupling_matches_oracle(pkg):
+    """AndersenThermostat as the coupling of VelocityVerlet (simulators.jl:630): same atoms re-drawn at the same steps as the oracle"""
+    case = S.lj_fluid(8, dtype=np.float64)
+    (seed,) = draws(13, 1)
+    o = case.oracle(np.float64)
+    o.set_andersen(KB * 300.0, 0.002 / 0.05, seed=seed)
+    o.vv_run(20, 0.002, remove_cm_every=1)
+    s = case.system(pkg, np.float64)
+    pkg.simulate(s, pkg.VelocityVerlet(dt=0.002, coupling=pkg.AndersenThermostat(300.0, 0.05)), 20, rng=13)
+    assert np.abs(s.coords - o.coords).max() < 1e-9 and np.abs(s.velocities - o.vel).max() < 1e-8
+    plain = case.system(pkg, np.float64)
+    pkg.simulate(plain, pkg.VelocityVerlet(dt=0.002), 20)
+    assert np.abs(plain.velocities - s.velocities).max() > 0.05     # the thermostat really acted; and it is off again afterwards:
+    pkg.simulate(s, pkg.VelocityVerlet(dt=0.002), 1, init_step=20)
+    o.set_andersen(0, 0, 0); o.vv_run(1, 0.002, first_step=20, remove_cm_every=1)
+    assert np.abs(s.velocities - o.vel).max() < 1e-8
