@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--workload", default=os.environ.get("MOLLYHIP_BENCH_WORKLOAD", "lj1m"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--integrator", default="vv", choices=["vv", "langevin"], help="vv = the headline VelocityVerlet step; langevin = Langevin middle integrator (single GPU)")
     ap.add_argument("--profile-steps", type=int, default=200, help="steps of the separate hipEvent-timed pass")
     args = ap.parse_args()
 
@@ -117,15 +118,20 @@ def main():
         s = case.system(m, dtype)
         s.push_state(velocities=True)
         ctx = s.engine()
-        s._check(L.mhip_vv_run(ctx, 0, args.warmup, dt, 1))          # untimed warm-up (includes melting the lattice)
+        if args.integrator == "langevin":   # thermostatted at the LJ fluid's 85 K / the protein's 300 K, friction 1 / ps
+            kT = m.BOLTZMANN * (85.0 if args.workload.startswith("lj") else 300.0)
+            run = lambda first, n: s._check(L.mhip_langevin_run(ctx, first, n, dt, kT, 1.0, 1, 0x9E3779B97F4A7C15, first))
+        else:
+            run = lambda first, n: s._check(L.mhip_vv_run(ctx, first, n, dt, 1))
+        run(0, args.warmup)                                          # untimed warm-up (includes melting the lattice)
         s._check(L.mhip_synchronize(ctx))
         t0 = time.perf_counter()
-        s._check(L.mhip_vv_run(ctx, args.warmup, args.steps, dt, 1))  # timed: exactly K steps; returns after a stream sync
+        run(args.warmup, args.steps)                                 # timed: exactly K steps; returns after a stream sync
         s._check(L.mhip_synchronize(ctx))
         ms_per_step = (time.perf_counter() - t0) * 1e3 / args.steps
         # separate pass with hipEvent stage timers on the engine's stream (never mixed into the timed region)
         s._check(L.mhip_set_profiling(ctx, 1))
-        s._check(L.mhip_vv_run(ctx, args.warmup + args.steps, args.profile_steps, dt, 1))
+        run(args.warmup + args.steps, args.profile_steps)
         st = s.stats()
         s._check(L.mhip_set_profiling(ctx, 0))
         s._check(L.mhip_check_finite(ctx))
@@ -159,7 +165,7 @@ def main():
                                 "6mrr_pme": "6mrr (15954 atoms) Amber99SB-ILDN/TIP3P, LJ + Ewald direct space + PME reciprocal space (order 5, mesh 46x46x51, every step) + bonded + EwaldExclusion, Float32, dt 0.5 fs",
                                 "6mrr_direct": "6mrr (15954 atoms) Amber99SB-ILDN/TIP3P, LJ + Ewald direct space only (no reciprocal PME) + bonded + EwaldExclusion, Float32, dt 0.5 fs",
                                 "6mrr_rf64": "6mrr reaction-field Coulomb + LJ + bonded, Float64, dt 0.5 fs"}[args.workload],
-                   "name": args.workload, "n_atoms": n_atoms, "dt_fs": dt * 1e3, "rebuild_every": case.rebuild_every,
+                   "name": args.workload, "integrator": args.integrator, "n_atoms": n_atoms, "dt_fs": dt * 1e3, "rebuild_every": case.rebuild_every,
                    "parallelism": "single domain" if world == 1 else extra.get("parallelism"),
                    "block_atoms": st["block_atoms"], "j_split": st["j_split"], "pairs_half_list": st["n_pairs_full"] // 2},
         "roofline": roofline,

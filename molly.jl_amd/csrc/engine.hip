@@ -194,7 +194,7 @@ template <class T> class Engine final : public EngineBase {
         setup_inter(); setup_grid();
         for (int k = 0; k < 2; ++k) { pos[k].reserve(cap); vel[k].reserve(cap); frc[k].reserve(cap); lj[k].reserve(cap); orig[k].reserve(cap); }
         inv.reserve(cap); key_in.reserve(cap); key_out.reserve(cap); idx_in.reserve(cap); perm.reserve(cap);
-        flags.reserve(N_FLAGS); red_out.reserve(8); vcm.reserve(4); cm_step.reserve(4 * 1024);
+        flags.reserve(N_FLAGS); red_out.reserve(8); vcm.reserve(4); cm_step.reserve(2 * 4 * 1024);   // two halves: k_vv_mid reads one while it writes the other
         MHIP_HIP(hipHostMalloc((void**)&h_flags, N_FLAGS * sizeof(int32_t)));
         MHIP_HIP(hipHostMalloc((void**)&h_red, 8 * sizeof(double)));
         for (int k = 0; k < 2; ++k) { MHIP_HIP(hipMemsetAsync(pos[k].p, 0, cap * sizeof(T4), stream)); MHIP_HIP(hipMemsetAsync(vel[k].p, 0, cap * sizeof(T4), stream)); MHIP_HIP(hipMemsetAsync(frc[k].p, 0, cap * sizeof(T4), stream)); MHIP_HIP(hipMemsetAsync(lj[k].p, 0, cap * sizeof(T2), stream)); }
@@ -1102,16 +1102,44 @@ template <class T> class Engine final : public EngineBase {
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         if (first_step == 0 && remove_cm_every != 0) remove_cm();                 // simulators.jl:563
         vv_init(first_step);                                                      // :564-571
-        for (int64_t step = first_step + 1; step <= first_step + n_steps; ++step) {
-            vv_stage1(dt);                                                        // :594-609
+        // fused stepping: first kick + drift once, then ONE integrator launch between consecutive force passes (k_vv_mid), the
+        // plain second kick at the end.  A thermostat needs v_n between the kicks: the two-launch form then.
+        static const bool fuse_env = env_int("MOLLYHIP_VV_FUSE", 1) != 0;
+        const bool fused = fuse_env && !(andersen_prob > 0);
+        const bool pre = dual;                                                    // without the dual list: the reference's order
+        const int64_t last = first_step + n_steps;
+        int half = 0;
+        if (fused && n_steps > 0) vv_stage1(dt);
+        for (int64_t step = first_step + 1; step <= last; ++step) {
+            if (!fused) vv_stage1(dt);                                            // :594-609
             // find_neighbors at step % n_steps == 0 (:645, neighbors.jl:396) builds the list from the coordinates of THIS step; it is
             // scheduled before the force pass so that, with the dual pair list, that pass can prune the outer list on the way.
             // Forces are unaffected: the pass walks a superset of the old list and every interaction has a cutoff <= r_list.
-            const bool pre = dual;                                                // without the dual list: the reference's order
             if (pre && step % every == 0) refresh(step);
-            stage2_impl(step, dt, remove_cm_every != 0 && step % remove_cm_every == 0); // :612-628
-            apply_coupling(step);                                                 // :630
-            if (!pre && step % every == 0) refresh(step);
+            const bool cm = remove_cm_every != 0 && step % remove_cm_every == 0;
+            if (!fused) {
+                stage2_impl(step, dt, cm);                                        // :612-628
+                apply_coupling(step);                                             // :630
+                if (!pre && step % every == 0) refresh(step);
+                continue;
+            }
+            step_forces(step);
+            if (!pre && step % every == 0) { fold_side_forces(); refresh(step); }   // the sort permutes vel / frc with the atoms; Σ m v does not care
+            const int nb = std::min(cdiv(n_owned, 256), 1024);
+            const double* cm_in = cm_pending == 2 ? cm_src() : (const double*)nullptr;
+            double* cm_out = cm ? cm_step.p + (size_t)half * 4 * 1024 : (double*)nullptr;
+            prof.begin(2, stream);
+            auto go = [&](auto kern) {
+                hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, stream, n_owned, pos[cur].p, vel[cur].p, (const T4*)frc[cur].p, T(dt), T(dt) / T(2),
+                                   cm_in, n_cm_step, cm_out, (const T4*)pend_a, (const T4*)pend_b, G);
+            };
+            if (step == last) { if (cm) go(k_vv_mid<T, true, true>); else go(k_vv_mid<T, false, true>); }
+            else { if (cm) go(k_vv_mid<T, true, false>); else go(k_vv_mid<T, false, false>); }
+            prof.end(2, stream);
+            pend_a = pend_b = nullptr;
+            cm_pending = 0; cm_ext = nullptr;
+            if (cm) { cm_pending = 2; cm_ext = cm_out; n_cm_step = nb; half ^= 1; }
+            if (step != last) frc_valid = false;                                  // frc[cur] belongs to the coordinates before the drift
         }
         flush_cm();
         MHIP_HIP(hipGetLastError());
@@ -1162,18 +1190,20 @@ template <class T> class Engine final : public EngineBase {
         StochP<T> P = stoch_params(kT, key, ctr1_0);
         P.dt = T(dt); P.dt_half = T(dt) / T(2); P.vel_scale = T(vs); P.noise_kt = std::sqrt(1.0 - vs * vs) * std::sqrt(kT);
         const int nb = std::min(cdiv(n_owned, 256), 1024);
+        int half = 0;
         for (int64_t step = first_step + 1; step <= first_step + n_steps; ++step) {
             step_forces(step);                                                    // :1173
             fold_side_forces();
             const bool cm = remove_cm_every != 0 && step % remove_cm_every == 0;
             P.ctr1 = ctr1_0 + (uint64_t)(step - first_step - 1);
             prof.begin(2, stream);
+            double* cm_out = cm ? cm_step.p + (size_t)half * 4 * 1024 : (double*)nullptr;   // the other half may still be read by this launch
             launch_langevin<T>(stream, nb, n_owned, pos[cur].p, vel[cur].p, (const T4*)frc[cur].p, orig[cur].p, P,
                                cm_pending == 1 ? (const T*)vcm.p : (const T*)nullptr, cm_pending == 2 ? cm_src() : (const double*)nullptr, n_cm_step,
-                               cm ? cm_step.p : (double*)nullptr, G);
+                               cm_out, G);
             prof.end(2, stream);
             cm_pending = 0; cm_ext = nullptr; frc_valid = false;
-            if (cm) { cm_pending = 2; n_cm_step = nb; }                           // :1204-1206, subtracted by the next consumer
+            if (cm) { cm_pending = 2; cm_ext = cm_out; n_cm_step = nb; half ^= 1; }   // :1204-1206, subtracted by the next consumer
             apply_coupling(step);                                                 // :1208
             if (step % every == 0) refresh(step);                                 // :1211 — the next force pass prunes the fresh outer list
         }

@@ -1101,6 +1101,59 @@ __global__ void k_vv2(int64_t n, typename Vec<T>::T4* vel, typename Vec<T>::T4* 
     }
 }
 
+// Second kick of step n and first kick + drift of step n+1 in ONE pass over the atoms (vv_run, single domain): halves the integrator's
+// launches and its HBM traffic (48 B read + 32 B written per fp32 atom instead of 80 + 48).  remove_CM_motion! sits between the two
+// kicks and needs Σ m v of ALL atoms, so it is applied one kernel late: this launch accumulates the partials of Σ m v_n (before the
+// removal), carries on with the unshifted velocity, and the NEXT launch subtracts v_cm from the velocity it finds and v_cm·dt from
+// the position that was drifted with it.  The forces in between saw every atom translated by the same v_cm·dt (≈ 1e-11 nm): they are
+// translation invariant.  LAST: stop after the second kick (the run's final step), leaving v_n and x_n for the caller.
+template <class T, bool CM, bool LAST>
+__global__ void k_vv_mid(int64_t n, typename Vec<T>::T4* pos, typename Vec<T>::T4* vel, const typename Vec<T>::T4* __restrict__ frc, T dt, T dt2,
+                         const double* __restrict__ cm_in, int n_cm_in, double* cm_out,
+                         const typename Vec<T>::T4* __restrict__ fa, const typename Vec<T>::T4* __restrict__ fb, GridP<T> G) {
+    T vc[3] = {T(0), T(0), T(0)};
+    const bool sub = cm_in != nullptr;
+    if (sub) block_vcm<T>(cm_in, n_cm_in, vc);
+    const T sh[3] = {M<T>::mul(vc[0], dt), M<T>::mul(vc[1], dt), M<T>::mul(vc[2], dt)};
+    double px = 0, py = 0, pz = 0, m = 0;
+    for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
+        auto v = vel[s]; auto f = frc[s];
+        typename Vec<T>::T4 p;
+        if (!LAST || sub) p = pos[s];
+        if (fa) { const auto g = fa[s]; f.x += g.x; f.y += g.y; f.z += g.z; }
+        if (fb) { const auto g = fb[s]; f.x += g.x; f.y += g.y; f.z += g.z; }
+        if (sub) {                                                             // remove_CM_motion! of the previous step, one launch late
+            v.x -= vc[0]; v.y -= vc[1]; v.z -= vc[2];
+            p.x = M<T>::sub(p.x, sh[0]); p.y = M<T>::sub(p.y, sh[1]); p.z = M<T>::sub(p.z, sh[2]);
+        }
+        const T im = (v.w == T(0)) ? T(0) : T(1) / v.w;
+        const T kx = (f.x * im) * dt2, ky = (f.y * im) * dt2, kz = (f.z * im) * dt2;
+        v.x += kx; v.y += ky; v.z += kz;                                       // :616, v_n before this step's CM removal
+        if constexpr (CM) { px += (double)v.x * v.w; py += (double)v.y * v.w; pz += (double)v.z * v.w; m += v.w; }
+        if constexpr (!LAST) {
+            v.x += kx; v.y += ky; v.z += kz;                                   // :594 of the next step
+            p.x += v.x * dt; p.y += v.y * dt; p.z += v.z * dt;                 // :602
+        }
+        if (!LAST || sub) {
+            if (G.periodic[0]) p.x = wrap_1d(p.x, G.L[0]);                     // :609
+            if (G.periodic[1]) p.y = wrap_1d(p.y, G.L[1]);
+            if (G.periodic[2]) p.z = wrap_1d(p.z, G.L[2]);
+            pos[s] = p;
+        }
+        if (LAST && (fa || fb)) const_cast<typename Vec<T>::T4*>(frc)[s] = f;  // the total force of the last step stays readable
+        vel[s] = v;
+    }
+    if constexpr (CM) {
+        __shared__ double shm[4][4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { px += __shfl_xor(px, o, 64); py += __shfl_xor(py, o, 64); pz += __shfl_xor(pz, o, 64); m += __shfl_xor(m, o, 64); }
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { shm[w][0] = px; shm[w][1] = py; shm[w][2] = pz; shm[w][3] = m; }
+        __syncthreads();
+        if (threadIdx.x < 4) { double a = 0; for (int q = 0; q < (int)(blockDim.x >> 6); ++q) a += shm[q][threadIdx.x]; cm_out[4 * (int64_t)blockIdx.x + threadIdx.x] = a; }
+    }
+}
+
 // frc += fa (+ fb): the same fold outside the integrator
 template <class T>
 __global__ void k_add_forces(int64_t n, typename Vec<T>::T4* frc, const typename Vec<T>::T4* __restrict__ fa, const typename Vec<T>::T4* __restrict__ fb) {

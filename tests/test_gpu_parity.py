@@ -376,3 +376,21 @@ def test_pairwise_virial_vs_oracle(pkg, kind, dtype):
     assert pkg.scalar_virial(s) == pytest.approx(np.trace(w), rel=1e-12)
     f = pkg.forces(s)                                   # the virial call left the engine's forces untouched
     assert np.isfinite(f).all()
+
+
+@pytest.mark.parametrize("n_steps,cm_every,first", [(1, 1, 5), (2, 1, 5), (7, 3, 4), (12, 1, 0), (6, 0, 2)])
+def test_fused_velocity_verlet_with_net_momentum_matches_oracle(pkg, n_steps, cm_every, first):
+    """vv_run's one-launch-per-step form (k_vv_mid) applies remove_CM_motion! one launch late, to the velocity AND to the position that
+    was drifted with it.  A system with a large net momentum entered at init_step > 0 (no up-front removal, simulators.jl:563) makes
+    that shift visible: v_cm·dt ≈ 1e-3 nm.  Also the run lengths around the first / last step special cases and a 3-step CM cadence."""
+    case = S.lj_fluid(8, dtype=np.float64)
+    case.velocities = case.velocities + np.array([0.6, -0.4, 0.25])
+    o = case.oracle(np.float64)
+    o.vv_run(n_steps, 0.002, first_step=first, remove_cm_every=cm_every)
+    s = case.system(pkg, np.float64)
+    pkg.simulate(s, pkg.VelocityVerlet(dt=0.002, remove_CM_motion=cm_every), n_steps, init_step=first)
+    d = s.coords - o.coords
+    d -= np.round(d / case.box) * case.box
+    assert np.abs(d).max() < 1e-10 and np.abs(s.velocities - o.vel).max() < 1e-9
+    f_ref = o.forces(o.neighbors("cell"))
+    assert np.abs(pkg.forces(s) - f_ref).max() < 1e-7 * np.abs(f_ref).max()
