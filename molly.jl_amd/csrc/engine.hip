@@ -528,6 +528,12 @@ template <class T> class Engine final : public EngineBase {
             const double d = std::sqrt((double)d2), checks = std::max<int64_t>(1, (step_n - last_prune_step) / every);
             reprune = 2.0 * d * (checks + 1.0) / checks > skin * 0.98;
         }
+        if (reprune && n_ghost == 0 && !stale) {
+            // a prune is only as good as the outer list behind it (nobody moved more than half the margin since the outer search):
+            // if that is already used up, search again now instead of running a prune pass that would have to be thrown away
+            const double d_outer = std::sqrt((double)max_disp2_since(pos_snap));
+            if (2.0 * d_outer > outer_margin * 0.98) { rebuild(step_n); return; }
+        }
         if (reprune) inner_valid = false;         // the next force pass re-prunes the outer list at the then-current coordinates
         last_build_step = step_n; ++n_rebuilds;
     }
