@@ -200,6 +200,13 @@ int32_t mhip_specific_potential_energy(mhip_ctx* ctx, double* pe_out);
 int32_t mhip_set_pme(mhip_ctx* ctx, int32_t order, const int32_t* mesh3, double alpha, double eps_r);
 /* reciprocal-space forces, added to (accumulate != 0) or written into f_xyz   (ewald_pe_forces!, ewald.jl:873-916) */
 int32_t mhip_general_forces(mhip_ctx* ctx, int32_t accumulate, void* f_xyz, int32_t mem_kind);
+/* TriclinicBoundary(v1, v2, v3; approx_images) (spatial.jl:131-220; minimum image :528-551, wrap_coords :588-602): basis9 = the three
+ * basis vectors row by row; v1 along x, v2 in the xy plane, v3.z > 0 (MHIP_ERR_INVALID otherwise, as the constructor's
+ * ArgumentError).  The context must have been created with box = (v1.x, v2.y, v3.z), all axes periodic.  Call before mhip_set_state.
+ * Restricted to what the reference's own GPU test covers and a little more (test/gpu_consistency.jl:287-337): single domain, no PME,
+ * systems of at most 32 759 atoms — the whole system is one cell and every distance takes the exact in-loop minimum image.
+ * approx_images != 0: the three-floor formula; 0: the search over the 27 neighbouring images. */
+int32_t mhip_set_triclinic(mhip_ctx* ctx, const double* basis9, int32_t approx_images);
 /* E_recip + E_self + E_net-charge                                           (ewald.jl:898-928) */
 int32_t mhip_general_potential_energy(mhip_ctx* ctx, double* pe_out);
 /* reciprocal-space virial (recip_conv_inner!, ewald.jl:701-723, 747-750) + the net-charge term (:925-927), ADDED to 9 host doubles */

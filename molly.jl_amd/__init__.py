@@ -8,7 +8,7 @@ from .api import (  # noqa: F401
     AndersenThermostat, Atom, BOLTZMANN, COULOMB_CONST, CellListMapNeighborFinder, Coulomb, CoulombEwald, CoulombReactionField,
     CubicBoundary, CubicSplineCutoff, DistanceCutoff, DistanceNeighborFinder, EwaldExclusions, GPUNeighborFinder,
     HarmonicAngles, HarmonicBonds, Langevin, LennardJones, NeighborList, NoCutoff, NoNeighborFinder, PeriodicTorsions,
-    PME, PolynomialCutoff, ShiftedForceCutoff, ShiftedPotentialCutoff, System, VelocityVerlet, find_neighbors, forces,
+    PME, PolynomialCutoff, ShiftedForceCutoff, ShiftedPotentialCutoff, System, TriclinicBoundary, VelocityVerlet, find_neighbors, forces,
     kinetic_energy, potential_energy, pressure, scalar_pressure, random_velocities, apply_coupling, remove_CM_motion, scalar_virial, simulate, temperature, total_energy, use_neighbors, virial,
     wrap_coords,
 )

@@ -101,6 +101,7 @@ SIGNATURES = {
     "mhip_specific_virial": (_I32, [_P, _P]),
     "mhip_general_virial": (_I32, [_P, _P]),
     "mhip_set_pme": (_I32, [_P, _I32, _P, _D, _D]),
+    "mhip_set_triclinic": (_I32, [_P, _P, _I32]),
     "mhip_general_forces": (_I32, [_P, _I32, _P, _I32]),
     "mhip_general_potential_energy": (_I32, [_P, C.POINTER(_D)]),
     "mhip_set_ghost_margin": (_I32, [_P, _D]),

@@ -167,6 +167,24 @@ class CubicBoundary:
         self.side_lengths = sl
 
 
+class TriclinicBoundary:
+    """TriclinicBoundary(v1, v2, v3; approx_images=true) (spatial.jl:131-220): v1 along x, v2 in the xy plane, v3.z > 0.  The engine
+    supports it for single-GPU systems of up to 32 759 atoms without PME (include/mollyhip.h, mhip_set_triclinic)."""
+
+    def __init__(self, v1, v2, v3, approx_images=True):
+        bv = np.array([v1, v2, v3], dtype=np.float64).reshape(3, 3)
+        if not (bv[0, 0] > 0) or bv[0, 1] != 0 or bv[0, 2] != 0:   # spatial.jl:173-177
+            raise ValueError(f"first basis vector must be along the x-axis (no y or z component) and have a positive x component, got {bv[0]}")
+        if not (bv[1, 1] > 0) or bv[1, 2] != 0:                     # :178-182
+            raise ValueError(f"second basis vector must be in the xy plane (no z component) and have a positive y component, got {bv[1]}")
+        if not (bv[2, 2] > 0):                                      # :183-186
+            raise ValueError(f"third basis vector must have a positive z component, got {bv[2]}")
+        self.basis_vectors = bv
+        self.approx_images = bool(approx_images)
+        self.side_lengths = np.array([bv[0, 0], bv[1, 1], bv[2, 2]])     # box_volume = v1.x · v2.y · v3.z; the engine's config box
+        self.reciprocal_size = 1.0 / self.side_lengths
+
+
 @dataclass
 class Atom:
     index: int = 0
@@ -294,7 +312,7 @@ class System:
         if velocities is not None and len(velocities) != n:
             raise ValueError(f"there are {n} coordinates but {len(velocities)} velocities")
         self.velocities = np.zeros((n, 3), T) if velocities is None else np.ascontiguousarray(velocities, dtype=T).reshape(n, 3).copy()
-        self.boundary = boundary if isinstance(boundary, CubicBoundary) else CubicBoundary(boundary)
+        self.boundary = boundary if isinstance(boundary, (CubicBoundary, TriclinicBoundary)) else CubicBoundary(boundary)
         self.pairwise_inters = tuple(pairwise_inters)
         self.specific_inter_lists = tuple(specific_inter_lists)
         self.general_inters = tuple(general_inters)
@@ -371,6 +389,9 @@ class System:
         if rc != 0:
             raise MollyHipError(rc, L.mhip_last_error(None).decode())
         self._ctx = ctx
+        if isinstance(self.boundary, TriclinicBoundary):
+            bv = np.ascontiguousarray(self.boundary.basis_vectors, dtype=np.float64)
+            self._check(L.mhip_set_triclinic(ctx, self._ptr(bv), 1 if self.boundary.approx_images else 0))
         self._push_atoms()
         return ctx
 
@@ -604,6 +625,19 @@ def apply_coupling(sys, thermostat, sim, rng=None):
 
 
 def wrap_coords(coords, boundary):
+    """wrap_coords(v, boundary) (spatial.jl:573-602)"""
     c = np.asarray(coords)
+    if isinstance(boundary, TriclinicBoundary):
+        T = c.dtype.type
+        bv = boundary.basis_vectors.astype(c.dtype); rs = (T(1) / np.array([bv[0, 0], bv[1, 1], bv[2, 2]], dtype=c.dtype)).astype(c.dtype)
+        a, b, cc = boundary.basis_vectors
+        cot_bc = T(abs((b[1] * cc[1] + b[2] * cc[2]) / (b[1] * cc[2] - b[2] * cc[1])))
+        cxz, cyz, cot_ab = T(cc[0] / abs(cc[2])), T(cc[1] / abs(cc[2])), T(b[0] / b[1])
+        v = c.reshape(-1, 3).copy()
+        v -= bv[2] * np.floor(v[:, 2] * rs[2])[:, None]
+        v -= bv[1] * np.floor((v[:, 1] - v[:, 2] * cot_bc) * rs[1])[:, None]
+        dx, dy = v[:, 2] * cxz, v[:, 2] * cyz
+        v -= bv[0] * np.floor((v[:, 0] - dx - (v[:, 1] - dy) * cot_ab) * rs[0])[:, None]
+        return v.reshape(c.shape)
     L = boundary.side_lengths.astype(c.dtype)
     return c - np.floor(c / L) * L

@@ -15,9 +15,7 @@
 namespace mhip {
 
 template <class T> __device__ inline void min_image(const typename Vec<T>::T4& a, const typename Vec<T>::T4& b, const GridP<T>& G, T* d) {
-    d[0] = G.periodic[0] ? vector_1d_exact(a.x, b.x, G.L[0]) : b.x - a.x;
-    d[1] = G.periodic[1] ? vector_1d_exact(a.y, b.y, G.L[1]) : b.y - a.y;
-    d[2] = G.periodic[2] ? vector_1d_exact(a.z, b.z, G.L[2]) : b.z - a.z;
+    min_image_exact<T>(a.x, a.y, a.z, b.x, b.y, b.z, G, d[0], d[1], d[2]);
 }
 template <class T> __device__ inline void cross3(const T* a, const T* b, T* c) {
     c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];

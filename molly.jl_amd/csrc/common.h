@@ -37,6 +37,13 @@ template <class T> struct GridP {
     int ncell;
     T r_list, r_list2;         // +inf when every pair interacts
     int no_list;
+    // TriclinicBoundary (spatial.jl:131-220): 0 = cubic; 1 = approx_images (three floor steps, :528-534); 2 = the exact search over
+    // the 27 neighbouring images (:536-551).  The whole system is then ONE cell: every block's tile holds every atom and all
+    // distances take the exact in-loop minimum image (small systems only, as in test/gpu_consistency.jl:287-337).
+    int triclinic;
+    T bv[3][3];                // basis vectors (rows): a ∥ x, b in the xy plane
+    T rs[3];                   // reciprocal_size = 1/a_x, 1/b_y, 1/c_z
+    T cot_bc, cxz, cyz, cot_ab;   // wrap_coords constants (:192-210, 588-602)
 };
 
 // pairwise_inters in device-friendly form (constants rounded to T on the host exactly as the

@@ -70,6 +70,7 @@ struct EngineBase {
     virtual void specific_virial(double*) = 0;
     virtual void general_virial(double*) = 0;
     virtual void set_pme(int32_t, const int32_t*, double, double) = 0;
+    virtual void set_triclinic(const double*, int32_t) = 0;
     virtual void general_forces(int, void*, int) = 0;
     virtual double general_potential_energy() = 0;
     virtual void set_ghost_margin(double) = 0;
@@ -148,6 +149,7 @@ template <class T> class Engine final : public EngineBase {
     // ghosted sub-domain whose ghost shell reaches r_list + ghost_margin: the ghost PLAN then lives as long as an outer list
     // (until some atom moved ghost_margin/2), so the dual list works here too and the host re-plans only when mhip_plan_disp2_dev says so
     double ghost_margin = 0; const double* cm_ext = nullptr;
+    int tri_mode = 0; double tri_bv[9] = {};   // TriclinicBoundary: 0 off, 1 approx_images, 2 exact images; basis vectors row-major
     long long grid_key = -1;
     bool host_prune = false;     // ghost plans: the HOST decides, collectively over the ranks, when the inner list is re-pruned (mhip_request_prune)
     // single list, same idea: a rebuild step whose displacement check shows the list still covers every cutoff sphere is skipped
@@ -271,8 +273,9 @@ template <class T> class Engine final : public EngineBase {
             if (ip.coul_kind != MHIP_COUL_NONE) rc_max = std::max(rc_max, ip.coul_rc);
             skin = G.no_list ? 0.0 : cfg.r_list - rc_max;
         }
+        if (tri_mode) outer_margin = 0;   // one cell, exact images everywhere: plain fixed-cadence lists
         dual = outer_margin > 0 && outer_every > 1 && lj_cut_ok && coul_cut_ok && skin > 0;   // ghosted: only with a ghost margin (else re-planned every rebuild)
-        lazy_single = !dual && !G.no_list && lj_cut_ok && coul_cut_ok && skin > 0 && n_ghost == 0 && !strict_cadence;
+        lazy_single = !dual && !G.no_list && lj_cut_ok && coul_cut_ok && skin > 0 && n_ghost == 0 && !strict_cadence && !tri_mode;
         if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] grid: dual %d margin %.3f skin %.3f lj_ok %d coul_ok %d ghosts %lld\n", (int)dual, outer_margin, skin, (int)lj_cut_ok, (int)coul_cut_ok, (long long)n_ghost);
         const double r_search = G.no_list ? 0.0 : cfg.r_list + (dual ? outer_margin : 0.0);
         G.r_list = G.no_list ? std::numeric_limits<T>::infinity() : T(r_search);
@@ -282,13 +285,21 @@ template <class T> class Engine final : public EngineBase {
             if (!(cfg.box[d] > 0) || std::isinf(cfg.box[d]) || std::isnan(cfg.box[d])) throw ApiError{MHIP_ERR_INVALID, "box side lengths must be positive and finite"};
             G.L[d] = T(cfg.box[d]); G.invL[d] = T(1) / G.L[d]; G.origin[d] = cfg.periodic[d] ? T(0) : T(cfg.origin[d]); G.periodic[d] = cfg.periodic[d] ? 1 : 0;
             int nc = 1;
-            if (!G.no_list) { nc = (int)std::floor(cfg.box[d] / (r_search / S)); nc = std::max(1, std::min(nc, 1024)); }
+            if (!G.no_list && !tri_mode) { nc = (int)std::floor(cfg.box[d] / (r_search / S)); nc = std::max(1, std::min(nc, 1024)); }
             G.nc[d] = nc; G.cs[d] = T(cfg.box[d] / nc); G.inv_cs[d] = T(nc / cfg.box[d]);
             G.stencil[d] = S; G.all_cells[d] = (G.no_list || 2 * S + 1 >= nc) ? 1 : 0;
         }
         // keep the cell table small: coarsen until ncell <= 2^22
         while ((int64_t)G.nc[0] * G.nc[1] * G.nc[2] > (1 << 22)) for (int d = 0; d < 3; ++d) { G.nc[d] = std::max(1, G.nc[d] / 2); G.cs[d] = T(cfg.box[d] / G.nc[d]); G.inv_cs[d] = T(G.nc[d] / cfg.box[d]); }
         G.ncell = G.nc[0] * G.nc[1] * G.nc[2];
+        G.triclinic = tri_mode;
+        if (tri_mode) {   // constants of TriclinicBoundary's constructor (spatial.jl:187-210), rounded to T as the struct stores them
+            const double* a = tri_bv; const double* b = tri_bv + 3; const double* c = tri_bv + 6;
+            for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) G.bv[r][k] = T(tri_bv[3 * r + k]);
+            G.rs[0] = T(1) / T(a[0]); G.rs[1] = T(1) / T(b[1]); G.rs[2] = T(1) / T(c[2]);
+            G.cot_bc = T(std::fabs((b[1] * c[1] + b[2] * c[2]) / (b[1] * c[2] - b[2] * c[1])));
+            G.cxz = T(c[0] / std::fabs(c[2])); G.cyz = T(c[1] / std::fabs(c[2])); G.cot_ab = T(b[0] / b[1]);
+        }
         std::vector<uint32_t> rank;
         hilbert_ok = hilbert_cell_ranks(G.nc[0], G.nc[1], G.nc[2], rank);
         cell_rank.reserve(G.ncell);
@@ -328,6 +339,7 @@ template <class T> class Engine final : public EngineBase {
         double vol = 1; for (int d = 0; d < 3; ++d) vol *= cfg.box[d];
         double rho = (double)n_tot / vol;
         if (G.no_list) { T_cap = (int)n_tot + 8; R_cap = cdiv(n_tot, 4) + 2; C_cap = 8; }
+        else if (tri_mode) { T_cap = (int)n_tot + 8; R_cap = (int)std::min<double>(1.5 * rho * 4.0 / 3.0 * M_PI * std::pow(cfg.r_list, 3) / 4 / JS + 8, n_tot / 4.0 + 2); C_cap = 8; }
         else {
             double r = (cfg.r_list + (dual ? outer_margin : 0.0)) * 1.001, a = std::cbrt(BI / rho);
             double v_tile = a * a * a + 6 * a * a * r + 3 * M_PI * a * r * r + 4.0 / 3.0 * M_PI * r * r * r;
@@ -724,6 +736,7 @@ template <class T> class Engine final : public EngineBase {
 
     void set_atom_counts(int64_t no, int64_t ng) override {
         if (no <= 0 || ng < 0 || no + ng > cap) throw ApiError{MHIP_ERR_INVALID, "atom counts exceed the context capacity"};
+        if (ng > 0 && tri_mode) throw ApiError{MHIP_ERR_UNSUPPORTED, "TriclinicBoundary is single-domain"};
         n_owned = no; n_ghost = ng; n_tot = no + ng;
         // new local atom set: restart from the identity order
         hipLaunchKernelGGL(k_iota2, dim3(std::min(cdiv(n_tot, 256), 1024)), dim3(256), 0, stream, n_tot, orig[cur].p, inv.p);
@@ -916,7 +929,25 @@ template <class T> class Engine final : public EngineBase {
         return read_sum(n_part);
     }
 
+    // TriclinicBoundary(v1, v2, v3; approx_images) (spatial.jl:131-220).  cfg.box must hold (v1.x, v2.y, v3.z).  Single domain, no PME,
+    // systems that fit one tile (every block sees every atom; all distances by the exact in-loop minimum image).
+    void set_triclinic(const double* bv9, int32_t approx_images) override {
+        if (!(bv9[0] > 0) || bv9[1] != 0 || bv9[2] != 0) throw ApiError{MHIP_ERR_INVALID, "first basis vector must be along the x-axis (no y or z component) and have a positive x component"};
+        if (!(bv9[4] > 0) || bv9[5] != 0) throw ApiError{MHIP_ERR_INVALID, "second basis vector must be in the xy plane (no z component) and have a positive y component"};
+        if (!(bv9[8] > 0)) throw ApiError{MHIP_ERR_INVALID, "third basis vector must have a positive z component"};
+        for (int d = 0; d < 3; ++d) if (!cfg.periodic[d]) throw ApiError{MHIP_ERR_UNSUPPORTED, "TriclinicBoundary is periodic on all three axes"};
+        if (n_ghost > 0 || pme.on()) throw ApiError{MHIP_ERR_UNSUPPORTED, "TriclinicBoundary: single domain, no PME"};
+        if (cfg.n_atoms + 8 > TILE_SLOT_MAX) throw ApiError{MHIP_ERR_UNSUPPORTED, "TriclinicBoundary is limited to systems that fit one tile (32 759 atoms)"};
+        if (std::fabs(bv9[0] - cfg.box[0]) > 1e-12 * bv9[0] || std::fabs(bv9[4] - cfg.box[1]) > 1e-12 * bv9[4] || std::fabs(bv9[8] - cfg.box[2]) > 1e-12 * bv9[8])
+            throw ApiError{MHIP_ERR_INVALID, "the context's box must be (v1.x, v2.y, v3.z) of the triclinic basis"};
+        MHIP_HIP(hipStreamSynchronize(stream));
+        std::memcpy(tri_bv, bv9, sizeof(tri_bv));
+        tri_mode = approx_images ? 1 : 2;
+        setup_grid(); choose_blocking();
+        stale = true; frc_valid = false; state_set = false;
+    }
     void set_pme(int32_t order, const int32_t* mesh, double alpha, double eps_r) override {
+        if (order && tri_mode) throw ApiError{MHIP_ERR_UNSUPPORTED, "PME on a TriclinicBoundary is outside the scope"};
         MHIP_HIP(hipStreamSynchronize(stream));
         int32_t none[3] = {0, 0, 0};
         pme.setup(order, order ? mesh : none, alpha, cfg.inter.coul_ke, eps_r, cfg.box, cfg.periodic);
@@ -1421,6 +1452,9 @@ int32_t mhip_philox4x32_10(const uint32_t* ctr4, const uint32_t* key2, uint32_t*
 }
 int32_t mhip_specific_virial(mhip_ctx* ctx, double* out9) { NEED_CTX(); return guard(ctx, [&] { if (!out9) throw mhip::ApiError{MHIP_ERR_INVALID, "null output"}; ctx->e->specific_virial(out9); }); }
 int32_t mhip_general_virial(mhip_ctx* ctx, double* out9) { NEED_CTX(); return guard(ctx, [&] { if (!out9) throw mhip::ApiError{MHIP_ERR_INVALID, "null output"}; ctx->e->general_virial(out9); }); }
+int32_t mhip_set_triclinic(mhip_ctx* ctx, const double* basis9, int32_t approx_images) {
+    NEED_CTX(); return guard(ctx, [&] { if (!basis9) throw mhip::ApiError{MHIP_ERR_INVALID, "null basis"}; ctx->e->set_triclinic(basis9, approx_images); });
+}
 int32_t mhip_set_pme(mhip_ctx* ctx, int32_t order, const int32_t* mesh, double alpha, double eps_r) {
     NEED_CTX(); return guard(ctx, [&] { if (order != 0 && !mesh) throw mhip::ApiError{MHIP_ERR_INVALID, "null mesh"}; ctx->e->set_pme(order, mesh, alpha, eps_r); });
 }

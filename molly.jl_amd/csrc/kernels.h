@@ -64,8 +64,7 @@ __global__ void k_scatter_state(int64_t n_tot, int64_t n_owned, const int32_t* _
     int s = inv[o];
     if (xyz) {
         T c[3] = {xyz[3 * o], xyz[3 * o + 1], xyz[3 * o + 2]};
-#pragma unroll
-        for (int d = 0; d < 3; ++d) if (G.periodic[d]) c[d] = wrap_1d(c[d], G.L[d]);   // wrap_coords, simulators.jl:561
+        wrap_point(c[0], c[1], c[2], G);   // wrap_coords, simulators.jl:561
         pos[s].x = c[0]; pos[s].y = c[1]; pos[s].z = c[2];
     }
     if (vxyz && o < n_owned) { vel[s].x = vxyz[3 * o]; vel[s].y = vxyz[3 * o + 1]; vel[s].z = vxyz[3 * o + 2]; }
@@ -448,9 +447,8 @@ __global__ void k_build(BuildArgs<T> A) {
                             bool ok = false;
                             if ((maybe >> lane) & 1ull) {
                                 T4 pj = A.pos[A.tile_idx[(int64_t)b * A.T_cap + jl]];
-                                T ex = G.periodic[0] ? vector_1d_exact(ox, pj.x, G.L[0]) : M<T>::sub(pj.x, ox);
-                                T ey = G.periodic[1] ? vector_1d_exact(oy, pj.y, G.L[1]) : M<T>::sub(pj.y, oy);
-                                T ez = G.periodic[2] ? vector_1d_exact(oz, pj.z, G.L[2]) : M<T>::sub(pj.z, oz);
+                                T ex, ey, ez;
+                                min_image_exact<T>(ox, oy, oz, pj.x, pj.y, pj.z, G, ex, ey, ez);
                                 ok = norm2_exact(ex, ey, ez) <= G.r_list2;
                             }
                             in |= __ballot(ok);
@@ -461,9 +459,8 @@ __global__ void k_build(BuildArgs<T> A) {
             } else {
                 for (int i = 0; i < WAVE; ++i) {
                     const T ox = lane_bcast(my[0], i), oy = lane_bcast(my[1], i), oz = lane_bcast(my[2], i);
-                    T ex = G.periodic[0] ? vector_1d_exact(ox, px.x, G.L[0]) : M<T>::sub(px.x, ox);
-                    T ey = G.periodic[1] ? vector_1d_exact(oy, px.y, G.L[1]) : M<T>::sub(px.y, oy);
-                    T ez = G.periodic[2] ? vector_1d_exact(oz, px.z, G.L[2]) : M<T>::sub(px.z, oz);
+                    T ex, ey, ez;
+                    min_image_exact<T>(ox, oy, oz, px.x, px.y, px.z, G, ex, ey, ez);
                     const unsigned long long in = __ballot(near && norm2_exact(ex, ey, ez) <= G.r_list2);
                     if (lane == i) { mine_lo = (int)(uint32_t)in; mine_hi = (int)(uint32_t)(in >> 32); }   // v_cndmask ×2
                 }
@@ -662,9 +659,8 @@ __global__ void k_filter(FilterArgs<T> A) {
             }
             if (maybe) {
                 T4 pj = A.pos[tix[slot]];
-                T ex = G.periodic[0] ? vector_1d_exact(pi.x, pj.x, G.L[0]) : M<T>::sub(pj.x, pi.x);
-                T ey = G.periodic[1] ? vector_1d_exact(pi.y, pj.y, G.L[1]) : M<T>::sub(pj.y, pi.y);
-                T ez = G.periodic[2] ? vector_1d_exact(pi.z, pj.z, G.L[2]) : M<T>::sub(pj.z, pi.z);
+                T ex, ey, ez;
+                min_image_exact<T>(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z, G, ex, ey, ez);
                 in = norm2_exact(ex, ey, ez) <= A.r_in2;
             }
             if (in) { emit(e); l_used[slot] = 1; }   // benign race: every writer stores the same byte
@@ -882,11 +878,11 @@ __global__ void k_forces(ForceArgs<T> A) {
                     if constexpr (PER_ATOM_LJ) ljj = l_lj[slot];
                     T dx, dy, dz;
                     if constexpr (MINIMG) {
-                        dx = G.periodic[0] ? vector_1d_exact(pi.x, pj.x, G.L[0]) : pj.x - pi.x;
-                        dy = G.periodic[1] ? vector_1d_exact(pi.y, pj.y, G.L[1]) : pj.y - pi.y;
-                        dz = G.periodic[2] ? vector_1d_exact(pi.z, pj.z, G.L[2]) : pj.z - pi.z;
+                        min_image_exact<T>(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z, G, dx, dy, dz);
                     } else { dx = pj.x - pi.x; dy = pj.y - pi.y; dz = pj.z - pi.z; }
                     T r2 = dx * dx + dy * dy + dz * dz;
+                    // the triclinic minimum image folds ANY separation back into the cell, the far-away sentinel atom included
+                    if constexpr (MINIMG) { if (G.triclinic && !real) r2 = T(1.0e30); }
                     if constexpr (PRUNE) { if (real && valid && r2 <= A.r_prune2) { emit(e); l_mark[e & 0x7fffu] = 1; } }   // benign race: same byte value
                     T fr = pair_eval<T, LJM, COULM, ENERGY>(A.I, r2, pi.w, pj.w, lji.x, ljj.x, lji.y, ljj.y, special, pe);
                     fx -= fr * dx; fy -= fr * dy; fz -= fr * dz;   // force on i is −f (force.jl:873)
@@ -1067,9 +1063,7 @@ __global__ void k_vv1(int64_t n, typename Vec<T>::T4* pos, typename Vec<T>::T4* 
         T im = (v.w == T(0)) ? T(0) : T(1) / v.w;                              // calc_accels, force.jl:17
         v.x += (f.x * im) * dt2; v.y += (f.y * im) * dt2; v.z += (f.z * im) * dt2;   // :594
         p.x += v.x * dt; p.y += v.y * dt; p.z += v.z * dt;                     // :602
-        if (G.periodic[0]) p.x = wrap_1d(p.x, G.L[0]);                         // :609
-        if (G.periodic[1]) p.y = wrap_1d(p.y, G.L[1]);
-        if (G.periodic[2]) p.z = wrap_1d(p.z, G.L[2]);
+        wrap_point(p.x, p.y, p.z, G);                                          // :609
         vel[s] = v; pos[s] = p;
     }
 }
@@ -1135,9 +1129,7 @@ __global__ void k_vv_mid(int64_t n, typename Vec<T>::T4* pos, typename Vec<T>::T
             p.x += v.x * dt; p.y += v.y * dt; p.z += v.z * dt;                 // :602
         }
         if (!LAST || sub) {
-            if (G.periodic[0]) p.x = wrap_1d(p.x, G.L[0]);                     // :609
-            if (G.periodic[1]) p.y = wrap_1d(p.y, G.L[1]);
-            if (G.periodic[2]) p.z = wrap_1d(p.z, G.L[2]);
+            wrap_point(p.x, p.y, p.z, G);                                      // :609
             pos[s] = p;
         }
         if (LAST && (fa || fb)) const_cast<typename Vec<T>::T4*>(frc)[s] = f;  // the total force of the last step stays readable

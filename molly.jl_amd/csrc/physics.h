@@ -75,6 +75,58 @@ template <class T> __device__ inline T wrap_1d(T c, T L) {
     return M<T>::sub(c, M<T>::mul(M<T>::floor(c / L), L));
 }
 
+// ---- TriclinicBoundary ------------------------------------------------------------------------------
+// vector(c1, c2, ::TriclinicBoundary) spatial.jl:528-551, every operation rounded on its own as Julia does
+template <class T> __device__ inline void tri_min_image(T ax, T ay, T az, T bx, T by, T bz, const GridP<T>& G, T& dx, T& dy, T& dz) {
+    using Mt = M<T>;
+    if (G.triclinic == 1) {   // approx_images = true
+        dx = Mt::sub(bx, ax); dy = Mt::sub(by, ay); dz = Mt::sub(bz, az);
+        T k = Mt::floor(Mt::add(Mt::mul(dz, G.rs[2]), T(0.5)));
+        dx = Mt::sub(dx, Mt::mul(G.bv[2][0], k)); dy = Mt::sub(dy, Mt::mul(G.bv[2][1], k)); dz = Mt::sub(dz, Mt::mul(G.bv[2][2], k));
+        k = Mt::floor(Mt::add(Mt::mul(dy, G.rs[1]), T(0.5)));
+        dx = Mt::sub(dx, Mt::mul(G.bv[1][0], k)); dy = Mt::sub(dy, Mt::mul(G.bv[1][1], k)); dz = Mt::sub(dz, Mt::mul(G.bv[1][2], k));
+        k = Mt::floor(Mt::add(Mt::mul(dx, G.rs[0]), T(0.5)));
+        dx = Mt::sub(dx, Mt::mul(G.bv[0][0], k)); dy = Mt::sub(dy, Mt::mul(G.bv[0][1], k)); dz = Mt::sub(dz, Mt::mul(G.bv[0][2], k));
+        return;
+    }
+    T best = T(3.0e38) * T(3.0e38);   // typemax: +inf
+    dx = T(0); dy = T(0); dz = T(0);
+    for (int ox = -1; ox <= 1; ++ox) for (int oy = -1; oy <= 1; ++oy) for (int oz = -1; oz <= 1; ++oz) {
+        T c[3] = {bx, by, bz}, e[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {   // ((c2 + ox·bv1) + oy·bv2) + oz·bv3, then − c1
+            c[d] = Mt::add(Mt::add(Mt::add(c[d], Mt::mul(T(ox), G.bv[0][d])), Mt::mul(T(oy), G.bv[1][d])), Mt::mul(T(oz), G.bv[2][d]));
+        }
+        e[0] = Mt::sub(c[0], ax); e[1] = Mt::sub(c[1], ay); e[2] = Mt::sub(c[2], az);
+        const T sq = Mt::add(Mt::add(Mt::mul(e[0], e[0]), Mt::mul(e[1], e[1])), Mt::mul(e[2], e[2]));
+        if (sq < best) { best = sq; dx = e[0]; dy = e[1]; dz = e[2]; }
+    }
+}
+// wrap_coords(v, ::TriclinicBoundary) spatial.jl:588-602
+template <class T> __device__ inline void tri_wrap(T& x, T& y, T& z, const GridP<T>& G) {
+    using Mt = M<T>;
+    T k = Mt::floor(Mt::mul(z, G.rs[2]));
+    x = Mt::sub(x, Mt::mul(G.bv[2][0], k)); y = Mt::sub(y, Mt::mul(G.bv[2][1], k)); z = Mt::sub(z, Mt::mul(G.bv[2][2], k));
+    k = Mt::floor(Mt::mul(Mt::sub(y, Mt::mul(z, G.cot_bc)), G.rs[1]));
+    x = Mt::sub(x, Mt::mul(G.bv[1][0], k)); y = Mt::sub(y, Mt::mul(G.bv[1][1], k)); z = Mt::sub(z, Mt::mul(G.bv[1][2], k));
+    const T ddx = Mt::mul(z, G.cxz), ddy = Mt::mul(z, G.cyz);
+    k = Mt::floor(Mt::mul(Mt::sub(Mt::sub(x, ddx), Mt::mul(Mt::sub(y, ddy), G.cot_ab)), G.rs[0]));
+    x = Mt::sub(x, Mt::mul(G.bv[0][0], k)); y = Mt::sub(y, Mt::mul(G.bv[0][1], k)); z = Mt::sub(z, Mt::mul(G.bv[0][2], k));
+}
+// the boundary's vector(c1, c2) with the reference's arithmetic, and its wrap_coords — cubic or triclinic
+template <class T> __device__ inline void min_image_exact(T ax, T ay, T az, T bx, T by, T bz, const GridP<T>& G, T& dx, T& dy, T& dz) {
+    if (G.triclinic) { tri_min_image(ax, ay, az, bx, by, bz, G, dx, dy, dz); return; }
+    dx = G.periodic[0] ? vector_1d_exact(ax, bx, G.L[0]) : M<T>::sub(bx, ax);
+    dy = G.periodic[1] ? vector_1d_exact(ay, by, G.L[1]) : M<T>::sub(by, ay);
+    dz = G.periodic[2] ? vector_1d_exact(az, bz, G.L[2]) : M<T>::sub(bz, az);
+}
+template <class T> __device__ inline void wrap_point(T& x, T& y, T& z, const GridP<T>& G) {
+    if (G.triclinic) { tri_wrap(x, y, z, G); return; }
+    if (G.periodic[0]) x = wrap_1d(x, G.L[0]);
+    if (G.periodic[1]) y = wrap_1d(y, G.L[1]);
+    if (G.periodic[2]) z = wrap_1d(z, G.L[2]);
+}
+
 // ---- cutoff strategies on a bare pair potential, cutoffs.jl ----------------------------------------
 template <class T> struct LJBare {   // lennard_jones.jl:106-109, 137-140; params (σ², ϵ)
     T s2, e;

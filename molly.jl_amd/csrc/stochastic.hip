@@ -88,9 +88,7 @@ __global__ void __launch_bounds__(256) k_langevin(int64_t n, typename Vec<T>::T4
         const T ns = thermal_scale<T>(P.noise_kt, v.w);
         v.x = fma_t(P.vel_scale, v.x, z[0] * ns); v.y = fma_t(P.vel_scale, v.y, z[1] * ns); v.z = fma_t(P.vel_scale, v.z, z[2] * ns);   // kernels.jl:739
         p.x = fma_t(P.dt_half, v.x, p.x); p.y = fma_t(P.dt_half, v.y, p.y); p.z = fma_t(P.dt_half, v.z, p.z);   // :1192
-        if (G.periodic[0]) p.x = wrap_1d(p.x, G.L[0]);                         // :1201
-        if (G.periodic[1]) p.y = wrap_1d(p.y, G.L[1]);
-        if (G.periodic[2]) p.z = wrap_1d(p.z, G.L[2]);
+        wrap_point(p.x, p.y, p.z, G);                                          // :1201
         vel[s] = v; pos[s] = p;
         if constexpr (CM) { px += (double)v.x * v.w; py += (double)v.y * v.w; pz += (double)v.z * v.w; m += v.w; }
     }

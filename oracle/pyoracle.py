@@ -53,7 +53,8 @@ class OrcSystem(C.Structure):
                 ("t_per", C.c_void_p), ("t_phase", C.c_void_p), ("t_k0", C.c_void_p),
                 ("n_ewx", C.c_int64), ("x_i", C.c_void_p), ("x_j", C.c_void_p),
                 ("pme_order", C.c_int32), ("pme_mesh", C.c_int32 * 3), ("pme_eps_r", C.c_double),
-                ("andersen_kT", C.c_double), ("andersen_prob", C.c_double), ("andersen_seed", C.c_uint64)]
+                ("andersen_kT", C.c_double), ("andersen_prob", C.c_double), ("andersen_seed", C.c_uint64),
+                ("triclinic", C.c_int32), ("pad1", C.c_int32), ("tri_bv", C.c_double * 9)]
 
 
 def build(native=False, quiet=True):
@@ -118,7 +119,7 @@ class OracleSystem:
 
     def __init__(self, coords, box, inter, dtype=np.float64, velocities=None, charge=None, sigma=None, eps=None,
                  mass=None, r_list=float("inf"), rebuild_every=10, excluded=None, special=None, bonds=None,
-                 angles=None, torsions=None, ewald_excl=None, native=False, pme=None):
+                 angles=None, torsions=None, ewald_excl=None, native=False, pme=None, triclinic=None):
         self.dtype = np.dtype(dtype)
         self.prec = 32 if self.dtype == np.float32 else 64
         T = self.dtype
@@ -171,6 +172,12 @@ class OracleSystem:
                  np.ascontiguousarray(torsions["phase"], dtype=T), np.ascontiguousarray(torsions["k0"], dtype=T)]
             self._keep += t
             s.n_tors = len(t[0]); s.t_i, s.t_j, s.t_k, s.t_l, s.t_per, s.t_phase, s.t_k0 = map(_ptr, t)
+        if triclinic is not None:   # dict(basis=3x3 rows v1 v2 v3, approx_images=True); `box` must be (v1.x, v2.y, v3.z)
+            bv = np.asarray(triclinic["basis"], dtype=np.float64).reshape(3, 3)
+            assert np.allclose(self.box, np.diag(bv)), "box must hold the diagonal of the triclinic basis"
+            s.triclinic = 1 if triclinic.get("approx_images", True) else 2
+            for k in range(9):
+                s.tri_bv[k] = float(bv.reshape(-1)[k])
         if pme is not None:   # general interaction PME: dict(order=5, mesh=(nx, ny, nz), eps_r=1.0); α and ke come from `inter`
             s.pme_order = int(pme.get("order", 5)); s.pme_eps_r = float(pme.get("eps_r", 1.0))
             for d in range(3):

@@ -1,0 +1,107 @@
+"""TriclinicBoundary on the MI355X (mhip_set_triclinic): the reference's own GPU test (test/gpu_consistency.jl:287-337) and its
+free-flight test (test/basic.jl:233-260) through the C ABI, neighbour lists, dynamics and the bonded terms against the oracle."""
+import numpy as np
+import pytest
+
+from tests import systems as S
+from tests.test_oracle_triclinic import BASIS, tri_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("approx", [True, False])
+@pytest.mark.parametrize("dtype,rtol,atol", [(np.float64, 1e-8, 1e-10), (np.float32, 2e-4, 1e-3)])
+def test_triclinic_forces_energy_and_list_match_oracle(pkg, dtype, rtol, atol, approx):
+    """test/gpu_consistency.jl:287-337: 50 LJ atoms (σ 0.3, ϵ 1) in the cell (2,0,0), (0.1,2,0), (0.2,0.3,2), cutoff 0.8; GPU forces and
+    energy against the CPU path at rtol 1e-8 / atol 1e-10 (fp64)"""
+    case = tri_case(50, dtype, approx)
+    o = case.oracle(np.float64)
+    nl = o.neighbors("brute")
+    f_ref, e_ref = o.forces(nl), o.potential_energy(nl)
+    s = case.system(pkg, dtype)
+    f = pkg.forces(s).astype(np.float64)
+    assert np.all(np.abs(f - f_ref) <= rtol * np.abs(f_ref) + atol * max(1.0, np.abs(f_ref).max() if dtype == np.float32 else 1.0))
+    assert pkg.potential_energy(s) == pytest.approx(e_ref, rel=rtol, abs=atol)
+    got = pkg.find_neighbors(s)
+    ref = case.oracle(dtype).neighbors("brute")
+    assert all(np.array_equal(u, v) for u, v in zip(S.sorted_pairs(got.i, got.j, got.special), S.sorted_pairs(*ref)))   # bit-exact pair set
+
+
+def dense_case(seed=11):
+    """343 atoms on a jittered lattice in fractional coordinates of a strongly sheared cell: crosses every face, no overlaps"""
+    rng = np.random.default_rng(seed)
+    n_side = 7
+    g = np.stack(np.meshgrid(*[np.arange(n_side)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float64)
+    basis = np.array([[2.4, 0.0, 0.0], [0.5, 2.3, 0.0], [-0.4, 0.6, 2.2]])
+    x = ((g + 0.5) / n_side + rng.uniform(-0.02, 0.02, g.shape)) @ basis
+    n = len(x)
+    v = rng.normal(size=(n, 3)) * 0.3
+    return basis, S.Case(x, np.diag(basis), lj=dict(cutoff=("shifted_force", 0.9)), r_list=1.0, rebuild_every=5, velocities=v, sigma=np.full(n, 0.3),
+                         eps=np.full(n, 0.8), mass=np.full(n, 12.0), triclinic=dict(basis=basis), name="tri_dense")
+
+
+def test_triclinic_dense_fluid_trajectory_matches_oracle(pkg):
+    """a denser system that crosses every face of the cell: 40 velocity-Verlet steps with CM removal, then 20 Langevin steps, fp64
+    against the oracle; coordinates stay wrapped into the cell"""
+    basis, case = dense_case()
+    o = case.oracle(np.float64)
+    o.vv_run(40, 0.002, remove_cm_every=1)
+    s = case.system(pkg, np.float64)
+    pkg.simulate(s, pkg.VelocityVerlet(dt=0.002), 40)
+    d = np.linalg.solve(basis.T, (s.coords - o.coords).T).T
+    d -= np.round(d)
+    assert np.abs(d @ basis).max() < 1e-9 and np.abs(s.velocities - o.vel).max() < 1e-8
+    frac = np.linalg.solve(basis.T, s.coords.T).T
+    assert frac.min() > -1e-12 and frac.max() < 1 + 1e-12                   # wrapped into the cell
+    rng = np.random.default_rng(4)
+    key, ctr1 = (int(rng.integers(0, 2 ** 64, dtype=np.uint64)) for _ in range(2))
+    o.langevin_run(20, 0.002, 8.314462618e-3 * 200.0, 2.0, key=key, ctr1=ctr1, first_step=40, remove_cm_every=1)
+    pkg.simulate(s, pkg.Langevin(dt=0.002, temperature=200.0, friction=2.0), 20, init_step=40, rng=4)
+    d = np.linalg.solve(basis.T, (s.coords - o.coords).T).T
+    d -= np.round(d)
+    assert np.abs(d @ basis).max() < 1e-9
+
+
+def test_triclinic_free_flight(pkg):
+    """test/basic.jl:233-260 on the device: no forces, 1000 steps — velocities unchanged, coordinates wrapped, displacements = v·t"""
+    basis = np.array([[2.2, 0.0, 0.0], [1.0, 1.7320508075688772, 0.0], [1.3788800, 0.5399122, 1.0233204]])
+    rng = np.random.default_rng(5)
+    n = 1000
+    x = rng.uniform(0, 1, (n, 3)) @ basis
+    v = rng.normal(size=(n, 3)) * np.sqrt(8.314462618e-3 * 100.0)
+    case = S.Case(x, np.diag(basis), lj=dict(cutoff=("distance", 0.4)), r_list=0.45, velocities=v, sigma=np.full(n, 0.3), eps=np.zeros(n), mass=np.ones(n),
+                  triclinic=dict(basis=basis))
+    s = case.system(pkg, np.float64)
+    s.push_state(); s.pull_state()
+    prev = s.coords.copy()
+    for k in range(10):
+        pkg.simulate(s, pkg.VelocityVerlet(dt=0.002, remove_CM_motion=0), 100, init_step=100 * k)
+        assert np.array_equal(pkg.wrap_coords(s.coords, s.boundary), s.coords)
+        d = np.linalg.solve(basis.T, (s.coords - prev - 0.2 * v).T).T
+        assert np.abs(d - np.round(d)).max() < 1e-9
+        prev = s.coords.copy()
+    assert np.allclose(s.velocities, v, rtol=1e-12, atol=0)
+
+
+def test_triclinic_bonded_terms(pkg):
+    """bonds and angles across the faces of the cell take the same minimum image (force.jl:991-1060 with vector(…, boundary))"""
+    case = tri_case(48, np.float64, True, seed=8, spread=1.9)
+    i = np.arange(0, 48, 3)
+    case.bonds = dict(i=i, j=i + 1, k=np.full(len(i), 2000.0), r0=np.full(len(i), 0.35))
+    case.angles = dict(i=i, j=i + 1, k=i + 2, kth=np.full(len(i), 300.0), th0=np.full(len(i), 1.9))
+    o = case.oracle(np.float64)
+    f_ref = o.forces(None, pairwise=False, specific=True)
+    s = case.system(pkg, np.float64)
+    f = pkg.forces(s, pairwise=False)
+    assert np.abs(f - f_ref).max() < 1e-9 * np.abs(f_ref).max()
+    assert pkg.potential_energy(s, pairwise=False) == pytest.approx(o.potential_energy(None, pairwise=False, specific=True), rel=1e-11)
+
+
+def test_triclinic_is_refused_where_it_is_not_supported(pkg):
+    with pytest.raises(ValueError):
+        pkg.TriclinicBoundary((2.0, 1.0, 0.0), (1.0, 2.0, 0.0), (1.0, 1.0, 2.0))       # test/basic.jl:202-206
+    case = S.charged_fluid(6, dict(kind="ewald", rc=0.9), dtype=np.float64, with_exceptions=False, pme=dict(order=5))
+    case.triclinic = dict(basis=np.diag(case.box) + np.array([[0, 0, 0], [0.1, 0, 0], [0, 0, 0]]))
+    s = case.system(pkg, np.float64)
+    with pytest.raises(pkg.MollyHipError):
+        pkg.forces(s)
