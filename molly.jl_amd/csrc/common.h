@@ -12,7 +12,9 @@
 namespace mhip {
 
 constexpr int WAVE = 64;
-constexpr int MAX_LDS_BYTES = 160 * 1024;   // LDS per CU on gfx950 (MI355X_MICROARCH.md)
+// dynamic LDS a kernel may ask for: the 160 KiB of a gfx950 CU (MI355X_MICROARCH.md) minus room for the kernels' static __shared__
+// arrays (k_build: ≈ 1.6 KB) — the sum is what hipFuncSetAttribute / the launch are checked against
+constexpr int MAX_LDS_BYTES = 160 * 1024 - 2048;
 constexpr int TILE_SLOT_MAX = 32767;        // 15-bit tile slot + 1-bit special flag per list entry
 
 template <class T> struct Vec;

@@ -120,3 +120,35 @@ def test_velocity_verlet_with_andersen_coupling_matches_oracle(pkg):
     pkg.simulate(s, pkg.VelocityVerlet(dt=0.002), 1, init_step=20)
     o.set_andersen(0, 0, 0); o.vv_run(1, 0.002, first_step=20, remove_cm_every=1)
     assert np.abs(s.velocities - o.vel).max() < 1e-8
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_reference_bars_for_device_noise(pkg, dtype):
+    """test/gpu_consistency.jl:587-679 at its own sizes and bars: 50 000 atoms of mass 10 at 298 K, three massless (virtual-site) atoms whose
+    velocities must be actively zeroed — device against host within 16 eps(FT)·sqrt(kT/m); and one O-step with vel_scale 0.8,
+    noise_scale 0.3, key 0x1234567890abcdef, ctr1 0xfedcba0987654321 on N(0,1) velocities within 16 eps(FT)"""
+    n = 50000
+    eps = np.finfo(dtype).eps
+    mass = np.full(n, 10.0); mass[[1, 3, 6]] = 0.0
+    case = ideal_gas(n, dtype, mass=mass)
+    case.velocities = np.ones((n, 3))                           # the buffers start non-zero (:624-627)
+    ctr1, key = draws(10, 2)
+    o = case.oracle(dtype); o.random_velocities(KB * 298.0, key=key, ctr1=ctr1)
+    s = case.system(pkg, dtype)
+    pkg.random_velocities(s, 298.0, rng=10)
+    vel_scale = np.sqrt(KB * 298.0 / 10.0)
+    assert np.linalg.norm(s.velocities.astype(np.float64) - o.vel, axis=1).max() < 16 * eps * vel_scale
+    assert np.all(s.velocities[[1, 3, 6]] == 0) and np.all(o.vel[[1, 3, 6]] == 0)
+
+    gas = ideal_gas(n, dtype, mass=np.ones(n))
+    gas.velocities = np.random.default_rng(15).normal(size=(n, 3)).astype(dtype).astype(np.float64)
+    dt = 0.001
+    friction, kT = -np.log(0.8) / dt, 0.25                      # exp(−γ dt) = 0.8 ; sqrt(1 − 0.8²)·sqrt(kT/m) = 0.3
+    o = gas.oracle(dtype)
+    o.langevin_run(1, dt, kT, friction, key=0x1234567890abcdef, ctr1=0xfedcba0987654321, remove_cm_every=0)
+    s = gas.system(pkg, dtype)
+    s.push_state(velocities=True)
+    s._check(pkg.lib().mhip_langevin_run(s._ctx, 0, 1, dt, kT, friction, 0, 0x1234567890abcdef, 0xfedcba0987654321))
+    s.pull_state()
+    assert not np.array_equal(s.velocities, gas.velocities.astype(dtype))
+    assert np.linalg.norm(s.velocities.astype(np.float64) - o.vel, axis=1).max() < 16 * eps
