@@ -77,3 +77,37 @@ def test_host_mirror_validation(pkg):
     assert (it.coul_kind, it.coul_rc, it.rf_dielectric) == (2, 1.0, 78.3)
     with pytest.raises(pkg.MollyHipError):
         pkg.System(coords=np.zeros((4, 3)), boundary=pkg.CubicBoundary(2.0), pairwise_inters=(object(),)).interactions()
+
+
+def test_host_mirror_of_the_widened_rows(pkg):
+    """TriclinicBoundary's constructor checks (test/basic.jl:202-212 → ArgumentError), the host wrap_coords against the oracle's, the
+    Langevin constants (simulators.jl:1091-1093) and the simulators / couplings simulate() accepts"""
+    from tests import systems as S
+    with pytest.raises(ValueError):
+        pkg.TriclinicBoundary((2.0, 1.0, 0.0), (1.0, 2.0, 0.0), (1.0, 1.0, 2.0))
+    with pytest.raises(ValueError):
+        pkg.TriclinicBoundary((2.0, 0.0, 0.0), (1.0, 2.0, 0.5), (1.0, 1.0, 2.0))
+    with pytest.raises(ValueError):
+        pkg.TriclinicBoundary((2.0, 0.0, 0.0), (1.0, 2.0, 0.0), (1.0, 1.0, -2.0))
+    basis = np.array([[2.2, 0.0, 0.0], [1.0, 1.7320508075688772, 0.0], [1.37888, 0.5399122, 1.0233204]])
+    b = pkg.TriclinicBoundary(*basis)
+    assert b.side_lengths.tolist() == [2.2, 1.7320508075688772, 1.0233204] and b.approx_images
+    assert np.prod(b.side_lengths) == pytest.approx(3.89937463181886, rel=1e-6)          # volume(b), test/basic.jl:193
+    pts = np.random.default_rng(2).uniform(-9, 9, (400, 3))
+    case = S.Case(pts, np.diag(basis), lj=dict(cutoff=("distance", 0.4)), r_list=0.45, sigma=np.full(400, 0.3), eps=np.zeros(400), mass=np.ones(400),
+                  triclinic=dict(basis=basis))
+    o = case.oracle(np.float64); o.wrap()
+    assert np.array_equal(pkg.wrap_coords(pts, b), o.coords)                              # same operations in the same order
+    assert np.array_equal(pkg.wrap_coords(pts, pkg.CubicBoundary(2.0)), pts - np.floor(pts / 2.0) * 2.0)
+
+    sim = pkg.Langevin(dt=0.002, temperature=300.0, friction=1.5)
+    assert sim.vel_scale == np.exp(-0.002 * 1.5) and sim.noise_scale == np.sqrt(1 - sim.vel_scale ** 2) and sim.remove_CM_motion == 1
+    s = pkg.System(coords=np.zeros((4, 3)), boundary=pkg.CubicBoundary(2.0), pairwise_inters=(pkg.LennardJones(),))
+    with pytest.raises(pkg.MollyHipError):
+        pkg.simulate(s, object(), 1)                                                      # unknown simulator
+    with pytest.raises(pkg.MollyHipError):
+        pkg.simulate(s, pkg.VelocityVerlet(dt=0.001, coupling=object()), 1)               # only AndersenThermostat couples
+    with pytest.raises(ValueError):
+        pkg.simulate(s, pkg.VelocityVerlet(dt=0.001), 1, init_step=-1)
+    with pytest.raises(pkg.MollyHipError):
+        pkg.apply_coupling(s, object(), sim)
