@@ -4,9 +4,13 @@ import math
 
 import numpy as np
 
-from oracle import pyoracle as orc
 
 CUT = {"none": 0, "distance": 1, "shifted_potential": 2, "shifted_force": 3, "cubic_spline": 4, "polynomial": 5}
+
+
+def pme_mesh(box, alpha, error_tol=0.0005):
+    """pme_params (ewald.jl:479-482): mesh points per axis, max(ceil(2 α L / (3 tol^0.2)), 6)"""
+    return tuple(max(int(np.ceil(2.0 * alpha * float(L) / (3.0 * error_tol ** 0.2))), 6) for L in box)
 
 
 class Case:
@@ -34,7 +38,7 @@ class Case:
         if self.pme is None:
             return None
         alpha = self.inter_dict(dtype)["ewald_alpha"]
-        mesh = self.pme.get("mesh") or orc.pme_mesh(self.box, alpha, self.pme.get("error_tol", self.coul.get("tol", 5e-4)))
+        mesh = self.pme.get("mesh") or pme_mesh(self.box, alpha, self.pme.get("error_tol", self.coul.get("tol", 5e-4)))
         return dict(order=self.pme.get("order", 5), mesh=tuple(int(v) for v in mesh), eps_r=self.pme.get("eps_r", 1.0))
 
     # -- interaction dict for the oracle (field names of mhip_interactions) ---------------------------------
@@ -66,6 +70,7 @@ class Case:
         return t
 
     def oracle(self, dtype=np.float64, coords=None, velocities=None):
+        from oracle import pyoracle as orc   # only where a checker is asked for: bench.py builds its systems from this module too
         return orc.OracleSystem(self.coords if coords is None else coords, self.box, self.inter_dict(dtype), dtype=dtype,
                                 velocities=self.velocities if velocities is None else velocities,
                                 charge=self.charge, sigma=self.sigma, eps=self.eps, mass=self.mass, r_list=self.r_list,
