@@ -111,3 +111,23 @@ def test_host_mirror_of_the_widened_rows(pkg):
         pkg.simulate(s, pkg.VelocityVerlet(dt=0.001), 1, init_step=-1)
     with pytest.raises(pkg.MollyHipError):
         pkg.apply_coupling(s, object(), sim)
+
+
+def test_header_is_plain_c_and_a_c_client_links(tmp_path):
+    """the drop-in boundary is a C ABI: include/mollyhip.h must compile as C99 (no C++ in the signatures), and a plain C client that
+    takes the address of every entry point links against libmollyhip.so"""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "include", "mollyhip.h")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr], check=True)
+    names = sorted(set(re.findall(r"\b(mhip_[a-z0-9_]+)\s*\(", open(hdr).read())))
+    assert len(names) >= 55
+    src = tmp_path / "client.c"
+    src.write_text('#include "mollyhip.h"\n#include <stdio.h>\nint main(void) {\n  const void* p[] = {' + ", ".join(f"(const void*)&{n}" for n in names) +
+                   '};\n  unsigned i, n = 0; for (i = 0; i < sizeof p / sizeof p[0]; ++i) n += p[i] != 0;\n  printf("%u\\n", n); return 0; }\n')
+    exe = tmp_path / "client"
+    lib_dir = os.path.join(root, "molly.jl_amd")
+    subprocess.run(["gcc", "-std=c99", "-Wno-pedantic", "-I", os.path.join(root, "include"), str(src), "-o", str(exe), "-L", lib_dir, "-l:libmollyhip.so",
+                    f"-Wl,-rpath,{lib_dir}", "-Wl,--allow-shlib-undefined"], check=True)
