@@ -83,6 +83,23 @@ def test_triclinic_free_flight(pkg):
     assert np.allclose(s.velocities, v, rtol=1e-12, atol=0)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_triclinic_neighbour_list_of_1000_atoms_is_the_brute_force_set(pkg, dtype):
+    """test/basic.jl:544-577: 1000 atoms placed in the cell (2,0,0), (0.7,1.8,0), (0.5,0.3,1.6), cutoff 0.6 nm — the list equals the pairs
+    with norm(vector(ci, cj, boundary)) <= cutoff, here as an exact set comparison in the same precision"""
+    basis = np.array([[2.0, 0.0, 0.0], [0.7, 1.8, 0.0], [0.5, 0.3, 1.6]])
+    rng = np.random.default_rng(21)
+    n = 1000
+    x = (rng.uniform(0, 1, (n, 3)) @ basis).astype(dtype).astype(np.float64)
+    case = S.Case(x, np.diag(basis), lj=dict(cutoff=("distance", 0.6)), r_list=0.6, velocities=np.zeros((n, 3)), sigma=np.full(n, 0.05), eps=np.full(n, 0.1),
+                  mass=np.ones(n), triclinic=dict(basis=basis), name="tri1000")
+    ref = case.oracle(dtype).neighbors("brute")
+    s = case.system(pkg, dtype)
+    got = pkg.find_neighbors(s)
+    assert got.n == len(ref[0]) and got.n > 20000
+    assert all(np.array_equal(u, v) for u, v in zip(S.sorted_pairs(got.i, got.j, got.special), S.sorted_pairs(*ref)))
+
+
 def test_triclinic_bonded_terms(pkg):
     """bonds and angles across the faces of the cell take the same minimum image (force.jl:991-1060 with vector(…, boundary))"""
     case = tri_case(48, np.float64, True, seed=8, spread=1.9)
