@@ -60,3 +60,43 @@ def test_different_implementations_agree(pkg, triclinic):
         d = (d - np.round(d)) @ basis
         assert np.abs(d).sum() / (3 * case.n) < 1e-4, (use_list, r_list, dtype)
         assert abs(e0 - e_ref) < 5e-4, (use_list, r_list, dtype)
+
+
+def place_atoms(n, box, min_dist, rng):
+    pts = np.empty((0, 3))
+    while len(pts) < n:
+        c = rng.uniform(0, box, 3)
+        d = pts - c
+        d -= np.round(d / box) * box
+        if len(pts) == 0 or (d ** 2).sum(axis=1).min() > min_dist ** 2:
+            pts = np.vstack([pts, c])
+    return pts
+
+
+LJ_VARIANTS = [(("none",), True), (("none",), False), (("distance", 1.0), True), (("shifted_potential", 1.0), True), (("shifted_force", 1.0), True),
+               (("cubic_spline", 1.0, 0.6), True)]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("cutoff,use_list", LJ_VARIANTS)
+def test_lj_on_cpu_and_gpu(pkg, cutoff, use_list, dtype):
+    """test/simulation.jl:559-629: 100 atoms (σ 0.2, ϵ 0.2, mass 10) in a 2 nm box, six LennardJones variants — NoCutoff over a 1.2 nm
+    neighbour list (the result then depends on list membership and on the 10-step cadence), NoCutoff without a list, and the four cutoff
+    strategies — 100 VelocityVerlet steps of 2 fs.  Bars of the reference: |ΔE| at the start < 5e-4, mean |Δx| < 5e-4 nm, final |ΔE| < 5e-3 kJ/mol"""
+    rng = np.random.default_rng(12)
+    n, box = 100, 2.0
+    x = place_atoms(n, box, 0.2, rng).astype(np.float32).astype(np.float64)
+    v = (rng.normal(size=(n, 3)) * np.sqrt(8.314462618e-3 * 298.0 / 10.0) * 0.01).astype(np.float32).astype(np.float64)
+    case = S.Case(x, box, lj=dict(cutoff=cutoff), r_list=1.2 if use_list else np.inf, rebuild_every=10, velocities=v, sigma=np.full(n, 0.2), eps=np.full(n, 0.2),
+                  mass=np.full(n, 10.0), name="lj100")
+    o = case.oracle(np.float64)
+    e0_ref = o.potential_energy(o.neighbors("brute") if use_list else None)
+    o.vv_run(100, 0.002, remove_cm_every=1)
+    e1_ref = o.potential_energy(o.neighbors("brute") if use_list else None)
+    s = case.system(pkg, dtype)
+    assert abs(pkg.potential_energy(s) - e0_ref) < 5e-4
+    pkg.simulate(s, pkg.VelocityVerlet(dt=0.002), 100)
+    d = s.coords.astype(np.float64) - o.coords
+    d -= np.round(d / box) * box
+    assert np.abs(d).sum() / (3 * n) < 5e-4
+    assert abs(pkg.potential_energy(s) - e1_ref) < 5e-3
