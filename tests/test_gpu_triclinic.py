@@ -114,6 +114,21 @@ def test_triclinic_bonded_terms(pkg):
     assert pkg.potential_energy(s, pairwise=False) == pytest.approx(o.potential_energy(None, pairwise=False, specific=True), rel=1e-11)
 
 
+def test_triclinic_virial_and_pressure(pkg):
+    """virial(sys) = Σ dr ⊗ f with the boundary's minimum image (force.jl:848-852, 991-1060); the volume of the cell is v1.x·v2.y·v3.z"""
+    basis, case = dense_case(seed=3)
+    i = np.arange(0, 342, 3)
+    case.bonds = dict(i=i, j=i + 1, k=np.full(len(i), 500.0), r0=np.full(len(i), 0.33))
+    o = case.oracle(np.float64)
+    nl = o.neighbors("brute")
+    w_ref = o.virial(nl, pairwise=True, specific=True)
+    s = case.system(pkg, np.float64)
+    w = pkg.virial(s)
+    assert np.abs(w - w_ref).max() < 1e-9 * np.abs(w_ref).max()
+    k = 0.5 * np.einsum("i,ia,ib->ab", case.mass, case.velocities, case.velocities)
+    assert np.abs(pkg.pressure(s) - (2 * k + w_ref) / np.prod(np.diag(basis))).max() < 1e-9 * np.abs(w_ref).max() / np.prod(np.diag(basis))
+
+
 def test_triclinic_is_refused_where_it_is_not_supported(pkg):
     with pytest.raises(ValueError):
         pkg.TriclinicBoundary((2.0, 1.0, 0.0), (1.0, 2.0, 0.0), (1.0, 1.0, 2.0))       # test/basic.jl:202-206
