@@ -10,11 +10,14 @@
 #include <string>
 #include <vector>
 
+#include <unistd.h>
+
 #include "bonded.h"
 #include "stochastic.h"
 #include "pme.h"
 #include "hilbert.h"
 #include "kernels.h"
+#include "forces_launch.h"
 #include "sortscan.h"
 
 namespace mhip {
@@ -113,7 +116,6 @@ struct Prof {
 
 static int env_int(const char* name, int dflt) { const char* v = std::getenv(name); return v && *v ? std::atoi(v) : dflt; }
 
-void launch_forces_uniform_f32(const ForceArgs<float>& A, bool seg, bool prune, size_t lds, unsigned threads, hipStream_t stream);
 
 template <class T> class Engine final : public EngineBase {
     using T4 = typename Vec<T>::T4;
@@ -136,6 +138,7 @@ template <class T> class Engine final : public EngineBase {
     // exceptions (CSR over caller indices)
     DBuf<int32_t> xl_start; DBuf<uint32_t> xl_list; bool has_exc = false; int xl_span = 0; int64_t n_special = 0;
     static constexpr int X_CAP = 32;
+    static constexpr int MAX_THREADS = BlockLimits<T>::max_threads;
     // blocks
     int BI = 256, JS = 1, n_blocks = 0, T_cap = 0, R_cap = 0, C_cap = 0, max_tile = 0, max_rows = 0;
     int ljm_base = LJ_OFF;   // LJ mode implied by the interaction; ljm may be upgraded to the uniform fast path
@@ -172,10 +175,21 @@ template <class T> class Engine final : public EngineBase {
     DBuf<T4> frc_side[2]; const T4* pend_a = nullptr; const T4* pend_b = nullptr; bool overlap = true;
 
     int cm_pending = 0; bool stale = true, minimg = false, params_set = false, state_set = false, frc_valid = false;
+    bool coords_moved = false, export_needs_search = false; int64_t n_set_state_refresh = 0;
+    const bool keep_lists_on_set_state = env_int("MOLLYHIP_SET_STATE_REBUILDS", 0) == 0;
     int64_t last_build_step = std::numeric_limits<int64_t>::min();
     int64_t n_rebuilds = 0, n_force_calls = 0; double last_rebuild_ms = 0;
     size_t lds_force = 0; int tile_lds = 0; bool segmented = false;
     Prof prof;
+    // MOLLYHIP_TRACE=1: drain the stream, then name the launch that follows on stderr — the last name a dying process printed is the
+    // kernel that faulted (a GPU fault aborts the process from the runtime's callback, no status ever comes back)
+    const bool trace_on = env_int("MOLLYHIP_TRACE", 0) != 0;
+    void tr(const char* what) {
+        if (!trace_on) return;
+        (void)hipStreamSynchronize(stream);
+        std::fprintf(stderr, "[mhip %d] %s (n_owned %lld n_ghost %lld BI %d JS %d T_cap %d R_cap %d)\n", (int)getpid(), what, (long long)n_owned, (long long)n_ghost, BI, JS, T_cap, R_cap);
+        std::fflush(stderr);
+    }
 
   public:
     explicit Engine(const mhip_config& c) : cfg(c) {
@@ -329,7 +343,8 @@ template <class T> class Engine final : public EngineBase {
         else { bi = 64; js = 16; }
         bi = env_int("MOLLYHIP_BLOCK_I", bi); js = env_int("MOLLYHIP_J_SPLIT", js);
         if (bi != 64 && bi != 128 && bi != 256) throw ApiError{MHIP_ERR_INVALID, "MOLLYHIP_BLOCK_I must be 64, 128 or 256"};
-        if (js < 1 || bi * js > 1024) throw ApiError{MHIP_ERR_INVALID, "MOLLYHIP_J_SPLIT out of range (BLOCK_I*J_SPLIT <= 1024)"};
+        js = std::min(js, MAX_THREADS / bi);                // the block kernels' launch bound (fp64: 512 lanes, 256 VGPRs per lane)
+        if (js < 1) throw ApiError{MHIP_ERR_INVALID, "MOLLYHIP_J_SPLIT must be positive"};
         BI = bi; JS = js;
         estimate_capacities();
     }
@@ -396,12 +411,15 @@ template <class T> class Engine final : public EngineBase {
         prof.begin(3, stream);
         MHIP_HIP(hipMemsetAsync(cell_cnt.p, 0, (size_t)ncell2 * sizeof(int32_t), stream));
         const int nb256 = cdiv(n_tot, 256);
+        tr("k_cell_keys");
         hipLaunchKernelGGL(k_cell_keys<T>, dim3(nb256), dim3(256), 0, stream, n_tot, n_owned, (const T4*)pos[o].p, (const int32_t*)inv.p,
                            (const uint32_t*)cell_rank.p, key_in.p, idx_in.p, cell_cnt.p, G);
+        tr("sort_pairs");
         size_t tb = cub_tmp.n;
         MHIP_HIP(sort_pairs_u32(cub_tmp.p, tb, key_in.p, key_out.p, idx_in.p, perm.p, (int)n_tot, ilog2(2 * G.ncell + 1) + 1 > 32 ? 32 : ilog2(2 * G.ncell + 1) + 1, stream));
         tb = cub_tmp.n;
         MHIP_HIP(exclusive_sum_i32(cub_tmp.p, tb, cell_cnt.p, cell_start.p, ncell2, stream));
+        tr("k_permute");
         hipLaunchKernelGGL(k_permute<T>, dim3(nb256), dim3(256), 0, stream, n_tot, (const int32_t*)perm.p, (const T4*)pos[o].p, (const T4*)vel[o].p,
                            (const T4*)frc[o].p, (const T2*)lj[o].p, (const int32_t*)orig[o].p, pos[n].p, vel[n].p, frc[n].p, lj[n].p, orig[n].p, inv.p);
         prof.end(3, stream);
@@ -412,7 +430,7 @@ template <class T> class Engine final : public EngineBase {
             n_blocks = cdiv(n_owned, BI);
             size_t lds = build_lds_bytes(T_cap, BI, C_cap);
             if (lds > (size_t)MAX_LDS_BYTES) {
-                if (BI > 64) { BI /= 2; JS = std::min(JS * 2, 1024 / BI); estimate_capacities(); continue; }
+                if (BI > 64) { BI /= 2; JS = std::min(JS * 2, MAX_THREADS / BI); estimate_capacities(); continue; }
                 throw ApiError{MHIP_ERR_CAPACITY, "neighbourhood tile of one 64-atom block does not fit the 160 KiB LDS (r_list too large for this density): T_cap " + std::to_string(T_cap) +
                                " C_cap " + std::to_string(C_cap) + " bytes " + std::to_string(lds)};
             }
@@ -429,6 +447,7 @@ template <class T> class Engine final : public EngineBase {
             A.approx = dual && !env_int("MOLLYHIP_EXACT_OUTER", 0) ? 1 : 0;
             set_lds_limit(k_build<T>, lds);
             prof.begin(1, stream);
+            tr("k_build");
             hipLaunchKernelGGL(k_build<T>, dim3(n_blocks), dim3(BI * JS), lds, stream, A);
             hipLaunchKernelGGL(k_build_summary, dim3(std::min(64, cdiv(n_blocks * JS * (BI / WAVE), 256))), dim3(256), 0, stream, n_blocks, n_blocks * JS * (BI / WAVE), R_cap, (const int32_t*)tile_cnt.p, wave_rows.p, (const float*)nullptr, flags.p);
             prof.end(1, stream);
@@ -438,12 +457,12 @@ template <class T> class Engine final : public EngineBase {
             int ovf = h_flags[FLAG_OVERFLOW];
             if (!ovf) break;
             if (ovf & OVF_SLOT) {
-                if (BI > 64) { BI /= 2; JS = std::min(JS * 2, 1024 / BI); estimate_capacities(); continue; }
+                if (BI > 64) { BI /= 2; JS = std::min(JS * 2, MAX_THREADS / BI); estimate_capacities(); continue; }
                 throw ApiError{MHIP_ERR_CAPACITY, "more than 32766 atoms within r_list of one 64-atom block"};
             }
             if (ovf & OVF_BOXCELLS) {
                 if (h_flags[FLAG_MAX_CELLS] <= MAX_BOX_CELLS) { C_cap = std::min<int>(MAX_BOX_CELLS, (int)(h_flags[FLAG_MAX_CELLS] * 1.1) + 8); continue; }
-                if (BI > 64) { BI /= 2; JS = std::min(JS * 2, 1024 / BI); estimate_capacities(); continue; }
+                if (BI > 64) { BI /= 2; JS = std::min(JS * 2, MAX_THREADS / BI); estimate_capacities(); continue; }
                 throw ApiError{MHIP_ERR_CAPACITY, "block neighbourhood spans more than 8192 cells"};
             }
             if (ovf & OVF_TILE) T_cap = std::min<int>((TILE_SLOT_MAX - 1) & ~3, (((int)(h_flags[FLAG_MAX_TILE] * 1.15) + 32) + 3) & ~3);
@@ -466,7 +485,7 @@ template <class T> class Engine final : public EngineBase {
             MHIP_HIP(hipMemcpyAsync(pos_snap_in.p, pos[cur].p, (size_t)n_tot * sizeof(T4), hipMemcpyDeviceToDevice, stream));
             last_prune_step = step_n;
         }
-        stale = false; last_build_step = step_n; ++n_rebuilds;
+        stale = false; coords_moved = false; export_needs_search = false; last_build_step = step_n; ++n_rebuilds;
         last_rebuild_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
 
@@ -499,6 +518,7 @@ template <class T> class Engine final : public EngineBase {
         size_t lds = (size_t)F.T_lds * sizeof(float4) + (size_t)((T_cap + 8) & ~7) + (size_t)((T_cap + 2) & ~1) * 2 + (size_t)BI * JS * 4 + 64;
         set_lds_limit(k_filter<T>, lds);
         prof.begin(4, stream);
+        tr("k_filter");
         hipLaunchKernelGGL(k_filter<T>, dim3(n_blocks), dim3(BI * JS), lds, stream, F);
         hipLaunchKernelGGL(k_build_summary, dim3(std::min(64, cdiv(n_blocks * JS * (BI / WAVE), 256))), dim3(256), 0, stream, n_blocks, n_blocks * JS * (BI / WAVE), R_cap,
                            (const int32_t*)tile_cnt_in.p, rows_x.p, (const float*)blk_disp2.p, flags.p);
@@ -508,6 +528,7 @@ template <class T> class Engine final : public EngineBase {
 
     // max |x − x_snap|² over all local atoms (one small kernel + one host sync)
     float max_disp2_since(const DBuf<T4>& snap) {
+        tr("k_max_disp");
         MHIP_HIP(hipMemsetAsync(flags.p + FLAG_MAX_DISP2, 0, sizeof(int32_t), stream));
         hipLaunchKernelGGL(k_max_disp<T>, dim3(std::min(cdiv(n_tot, 256), 1024)), dim3(256), 0, stream, n_tot, (const T4*)pos[cur].p, (const T4*)snap.p,
                            reinterpret_cast<unsigned int*>(flags.p + FLAG_MAX_DISP2), G);
@@ -563,39 +584,35 @@ template <class T> class Engine final : public EngineBase {
         rebuild(step_n);
     }
 
+    // Neighbours at the first step of a run (find_neighbors with current_neighbors = nothing, simulators.jl:564).  The reference
+    // searches afresh there; a fresh search changes results only where list MEMBERSHIP matters (an interaction without a cutoff
+    // inside r_list).  Lists that carry a skin are kept if the displacement checks say they still cover every cutoff sphere: a run
+    // continued in chunks then walks the same lists in the same order as the uncut run and reproduces it bit for bit.
+    void start_lists(int64_t first_step) {
+        const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
+        lists_after_set_state();
+        if (stale || !(dual || lazy_single) || !keep_lists_on_set_state) { rebuild(first_step); return; }
+        if (first_step % every == 0 && first_step != last_build_step) refresh(first_step);
+    }
+
     void ensure_built(int64_t step_n) {
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
+        lists_after_set_state();
         if (stale) rebuild(step_n);
         else if (step_n % every == 0 && step_n != last_build_step) refresh(step_n);
     }
 
     // ---------------------------------------------------------------------------------------------
-    template <int LJM, int COULM, bool ENERGY, bool MINIMG, bool SEGM, bool PRUNE> void launch_forces_k(const ForceArgs<T>& A) {
-        if constexpr (std::is_same<T, float>::value && LJM == LJ_DIST_UNIFORM && COULM == MHIP_COUL_NONE && !ENERGY && !MINIMG) {
-            launch_forces_uniform_f32(A, SEGM, PRUNE, lds_force, (unsigned)(BI * JS), stream);   // compiled in forces_uniform.hip
-            return;
-        }
-        auto kern = k_forces<T, LJM, COULM, ENERGY, MINIMG, SEGM, PRUNE>;
-        set_lds_limit(kern, lds_force);
-        hipLaunchKernelGGL(kern, dim3(A.blocks_per_xcd * 8), dim3(BI * JS), lds_force, stream, A);
-    }
-    template <int LJM, int COULM, bool ENERGY, bool MINIMG> void launch_forces_t(const ForceArgs<T>& A) {
-        const bool prune = A.nbr_dst != nullptr;
-        if constexpr (!ENERGY) {
-            if (prune) { if (segmented) launch_forces_k<LJM, COULM, false, MINIMG, true, true>(A); else launch_forces_k<LJM, COULM, false, MINIMG, false, true>(A); return; }
-        }
-        if (segmented) launch_forces_k<LJM, COULM, ENERGY, MINIMG, true, false>(A); else launch_forces_k<LJM, COULM, ENERGY, MINIMG, false, false>(A);
-    }
-    template <int LJM, int COULM> void launch_forces_c(const ForceArgs<T>& A, bool energy) {
-        if (energy) { if (minimg) launch_forces_t<LJM, COULM, true, true>(A); else launch_forces_t<LJM, COULM, true, false>(A); }
-        else { if (minimg) launch_forces_t<LJM, COULM, false, true>(A); else launch_forces_t<LJM, COULM, false, false>(A); }
-    }
-    template <int LJM> void launch_forces_l(const ForceArgs<T>& A, bool energy) {
+    // the pair-kernel variants are compiled in forces_inst.hip (one translation unit per precision and Coulomb kind)
+    void launch_forces_any(const ForceArgs<T>& A, bool energy) {
+        const bool prune = A.nbr_dst != nullptr && !energy;
+        const unsigned threads = (unsigned)(BI * JS);
+        if (lds_force > (size_t)MAX_LDS_BYTES) throw ApiError{MHIP_ERR_CAPACITY, "atom tile does not fit the 160 KiB LDS"};
         switch (coulm) {
-        case MHIP_COUL_NONE: launch_forces_c<LJM, MHIP_COUL_NONE>(A, energy); break;
-        case MHIP_COUL_PLAIN: launch_forces_c<LJM, MHIP_COUL_PLAIN>(A, energy); break;
-        case MHIP_COUL_REACTION_FIELD: launch_forces_c<LJM, MHIP_COUL_REACTION_FIELD>(A, energy); break;
-        default: launch_forces_c<LJM, MHIP_COUL_EWALD_DIRECT>(A, energy); break;
+        case MHIP_COUL_NONE: launch_forces_tc<T, MHIP_COUL_NONE>(A, ljm, energy, minimg, segmented, prune, lds_force, threads, stream); break;
+        case MHIP_COUL_PLAIN: launch_forces_tc<T, MHIP_COUL_PLAIN>(A, ljm, energy, minimg, segmented, prune, lds_force, threads, stream); break;
+        case MHIP_COUL_REACTION_FIELD: launch_forces_tc<T, MHIP_COUL_REACTION_FIELD>(A, ljm, energy, minimg, segmented, prune, lds_force, threads, stream); break;
+        default: launch_forces_tc<T, MHIP_COUL_EWALD_DIRECT>(A, ljm, energy, minimg, segmented, prune, lds_force, threads, stream); break;
         }
     }
     // pairwise forces of the current coordinates into frc[cur] (overwrites); energy → red_part[0..n_blocks)
@@ -629,12 +646,9 @@ template <class T> class Engine final : public EngineBase {
         }
         A.blk_center = blk_center.p; A.frc = frc[cur].p; A.pe_part = red_part.p;
         prof.begin(prune ? 4 : 0, stream);   // stage 4 = force passes that also prune the outer list
-        switch (ljm) {
-        case LJ_OFF: launch_forces_l<LJ_OFF>(A, energy); break;
-        case LJ_DIST: launch_forces_l<LJ_DIST>(A, energy); break;
-        case LJ_DIST_UNIFORM: launch_forces_l<LJ_DIST_UNIFORM>(A, energy); break;
-        default: launch_forces_l<LJ_GENERIC>(A, energy); break;
-        }
+        tr(prune ? "k_forces (prune)" : (energy ? "k_forces (energy)" : "k_forces"));
+        launch_forces_any(A, energy);
+        tr("after k_forces");
         prof.end(prune ? 4 : 0, stream);
         MHIP_HIP(hipGetLastError());
         ++n_force_calls;
@@ -829,7 +843,34 @@ template <class T> class Engine final : public EngineBase {
         hipLaunchKernelGGL(k_scatter_state<T>, dim3(cdiv(n_tot, 256)), dim3(256), 0, stream, n_tot, n_owned, (const int32_t*)inv.p, dx, dv, pos[cur].p, vel[cur].p, G);
         MHIP_HIP(hipGetLastError());
         if (mem_kind == MHIP_MEM_HOST) MHIP_HIP(hipStreamSynchronize(stream));
-        if (xyz) { stale = true; frc_valid = false; state_set = true; }
+        if (xyz) {
+            // New coordinates, same atoms: the sorted order, the tiles and the pair lists stay (≙ the reference's GPU path, which re-reads
+            // moved coordinates at every call and redoes its sort / tile search only at the step cadence, ext/MollyCUDAExt.jl:774-783).
+            // Whether the lists still cover every cutoff sphere is decided by displacement at the next force call (lists_after_set_state);
+            // lists that have no skin to spend are rebuilt at once, as before.
+            if (!stale && keep_lists_on_set_state && (dual || lazy_single)) coords_moved = true; else stale = true;
+            frc_valid = false; state_set = true;
+        }
+    }
+
+    // after set_state handed over moved coordinates: keep the lists if nobody outran their margins, else prune / search again
+    void lists_after_set_state() {
+        if (!coords_moved) return;
+        coords_moved = false;
+        if (stale) return;
+        if (dual) {
+            const double d_outer = std::sqrt((double)max_disp2_since(pos_snap));
+            if (!(2.0 * d_outer <= outer_margin * 0.98)) { stale = true; return; }
+            if (inner_valid) {
+                const double d_in = std::sqrt((double)max_disp2_since(pos_snap_in));
+                if (!(2.0 * d_in <= skin * 0.98)) inner_valid = false;      // the next force pass re-prunes the outer list
+            }
+        } else {   // lazy_single: one list of radius r_list, snapshot of its build in pos_snap_in
+            const double d = std::sqrt((double)max_disp2_since(pos_snap_in));
+            if (!(2.0 * d <= skin * 0.98)) stale = true;
+            else if (d > 0) export_needs_search = true;    // fine for forces; mhip_export_neighbors wants the list of the new coordinates
+        }
+        if (stale || !inner_valid) ++n_set_state_refresh;
     }
 
     void get_state(void* xyz, void* v, int mem_kind) override {
@@ -1041,12 +1082,13 @@ template <class T> class Engine final : public EngineBase {
     // simulators.jl:561-571: wrap (done by set_state / the integrator), neighbours, forces at first_step
     void vv_init(int64_t first_step) override {
         if (!state_set) throw ApiError{MHIP_ERR_STATE, "set_state must be called before vv_run"};
-        rebuild(first_step);
+        start_lists(first_step);
         step_forces(first_step);
         fold_side_forces();
     }
     void vv_stage1(double dt) override {
         if (!frc_valid) throw ApiError{MHIP_ERR_STATE, "vv_stage1 needs forces from vv_init / vv_stage2"};
+        tr("k_vv1");
         prof.begin(2, stream);
         hipLaunchKernelGGL(k_vv1<T>, dim3(std::min(cdiv(n_owned, 256), 1024)), dim3(256), 0, stream, n_owned, pos[cur].p, vel[cur].p, (const T4*)frc[cur].p, T(dt), T(dt) / T(2),
                            cm_pending == 1 ? (const T*)vcm.p : (const T*)nullptr, cm_pending == 2 ? cm_src() : (const double*)nullptr, n_cm_step, G);
@@ -1057,6 +1099,7 @@ template <class T> class Engine final : public EngineBase {
         step_forces(step_n);
         // with an external partial buffer every one of its n_parts_ext slots gets a block (blocks without atoms write zeros)
         const int nb = cm_parts_ext ? n_parts_ext : std::min(cdiv(n_owned, 256), 1024);
+        tr("k_vv2");
         prof.begin(2, stream);
         if (cm) {
             hipLaunchKernelGGL((k_vv2<T, true>), dim3(nb), dim3(256), 0, stream, n_owned, vel[cur].p, frc[cur].p, T(dt) / T(2), cm_parts_ext ? cm_parts_ext : cm_step.p, pend_a, pend_b);
@@ -1131,7 +1174,7 @@ template <class T> class Engine final : public EngineBase {
         }
         MHIP_HIP(hipGetLastError());
     }
-    void rebuild_now(int64_t step_n) override { flush_cm(); if (stale) rebuild(step_n); else refresh(step_n); }
+    void rebuild_now(int64_t step_n) override { flush_cm(); lists_after_set_state(); if (stale) rebuild(step_n); else refresh(step_n); }
 
     void vv_run(int64_t first_step, int64_t n_steps, double dt, int remove_cm_every) override {
         if (!state_set || !params_set) throw ApiError{MHIP_ERR_STATE, "set_atoms and set_state must be called before vv_run"};
@@ -1222,7 +1265,7 @@ template <class T> class Engine final : public EngineBase {
         if (!(kT >= 0) || !(friction >= 0)) throw ApiError{MHIP_ERR_INVALID, "temperature and friction must be non-negative"};
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         if (first_step == 0 && remove_cm_every != 0) remove_cm();                 // :1115
-        rebuild(first_step);                                                      // :1116
+        start_lists(first_step);                                                  // :1116
         const double vs = std::exp(-dt * friction);                               // :1091-1092
         StochP<T> P = stoch_params(kT, key, ctr1_0);
         P.dt = T(dt); P.dt_half = T(dt) / T(2); P.vel_scale = T(vs); P.noise_kt = std::sqrt(1.0 - vs * vs) * std::sqrt(kT);
@@ -1250,8 +1293,12 @@ template <class T> class Engine final : public EngineBase {
     }
 
     int64_t export_neighbors(int32_t* oi, int32_t* oj, uint8_t* osp, int64_t capacity) override {
-        if (stale) throw ApiError{MHIP_ERR_STATE, "no neighbour list: call forces / rebuild first"};
-        if (lazy_single && last_build_step != last_prune_step) { flush_cm(); rebuild(last_build_step); }   // skipped rebuilds: hand out the list of NOW
+        lists_after_set_state();
+        if (stale) {   // never built, or invalidated by new coordinates / exceptions: search now
+            if (!state_set || !params_set) throw ApiError{MHIP_ERR_STATE, "no neighbour list: call set_atoms and set_state first"};
+            flush_cm(); rebuild(last_build_step == std::numeric_limits<int64_t>::min() ? 0 : last_build_step);
+        }
+        if (lazy_single && (last_build_step != last_prune_step || export_needs_search)) { flush_cm(); rebuild(last_build_step); }   // skipped rebuilds / moved coordinates: hand out the list of NOW
         const int32_t *x_tidx = tile_idx.p, *x_tcnt = tile_cnt.p, *x_rows = wave_rows.p; const uint2* x_nbr = nbr.p;
         if (dual) {
             // the reference's list at the current coordinates = the outer list filtered with the exact predicate; valid as long as
@@ -1318,12 +1365,14 @@ template <class T> class Engine final : public EngineBase {
 
     void gather_coords(const int32_t* idx_dev, const void* shift_dev, int64_t n, void* out_dev) override {
         if (n <= 0) return;
+        tr("k_gather_coords");
         hipLaunchKernelGGL(k_gather_coords<T>, dim3(cdiv(n, 256)), dim3(256), 0, stream, n, idx_dev, (const T*)shift_dev, (const int32_t*)inv.p, (const T4*)pos[cur].p, (T*)out_dev);
         MHIP_HIP(hipGetLastError());
     }
     void scatter_coords(int64_t first, int64_t n, const void* in_dev) override {
         if (n <= 0) return;
         if (first < 0 || first + n > n_tot) throw ApiError{MHIP_ERR_INVALID, "scatter_coords range out of bounds"};
+        tr("k_scatter_coords");
         hipLaunchKernelGGL(k_scatter_coords<T>, dim3(cdiv(n, 256)), dim3(256), 0, stream, first, n, (const T*)in_dev, (const int32_t*)inv.p, pos[cur].p);
         MHIP_HIP(hipGetLastError());
     }

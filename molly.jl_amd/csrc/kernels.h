@@ -31,16 +31,16 @@ template <class T> __device__ inline int cell_coord(T x, int d, const GridP<T>& 
     return min(max(c, 0), G.nc[d] - 1);
 }
 
-// value of `v` in lane `src` (wave-uniform index) broadcast to every lane through the scalar file (v_readlane_b32)
-// lane `dst` (wave-uniform) of lo/hi := the two halves of a wave mask held in scalar registers (v_writelane_b32; the lane
-// select goes through m0 because a VOP3 may read only one ordinary SGPR on gfx9)
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
+// lane `dst` (wave-uniform) of lo/hi := the two halves of a wave mask held in scalar registers (v_writelane_b32).  clang has no
+// __builtin for it, so the LLVM intrinsic is bound by name: the compiler then knows the instruction and pads the gfx950 hazard between
+// the v_cmp that produced the mask (a VALU write of VCC / an SGPR pair) and the VALU read of it as writelane data (2 wait states; a
+// hand-written asm block is invisible to the hazard recogniser), and m0 stays the compiler's.
+extern "C" __device__ int mhip_writelane_i32(int src, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 __device__ inline void mask_to_lane(int& lo, int& hi, unsigned long long mask, int dst) {
-    const int mlo = (int)(uint32_t)mask, mhi = (int)(uint32_t)(mask >> 32);
-    asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0" : "+v"(lo), "+v"(hi) : "s"(mlo), "s"(mhi), "s"(dst) : "m0");
+    lo = mhip_writelane_i32((int)(uint32_t)mask, dst, lo);
+    hi = mhip_writelane_i32((int)(uint32_t)(mask >> 32), dst, hi);
 }
-#pragma clang diagnostic pop
+// value of `v` in lane `src` (wave-uniform index) broadcast to every lane through the scalar file (v_readlane_b32)
 __device__ inline float lane_bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 __device__ inline double lane_bcast(double v, int src) {
     long long b = __double_as_longlong(v);
@@ -188,8 +188,12 @@ __device__ inline int block_excl_scan(int32_t* a, int n, int32_t* part, int tid,
     return a[n];
 }
 
+// Thread-count limits of the block kernels (BI·JS lanes).  fp64 is held to 512 lanes so that a lane may use up to 256 VGPRs: at 1024
+// lanes (128 VGPRs) every fp64 pair-kernel variant spilled to scratch.
+template <class T> struct BlockLimits { static constexpr int max_threads = sizeof(T) == 8 ? 512 : 1024; };
+
 template <class T>
-__global__ void k_build(BuildArgs<T> A) {
+__global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs<T> A) {
     using T4 = typename Vec<T>::T4;
     extern __shared__ __align__(32) unsigned char smem[];
     const GridP<T>& G = A.G;
@@ -581,7 +585,7 @@ template <class T> struct FilterArgs {
 };
 
 template <class T>
-__global__ void k_filter(FilterArgs<T> A) {
+__global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_filter(FilterArgs<T> A) {
     using T4 = typename Vec<T>::T4;
     extern __shared__ __align__(32) unsigned char smem[];
     const GridP<T>& G = A.G;
@@ -739,7 +743,7 @@ template <class T> struct ForceArgs {
 };
 
 template <class T, int LJM, int COULM, bool ENERGY, bool MINIMG, bool SEG, bool PRUNE>
-__global__ void k_forces(ForceArgs<T> A) {
+__global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_forces(ForceArgs<T> A) {
     using T4 = typename Vec<T>::T4;
     using T2 = typename Vec<T>::T2;
     constexpr bool PER_ATOM_LJ = (LJM == LJ_DIST || LJM == LJ_GENERIC);
@@ -863,10 +867,13 @@ __global__ void k_forces(ForceArgs<T> A) {
                 fx = (T)fxy.x; fy = (T)fxy.y; fz = (T)fzf;
                 return;
             }
+            // (the fp64 Ewald loop with the in-loop minimum image — 27-image search included — is not unrolled: four copies of it
+            // exceed the 256 VGPRs of a 512-lane block and spill)
+            constexpr int UNROLL = (sizeof(T) == 8 && COULM == MHIP_COUL_EWALD_DIRECT) ? (MINIMG ? 1 : (LJM == LJ_GENERIC && ENERGY ? 2 : 4)) : 4;
             for (int r = 0; r < rows; ++r) {
                 const uint2 e4 = e_next;
                 if (r + 1 < rows) e_next = my_rows[(int64_t)(r + 1) * A.BI];
-#pragma unroll
+#pragma unroll UNROLL
                 for (int k = 0; k < 4; ++k) {
                     uint32_t e = ((k < 2 ? e4.x : e4.y) >> (16 * (k & 1))) & 0xffffu;
                     uint32_t slot = e & 0x7fffu;
@@ -1050,6 +1057,12 @@ __device__ inline void block_vcm(const double* __restrict__ part, int n_part, T*
     for (int c = 0; c < 3; ++c) vcm3[c] = (T)(t[c] / t[3]);
 }
 
+// The integrator's arithmetic is the reference's, operation by operation (no fused multiply-add, a true division): a = f / m with 0 for
+// massless atoms (calc_accels, force.jl:17), v += a·dt/2 (simulators.jl:594, 616), x += v·dt (:602).  Every kernel below goes through
+// these two helpers, so a run cut into chunks repeats the uncut run bit for bit (test/simulation.jl:16-57).
+template <class T> __device__ inline T accel_of(T f, T m) { return m == T(0) ? T(0) : f / m; }
+template <class T> __device__ inline T step_add(T x, T rate, T h) { return M<T>::add(x, M<T>::mul(rate, h)); }
+
 template <class T>
 __global__ void k_vv1(int64_t n, typename Vec<T>::T4* pos, typename Vec<T>::T4* vel, const typename Vec<T>::T4* __restrict__ frc,
                       T dt, T dt2, const T* __restrict__ vcm, const double* __restrict__ cm_part, int n_cm_part, GridP<T> G) {
@@ -1060,9 +1073,8 @@ __global__ void k_vv1(int64_t n, typename Vec<T>::T4* pos, typename Vec<T>::T4* 
     for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
         auto v = vel[s]; auto p = pos[s]; auto f = frc[s];
         if (sub) { v.x -= vc[0]; v.y -= vc[1]; v.z -= vc[2]; }                // deferred remove_CM_motion!
-        T im = (v.w == T(0)) ? T(0) : T(1) / v.w;                              // calc_accels, force.jl:17
-        v.x += (f.x * im) * dt2; v.y += (f.y * im) * dt2; v.z += (f.z * im) * dt2;   // :594
-        p.x += v.x * dt; p.y += v.y * dt; p.z += v.z * dt;                     // :602
+        v.x = step_add(v.x, accel_of(f.x, v.w), dt2); v.y = step_add(v.y, accel_of(f.y, v.w), dt2); v.z = step_add(v.z, accel_of(f.z, v.w), dt2);   // :594
+        p.x = step_add(p.x, v.x, dt); p.y = step_add(p.y, v.y, dt); p.z = step_add(p.z, v.z, dt);   // :602
         wrap_point(p.x, p.y, p.z, G);                                          // :609
         vel[s] = v; pos[s] = p;
     }
@@ -1079,8 +1091,7 @@ __global__ void k_vv2(int64_t n, typename Vec<T>::T4* vel, typename Vec<T>::T4* 
         if (fa) { const auto g = fa[s]; f.x += g.x; f.y += g.y; f.z += g.z; }
         if (fb) { const auto g = fb[s]; f.x += g.x; f.y += g.y; f.z += g.z; }
         if (fa || fb) frc[s] = f;
-        T im = (v.w == T(0)) ? T(0) : T(1) / v.w;
-        v.x += (f.x * im) * dt2; v.y += (f.y * im) * dt2; v.z += (f.z * im) * dt2;   // :616
+        v.x = step_add(v.x, accel_of(f.x, v.w), dt2); v.y = step_add(v.y, accel_of(f.y, v.w), dt2); v.z = step_add(v.z, accel_of(f.z, v.w), dt2);   // :616
         vel[s] = v;
         if constexpr (CM) { px += (double)v.x * v.w; py += (double)v.y * v.w; pz += (double)v.z * v.w; m += v.w; }
     }
@@ -1120,13 +1131,12 @@ __global__ void k_vv_mid(int64_t n, typename Vec<T>::T4* pos, typename Vec<T>::T
             v.x -= vc[0]; v.y -= vc[1]; v.z -= vc[2];
             p.x = M<T>::sub(p.x, sh[0]); p.y = M<T>::sub(p.y, sh[1]); p.z = M<T>::sub(p.z, sh[2]);
         }
-        const T im = (v.w == T(0)) ? T(0) : T(1) / v.w;
-        const T kx = (f.x * im) * dt2, ky = (f.y * im) * dt2, kz = (f.z * im) * dt2;
-        v.x += kx; v.y += ky; v.z += kz;                                       // :616, v_n before this step's CM removal
+        const T kx = M<T>::mul(accel_of(f.x, v.w), dt2), ky = M<T>::mul(accel_of(f.y, v.w), dt2), kz = M<T>::mul(accel_of(f.z, v.w), dt2);
+        v.x = M<T>::add(v.x, kx); v.y = M<T>::add(v.y, ky); v.z = M<T>::add(v.z, kz);   // :616, v_n before this step's CM removal
         if constexpr (CM) { px += (double)v.x * v.w; py += (double)v.y * v.w; pz += (double)v.z * v.w; m += v.w; }
         if constexpr (!LAST) {
-            v.x += kx; v.y += ky; v.z += kz;                                   // :594 of the next step
-            p.x += v.x * dt; p.y += v.y * dt; p.z += v.z * dt;                 // :602
+            v.x = M<T>::add(v.x, kx); v.y = M<T>::add(v.y, ky); v.z = M<T>::add(v.z, kz);   // :594 of the next step
+            p.x = step_add(p.x, v.x, dt); p.y = step_add(p.y, v.y, dt); p.z = step_add(p.z, v.z, dt);   // :602
         }
         if (!LAST || sub) {
             wrap_point(p.x, p.y, p.z, G);                                      // :609

@@ -12,6 +12,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """The multi-process tests (several ranks sharing the one GPU, spawned children, gloo rendezvous) run LAST: a spawn hiccup
+    under `-x` must not hide the single-process parity tests behind it."""
+    late = [it for it in items if "test_gpu_domain" in it.nodeid]
+    if late:
+        rest = [it for it in items if "test_gpu_domain" not in it.nodeid]
+        items[:] = rest + late
+
+
 @pytest.fixture(scope="session")
 def pkg():
     """The product package (directory `molly.jl_amd/`, importable as `molly_jl_amd`)."""

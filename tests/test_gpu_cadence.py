@@ -1,0 +1,161 @@
+"""The list-lifetime contracts of the drop-in boundary and of the benchmarked kernel variant, on the GPU through the C ABI.
+
+* `mhip_set_state` with unchanged topology refreshes coordinates WITHOUT throwing the pair lists away — the four-function drop-in path
+  (set_state → forces(step_n) per step, as the stock `simulate!` loop drives `pairwise_forces_loop_gpu!`, ext/MollyCUDAExt.jl:774-783)
+  must not re-sort and re-search at every call;
+* the uniform-LJ fp32 prune emitter (the variant `bench.py` times) keeps the exported list bit-identical to a fresh reference search;
+* velocity Verlet with massless atoms (calc_accels = 0 for m = 0, src/force.jl:17);
+* a run cut into chunks repeats the uncut run with exact `==` (test/simulation.jl:16-57).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import systems as S
+
+pytestmark = pytest.mark.gpu
+
+
+def export_list(pkg, s):
+    L = pkg.lib()
+    n = C.c_int64(0)
+    s._check(L.mhip_export_neighbors(s.engine(), None, None, None, 0, C.byref(n)))
+    i = np.empty(n.value, np.int32); j = np.empty(n.value, np.int32); sp = np.empty(n.value, np.uint8)
+    s._check(L.mhip_export_neighbors(s.engine(), s._ptr(i), s._ptr(j), s._ptr(sp), n.value, C.byref(n)))
+    return S.sorted_pairs(i, j, sp)
+
+
+@pytest.mark.parametrize("maker,dtype", [("lj", np.float32), ("lj", np.float64), ("charged", np.float32)])
+def test_set_state_then_forces_every_step_keeps_the_lists(pkg, maker, dtype):
+    """30 consecutive steps driven from the HOST: integrate on the CPU side (the oracle's velocity Verlet), hand the coordinates over
+    with set_state, ask for forces(step_n).  Forces stay at oracle parity at every step while the engine searches at most twice and
+    prunes a handful of times — not 30 sorts + searches."""
+    case = S.lj_fluid(16, dtype=dtype) if maker == "lj" else S.charged_fluid(14, dict(kind="rf", rc=1.0), dtype=dtype, stable=True)
+    s = case.system(pkg, dtype)
+    o = case.oracle(np.float64)
+    dt = 0.002 if maker == "lj" else 0.0005
+    worst = 0.0
+    for step in range(0, 31):
+        if step:
+            o.vv_run(1, dt, first_step=step - 1, remove_cm_every=1)      # one reference step on the host
+        x = o.coords.copy()
+        s.coords[:] = x.astype(dtype)
+        f = pkg.forces(s, step_n=step).astype(np.float64)              # push_state → mhip_set_state → mhip_forces(step_n)
+        oo = case.oracle(np.float64, coords=s.coords.astype(np.float64))
+        f_ref = oo.forces(oo.neighbors("cell", nthreads=4), nthreads=4)
+        err = np.linalg.norm(f - f_ref, axis=1).max() / np.linalg.norm(f_ref, axis=1).max()
+        worst = max(worst, err)
+        assert err < (1e-9 if dtype == np.float64 else 2e-4), f"step {step}: relative force error {err:.3e}"
+    st = s.stats()
+    assert st["n_outer_builds"] <= 2, st        # the first search (+ at most one when the margin is used up)
+    assert st["n_outer_builds"] + st["n_filter_passes"] <= 6, st
+    assert st["n_force_calls"] >= 31
+
+
+def test_set_state_with_far_moved_coordinates_searches_again(pkg):
+    """the safety side of the same contract: coordinates that moved further than the lists' margins allow must trigger a new search"""
+    case = S.lj_fluid(12, dtype=np.float64)
+    s = case.system(pkg, np.float64)
+    pkg.forces(s)
+    n0 = s.stats()["n_outer_builds"]
+    rng = np.random.default_rng(3)
+    x2 = case.coords + rng.normal(size=case.coords.shape) * 0.3
+    x2 -= np.floor(x2 / case.box) * case.box
+    keep = np.ones(case.n, bool)      # avoid overlapping atoms: pull apart any pair closer than 0.25 nm by dropping the move
+    oo = case.oracle(np.float64, coords=x2)
+    i, j, _ = oo.neighbors("cell")
+    d = x2[i] - x2[j]; d -= np.round(d / case.box) * case.box
+    close = np.linalg.norm(d, axis=1) < 0.25
+    keep[i[close]] = False; keep[j[close]] = False
+    x2 = np.where(keep[:, None], x2, case.coords)
+    s.coords[:] = x2
+    oo = case.oracle(np.float64, coords=x2)
+    f_ref = oo.forces(oo.neighbors("cell"))
+    f = pkg.forces(s, step_n=1)
+    assert np.abs(f - f_ref).max() <= 1e-9 * np.abs(f_ref).max() + 1e-8
+    assert s.stats()["n_outer_builds"] == n0 + 1
+
+
+def test_uniform_lj_fp32_dual_list_stays_bit_exact(pkg):
+    """the one-type fp32 LJ fluid takes the hand-packed pair loop whose PRUNE instantiation emits the inner list (kernels.h, walk_rows):
+    after 60 steps — prunes included — the list handed out equals a fresh fp32 reference search of the coordinates the engine holds"""
+    case = S.lj_fluid(20, dtype=np.float32)
+    s = case.system(pkg, np.float32)
+    pkg.simulate(s, pkg.VelocityVerlet(dt=0.002), 60)
+    st = s.stats()
+    assert st["minimg_mode"] == 0 and st["n_filter_passes"] >= 1, st      # block-local coordinates, the dual list really pruned
+    got = export_list(pkg, s)
+    o = case.oracle(np.float32, coords=s.coords.astype(np.float64))
+    want = S.sorted_pairs(*o.neighbors("cell", nthreads=4))
+    assert len(got[0]) == len(want[0])
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+    # and the forces of that state against the fp64 oracle at the fp32 bar
+    tol, o64, nl = S.fp32_force_tolerance(case, coords=s.coords.astype(np.float64))
+    f_ref = o64.forces(nl, nthreads=4)
+    err = np.linalg.norm(pkg.forces(s, step_n=60).astype(np.float64) - f_ref, axis=1)
+    assert np.all(err <= tol), f"worst err {err.max():.3e} tol {tol[err.argmax()]:.3e}"
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_velocity_verlet_with_massless_atoms(pkg, dtype):
+    """calc_accels is 0 for m = 0 (src/force.jl:17): massless atoms coast with their initial velocity, take part in the pair forces on
+    the others, and carry no weight in remove_CM_motion!"""
+    case = S.lj_fluid(8, dtype=dtype)
+    mass = case.mass.copy(); mass[::7] = 0.0
+    case.mass = mass
+    o = case.oracle(np.float64)
+    o.vv_run(25, 0.002, remove_cm_every=1)
+    s = case.system(pkg, dtype)
+    v0 = s.velocities.copy()
+    pkg.simulate(s, pkg.VelocityVerlet(dt=0.002), 25)
+    d = s.coords.astype(np.float64) - o.coords
+    d -= np.round(d / case.box) * case.box
+    if dtype == np.float64:
+        assert np.abs(d).max() < 1e-10 and np.abs(s.velocities - o.vel).max() < 1e-9
+    else:
+        assert np.abs(d).mean() < 1e-5 and np.abs(d).max() < 1e-3
+    # massless atoms: only the centre-of-mass corrections touched their velocities
+    dv = (s.velocities[::7].astype(np.float64) - v0[::7].astype(np.float64))
+    assert np.abs(dv - dv.mean(axis=0)).max() < (1e-12 if dtype == np.float64 else 1e-5)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_chunked_continuation_is_exact_without_cm_removal(pkg, dtype):
+    """test/simulation.jl:16-57 asserts `==` between 10 steps and 3 + 3 + 4 steps.  With the lists kept across chunk starts and the
+    integrator's arithmetic shared by all its kernels, the chunked run walks the same lists in the same order: exact equality, when no
+    centre-of-mass removal is pending across a chunk boundary (the fused integrator applies it one launch late, which rounds
+    differently from applying it at the end of a chunk — see test_chunked_continuation for that case, at rounding level)."""
+    case = S.lj_fluid(10, dtype=dtype)
+    sim = pkg.VelocityVerlet(dt=0.002, remove_CM_motion=0)
+    a = case.system(pkg, dtype)
+    pkg.simulate(a, sim, 10)
+    b = case.system(pkg, dtype)
+    pkg.simulate(b, sim, 3)
+    pkg.simulate(b, sim, 3, init_step=3)
+    pkg.simulate(b, sim, 4, init_step=6)
+    assert np.array_equal(a.coords, b.coords) and np.array_equal(a.velocities, b.velocities)
+    # 25 steps cut at 7 and 14 (the rebuild steps 10 and 20 fall inside chunks)
+    a = case.system(pkg, dtype); pkg.simulate(a, sim, 25)
+    b = case.system(pkg, dtype)
+    for first, n in ((0, 7), (7, 7), (14, 11)):
+        pkg.simulate(b, sim, n, init_step=first)
+    assert np.array_equal(a.coords, b.coords) and np.array_equal(a.velocities, b.velocities)
+
+
+def test_full_size_1m_lj_against_oracle(pkg):
+    """BASELINE.json configs[3] on one GPU — the system `bench.py` times: 1 000 000-atom LJ fluid, fp32, forces against the fp64 oracle
+    at the fp32 bar, Newton's third law, full list = 2 × the fp32 reference's half list."""
+    case = S.lj_fluid(100, seed=4, dtype=np.float32)
+    tol, o, nl = S.fp32_force_tolerance(case)
+    f_ref = o.forces(nl, nthreads=16)
+    s = case.system(pkg, np.float32)
+    f = pkg.forces(s).astype(np.float64)
+    err = np.linalg.norm(f - f_ref, axis=1)
+    assert np.all(err <= tol), f"worst err {err.max():.3e} tol {tol[err.argmax()]:.3e}"
+    assert S.rel_rms(err, f_ref) <= 1e-5
+    assert np.abs(f.sum(axis=0)).max() < 1e-6 * o.pair_force_scale.sum()
+    st = s.stats()
+    o32 = case.oracle(np.float32)
+    assert st["n_pairs_full"] == 2 * len(o32.neighbors("cell", nthreads=16)[0])
+    assert st["minimg_mode"] == 0 and st["block_atoms"] * st["j_split"] <= 1024
