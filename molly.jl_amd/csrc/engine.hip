@@ -144,7 +144,7 @@ template <class T> class Engine final : public EngineBase {
     int ljm_base = LJ_OFF;   // LJ mode implied by the interaction; ljm may be upgraded to the uniform fast path
     DBuf<int32_t> tile_idx, tile_cnt, wave_rows; DBuf<uint2> nbr; DBuf<T4> blk_center;
     // dual pair list: outer list (nbr / wave_rows, radius r_list + margin) and the inner list filtered from it
-    DBuf<int32_t> wave_rows_in, tile_idx_in, tile_cnt_in, rows_x; DBuf<uint2> nbr_in, nbr_x; DBuf<T4> pos_snap; DBuf<float> blk_disp2; int max_tile_in = 0;
+    DBuf<int32_t> wave_rows_in, tile_idx_in, tile_cnt_in, rows_x, tile_idx_x, tile_cnt_x; DBuf<uint2> nbr_in, nbr_x; DBuf<T4> pos_snap; DBuf<float> blk_disp2; int max_tile_in = 0;
     bool inner_valid = false, prune_disp_exceeded = false;
     int64_t last_prune_step = 0;
     DBuf<T4> pos_snap_in;        // coordinates at the last prune (validity of the inner list: 2·displacement <= skin)
@@ -229,7 +229,7 @@ template <class T> class Engine final : public EngineBase {
         for (int k = 0; k < 2; ++k) { pos[k].release(); vel[k].release(); frc[k].release(); lj[k].release(); orig[k].release(); }
         inv.release(); key_in.release(); key_out.release(); cell_rank.release(); idx_in.release(); perm.release(); cell_cnt.release(); cell_start.release(); cub_tmp.release();
         pos_snap_in.release();
-        wave_rows_in.release(); nbr_in.release(); pos_snap.release(); blk_disp2.release(); tile_idx_in.release(); tile_cnt_in.release(); rows_x.release(); nbr_x.release();
+        wave_rows_in.release(); nbr_in.release(); pos_snap.release(); blk_disp2.release(); tile_idx_in.release(); tile_cnt_in.release(); rows_x.release(); nbr_x.release(); tile_idx_x.release(); tile_cnt_x.release();
         xl_start.release(); xl_list.release(); tile_idx.release(); tile_cnt.release(); wave_rows.release(); nbr.release(); blk_center.release();
         flags.release(); red_part.release(); red_out.release(); cm_step.release(); vcm.release(); stage_a.release(); stage_b.release(); stage_i.release(); bonded.release(); pme.release();
         prof.release();
@@ -505,14 +505,15 @@ template <class T> class Engine final : public EngineBase {
 
     // inner list := outer entries with r2 <= r_list² at the current coordinates (+ max displacement since the outer build)
     void launch_filter() {
+        // the filtered list has its OWN compacted tile (tile_idx_x): the inner list of the force passes keeps referring to tile_idx_in
         rows_x.reserve((size_t)n_blocks * JS * (BI / WAVE)); nbr_x.reserve((size_t)n_blocks * JS * R_cap * BI);
-        tile_idx_in.reserve((size_t)n_blocks * T_cap); tile_cnt_in.reserve(n_blocks);
+        tile_idx_x.reserve((size_t)n_blocks * T_cap); tile_cnt_x.reserve(n_blocks);
         MHIP_HIP(hipMemsetAsync(flags.p, 0, N_FLAGS * sizeof(int32_t), stream));
         blk_disp2.reserve(n_blocks);
         FilterArgs<T> F;
         F.G = G; F.n_owned = n_owned; F.BI = BI; F.BI_shift = ilog2(BI); F.JS = JS; F.T_cap = T_cap; F.R_cap = R_cap; F.n_blocks = n_blocks;
         F.pos = pos[cur].p; F.pos_snap = pos_snap.p; F.tile_idx = tile_idx.p; F.tile_cnt = tile_cnt.p; F.nbr_out = nbr.p; F.rows_out = wave_rows.p;
-        F.nbr_in = nbr_x.p; F.rows_in = rows_x.p; F.tile_idx_in = tile_idx_in.p; F.tile_cnt_in = tile_cnt_in.p; F.blk_center = blk_center.p; F.blk_disp2 = blk_disp2.p; F.flags = flags.p; F.r_in = r_in; F.r_in2 = r_in2; F.exact_all = minimg ? 1 : 0;
+        F.nbr_in = nbr_x.p; F.rows_in = rows_x.p; F.tile_idx_in = tile_idx_x.p; F.tile_cnt_in = tile_cnt_x.p; F.blk_center = blk_center.p; F.blk_disp2 = blk_disp2.p; F.flags = flags.p; F.r_in = r_in; F.r_in2 = r_in2; F.exact_all = minimg ? 1 : 0;
         F.T_lds = std::min<int>(max_tile, (MAX_LDS_BYTES - 256) / (int)sizeof(float4));
         F.T_lds = minimg ? 0 : F.T_lds;
         size_t lds = (size_t)F.T_lds * sizeof(float4) + (size_t)((T_cap + 8) & ~7) + (size_t)((T_cap + 2) & ~1) * 2 + (size_t)BI * JS * 4 + 64;
@@ -521,7 +522,7 @@ template <class T> class Engine final : public EngineBase {
         tr("k_filter");
         hipLaunchKernelGGL(k_filter<T>, dim3(n_blocks), dim3(BI * JS), lds, stream, F);
         hipLaunchKernelGGL(k_build_summary, dim3(std::min(64, cdiv(n_blocks * JS * (BI / WAVE), 256))), dim3(256), 0, stream, n_blocks, n_blocks * JS * (BI / WAVE), R_cap,
-                           (const int32_t*)tile_cnt_in.p, rows_x.p, (const float*)blk_disp2.p, flags.p);
+                           (const int32_t*)tile_cnt_x.p, rows_x.p, (const float*)blk_disp2.p, flags.p);
         prof.end(4, stream);
         MHIP_HIP(hipGetLastError());
     }
@@ -1292,13 +1293,16 @@ template <class T> class Engine final : public EngineBase {
         MHIP_HIP(hipStreamSynchronize(stream));
     }
 
-    int64_t export_neighbors(int32_t* oi, int32_t* oj, uint8_t* osp, int64_t capacity) override {
-        lists_after_set_state();
+    int64_t export_neighbors(int32_t* oi, int32_t* oj, uint8_t* osp, int64_t capacity) override { return export_list(oi, oj, osp, capacity, true); }
+    // now = false (statistics): count the pairs of the list in use, never search for it
+    int64_t export_list(int32_t* oi, int32_t* oj, uint8_t* osp, int64_t capacity, bool now) {
+        if (now) lists_after_set_state();
         if (stale) {   // never built, or invalidated by new coordinates / exceptions: search now
+            if (!now) return 0;
             if (!state_set || !params_set) throw ApiError{MHIP_ERR_STATE, "no neighbour list: call set_atoms and set_state first"};
             flush_cm(); rebuild(last_build_step == std::numeric_limits<int64_t>::min() ? 0 : last_build_step);
         }
-        if (lazy_single && (last_build_step != last_prune_step || export_needs_search)) { flush_cm(); rebuild(last_build_step); }   // skipped rebuilds / moved coordinates: hand out the list of NOW
+        if (now && lazy_single && (last_build_step != last_prune_step || export_needs_search)) { flush_cm(); rebuild(last_build_step); }   // skipped rebuilds / moved coordinates: hand out the list of NOW
         const int32_t *x_tidx = tile_idx.p, *x_tcnt = tile_cnt.p, *x_rows = wave_rows.p; const uint2* x_nbr = nbr.p;
         if (dual) {
             // the reference's list at the current coordinates = the outer list filtered with the exact predicate; valid as long as
@@ -1308,11 +1312,11 @@ template <class T> class Engine final : public EngineBase {
                 MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
                 MHIP_HIP(hipStreamSynchronize(stream));
                 float d2; std::memcpy(&d2, &h_flags[FLAG_MAX_DISP2], sizeof(float));
-                if (2.0 * std::sqrt((double)d2) <= outer_margin * 0.98) break;
+                if (2.0 * std::sqrt((double)d2) <= outer_margin * 0.98 || !now) break;
                 flush_cm(); rebuild(last_build_step);
                 if (!dual) break;
             }
-            if (dual) { x_tidx = tile_idx_in.p; x_tcnt = tile_cnt_in.p; x_rows = rows_x.p; x_nbr = nbr_x.p; }
+            if (dual) { x_tidx = tile_idx_x.p; x_tcnt = tile_cnt_x.p; x_rows = rows_x.p; x_nbr = nbr_x.p; }
             else { x_tidx = tile_idx.p; x_tcnt = tile_cnt.p; x_rows = wave_rows.p; x_nbr = nbr.p; }
         }
         DBuf<unsigned long long> counter; counter.reserve(1);
@@ -1353,7 +1357,7 @@ template <class T> class Engine final : public EngineBase {
             std::vector<int32_t> tc(n_blocks);
             MHIP_HIP(hipMemcpy(tc.data(), tile_cnt.p, n_blocks * sizeof(int32_t), hipMemcpyDeviceToHost));
             int64_t t = 0; for (int v : tc) t += v; s->tile_atoms_total = t;
-            s->n_pairs_full = 2 * export_neighbors(nullptr, nullptr, nullptr, 0);
+            s->n_pairs_full = 2 * export_list(nullptr, nullptr, nullptr, 0, false);
         }
         const int64_t w = sizeof(T), Rp = (coulm != MHIP_COUL_NONE ? 6 : 4) * w;
         s->algorithmic_bytes_step = n_owned * (Rp + 22 * w) + 4 * (s->n_pairs_full / 2);   // N(R_p + 22w) + 4L

@@ -54,6 +54,19 @@ template <class T> __device__ inline T wave_max(T v) {
     return v;
 }
 
+// x − c on a periodic axis, nearest image, for x and c wrapped into [0, L] (the image is then at k ∈ {−1, 0, +1} box lengths).  The two
+// LARGE numbers are subtracted first — (L − c) when c is the one near L, (x − L) when x is: both differences are exact (Sterbenz) —
+// so the result carries the rounding of a small number, not the ulp of L: 3.8e-6 nm in a 36 nm fp32 box, which is 7e-5 of the force
+// of a contact pair across the periodic boundary (the reference's fp32 vector_1D, v = c2 − c1 first, carries exactly that error).
+template <class T> __device__ inline T local_coord(T x, T c, T L, T invL) {
+    T t = x - c;
+    const T k = M<T>::rint(t * invL);
+    if (k == T(-1)) t = x + (L - c);
+    else if (k == T(1)) t = (x - L) - c;
+    else if (k != T(0)) t -= L * k;
+    return t;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // set_state / set_atoms: caller order → current sorted slots
 template <class T>
@@ -762,10 +775,9 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_forces(ForceArg
 
     auto localise = [&](T4 p) -> T4 {
         if constexpr (!MINIMG) {
-            p.x -= ctr.x; p.y -= ctr.y; p.z -= ctr.z;
-            if (G.periodic[0]) p.x -= G.L[0] * M<T>::rint(p.x * G.invL[0]);
-            if (G.periodic[1]) p.y -= G.L[1] * M<T>::rint(p.y * G.invL[1]);
-            if (G.periodic[2]) p.z -= G.L[2] * M<T>::rint(p.z * G.invL[2]);
+            p.x = G.periodic[0] ? local_coord(p.x, ctr.x, G.L[0], G.invL[0]) : p.x - ctr.x;
+            p.y = G.periodic[1] ? local_coord(p.y, ctr.y, G.L[1], G.invL[1]) : p.y - ctr.y;
+            p.z = G.periodic[2] ? local_coord(p.z, ctr.z, G.L[2], G.invL[2]) : p.z - ctr.z;
         }
         return p;
     };
