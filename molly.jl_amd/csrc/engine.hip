@@ -149,6 +149,10 @@ template <class T> class Engine final : public EngineBase {
     int64_t last_prune_step = 0;
     DBuf<T4> pos_snap_in;        // coordinates at the last prune (validity of the inner list: 2·displacement <= skin)
     double skin = 0; bool strict_cadence = false; int64_t n_disp_checks = 0;
+    // The inner list of the dual scheme only has to hold every pair inside the CUTOFFS (mhip_export_neighbors filters the outer list to
+    // r_list itself): it is pruned to rc_max + skin_in, skin_in <= skin.  A smaller radius means fewer entries per force pass (∝ r³) and
+    // more frequent prunes; MOLLYHIP_INNER_SKIN_PM (picometres, default 100) sets it, the ghosted path keeps skin_in = skin.
+    double skin_in = 0, rc_max_ = 0; T r_prune2 = 0;
     // ghosted sub-domain whose ghost shell reaches r_list + ghost_margin: the ghost PLAN then lives as long as an outer list
     // (until some atom moved ghost_margin/2), so the dual list works here too and the host re-plans only when mhip_plan_disp2_dev says so
     double ghost_margin = 0; const double* cm_ext = nullptr;
@@ -286,6 +290,10 @@ template <class T> class Engine final : public EngineBase {
             if (ip.lj_enabled) rc_max = std::max(rc_max, ip.lj_rc);
             if (ip.coul_kind != MHIP_COUL_NONE) rc_max = std::max(rc_max, ip.coul_rc);
             skin = G.no_list ? 0.0 : cfg.r_list - rc_max;
+            rc_max_ = rc_max;
+            skin_in = (n_ghost > 0 || host_prune) ? skin : std::min(skin, std::max(1, env_int("MOLLYHIP_INNER_SKIN_PM", 100)) * 1e-3);
+            const T rp = T(rc_max + skin_in);
+            r_prune2 = (skin_in < skin) ? rp * rp : r_in2;
         }
         if (tri_mode) outer_margin = 0;   // one cell, exact images everywhere: plain fixed-cadence lists
         dual = outer_margin > 0 && outer_every > 1 && lj_cut_ok && coul_cut_ok && skin > 0;   // ghosted: only with a ghost margin (else re-planned every rebuild)
@@ -326,7 +334,7 @@ template <class T> class Engine final : public EngineBase {
     size_t build_lds_bytes(int tcap, int bi, int ccap) const {
         // tile (coords + slot) | max(cell tables, per-wave candidate bit masks) | scan scratch
         // tile (coords + caller index) | cell tables | scan scratch | per-lane exception lists
-        return (size_t)tcap * (sizeof(float4) + 4) + (2 * (size_t)ccap + 2) * 4 + 8 + (size_t)bi * JS * 4 + (has_exc ? (size_t)X_CAP * bi * 4 : 0) + 64;
+        return (size_t)tcap * (sizeof(float4) + 4) + (2 * (size_t)ccap + 2) * 4 + 8 + (size_t)bi * JS * 4 + (has_exc ? (size_t)X_CAP * bi * 4 : 0) + ((size_t)ccap + 2) * 4 + 64;   // … | first tile slot per box cell
     }
     size_t force_lds_bytes(int tlds) const {
         const bool per_atom_lj = (ljm == LJ_DIST || ljm == LJ_GENERIC);
@@ -445,10 +453,11 @@ template <class T> class Engine final : public EngineBase {
             A.margin = G.no_list ? T(0) : G.r_list * T(1e-3);
             A.debug = env_int("MOLLYHIP_BUILD_DEBUG", 0);
             A.approx = dual && !env_int("MOLLYHIP_EXACT_OUTER", 0) ? 1 : 0;
-            set_lds_limit(k_build<T>, lds);
+            A.walk = env_int("MOLLYHIP_BUILD_WALK", 1) && !G.no_list && !tri_mode ? 1 : 0;
             prof.begin(1, stream);
             tr("k_build");
-            hipLaunchKernelGGL(k_build<T>, dim3(n_blocks), dim3(BI * JS), lds, stream, A);
+            if (A.walk) { set_lds_limit(k_build<T, true>, lds); hipLaunchKernelGGL((k_build<T, true>), dim3(n_blocks), dim3(BI * JS), lds, stream, A); }
+            else { set_lds_limit(k_build<T, false>, lds); hipLaunchKernelGGL((k_build<T, false>), dim3(n_blocks), dim3(BI * JS), lds, stream, A); }
             hipLaunchKernelGGL(k_build_summary, dim3(std::min(64, cdiv(n_blocks * JS * (BI / WAVE), 256))), dim3(256), 0, stream, n_blocks, n_blocks * JS * (BI / WAVE), R_cap, (const int32_t*)tile_cnt.p, wave_rows.p, (const float*)nullptr, flags.p);
             prof.end(1, stream);
             MHIP_HIP(hipGetLastError());
@@ -504,16 +513,21 @@ template <class T> class Engine final : public EngineBase {
     }
 
     // inner list := outer entries with r2 <= r_list² at the current coordinates (+ max displacement since the outer build)
-    void launch_filter() {
-        // the filtered list has its OWN compacted tile (tile_idx_x): the inner list of the force passes keeps referring to tile_idx_in
-        rows_x.reserve((size_t)n_blocks * JS * (BI / WAVE)); nbr_x.reserve((size_t)n_blocks * JS * R_cap * BI);
-        tile_idx_x.reserve((size_t)n_blocks * T_cap); tile_cnt_x.reserve(n_blocks);
+    // to_inner = false: the exact list of radius r_list for mhip_export_neighbors, into its OWN arrays (nbr_x, tile_idx_x: the inner list
+    // of the force passes keeps referring to tile_idx_in).  to_inner = true: the prune of the dual scheme as a kernel of its own — the
+    // inner list (any superset of the pairs within rc_max + skin_in) into nbr_in / tile_idx_in.
+    void launch_filter(bool to_inner = false) {
+        DBuf<int32_t>& d_rows = to_inner ? wave_rows_in : rows_x; DBuf<uint2>& d_nbr = to_inner ? nbr_in : nbr_x;
+        DBuf<int32_t>& d_tidx = to_inner ? tile_idx_in : tile_idx_x; DBuf<int32_t>& d_tcnt = to_inner ? tile_cnt_in : tile_cnt_x;
+        d_rows.reserve((size_t)n_blocks * JS * (BI / WAVE)); d_nbr.reserve((size_t)n_blocks * JS * R_cap * BI);
+        d_tidx.reserve((size_t)n_blocks * T_cap); d_tcnt.reserve(n_blocks);
         MHIP_HIP(hipMemsetAsync(flags.p, 0, N_FLAGS * sizeof(int32_t), stream));
         blk_disp2.reserve(n_blocks);
         FilterArgs<T> F;
         F.G = G; F.n_owned = n_owned; F.BI = BI; F.BI_shift = ilog2(BI); F.JS = JS; F.T_cap = T_cap; F.R_cap = R_cap; F.n_blocks = n_blocks;
         F.pos = pos[cur].p; F.pos_snap = pos_snap.p; F.tile_idx = tile_idx.p; F.tile_cnt = tile_cnt.p; F.nbr_out = nbr.p; F.rows_out = wave_rows.p;
-        F.nbr_in = nbr_x.p; F.rows_in = rows_x.p; F.tile_idx_in = tile_idx_x.p; F.tile_cnt_in = tile_cnt_x.p; F.blk_center = blk_center.p; F.blk_disp2 = blk_disp2.p; F.flags = flags.p; F.r_in = r_in; F.r_in2 = r_in2; F.exact_all = minimg ? 1 : 0;
+        F.nbr_in = d_nbr.p; F.rows_in = d_rows.p; F.tile_idx_in = d_tidx.p; F.tile_cnt_in = d_tcnt.p; F.blk_center = blk_center.p; F.blk_disp2 = blk_disp2.p; F.flags = flags.p;
+        F.r_in = r_in; F.r_in2 = to_inner ? r_prune2 : r_in2; F.exact_all = minimg ? 1 : 0; F.approx = to_inner && r_prune2 != r_in2 ? 1 : 0; F.debug = env_int("MOLLYHIP_FILTER_DEBUG", 0);
         F.T_lds = std::min<int>(max_tile, (MAX_LDS_BYTES - 256) / (int)sizeof(float4));
         F.T_lds = minimg ? 0 : F.T_lds;
         size_t lds = (size_t)F.T_lds * sizeof(float4) + (size_t)((T_cap + 8) & ~7) + (size_t)((T_cap + 2) & ~1) * 2 + (size_t)BI * JS * 4 + 64;
@@ -522,22 +536,34 @@ template <class T> class Engine final : public EngineBase {
         tr("k_filter");
         hipLaunchKernelGGL(k_filter<T>, dim3(n_blocks), dim3(BI * JS), lds, stream, F);
         hipLaunchKernelGGL(k_build_summary, dim3(std::min(64, cdiv(n_blocks * JS * (BI / WAVE), 256))), dim3(256), 0, stream, n_blocks, n_blocks * JS * (BI / WAVE), R_cap,
-                           (const int32_t*)tile_cnt_x.p, rows_x.p, (const float*)blk_disp2.p, flags.p);
+                           (const int32_t*)d_tcnt.p, d_rows.p, (const float*)blk_disp2.p, flags.p);
         prof.end(4, stream);
         MHIP_HIP(hipGetLastError());
     }
 
-    // max |x − x_snap|² over all local atoms (one small kernel + one host sync)
+    // max |x − x_snap|² over all local atoms, and the largest speed among the owned atoms (one small kernel + one host sync)
+    double last_vmax = 0, prev_vmax = 0;
     float max_disp2_since(const DBuf<T4>& snap) {
         tr("k_max_disp");
-        MHIP_HIP(hipMemsetAsync(flags.p + FLAG_MAX_DISP2, 0, sizeof(int32_t), stream));
+        MHIP_HIP(hipMemsetAsync(flags.p + FLAG_MAX_DISP2, 0, 2 * sizeof(int32_t), stream));
         hipLaunchKernelGGL(k_max_disp<T>, dim3(std::min(cdiv(n_tot, 256), 1024)), dim3(256), 0, stream, n_tot, (const T4*)pos[cur].p, (const T4*)snap.p,
-                           reinterpret_cast<unsigned int*>(flags.p + FLAG_MAX_DISP2), G);
+                           reinterpret_cast<unsigned int*>(flags.p + FLAG_MAX_DISP2), G, (const T4*)vel[cur].p, n_owned, reinterpret_cast<unsigned int*>(flags.p + FLAG_MAX_V2));
         MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         MHIP_HIP(hipStreamSynchronize(stream));
-        float d2; std::memcpy(&d2, &h_flags[FLAG_MAX_DISP2], sizeof(float));
+        float d2, v2; std::memcpy(&d2, &h_flags[FLAG_MAX_DISP2], sizeof(float)); std::memcpy(&v2, &h_flags[FLAG_MAX_V2], sizeof(float));
+        prev_vmax = last_vmax; last_vmax = std::sqrt((double)v2);
         ++n_disp_checks;
         return d2;
+    }
+    // Upper estimate of how much further anybody gets until the next displacement check, `every` steps from now.  Inside a run the
+    // time step is known: the fastest atom's speed now, stretched by how much the top speed grew since the last check (at least 10 %),
+    // times the interval.  Driven from outside through forces(step_n) there is no time step: the displacement rate seen so far, times 1.5.
+    double cur_dt = 0;
+    double drift_ahead(double d_so_far, int64_t steps_so_far, int every) const {
+        const double empirical = 1.5 * d_so_far * (double)every / (double)std::max<int64_t>(steps_so_far, 1);
+        if (!(cur_dt > 0)) return empirical;
+        const double growth = prev_vmax > 0 ? std::min(std::max(last_vmax / prev_vmax, 1.1), 3.0) : 1.25;
+        return last_vmax * growth * cur_dt * every;
     }
 
     // rebuild step of the cadence (find_neighbors at step_n % n_steps == 0): a fresh search, or — with the dual list —
@@ -546,9 +572,9 @@ template <class T> class Engine final : public EngineBase {
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         if (!dual && lazy_single && !stale && step_n > last_prune_step) {
             // single list built with r_list at step last_prune_step: it still holds every pair within the cutoffs unless somebody moved skin/2
-            const double d = std::sqrt((double)max_disp2_since(pos_snap_in)), checks = std::max<int64_t>(1, (step_n - last_prune_step) / every);
-            if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] step %lld: max disp %.5f nm since the build of step %lld (skin %.3f)\n", (long long)step_n, d, (long long)last_prune_step, skin);
-            if (2.0 * d * (checks + 1.0) / checks <= skin * 0.98) { last_build_step = step_n; ++n_skipped; return; }
+            const double d = std::sqrt((double)max_disp2_since(pos_snap_in));
+            if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] step %lld: max disp %.5f nm since the build of step %lld (skin %.3f), v_max %.4f\n", (long long)step_n, d, (long long)last_prune_step, skin, last_vmax);
+            if (2.0 * (d + drift_ahead(d, step_n - last_prune_step, every)) <= skin * 0.98) { last_build_step = step_n; ++n_skipped; return; }
         }
         if (!dual || stale || (n_ghost == 0 && ((step_n - last_outer_step) >= (int64_t)outer_every * every || step_n < last_outer_step))) { rebuild(step_n); return; }
         // The inner list (pairs within r_list when it was pruned) provably contains every pair within the cutoffs as long as no atom
@@ -559,14 +585,14 @@ template <class T> class Engine final : public EngineBase {
         if (!reprune) {
             const float d2 = max_disp2_since(pos_snap_in);
             // headroom for the drift until the next check: the displacement so far, extrapolated one more interval
-            const double d = std::sqrt((double)d2), checks = std::max<int64_t>(1, (step_n - last_prune_step) / every);
-            reprune = 2.0 * d * (checks + 1.0) / checks > skin * 0.98;
+            const double d = std::sqrt((double)d2);
+            reprune = 2.0 * (d + drift_ahead(d, step_n - last_prune_step, every)) > skin_in * 0.98;
         }
         if (reprune && n_ghost == 0 && !stale) {
             // a prune is only as good as the outer list behind it (nobody moved more than half the margin since the outer search):
             // if that is already used up, search again now instead of running a prune pass that would have to be thrown away
             const double d_outer = std::sqrt((double)max_disp2_since(pos_snap));
-            if (2.0 * d_outer > outer_margin * 0.98) { rebuild(step_n); return; }
+            if (2.0 * d_outer > prune_margin() * 0.98) { rebuild(step_n); return; }
         }
         if (reprune) inner_valid = false;         // the next force pass re-prunes the outer list at the then-current coordinates
         last_build_step = step_n; ++n_rebuilds;
@@ -624,14 +650,22 @@ template <class T> class Engine final : public EngineBase {
         A.pos = pos[cur].p; A.lj = lj[cur].p; A.tile_idx = tile_idx.p; A.tile_cnt = tile_cnt.p;
         // dual pair list: a force pass whose inner list is stale walks the OUTER list (always a valid superset — the cutoff is
         // applied per pair) and, if it is a plain force call, prunes it into the inner list on the way
+        if (dual && !inner_valid && !energy && prune_by_kernel) prune_with_filter();
         const bool use_inner = dual && inner_valid;
         const bool prune = dual && !inner_valid && !energy;
         carve_force_lds(use_inner ? max_tile_in : max_tile);
         A.T_lds = tile_lds;
         if (use_inner) { A.tile_idx = tile_idx_in.p; A.tile_cnt = tile_cnt_in.p; }
         A.nbr = use_inner ? nbr_in.p : nbr.p; A.wave_rows = use_inner ? wave_rows_in.p : wave_rows.p;
-        A.nbr_dst = nullptr; A.rows_dst = nullptr; A.pos_snap = nullptr; A.blk_disp2 = nullptr; A.r_prune2 = r_in2;
+        A.nbr_dst = nullptr; A.rows_dst = nullptr; A.pos_snap = nullptr; A.blk_disp2 = nullptr; A.r_prune2 = r_prune2;
         A.tile_idx_dst = nullptr; A.tile_cnt_dst = nullptr; A.mark_off = 0; A.any_special = n_special > 0 ? 1 : 0;
+        // the packed fp32 one-type loop keeps the tile as three arrays SOA_STRIDE dwords apart
+        const bool fast_f32 = std::is_same<T, float>::value && ljm == LJ_DIST_UNIFORM && coulm == MHIP_COUL_NONE && !energy && !minimg && !segmented && n_special == 0;
+        A.soa = 0;
+        if (fast_f32 && !env_int("MOLLYHIP_NO_SOA", 0))
+            for (int k = 2; k >= 0; --k) if ((use_inner ? max_tile_in : max_tile) + 1 < SOA_STRIDES[k]) A.soa = SOA_STRIDES[k];   // the smallest stride that holds tile + sentinel
+        if (A.soa) lds_force = std::max(lds_force, (size_t)3 * A.soa * sizeof(float) + 64);
+        lds_force += (size_t)env_int("MOLLYHIP_LDS_PAD_KB", 0) * 1024;   // occupancy experiments
         if (prune) {
             wave_rows_in.reserve((size_t)n_blocks * JS * (BI / WAVE)); nbr_in.reserve((size_t)n_blocks * JS * R_cap * BI); blk_disp2.reserve(n_blocks);
             MHIP_HIP(hipMemsetAsync(blk_disp2.p, 0, (size_t)n_blocks * sizeof(float), stream));
@@ -665,9 +699,32 @@ template <class T> class Engine final : public EngineBase {
             float d2; std::memcpy(&d2, &h_flags[FLAG_MAX_DISP2], sizeof(float));
             total_rows = h_flags[FLAG_TOTAL_ROWS]; max_tile_in = h_flags[FLAG_MAX_TILE];
             ++n_filters;
-            inner_valid = true; prune_disp_exceeded = 2.0 * std::sqrt((double)d2) > outer_margin * 0.98;
-            if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] prune: max disp %.5f nm (margin %.3f) rows %lld exceeded %d calls %lld\n", std::sqrt((double)d2), outer_margin, (long long)total_rows, (int)prune_disp_exceeded, (long long)n_force_calls);
+            inner_valid = true; prune_disp_exceeded = 2.0 * std::sqrt((double)d2) > prune_margin() * 0.98;
+            if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] prune: max disp %.5f nm (margin %.3f) rows %lld exceeded %d calls %lld\n", std::sqrt((double)d2), prune_margin(), (long long)total_rows, (int)prune_disp_exceeded, (long long)n_force_calls);
         }
+    }
+
+    // How far atoms may have moved since the outer search for a prune to be trustworthy: the outer list holds every pair within
+    // r_list + outer_margin of then, the prune wants every pair within rc_max + skin_in of now.
+    double prune_margin() const { return outer_margin + (skin - skin_in); }
+
+    // the prune as a kernel of its own (k_filter into the inner arrays), followed by a plain force pass over the fresh inner list
+    const bool prune_by_kernel = env_int("MOLLYHIP_PRUNE_KERNEL", 0) != 0;
+    void prune_with_filter() {
+        pos_snap_in.reserve(cap);
+        MHIP_HIP(hipMemcpyAsync(pos_snap_in.p, pos[cur].p, (size_t)n_tot * sizeof(T4), hipMemcpyDeviceToDevice, stream));
+        last_prune_step = last_build_step;
+        launch_filter(true);
+        if (n_ghost > 0)   // the blocks record the displacement of the owned atoms; the ghosts' comes on top
+            hipLaunchKernelGGL(k_max_disp<T>, dim3(std::min(cdiv(n_ghost, 256), 1024)), dim3(256), 0, stream, n_ghost, (const T4*)pos[cur].p + n_owned, (const T4*)pos_snap.p + n_owned,
+                               reinterpret_cast<unsigned int*>(flags.p + FLAG_MAX_DISP2), G);
+        MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        MHIP_HIP(hipStreamSynchronize(stream));
+        float d2; std::memcpy(&d2, &h_flags[FLAG_MAX_DISP2], sizeof(float));
+        total_rows = h_flags[FLAG_TOTAL_ROWS]; max_tile_in = h_flags[FLAG_MAX_TILE];
+        ++n_filters;
+        inner_valid = true; prune_disp_exceeded = 2.0 * std::sqrt((double)d2) > prune_margin() * 0.98;
+        if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] prune (kernel): max disp %.5f nm (margin %.3f) rows %lld exceeded %d\n", std::sqrt((double)d2), prune_margin(), (long long)total_rows, (int)prune_disp_exceeded);
     }
 
     double read_sum(int n_part) {
@@ -861,10 +918,10 @@ template <class T> class Engine final : public EngineBase {
         if (stale) return;
         if (dual) {
             const double d_outer = std::sqrt((double)max_disp2_since(pos_snap));
-            if (!(2.0 * d_outer <= outer_margin * 0.98)) { stale = true; return; }
+            if (!(2.0 * d_outer <= prune_margin() * 0.98)) { stale = true; return; }
             if (inner_valid) {
                 const double d_in = std::sqrt((double)max_disp2_since(pos_snap_in));
-                if (!(2.0 * d_in <= skin * 0.98)) inner_valid = false;      // the next force pass re-prunes the outer list
+                if (!(2.0 * d_in <= skin_in * 0.98)) inner_valid = false;   // the next force pass re-prunes the outer list
             }
         } else {   // lazy_single: one list of radius r_list, snapshot of its build in pos_snap_in
             const double d = std::sqrt((double)max_disp2_since(pos_snap_in));
@@ -889,6 +946,7 @@ template <class T> class Engine final : public EngineBase {
     }
 
     void forces(int64_t step_n, int accumulate, void* f_xyz, int mem_kind) override {
+        cur_dt = 0;   // driven from outside: no time step to bound the drift with
         ensure_built(step_n);
         launch_pair_kernel(false);
         frc_valid = false;   // frc holds the pairwise part only
@@ -1089,6 +1147,7 @@ template <class T> class Engine final : public EngineBase {
     }
     void vv_stage1(double dt) override {
         if (!frc_valid) throw ApiError{MHIP_ERR_STATE, "vv_stage1 needs forces from vv_init / vv_stage2"};
+        cur_dt = dt;
         tr("k_vv1");
         prof.begin(2, stream);
         hipLaunchKernelGGL(k_vv1<T>, dim3(std::min(cdiv(n_owned, 256), 1024)), dim3(256), 0, stream, n_owned, pos[cur].p, vel[cur].p, (const T4*)frc[cur].p, T(dt), T(dt) / T(2),
@@ -1181,6 +1240,7 @@ template <class T> class Engine final : public EngineBase {
         if (!state_set || !params_set) throw ApiError{MHIP_ERR_STATE, "set_atoms and set_state must be called before vv_run"};
         if (n_ghost > 0) throw ApiError{MHIP_ERR_STATE, "vv_run is single-domain; drive ghosted domains with vv_stage1/vv_stage2"};
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
+        cur_dt = dt;
         if (first_step == 0 && remove_cm_every != 0) remove_cm();                 // simulators.jl:563
         vv_init(first_step);                                                      // :564-571
         // fused stepping: first kick + drift once, then ONE integrator launch between consecutive force passes (k_vv_mid), the
@@ -1265,6 +1325,7 @@ template <class T> class Engine final : public EngineBase {
         if (n_ghost > 0) throw ApiError{MHIP_ERR_STATE, "langevin_run is single-domain"};
         if (!(kT >= 0) || !(friction >= 0)) throw ApiError{MHIP_ERR_INVALID, "temperature and friction must be non-negative"};
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
+        cur_dt = dt;
         if (first_step == 0 && remove_cm_every != 0) remove_cm();                 // :1115
         start_lists(first_step);                                                  // :1116
         const double vs = std::exp(-dt * friction);                               // :1091-1092

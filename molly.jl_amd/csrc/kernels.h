@@ -16,7 +16,7 @@
 
 namespace mhip {
 
-enum { FLAG_MINIMG = 0, FLAG_OVERFLOW = 1, FLAG_MAX_TILE = 2, FLAG_MAX_ROWS = 3, FLAG_NAN = 4, FLAG_TOTAL_ROWS = 5, FLAG_MAX_CELLS = 6, FLAG_MAX_DISP2 = 7, N_FLAGS = 8 };
+enum { FLAG_MINIMG = 0, FLAG_OVERFLOW = 1, FLAG_MAX_TILE = 2, FLAG_MAX_ROWS = 3, FLAG_NAN = 4, FLAG_TOTAL_ROWS = 5, FLAG_MAX_CELLS = 6, FLAG_MAX_DISP2 = 7, FLAG_MAX_V2 = 8, N_FLAGS = 10 };
 enum { OVF_TILE = 1, OVF_ROWS = 2, OVF_BOXCELLS = 4, OVF_SLOT = 8 };
 
 constexpr int MAX_BOX_CELLS = 8192;
@@ -174,6 +174,7 @@ template <class T> struct BuildArgs {
     T margin;
     int debug;                       // MOLLYHIP_BUILD_DEBUG: stop after stage n (timing experiments only)
     int approx;                      // outer list of the dual scheme: any superset of r_list will do, skip the exact band test
+    int walk;                        // search by walking every i-atom's cell stencil over the tile (1) or transposed, tile groups against the wave's i-atoms (0)
 };
 
 // exclusive prefix sum of a[0..n) in LDS, in place; a[n] receives the total.  `part` holds blockDim ints.
@@ -205,7 +206,7 @@ __device__ inline int block_excl_scan(int32_t* a, int n, int32_t* part, int tid,
 // lanes (128 VGPRs) every fp64 pair-kernel variant spilled to scratch.
 template <class T> struct BlockLimits { static constexpr int max_threads = sizeof(T) == 8 ? 512 : 1024; };
 
-template <class T>
+template <class T, bool WALK>
 __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs<T> A) {
     using T4 = typename Vec<T>::T4;
     extern __shared__ __align__(32) unsigned char smem[];
@@ -221,6 +222,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
     int32_t* c_rank = c_raw + (A.C_cap + 1);                  // C_cap: Hilbert rank of each box cell
     int32_t* part = c_rank + A.C_cap + 1;                     // nthr
     uint32_t* x_part = reinterpret_cast<uint32_t*>(part + nthr);   // [X_cap][BI] per-atom exception lists (only if xl_start)
+    int32_t* t_off = reinterpret_cast<int32_t*>(x_part + (A.xl_start ? A.X_cap * A.BI : 0));   // C_cap + 1: first tile slot of each box cell (walk)
     __shared__ T s_sub[4][6];                                 // per-wave bounding boxes of the i-atoms
     __shared__ T s_ctr[3], s_half[3];
     __shared__ int s_boxlo[3], s_boxlen[3], s_full[3], s_exact, s_wtot[16];
@@ -333,6 +335,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
     if (A.debug == 2) return;
 
     // 2. atom-level pruning + ordered compaction into the LDS tile (cell-major, sorted order inside a cell)
+    if constexpr (WALK) { for (int q = tid; q <= ncb; q += nthr) t_off[q] = 0; __syncthreads(); }
     int tile_n = 0;
     for (int base = 0; base < nraw; base += nthr) {
         const int t = base + tid;
@@ -360,6 +363,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
             t_pos[dst] = make_float4((float)p.x, (float)p.y, (float)p.z, 0.f); t_orig[dst] = A.orig[s]; A.tile_idx[(int64_t)b * A.T_cap + dst] = s;
             const int64_t rel = (int64_t)s - (int64_t)b * A.BI;
             if (rel >= 0 && rel < A.BI) s_self[rel] = dst;     // an i-atom always survives the pruning of its own block
+            if constexpr (WALK) atomicAdd(&t_off[q], 1);       // tile atoms per box cell (the compaction keeps the cell-major order)
         }
         tile_n += tot;
         __syncthreads();
@@ -370,6 +374,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
         return;   // the host grows the capacities and rebuilds
     }
     if (tid == 0) A.tile_cnt[b] = tile_n;
+    if (WALK && !exact_only) block_excl_scan(t_off, ncb, part, tid, nthr);   // → first tile slot of every box cell, t_off[ncb] = tile_n
     if (A.debug == 3) return;
 
     // 3. neighbour search, transposed: the LANES hold 64 tile atoms (one coalesced LDS read per group), the wave
@@ -412,6 +417,53 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
         const uint32_t self_t = valid ? (uint32_t)s_self[li] : 0xffffffffu;
         // this wave's share of the tile: the atoms t ≡ js (mod JS), a uniform sample in tile order, so that the JS
         // sub-lists of an i-atom come out equally long (little sentinel padding)
+        // 3a. walk: every lane runs over the cells within `stencil` of its own atom's cell, row by row in x — the atoms of a row of cells are
+        //     contiguous in the tile (cell-major, x fastest) — and tests each candidate itself.  (2·stencil + 1)³ cells hold about
+        //     3.7 candidates per neighbour found; the transposed search below tests every i-atom of the wave against every 64-atom
+        //     group of the tile that any of them can reach, about 10 per neighbour, and moves every hit through the scalar unit.
+        //     Periodic axes never wrap inside a block's cell box here: a box that spans a whole periodic axis is an exact_only block.
+        if (WALK && !exact_only) {
+            if (valid) {
+                int qc[3], lo[3], hi[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    int q = cell_coord(my[d], d, G) - s_boxlo[d];
+                    if (G.periodic[d]) { if (q < 0) q += G.nc[d]; else if (q >= G.nc[d]) q -= G.nc[d]; }
+                    qc[d] = q; lo[d] = max(q - G.stencil[d], 0); hi[d] = min(q + G.stencil[d], s_boxlen[d] - 1);
+                }
+                for (int qz = lo[2]; qz <= hi[2]; ++qz) for (int qy = lo[1]; qy <= hi[1]; ++qy) {
+                    const int row = (qz * ly + qy) * lx;
+                    const int t0 = t_off[row + lo[0]], t1 = t_off[row + hi[0] + 1];
+                    int t = t0 + (A.JS > 1 ? ((js - t0) % A.JS + A.JS) % A.JS : 0);          // this j-split takes the slots ≡ js (mod JS)
+                    for (; t < t1; t += A.JS) {
+                        const float4 pl = t_pos[t];
+                        const float dx = pl.x - ml[0], dy = pl.y - ml[1], dz = pl.z - ml[2];
+                        const float r2 = dx * dx + dy * dy + dz * dz;
+                        bool in = A.approx ? r2 <= band_hi : r2 < band_lo;
+                        if (!A.approx && !in && r2 <= band_hi) {   // rare: decide with the reference's exact arithmetic on the stored coordinates
+                            T4 pj = A.pos[A.tile_idx[(int64_t)b * A.T_cap + t]];
+                            T ex, ey, ez;
+                            min_image_exact<T>(my[0], my[1], my[2], pj.x, pj.y, pj.z, G, ex, ey, ez);
+                            in = norm2_exact(ex, ey, ez) <= G.r_list2;
+                        }
+                        if (!in || (uint32_t)t == self_t) continue;
+                        uint32_t sp = 0;
+                        const int oj = nxl > 0 ? t_orig[t] : 0;
+                        if (nxl > 0 && (unsigned)(oj - oi + A.xl_span) <= (unsigned)(2 * A.xl_span)) {
+                            uint32_t hit = 0;
+                            for (int k = 0; k < nxl; ++k) {
+                                uint32_t e = k < A.X_cap ? x_part[k * A.BI + li] : A.xl_list[xl0 + k];
+                                hit = ((e & XL_INDEX) == (uint32_t)oj) ? e : hit;
+                            }
+                            if (hit & XL_EXCLUDED) continue;
+                            sp = hit >> 31;
+                        }
+                        emit((uint32_t)t | (sp << 15));
+                    }
+                }
+                (void)qc;
+            }
+        } else {
         const int nwords = (tile_n + 64 * A.JS - 1) / (64 * A.JS);
         for (int w = 0; w < nwords; ++w) {
             const int jl = ((w << 6) + lane) * A.JS + js;
@@ -504,6 +556,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
                 emit(t | (sp << 15));
             }
         }
+        }   // transposed search
     }
     if (A.debug == 4) return;
     // 4. pad every lane to the wave's row count with the sentinel slot (a far-away dummy atom)
@@ -554,10 +607,12 @@ __global__ void k_uniform_check(int64_t n, const T* __restrict__ sig, const T* _
 }
 
 // ---------------------------------------------------------------------------------------------------
-// max over n atoms of |x - x_snap|² (nearest image) → atomicMax into *out_word (float bits; d² >= 0 so uint order works)
+// max over n atoms of |x - x_snap|² (nearest image) → atomicMax into *out_word (float bits; d² >= 0 so uint order works); with
+// `vel`, also the largest |v|² of the first n_vel atoms → *v2_word (how far anybody can get before the next check)
 template <class T>
-__global__ void k_max_disp(int64_t n, const typename Vec<T>::T4* __restrict__ pos, const typename Vec<T>::T4* __restrict__ snap, unsigned int* out_word, GridP<T> G) {
-    float d2 = 0.f;
+__global__ void k_max_disp(int64_t n, const typename Vec<T>::T4* __restrict__ pos, const typename Vec<T>::T4* __restrict__ snap, unsigned int* out_word, GridP<T> G,
+                           const typename Vec<T>::T4* __restrict__ vel = nullptr, int64_t n_vel = 0, unsigned int* v2_word = nullptr) {
+    float d2 = 0.f, v2 = 0.f;
     for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
         auto p = pos[s]; auto q = snap[s];
         T ex = p.x - q.x, ey = p.y - q.y, ez = p.z - q.z;
@@ -565,12 +620,18 @@ __global__ void k_max_disp(int64_t n, const typename Vec<T>::T4* __restrict__ po
         if (G.periodic[1]) ey -= G.L[1] * M<T>::rint(ey * G.invL[1]);
         if (G.periodic[2]) ez -= G.L[2] * M<T>::rint(ez * G.invL[2]);
         d2 = fmaxf(d2, (float)(ex * ex + ey * ey + ez * ez));
+        if (vel && s < n_vel) { auto v = vel[s]; v2 = fmaxf(v2, (float)(v.x * v.x + v.y * v.y + v.z * v.z)); }
     }
-    d2 = wave_max(d2);
-    __shared__ float sh[4];
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = d2;
+    d2 = wave_max(d2); v2 = wave_max(v2);
+    __shared__ float sh[4], shv[4];
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = d2; shv[threadIdx.x >> 6] = v2; }
     __syncthreads();
-    if (threadIdx.x == 0) { float m = 0.f; for (int q = 0; q < (int)(blockDim.x >> 6); ++q) m = fmaxf(m, sh[q]); atomicMax(out_word, __float_as_uint(m)); }
+    if (threadIdx.x == 0) {
+        float m = 0.f, mv = 0.f;
+        for (int q = 0; q < (int)(blockDim.x >> 6); ++q) { m = fmaxf(m, sh[q]); mv = fmaxf(mv, shv[q]); }
+        atomicMax(out_word, __float_as_uint(m));
+        if (v2_word) atomicMax(v2_word, __float_as_uint(mv));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -595,6 +656,8 @@ template <class T> struct FilterArgs {
     int32_t* flags;
     T r_in, r_in2;                            // r_list and r_list² as the reference forms them (dist_cutoff ^ 2)
     int exact_all;                            // small boxes: block-local coordinates are ambiguous, decide every pair exactly
+    int approx;                               // any superset of r_in will do (the force passes' inner list): no exact decisions in the band
+    int debug;                                // MOLLYHIP_FILTER_DEBUG (timing experiments only): 1 no row stores, 2 and no marks, 3 and no compaction / renumbering
 };
 
 template <class T>
@@ -656,7 +719,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_filter(FilterAr
         if (k == 0) { pack[0] = 0; pack[1] = 0; }
         pack[k >> 1] |= e << (16 * (k & 1));
         ++cnt;
-        if (k == 3) dst[(int64_t)((cnt >> 2) - 1) * A.BI] = make_uint2(pack[0], pack[1]);
+        if (k == 3 && A.debug < 1) dst[(int64_t)((cnt >> 2) - 1) * A.BI] = make_uint2(pack[0], pack[1]);
     };
     uint2 e_next = (0 < rows) ? src[0] : make_uint2(0, 0);
     for (int r = 0; r < rows; ++r) {
@@ -673,6 +736,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_filter(FilterAr
                 float dx = pj.x - pil.x, dy = pj.y - pil.y, dz = pj.z - pil.z;
                 float r2 = dx * dx + dy * dy + dz * dz;
                 in = r2 < band_lo; maybe = !in && r2 <= band_hi;
+                if (A.approx) { in = in || maybe; maybe = false; }
             }
             if (maybe) {
                 T4 pj = A.pos[tix[slot]];
@@ -680,13 +744,14 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_filter(FilterAr
                 min_image_exact<T>(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z, G, ex, ey, ez);
                 in = norm2_exact(ex, ey, ez) <= A.r_in2;
             }
-            if (in) { emit(e); l_used[slot] = 1; }   // benign race: every writer stores the same byte
+            if (in) { emit(e); if (A.debug < 2) l_used[slot] = 1; }   // benign race: every writer stores the same byte
         }
     }
     int rows_mine = (cnt + 3) >> 2;
     int rows_wave = wave_max(rows_mine);
     while (((cnt + 3) >> 2) < rows_wave || (cnt & 3)) emit(SENT);
     if (lane == 0) A.rows_in[wslot] = rows_wave;
+    if (A.debug >= 3) return;
     // compact the tile to the referenced atoms: rank of every used slot (ordered), new tile list, rows rewritten in place
     __syncthreads();
     {
@@ -753,9 +818,13 @@ template <class T> struct ForceArgs {
     // … and the tile is compacted to the atoms the inner list references (slots renumbered in the emitted rows)
     int32_t* tile_idx_dst; int32_t* tile_cnt_dst; int mark_off;   // byte offset of the mark array in dynamic LDS
     int any_special;                 // 0: no special (1-4) pair exists, the per-entry weight select is compiled out (uniform-LJ fluids)
+    int soa;                         // != 0: the packed fp32 one-type loop with the tile as x[] / y[] / z[] arrays `soa` dwords apart
 };
+// strides the packed loop is compiled for (odd numbers of dwords): tiles of up to stride − 1 atoms, 12·stride bytes of LDS.  The
+// smallest that holds the tile is used: 36 KiB leaves room for four 512-lane blocks per CU, 48 KiB for three (measured: −12 % per pass).
+constexpr int SOA_STRIDES[3] = {2049, 3073, 4097};
 
-template <class T, int LJM, int COULM, bool ENERGY, bool MINIMG, bool SEG, bool PRUNE>
+template <class T, int LJM, int COULM, bool ENERGY, bool MINIMG, bool SEG, bool PRUNE, int SOA_STRIDE = 4097>
 __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_forces(ForceArgs<T> A) {
     using T4 = typename Vec<T>::T4;
     using T2 = typename Vec<T>::T2;
@@ -816,22 +885,24 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_forces(ForceArg
     for (int seg_lo = 0; seg_lo < (SEG ? tile_n : 1); seg_lo += seg_cap) {
         const int n_here = SEG ? min(seg_cap, tile_n - seg_lo) : tile_n;
         if (SEG && seg_lo > 0) __syncthreads();
-        // stage the tile: gathers of 16 B atoms (mostly L2 hits) into LDS, periodic image resolved once per atom.
-        // The fp32 one-type loop needs x, y, z only and keeps them PACKED (12-byte stride): the random gather then touches every
-        // LDS bank evenly and runs 1.47x faster than the 16-byte-stride ds_read_b96 (tools/micro/lds_gather.hip) — the LDS pipe is
-        // this kernel's busiest unit.
+        // stage the tile: gathers of 16 B atoms (mostly L2 hits) into LDS, periodic image resolved once per staged atom.
+        // The fp32 one-type loop needs x, y, z only and keeps them as three arrays SOA_STRIDE dwords apart (x[t], y[t], z[t]): each
+        // component of two partners is then fetched by its own ds_read_b32 into the two halves of a 64-bit register and the whole pair
+        // arithmetic is packed (v_pk_*_f32).  The odd stride keeps the LDS load/store optimiser from fusing the x and y reads of one
+        // partner into a ds_read2(st64)_b32 — which would put (x, y) of ONE partner side by side and cost a transpose per component —
+        // and spreads the three reads over different banks.
         constexpr bool FAST_CT = std::is_same<T, float>::value && LJM == LJ_DIST_UNIFORM && COULM == MHIP_COUL_NONE && !ENERGY && !MINIMG && !SEG;
-        const bool packed3 = FAST_CT && !A.any_special;
+        const bool packed3 = FAST_CT && !A.any_special && A.soa == SOA_STRIDE;
         float* l_p3 = reinterpret_cast<float*>(smem);
         for (int t = tid; t < n_here; t += nthr) {
             int s = tix[seg_lo + t];
             const T4 pl = localise(A.pos[s]);
-            if (packed3) { l_p3[3 * t] = (float)pl.x; l_p3[3 * t + 1] = (float)pl.y; l_p3[3 * t + 2] = (float)pl.z; }
+            if (packed3) { l_p3[t] = (float)pl.x; l_p3[SOA_STRIDE + t] = (float)pl.y; l_p3[2 * SOA_STRIDE + t] = (float)pl.z; }
             else l_pos[t] = pl;
             if constexpr (PER_ATOM_LJ) l_lj[t] = A.lj[s];
         }
         if (tid == 0) {   // sentinel: far away (beyond every cutoff), no charge, no LJ
-            if (packed3) { l_p3[3 * n_here] = 1e4f; l_p3[3 * n_here + 1] = 1e4f; l_p3[3 * n_here + 2] = 1e4f; }
+            if (packed3) { l_p3[n_here] = 1e4f; l_p3[SOA_STRIDE + n_here] = 1e4f; l_p3[2 * SOA_STRIDE + n_here] = 1e4f; }
             else l_pos[n_here] = make4<T>(T(1e4), T(1e4), T(1e4), T(0));
             if constexpr (PER_ATOM_LJ) l_lj[n_here] = make2<T>(T(0), T(0));
         }
@@ -844,41 +915,47 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_forces(ForceArg
             // (x, y) of one partner as they come out of ds_read_b96, then the radial part of two partners side by side — so that it
             // maps onto v_pk_{add,mul,fma}_f32 without the register shuffles of the auto-vectorised generic loop (forces_uniform.hip
             // is compiled with the SLP vectoriser off).  Same operation order per pair as pair_eval.
-            if constexpr (std::is_same<T, float>::value && LJM == LJ_DIST_UNIFORM && COULM == MHIP_COUL_NONE && !ENERGY && !MINIMG && !SEG && !SPEC) {
+            if constexpr (FAST_CT && !SPEC) { if (packed3) {
+                // Two partners side by side in the halves of 64-bit registers, component by component: (xa, xb), (ya, yb), (za, zb) come
+                // straight out of three ds_read_b32 each, so the displacement, r², the LJ polynomial, the cutoff and the accumulation
+                // are ALL v_pk_*_f32 (two pairs per instruction).  The remaining scalar work per two partners: slot unpacking, one
+                // product, ONE v_rcp_f32 (quarter rate: it costs four plain instructions) shared through 1/ra² = rb²·(1/(ra²rb²)).
+                // The cutoff is a clamped v_pk_fma instead of v_cmp + v_cndmask per partner: clamp((rc²⁺ − r²)·2¹⁰⁰) is exactly 1 for
+                // r² <= rc² and exactly 0 above (rc²⁺ = the float after rc²), the test of the reference (r <= rc).
                 typedef float v2f __attribute__((ext_vector_type(2)));
-                const v2f pixy = {(float)pi.x, (float)pi.y};   // (casts: the branch must also parse for T = double)
-                const float piz = (float)pi.z, s2 = (float)A.I.lj_s2, c24 = (float)A.I.lj_24e, rc2 = (float)A.I.lj_rc2, rp2 = (float)A.r_prune2;
-                float fzf = (float)fz;
-                v2f fxy = {(float)fx, (float)fy};
+                const v2f pix = {(float)pi.x, (float)pi.x}, piy = {(float)pi.y, (float)pi.y}, piz = {(float)pi.z, (float)pi.z};   // (casts: the branch must also parse for T = double)
+                const float s2 = (float)A.I.lj_s2, c24 = (float)A.I.lj_24e, rc2 = (float)A.I.lj_rc2, rp2 = (float)A.r_prune2;
+                const float rc2n = __int_as_float(__float_as_int(rc2) + 1);
+                const v2f cut_a = {-0x1p100f, -0x1p100f}, cut_b = {rc2n * 0x1p100f, rc2n * 0x1p100f};
+                const v2f c48v = {c24 + c24, c24 + c24}, c24v = {c24, c24};
+                v2f fx2 = {(float)fx, 0.f}, fy2 = {(float)fy, 0.f}, fz2 = {(float)fz, 0.f};
                 for (int r = 0; r < rows; ++r) {
                     const uint2 e4 = e_next;
                     if (r + 1 < rows) e_next = my_rows[(int64_t)(r + 1) * A.BI];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const uint32_t w = h ? e4.y : e4.x;
-                        const uint32_t sa = w & 0x7fffu, sb = (w >> 16) & 0x7fffu;
-                        const float *pa = l_p3 + 3 * sa, *pb = l_p3 + 3 * sb;
-                        const v2f da = (v2f){pa[0], pa[1]} - pixy, db = (v2f){pb[0], pb[1]} - pixy;
-                        const float dza = pa[2] - piz, dzb = pb[2] - piz;
-                        const v2f qa = da * da, qb = db * db;
-                        v2f r2;
-                        r2.x = __builtin_fmaf(dza, dza, qa.x) + qa.y;
-                        r2.y = __builtin_fmaf(dzb, dzb, qb.x) + qb.y;
+                        const uint32_t sa = w & 0x7fffu, sb = __builtin_amdgcn_ubfe(w, 16, 15);   // (v_bfe_u32, then one v_lshl_add_u32 each)
+                        const float *pa = l_p3 + sa, *pb = l_p3 + sb;
+                        const v2f dx = (v2f){pa[0], pb[0]} - pix, dy = (v2f){pa[SOA_STRIDE], pb[SOA_STRIDE]} - piy, dz = (v2f){pa[2 * SOA_STRIDE], pb[2 * SOA_STRIDE]} - piz;
+                        const v2f r2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
                         if constexpr (PRUNE) {
                             if (sa < (uint32_t)tile_n && valid && r2.x <= rp2) { emit(w & 0xffffu); l_mark[sa] = 1; }
                             if (sb < (uint32_t)tile_n && valid && r2.y <= rp2) { emit(w >> 16); l_mark[sb] = 1; }
                         }
-                        const v2f inv = {__builtin_amdgcn_rcpf(r2.x), __builtin_amdgcn_rcpf(r2.y)};
-                        v2f six = inv * s2; six = six * six * six;
-                        v2f f = (six * (six + six - 1.0f)) * inv * c24;
-                        f.x = r2.x <= rc2 ? f.x : 0.f; f.y = r2.y <= rc2 ? f.y : 0.f;
-                        fxy -= da * f.x; fxy -= db * f.y;
-                        fzf -= dza * f.x; fzf -= dzb * f.y;
+                        const float t = __builtin_amdgcn_rcpf(r2.x * r2.y);
+                        const v2f inv = (v2f){r2.y, r2.x} * t;
+                        const v2f u = inv * s2, u3 = u * u * u;
+                        v2f f = __builtin_elementwise_fma(u3, c48v, -c24v) * u3 * inv;        // 24ϵ(2u⁶ − u³)/r², u = σ²/r²
+                        v2f in;
+                        asm("v_pk_fma_f32 %0, %1, %2, %3 clamp\n\ts_nop 0" : "=v"(in) : "v"(r2), "s"(cut_a), "v"(cut_b));   // (the nop: a dependent read of a packed result needs one wait state, and asm is invisible to the hazard recogniser)
+                        f *= in;
+                        fx2 -= dx * f; fy2 -= dy * f; fz2 -= dz * f;
                     }
                 }
-                fx = (T)fxy.x; fy = (T)fxy.y; fz = (T)fzf;
+                fx = (T)(fx2.x + fx2.y); fy = (T)(fy2.x + fy2.y); fz = (T)(fz2.x + fz2.y);
                 return;
-            }
+            } }
             // (the fp64 Ewald loop with the in-loop minimum image — 27-image search included — is not unrolled: four copies of it
             // exceed the 256 VGPRs of a 512-lane block and spill)
             constexpr int UNROLL = (sizeof(T) == 8 && COULM == MHIP_COUL_EWALD_DIRECT) ? (MINIMG ? 1 : (LJM == LJ_GENERIC && ENERGY ? 2 : 4)) : 4;
