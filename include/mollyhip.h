@@ -299,6 +299,10 @@ int32_t mhip_vv_halo_begin(mhip_ctx* ctx, double dt, const int32_t* idx_dev, con
                            int64_t n_send, void* send_dev);
 int32_t mhip_vv_halo_end(mhip_ctx* ctx, int64_t step_n, double dt, int64_t first_ghost, int64_t n_ghost,
                          const void* recv_dev, double* cm_out4_dev);
+/* Optional, between vv_halo_begin and vv_halo_end — while the ghost coordinates are on the wire: the pair forces of the atom
+ * blocks whose neighbourhood holds no ghost atom.  *launched = 1 if that part of the force pass was issued (vv_halo_end then only
+ * does the blocks that need ghosts), 0 on steps where the pass must run in one piece (a search or a prune is due). */
+int32_t mhip_vv_halo_interior(mhip_ctx* ctx, int64_t step_n, int32_t* launched);
 /* The same without the finalize launch: cm_parts_dev receives n_parts (<= 1024) per-block partials {Σ m vx, Σ m vy, Σ m vz, Σ m}
  * (double[4·n_parts], unused ones zero).  The host SUM-all-reduces the whole array over the ranks and hands it back through
  * mhip_remove_cm_parts_dev; the next first kick re-sums it in fixed order.  The array must stay untouched until then. */

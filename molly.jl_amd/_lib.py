@@ -109,6 +109,7 @@ SIGNATURES = {
     "mhip_request_prune": (_I32, [_P]),
     "mhip_vv_halo_begin": (_I32, [_P, _D, _P, _P, _I64, _P]),
     "mhip_vv_halo_end": (_I32, [_P, _I64, _D, _I64, _I64, _P, _P]),
+    "mhip_vv_halo_interior": (_I32, [_P, _I64, C.POINTER(_I32)]),
     "mhip_vv_halo_end_parts": (_I32, [_P, _I64, _D, _I64, _I64, _P, _P, _I32]),
     "mhip_remove_cm_parts_dev": (_I32, [_P, _P, _I32]),
 }

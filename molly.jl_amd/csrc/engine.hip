@@ -80,6 +80,7 @@ struct EngineBase {
     virtual void plan_disp2_dev(float*) = 0;
     virtual void request_prune() = 0;
     virtual void halo_begin(double, const int32_t*, const void*, int64_t, void*) = 0;
+    virtual int halo_interior(int64_t) = 0;
     virtual void halo_end(int64_t, double, int64_t, int64_t, const void*, double*) = 0;
     virtual void halo_end_parts(int64_t, double, int64_t, int64_t, const void*, double*, int32_t) = 0;
     virtual void remove_cm_parts_dev(const double*, int32_t) = 0;
@@ -146,6 +147,7 @@ template <class T> class Engine final : public EngineBase {
     // dual pair list: outer list (nbr / wave_rows, radius r_list + margin) and the inner list filtered from it
     DBuf<int32_t> wave_rows_in, tile_idx_in, tile_cnt_in, rows_x, tile_idx_x, tile_cnt_x; DBuf<uint2> nbr_in, nbr_x; DBuf<T4> pos_snap; DBuf<float> blk_disp2; int max_tile_in = 0;
     bool inner_valid = false, prune_disp_exceeded = false;
+    DBuf<int32_t> blk_ghost, blk_ghost_in; bool ghost_flags_ok = false, ghost_flags_in_ok = false, interior_done = false;
     int64_t last_prune_step = 0;
     DBuf<T4> pos_snap_in;        // coordinates at the last prune (validity of the inner list: 2·displacement <= skin)
     double skin = 0; bool strict_cadence = false; int64_t n_disp_checks = 0;
@@ -233,7 +235,7 @@ template <class T> class Engine final : public EngineBase {
         for (int k = 0; k < 2; ++k) { pos[k].release(); vel[k].release(); frc[k].release(); lj[k].release(); orig[k].release(); }
         inv.release(); key_in.release(); key_out.release(); cell_rank.release(); idx_in.release(); perm.release(); cell_cnt.release(); cell_start.release(); cub_tmp.release();
         pos_snap_in.release();
-        wave_rows_in.release(); nbr_in.release(); pos_snap.release(); blk_disp2.release(); tile_idx_in.release(); tile_cnt_in.release(); rows_x.release(); nbr_x.release(); tile_idx_x.release(); tile_cnt_x.release();
+        wave_rows_in.release(); nbr_in.release(); pos_snap.release(); blk_disp2.release(); tile_idx_in.release(); tile_cnt_in.release(); rows_x.release(); nbr_x.release(); tile_idx_x.release(); tile_cnt_x.release(); blk_ghost.release(); blk_ghost_in.release();
         xl_start.release(); xl_list.release(); tile_idx.release(); tile_cnt.release(); wave_rows.release(); nbr.release(); blk_center.release();
         flags.release(); red_part.release(); red_out.release(); cm_step.release(); vcm.release(); stage_a.release(); stage_b.release(); stage_i.release(); bonded.release(); pme.release();
         prof.release();
@@ -331,10 +333,10 @@ template <class T> class Engine final : public EngineBase {
 
     static int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
 
-    size_t build_lds_bytes(int tcap, int bi, int ccap) const {
+    size_t build_lds_bytes(int tcap, int bi, int ccap, bool walk = true) const {
         // tile (coords + slot) | max(cell tables, per-wave candidate bit masks) | scan scratch
         // tile (coords + caller index) | cell tables | scan scratch | per-lane exception lists
-        return (size_t)tcap * (sizeof(float4) + 4) + (2 * (size_t)ccap + 2) * 4 + 8 + (size_t)bi * JS * 4 + (has_exc ? (size_t)X_CAP * bi * 4 : 0) + ((size_t)ccap + 2) * 4 + 64;   // … | first tile slot per box cell
+        return (size_t)tcap * (sizeof(float4) + 4) + (2 * (size_t)ccap + 2) * 4 + 8 + (size_t)bi * JS * 4 + (has_exc ? (size_t)X_CAP * bi * 4 : 0) + (walk ? ((size_t)ccap + 2) * 4 : 0) + 64;   // … | first tile slot per box cell (walk)
     }
     size_t force_lds_bytes(int tlds) const {
         const bool per_atom_lj = (ljm == LJ_DIST || ljm == LJ_GENERIC);
@@ -436,7 +438,9 @@ template <class T> class Engine final : public EngineBase {
 
         for (int attempt = 0; attempt < 12; ++attempt) {
             n_blocks = cdiv(n_owned, BI);
-            size_t lds = build_lds_bytes(T_cap, BI, C_cap);
+            bool walk = env_int("MOLLYHIP_BUILD_WALK", 1) && !G.no_list && !tri_mode;
+            size_t lds = build_lds_bytes(T_cap, BI, C_cap, walk);
+            if (walk && lds > (size_t)MAX_LDS_BYTES) { walk = false; lds = build_lds_bytes(T_cap, BI, C_cap, false); }   // no room for the cell offsets: transposed search
             if (lds > (size_t)MAX_LDS_BYTES) {
                 if (BI > 64) { BI /= 2; JS = std::min(JS * 2, MAX_THREADS / BI); estimate_capacities(); continue; }
                 throw ApiError{MHIP_ERR_CAPACITY, "neighbourhood tile of one 64-atom block does not fit the 160 KiB LDS (r_list too large for this density): T_cap " + std::to_string(T_cap) +
@@ -453,7 +457,7 @@ template <class T> class Engine final : public EngineBase {
             A.margin = G.no_list ? T(0) : G.r_list * T(1e-3);
             A.debug = env_int("MOLLYHIP_BUILD_DEBUG", 0);
             A.approx = dual && !env_int("MOLLYHIP_EXACT_OUTER", 0) ? 1 : 0;
-            A.walk = env_int("MOLLYHIP_BUILD_WALK", 1) && !G.no_list && !tri_mode ? 1 : 0;
+            A.walk = walk ? 1 : 0;
             prof.begin(1, stream);
             tr("k_build");
             if (A.walk) { set_lds_limit(k_build<T, true>, lds); hipLaunchKernelGGL((k_build<T, true>), dim3(n_blocks), dim3(BI * JS), lds, stream, A); }
@@ -487,14 +491,18 @@ template <class T> class Engine final : public EngineBase {
         if (dual) {   // remember where everybody was; the next force pass prunes the outer list into the inner one
             pos_snap.reserve(cap);
             MHIP_HIP(hipMemcpyAsync(pos_snap.p, pos[cur].p, (size_t)n_tot * sizeof(T4), hipMemcpyDeviceToDevice, stream));
-            inner_valid = false; prune_disp_exceeded = false;
+            inner_valid = false; prune_disp_exceeded = false; ghost_flags_in_ok = false;
+            if (cur_dt > 0 && skin_in < skin && !host_prune) {   // inside a run: how fast is the fastest atom? (sizes the inner skin before the first prune)
+                (void)max_disp2_since(pos_snap);
+                adapt_inner_skin(drift_ahead(0.0, 1, cfg.rebuild_every > 0 ? cfg.rebuild_every : 10));
+            }
         }
         if (lazy_single) {
             pos_snap_in.reserve(cap);
             MHIP_HIP(hipMemcpyAsync(pos_snap_in.p, pos[cur].p, (size_t)n_tot * sizeof(T4), hipMemcpyDeviceToDevice, stream));
             last_prune_step = step_n;
         }
-        stale = false; coords_moved = false; export_needs_search = false; last_build_step = step_n; ++n_rebuilds;
+        stale = false; coords_moved = false; export_needs_search = false; ghost_flags_ok = false; ghost_flags_in_ok = false; last_build_step = step_n; ++n_rebuilds;
         last_rebuild_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
 
@@ -559,6 +567,18 @@ template <class T> class Engine final : public EngineBase {
     // time step is known: the fastest atom's speed now, stretched by how much the top speed grew since the last check (at least 10 %),
     // times the interval.  Driven from outside through forces(step_n) there is no time step: the displacement rate seen so far, times 1.5.
     double cur_dt = 0;
+    // The inner list must outlive at least one check interval: if the fastest atoms cover more than a third of the inner skin between
+    // two checks, the skin grows (up to the reference's own r_list − cutoff) and the list is pruned afresh with the larger radius.
+    void adapt_inner_skin(double drift_per_interval) {
+        if (!dual || host_prune || !(skin_in < skin)) return;
+        const double need = std::min(skin, 3.0 * drift_per_interval / 0.98);
+        if (need <= skin_in) return;
+        skin_in = need;
+        const T rp = T(rc_max_ + skin_in);
+        r_prune2 = (skin_in < skin) ? rp * rp : r_in2;
+        inner_valid = false;
+        if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] inner skin raised to %.3f nm (drift per check interval %.4f nm)\n", skin_in, drift_per_interval);
+    }
     double drift_ahead(double d_so_far, int64_t steps_so_far, int every) const {
         const double empirical = 1.5 * d_so_far * (double)every / (double)std::max<int64_t>(steps_so_far, 1);
         if (!(cur_dt > 0)) return empirical;
@@ -585,8 +605,9 @@ template <class T> class Engine final : public EngineBase {
         if (!reprune) {
             const float d2 = max_disp2_since(pos_snap_in);
             // headroom for the drift until the next check: the displacement so far, extrapolated one more interval
-            const double d = std::sqrt((double)d2);
-            reprune = 2.0 * (d + drift_ahead(d, step_n - last_prune_step, every)) > skin_in * 0.98;
+            const double d = std::sqrt((double)d2), ahead = drift_ahead(d, step_n - last_prune_step, every);
+            adapt_inner_skin(ahead);
+            reprune = !inner_valid || 2.0 * (d + ahead) > skin_in * 0.98;
         }
         if (reprune && n_ghost == 0 && !stale) {
             // a prune is only as good as the outer list behind it (nobody moved more than half the margin since the outer search):
@@ -643,7 +664,7 @@ template <class T> class Engine final : public EngineBase {
         }
     }
     // pairwise forces of the current coordinates into frc[cur] (overwrites); energy → red_part[0..n_blocks)
-    void launch_pair_kernel(bool energy) {
+    void launch_pair_kernel(bool energy, int part = 0) {
         ForceArgs<T> A;
         A.G = G; A.I = I; A.n_owned = n_owned; A.BI = BI; A.BI_shift = ilog2(BI); A.JS = JS; A.T_cap = T_cap; A.T_lds = tile_lds; A.R_cap = R_cap;
         A.n_blocks = n_blocks; A.blocks_per_xcd = cdiv(n_blocks, 8);
@@ -665,6 +686,16 @@ template <class T> class Engine final : public EngineBase {
         if (fast_f32 && !env_int("MOLLYHIP_NO_SOA", 0))
             for (int k = 2; k >= 0; --k) if ((use_inner ? max_tile_in : max_tile) + 1 < SOA_STRIDES[k]) A.soa = SOA_STRIDES[k];   // the smallest stride that holds tile + sentinel
         if (A.soa) lds_force = std::max(lds_force, (size_t)3 * A.soa * sizeof(float) + 64);
+        A.part = 0; A.blk_ghost = nullptr;
+        if (part != 0 && !prune) {   // blocks without / with ghost atoms in their tile (flags of the tile this pass stages)
+            DBuf<int32_t>& fl = use_inner ? blk_ghost_in : blk_ghost; bool& ok = use_inner ? ghost_flags_in_ok : ghost_flags_ok;
+            if (!ok) {
+                fl.reserve(n_blocks);
+                hipLaunchKernelGGL(k_block_ghost_flags, dim3(n_blocks), dim3(WAVE), 0, stream, n_blocks, T_cap, n_owned, (const int32_t*)A.tile_idx, (const int32_t*)A.tile_cnt, fl.p);
+                ok = true;
+            }
+            A.part = part; A.blk_ghost = fl.p;
+        }
         lds_force += (size_t)env_int("MOLLYHIP_LDS_PAD_KB", 0) * 1024;   // occupancy experiments
         if (prune) {
             wave_rows_in.reserve((size_t)n_blocks * JS * (BI / WAVE)); nbr_in.reserve((size_t)n_blocks * JS * R_cap * BI); blk_disp2.reserve(n_blocks);
@@ -698,7 +729,7 @@ template <class T> class Engine final : public EngineBase {
             MHIP_HIP(hipStreamSynchronize(stream));
             float d2; std::memcpy(&d2, &h_flags[FLAG_MAX_DISP2], sizeof(float));
             total_rows = h_flags[FLAG_TOTAL_ROWS]; max_tile_in = h_flags[FLAG_MAX_TILE];
-            ++n_filters;
+            ++n_filters; ghost_flags_in_ok = false;
             inner_valid = true; prune_disp_exceeded = 2.0 * std::sqrt((double)d2) > prune_margin() * 0.98;
             if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] prune: max disp %.5f nm (margin %.3f) rows %lld exceeded %d calls %lld\n", std::sqrt((double)d2), prune_margin(), (long long)total_rows, (int)prune_disp_exceeded, (long long)n_force_calls);
         }
@@ -722,7 +753,7 @@ template <class T> class Engine final : public EngineBase {
         MHIP_HIP(hipStreamSynchronize(stream));
         float d2; std::memcpy(&d2, &h_flags[FLAG_MAX_DISP2], sizeof(float));
         total_rows = h_flags[FLAG_TOTAL_ROWS]; max_tile_in = h_flags[FLAG_MAX_TILE];
-        ++n_filters;
+        ++n_filters; ghost_flags_in_ok = false;
         inner_valid = true; prune_disp_exceeded = 2.0 * std::sqrt((double)d2) > prune_margin() * 0.98;
         if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] prune (kernel): max disp %.5f nm (margin %.3f) rows %lld exceeded %d\n", std::sqrt((double)d2), prune_margin(), (long long)total_rows, (int)prune_disp_exceeded);
     }
@@ -766,7 +797,8 @@ template <class T> class Engine final : public EngineBase {
             prof.end(k == 0 ? 5 : 6, side[k]);
             MHIP_HIP(hipEventRecord(ev_side[k], side[k]));
         }
-        launch_pair_kernel(false);
+        launch_pair_kernel(false, interior_done ? 2 : 0);   // (the blocks without ghosts may have run already, while the ghosts were on the wire)
+        interior_done = false;
         bool redo = false;
         if (prune_disp_exceeded) {   // the outer list could not vouch for this pass: search again and redo it on the fresh list
             for (int k = 0; k < 2; ++k) if (k == 0 ? side_b : side_p) MHIP_HIP(hipStreamWaitEvent(stream, ev_side[k], 0));   // they read the old order
@@ -1225,6 +1257,18 @@ template <class T> class Engine final : public EngineBase {
         vv_stage1(dt);
         gather_coords(idx_dev, shift_dev, n, out_dev);
     }
+    // Between halo_begin and halo_end, while the ghost coordinates travel: the pair forces of the blocks whose tile holds no ghost.
+    // Only on steps whose force pass is a plain one over lists that are known to be good (no search, no prune, no cadence decision
+    // pending); returns 1 if it launched, 0 if halo_end will do the whole pass.
+    int halo_interior(int64_t step_n) override {
+        interior_done = false;
+        const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
+        if (n_ghost == 0 || stale || !frc_valid_for_split() || (step_n % every == 0 && step_n != last_build_step)) return 0;
+        launch_pair_kernel(false, 1);
+        interior_done = true;
+        return 1;
+    }
+    bool frc_valid_for_split() const { return dual ? inner_valid : !lazy_single; }
     void halo_end(int64_t step_n, double dt, int64_t first, int64_t n, const void* in_dev, double* cm_out4_dev) override {
         scatter_coords(first, n, in_dev);
         stage2_cadenced(step_n, dt, cm_out4_dev != nullptr);
@@ -1582,6 +1626,7 @@ int32_t mhip_set_ghost_margin(mhip_ctx* ctx, double m) { NEED_CTX(); return guar
 int32_t mhip_plan_disp2_dev(mhip_ctx* ctx, float* out) { NEED_CTX(); return guard(ctx, [&] { if (!out) throw mhip::ApiError{MHIP_ERR_INVALID, "null output"}; ctx->e->plan_disp2_dev(out); }); }
 int32_t mhip_request_prune(mhip_ctx* ctx) { NEED_CTX(); return guard(ctx, [&] { ctx->e->request_prune(); }); }
 int32_t mhip_vv_halo_begin(mhip_ctx* ctx, double dt, const int32_t* idx, const void* shift, int64_t n, void* out) { NEED_CTX(); return guard(ctx, [&] { ctx->e->halo_begin(dt, idx, shift, n, out); }); }
+int32_t mhip_vv_halo_interior(mhip_ctx* ctx, int64_t step_n, int32_t* launched) { NEED_CTX(); return guard(ctx, [&] { int r = ctx->e->halo_interior(step_n); if (launched) *launched = r; }); }
 int32_t mhip_vv_halo_end(mhip_ctx* ctx, int64_t step_n, double dt, int64_t first, int64_t n, const void* in, double* cm_out4) {
     NEED_CTX(); return guard(ctx, [&] { ctx->e->halo_end(step_n, dt, first, n, in, cm_out4); });
 }

@@ -819,6 +819,9 @@ template <class T> struct ForceArgs {
     int32_t* tile_idx_dst; int32_t* tile_cnt_dst; int mark_off;   // byte offset of the mark array in dynamic LDS
     int any_special;                 // 0: no special (1-4) pair exists, the per-entry weight select is compiled out (uniform-LJ fluids)
     int soa;                         // != 0: the packed fp32 one-type loop with the tile as x[] / y[] / z[] arrays `soa` dwords apart
+    // ghosted sub-domains: a pass over only the blocks whose tile holds no ghost atom (part 1: they can run while the ghost coordinates
+    // are still on the wire) or only the others (part 2); 0 = every block
+    const int32_t* blk_ghost; int part;
 };
 // strides the packed loop is compiled for (odd numbers of dwords): tiles of up to stride − 1 atoms, 12·stride bytes of LDS.  The
 // smallest that holds the tile is used: 36 KiB leaves room for four 512-lane blocks per CU, 48 KiB for three (measured: −12 % per pass).
@@ -836,6 +839,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_forces(ForceArg
     const int wg = blockIdx.x;
     const int b = (wg & 7) * A.blocks_per_xcd + (wg >> 3);
     if (b >= A.n_blocks) return;
+    if (A.part != 0 && (A.blk_ghost[b] != 0) != (A.part == 2)) return;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int tile_n = A.tile_cnt[b];
     T4* l_pos = reinterpret_cast<T4*>(smem);
@@ -1126,6 +1130,18 @@ __global__ void k_export_nl(int n_blocks, int BI, int JS, int T_cap, int R_cap, 
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per block: does its tile hold a ghost atom?  (Ghosts sort after all owned atoms.)  One wave per block.
+[[maybe_unused]] static __global__ void k_block_ghost_flags(int n_blocks, int T_cap, int64_t n_owned, const int32_t* __restrict__ tile_idx, const int32_t* __restrict__ tile_cnt, int32_t* out) {
+    const int b = blockIdx.x;
+    if (b >= n_blocks) return;
+    bool g = false;
+    const int n = tile_cnt[b];
+    for (int t = threadIdx.x; t < n; t += blockDim.x) g = g || tile_idx[(int64_t)b * T_cap + t] >= n_owned;
+    const unsigned long long any = __ballot(g);
+    if (threadIdx.x == 0) out[b] = any != 0ull;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -177,6 +177,14 @@ class HipDomainEngine:
         if rc != 0:
             self._chk(rc)
 
+    def halo_interior(self, step):
+        """pair forces of the blocks that need no ghost atom, issued while the ghost exchange is in flight; True if launched"""
+        launched = C.c_int32(0)
+        rc = self.L.mhip_vv_halo_interior(self.ctx, step, C.byref(launched))
+        if rc != 0:
+            self._chk(rc)
+        return bool(launched.value)
+
     def halo_end(self, step, dt, first, n, buf, cm_parts):
         """cm_parts: None, or a device double tensor of 4·k entries (k per-block partials of Σ m v, Σ m — see CM_PARTS)"""
         key = (buf.data_ptr(), None if cm_parts is None else cm_parts.data_ptr())
@@ -237,10 +245,19 @@ class DomainRun:
         # Σ m v travels as per-block partials (no finalize launch on the device): CM_PARTS × {Px, Py, Pz, M}, summed over the ranks
         self.cm_buf = torch.zeros(4 * CM_PARTS, dtype=torch.float64, device=device)
         self.d2_buf = torch.zeros(2, dtype=torch.float32, device=device)
-        self.stats = {"exchange_calls": 0, "ghost_atoms": 0, "migrated": 0, "plans": 0, "plan_checks": 0, "prunes": 0}
+        self.stats = {"exchange_calls": 0, "ghost_atoms": 0, "migrated": 0, "plans": 0, "plan_checks": 0, "prunes": 0, "interior_passes": 0}
+        self.overlap = _os.environ.get("MOLLYHIP_HALO_OVERLAP", "1") != "0" and hasattr(engine, "halo_interior")
         # gloo cannot move device memory: stage through the host (used by the multi-process tests that share ONE GPU;
         # the production path is backend "nccl" = RCCL, device buffers end to end)
         self.stage_host = torch.device(device).type == "cuda" and dist.get_backend(group) == "gloo"
+
+    def _a2a_async(self, recv, send, rc, sc):
+        """ghost exchange that leaves the compute stream free: RCCL runs it on its own stream (async_op) and the returned wait()
+        makes the compute stream wait for it; the host-staged gloo form (tests: several ranks on one GPU) is synchronous, but the
+        kernels issued before it keep the GPU busy while the host moves the bytes"""
+        if self.stage_host or not (self.world > 1 and self.g.dirs):
+            return None
+        return dist.all_to_all_single(recv, send, rc, sc, group=self.group, async_op=True)
 
     def _a2a(self, recv, send, rc=None, sc=None):
         if self.stage_host:
@@ -330,8 +347,15 @@ class DomainRun:
     def step(self, step_n, dt, remove_cm_every=1):
         cm = bool(remove_cm_every) and step_n % remove_cm_every == 0
         self.e.halo_begin(dt, self.send_idx, self.send_shift, self.send_buf)      # kick, drift, pack my atoms the peers need
-        if self.world > 1 and self.g.dirs:
-            self._a2a(self.recv_x.view(-1), self.send_buf.view(-1), self._rc3, self._sc3)
+        exchange = self.world > 1 and bool(self.g.dirs)
+        work = self._a2a_async(self.recv_x.view(-1), self.send_buf.view(-1), self._rc3, self._sc3) if (exchange and self.overlap) else None
+        if self.overlap and self.e.halo_interior(step_n):                          # blocks without ghosts: computed while the ghosts travel
+            self.stats["interior_passes"] += 1
+        if exchange:
+            if work is not None:
+                work.wait()                                                       # the compute stream waits for the exchange here
+            else:
+                self._a2a(self.recv_x.view(-1), self.send_buf.view(-1), self._rc3, self._sc3)
             self.stats["exchange_calls"] += 1
         self.e.halo_end(step_n, dt, self.n_owned, self.n_ghost, self.recv_x, self.cm_buf if cm else None)   # unpack, forces, kick
         if cm:
@@ -458,16 +482,19 @@ def bench_distributed(m, case, dtype, dt, args, rank, local_rank, world):
     rc_max = max([c[1] for c in ([case.lj.get("cutoff", ("none", 0.0))] if case.lj else []) if len(c) > 1] + ([case.coul.get("rc", 0.0)] if case.coul else []) + [0.0])
     run = DomainRun(bg, eng, tdtype, device, case.rebuild_every, ghost_margin=gm, skin=case.r_list - rc_max)
     run.setup_from_global(case.coords, case.velocities, np.zeros(case.n) if case.charge is None else case.charge, case.sigma, case.eps, case.mass)
-    run.run(0, args.warmup, dt)
+    # untimed: equilibrate the jittered lattice first (SURVEY §8(d) cfg 4), then the warm-up
+    equil = getattr(args, "equil", None)
+    equil = equil if equil is not None else (2000 if getattr(args, "workload", "lj1m").startswith("lj") else 0)
+    run.run(0, equil + args.warmup, dt)
     torch.cuda.synchronize(); dist.barrier()
     t0 = time.perf_counter()
-    run.run(args.warmup, args.steps, dt)
+    run.run(equil + args.warmup, args.steps, dt)
     torch.cuda.synchronize(); dist.barrier()
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     ms_per_step = float(el.item()) * 1e3 / args.steps
     eng.set_profiling(True)
-    run.run(args.warmup + args.steps, args.profile_steps, dt)
+    run.run(equil + args.warmup + args.steps, args.profile_steps, dt)
     torch.cuda.synchronize()
     st = eng.stats()
     eng.set_profiling(False)

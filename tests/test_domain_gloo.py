@@ -1,4 +1,4 @@
-"""world_size 2 and 4 runs of the spatial decomposition (molly_jl_amd.domain) over gloo on CPU: brick ownership, ghost
+"""world_size 2, 4 and 8 runs of the spatial decomposition (molly_jl_amd.domain) over gloo on CPU: brick ownership, ghost
 plan, per-step all_to_all ghost exchange, remove_CM all-reduce and migration, checked against the single-domain oracle."""
 import os
 import socket
@@ -42,7 +42,7 @@ def _worker(rank, world, port, n_side, n_steps, out_dir, gm=0.0, skin=0.2):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_decomposed_run_matches_single_domain_oracle(world, tmp_path):
     n_side, n_steps = 10, 12      # 1000 atoms, box 3.6 nm → bricks 1.8 nm ≥ r_list 1.2 nm; rebuild + migration at steps 5, 10
     port = _free_port()
@@ -55,7 +55,7 @@ def test_decomposed_run_matches_single_domain_oracle(world, tmp_path):
     d -= np.round(d / case.box) * case.box
     assert np.abs(d).max() < 1e-9 and np.abs(res["v"] - o.vel).max() < 1e-8
     assert int(res["ghosts"]) > 0
-    assert tuple(res["grid"]) == ((2, 1, 1) if world == 2 else (2, 2, 1))
+    assert tuple(res["grid"]) == {2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}[world]      # 8 ranks: every axis cut, seven peers each
 
 
 @pytest.mark.parametrize("gm,skin,expect", [(0.3, 0.2, "one plan"), (0.3, 0.012, "prunes"), (0.012, 0.012, "replans")])
