@@ -237,7 +237,7 @@ template <class T> class Engine final : public EngineBase {
         pos_snap_in.release();
         wave_rows_in.release(); nbr_in.release(); pos_snap.release(); blk_disp2.release(); tile_idx_in.release(); tile_cnt_in.release(); rows_x.release(); nbr_x.release(); tile_idx_x.release(); tile_cnt_x.release(); blk_ghost.release(); blk_ghost_in.release();
         xl_start.release(); xl_list.release(); tile_idx.release(); tile_cnt.release(); wave_rows.release(); nbr.release(); blk_center.release();
-        flags.release(); red_part.release(); red_out.release(); cm_step.release(); vcm.release(); stage_a.release(); stage_b.release(); stage_i.release(); bonded.release(); pme.release();
+        flags.release(); red_part.release(); red_out.release(); cm_step.release(); vcm.release(); stage_a.release(); stage_b.release(); stage_i.release(); bonded.release(); pme.release(); frc_scratch.release(); nl_counter.release();
         prof.release();
         for (int k = 0; k < 2; ++k) { if (side[k]) { (void)hipStreamSynchronize(side[k]); (void)hipStreamDestroy(side[k]); } if (ev_side[k]) (void)hipEventDestroy(ev_side[k]); frc_side[k].release(); }
         if (ev_pos) (void)hipEventDestroy(ev_pos);
@@ -710,7 +710,7 @@ template <class T> class Engine final : public EngineBase {
             lds_force = (size_t)A.mark_off + (size_t)((T_cap + 8) & ~7) + ((size_t)BI * JS + 2) * 4 + 16;   // + marks + scan scratch
             if (lds_force > (size_t)MAX_LDS_BYTES) throw ApiError{MHIP_ERR_CAPACITY, "prune pass LDS carve-up exceeds 160 KiB"};
         }
-        A.blk_center = blk_center.p; A.frc = frc[cur].p; A.pe_part = red_part.p;
+        A.blk_center = blk_center.p; A.frc = frc_override ? frc_override : frc[cur].p; A.pe_part = red_part.p;
         prof.begin(prune ? 4 : 0, stream);   // stage 4 = force passes that also prune the outer list
         tr(prune ? "k_forces (prune)" : (energy ? "k_forces (energy)" : "k_forces"));
         launch_forces_any(A, energy);
@@ -994,35 +994,32 @@ template <class T> class Engine final : public EngineBase {
         export_frc(accumulate, f_xyz, mem_kind);
     }
 
+    // The energy variant of the pair kernel also writes forces: they go to a scratch array (kept by the context: no allocation per
+    // call on the logging path), the forces the integrator carries stay where they are.
+    DBuf<T4> frc_scratch; DBuf<unsigned long long> nl_counter;
+    T4* frc_override = nullptr;
+    void energy_pass() {
+        frc_scratch.reserve(cap);
+        frc_override = frc_scratch.p;
+        try { launch_pair_kernel(true); } catch (...) { frc_override = nullptr; throw; }
+        frc_override = nullptr;
+    }
     double potential_energy(int64_t step_n) override {
         ensure_built(step_n);
-        DBuf<T4> keep;   // the energy pass must not clobber the forces the integrator carries
-        keep.reserve(n_tot);
-        MHIP_HIP(hipMemcpyAsync(keep.p, frc[cur].p, (size_t)n_tot * sizeof(T4), hipMemcpyDeviceToDevice, stream));
-        launch_pair_kernel(true);
-        MHIP_HIP(hipMemcpyAsync(frc[cur].p, keep.p, (size_t)n_tot * sizeof(T4), hipMemcpyDeviceToDevice, stream));
-        double pe = read_sum(n_blocks);
-        keep.release();
-        return pe;
+        energy_pass();
+        return read_sum(n_blocks);
     }
 
     // Σ over the pair list of dr ⊗ f (force.jl:848-852, 877-880), ADDED to out9 (row-major 3x3, host doubles).  Runs the energy variant
     // of the pair kernel, whose forces are discarded like those of potential_energy.
     void pairwise_virial(int64_t step_n, double* out9) override {
         ensure_built(step_n);
-        DBuf<T4> keep;
-        keep.reserve(n_tot);
-        MHIP_HIP(hipMemcpyAsync(keep.p, frc[cur].p, (size_t)n_tot * sizeof(T4), hipMemcpyDeviceToDevice, stream));
-        launch_pair_kernel(true);
-        MHIP_HIP(hipMemcpyAsync(frc[cur].p, keep.p, (size_t)n_tot * sizeof(T4), hipMemcpyDeviceToDevice, stream));
-        double v[6];
-        for (int c = 0; c < 6; ++c) {
-            hipLaunchKernelGGL(k_sum_double, dim3(1), dim3(256), 0, stream, n_blocks, (const double*)red_part.p + (size_t)(c + 1) * n_blocks, red_out.p);
-            MHIP_HIP(hipMemcpyAsync(h_red, red_out.p, sizeof(double), hipMemcpyDeviceToHost, stream));
-            MHIP_HIP(hipStreamSynchronize(stream));
-            v[c] = h_red[0];
-        }
-        keep.release();
+        energy_pass();
+        double v[6];   // six component sums in one launch (one block each), one readback
+        hipLaunchKernelGGL(k_sum_double, dim3(6), dim3(256), 0, stream, n_blocks, (const double*)red_part.p + (size_t)n_blocks, red_out.p);
+        MHIP_HIP(hipMemcpyAsync(h_red, red_out.p, 6 * sizeof(double), hipMemcpyDeviceToHost, stream));
+        MHIP_HIP(hipStreamSynchronize(stream));
+        for (int c = 0; c < 6; ++c) v[c] = h_red[c];
         out9[0] += v[0]; out9[4] += v[1]; out9[8] += v[2];
         out9[1] += v[3]; out9[3] += v[3]; out9[2] += v[4]; out9[6] += v[4]; out9[5] += v[5]; out9[7] += v[5];
     }
@@ -1424,7 +1421,7 @@ template <class T> class Engine final : public EngineBase {
             if (dual) { x_tidx = tile_idx_x.p; x_tcnt = tile_cnt_x.p; x_rows = rows_x.p; x_nbr = nbr_x.p; }
             else { x_tidx = tile_idx.p; x_tcnt = tile_cnt.p; x_rows = wave_rows.p; x_nbr = nbr.p; }
         }
-        DBuf<unsigned long long> counter; counter.reserve(1);
+        DBuf<unsigned long long>& counter = nl_counter; counter.reserve(1);
         MHIP_HIP(hipMemsetAsync(counter.p, 0, sizeof(unsigned long long), stream));
         hipLaunchKernelGGL(k_export_nl<T>, dim3(n_blocks), dim3(BI), 0, stream, n_blocks, BI, JS, T_cap, R_cap, n_owned, (const int32_t*)orig[cur].p, x_tidx, x_tcnt, x_nbr, x_rows,
                            (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr, counter.p, 0ull);
@@ -1442,7 +1439,6 @@ template <class T> class Engine final : public EngineBase {
             MHIP_HIP(hipStreamSynchronize(stream));
             di.release(); dj.release(); ds.release();
         }
-        counter.release();
         return (int64_t)n;
     }
 

@@ -1335,14 +1335,15 @@ __global__ void k_ke_partials(int64_t n, const typename Vec<T>::T4* __restrict__
     if (threadIdx.x == 0) { double a = 0; for (int q = 0; q < (int)(blockDim.x >> 6); ++q) a += sh[q]; part[blockIdx.x] = a; }
 }
 
-// one block: fixed-order sum of n doubles
+// fixed-order sum of n doubles per block: block c sums part[c·n .. (c+1)·n) into out[c] (component-major partial arrays)
 [[maybe_unused]] static __global__ void k_sum_double(int n, const double* __restrict__ part, double* out) {
     __shared__ double sh[256];
+    part += (size_t)blockIdx.x * n;
     double a = 0;
     for (int q = threadIdx.x; q < n; q += blockDim.x) a += part[q];
     sh[threadIdx.x] = a;
     __syncthreads();
-    if (threadIdx.x == 0) { double t = 0; for (int q = 0; q < (int)blockDim.x; ++q) t += sh[q]; *out = t; }
+    if (threadIdx.x == 0) { double t = 0; for (int q = 0; q < (int)blockDim.x; ++q) t += sh[q]; out[blockIdx.x] = t; }
 }
 
 template <class T>

@@ -507,7 +507,11 @@ template <class T> struct Pme {
         if (!(alpha > 0) || !(eps_r > 0)) throw ApiError{MHIP_ERR_INVALID, "PME needs alpha > 0 and eps_r > 0"};
         for (int d = 0; d < 3; ++d) {
             if (!periodic[d]) throw ApiError{MHIP_ERR_UNSUPPORTED, "PME needs a fully periodic box"};
-            if (mesh[d] < ord || mesh[d] > 4096) throw ApiError{MHIP_ERR_INVALID, "PME mesh size out of range (order .. 4096 per axis)"};
+            // the axis transforms are direct DFTs on LDS-staged lines (one output per thread, any length: the reference's meshes have
+            // factors like 23 and 17): O(n) work per mesh point and pass.  That is the right trade for 6mrr-class meshes (46x46x51: each
+            // pass sits at the launch floor) and the wrong one for the meshes of 100 nm boxes; past 512 points per axis the call is
+            // refused instead of quietly taking tens of milliseconds per step (an FFT library path is not linked).
+            if (mesh[d] < ord || mesh[d] > 512) throw ApiError{MHIP_ERR_UNSUPPORTED, "PME mesh size out of range: B-spline order .. 512 points per axis (direct-DFT transforms, sized for protein-box meshes)"};
         }
         if ((int64_t)mesh[0] * mesh[1] * mesh[2] > ((int64_t)1 << 28)) throw ApiError{MHIP_ERR_CAPACITY, "PME mesh too large"};
         order = ord;

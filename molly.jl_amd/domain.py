@@ -462,6 +462,9 @@ def bench_distributed(m, case, dtype, dt, args, rank, local_rank, world):
     if "MOLLYHIP_FORCE_DEVICE" in os.environ:
         local_rank = int(os.environ["MOLLYHIP_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
+    if world == 1:   # the N = 1 box driven through this loop (MOLLYHIP_FORCE_DOMAIN): a single-rank group needs no launcher
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29511")):
+            os.environ.setdefault(k, v)
     if not dist.is_initialized():
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

@@ -5,7 +5,7 @@
 # are collected without any sys/hip/hsa trace domain).  Raw output → gpurun_out/prof_<tag>/, the summary that
 # is committed → gpurun_out/prof_<tag>/summary.json (copy it to profiles/).
 set -u
-WL=${1:-lj1m}; TAG=${2:-r01_$WL}; STEPS=${3:-200}
+WL=${1:-lj1m}; TAG=${2:-r02_$WL}; STEPS=${3:-200}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"

@@ -12,8 +12,9 @@ from collections import defaultdict
 
 def short(name):
     m = re.search(r"k_forces<([^>]*)>", name)
-    if m:   # the PRUNE instantiation (last template flag) is a different kernel: it also writes the inner pair list
-        return "k_forces_prune" if m.group(1).split(",")[-1].strip() == "true" else "k_forces"
+    if m:   # the PRUNE instantiation (7th template argument; an 8th, the tile stride of the packed loop, may follow) is a different
+        args = [a.strip() for a in m.group(1).split(",")]      # kernel: it also writes the inner pair list
+        return "k_forces_prune" if len(args) > 6 and args[6] == "true" else "k_forces"
     m = re.search(r"k_pme_dft<([^>]*)>", name)
     if m:
         mode = m.group(1).split(",")[1].strip()
