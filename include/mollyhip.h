@@ -203,8 +203,9 @@ int32_t mhip_general_forces(mhip_ctx* ctx, int32_t accumulate, void* f_xyz, int3
 /* TriclinicBoundary(v1, v2, v3; approx_images) (spatial.jl:131-220; minimum image :528-551, wrap_coords :588-602): basis9 = the three
  * basis vectors row by row; v1 along x, v2 in the xy plane, v3.z > 0 (MHIP_ERR_INVALID otherwise, as the constructor's
  * ArgumentError).  The context must have been created with box = (v1.x, v2.y, v3.z), all axes periodic.  Call before mhip_set_state.
- * Restricted to what the reference's own GPU test covers and a little more (test/gpu_consistency.jl:287-337): single domain, no PME,
- * systems of at most 32 759 atoms — the whole system is one cell and every distance takes the exact in-loop minimum image.
+ * Single domain, no PME (MHIP_ERR_UNSUPPORTED otherwise).  The neighbour search runs on a cell grid in fractional coordinates scaled
+ * by the cell's perpendicular heights; a box too small for any grid (fewer than 6 cells of r_list / 2 on every axis) is handled as one
+ * cell — every distance by the exact in-loop minimum image — and is then limited to 32 759 atoms.
  * approx_images != 0: the three-floor formula; 0: the search over the 27 neighbouring images. */
 int32_t mhip_set_triclinic(mhip_ctx* ctx, const double* basis9, int32_t approx_images);
 /* E_recip + E_self + E_net-charge                                           (ewald.jl:898-928) */

@@ -46,6 +46,11 @@ template <class T> struct GridP {
     T bv[3][3];                // basis vectors (rows): a ∥ x, b in the xy plane
     T rs[3];                   // reciprocal_size = 1/a_x, 1/b_y, 1/c_z
     T cot_bc, cxz, cyz, cot_ab;   // wrap_coords constants (:192-210, 588-602)
+    // Cell grid of a triclinic box (tri_grid = 1): the cells live in u = s·h, fractional coordinates scaled by the perpendicular
+    // heights h of the cell.  u_d is the projection of x on the unit normal of face pair d, so |Δu_d| <= |Δx| on every axis: the grid,
+    // the bounding boxes and every pruning step work per axis in u (a Chebyshev test), distances are Cartesian.
+    int tri_grid;
+    T hgt[3];
 };
 
 // pairwise_inters in device-friendly form (constants rounded to T on the host exactly as the

@@ -159,6 +159,7 @@ template <class T> class Engine final : public EngineBase {
     // (until some atom moved ghost_margin/2), so the dual list works here too and the host re-plans only when mhip_plan_disp2_dev says so
     double ghost_margin = 0; const double* cm_ext = nullptr;
     int tri_mode = 0; double tri_bv[9] = {};   // TriclinicBoundary: 0 off, 1 approx_images, 2 exact images; basis vectors row-major
+    bool tri_grid = false;                     // … with a cell grid in height-scaled fractional coordinates (else: one cell, every block sees every atom)
     long long grid_key = -1;
     bool host_prune = false;     // ghost plans: the HOST decides, collectively over the ranks, when the inner list is re-pruned (mhip_request_prune)
     // single list, same idea: a rebuild step whose displacement check shows the list still covers every cutoff sphere is skipped
@@ -305,16 +306,38 @@ template <class T> class Engine final : public EngineBase {
         G.r_list = G.no_list ? std::numeric_limits<T>::infinity() : T(r_search);
         G.r_list2 = G.no_list ? std::numeric_limits<T>::infinity() : (dual ? G.r_list * G.r_list : r_in2);
         const int S = std::max(1, env_int("MOLLYHIP_STENCIL", 2));
-        for (int d = 0; d < 3; ++d) {
-            if (!(cfg.box[d] > 0) || std::isinf(cfg.box[d]) || std::isnan(cfg.box[d])) throw ApiError{MHIP_ERR_INVALID, "box side lengths must be positive and finite"};
-            G.L[d] = T(cfg.box[d]); G.invL[d] = T(1) / G.L[d]; G.origin[d] = cfg.periodic[d] ? T(0) : T(cfg.origin[d]); G.periodic[d] = cfg.periodic[d] ? 1 : 0;
-            int nc = 1;
-            if (!G.no_list && !tri_mode) { nc = (int)std::floor(cfg.box[d] / (r_search / S)); nc = std::max(1, std::min(nc, 1024)); }
-            G.nc[d] = nc; G.cs[d] = T(cfg.box[d] / nc); G.inv_cs[d] = T(nc / cfg.box[d]);
-            G.stencil[d] = S; G.all_cells[d] = (G.no_list || 2 * S + 1 >= nc) ? 1 : 0;
+        // extent of the cell grid per axis: the box side, or — TriclinicBoundary — the perpendicular height of the cell along that
+        // axis (the grid lives in u = s·h, common.h): h = V / |b × c|, V / |c × a|, V / |a × b| for the basis a ∥ x, b in the xy plane
+        double ext[3] = {cfg.box[0], cfg.box[1], cfg.box[2]};
+        if (tri_mode) {
+            const double* a = tri_bv; const double* b = tri_bv + 3; const double* c = tri_bv + 6;
+            const double V = a[0] * b[1] * c[2];
+            auto cross_norm = [](const double* u, const double* v) { const double x = u[1] * v[2] - u[2] * v[1], y = u[2] * v[0] - u[0] * v[2], z = u[0] * v[1] - u[1] * v[0]; return std::sqrt(x * x + y * y + z * z); };
+            ext[0] = V / cross_norm(b, c); ext[1] = V / cross_norm(c, a); ext[2] = V / cross_norm(a, b);
         }
+        tri_grid = false;
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int d = 0; d < 3; ++d) {
+                if (!(cfg.box[d] > 0) || std::isinf(cfg.box[d]) || std::isnan(cfg.box[d])) throw ApiError{MHIP_ERR_INVALID, "box side lengths must be positive and finite"};
+                G.L[d] = T(cfg.box[d]); G.invL[d] = T(1) / G.L[d]; G.origin[d] = cfg.periodic[d] ? T(0) : T(cfg.origin[d]); G.periodic[d] = cfg.periodic[d] ? 1 : 0;
+                int nc = 1;
+                if (!G.no_list && (!tri_mode || tri_grid)) { nc = (int)std::floor(ext[d] / (r_search / S)); nc = std::max(1, std::min(nc, 1024)); }
+                G.nc[d] = nc; G.cs[d] = T(ext[d] / nc); G.inv_cs[d] = T(nc / ext[d]);
+                G.stencil[d] = S; G.all_cells[d] = (G.no_list || 2 * S + 1 >= nc) ? 1 : 0;
+                G.hgt[d] = T(ext[d]);
+            }
+            // A triclinic box gets a real cell grid when at least one axis has more cells than a stencil spans (else every block would
+            // see every atom anyway: the one-cell form of round 1, all distances by the exact in-loop minimum image).
+            if (pass == 0 && tri_mode && !G.no_list && !env_int("MOLLYHIP_TRI_ONE_CELL", 0)) {
+                bool any = false;
+                for (int d = 0; d < 3; ++d) any = any || (int)std::floor(ext[d] / (r_search / S)) > 2 * S + 1;
+                if (any) { tri_grid = true; continue; }
+            }
+            break;
+        }
+        G.tri_grid = tri_grid ? 1 : 0;
         // keep the cell table small: coarsen until ncell <= 2^22
-        while ((int64_t)G.nc[0] * G.nc[1] * G.nc[2] > (1 << 22)) for (int d = 0; d < 3; ++d) { G.nc[d] = std::max(1, G.nc[d] / 2); G.cs[d] = T(cfg.box[d] / G.nc[d]); G.inv_cs[d] = T(G.nc[d] / cfg.box[d]); }
+        while ((int64_t)G.nc[0] * G.nc[1] * G.nc[2] > (1 << 22)) for (int d = 0; d < 3; ++d) { G.nc[d] = std::max(1, G.nc[d] / 2); G.cs[d] = T(ext[d] / G.nc[d]); G.inv_cs[d] = T(G.nc[d] / ext[d]); }
         G.ncell = G.nc[0] * G.nc[1] * G.nc[2];
         G.triclinic = tri_mode;
         if (tri_mode) {   // constants of TriclinicBoundary's constructor (spatial.jl:187-210), rounded to T as the struct stores them
@@ -364,14 +387,15 @@ template <class T> class Engine final : public EngineBase {
         double vol = 1; for (int d = 0; d < 3; ++d) vol *= cfg.box[d];
         double rho = (double)n_tot / vol;
         if (G.no_list) { T_cap = (int)n_tot + 8; R_cap = cdiv(n_tot, 4) + 2; C_cap = 8; }
-        else if (tri_mode) { T_cap = (int)n_tot + 8; R_cap = (int)std::min<double>(1.5 * rho * 4.0 / 3.0 * M_PI * std::pow(cfg.r_list, 3) / 4 / JS + 8, n_tot / 4.0 + 2); C_cap = 8; }
+        else if (tri_mode && !tri_grid) { T_cap = (int)n_tot + 8; R_cap = (int)std::min<double>(1.5 * rho * 4.0 / 3.0 * M_PI * std::pow(cfg.r_list, 3) / 4 / JS + 8, n_tot / 4.0 + 2); C_cap = 8; }
         else {
             double r = (cfg.r_list + (dual ? outer_margin : 0.0)) * 1.001, a = std::cbrt(BI / rho);
             double v_tile = a * a * a + 6 * a * a * r + 3 * M_PI * a * r * r + 4.0 / 3.0 * M_PI * r * r * r;
+            if (tri_grid) v_tile = (a + 2 * r) * (a + 2 * r) * (a + 2 * r) * 1.3;   // per-axis (Chebyshev) pruning in a skewed frame: a box, not a rounded one
             T_cap = (int)std::min<double>(1.4 * rho * v_tile + 64, (double)n_tot + 8);
             R_cap = (int)std::min<double>(1.5 * rho * 4.0 / 3.0 * M_PI * r * r * r / 4 / JS + 8, n_tot / 4.0 + 2);
             double cells = 1;
-            for (int d = 0; d < 3; ++d) cells *= std::min<double>(G.nc[d], (1.3 * a + 2 * r) / (cfg.box[d] / G.nc[d]) + 2);
+            for (int d = 0; d < 3; ++d) cells *= std::min<double>(G.nc[d], (1.3 * a + 2 * r) / (double)G.cs[d] + 2);
             C_cap = (int)std::min<double>(cells * 1.2 + 8, MAX_BOX_CELLS);
         }
         T_cap = std::max(T_cap, 16); R_cap = std::max(R_cap, 2); C_cap = std::max(C_cap, 8);
@@ -435,12 +459,13 @@ template <class T> class Engine final : public EngineBase {
         prof.end(3, stream);
         cur = n;
         if (n_ghost > 0 && has_exc) throw ApiError{MHIP_ERR_UNSUPPORTED, "exclusion lists with ghost atoms are not supported"};
+        if (tri_mode && !tri_grid && n_tot + 8 > TILE_SLOT_MAX) throw ApiError{MHIP_ERR_UNSUPPORTED, "a TriclinicBoundary whose cell heights allow no cell grid (fewer than 6 cells of r_list/2 on every axis) is limited to 32 759 atoms"};
 
         for (int attempt = 0; attempt < 12; ++attempt) {
             n_blocks = cdiv(n_owned, BI);
-            bool walk = env_int("MOLLYHIP_BUILD_WALK", 1) && !G.no_list && !tri_mode;
+            bool walk = (env_int("MOLLYHIP_BUILD_WALK", 1) || tri_grid) && !G.no_list && (!tri_mode || tri_grid);
             size_t lds = build_lds_bytes(T_cap, BI, C_cap, walk);
-            if (walk && lds > (size_t)MAX_LDS_BYTES) { walk = false; lds = build_lds_bytes(T_cap, BI, C_cap, false); }   // no room for the cell offsets: transposed search
+            if (walk && !tri_grid && lds > (size_t)MAX_LDS_BYTES) { walk = false; lds = build_lds_bytes(T_cap, BI, C_cap, false); }   // no room for the cell offsets: transposed search (its box tests are Cartesian: not on a triclinic grid)
             if (lds > (size_t)MAX_LDS_BYTES) {
                 if (BI > 64) { BI /= 2; JS = std::min(JS * 2, MAX_THREADS / BI); estimate_capacities(); continue; }
                 throw ApiError{MHIP_ERR_CAPACITY, "neighbourhood tile of one 64-atom block does not fit the 160 KiB LDS (r_list too large for this density): T_cap " + std::to_string(T_cap) +
@@ -1066,7 +1091,6 @@ template <class T> class Engine final : public EngineBase {
         if (!(bv9[8] > 0)) throw ApiError{MHIP_ERR_INVALID, "third basis vector must have a positive z component"};
         for (int d = 0; d < 3; ++d) if (!cfg.periodic[d]) throw ApiError{MHIP_ERR_UNSUPPORTED, "TriclinicBoundary is periodic on all three axes"};
         if (n_ghost > 0 || pme.on()) throw ApiError{MHIP_ERR_UNSUPPORTED, "TriclinicBoundary: single domain, no PME"};
-        if (cfg.n_atoms + 8 > TILE_SLOT_MAX) throw ApiError{MHIP_ERR_UNSUPPORTED, "TriclinicBoundary is limited to systems that fit one tile (32 759 atoms)"};
         if (std::fabs(bv9[0] - cfg.box[0]) > 1e-12 * bv9[0] || std::fabs(bv9[4] - cfg.box[1]) > 1e-12 * bv9[4] || std::fabs(bv9[8] - cfg.box[2]) > 1e-12 * bv9[8])
             throw ApiError{MHIP_ERR_INVALID, "the context's box must be (v1.x, v2.y, v3.z) of the triclinic basis"};
         MHIP_HIP(hipStreamSynchronize(stream));

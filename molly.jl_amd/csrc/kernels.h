@@ -54,6 +54,25 @@ template <class T> __device__ inline T wave_max(T v) {
     return v;
 }
 
+// triclinic boxes: fractional coordinates of the upper-triangular basis (a ∥ x, b in the xy plane) and their height-scaled form u
+template <class T> __device__ inline void frac_coords(T x, T y, T z, const GridP<T>& G, T s[3]) {
+    s[2] = z * G.rs[2]; s[1] = (y - s[2] * G.bv[2][1]) * G.rs[1]; s[0] = (x - s[1] * G.bv[1][0] - s[2] * G.bv[2][0]) * G.rs[0];
+}
+// cell of a stored (wrapped) coordinate on the search grid, all three axes
+template <class T> __device__ inline void cell_coords(T x, T y, T z, const GridP<T>& G, int c[3]) {
+    if (G.tri_grid) {
+        T s[3]; frac_coords(x, y, z, G, s);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { int q = (int)M<T>::floor(s[d] * G.hgt[d] * G.inv_cs[d]); c[d] = min(max(q, 0), G.nc[d] - 1); }
+    } else { c[0] = cell_coord(x, 0, G); c[1] = cell_coord(y, 1, G); c[2] = cell_coord(z, 2, G); }
+}
+// Coordinates of a stored position relative to a block centre, nearest periodic image.  Cubic: ctr = the centre itself.  Triclinic
+// grid: ctr = the centre's FRACTIONAL coordinates; the image is resolved in fractional space (rint per axis), the result is
+// Cartesian.  For two atoms localised against the same centre the difference of the results is their true separation for that
+// pair of images, and whenever it is shorter than half the smallest cell height it is the minimum image (any other image differs by
+// a lattice vector, whose projection on some face normal is at least that height).
+template <class T, class V4> __device__ inline void local_xyz(T& x, T& y, T& z, const V4& ctr, const GridP<T>& G);
+
 // x − c on a periodic axis, nearest image, for x and c wrapped into [0, L] (the image is then at k ∈ {−1, 0, +1} box lengths).  The two
 // LARGE numbers are subtracted first — (L − c) when c is the one near L, (x − L) when x is: both differences are exact (Sterbenz) —
 // so the result carries the rounding of a small number, not the ulp of L: 3.8e-6 nm in a 36 nm fp32 box, which is 7e-5 of the force
@@ -65,6 +84,31 @@ template <class T> __device__ inline T local_coord(T x, T c, T L, T invL) {
     else if (k == T(1)) t = (x - L) - c;
     else if (k != T(0)) t -= L * k;
     return t;
+}
+
+template <class T, class V4> __device__ inline void local_xyz(T& x, T& y, T& z, const V4& ctr, const GridP<T>& G) {
+    if (G.tri_grid) {
+        T s[3]; frac_coords(x, y, z, G, s);
+        T d0 = s[0] - ctr.x, d1 = s[1] - ctr.y, d2 = s[2] - ctr.z;
+        d0 -= M<T>::rint(d0); d1 -= M<T>::rint(d1); d2 -= M<T>::rint(d2);
+        x = d0 * G.bv[0][0] + d1 * G.bv[1][0] + d2 * G.bv[2][0]; y = d1 * G.bv[1][1] + d2 * G.bv[2][1]; z = d2 * G.bv[2][2];
+    } else {
+        x = G.periodic[0] ? local_coord(x, (T)ctr.x, G.L[0], G.invL[0]) : x - ctr.x;
+        y = G.periodic[1] ? local_coord(y, (T)ctr.y, G.L[1], G.invL[1]) : y - ctr.y;
+        z = G.periodic[2] ? local_coord(z, (T)ctr.z, G.L[2], G.invL[2]) : z - ctr.z;
+    }
+}
+// nearest-image displacement between two stored positions of the SAME atom (displacement checks: small vectors)
+template <class T> __device__ inline void disp_image(T& ex, T& ey, T& ez, const GridP<T>& G) {
+    if (G.triclinic) {
+        T s[3]; frac_coords(ex, ey, ez, G, s);
+        s[0] -= M<T>::rint(s[0]); s[1] -= M<T>::rint(s[1]); s[2] -= M<T>::rint(s[2]);
+        ex = s[0] * G.bv[0][0] + s[1] * G.bv[1][0] + s[2] * G.bv[2][0]; ey = s[1] * G.bv[1][1] + s[2] * G.bv[2][1]; ez = s[2] * G.bv[2][2];
+    } else {
+        if (G.periodic[0]) ex -= G.L[0] * M<T>::rint(ex * G.invL[0]);
+        if (G.periodic[1]) ey -= G.L[1] * M<T>::rint(ey * G.invL[1]);
+        if (G.periodic[2]) ez -= G.L[2] * M<T>::rint(ez * G.invL[2]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -128,8 +172,8 @@ __global__ void k_cell_keys(int64_t n_tot, int64_t n_owned, const typename Vec<T
     if (o >= n_tot) return;
     int s = inv[o];
     auto p = pos[s];
-    int cx = cell_coord(p.x, 0, G), cy = cell_coord(p.y, 1, G), cz = cell_coord(p.z, 2, G);
-    uint32_t k = cell_rank[(cz * G.nc[1] + cy) * G.nc[0] + cx];
+    int cc[3]; cell_coords(p.x, p.y, p.z, G, cc);
+    uint32_t k = cell_rank[(cc[2] * G.nc[1] + cc[1]) * G.nc[0] + cc[0]];
     if (o >= n_owned) k += (uint32_t)G.ncell;
     key[o] = k; idx[o] = s;
     atomicAdd(&cell_cnt[k], 1);
@@ -233,8 +277,10 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
     const bool valid = si < A.n_owned;
     T4 pi = A.pos[valid ? si : (int64_t)b * A.BI];            // a block is never empty
     T my[3] = {pi.x, pi.y, pi.z};
+    T mu[3] = {pi.x, pi.y, pi.z};                             // the same point in the frame of the cell grid (triclinic: u = s·h)
+    if (G.tri_grid) { T sf[3]; frac_coords(my[0], my[1], my[2], G, sf); mu[0] = sf[0] * G.hgt[0]; mu[1] = sf[1] * G.hgt[1]; mu[2] = sf[2] * G.hgt[2]; }
     {
-        T mn[3] = {my[0], my[1], my[2]}, mx[3] = {my[0], my[1], my[2]};
+        T mn[3] = {mu[0], mu[1], mu[2]}, mx[3] = {mu[0], mu[1], mu[2]};
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
@@ -260,7 +306,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
                     if (len >= G.nc[d]) { cl = 0; len = G.nc[d]; s_full[d] = 1; }
                     s_boxlo[d] = cl; s_boxlen[d] = len;
                     // block-local coordinates are unambiguous only if block half-extent + reach (+ drift) < L/2
-                    if (s_full[d] || !(half + reach * T(1.25) < G.L[d] * T(0.5))) exact = 1;
+                    if (s_full[d] || !(half + reach * T(1.25) < (G.tri_grid ? G.hgt[d] : G.L[d]) * T(0.5))) exact = 1;
                 } else {
                     cl = max(cl, 0); ch = min(ch, G.nc[d] - 1);
                     s_boxlo[d] = cl; s_boxlen[d] = max(ch - cl + 1, 1);
@@ -271,7 +317,9 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
         if (ovf) atomicOr(&A.flags[FLAG_OVERFLOW], ovf);
         if (exact) atomicOr(&A.flags[FLAG_MINIMG], 1);
         s_exact = exact;
-        A.blk_center[b] = make4<T>(s_ctr[0], s_ctr[1], s_ctr[2], T(0));
+        // what the pair kernel localises against: the centre itself, or (triclinic grid) its fractional coordinates
+        if (G.tri_grid) A.blk_center[b] = make4<T>(s_ctr[0] / G.hgt[0], s_ctr[1] / G.hgt[1], s_ctr[2] / G.hgt[2], T(0));
+        else A.blk_center[b] = make4<T>(s_ctr[0], s_ctr[1], s_ctr[2], T(0));
     }
     __syncthreads();
     if (A.debug == 1) return;
@@ -282,12 +330,24 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
     const T reach = G.no_list ? G.r_list : G.r_list + A.margin;
     const T reach2 = G.no_list ? G.r_list2 : reach * reach;
 
-    auto localise = [&](T x, int d) -> T {   // coordinate relative to the block centre, nearest periodic image
-        T t = x - ctr[d];
-        if (G.periodic[d]) t -= G.L[d] * M<T>::rint(t * G.invL[d]);
-        return t;
+    // a stored position → loc: Cartesian coordinates relative to the block centre, nearest periodic image (the tile, the search);
+    // ub: the same point in the frame of the wave boxes, relative to the centre (cubic: the same numbers; triclinic grid: u)
+    const T cfrac[3] = {G.tri_grid ? ctr[0] / G.hgt[0] : T(0), G.tri_grid ? ctr[1] / G.hgt[1] : T(0), G.tri_grid ? ctr[2] / G.hgt[2] : T(0)};
+    auto localise3 = [&](T x, T y, T z, T loc[3], T ub[3]) {
+        if (G.tri_grid) {
+            T sf[3], fd[3]; frac_coords(x, y, z, G, sf);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { T t = sf[d] - cfrac[d]; t -= M<T>::rint(t); fd[d] = t; ub[d] = t * G.hgt[d]; }
+            loc[0] = fd[0] * G.bv[0][0] + fd[1] * G.bv[1][0] + fd[2] * G.bv[2][0]; loc[1] = fd[1] * G.bv[1][1] + fd[2] * G.bv[2][1]; loc[2] = fd[2] * G.bv[2][2];
+        } else {
+            const T xyz[3] = {x, y, z};
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { T t = xyz[d] - ctr[d]; if (G.periodic[d]) t -= G.L[d] * M<T>::rint(t * G.invL[d]); loc[d] = t; ub[d] = t; }
+        }
     };
-    // squared distance from a local point to the nearest per-wave bounding box ("full" axes never prune)
+    // squared distance from a point (frame of the boxes) to the nearest per-wave bounding box ("full" axes never prune).  On a triclinic
+    // grid the axes of that frame are not orthogonal: each |Δu_d| is a lower bound of the distance on its own, so the test is the
+    // LARGEST per-axis gap (Chebyshev), not their Euclidean sum.
     auto sub_dist2 = [&](T lx_, T ly_, T lz_) -> T {
         T best = T(3.0e38);
         T pc[3] = {lx_, ly_, lz_};
@@ -298,7 +358,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
                 if (s_full[d]) continue;
                 T lo = s_sub[w][d] - ctr[d], hi = s_sub[w][3 + d] - ctr[d];
                 T e = lo - pc[d]; T f = pc[d] - hi; e = e > f ? e : f; e = e > T(0) ? e : T(0);
-                acc += e * e;
+                acc = G.tri_grid ? (e * e > acc ? e * e : acc) : acc + e * e;
             }
             best = acc < best ? acc : best;
         }
@@ -318,7 +378,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
                 if (s_full[d]) continue;
                 T clo = (G.periodic[d] ? T(0) : G.origin[d]) + T(g[d]) * G.cs[d], chi = clo + G.cs[d];
                 T e = s_sub[w][d] - chi; T f = clo - s_sub[w][3 + d]; e = e > f ? e : f; e = e > T(0) ? e : T(0);
-                acc += e * e;
+                acc = G.tri_grid ? (e * e > acc ? e * e : acc) : acc + e * e;
             }
             best = acc < best ? acc : best;
         }
@@ -348,10 +408,10 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
             int own = A.cell_start[r + 1] - A.cell_start[r];
             s = k < own ? A.cell_start[r] + k : A.cell_start[G.ncell + r] + (k - own);
             p = A.pos[s];
-            T l0 = localise(p.x, 0), l1 = localise(p.y, 1), l2 = localise(p.z, 2);
+            T loc[3], ub[3]; localise3(p.x, p.y, p.z, loc, ub);
             // exact_only blocks (small boxes): images are ambiguous, keep the whole cell-pruned set
-            keep = exact_only ? true : sub_dist2(l0, l1, l2) <= reach2;
-            p.x = l0; p.y = l1; p.z = l2;
+            keep = exact_only ? true : sub_dist2(ub[0], ub[1], ub[2]) <= reach2;
+            p.x = loc[0]; p.y = loc[1]; p.z = loc[2];
         }
         unsigned long long m = __ballot(keep);
         if (lane == 0) s_wtot[wv_all] = __popcll(m);
@@ -406,7 +466,8 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
             if (js == 0) for (int k = 0; k < min(nxl, A.X_cap); ++k) x_part[k * A.BI + li] = A.xl_list[xl0 + k];
         }
         if (A.xl_start) __syncthreads();
-        const float ml[3] = {(float)localise(my[0], 0), (float)localise(my[1], 1), (float)localise(my[2], 2)};
+        T my_loc[3], my_ub[3]; localise3(my[0], my[1], my[2], my_loc, my_ub);
+        const float ml[3] = {(float)my_loc[0], (float)my_loc[1], (float)my_loc[2]};
         const float rl2 = G.no_list ? 3.0e38f : (float)G.r_list2;
         const float band_lo = rl2 * (1.0f - 1e-4f), band_hi = G.no_list ? 3.0e38f : rl2 * (1.0f + 1e-4f);
         const float reach2f = G.no_list ? 3.0e38f : (float)reach2;
@@ -424,10 +485,11 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
         //     Periodic axes never wrap inside a block's cell box here: a box that spans a whole periodic axis is an exact_only block.
         if (WALK && !exact_only) {
             if (valid) {
-                int qc[3], lo[3], hi[3];
+                int qc[3], lo[3], hi[3], mycell[3];
+                cell_coords(my[0], my[1], my[2], G, mycell);
 #pragma unroll
                 for (int d = 0; d < 3; ++d) {
-                    int q = cell_coord(my[d], d, G) - s_boxlo[d];
+                    int q = mycell[d] - s_boxlo[d];
                     if (G.periodic[d]) { if (q < 0) q += G.nc[d]; else if (q >= G.nc[d]) q -= G.nc[d]; }
                     qc[d] = q; lo[d] = max(q - G.stencil[d], 0); hi[d] = min(q + G.stencil[d], s_boxlen[d] - 1);
                 }
@@ -616,9 +678,7 @@ __global__ void k_max_disp(int64_t n, const typename Vec<T>::T4* __restrict__ po
     for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
         auto p = pos[s]; auto q = snap[s];
         T ex = p.x - q.x, ey = p.y - q.y, ez = p.z - q.z;
-        if (G.periodic[0]) ex -= G.L[0] * M<T>::rint(ex * G.invL[0]);
-        if (G.periodic[1]) ey -= G.L[1] * M<T>::rint(ey * G.invL[1]);
-        if (G.periodic[2]) ez -= G.L[2] * M<T>::rint(ez * G.invL[2]);
+        disp_image(ex, ey, ez, G);
         d2 = fmaxf(d2, (float)(ex * ex + ey * ey + ez * ez));
         if (vel && s < n_vel) { auto v = vel[s]; v2 = fmaxf(v2, (float)(v.x * v.x + v.y * v.y + v.z * v.z)); }
     }
@@ -675,11 +735,8 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_filter(FilterAr
     const T4 ctr = A.blk_center[b];
     const bool use_lds = !A.exact_all && tile_n <= A.T_lds;
     auto localise = [&](T4 p) -> float4 {
-        T x = p.x - ctr.x, y = p.y - ctr.y, z = p.z - ctr.z;
-        if (G.periodic[0]) x -= G.L[0] * M<T>::rint(x * G.invL[0]);
-        if (G.periodic[1]) y -= G.L[1] * M<T>::rint(y * G.invL[1]);
-        if (G.periodic[2]) z -= G.L[2] * M<T>::rint(z * G.invL[2]);
-        return make_float4((float)x, (float)y, (float)z, 0.f);
+        local_xyz(p.x, p.y, p.z, ctr, G);
+        return make_float4((float)p.x, (float)p.y, (float)p.z, 0.f);
     };
     const int32_t* tix = A.tile_idx + (int64_t)b * A.T_cap;
     if (use_lds) for (int t = tid; t < tile_n; t += nthr) l_pos[t] = localise(A.pos[tix[t]]);
@@ -696,9 +753,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_filter(FilterAr
         if (valid && js == 0) {
             T4 q = A.pos_snap[si];
             T dx = pi.x - q.x, dy = pi.y - q.y, dz = pi.z - q.z;
-            if (G.periodic[0]) dx -= G.L[0] * M<T>::rint(dx * G.invL[0]);
-            if (G.periodic[1]) dy -= G.L[1] * M<T>::rint(dy * G.invL[1]);
-            if (G.periodic[2]) dz -= G.L[2] * M<T>::rint(dz * G.invL[2]);
+            disp_image(dx, dy, dz, G);
             d2 = (float)(dx * dx + dy * dy + dz * dz);
         }
         d2 = wave_max(d2);
@@ -847,11 +902,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_forces(ForceArg
     const T4 ctr = A.blk_center[b];
 
     auto localise = [&](T4 p) -> T4 {
-        if constexpr (!MINIMG) {
-            p.x = G.periodic[0] ? local_coord(p.x, ctr.x, G.L[0], G.invL[0]) : p.x - ctr.x;
-            p.y = G.periodic[1] ? local_coord(p.y, ctr.y, G.L[1], G.invL[1]) : p.y - ctr.y;
-            p.z = G.periodic[2] ? local_coord(p.z, ctr.z, G.L[2], G.invL[2]) : p.z - ctr.z;
-        }
+        if constexpr (!MINIMG) local_xyz(p.x, p.y, p.z, ctr, G);
         return p;
     };
     const int li = tid & (A.BI - 1), js = tid >> A.BI_shift;
@@ -1009,9 +1060,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_forces(ForceArg
         if (valid && js == 0) {
             T4 q = A.pos_snap[si], p0 = A.pos[si];
             T ex = p0.x - q.x, ey = p0.y - q.y, ez = p0.z - q.z;
-            if (G.periodic[0]) ex -= G.L[0] * M<T>::rint(ex * G.invL[0]);
-            if (G.periodic[1]) ey -= G.L[1] * M<T>::rint(ey * G.invL[1]);
-            if (G.periodic[2]) ez -= G.L[2] * M<T>::rint(ez * G.invL[2]);
+            disp_image(ex, ey, ez, G);
             d2 = (float)(ex * ex + ey * ey + ez * ez);
         }
         d2 = wave_max(d2);

@@ -100,6 +100,62 @@ def test_triclinic_neighbour_list_of_1000_atoms_is_the_brute_force_set(pkg, dtyp
     assert all(np.array_equal(u, v) for u, v in zip(S.sorted_pairs(got.i, got.j, got.special), S.sorted_pairs(*ref)))
 
 
+def sheared_fluid(dtype, n_side=20, seed=17):
+    """n_side³ argon-like atoms on a jittered lattice in the fractional coordinates of a sheared cell whose perpendicular heights
+    (≈ 7 nm at 8000 atoms) hold 11 cells of r_list / 2 on every axis and leave every 64-atom block's neighbourhood well inside half a
+    height: the cell-grid form of the triclinic search with block-local coordinates, not the one-cell form"""
+    rng = np.random.default_rng(seed)
+    g = np.stack(np.meshgrid(*[np.arange(n_side)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float64)
+    basis = np.array([[6.0, 0.0, 0.0], [1.3, 5.8, 0.0], [-0.9, 1.5, 5.6]]) * (n_side / 16.0)
+    x = (((g + 0.5) / n_side + rng.uniform(-0.008, 0.008, g.shape)) @ basis).astype(dtype).astype(np.float64)
+    n = len(x)
+    v = (rng.normal(size=(n, 3)) * 0.13).astype(dtype).astype(np.float64)
+    v -= v.mean(axis=0)
+    return basis, S.Case(x, np.diag(basis), lj=dict(cutoff=("distance", 1.0)), r_list=1.2, rebuild_every=10, velocities=v, sigma=np.full(n, 0.34),
+                         eps=np.full(n, 0.997), mass=np.full(n, 39.948), triclinic=dict(basis=basis), name=f"tri_fluid{n}")
+
+
+@pytest.mark.parametrize("approx", [True, False])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_triclinic_cell_grid_list_and_forces(pkg, dtype, approx):
+    """a triclinic box large enough for a cell grid (spatial.jl:528-551 for the images, neighbors.jl:390-423 for the predicate): the
+    pair set equals the brute-force set of the same precision, forces and energy match the fp64 oracle, and the blocks really saw
+    only their neighbourhood (tiles smaller than the system, block-local coordinates instead of the in-loop minimum image)"""
+    basis, case = sheared_fluid(dtype)
+    case.triclinic["approx_images"] = approx
+    ref = case.oracle(dtype).neighbors("brute", nthreads=8)
+    s = case.system(pkg, dtype)
+    got = pkg.find_neighbors(s)
+    assert got.n == len(ref[0])
+    assert all(np.array_equal(u, v) for u, v in zip(S.sorted_pairs(got.i, got.j, got.special), S.sorted_pairs(*ref)))
+    st = s.stats()
+    assert st["minimg_mode"] == 0 and st["max_tile_atoms"] < 3 * case.n // 4, st
+    o = case.oracle(np.float64)
+    nl = o.neighbors("brute", nthreads=8)
+    f_ref, e_ref = o.forces(nl, nthreads=4), o.potential_energy(nl)
+    f = pkg.forces(s).astype(np.float64)
+    if dtype == np.float64:
+        assert np.abs(f - f_ref).max() < 1e-8 * np.abs(f_ref).max()
+        assert pkg.potential_energy(s) == pytest.approx(e_ref, rel=1e-10)
+    else:
+        scale, _ = o.force_scale(nl)
+        assert np.all(np.linalg.norm(f - f_ref, axis=1) <= 6e-5 * scale + 1e-4)
+        assert pkg.potential_energy(s) == pytest.approx(e_ref, rel=3e-5)
+
+
+def test_triclinic_cell_grid_trajectory(pkg):
+    """60 velocity-Verlet steps (six list rebuilds, atoms crossing every face) of the sheared fluid against the oracle, fp64"""
+    basis, case = sheared_fluid(np.float64, n_side=20)
+    o = case.oracle(np.float64)
+    o.vv_run(60, 0.002, remove_cm_every=1, nthreads=8)
+    s = case.system(pkg, np.float64)
+    pkg.simulate(s, pkg.VelocityVerlet(dt=0.002), 60)
+    d = np.linalg.solve(basis.T, (s.coords - o.coords).T).T
+    d -= np.round(d)
+    assert np.abs(d @ basis).max() < 1e-9 and np.abs(s.velocities - o.vel).max() < 1e-8
+    assert s.stats()["minimg_mode"] == 0
+
+
 def test_triclinic_bonded_terms(pkg):
     """bonds and angles across the faces of the cell take the same minimum image (force.jl:991-1060 with vector(…, boundary))"""
     case = tri_case(48, np.float64, True, seed=8, spread=1.9)
