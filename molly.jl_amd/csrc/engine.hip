@@ -579,7 +579,7 @@ template <class T> class Engine final : public EngineBase {
     float max_disp2_since(const DBuf<T4>& snap) {
         tr("k_max_disp");
         MHIP_HIP(hipMemsetAsync(flags.p + FLAG_MAX_DISP2, 0, 2 * sizeof(int32_t), stream));
-        hipLaunchKernelGGL(k_max_disp<T>, dim3(std::min(cdiv(n_tot, 256), 1024)), dim3(256), 0, stream, n_tot, (const T4*)pos[cur].p, (const T4*)snap.p,
+        hipLaunchKernelGGL(k_max_disp<T>, dim3(std::min(cdiv(n_tot, 1024), 512)), dim3(1024), 0, stream, n_tot, (const T4*)pos[cur].p, (const T4*)snap.p,   // (every block ends in two atomics on the same two words: 4096 blocks of 256 lanes took 94 us at 1M atoms, 1024 blocks 30 us)
                            reinterpret_cast<unsigned int*>(flags.p + FLAG_MAX_DISP2), G, (const T4*)vel[cur].p, n_owned, reinterpret_cast<unsigned int*>(flags.p + FLAG_MAX_V2));
         MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         MHIP_HIP(hipStreamSynchronize(stream));
@@ -892,7 +892,7 @@ template <class T> class Engine final : public EngineBase {
         MHIP_HIP(hipStreamSynchronize(stream));
         // one atom type (every σ, ϵ equal and non-zero, no λ = 0) + DistanceCutoff → uniform-LJ kernel variant
         ljm = ljm_base;
-        if (ljm_base == LJ_DIST && ds && de && !(env_int("MOLLYHIP_NO_UNIFORM_LJ", 0))) {
+        if (ljm_base == LJ_DIST && ds && de && !tri_mode && !(env_int("MOLLYHIP_NO_UNIFORM_LJ", 0))) {   // (the one-type kernels know cubic boxes only)
             // decided on the device (a sub-domain hands its parameters over at every re-plan): flag ≠ 0 if some σ, ϵ differs from atom 0's or a λ is 0
             MHIP_HIP(hipMemsetAsync(flags.p, 0, N_FLAGS * sizeof(int32_t), stream));
             hipLaunchKernelGGL(k_uniform_check<T>, dim3(std::min(cdiv(n_tot, 256), 1024)), dim3(256), 0, stream, n_tot, ds, de, dl, flags.p);
@@ -1096,6 +1096,7 @@ template <class T> class Engine final : public EngineBase {
         MHIP_HIP(hipStreamSynchronize(stream));
         std::memcpy(tri_bv, bv9, sizeof(tri_bv));
         tri_mode = approx_images ? 1 : 2;
+        ljm = ljm_base;                          // the one-type LJ kernels are cubic-only
         setup_grid(); choose_blocking();
         stale = true; frc_valid = false; state_set = false;
     }

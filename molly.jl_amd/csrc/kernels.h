@@ -71,6 +71,7 @@ template <class T> __device__ inline void cell_coords(T x, T y, T z, const GridP
 // Cartesian.  For two atoms localised against the same centre the difference of the results is their true separation for that
 // pair of images, and whenever it is shorter than half the smallest cell height it is the minimum image (any other image differs by
 // a lattice vector, whose projection on some face normal is at least that height).
+template <bool TRI, class T, class V4> __device__ inline void local_xyz_t(T& x, T& y, T& z, const V4& ctr, const GridP<T>& G);
 template <class T, class V4> __device__ inline void local_xyz(T& x, T& y, T& z, const V4& ctr, const GridP<T>& G);
 
 // x − c on a periodic axis, nearest image, for x and c wrapped into [0, L] (the image is then at k ∈ {−1, 0, +1} box lengths).  The two
@@ -86,8 +87,10 @@ template <class T> __device__ inline T local_coord(T x, T c, T L, T invL) {
     return t;
 }
 
-template <class T, class V4> __device__ inline void local_xyz(T& x, T& y, T& z, const V4& ctr, const GridP<T>& G) {
-    if (G.tri_grid) {
+// (TRI is a template argument where the call sits in a hot staging loop: with the branch inside the loop the pair kernel of the
+// cubic 1M-atom fluid ran 12 % slower, 0.105 against 0.093 ms per pass)
+template <bool TRI, class T, class V4> __device__ inline void local_xyz_t(T& x, T& y, T& z, const V4& ctr, const GridP<T>& G) {
+    if constexpr (TRI) {
         T s[3]; frac_coords(x, y, z, G, s);
         T d0 = s[0] - ctr.x, d1 = s[1] - ctr.y, d2 = s[2] - ctr.z;
         d0 -= M<T>::rint(d0); d1 -= M<T>::rint(d1); d2 -= M<T>::rint(d2);
@@ -97,6 +100,9 @@ template <class T, class V4> __device__ inline void local_xyz(T& x, T& y, T& z, 
         y = G.periodic[1] ? local_coord(y, (T)ctr.y, G.L[1], G.invL[1]) : y - ctr.y;
         z = G.periodic[2] ? local_coord(z, (T)ctr.z, G.L[2], G.invL[2]) : z - ctr.z;
     }
+}
+template <class T, class V4> __device__ inline void local_xyz(T& x, T& y, T& z, const V4& ctr, const GridP<T>& G) {
+    if (G.tri_grid) local_xyz_t<true>(x, y, z, ctr, G); else local_xyz_t<false>(x, y, z, ctr, G);
 }
 // nearest-image displacement between two stored positions of the SAME atom (displacement checks: small vectors)
 template <class T> __device__ inline void disp_image(T& ex, T& ey, T& ez, const GridP<T>& G) {
@@ -683,7 +689,7 @@ __global__ void k_max_disp(int64_t n, const typename Vec<T>::T4* __restrict__ po
         if (vel && s < n_vel) { auto v = vel[s]; v2 = fmaxf(v2, (float)(v.x * v.x + v.y * v.y + v.z * v.z)); }
     }
     d2 = wave_max(d2); v2 = wave_max(v2);
-    __shared__ float sh[4], shv[4];
+    __shared__ float sh[16], shv[16];   // (up to 1024 lanes per block: few blocks, few atomics on the two result words)
     if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = d2; shv[threadIdx.x >> 6] = v2; }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -901,14 +907,20 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_forces(ForceArg
     T2* l_lj = reinterpret_cast<T2*>(l_pos + (A.T_lds + 1));
     const T4 ctr = A.blk_center[b];
 
-    auto localise = [&](T4 p) -> T4 {
-        if constexpr (!MINIMG) local_xyz(p.x, p.y, p.z, ctr, G);
+    auto localise = [&](T4 p, auto tri_tag) -> T4 {
+        if constexpr (!MINIMG) local_xyz_t<decltype(tri_tag)::value>(p.x, p.y, p.z, ctr, G);
         return p;
     };
+    // (the fp32 one-type kernels are kept free of the triclinic path — its mere presence cost them 12 % per pass at 1M atoms — and the
+    // engine does not select them for a TriclinicBoundary)
+    constexpr bool NO_TRI = std::is_same<T, float>::value && LJM == LJ_DIST_UNIFORM && COULM == MHIP_COUL_NONE && !ENERGY;
+    const bool tri_local = !MINIMG && !NO_TRI && G.tri_grid;
     const int li = tid & (A.BI - 1), js = tid >> A.BI_shift;
     const int64_t si = (int64_t)b * A.BI + li;
     const bool valid = si < A.n_owned;
-    T4 pi = localise(A.pos[valid ? si : (int64_t)b * A.BI]);
+    T4 pi = A.pos[valid ? si : (int64_t)b * A.BI];
+    if constexpr (NO_TRI) pi = localise(pi, std::false_type{});
+    else pi = tri_local ? localise(pi, std::true_type{}) : localise(pi, std::false_type{});
     T2 lji = make2<T>(T(0), T(0));
     if constexpr (PER_ATOM_LJ) lji = A.lj[valid ? si : (int64_t)b * A.BI];
     const int rows = A.wave_rows[(b * A.JS + js) * (A.BI >> 6) + (li >> 6)];               // this wave's own sub-list: the
@@ -949,13 +961,17 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_forces(ForceArg
         constexpr bool FAST_CT = std::is_same<T, float>::value && LJM == LJ_DIST_UNIFORM && COULM == MHIP_COUL_NONE && !ENERGY && !MINIMG && !SEG;
         const bool packed3 = FAST_CT && !A.any_special && A.soa == SOA_STRIDE;
         float* l_p3 = reinterpret_cast<float*>(smem);
-        for (int t = tid; t < n_here; t += nthr) {
-            int s = tix[seg_lo + t];
-            const T4 pl = localise(A.pos[s]);
-            if (packed3) { l_p3[t] = (float)pl.x; l_p3[SOA_STRIDE + t] = (float)pl.y; l_p3[2 * SOA_STRIDE + t] = (float)pl.z; }
-            else l_pos[t] = pl;
-            if constexpr (PER_ATOM_LJ) l_lj[t] = A.lj[s];
-        }
+        auto stage = [&](auto tri_tag) {
+            for (int t = tid; t < n_here; t += nthr) {
+                int s = tix[seg_lo + t];
+                const T4 pl = localise(A.pos[s], tri_tag);
+                if (packed3) { l_p3[t] = (float)pl.x; l_p3[SOA_STRIDE + t] = (float)pl.y; l_p3[2 * SOA_STRIDE + t] = (float)pl.z; }
+                else l_pos[t] = pl;
+                if constexpr (PER_ATOM_LJ) l_lj[t] = A.lj[s];
+            }
+        };
+        if constexpr (NO_TRI) stage(std::false_type{});
+        else { if (tri_local) stage(std::true_type{}); else stage(std::false_type{}); }
         if (tid == 0) {   // sentinel: far away (beyond every cutoff), no charge, no LJ
             if (packed3) { l_p3[n_here] = 1e4f; l_p3[SOA_STRIDE + n_here] = 1e4f; l_p3[2 * SOA_STRIDE + n_here] = 1e4f; }
             else l_pos[n_here] = make4<T>(T(1e4), T(1e4), T(1e4), T(0));
