@@ -708,7 +708,7 @@ template <class T> class Engine final : public EngineBase {
         // the packed fp32 one-type loop keeps the tile as three arrays SOA_STRIDE dwords apart
         const bool fast_f32 = std::is_same<T, float>::value && ljm == LJ_DIST_UNIFORM && coulm == MHIP_COUL_NONE && !energy && !minimg && !segmented && n_special == 0;
         A.soa = 0;
-        if (fast_f32 && !env_int("MOLLYHIP_NO_SOA", 0))
+        if (fast_f32 && !no_soa)
             for (int k = 2; k >= 0; --k) if ((use_inner ? max_tile_in : max_tile) + 1 < SOA_STRIDES[k]) A.soa = SOA_STRIDES[k];   // the smallest stride that holds tile + sentinel
         if (A.soa) lds_force = std::max(lds_force, (size_t)3 * A.soa * sizeof(float) + 64);
         A.part = 0; A.blk_ghost = nullptr;
@@ -721,7 +721,7 @@ template <class T> class Engine final : public EngineBase {
             }
             A.part = part; A.blk_ghost = fl.p;
         }
-        lds_force += (size_t)env_int("MOLLYHIP_LDS_PAD_KB", 0) * 1024;   // occupancy experiments
+        lds_force += (size_t)lds_pad_kb * 1024;   // occupancy experiments (MOLLYHIP_LDS_PAD_KB)
         if (prune) {
             wave_rows_in.reserve((size_t)n_blocks * JS * (BI / WAVE)); nbr_in.reserve((size_t)n_blocks * JS * R_cap * BI); blk_disp2.reserve(n_blocks);
             MHIP_HIP(hipMemsetAsync(blk_disp2.p, 0, (size_t)n_blocks * sizeof(float), stream));
@@ -766,6 +766,7 @@ template <class T> class Engine final : public EngineBase {
 
     // the prune as a kernel of its own (k_filter into the inner arrays), followed by a plain force pass over the fresh inner list
     const bool prune_by_kernel = env_int("MOLLYHIP_PRUNE_KERNEL", 0) != 0;
+    const bool no_soa = env_int("MOLLYHIP_NO_SOA", 0) != 0; const int lds_pad_kb = env_int("MOLLYHIP_LDS_PAD_KB", 0);
     void prune_with_filter() {
         pos_snap_in.reserve(cap);
         MHIP_HIP(hipMemcpyAsync(pos_snap_in.p, pos[cur].p, (size_t)n_tot * sizeof(T4), hipMemcpyDeviceToDevice, stream));
