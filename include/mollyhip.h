@@ -311,6 +311,46 @@ int32_t mhip_vv_halo_end_parts(mhip_ctx* ctx, int64_t step_n, double dt, int64_t
                                const void* recv_dev, double* cm_parts_dev, int32_t n_parts);
 int32_t mhip_remove_cm_parts_dev(mhip_ctx* ctx, const double* total_parts_dev, int32_t n_parts);
 
+/* ---- the fused form of the ghosted step: ONE engine call per step after the ghost exchange --------------------------------------
+ * (≙ simulators.jl:594-629 for one sub-domain: second kick of step n, remove_CM_motion!, first kick and drift of step n + 1 in one
+ * integrator launch, as mhip_vv_run does on a single domain.)
+ *
+ * The buffers of a ghost plan are registered once (mhip_set_halo_plan; device memory, valid until the next call or the next
+ * mhip_set_atom_counts, which drops the plan).  The send buffer holds n_send_rows rows of 3 reals: row k is the coordinate of local
+ * atom send_idx[k] + send_shift[k], or — send_idx[k] < 0 — one of the cm_rows rows after each peer's atoms that carry this rank's
+ * {Σ m vx, Σ m vy, Σ m vz, Σ m} of the step before (4 doubles = cm_rows·3 reals, cm_rows = 3 in fp32, 2 in fp64; send_cm_pos lists
+ * the n_send_cm row numbers, peer by peer, row 0 .. cm_rows-1 each).  The receive buffer mirrors it: recv_dst[k] >= 0 is the ghost
+ * slot (first_ghost + recv_dst[k]) that row k fills, recv_dst[k] = -1 - (p·cm_rows + r) marks row r of peer p's sums (p = 0 ..
+ * n_cm_peers-1).  With every other rank a peer (1, 2, 4, 8 bricks) the centre-of-mass sum needs no all-reduce of its own: the next
+ * integrator launch adds the peers' rows to its own sum and removes v_cm one launch late, together with v_cm·dt from the
+ * coordinates that were drifted with it — the scheme of mhip_vv_run; forces are translation invariant.
+ *
+ *   mhip_vv_halo_start : first kick + drift + pack (after mhip_vv_init, after a step that stopped, after a re-plan)
+ *   [ghost exchange of the send buffer into the receive buffer; mhip_vv_halo_interior meanwhile]
+ *   mhip_vv_halo_mid   : unpack, pair forces, second kick of step_n, then — unless flags bit 1 — first kick + drift of the next step
+ *                        and pack.  flags bit 0: remove_CM_motion! at this step.  flags bit 1 ("stop"): end behind the second kick
+ *                        with coordinates and velocities of step_n in place (rebuild cadence, end of a run); the step's Σ m v then
+ *                        goes to cm_parts_dev as n_parts per-block partials for an all-reduce + mhip_remove_cm_parts_dev, exactly
+ *                        as mhip_vv_halo_end_parts leaves it. */
+typedef struct {
+    int64_t first_ghost, n_recv_rows;
+    const void* recv; const int32_t* recv_dst;
+    int32_t n_cm_peers, cm_rows;
+    const int32_t* send_idx; const void* send_shift;
+    int64_t n_send_rows; void* send;
+    const int32_t* send_cm_pos; int32_t n_send_cm;
+} mhip_halo_plan;
+int32_t mhip_set_halo_plan(mhip_ctx* ctx, const mhip_halo_plan* plan);
+int32_t mhip_vv_halo_start(mhip_ctx* ctx, double dt);
+int32_t mhip_vv_halo_mid(mhip_ctx* ctx, int64_t step_n, double dt, int32_t flags, double* cm_parts_dev, int32_t n_parts);
+/* The prune / re-plan decision of a ghost plan by the engine's own criteria (tight inner skin + drift bound, as on a single domain):
+ * out3_dev = { max |x - x_plan|^2, max |x - x_prune|^2, max |v|^2 of the owned atoms } as device floats; MAX-all-reduce them, hand
+ * the result (host memory) to mhip_plan_decide on EVERY rank.  *action: 0 = nothing, 1 = the next force pass re-prunes the outer
+ * list (already arranged), 2 = re-plan (migrate, new ghost plan).  Supersedes mhip_plan_disp2_dev + mhip_request_prune, which keep
+ * scheduling against the reference's skin r_list - cutoff. */
+int32_t mhip_plan_state_dev(mhip_ctx* ctx, float* out3_dev);
+int32_t mhip_plan_decide(mhip_ctx* ctx, int64_t step_n, const float* reduced3, int32_t* action);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,13 @@ class Stats(C.Structure):
         return d
 
 
+class HaloPlan(C.Structure):
+    """mhip_halo_plan: the device buffers of one ghost plan (include/mollyhip.h)"""
+    _fields_ = [("first_ghost", C.c_int64), ("n_recv_rows", C.c_int64), ("recv", C.c_void_p), ("recv_dst", C.c_void_p),
+                ("n_cm_peers", C.c_int32), ("cm_rows", C.c_int32), ("send_idx", C.c_void_p), ("send_shift", C.c_void_p),
+                ("n_send_rows", C.c_int64), ("send", C.c_void_p), ("send_cm_pos", C.c_void_p), ("n_send_cm", C.c_int32)]
+
+
 # every entry point of include/mollyhip.h: name -> (restype, argtypes)
 _P, _I32, _I64, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_double
 SIGNATURES = {
@@ -112,6 +119,11 @@ SIGNATURES = {
     "mhip_vv_halo_interior": (_I32, [_P, _I64, C.POINTER(_I32)]),
     "mhip_vv_halo_end_parts": (_I32, [_P, _I64, _D, _I64, _I64, _P, _P, _I32]),
     "mhip_remove_cm_parts_dev": (_I32, [_P, _P, _I32]),
+    "mhip_set_halo_plan": (_I32, [_P, C.POINTER(HaloPlan)]),
+    "mhip_vv_halo_start": (_I32, [_P, _D]),
+    "mhip_vv_halo_mid": (_I32, [_P, _I64, _D, _I32, _P, _I32]),
+    "mhip_plan_state_dev": (_I32, [_P, _P]),
+    "mhip_plan_decide": (_I32, [_P, _I64, C.POINTER(C.c_float), C.POINTER(_I32)]),
 }
 
 

@@ -78,6 +78,11 @@ struct EngineBase {
     virtual double general_potential_energy() = 0;
     virtual void set_ghost_margin(double) = 0;
     virtual void plan_disp2_dev(float*) = 0;
+    virtual void plan_state_dev(float*) = 0;
+    virtual int plan_decide(int64_t, const float*) = 0;
+    virtual void set_halo_plan(const mhip_halo_plan*) = 0;
+    virtual void halo_start(double) = 0;
+    virtual void halo_mid(int64_t, double, int32_t, double*, int32_t) = 0;
     virtual void request_prune() = 0;
     virtual void halo_begin(double, const int32_t*, const void*, int64_t, void*) = 0;
     virtual int halo_interior(int64_t) = 0;
@@ -161,10 +166,11 @@ template <class T> class Engine final : public EngineBase {
     int tri_mode = 0; double tri_bv[9] = {};   // TriclinicBoundary: 0 off, 1 approx_images, 2 exact images; basis vectors row-major
     bool tri_grid = false;                     // … with a cell grid in height-scaled fractional coordinates (else: one cell, every block sees every atom)
     long long grid_key = -1;
+    bool engine_sched = false;   // … unless it hands the reduced displacements to mhip_plan_decide: then the engine's own criteria (inner skin, drift bound) decide
     bool host_prune = false;     // ghost plans: the HOST decides, collectively over the ranks, when the inner list is re-pruned (mhip_request_prune)
     // single list, same idea: a rebuild step whose displacement check shows the list still covers every cutoff sphere is skipped
     bool lazy_single = false; int64_t n_skipped = 0;
-    bool dual = false, dual_disabled = false; int early_outer = 0; double outer_margin = 0; int outer_every = 1; int64_t last_outer_step = 0, n_outer = 0, n_filters = 0; T r_in = 0, r_in2 = 0;
+    bool dual = false, dual_disabled = false; int margin_halvings = 0; int early_outer = 0; double outer_margin = 0; int outer_every = 1; int64_t last_outer_step = 0, n_outer = 0, n_filters = 0; T r_in = 0, r_in2 = 0;
     DBuf<int32_t> flags; int32_t* h_flags = nullptr;
     int64_t total_rows = 0;
     // reductions
@@ -278,7 +284,7 @@ template <class T> class Engine final : public EngineBase {
         r_in2 = G.no_list ? std::numeric_limits<T>::infinity() : r_in * r_in;                 // dist_cutoff^2, neighbors.jl:400
         // dual pair list: search with r_list + margin every `outer_every` rebuild intervals, filter to exactly r_list at
         // every rebuild step (MOLLYHIP_OUTER_MARGIN_PM in picometres, 0 disables; MOLLYHIP_OUTER_EVERY)
-        outer_margin = (G.no_list || dual_disabled) ? 0.0 : env_int("MOLLYHIP_OUTER_MARGIN_PM", 200) * 1e-3;
+        outer_margin = (G.no_list || dual_disabled) ? 0.0 : std::ldexp(env_int("MOLLYHIP_OUTER_MARGIN_PM", 200) * 1e-3, -margin_halvings);
         if (n_ghost > 0) outer_margin = std::min(outer_margin, ghost_margin);   // the shell handed over must cover the outer radius
         outer_every = std::max(1, env_int("MOLLYHIP_OUTER_EVERY", 1000));   // upper bound only: the outer list is re-searched when displacement says so
         strict_cadence = env_int("MOLLYHIP_STRICT_CADENCE", 0) != 0;         // 1: re-prune at every rebuild step, whatever the displacement
@@ -294,7 +300,7 @@ template <class T> class Engine final : public EngineBase {
             if (ip.coul_kind != MHIP_COUL_NONE) rc_max = std::max(rc_max, ip.coul_rc);
             skin = G.no_list ? 0.0 : cfg.r_list - rc_max;
             rc_max_ = rc_max;
-            skin_in = (n_ghost > 0 || host_prune) ? skin : std::min(skin, std::max(1, env_int("MOLLYHIP_INNER_SKIN_PM", 100)) * 1e-3);
+            skin_in = ((n_ghost > 0 || host_prune) && !engine_sched) ? skin : std::min(skin, std::max(1, env_int("MOLLYHIP_INNER_SKIN_PM", 100)) * 1e-3);
             const T rp = T(rc_max + skin_in);
             r_prune2 = (skin_in < skin) ? rp * rp : r_in2;
         }
@@ -431,9 +437,11 @@ template <class T> class Engine final : public EngineBase {
         try { rebuild_impl(step_n); }
         catch (const ApiError& e) {
             if (e.code != MHIP_ERR_CAPACITY || !dual) throw;
-            if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] dual list off (capacity): %s\n", e.msg.c_str());
-            dual_disabled = true; setup_grid(); choose_blocking(); stale = true;
-            rebuild_impl(step_n);
+            // dense small systems (a 64-atom block of water with a 1.4 nm shell is half of 6mrr): halve the outer margin before giving up on it
+            if (outer_margin > 0.06) ++margin_halvings; else dual_disabled = true;
+            if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] dual list %s (capacity): %s\n", dual_disabled ? "off" : "margin halved", e.msg.c_str());
+            setup_grid(); choose_blocking(); stale = true;
+            rebuild(step_n);
         }
     }
 
@@ -595,7 +603,7 @@ template <class T> class Engine final : public EngineBase {
     // The inner list must outlive at least one check interval: if the fastest atoms cover more than a third of the inner skin between
     // two checks, the skin grows (up to the reference's own r_list − cutoff) and the list is pruned afresh with the larger radius.
     void adapt_inner_skin(double drift_per_interval) {
-        if (!dual || host_prune || !(skin_in < skin)) return;
+        if (!dual || (host_prune && !engine_sched) || !(skin_in < skin) || inner_skin_fixed) return;
         const double need = std::min(skin, 3.0 * drift_per_interval / 0.98);
         if (need <= skin_in) return;
         skin_in = need;
@@ -766,6 +774,7 @@ template <class T> class Engine final : public EngineBase {
 
     // the prune as a kernel of its own (k_filter into the inner arrays), followed by a plain force pass over the fresh inner list
     const bool prune_by_kernel = env_int("MOLLYHIP_PRUNE_KERNEL", 0) != 0;
+    const bool inner_skin_fixed = env_int("MOLLYHIP_INNER_SKIN_FIXED", 0) != 0;
     const bool no_soa = env_int("MOLLYHIP_NO_SOA", 0) != 0; const int lds_pad_kb = env_int("MOLLYHIP_LDS_PAD_KB", 0);
     void prune_with_filter() {
         pos_snap_in.reserve(cap);
@@ -872,11 +881,11 @@ template <class T> class Engine final : public EngineBase {
         hipLaunchKernelGGL(k_iota2, dim3(std::min(cdiv(n_tot, 256), 1024)), dim3(256), 0, stream, n_tot, orig[cur].p, inv.p);
         MHIP_HIP(hipMemsetAsync(frc[cur].p, 0, n_tot * sizeof(T4), stream));
         MHIP_HIP(hipGetLastError());
-        stale = true; cm_pending = 0; cm_ext = nullptr; frc_valid = false;
+        stale = true; cm_pending = 0; cm_ext = nullptr; frc_valid = false; hp_set = false; halo_cm_in = false;
         // the search radius depends on whether there are ghosts and on the ghost margin, the blocking on the size class: a re-plan
         // that changes neither keeps the grid, its Hilbert table and the (already adapted) capacities
         const int size_class = n_owned >= 100000 ? 2 : (n_owned >= 40000 ? 1 : 0);
-        const long long key = (n_ghost > 0 ? 1 : 0) | (dual_disabled ? 2 : 0) | (size_class << 2) | ((long long)std::llround(ghost_margin * 1e6) << 8);
+        const long long key = (n_ghost > 0 ? 1 : 0) | (dual_disabled ? 2 : 0) | (size_class << 2) | (margin_halvings << 4) | ((long long)std::llround(ghost_margin * 1e6) << 8);
         if (key != grid_key) { setup_grid(); choose_blocking(); grid_key = key; }
     }
 
@@ -1275,6 +1284,120 @@ template <class T> class Engine final : public EngineBase {
         MHIP_HIP(hipGetLastError());
     }
     void request_prune() override { inner_valid = false; }
+    // {max |x − x_plan|², max |x − x_prune|², max |v|² of the owned atoms} as floats in device memory, ready for ONE MAX all-reduce over
+    // the ranks; mhip_plan_decide takes the reduced triple.  +inf in [0]: this sub-domain is re-planned at every rebuild step anyway.
+    void plan_state_dev(float* out_dev) override {
+        const uint32_t inf_bits = 0x7f800000u;
+        MHIP_HIP(hipMemsetAsync(out_dev, 0, 3 * sizeof(float), stream));
+        if (!dual || stale) { MHIP_HIP(hipMemsetD32Async((hipDeviceptr_t)out_dev, (int)inf_bits, 2, stream)); return; }
+        const dim3 g(std::min(cdiv(n_owned, 1024), 512));
+        unsigned int* w = reinterpret_cast<unsigned int*>(out_dev);
+        // owned atoms only: every ghost is an owned atom of some rank, and the MAX runs over all of them (the call may come before
+        // this step's ghost coordinates are in)
+        hipLaunchKernelGGL(k_max_disp<T>, g, dim3(1024), 0, stream, n_owned, (const T4*)pos[cur].p, (const T4*)pos_snap.p, w, G, (const T4*)vel[cur].p, n_owned, w + 2,
+                           inner_valid ? (const T4*)pos_snap_in.p : (const T4*)nullptr, inner_valid ? w + 1 : (unsigned int*)nullptr);
+        if (!inner_valid) MHIP_HIP(hipMemsetD32Async((hipDeviceptr_t)(out_dev + 1), (int)inf_bits, 1, stream));
+        MHIP_HIP(hipGetLastError());
+    }
+    // The collective decision at the rebuild cadence, made by every rank from the same reduced numbers with the criteria of the
+    // single-domain engine (refresh): 0 = the inner list lives on, 1 = the next force pass re-prunes the outer list, 2 = the ghost
+    // plan cannot vouch for a prune any more (or there is no margin): re-plan.  The inner list is pruned with the tight inner skin
+    // (rc + skin_in, grown when the fastest atoms would outrun a third of it between two checks) as in mhip_vv_run.
+    int plan_decide(int64_t step_n, const float* red3) override {
+        const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
+        if (!engine_sched) {   // first use: from now on the inner list may be tighter than r_list
+            engine_sched = true;
+            skin_in = std::min(skin, std::max(1, env_int("MOLLYHIP_INNER_SKIN_PM", 100)) * 1e-3);
+            const T rp = T(rc_max_ + skin_in);
+            r_prune2 = (skin_in < skin) ? rp * rp : r_in2;
+        }
+        if (!dual || stale || std::isinf(red3[0])) return 2;
+        prev_vmax = last_vmax; last_vmax = std::sqrt((double)red3[2]);
+        ++n_disp_checks;
+        bool reprune = !inner_valid || std::isinf(red3[1]);
+        if (!reprune) {
+            const double d = std::sqrt((double)red3[1]), ahead = drift_ahead(d, step_n - last_prune_step, every);
+            adapt_inner_skin(ahead);
+            reprune = !inner_valid || 2.0 * (d + ahead) > skin_in * 0.98;
+        }
+        if (!reprune) return 0;
+        // the prune runs inside the NEXT force pass, one step from now: leave it that step of headroom
+        if (2.0 * (std::sqrt((double)red3[0]) + last_vmax * cur_dt * 1.25) > prune_margin() * 0.98) return 2;
+        inner_valid = false;
+        return 1;
+    }
+
+    // ---- one MD step of a ghosted sub-domain in ONE call after the ghost exchange (fused integrator, Σ m v on the ghost message) --------
+    mhip_halo_plan hp{}; bool hp_set = false, halo_cm_in = false; int cm_half = 0;
+    DBuf<double> cm_all;         // [0] this rank's {ΣPx, ΣPy, ΣPz, ΣM} of the step before (k_halo_pack), [1 + p] peer p's (k_halo_unpack)
+    void set_halo_plan(const mhip_halo_plan* p) override {
+        if (!p) { hp_set = false; return; }
+        if (p->n_recv_rows < 0 || p->n_send_rows < 0 || p->n_cm_peers < 0 || p->n_cm_peers > 26 || p->cm_rows < 0 || p->cm_rows > 4 || p->n_send_cm < 0)
+            throw ApiError{MHIP_ERR_INVALID, "halo plan: counts out of range"};
+        if ((p->n_recv_rows > 0 && (!p->recv || !p->recv_dst)) || (p->n_send_rows > 0 && (!p->send || !p->send_idx || !p->send_shift)) || (p->n_send_cm > 0 && !p->send_cm_pos))
+            throw ApiError{MHIP_ERR_INVALID, "halo plan: null buffer"};
+        if (p->cm_rows > 0 && p->cm_rows * 3 * (int)sizeof(T) < 32) throw ApiError{MHIP_ERR_INVALID, "halo plan: cm_rows rows cannot hold four doubles"};
+        hp = *p; hp_set = true; halo_cm_in = false;
+        cm_all.reserve(4 * 28);
+        MHIP_HIP(hipMemsetAsync(cm_all.p, 0, 4 * 28 * sizeof(double), stream));
+    }
+    void halo_pack(bool with_cm) {
+        if (hp.n_send_rows <= 0 && !with_cm) return;
+        tr("k_halo_pack");
+        hipLaunchKernelGGL(k_halo_pack<T>, dim3(cdiv(std::max<int64_t>(hp.n_send_rows, 1), 256) + 1), dim3(256), 0, stream, hp.n_send_rows, hp.send_idx, (const T*)hp.send_shift, (const int32_t*)inv.p,
+                           (const T4*)pos[cur].p, (T*)hp.send, with_cm ? (const double*)cm_step.p : (const double*)nullptr, n_cm_step, hp.send_cm_pos, hp.n_send_cm, std::max(hp.cm_rows, 1), cm_all.p);
+        MHIP_HIP(hipGetLastError());
+    }
+    // first kick + drift + pack: after vv_init, after a step that stopped behind its second kick, after a re-plan
+    void halo_start(double dt) override {
+        if (!hp_set) throw ApiError{MHIP_ERR_STATE, "mhip_set_halo_plan first"};
+        vv_stage1(dt);
+        halo_pack(false);
+        halo_cm_in = false;
+    }
+    // flags bit 0: this step removes the centre-of-mass motion; bit 1: stop behind the second kick (the step's Σ m v goes to
+    // cm_parts_dev as n_parts per-block partials for an all-reduce, nothing is packed) — at the rebuild cadence and at the end of a run
+    void halo_mid(int64_t step_n, double dt, int32_t flags, double* cm_parts_dev, int32_t n_parts) override {
+        if (!hp_set) throw ApiError{MHIP_ERR_STATE, "mhip_set_halo_plan first"};
+        const bool cm = (flags & 1) != 0, last = (flags & 2) != 0;
+        if (cm && last && (!cm_parts_dev || n_parts < 1 || n_parts > 1024)) throw ApiError{MHIP_ERR_INVALID, "n_parts must be 1..1024"};
+        if (cm && !last && hp.cm_rows <= 0 && hp.n_cm_peers > 0) throw ApiError{MHIP_ERR_INVALID, "halo plan carries no centre-of-mass rows"};
+        if (hp.n_recv_rows > 0) {
+            if (hp.first_ghost < 0 || hp.first_ghost > n_tot) throw ApiError{MHIP_ERR_INVALID, "halo plan: ghost range out of bounds"};
+            tr("k_halo_unpack");
+            hipLaunchKernelGGL(k_halo_unpack<T>, dim3(cdiv(hp.n_recv_rows, 256)), dim3(256), 0, stream, hp.n_recv_rows, (const T*)hp.recv, hp.recv_dst, hp.first_ghost, (const int32_t*)inv.p,
+                               pos[cur].p, cm_all.p, std::max(hp.cm_rows, 1));
+        }
+        cur_dt = dt;
+        const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
+        const bool due = step_n % every == 0 && step_n != last_build_step && (n_ghost == 0 || dual);
+        if (due && dual) refresh(step_n);
+        step_forces(step_n);
+        if (cm_pending) flush_cm();                                               // (a removal registered through the stepwise entry points)
+        const bool solo = hp.n_cm_peers == 0 && hp.n_send_rows == 0;              // no peers: the partials of the launch before are the whole sum
+        const double* cm_in = halo_cm_in ? (solo ? (const double*)cm_step.p + (size_t)(cm_half ^ 1) * 4 * 1024 : (const double*)cm_all.p) : (const double*)nullptr;
+        const int n_in = solo ? n_cm_step : 1 + hp.n_cm_peers;
+        const int nb = (cm && last) ? n_parts : std::min(cdiv(n_owned, 256), 1024);
+        double* cm_out = cm ? (last ? cm_parts_dev : cm_step.p + (size_t)(solo ? cm_half : 0) * 4 * 1024) : (double*)nullptr;
+        prof.begin(2, stream);
+        tr("k_vv_mid");
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, stream, n_owned, pos[cur].p, vel[cur].p, (const T4*)frc[cur].p, T(dt), T(dt) / T(2),
+                               cm_in, n_in, cm_out, (const T4*)pend_a, (const T4*)pend_b, G);
+        };
+        if (last) { if (cm) go(k_vv_mid<T, true, true>); else go(k_vv_mid<T, false, true>); }
+        else { if (cm) go(k_vv_mid<T, true, false>); else go(k_vv_mid<T, false, false>); }
+        prof.end(2, stream);
+        pend_a = pend_b = nullptr; cm_pending = 0; cm_ext = nullptr;
+        if (due && !dual) refresh(step_n);
+        if (!last) {
+            n_cm_step = nb;
+            if (solo) cm_half ^= 1; else halo_pack(cm);
+            halo_cm_in = cm;
+            frc_valid = false;                                                    // frc[cur] belongs to the coordinates before the drift
+        } else halo_cm_in = false;
+        MHIP_HIP(hipGetLastError());
+    }
     // one MD step of a ghosted sub-domain in two calls around the ghost exchange
     void halo_begin(double dt, const int32_t* idx_dev, const void* shift_dev, int64_t n, void* out_dev) override {
         vv_stage1(dt);
@@ -1647,6 +1770,15 @@ int32_t mhip_remove_cm_parts_dev(mhip_ctx* ctx, const double* parts, int32_t n_p
 int32_t mhip_set_ghost_margin(mhip_ctx* ctx, double m) { NEED_CTX(); return guard(ctx, [&] { ctx->e->set_ghost_margin(m); }); }
 int32_t mhip_plan_disp2_dev(mhip_ctx* ctx, float* out) { NEED_CTX(); return guard(ctx, [&] { if (!out) throw mhip::ApiError{MHIP_ERR_INVALID, "null output"}; ctx->e->plan_disp2_dev(out); }); }
 int32_t mhip_request_prune(mhip_ctx* ctx) { NEED_CTX(); return guard(ctx, [&] { ctx->e->request_prune(); }); }
+int32_t mhip_plan_state_dev(mhip_ctx* ctx, float* out3) { NEED_CTX(); return guard(ctx, [&] { if (!out3) throw mhip::ApiError{MHIP_ERR_INVALID, "null output"}; ctx->e->plan_state_dev(out3); }); }
+int32_t mhip_plan_decide(mhip_ctx* ctx, int64_t step_n, const float* reduced3, int32_t* action) {
+    NEED_CTX(); return guard(ctx, [&] { if (!reduced3 || !action) throw mhip::ApiError{MHIP_ERR_INVALID, "null argument"}; *action = ctx->e->plan_decide(step_n, reduced3); });
+}
+int32_t mhip_set_halo_plan(mhip_ctx* ctx, const mhip_halo_plan* plan) { NEED_CTX(); return guard(ctx, [&] { ctx->e->set_halo_plan(plan); }); }
+int32_t mhip_vv_halo_start(mhip_ctx* ctx, double dt) { NEED_CTX(); return guard(ctx, [&] { ctx->e->halo_start(dt); }); }
+int32_t mhip_vv_halo_mid(mhip_ctx* ctx, int64_t step_n, double dt, int32_t flags, double* cm_parts, int32_t n_parts) {
+    NEED_CTX(); return guard(ctx, [&] { ctx->e->halo_mid(step_n, dt, flags, cm_parts, n_parts); });
+}
 int32_t mhip_vv_halo_begin(mhip_ctx* ctx, double dt, const int32_t* idx, const void* shift, int64_t n, void* out) { NEED_CTX(); return guard(ctx, [&] { ctx->e->halo_begin(dt, idx, shift, n, out); }); }
 int32_t mhip_vv_halo_interior(mhip_ctx* ctx, int64_t step_n, int32_t* launched) { NEED_CTX(); return guard(ctx, [&] { int r = ctx->e->halo_interior(step_n); if (launched) *launched = r; }); }
 int32_t mhip_vv_halo_end(mhip_ctx* ctx, int64_t step_n, double dt, int64_t first, int64_t n, const void* in, double* cm_out4) {

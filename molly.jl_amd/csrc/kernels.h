@@ -679,24 +679,32 @@ __global__ void k_uniform_check(int64_t n, const T* __restrict__ sig, const T* _
 // `vel`, also the largest |v|² of the first n_vel atoms → *v2_word (how far anybody can get before the next check)
 template <class T>
 __global__ void k_max_disp(int64_t n, const typename Vec<T>::T4* __restrict__ pos, const typename Vec<T>::T4* __restrict__ snap, unsigned int* out_word, GridP<T> G,
-                           const typename Vec<T>::T4* __restrict__ vel = nullptr, int64_t n_vel = 0, unsigned int* v2_word = nullptr) {
-    float d2 = 0.f, v2 = 0.f;
+                           const typename Vec<T>::T4* __restrict__ vel = nullptr, int64_t n_vel = 0, unsigned int* v2_word = nullptr,
+                           const typename Vec<T>::T4* __restrict__ snap_b = nullptr, unsigned int* out_b = nullptr) {   // (a second snapshot in the same pass)
+    float d2 = 0.f, v2 = 0.f, b2 = 0.f;
     for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
         auto p = pos[s]; auto q = snap[s];
         T ex = p.x - q.x, ey = p.y - q.y, ez = p.z - q.z;
         disp_image(ex, ey, ez, G);
         d2 = fmaxf(d2, (float)(ex * ex + ey * ey + ez * ez));
+        if (snap_b) {
+            q = snap_b[s];
+            ex = p.x - q.x; ey = p.y - q.y; ez = p.z - q.z;
+            disp_image(ex, ey, ez, G);
+            b2 = fmaxf(b2, (float)(ex * ex + ey * ey + ez * ez));
+        }
         if (vel && s < n_vel) { auto v = vel[s]; v2 = fmaxf(v2, (float)(v.x * v.x + v.y * v.y + v.z * v.z)); }
     }
-    d2 = wave_max(d2); v2 = wave_max(v2);
-    __shared__ float sh[16], shv[16];   // (up to 1024 lanes per block: few blocks, few atomics on the two result words)
-    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = d2; shv[threadIdx.x >> 6] = v2; }
+    d2 = wave_max(d2); v2 = wave_max(v2); b2 = wave_max(b2);
+    __shared__ float sh[16], shv[16], shb[16];   // (up to 1024 lanes per block: few blocks, few atomics on the result words)
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = d2; shv[threadIdx.x >> 6] = v2; shb[threadIdx.x >> 6] = b2; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        float m = 0.f, mv = 0.f;
-        for (int q = 0; q < (int)(blockDim.x >> 6); ++q) { m = fmaxf(m, sh[q]); mv = fmaxf(mv, shv[q]); }
+        float m = 0.f, mv = 0.f, mb = 0.f;
+        for (int q = 0; q < (int)(blockDim.x >> 6); ++q) { m = fmaxf(m, sh[q]); mv = fmaxf(mv, shv[q]); mb = fmaxf(mb, shb[q]); }
         atomicMax(out_word, __float_as_uint(m));
         if (v2_word) atomicMax(v2_word, __float_as_uint(mv));
+        if (out_b) atomicMax(out_b, __float_as_uint(mb));
     }
 }
 
@@ -1438,6 +1446,57 @@ __global__ void k_scatter_coords(int64_t first, int64_t n, const T* __restrict__
     if (k >= n) return;
     int s = inv[first + k];
     pos[s].x = in[3 * k]; pos[s].y = in[3 * k + 1]; pos[s].z = in[3 * k + 2];
+}
+
+
+// The per-step halo message of a ghost plan (mhip_halo_plan): coordinate rows of the atoms the peers need and, after each peer's
+// rows, cm_rows rows that carry this rank's {ΣPx, ΣPy, ΣPz, ΣM} of the step before (four doubles seen as words of T, three per
+// row) — the centre-of-mass sum rides on the ghost exchange instead of an all-reduce of its own.  idx < 0 marks those rows; they are
+// written by ONE extra block that re-sums the per-block partials of the integrator launch (cm_part, n_part; nullptr: zeros) and
+// also leaves the total in cm_own, the first slot of the table the next integrator launch sums.
+template <class T>
+__global__ void __launch_bounds__(256) k_halo_pack(int64_t n, const int32_t* __restrict__ idx, const T* __restrict__ shift, const int32_t* __restrict__ inv,
+                                                   const typename Vec<T>::T4* __restrict__ pos, T* out, const double* __restrict__ cm_part, int n_part,
+                                                   const int32_t* __restrict__ cm_pos, int n_cm_pos, int cm_rows, double* cm_own) {
+    if (blockIdx.x == gridDim.x - 1) {
+        __shared__ double tot[4];
+        __shared__ double sh_cm[4][4];
+        double a[4] = {0, 0, 0, 0};
+        if (cm_part) for (int q = threadIdx.x; q < n_part; q += blockDim.x) { const double* p = cm_part + 4 * (int64_t)q; a[0] += p[0]; a[1] += p[1]; a[2] += p[2]; a[3] += p[3]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) for (int c = 0; c < 4; ++c) a[c] += __shfl_xor(a[c], o, 64);
+        if ((threadIdx.x & 63) == 0) for (int c = 0; c < 4; ++c) sh_cm[threadIdx.x >> 6][c] = a[c];
+        __syncthreads();
+        if (threadIdx.x < 4) { double t = 0; for (int q = 0; q < (int)(blockDim.x >> 6); ++q) t += sh_cm[q][threadIdx.x]; tot[threadIdx.x] = t; if (cm_own) cm_own[threadIdx.x] = t; }
+        __syncthreads();
+        constexpr int NW = 32 / (int)sizeof(T);
+        const T* w = reinterpret_cast<const T*>(tot);
+        for (int q = threadIdx.x; q < n_cm_pos; q += blockDim.x) {
+            const int r = q % cm_rows; const int64_t k = cm_pos[q];
+            for (int c = 0; c < 3; ++c) out[3 * k + c] = (3 * r + c < NW) ? w[3 * r + c] : T(0);
+        }
+        return;
+    }
+    const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int i = idx[k];
+    if (i < 0) return;
+    const auto p = pos[inv[i]];
+    out[3 * k] = p.x + shift[3 * k]; out[3 * k + 1] = p.y + shift[3 * k + 1]; out[3 * k + 2] = p.z + shift[3 * k + 2];
+}
+// the receiving side: dst >= 0 → coordinates of ghost slot first + dst; dst = −1 − (peer·cm_rows + r) → row r of that peer's sums,
+// collected in cm_all[1 + peer] (slot 0 is this rank's own, k_halo_pack)
+template <class T>
+__global__ void k_halo_unpack(int64_t n, const T* __restrict__ in, const int32_t* __restrict__ dst, int64_t first, const int32_t* __restrict__ inv,
+                              typename Vec<T>::T4* pos, double* cm_all, int cm_rows) {
+    const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int d = dst[k];
+    if (d >= 0) { const int s = inv[first + d]; pos[s].x = in[3 * k]; pos[s].y = in[3 * k + 1]; pos[s].z = in[3 * k + 2]; return; }
+    constexpr int NW = 32 / (int)sizeof(T);
+    const int code = -1 - d, peer = code / cm_rows, r = code - peer * cm_rows;
+    T* w = reinterpret_cast<T*>(cm_all + 4 * (int64_t)(1 + peer));
+    for (int c = 0; c < 3; ++c) if (3 * r + c < NW) w[3 * r + c] = in[3 * k + c];
 }
 
 }  // namespace mhip

@@ -194,6 +194,36 @@ class HipDomainEngine:
         if rc != 0:
             self._chk(rc)
 
+    # -- the fused step: one engine call per step after the ghost exchange (include/mollyhip.h, mhip_halo_plan) --------
+    def set_halo_plan(self, first_ghost, recv, recv_dst, n_cm_peers, cm_rows, send_idx, send_shift, send, send_cm_pos):
+        hp = _lib.HaloPlan()
+        hp.first_ghost, hp.n_recv_rows, hp.recv, hp.recv_dst = first_ghost, recv.shape[0], recv.data_ptr(), recv_dst.data_ptr()
+        hp.n_cm_peers, hp.cm_rows = n_cm_peers, cm_rows
+        hp.send_idx, hp.send_shift, hp.n_send_rows, hp.send = send_idx.data_ptr(), send_shift.data_ptr(), send.shape[0], send.data_ptr()
+        hp.send_cm_pos, hp.n_send_cm = send_cm_pos.data_ptr(), send_cm_pos.numel()
+        self._hp_keep = (recv, recv_dst, send_idx, send_shift, send, send_cm_pos)
+        self._chk(self.L.mhip_set_halo_plan(self.ctx, C.byref(hp)))
+
+    def halo_start(self, dt):
+        rc = self.L.mhip_vv_halo_start(self.ctx, dt)
+        if rc != 0:
+            self._chk(rc)
+
+    def halo_mid(self, step, dt, cm, stop, cm_parts):
+        rc = self.L.mhip_vv_halo_mid(self.ctx, step, dt, (1 if cm else 0) | (2 if stop else 0), self._p(cm_parts) if (cm and stop) else None,
+                                     cm_parts.numel() // 4 if (cm and stop) else 0)
+        if rc != 0:
+            self._chk(rc)
+
+    def plan_state(self, out3_f32):       # device float[3]: max displacement² since the plan / since the last prune, max speed²
+        self._chk(self.L.mhip_plan_state_dev(self.ctx, self._p(out3_f32)))
+
+    def plan_decide(self, step, reduced3):
+        arr = (C.c_float * 3)(*reduced3)
+        action = C.c_int32(0)
+        self._chk(self.L.mhip_plan_decide(self.ctx, step, arr, C.byref(action)))
+        return action.value
+
     def plan_disp2(self, out2_f32):       # device float[2]: max displacement² since the plan / since the last prune
         self._chk(self.L.mhip_plan_disp2_dev(self.ctx, self._p(out2_f32)))
 
@@ -245,6 +275,11 @@ class DomainRun:
         # Σ m v travels as per-block partials (no finalize launch on the device): CM_PARTS × {Px, Py, Pz, M}, summed over the ranks
         self.cm_buf = torch.zeros(4 * CM_PARTS, dtype=torch.float64, device=device)
         self.d2_buf = torch.zeros(2, dtype=torch.float32, device=device)
+        self.d3_buf = torch.zeros(3, dtype=torch.float32, device=device)
+        # fused stepping (one engine call per step, Σ m v on the ghost message): needs every other rank as a peer — 1, 2, 4, 8 bricks
+        peers = {p for (p, _, _) in grid.dirs}
+        self.fused = (_os.environ.get("MOLLYHIP_HALO_FUSED", "1") != "0" and hasattr(engine, "halo_mid") and len(peers) == grid.world - 1)
+        self.cm_rows = (3 if tdtype == torch.float32 else 2) if self.fused else 0
         self.stats = {"exchange_calls": 0, "ghost_atoms": 0, "migrated": 0, "plans": 0, "plan_checks": 0, "prunes": 0, "interior_passes": 0}
         self.overlap = _os.environ.get("MOLLYHIP_HALO_OVERLAP", "1") != "0" and hasattr(engine, "halo_interior")
         # gloo cannot move device memory: stage through the host (used by the multi-process tests that share ONE GPU;
@@ -268,6 +303,8 @@ class DomainRun:
             dist.all_to_all_single(recv, send, rc, sc, group=self.group)
 
     def _all_reduce(self, t, op=dist.ReduceOp.SUM):
+        if self.world == 1:
+            return                                           # a single rank's sum is its own
         if self.stage_host:
             c = t.cpu(); dist.all_reduce(c, op=op, group=self.group); t.copy_(c)
         else:
@@ -306,7 +343,8 @@ class DomainRun:
             hi = xd >= (g.hi[d] - rg)
             near.append(torch.stack([lo, torch.ones_like(lo), hi]))
         if g.dirs:
-            sel = torch.stack([near[0][dv[0] + 1] & near[1][dv[1] + 1] & near[2][dv[2] + 1] for (_, dv, _) in g.dirs])   # [ndir, n]
+            opt = torch.tensor([[dv[d] + 1 for (_, dv, _) in g.dirs] for d in range(3)], dtype=torch.int64, device=self.device)
+            sel = near[0][opt[0]] & near[1][opt[1]] & near[2][opt[2]]   # [ndir, n]: one gather per axis instead of one launch per direction
             pairs = torch.nonzero(sel)                      # sorted by direction, then atom
             self.send_idx = pairs[:, 1].to(torch.int32).contiguous()
             per_dir = torch.bincount(pairs[:, 0], minlength=len(g.dirs))
@@ -334,10 +372,38 @@ class DomainRun:
         par_all = torch.cat([self.par, recv_par], dim=0)
         x_all = torch.cat([self.x, self.recv_x], dim=0).contiguous()
         self.e.set_local(self.n_owned, self.n_ghost, par_all[:, 0], par_all[:, 1], par_all[:, 2], par_all[:, 3], x_all, self.v)
+        if self.fused:
+            self._halo_layout()
         self.e.vv_init(step)                                 # neighbour structures + forces at this step
         self.stats["ghost_atoms"] = self.n_ghost
         self.stats["plans"] += 1
         self.plan_step = self.prune_step = step
+
+    def _halo_layout(self):
+        """per-step message of the fused path: each peer's coordinate rows followed by cm_rows rows for Σ m v (mhip_halo_plan)"""
+        cr, dev = self.cm_rows, self.device
+        peers = sorted({p for (p, _, _) in self.g.dirs})
+        si, ss, cm_pos, rd = [], [], [], []
+        s_off = r_off = row = 0
+        cm_idx = torch.arange(-1, -1 - cr, -1, dtype=torch.int32, device=dev)
+        zero_shift = torch.zeros((cr, 3), dtype=self.tdtype, device=dev)
+        sc, rc = [0] * self.world, [0] * self.world
+        g_off = 0
+        for pi, p in enumerate(peers):
+            ns, nr = self.send_counts[p], self.recv_counts[p]
+            si += [self.send_idx[s_off:s_off + ns], cm_idx]; ss += [self.send_shift[s_off:s_off + ns], zero_shift]
+            cm_pos += list(range(row + ns, row + ns + cr))
+            rd += [torch.arange(g_off, g_off + nr, dtype=torch.int32, device=dev), torch.arange(-1 - pi * cr, -1 - (pi + 1) * cr, -1, dtype=torch.int32, device=dev)]
+            s_off += ns; r_off += nr; row += ns + cr; g_off += nr
+            sc[p], rc[p] = ns + cr, nr + cr
+        cat = lambda ts, shape, dt: torch.cat(ts).contiguous() if ts else torch.zeros(shape, dtype=dt, device=dev)
+        self.f_send_idx, self.f_send_shift = cat(si, (0,), torch.int32), cat(ss, (0, 3), self.tdtype)
+        self.f_recv_dst = cat(rd, (0,), torch.int32)
+        self.f_cm_pos = torch.tensor(cm_pos, dtype=torch.int32, device=dev)
+        self.f_send = torch.zeros((self.f_send_idx.numel(), 3), dtype=self.tdtype, device=dev)
+        self.f_recv = torch.zeros((self.f_recv_dst.numel(), 3), dtype=self.tdtype, device=dev)
+        self._fsc3, self._frc3 = [c * 3 for c in sc], [c * 3 for c in rc]
+        self.e.set_halo_plan(self.n_owned, self.f_recv, self.f_recv_dst, len(peers), cr, self.f_send_idx, self.f_send_shift, self.f_send, self.f_cm_pos)
 
     def _a2a_rows(self, recv, send):
         w = recv.shape[1]
@@ -365,35 +431,81 @@ class DomainRun:
             self.replan_if_due(step_n)
 
     def replan_if_due(self, step_n):
-        """Collective decision at the rebuild cadence (one MAX all-reduce of two floats, one host sync).  The inner pair lists are
-        re-pruned — on every rank at the same step — when the displacement since the last prune is about to use up the skin.  A
-        prune needs the ghost plan to be valid at that moment (nobody moved more than ghost_margin/2 since it was made): if it
-        is not, ownership, ghosts and outer lists are redone instead.  In between, nothing needs to hold but the skin criterion,
-        exactly as in the single-domain engine."""
-        if self.gm <= 0:
+        if self._replan_due(step_n):
             self.migrate(step_n)
-            return
+
+    def _replan_due(self, step_n):
+        """Collective decision at the rebuild cadence (one MAX all-reduce of a few floats, one host sync): True = ownership, ghosts and
+        outer lists have to be redone.  The inner pair lists are re-pruned — on every rank at the same step — when the displacement
+        since the last prune is about to use up the inner skin.  A prune needs the ghost plan to be valid at that moment (nobody
+        moved more than half the margin since it was made): if it is not, the plan is redone instead.  In between, nothing needs to
+        hold but the skin criterion, exactly as in the single-domain engine."""
+        if self.gm <= 0:
+            return True
+        if hasattr(self.e, "plan_decide") and _os.environ.get("MOLLYHIP_HOST_PRUNE", "0") == "0":
+            # the engine's own criteria (tight inner skin, drift bound from the fastest atom), fed with the MAX over the ranks
+            self.e.plan_state(self.d3_buf)
+            self._all_reduce(self.d3_buf, dist.ReduceOp.MAX)
+            red = [float(v) for v in self.d3_buf.tolist()]          # the one host sync per rebuild interval
+            self.stats["plan_checks"] += 1
+            action = 2 if math.isinf(red[0]) else self.e.plan_decide(step_n, red)
+            if action == 1:
+                self.prune_step = step_n
+                self.stats["prunes"] += 1
+            return action == 2
         self.e.plan_disp2(self.d2_buf)
         self._all_reduce(self.d2_buf, dist.ReduceOp.MAX)
         d2_plan, d2_prune = (float(v) for v in self.d2_buf.tolist())      # the one host sync per rebuild interval
         self.stats["plan_checks"] += 1
         if math.isinf(d2_plan):
-            self.migrate(step_n)
-            return
+            return True
         k = max(1, (step_n - self.prune_step) // self.every)
         prune_due = math.isinf(d2_prune) or 2.0 * math.sqrt(d2_prune) * (k + 1) / k > 0.98 * self.skin
         if not prune_due:
-            return
+            return False
         if 2.0 * math.sqrt(d2_plan) > 0.95 * self.gm:       # the plan cannot vouch for a prune any more
-            self.migrate(step_n)
-        else:
-            self.e.request_prune()                           # the next force pass walks the outer list and prunes
-            self.prune_step = step_n
-            self.stats["prunes"] += 1
+            return True
+        self.e.request_prune()                               # the next force pass walks the outer list and prunes
+        self.prune_step = step_n
+        self.stats["prunes"] += 1
+        return False
 
     def run(self, first_step, n_steps, dt, remove_cm_every=1):
-        for s in range(first_step + 1, first_step + n_steps + 1):
-            self.step(s, dt, remove_cm_every)
+        if not self.fused:
+            for s in range(first_step + 1, first_step + n_steps + 1):
+                self.step(s, dt, remove_cm_every)
+            return
+        # Fused stepping: per step the ghost exchange (with the step-before's Σ m v on board), the interior blocks meanwhile, then ONE
+        # engine call — unpack, boundary blocks, second kick, first kick + drift of the next step, pack.  The collective prune /
+        # re-plan decision is taken at the rebuild cadence BEFORE the step, from the displacements of the owned atoms (every ghost is
+        # somebody's owned atom, and the MAX runs over all ranks).  Only a step that is followed by a re-plan, and the last one, stop
+        # behind their second kick (state of step s in place; Σ m v all-reduced there); the next step then starts with halo_start.
+        last = first_step + n_steps
+        exchange = self.world > 1 and bool(self.g.dirs)
+        if n_steps > 0:
+            self.e.halo_start(dt)
+        for s in range(first_step + 1, last + 1):
+            cm = bool(remove_cm_every) and s % remove_cm_every == 0
+            replan = s % self.every == 0 and self._replan_due(s)
+            stop = replan or s == last
+            work = self._a2a_async(self.f_recv.view(-1), self.f_send.view(-1), self._frc3, self._fsc3) if (exchange and self.overlap) else None
+            if self.overlap and self.e.halo_interior(s):
+                self.stats["interior_passes"] += 1
+            if exchange:
+                if work is not None:
+                    work.wait()
+                else:
+                    self._a2a(self.f_recv.view(-1), self.f_send.view(-1), self._frc3, self._fsc3)
+                self.stats["exchange_calls"] += 1
+            self.e.halo_mid(s, dt, cm, stop, self.cm_buf)
+            if stop:
+                if cm:
+                    self._all_reduce(self.cm_buf)
+                    self.e.remove_cm(self.cm_buf)          # applied by the next first kick (or any read of the state)
+                if replan:
+                    self.migrate(s)
+                if s != last:
+                    self.e.halo_start(dt)
 
     # -- migration at the rebuild cadence -------------------------------------------------------------------------------
     def pull(self):
@@ -402,26 +514,40 @@ class DomainRun:
         self.x = x_all[: self.n_owned].contiguous()
 
     def migrate(self, step):
+        """Atoms that left the brick go to their new owner; everybody then makes a new ghost plan.  Only the leavers travel (a few
+        per thousand per re-plan): the atoms that stay keep their local order, arrivals are appended in (source rank, sender order)."""
         self.pull()
         x = self.x - torch.floor(self.x / self.boxt) * self.boxt      # wrap the cut (open) axes too
+        if self.world == 1:
+            self.x = x
+            self._plan_and_load(step)
+            return
         dest = self.g.owner_of(x)
-        order = torch.argsort(dest, stable=True)
-        send_counts = torch.bincount(dest, minlength=self.world)
+        li = torch.nonzero(dest != self.rank).squeeze(1)               # leavers (one host sync; the list is short)
+        ld = dest[li]
+        o = torch.argsort(ld, stable=True)
+        li, ld = li[o], ld[o]
+        send_counts = torch.bincount(ld, minlength=self.world)
         recv_counts = torch.empty_like(send_counts)
         self._a2a(recv_counts, send_counts)
         sc, rc = send_counts.tolist(), recv_counts.tolist()
-        payload = torch.cat([x, self.v, self.par], dim=1)[order].contiguous()         # 10 reals per atom
-        gid = self.gid[order].contiguous()
+        payload = torch.cat([x[li], self.v[li], self.par[li]], dim=1).contiguous()     # 10 reals per leaver
+        gid = self.gid[li].contiguous()
         n_new = int(sum(rc))
         rp = torch.empty((n_new, 10), dtype=self.tdtype, device=self.device)
         rg = torch.empty(n_new, dtype=torch.int64, device=self.device)
         self._a2a(rp.view(-1), payload.view(-1), [c * 10 for c in rc], [c * 10 for c in sc])
         self._a2a(rg, gid, rc, sc)
-        self.stats["migrated"] += int(self.n_owned - sc[self.rank])
-        o = torch.argsort(rg)                                          # deterministic local order: by global atom id
-        self.gid = rg[o].contiguous()
-        rp = rp[o]
-        self.x, self.v, self.par = rp[:, 0:3].contiguous(), rp[:, 3:6].contiguous(), rp[:, 6:10].contiguous()
+        self.stats["migrated"] += int(li.numel())
+        if li.numel() or n_new:
+            keep = torch.ones(x.shape[0], dtype=torch.bool, device=self.device)
+            keep[li] = False
+            self.x = torch.cat([x[keep], rp[:, 0:3]], dim=0).contiguous()
+            self.v = torch.cat([self.v[keep], rp[:, 3:6]], dim=0).contiguous()
+            self.par = torch.cat([self.par[keep], rp[:, 6:10]], dim=0).contiguous()
+            self.gid = torch.cat([self.gid[keep], rg], dim=0).contiguous()
+        else:
+            self.x = x
         self._plan_and_load(step)
 
     # -- gather the whole system on every rank (tests / final state) ------------------------------------------------------

@@ -9,9 +9,10 @@ from oracle import pyoracle as orc
 
 
 class OracleDomainEngine:
-    def __init__(self, inter_dict, box, periodic, r_list, dtype=np.float64, ghost_margin=0.0):
+    def __init__(self, inter_dict, box, periodic, r_list, dtype=np.float64, ghost_margin=0.0, skin=0.2, every=10):
         self.inter, self.r_list, self.dtype = inter_dict, r_list, dtype
         self.ghost_margin, self.n_prunes = ghost_margin, 0
+        self.skin, self.every, self.prune_step = skin, every, 0     # what plan_decide schedules with (the HIP engine: its inner skin)
         self.box = np.array([b if p else math.inf for b, p in zip(box, periodic)])   # open axes: no minimum image
         self.periodic = periodic
 
@@ -66,6 +67,90 @@ class OracleDomainEngine:
         self.stage2(step, dt)
         if cm_out4 is not None:
             self.cm_momentum(cm_out4)
+
+    # -- the fused step (mhip_set_halo_plan / mhip_vv_halo_start / mhip_vv_halo_mid): same message layout, same delayed removal of
+    #    the centre-of-mass motion (v −= v_cm and x −= v_cm·dt one integrator pass late) as the HIP engine
+    def set_halo_plan(self, first_ghost, recv, recv_dst, n_cm_peers, cm_rows, send_idx, send_shift, send, send_cm_pos):
+        self.hp = dict(first=first_ghost, recv=recv, dst=recv_dst.numpy().astype(np.int64), n_peers=n_cm_peers, cm_rows=cm_rows,
+                       idx=send_idx.numpy().astype(np.int64), shift=send_shift.numpy().astype(np.float64), send=send,
+                       cm_pos=send_cm_pos.numpy().astype(np.int64))
+        self.cm_all = np.zeros((1 + n_cm_peers, 4)); self.halo_cm_in = False; self.cm_own = np.zeros(4)
+
+    def _wrap_owned(self):
+        n = self.n_owned
+        for d in range(3):
+            if self.periodic[d]:
+                L = self.box[d]
+                self.x[:n, d] -= np.floor(self.x[:n, d] / L) * L
+
+    def _pack(self, with_cm):
+        h = self.hp
+        np_dt = h["send"].numpy().dtype
+        out = np.zeros((h["idx"].shape[0], 3), dtype=np_dt)
+        m = h["idx"] >= 0
+        out[m] = (self.x[h["idx"][m]] + h["shift"][m]).astype(np_dt)
+        tot = self.cm_own if with_cm else np.zeros(4)
+        words = np.zeros(3 * max(h["cm_rows"], 1), dtype=np_dt)
+        w = tot.astype(np.float64).view(np_dt)
+        words[: w.shape[0]] = w
+        for q, k in enumerate(h["cm_pos"]):
+            r = q % h["cm_rows"]
+            out[k] = words[3 * r: 3 * r + 3]
+        if with_cm:
+            self.cm_all[0] = tot
+        h["send"].copy_(torch.from_numpy(out))
+
+    def halo_start(self, dt):
+        self.stage1(dt)
+        self._pack(False)
+        self.halo_cm_in = False
+
+    def halo_mid(self, step, dt, cm, stop, cm_parts):
+        h = self.hp
+        buf, dst = h["recv"].numpy(), h["dst"]
+        g = dst >= 0
+        self.x[h["first"] + dst[g]] = buf[g].astype(np.float64)
+        if h["cm_rows"] > 0:
+            for k in np.nonzero(~g)[0]:
+                code = -1 - dst[k]; peer, r = divmod(code, h["cm_rows"])
+                w = self.cm_all[1 + peer].view(buf.dtype)                 # the peer's four doubles as words of the message type
+                hi = min(3 * r + 3, w.shape[0])
+                w[3 * r: hi] = buf[k, : hi - 3 * r]
+        self._forces()
+        n, m = self.n_owned, self.mass[: self.n_owned, None]
+        corrected = False
+        if self.halo_cm_in:
+            t = self.cm_all.sum(axis=0); c = t[:3] / t[3]
+            self.v -= c; self.x[:n] -= c * dt; corrected = True
+        kick = self.f / m * (dt / 2)
+        self.v += kick
+        if cm:
+            self.cm_own = np.concatenate([(self.v * m).sum(axis=0), [float(m.sum())]])
+        if not stop:
+            self.v += kick
+            self.x[:n] += self.v * dt
+            self._wrap_owned()
+            self._pack(cm)
+            self.halo_cm_in = bool(cm)
+        else:
+            if corrected:
+                self._wrap_owned()
+            if cm:
+                cm_parts.zero_(); cm_parts[:4] = torch.from_numpy(self.cm_own)
+            self.halo_cm_in = False
+
+    def plan_state(self, out3):
+        out3[0] = self._disp2(self.x_plan); out3[1] = self._disp2(self.x_prune); out3[2] = float((self.v * self.v).sum(axis=1).max())
+
+    def plan_decide(self, step, red):
+        d2_plan, d2_prune = red[0], red[1]
+        k = max(1, (step - self.prune_step) // self.every)
+        if not (math.isinf(d2_prune) or 2.0 * math.sqrt(d2_prune) * (k + 1) / k > 0.98 * self.skin):
+            return 0
+        if 2.0 * math.sqrt(d2_plan) > 0.95 * self.ghost_margin:
+            return 2
+        self.request_prune(); self.prune_step = step
+        return 1
 
     def _disp2(self, ref):
         d = self.x - ref

@@ -27,7 +27,7 @@ def _worker(rank, world, port, n_side, n_steps, out_dir, gm=0.0, skin=0.2):
     grid = domain.choose_grid(world, case.box)
     bg = domain.BrickGrid(case.box, grid, rank, case.r_list + gm)
     box, origin, periodic = bg.engine_box(pad=0.3)
-    eng = OracleDomainEngine(case.inter_dict(np.float64), case.box, periodic, case.r_list, ghost_margin=gm)
+    eng = OracleDomainEngine(case.inter_dict(np.float64), case.box, periodic, case.r_list, ghost_margin=gm, skin=skin, every=case.rebuild_every)
     run = domain.DomainRun(bg, eng, torch.float64, torch.device("cpu"), case.rebuild_every, ghost_margin=gm, skin=skin)
     run.setup_from_global(case.coords, case.velocities, np.zeros(case.n), case.sigma, case.eps, case.mass)
     # every atom is owned exactly once
@@ -37,7 +37,7 @@ def _worker(rank, world, port, n_side, n_steps, out_dir, gm=0.0, skin=0.2):
     xs, vs = run.gather_global(case.n)
     if rank == 0:
         np.savez(os.path.join(out_dir, "result.npz"), x=xs, v=vs, ghosts=run.n_ghost, migrated=run.stats["migrated"], grid=np.array(grid),
-                 plans=run.stats["plans"], checks=run.stats["plan_checks"], prunes=run.stats["prunes"])
+                 plans=run.stats["plans"], checks=run.stats["plan_checks"], prunes=run.stats["prunes"], fused=int(run.fused))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -58,6 +58,22 @@ def test_decomposed_run_matches_single_domain_oracle(world, tmp_path):
     assert tuple(res["grid"]) == {2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}[world]      # 8 ranks: every axis cut, seven peers each
 
 
+def test_stepwise_host_loop_matches_single_domain_oracle(tmp_path, monkeypatch):
+    """the two-call form of the step (halo_begin / halo_end, Σ m v all-reduced every step, prunes scheduled by the host): what grids
+    with more than two bricks per axis fall back to"""
+    monkeypatch.setenv("MOLLYHIP_HALO_FUSED", "0"); monkeypatch.setenv("MOLLYHIP_HOST_PRUNE", "1")
+    world, n_side, n_steps = 2, 10, 12
+    mp.spawn(_worker, args=(world, _free_port(), n_side, n_steps, str(tmp_path), 0.3, 0.012), nprocs=world, join=True)
+    res = np.load(os.path.join(tmp_path, "result.npz"))
+    case = S.lj_fluid(n_side, dtype=np.float64, rebuild_every=5)
+    o = case.oracle(np.float64)
+    o.vv_run(n_steps, 0.002, remove_cm_every=1)
+    d = res["x"] - o.coords
+    d -= np.round(d / case.box) * case.box
+    assert np.abs(d).max() < 1e-9 and np.abs(res["v"] - o.vel).max() < 1e-8
+    assert int(res["fused"]) == 0 and int(res["prunes"]) >= 1
+
+
 @pytest.mark.parametrize("gm,skin,expect", [(0.3, 0.2, "one plan"), (0.3, 0.012, "prunes"), (0.012, 0.012, "replans")])
 def test_long_lived_ghost_plan_matches_single_domain_oracle(gm, skin, expect, tmp_path):
     """ghost shell r_list + margin: prunes are scheduled collectively from the displacement since the last prune (skin), and a
@@ -73,7 +89,7 @@ def test_long_lived_ghost_plan_matches_single_domain_oracle(gm, skin, expect, tm
     d = res["x"] - o.coords
     d -= np.round(d / case.box) * case.box
     assert np.abs(d).max() < 1e-9 and np.abs(res["v"] - o.vel).max() < 1e-8
-    assert int(res["checks"]) == n_steps // 5
+    assert int(res["checks"]) == n_steps // 5 and int(res["fused"]) == 1
     if expect == "one plan":
         assert int(res["plans"]) == 1 and int(res["prunes"]) == 0     # 0.033 nm of drift in 30 steps: neither skin nor margin used up
     elif expect == "prunes":

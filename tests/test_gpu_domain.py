@@ -42,7 +42,7 @@ def _worker(rank, world, port, n_side, n_steps, dtype_name, out_dir, gm=0.0, hos
     if rank == 0:
         st = eng.stats()
         np.savez(os.path.join(out_dir, "result.npz"), x=xs, v=vs, ghosts=run.n_ghost, migrated=run.stats["migrated"], plans=run.stats["plans"],
-                 checks=run.stats["plan_checks"], outer=st["n_outer_builds"], prunes=st["n_filter_passes"], host_prunes=run.stats["prunes"])
+                 checks=run.stats["plan_checks"], outer=st["n_outer_builds"], prunes=st["n_filter_passes"], host_prunes=run.stats["prunes"], fused=int(run.fused))
     dist.barrier()
     eng.close()
     dist.destroy_process_group()
@@ -66,13 +66,20 @@ def test_hip_domains_match_single_domain_oracle(world, dtype_name, tmp_path):
     assert int(res["ghosts"]) > 0
 
 
-@pytest.mark.parametrize("world,dtype_name,gm,n_steps,host_skin", [(2, "f64", 0.2, 60, None), (8, "f64", 0.2, 40, None), (4, "f32", 0.2, 40, None),
-                                                                    (2, "f64", 0.2, 60, 0.03), (2, "f64", 0.03, 60, 0.02)])
-def test_long_lived_ghost_plans_with_dual_list(world, dtype_name, gm, n_steps, host_skin, tmp_path):
+@pytest.mark.parametrize("world,dtype_name,gm,n_steps,skin_pm,sched", [(1, "f64", 0.2, 60, None, "engine"), (2, "f64", 0.2, 60, None, "engine"), (8, "f64", 0.2, 40, None, "engine"), (4, "f32", 0.2, 40, None, "engine"),
+                                                                          (2, "f64", 0.2, 60, 30, "engine"), (2, "f64", 0.2, 60, 30, "host"), (2, "f64", 0.03, 60, 20, "host")])
+def test_long_lived_ghost_plans_with_dual_list(world, dtype_name, gm, n_steps, skin_pm, sched, tmp_path, monkeypatch):
     """ghost shell r_list + margin: ownership, ghost set and the engine's outer pair list live until a prune comes due after an
-    atom moved margin/2; the prunes (dual pair list with ghosts) are scheduled by the host, collectively.  host_skin shrinks the
-    skin the HOST schedules with (the engine's real skin is 0.2 nm) to force prunes and re-plans within a short run."""
+    atom moved margin/2; the prunes (dual pair list with ghosts) happen on every rank at the same step.  sched "engine": decided by
+    mhip_plan_decide from the all-reduced displacements with the engine's inner skin (skin_pm fixes it, in pm, to force prunes within
+    a short run); "host": by the host against the skin it is given (mhip_plan_disp2_dev + mhip_request_prune; the engine's real skin
+    is 0.2 nm)."""
     n_side = 16                       # bricks 2.9 nm >= 1.2 + 0.2
+    host_skin = None
+    if sched == "host":
+        monkeypatch.setenv("MOLLYHIP_HOST_PRUNE", "1"); host_skin = skin_pm * 1e-3
+    elif skin_pm is not None:
+        monkeypatch.setenv("MOLLYHIP_INNER_SKIN_PM", str(skin_pm)); monkeypatch.setenv("MOLLYHIP_INNER_SKIN_FIXED", "1")
     mp.spawn(_worker, args=(world, _free_port(), n_side, n_steps, dtype_name, str(tmp_path), gm, host_skin), nprocs=world, join=True)
     res = np.load(os.path.join(tmp_path, "result.npz"))
     dtype = np.float32 if dtype_name == "f32" else np.float64
@@ -85,11 +92,11 @@ def test_long_lived_ghost_plans_with_dual_list(world, dtype_name, gm, n_steps, h
         assert np.abs(d).max() < 1e-9 and np.abs(res["v"] - o.vel).max() < 1e-8
     else:
         assert np.abs(d).mean() < 1e-5 and np.abs(d).max() < 2e-3
-    assert int(res["checks"]) == n_steps // 10
-    if host_skin is None:
-        assert int(res["plans"]) == 1 and int(res["outer"]) == 1 and int(res["prunes"]) == 1 and int(res["host_prunes"]) == 0   # one plan, one search, its first prune
-    elif gm >= 0.2:
-        assert int(res["plans"]) == 1 and int(res["outer"]) == 1 and int(res["host_prunes"]) >= 2
-        assert int(res["host_prunes"]) <= int(res["prunes"]) <= 1 + int(res["host_prunes"])   # (a prune requested after the last step is never run)
+    assert int(res["checks"]) == n_steps // 10 and int(res["fused"]) == 1
+    if gm >= 0.2:
+        assert int(res["plans"]) == 1 and int(res["outer"]) == 1                                      # one plan, one search
+        assert int(res["prunes"]) >= 1 and int(res["host_prunes"]) <= int(res["prunes"]) <= 1 + int(res["host_prunes"])   # (a prune requested after the last step is never run)
+        if skin_pm is not None:
+            assert int(res["host_prunes"]) >= 2
     else:
-        assert int(res["plans"]) > 1 and int(res["host_prunes"]) >= 1                                                            # a due prune finds the plan stale
+        assert int(res["plans"]) > 1 and int(res["host_prunes"]) >= 1                                 # a due prune finds the plan stale
