@@ -166,11 +166,12 @@ template <class T> class Engine final : public EngineBase {
     int tri_mode = 0; double tri_bv[9] = {};   // TriclinicBoundary: 0 off, 1 approx_images, 2 exact images; basis vectors row-major
     bool tri_grid = false;                     // … with a cell grid in height-scaled fractional coordinates (else: one cell, every block sees every atom)
     long long grid_key = -1;
+    double skin_in_adapted = 0;
     bool engine_sched = false;   // … unless it hands the reduced displacements to mhip_plan_decide: then the engine's own criteria (inner skin, drift bound) decide
     bool host_prune = false;     // ghost plans: the HOST decides, collectively over the ranks, when the inner list is re-pruned (mhip_request_prune)
     // single list, same idea: a rebuild step whose displacement check shows the list still covers every cutoff sphere is skipped
     bool lazy_single = false; int64_t n_skipped = 0;
-    bool dual = false, dual_disabled = false; int margin_halvings = 0; int early_outer = 0; double outer_margin = 0; int outer_every = 1; int64_t last_outer_step = 0, n_outer = 0, n_filters = 0; T r_in = 0, r_in2 = 0;
+    bool dual = false, dual_disabled = false, margin_zero = false, want_margin_zero = false; int margin_halvings = 0; int early_outer = 0; double outer_margin = 0; int outer_every = 1; int64_t last_outer_step = 0, n_outer = 0, n_filters = 0; T r_in = 0, r_in2 = 0;
     DBuf<int32_t> flags; int32_t* h_flags = nullptr;
     int64_t total_rows = 0;
     // reductions
@@ -285,6 +286,9 @@ template <class T> class Engine final : public EngineBase {
         // dual pair list: search with r_list + margin every `outer_every` rebuild intervals, filter to exactly r_list at
         // every rebuild step (MOLLYHIP_OUTER_MARGIN_PM in picometres, 0 disables; MOLLYHIP_OUTER_EVERY)
         outer_margin = (G.no_list || dual_disabled) ? 0.0 : std::ldexp(env_int("MOLLYHIP_OUTER_MARGIN_PM", 200) * 1e-3, -margin_halvings);
+        // margin 0 keeps the two-list machinery without the wider search: the list is built with r_list and pruned once, right away —
+        // which compacts the tile to the atoms the rows refer to (a tile that needed two LDS segments in fp64 then fits in one)
+        if (margin_zero && n_ghost == 0) outer_margin = 0;
         if (n_ghost > 0) outer_margin = std::min(outer_margin, ghost_margin);   // the shell handed over must cover the outer radius
         outer_every = std::max(1, env_int("MOLLYHIP_OUTER_EVERY", 1000));   // upper bound only: the outer list is re-searched when displacement says so
         strict_cadence = env_int("MOLLYHIP_STRICT_CADENCE", 0) != 0;         // 1: re-prune at every rebuild step, whatever the displacement
@@ -300,12 +304,12 @@ template <class T> class Engine final : public EngineBase {
             if (ip.coul_kind != MHIP_COUL_NONE) rc_max = std::max(rc_max, ip.coul_rc);
             skin = G.no_list ? 0.0 : cfg.r_list - rc_max;
             rc_max_ = rc_max;
-            skin_in = ((n_ghost > 0 || host_prune) && !engine_sched) ? skin : std::min(skin, std::max(1, env_int("MOLLYHIP_INNER_SKIN_PM", 100)) * 1e-3);
+            skin_in = ((n_ghost > 0 || host_prune) && !engine_sched) ? skin : std::min(skin, std::max(skin_in_adapted, std::max(1, env_int("MOLLYHIP_INNER_SKIN_PM", 100)) * 1e-3));   // (a skin the run has grown stays grown)
             const T rp = T(rc_max + skin_in);
             r_prune2 = (skin_in < skin) ? rp * rp : r_in2;
         }
         if (tri_mode) outer_margin = 0;   // one cell, exact images everywhere: plain fixed-cadence lists
-        dual = outer_margin > 0 && outer_every > 1 && lj_cut_ok && coul_cut_ok && skin > 0;   // ghosted: only with a ghost margin (else re-planned every rebuild)
+        dual = (outer_margin > 0 || (margin_zero && n_ghost == 0 && !G.no_list && !dual_disabled)) && outer_every > 1 && lj_cut_ok && coul_cut_ok && skin > 0;   // ghosted: only with a ghost margin (else re-planned every rebuild)
         lazy_single = !dual && !G.no_list && lj_cut_ok && coul_cut_ok && skin > 0 && n_ghost == 0 && !strict_cadence && !tri_mode;
         if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] grid: dual %d margin %.3f skin %.3f lj_ok %d coul_ok %d ghosts %lld\n", (int)dual, outer_margin, skin, (int)lj_cut_ok, (int)coul_cut_ok, (long long)n_ghost);
         const double r_search = G.no_list ? 0.0 : cfg.r_list + (dual ? outer_margin : 0.0);
@@ -438,14 +442,15 @@ template <class T> class Engine final : public EngineBase {
         catch (const ApiError& e) {
             if (e.code != MHIP_ERR_CAPACITY || !dual) throw;
             // dense small systems (a 64-atom block of water with a 1.4 nm shell is half of 6mrr): halve the outer margin before giving up on it
-            if (outer_margin > 0.06) ++margin_halvings; else dual_disabled = true;
-            if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] dual list %s (capacity): %s\n", dual_disabled ? "off" : "margin halved", e.msg.c_str());
+            if (outer_margin > 0.06) ++margin_halvings; else if (!margin_zero && n_ghost == 0) margin_zero = true; else dual_disabled = true;
+            if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] dual list %s (capacity): %s\n", dual_disabled ? "off" : (margin_zero ? "without outer margin" : "margin halved"), e.msg.c_str());
             setup_grid(); choose_blocking(); stale = true;
             rebuild(step_n);
         }
     }
 
     void rebuild_impl(int64_t step_n) {
+        next_check_step = -1;
         if (!params_set || !state_set) throw ApiError{MHIP_ERR_STATE, "set_atoms and set_state must be called before forces"};
         auto t0 = std::chrono::steady_clock::now();
         const int o = cur, n = 1 - cur;
@@ -540,8 +545,9 @@ template <class T> class Engine final : public EngineBase {
     }
 
     // LDS carve-up of the force kernel: the whole tile if it fits the budget, else segments of the budget's size
-    void carve_force_lds(int tile_max) {
-        const size_t budget = std::min<size_t>((size_t)env_int("MOLLYHIP_LDS_BUDGET_KB", 160) * 1024, MAX_LDS_BYTES);
+    void carve_force_lds(int tile_max, size_t reserve = 0) {   // reserve: bytes the caller places behind the carve-up (prune pass: marks + scan scratch)
+        size_t budget = std::min<size_t>((size_t)env_int("MOLLYHIP_LDS_BUDGET_KB", 160) * 1024, MAX_LDS_BYTES);
+        if (budget > reserve + 8192) budget -= reserve;
         const bool per_atom_lj = (ljm == LJ_DIST || ljm == LJ_GENERIC);
         const size_t per_atom = sizeof(T4) + (per_atom_lj ? sizeof(T2) : 0);
         const size_t fixed = std::max((size_t)JS * 4 * BI * sizeof(T), (size_t)BI * sizeof(double)) + 64;
@@ -606,10 +612,14 @@ template <class T> class Engine final : public EngineBase {
         if (!dual || (host_prune && !engine_sched) || !(skin_in < skin) || inner_skin_fixed) return;
         const double need = std::min(skin, 3.0 * drift_per_interval / 0.98);
         if (need <= skin_in) return;
-        skin_in = need;
+        skin_in = need; skin_in_adapted = need;
         const T rp = T(rc_max_ + skin_in);
         r_prune2 = (skin_in < skin) ? rp * rp : r_in2;
         inner_valid = false;
+        // An outer list serves a second prune only while nobody moved (outer_margin + skin − skin_in)/2 since its search, and the inner
+        // list is not due before ≈ skin_in/2: with outer_margin <= 2·skin_in − skin every outer list is pruned exactly once, and its
+        // margin only makes the search dearer.
+        if (n_ghost == 0 && outer_margin > 0 && outer_margin <= 2.0 * skin_in - skin + 0.02) want_margin_zero = true;
         if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] inner skin raised to %.3f nm (drift per check interval %.4f nm)\n", skin_in, drift_per_interval);
     }
     double drift_ahead(double d_so_far, int64_t steps_so_far, int every) const {
@@ -619,15 +629,39 @@ template <class T> class Engine final : public EngineBase {
         return last_vmax * growth * cur_dt * every;
     }
 
+    // Checks between the cadence steps.  A list that cannot be vouched for over a whole interval (the fastest atom could use up the
+    // remaining slack in `every` steps) may still be good for k < every steps: instead of giving it up now, look again in k steps.
+    // Light, fast atoms (hydrogens at 0.5 fs: 0.06 nm of possible drift per 10 steps against 0.1 nm of slack) otherwise cost a
+    // search at nearly every interval.  Only inside mhip_vv_run / mhip_langevin_run, which own the step loop.
+    int64_t next_check_step = -1;
+    const bool fine_checks = env_int("MOLLYHIP_FINE_CHECKS", 1) != 0;
+    bool check_due(int64_t step, int every) const { return step % every == 0 || (next_check_step >= 0 && step >= next_check_step); }
+    // largest k < every such that a displacement of d now stays within `limit` for k more steps (0: none worth a check of its own)
+    int steps_within(double d, double limit, int64_t steps_so_far, int every) const {
+        if (!fine_checks || !in_run) return 0;
+        const double per_step = drift_ahead(d, steps_so_far, 1);
+        if (!(per_step > 0)) return 0;
+        const int k = (int)std::min<double>(std::floor((limit - d) / per_step), every - 1);
+        return k >= 3 ? k : 0;
+    }
+    bool in_run = false;
+    struct InRun { bool& f; explicit InRun(bool& b) : f(b) { f = true; } ~InRun() { f = false; } };
+
     // rebuild step of the cadence (find_neighbors at step_n % n_steps == 0): a fresh search, or — with the dual list —
     // a filter pass, falling back to the search when it is due or an atom moved more than half the margin
     void refresh(int64_t step_n) {
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
+        if (want_margin_zero && !margin_zero && n_ghost == 0) {
+            if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] outer margin dropped (inner skin %.3f nm leaves it no second prune)\n", skin_in);
+            margin_zero = true; setup_grid(); choose_blocking(); stale = true;
+        }
         if (!dual && lazy_single && !stale && step_n > last_prune_step) {
             // single list built with r_list at step last_prune_step: it still holds every pair within the cutoffs unless somebody moved skin/2
             const double d = std::sqrt((double)max_disp2_since(pos_snap_in));
             if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] step %lld: max disp %.5f nm since the build of step %lld (skin %.3f), v_max %.4f\n", (long long)step_n, d, (long long)last_prune_step, skin, last_vmax);
+            next_check_step = -1;
             if (2.0 * (d + drift_ahead(d, step_n - last_prune_step, every)) <= skin * 0.98) { last_build_step = step_n; ++n_skipped; return; }
+            if (const int k = steps_within(d, 0.49 * skin, step_n - last_prune_step, every)) { next_check_step = step_n + k; last_build_step = step_n; ++n_skipped; return; }
         }
         if (!dual || stale || (n_ghost == 0 && ((step_n - last_outer_step) >= (int64_t)outer_every * every || step_n < last_outer_step))) { rebuild(step_n); return; }
         // The inner list (pairs within r_list when it was pruned) provably contains every pair within the cutoffs as long as no atom
@@ -641,6 +675,9 @@ template <class T> class Engine final : public EngineBase {
             const double d = std::sqrt((double)d2), ahead = drift_ahead(d, step_n - last_prune_step, every);
             adapt_inner_skin(ahead);
             reprune = !inner_valid || 2.0 * (d + ahead) > skin_in * 0.98;
+            next_check_step = -1;
+            if (reprune && inner_valid && n_ghost == 0)
+                if (const int k = steps_within(d, 0.49 * skin_in, step_n - last_prune_step, every)) { next_check_step = step_n + k; reprune = false; }
         }
         if (reprune && n_ghost == 0 && !stale) {
             // a prune is only as good as the outer list behind it (nobody moved more than half the margin since the outer search):
@@ -673,14 +710,14 @@ template <class T> class Engine final : public EngineBase {
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         lists_after_set_state();
         if (stale || !(dual || lazy_single) || !keep_lists_on_set_state) { rebuild(first_step); return; }
-        if (first_step % every == 0 && first_step != last_build_step) refresh(first_step);
+        if (check_due(first_step, every) && first_step != last_build_step) refresh(first_step);
     }
 
     void ensure_built(int64_t step_n) {
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         lists_after_set_state();
         if (stale) rebuild(step_n);
-        else if (step_n % every == 0 && step_n != last_build_step) refresh(step_n);
+        else if (check_due(step_n, every) && step_n != last_build_step) refresh(step_n);
     }
 
     // ---------------------------------------------------------------------------------------------
@@ -707,7 +744,8 @@ template <class T> class Engine final : public EngineBase {
         if (dual && !inner_valid && !energy && prune_by_kernel) prune_with_filter();
         const bool use_inner = dual && inner_valid;
         const bool prune = dual && !inner_valid && !energy;
-        carve_force_lds(use_inner ? max_tile_in : max_tile);
+        const size_t prune_extra = prune ? (size_t)((T_cap + 8) & ~7) + ((size_t)BI * JS + 2) * 4 + 32 : 0;   // a tile that fills the LDS is segmented a little earlier
+        carve_force_lds(use_inner ? max_tile_in : max_tile, prune_extra);
         A.T_lds = tile_lds;
         if (use_inner) { A.tile_idx = tile_idx_in.p; A.tile_cnt = tile_cnt_in.p; }
         A.nbr = use_inner ? nbr_in.p : nbr.p; A.wave_rows = use_inner ? wave_rows_in.p : wave_rows.p;
@@ -762,7 +800,7 @@ template <class T> class Engine final : public EngineBase {
             MHIP_HIP(hipStreamSynchronize(stream));
             float d2; std::memcpy(&d2, &h_flags[FLAG_MAX_DISP2], sizeof(float));
             total_rows = h_flags[FLAG_TOTAL_ROWS]; max_tile_in = h_flags[FLAG_MAX_TILE];
-            ++n_filters; ghost_flags_in_ok = false;
+            ++n_filters; ghost_flags_in_ok = false; next_check_step = -1;
             inner_valid = true; prune_disp_exceeded = 2.0 * std::sqrt((double)d2) > prune_margin() * 0.98;
             if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] prune: max disp %.5f nm (margin %.3f) rows %lld exceeded %d calls %lld\n", std::sqrt((double)d2), prune_margin(), (long long)total_rows, (int)prune_disp_exceeded, (long long)n_force_calls);
         }
@@ -788,7 +826,7 @@ template <class T> class Engine final : public EngineBase {
         MHIP_HIP(hipStreamSynchronize(stream));
         float d2; std::memcpy(&d2, &h_flags[FLAG_MAX_DISP2], sizeof(float));
         total_rows = h_flags[FLAG_TOTAL_ROWS]; max_tile_in = h_flags[FLAG_MAX_TILE];
-        ++n_filters; ghost_flags_in_ok = false;
+        ++n_filters; ghost_flags_in_ok = false; next_check_step = -1;
         inner_valid = true; prune_disp_exceeded = 2.0 * std::sqrt((double)d2) > prune_margin() * 0.98;
         if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] prune (kernel): max disp %.5f nm (margin %.3f) rows %lld exceeded %d\n", std::sqrt((double)d2), prune_margin(), (long long)total_rows, (int)prune_disp_exceeded);
     }
@@ -885,7 +923,7 @@ template <class T> class Engine final : public EngineBase {
         // the search radius depends on whether there are ghosts and on the ghost margin, the blocking on the size class: a re-plan
         // that changes neither keeps the grid, its Hilbert table and the (already adapted) capacities
         const int size_class = n_owned >= 100000 ? 2 : (n_owned >= 40000 ? 1 : 0);
-        const long long key = (n_ghost > 0 ? 1 : 0) | (dual_disabled ? 2 : 0) | (size_class << 2) | (margin_halvings << 4) | ((long long)std::llround(ghost_margin * 1e6) << 8);
+        const long long key = (n_ghost > 0 ? 1 : 0) | (dual_disabled ? 2 : 0) | (size_class << 2) | (margin_halvings << 4) | (margin_zero ? 128 : 0) | ((long long)std::llround(ghost_margin * 1e6) << 8);
         if (key != grid_key) { setup_grid(); choose_blocking(); grid_key = key; }
     }
 
@@ -1238,7 +1276,7 @@ template <class T> class Engine final : public EngineBase {
     // (set_atom_counts / set_state → stale) by the host at every rebuild step instead.
     void stage2_cadenced(int64_t step_n, double dt, bool cm, double* cm_parts_ext = nullptr, int n_parts_ext = 0) {
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
-        const bool due = step_n % every == 0 && step_n != last_build_step && (n_ghost == 0 || dual);
+        const bool due = check_due(step_n, every) && step_n != last_build_step && (n_ghost == 0 || dual);
         if (due && dual) refresh(step_n);
         stage2_impl(step_n, dt, cm, cm_parts_ext, n_parts_ext);
         if (due && !dual) refresh(step_n);
@@ -1370,7 +1408,7 @@ template <class T> class Engine final : public EngineBase {
         }
         cur_dt = dt;
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
-        const bool due = step_n % every == 0 && step_n != last_build_step && (n_ghost == 0 || dual);
+        const bool due = check_due(step_n, every) && step_n != last_build_step && (n_ghost == 0 || dual);
         if (due && dual) refresh(step_n);
         step_forces(step_n);
         if (cm_pending) flush_cm();                                               // (a removal registered through the stepwise entry points)
@@ -1431,6 +1469,7 @@ template <class T> class Engine final : public EngineBase {
         if (n_ghost > 0) throw ApiError{MHIP_ERR_STATE, "vv_run is single-domain; drive ghosted domains with vv_stage1/vv_stage2"};
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         cur_dt = dt;
+        InRun guard_in_run(in_run);
         if (first_step == 0 && remove_cm_every != 0) remove_cm();                 // simulators.jl:563
         vv_init(first_step);                                                      // :564-571
         // fused stepping: first kick + drift once, then ONE integrator launch between consecutive force passes (k_vv_mid), the
@@ -1446,16 +1485,16 @@ template <class T> class Engine final : public EngineBase {
             // find_neighbors at step % n_steps == 0 (:645, neighbors.jl:396) builds the list from the coordinates of THIS step; it is
             // scheduled before the force pass so that, with the dual pair list, that pass can prune the outer list on the way.
             // Forces are unaffected: the pass walks a superset of the old list and every interaction has a cutoff <= r_list.
-            if (pre && step % every == 0) refresh(step);
+            if (pre && check_due(step, every)) refresh(step);
             const bool cm = remove_cm_every != 0 && step % remove_cm_every == 0;
             if (!fused) {
                 stage2_impl(step, dt, cm);                                        // :612-628
                 apply_coupling(step);                                             // :630
-                if (!pre && step % every == 0) refresh(step);
+                if (!pre && check_due(step, every)) refresh(step);
                 continue;
             }
             step_forces(step);
-            if (!pre && step % every == 0) { fold_side_forces(); refresh(step); }   // the sort permutes vel / frc with the atoms; Σ m v does not care
+            if (!pre && check_due(step, every)) { fold_side_forces(); refresh(step); }   // the sort permutes vel / frc with the atoms; Σ m v does not care
             const int nb = std::min(cdiv(n_owned, 256), 1024);
             const double* cm_in = cm_pending == 2 ? cm_src() : (const double*)nullptr;
             double* cm_out = cm ? cm_step.p + (size_t)half * 4 * 1024 : (double*)nullptr;
@@ -1516,6 +1555,7 @@ template <class T> class Engine final : public EngineBase {
         if (!(kT >= 0) || !(friction >= 0)) throw ApiError{MHIP_ERR_INVALID, "temperature and friction must be non-negative"};
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         cur_dt = dt;
+        InRun guard_in_run(in_run);
         if (first_step == 0 && remove_cm_every != 0) remove_cm();                 // :1115
         start_lists(first_step);                                                  // :1116
         const double vs = std::exp(-dt * friction);                               // :1091-1092
@@ -1537,7 +1577,7 @@ template <class T> class Engine final : public EngineBase {
             cm_pending = 0; cm_ext = nullptr; frc_valid = false;
             if (cm) { cm_pending = 2; cm_ext = cm_out; n_cm_step = nb; half ^= 1; }   // :1204-1206, subtracted by the next consumer
             apply_coupling(step);                                                 // :1208
-            if (step % every == 0) refresh(step);                                 // :1211 — the next force pass prunes the fresh outer list
+            if (check_due(step, every)) refresh(step);                            // :1211 — the next force pass prunes the fresh outer list
         }
         flush_cm();
         MHIP_HIP(hipGetLastError());
