@@ -165,19 +165,24 @@ template <class T> struct BondedArgs {
     GridP<T> G; InterP<T> I;
 };
 
-// SLOTS: the forces go to per-term slots (A.frc is then the slot array, type ranges at slot_base[]) instead of atomics
+// SLOTS: the forces go to per-term slots (A.frc is then the slot array, type ranges at slot_base[]) instead of atomics.
+// (blk, lane, bt) = term block, lane in it, lanes per term block: a kernel of its own uses its grid; the fused launch of
+// step_fused.h runs four 64-lane term blocks in each of its 256-lane workgroups.
 template <class T, bool ENERGY, bool SLOTS>
-__global__ void k_bonded(BondedArgs<T> A) {
-    const int blk = blockIdx.x;
-    double e = 0;
+__device__ inline void bonded_terms(const BondedArgs<T>& A, int blk, int lane, int bt, double& e) {
     auto run = [&](auto&& mk) {
-        if (blk < A.blk_b) { const int64_t t = (int64_t)blk * blockDim.x + threadIdx.x; d_bonds<T, ENERGY>(t, A.n_b, A.b_i, A.b_j, A.b_k, A.b_r0, A.inv, A.pos, mk(A.slot_base[0] + 2 * t), e, A.G); }
-        else if (blk < A.blk_b + A.blk_a) { const int64_t t = (int64_t)(blk - A.blk_b) * blockDim.x + threadIdx.x; d_angles<T, ENERGY>(t, A.n_a, A.a_i, A.a_j, A.a_k, A.a_kth, A.a_th0, A.inv, A.pos, mk(A.slot_base[1] + 3 * t), e, A.G); }
-        else if (blk < A.blk_b + A.blk_a + A.blk_t) { const int64_t t = (int64_t)(blk - A.blk_b - A.blk_a) * blockDim.x + threadIdx.x; d_torsions<T, ENERGY>(t, A.n_t, A.t_i, A.t_j, A.t_k, A.t_l, A.t_per, A.t_phase, A.t_k0, A.inv, A.pos, mk(A.slot_base[2] + 4 * t), e, A.G); }
-        else { const int64_t t = (int64_t)(blk - A.blk_b - A.blk_a - A.blk_t) * blockDim.x + threadIdx.x; d_ewald_excl<T, ENERGY>(t, A.n_x, A.x_i, A.x_j, A.inv, A.pos, mk(A.slot_base[3] + 2 * t), e, A.G, A.I); }
+        if (blk < A.blk_b) { const int64_t t = (int64_t)blk * bt + lane; d_bonds<T, ENERGY>(t, A.n_b, A.b_i, A.b_j, A.b_k, A.b_r0, A.inv, A.pos, mk(A.slot_base[0] + 2 * t), e, A.G); }
+        else if (blk < A.blk_b + A.blk_a) { const int64_t t = (int64_t)(blk - A.blk_b) * bt + lane; d_angles<T, ENERGY>(t, A.n_a, A.a_i, A.a_j, A.a_k, A.a_kth, A.a_th0, A.inv, A.pos, mk(A.slot_base[1] + 3 * t), e, A.G); }
+        else if (blk < A.blk_b + A.blk_a + A.blk_t) { const int64_t t = (int64_t)(blk - A.blk_b - A.blk_a) * bt + lane; d_torsions<T, ENERGY>(t, A.n_t, A.t_i, A.t_j, A.t_k, A.t_l, A.t_per, A.t_phase, A.t_k0, A.inv, A.pos, mk(A.slot_base[2] + 4 * t), e, A.G); }
+        else { const int64_t t = (int64_t)(blk - A.blk_b - A.blk_a - A.blk_t) * bt + lane; d_ewald_excl<T, ENERGY>(t, A.n_x, A.x_i, A.x_j, A.inv, A.pos, mk(A.slot_base[3] + 2 * t), e, A.G, A.I); }
     };
     if constexpr (SLOTS) run([&](int64_t first) { return SlotSink<T>{A.frc, first}; });
     else run([&](int64_t) { return AtomicSink<T>{A.frc}; });
+}
+template <class T, bool ENERGY, bool SLOTS>
+__global__ void k_bonded(BondedArgs<T> A) {
+    double e = 0;
+    bonded_terms<T, ENERGY, SLOTS>(A, (int)blockIdx.x, (int)threadIdx.x, (int)blockDim.x, e);
     if constexpr (ENERGY) block_sum_to(e, A.part);
 }
 
@@ -198,10 +203,12 @@ __global__ void k_bonded_virial(BondedArgs<T> A, int n_blocks_total) {
 // shuffle tree adds them): a backbone atom sits in dozens of torsion terms, and one lane walking them serially set the kernel's
 // duration.  Fixed order → bit-reproducible.
 constexpr int COLLECT_LANES = 8;
-template <class T>
-__global__ void k_bonded_collect(int64_t n_owned, const int32_t* __restrict__ orig, const int32_t* __restrict__ role_start, const int32_t* __restrict__ role_slot,
-                                 const typename Vec<T>::T4* __restrict__ slots, typename Vec<T>::T4* frc) {
-    const int64_t gt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, s = gt / COLLECT_LANES;
+// gt = global lane number (COLLECT_LANES per atom).  ASSIGN: out[s] = the sum (zero for atoms without terms) instead of out[s] += it —
+// for a launch that runs next to another writer of the force array (step_fused.h) and leaves its share in a side array.
+template <class T, bool ASSIGN>
+__device__ inline void bonded_collect_lane(int64_t gt, int64_t n_owned, const int32_t* __restrict__ orig, const int32_t* __restrict__ role_start, const int32_t* __restrict__ role_slot,
+                                           const typename Vec<T>::T4* __restrict__ slots, typename Vec<T>::T4* out) {
+    const int64_t s = gt / COLLECT_LANES;
     const int l = (int)(gt % COLLECT_LANES);
     const bool live = s < n_owned;
     int r0 = 0, r1 = 0;
@@ -210,11 +217,18 @@ __global__ void k_bonded_collect(int64_t n_owned, const int32_t* __restrict__ or
     for (int r = r0 + l; r < r1; r += COLLECT_LANES) { const auto v = slots[role_slot[r]]; fx += v.x; fy += v.y; fz += v.z; }
 #pragma unroll
     for (int o = COLLECT_LANES / 2; o > 0; o >>= 1) { fx += __shfl_xor(fx, o, 64); fy += __shfl_xor(fy, o, 64); fz += __shfl_xor(fz, o, 64); }
-    if (live && l == 0 && r1 > r0) {
-        auto f = frc[s];
+    if constexpr (ASSIGN) {
+        if (live && l == 0) out[s] = make4<T>(fx, fy, fz, T(0));
+    } else if (live && l == 0 && r1 > r0) {
+        auto f = out[s];
         f.x += fx; f.y += fy; f.z += fz;
-        frc[s] = f;
+        out[s] = f;
     }
+}
+template <class T>
+__global__ void k_bonded_collect(int64_t n_owned, const int32_t* __restrict__ orig, const int32_t* __restrict__ role_start, const int32_t* __restrict__ role_slot,
+                                 const typename Vec<T>::T4* __restrict__ slots, typename Vec<T>::T4* frc) {
+    bonded_collect_lane<T, false>(blockIdx.x * (int64_t)blockDim.x + threadIdx.x, n_owned, orig, role_start, role_slot, slots, frc);
 }
 
 template <class U> struct HBuf {   // device array filled from a host array once
@@ -289,6 +303,10 @@ template <class T> struct Bonded {
         return A;
     }
     int n_blocks() const { return cdiv(b_i.n, BT) + cdiv(a_i.n, BT) + cdiv(t_i.n, BT) + cdiv(x_i.n, BT); }
+    static bool use_atomics() { static const bool a = [] { const char* v = std::getenv("MOLLYHIP_BONDED_ATOMICS"); return v && *v && std::atoi(v) != 0; }(); return a; }
+    // the slot path's tables for the current capacity (rebuilt after any set_*); args for the term kernel writing into the slots
+    void ensure_roles(hipStream_t s, int64_t cap) { if (roles_dirty || roles_cap != cap) { MHIP_HIP(hipStreamSynchronize(s)); build_roles(cap); } }
+    BondedArgs<T> slot_args(const GridP<T>& G, const InterP<T>& I, const T4* pos, const int32_t* inv) const { return args(G, I, pos, inv, slots, nullptr); }
 
     // forces ADDED to frc (sorted order; `orig` = sorted→caller map of the n_owned owned atoms, `cap` = context capacity).
     // MOLLYHIP_BONDED_ATOMICS=1: the one-launch scatter with float atomics.

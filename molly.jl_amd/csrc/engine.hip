@@ -15,6 +15,7 @@
 #include "bonded.h"
 #include "stochastic.h"
 #include "pme.h"
+#include "step_fused.h"
 #include "hilbert.h"
 #include "kernels.h"
 #include "forces_launch.h"
@@ -813,6 +814,7 @@ template <class T> class Engine final : public EngineBase {
     // the prune as a kernel of its own (k_filter into the inner arrays), followed by a plain force pass over the fresh inner list
     const bool prune_by_kernel = env_int("MOLLYHIP_PRUNE_KERNEL", 0) != 0;
     const bool inner_skin_fixed = env_int("MOLLYHIP_INNER_SKIN_FIXED", 0) != 0;
+    const bool fuse_small = env_int("MOLLYHIP_FUSE_SMALL", 1) != 0;
     const bool no_soa = env_int("MOLLYHIP_NO_SOA", 0) != 0; const int lds_pad_kb = env_int("MOLLYHIP_LDS_PAD_KB", 0);
     void prune_with_filter() {
         pos_snap_in.reserve(cap);
@@ -880,6 +882,16 @@ template <class T> class Engine final : public EngineBase {
             redo = true;
         }
         pend_a = pend_b = nullptr;
+        // small systems: charge spreading next to the bonded terms, force interpolation next to the bonded sums (step_fused.h)
+        if (!overlap && fuse_small && bonded.any() && pme.on() && !Bonded<T>::use_atomics() && n_ghost == 0) {
+            frc_side[0].reserve(cap);
+            prof.begin(6, stream);
+            launch_pme_bonded_fused<T>(stream, pme, bonded, G, I, n_owned, cap, pos[cur].p, inv.p, orig[cur].p, frc[cur].p, frc_side[0].p);
+            prof.end(6, stream);
+            pend_a = frc_side[0].p;
+            frc_valid = true;
+            return;
+        }
         if (redo || !side_b) { if (bonded.any()) { prof.begin(5, stream); bonded.launch_forces(stream, G, I, pos[cur].p, inv.p, frc[cur].p, orig[cur].p, n_owned, cap); prof.end(5, stream); } }
         else { MHIP_HIP(hipStreamWaitEvent(stream, ev_side[0], 0)); pend_a = frc_side[0].p; }
         if (redo || !side_p) launch_pme_forces();

@@ -100,13 +100,13 @@ __device__ inline void pme_atom_tables(int64_t a0, int64_t n_atoms, const typena
 constexpr int PME_BOX_BYTES = 24 * 1024;   // LDS sub-mesh
 
 template <class T, int ORDER, int PME_SB>
-__global__ void __launch_bounds__(256) k_pme_spread(int64_t n_atoms, const typename Vec<T>::T4* __restrict__ pos, T* rgrid, PmeP<T> P) {
+__device__ inline void pme_spread_blocks(int bid, int nblk, int64_t n_atoms, const typename Vec<T>::T4* __restrict__ pos, T* rgrid, const PmeP<T>& P) {
     __shared__ T l_w[3 * ORDER * PME_SB]; __shared__ int l_i[3 * PME_SB]; __shared__ T l_q[PME_SB];
     constexpr int PME_BOX = PME_BOX_BYTES / (int)sizeof(T);
     __shared__ T l_box[PME_BOX]; __shared__ int l_lo[3], l_hi[3];
     const int tid = threadIdx.x, sub = tid & 31, hw = tid >> 5;
     T* mesh = rgrid;
-    for (int64_t a0 = (int64_t)blockIdx.x * PME_SB; a0 < n_atoms; a0 += (int64_t)gridDim.x * PME_SB) {
+    for (int64_t a0 = (int64_t)bid * PME_SB; a0 < n_atoms; a0 += (int64_t)nblk * PME_SB) {
         __syncthreads();
         // phase 1 (one thread per atom)
         if (tid < PME_SB) {
@@ -204,13 +204,18 @@ __global__ void __launch_bounds__(256) k_pme_spread(int64_t n_atoms, const typen
     }
 }
 
+template <class T, int ORDER, int PME_SB>
+__global__ void __launch_bounds__(256) k_pme_spread(int64_t n_atoms, const typename Vec<T>::T4* __restrict__ pos, T* rgrid, PmeP<T> P) {
+    pme_spread_blocks<T, ORDER, PME_SB>((int)blockIdx.x, (int)gridDim.x, n_atoms, pos, rgrid, P);
+}
+
 // interpolate_force_inner! (:805-840): Fs[i] -= q (∂θ/∂r ⊗ θ ⊗ θ) · φ, same two phases, shuffle reduction inside the half-wave
 template <class T, int ORDER>
-__global__ void __launch_bounds__(256) k_pme_gather(int64_t n_atoms, const typename Vec<T>::T4* __restrict__ pos, const T* __restrict__ grid,
-                                                    typename Vec<T>::T4* frc, PmeP<T> P) {
+__device__ inline void pme_gather_blocks(int bid, int nblk, int64_t n_atoms, const typename Vec<T>::T4* __restrict__ pos, const T* __restrict__ grid,
+                                         typename Vec<T>::T4* frc, const PmeP<T>& P) {
     __shared__ T l_w[6 * ORDER * PME_AB]; __shared__ int l_i[3 * PME_AB]; __shared__ T l_q[PME_AB];
     const int tid = threadIdx.x, sub = tid & 31, hw = tid >> 5;
-    for (int64_t a0 = (int64_t)blockIdx.x * PME_AB; a0 < n_atoms; a0 += (int64_t)gridDim.x * PME_AB) {
+    for (int64_t a0 = (int64_t)bid * PME_AB; a0 < n_atoms; a0 += (int64_t)nblk * PME_AB) {
         __syncthreads();
         pme_atom_tables<T, ORDER, true>(a0, n_atoms, pos, P, l_w, l_i, l_q);
         __syncthreads();
@@ -249,6 +254,12 @@ __global__ void __launch_bounds__(256) k_pme_gather(int64_t n_atoms, const typen
             }
         }
     }
+}
+
+template <class T, int ORDER>
+__global__ void __launch_bounds__(256) k_pme_gather(int64_t n_atoms, const typename Vec<T>::T4* __restrict__ pos, const T* __restrict__ grid,
+                                                    typename Vec<T>::T4* frc, PmeP<T> P) {
+    pme_gather_blocks<T, ORDER>((int)blockIdx.x, (int)gridDim.x, n_atoms, pos, grid, frc, P);
 }
 
 // The 3-D transform, one launch per axis, as direct DFTs on LDS-staged line tiles: a block stages C whole lines ([j][c],
