@@ -346,10 +346,12 @@ int32_t mhip_vv_halo_mid(mhip_ctx* ctx, int64_t step_n, double dt, int32_t flags
 /* The prune / re-plan decision of a ghost plan by the engine's own criteria (tight inner skin + drift bound, as on a single domain):
  * out3_dev = { max |x - x_plan|^2, max |x - x_prune|^2, max |v|^2 of the owned atoms } as device floats; MAX-all-reduce them, hand
  * the result (host memory) to mhip_plan_decide on EVERY rank.  *action: 0 = nothing, 1 = the next force pass re-prunes the outer
- * list (already arranged), 2 = re-plan (migrate, new ghost plan).  Supersedes mhip_plan_disp2_dev + mhip_request_prune, which keep
+ * list (already arranged), 2 = re-plan (migrate, new ghost plan).  check_in (nullable): with action 0, *check_in = k > 0 asks for the
+ * next check k steps from now instead of at the next cadence step — the list cannot be vouched for over a whole interval, but for k
+ * steps (0: regular cadence; NULL: such lists are re-pruned now).  Supersedes mhip_plan_disp2_dev + mhip_request_prune, which keep
  * scheduling against the reference's skin r_list - cutoff. */
 int32_t mhip_plan_state_dev(mhip_ctx* ctx, float* out3_dev);
-int32_t mhip_plan_decide(mhip_ctx* ctx, int64_t step_n, const float* reduced3, int32_t* action);
+int32_t mhip_plan_decide(mhip_ctx* ctx, int64_t step_n, const float* reduced3, int32_t* action, int32_t* check_in);
 
 #ifdef __cplusplus
 }

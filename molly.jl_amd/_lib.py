@@ -123,7 +123,7 @@ SIGNATURES = {
     "mhip_vv_halo_start": (_I32, [_P, _D]),
     "mhip_vv_halo_mid": (_I32, [_P, _I64, _D, _I32, _P, _I32]),
     "mhip_plan_state_dev": (_I32, [_P, _P]),
-    "mhip_plan_decide": (_I32, [_P, _I64, C.POINTER(C.c_float), C.POINTER(_I32)]),
+    "mhip_plan_decide": (_I32, [_P, _I64, C.POINTER(C.c_float), C.POINTER(_I32), C.POINTER(_I32)]),
 }
 
 

@@ -80,7 +80,7 @@ struct EngineBase {
     virtual void set_ghost_margin(double) = 0;
     virtual void plan_disp2_dev(float*) = 0;
     virtual void plan_state_dev(float*) = 0;
-    virtual int plan_decide(int64_t, const float*) = 0;
+    virtual int plan_decide(int64_t, const float*, int32_t*) = 0;
     virtual void set_halo_plan(const mhip_halo_plan*) = 0;
     virtual void halo_start(double) = 0;
     virtual void halo_mid(int64_t, double, int32_t, double*, int32_t) = 0;
@@ -638,8 +638,8 @@ template <class T> class Engine final : public EngineBase {
     const bool fine_checks = env_int("MOLLYHIP_FINE_CHECKS", 1) != 0;
     bool check_due(int64_t step, int every) const { return step % every == 0 || (next_check_step >= 0 && step >= next_check_step); }
     // largest k < every such that a displacement of d now stays within `limit` for k more steps (0: none worth a check of its own)
-    int steps_within(double d, double limit, int64_t steps_so_far, int every) const {
-        if (!fine_checks || !in_run) return 0;
+    int steps_within(double d, double limit, int64_t steps_so_far, int every, bool caller_owns_loop = false) const {
+        if (!fine_checks || !(in_run || caller_owns_loop)) return 0;
         const double per_step = drift_ahead(d, steps_so_far, 1);
         if (!(per_step > 0)) return 0;
         const int k = (int)std::min<double>(std::floor((limit - d) / per_step), every - 1);
@@ -1353,7 +1353,8 @@ template <class T> class Engine final : public EngineBase {
     // single-domain engine (refresh): 0 = the inner list lives on, 1 = the next force pass re-prunes the outer list, 2 = the ghost
     // plan cannot vouch for a prune any more (or there is no margin): re-plan.  The inner list is pruned with the tight inner skin
     // (rc + skin_in, grown when the fastest atoms would outrun a third of it between two checks) as in mhip_vv_run.
-    int plan_decide(int64_t step_n, const float* red3) override {
+    int plan_decide(int64_t step_n, const float* red3, int32_t* check_in) override {
+        if (check_in) *check_in = 0;
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         if (!engine_sched) {   // first use: from now on the inner list may be tighter than r_list
             engine_sched = true;
@@ -1369,6 +1370,9 @@ template <class T> class Engine final : public EngineBase {
             const double d = std::sqrt((double)red3[1]), ahead = drift_ahead(d, step_n - last_prune_step, every);
             adapt_inner_skin(ahead);
             reprune = !inner_valid || 2.0 * (d + ahead) > skin_in * 0.98;
+            // not good for a whole interval, but for k steps: the host looks again then (it owns the step loop)
+            if (reprune && inner_valid && check_in)
+                if (const int k = steps_within(d, 0.49 * skin_in, step_n - last_prune_step, every, true)) { *check_in = k; return 0; }
         }
         if (!reprune) return 0;
         // the prune runs inside the NEXT force pass, one step from now: leave it that step of headroom
@@ -1823,8 +1827,8 @@ int32_t mhip_set_ghost_margin(mhip_ctx* ctx, double m) { NEED_CTX(); return guar
 int32_t mhip_plan_disp2_dev(mhip_ctx* ctx, float* out) { NEED_CTX(); return guard(ctx, [&] { if (!out) throw mhip::ApiError{MHIP_ERR_INVALID, "null output"}; ctx->e->plan_disp2_dev(out); }); }
 int32_t mhip_request_prune(mhip_ctx* ctx) { NEED_CTX(); return guard(ctx, [&] { ctx->e->request_prune(); }); }
 int32_t mhip_plan_state_dev(mhip_ctx* ctx, float* out3) { NEED_CTX(); return guard(ctx, [&] { if (!out3) throw mhip::ApiError{MHIP_ERR_INVALID, "null output"}; ctx->e->plan_state_dev(out3); }); }
-int32_t mhip_plan_decide(mhip_ctx* ctx, int64_t step_n, const float* reduced3, int32_t* action) {
-    NEED_CTX(); return guard(ctx, [&] { if (!reduced3 || !action) throw mhip::ApiError{MHIP_ERR_INVALID, "null argument"}; *action = ctx->e->plan_decide(step_n, reduced3); });
+int32_t mhip_plan_decide(mhip_ctx* ctx, int64_t step_n, const float* reduced3, int32_t* action, int32_t* check_in) {
+    NEED_CTX(); return guard(ctx, [&] { if (!reduced3 || !action) throw mhip::ApiError{MHIP_ERR_INVALID, "null argument"}; *action = ctx->e->plan_decide(step_n, reduced3, check_in); });
 }
 int32_t mhip_set_halo_plan(mhip_ctx* ctx, const mhip_halo_plan* plan) { NEED_CTX(); return guard(ctx, [&] { ctx->e->set_halo_plan(plan); }); }
 int32_t mhip_vv_halo_start(mhip_ctx* ctx, double dt) { NEED_CTX(); return guard(ctx, [&] { ctx->e->halo_start(dt); }); }

@@ -219,10 +219,11 @@ class HipDomainEngine:
         self._chk(self.L.mhip_plan_state_dev(self.ctx, self._p(out3_f32)))
 
     def plan_decide(self, step, reduced3):
+        """(action, check_in): 0 nothing / 1 prune arranged / 2 re-plan; check_in > 0 = look again that many steps from now"""
         arr = (C.c_float * 3)(*reduced3)
-        action = C.c_int32(0)
-        self._chk(self.L.mhip_plan_decide(self.ctx, step, arr, C.byref(action)))
-        return action.value
+        action, check_in = C.c_int32(0), C.c_int32(0)
+        self._chk(self.L.mhip_plan_decide(self.ctx, step, arr, C.byref(action), C.byref(check_in)))
+        return action.value, check_in.value
 
     def plan_disp2(self, out2_f32):       # device float[2]: max displacement² since the plan / since the last prune
         self._chk(self.L.mhip_plan_disp2_dev(self.ctx, self._p(out2_f32)))
@@ -276,6 +277,7 @@ class DomainRun:
         self.cm_buf = torch.zeros(4 * CM_PARTS, dtype=torch.float64, device=device)
         self.d2_buf = torch.zeros(2, dtype=torch.float32, device=device)
         self.d3_buf = torch.zeros(3, dtype=torch.float32, device=device)
+        self.next_check = -1                 # an extra check between two cadence steps, asked for by plan_decide
         # fused stepping (one engine call per step, Σ m v on the ghost message): needs every other rank as a peer — 1, 2, 4, 8 bricks
         peers = {p for (p, _, _) in grid.dirs}
         self.fused = (_os.environ.get("MOLLYHIP_HALO_FUSED", "1") != "0" and hasattr(engine, "halo_mid") and len(peers) == grid.world - 1)
@@ -448,7 +450,8 @@ class DomainRun:
             self._all_reduce(self.d3_buf, dist.ReduceOp.MAX)
             red = [float(v) for v in self.d3_buf.tolist()]          # the one host sync per rebuild interval
             self.stats["plan_checks"] += 1
-            action = 2 if math.isinf(red[0]) else self.e.plan_decide(step_n, red)
+            action, check_in = (2, 0) if math.isinf(red[0]) else self.e.plan_decide(step_n, red)
+            self.next_check = step_n + check_in if check_in > 0 else -1
             if action == 1:
                 self.prune_step = step_n
                 self.stats["prunes"] += 1
@@ -486,7 +489,7 @@ class DomainRun:
             self.e.halo_start(dt)
         for s in range(first_step + 1, last + 1):
             cm = bool(remove_cm_every) and s % remove_cm_every == 0
-            replan = s % self.every == 0 and self._replan_due(s)
+            replan = (s % self.every == 0 or s == self.next_check) and self._replan_due(s)
             stop = replan or s == last
             work = self._a2a_async(self.f_recv.view(-1), self.f_send.view(-1), self._frc3, self._fsc3) if (exchange and self.overlap) else None
             if self.overlap and self.e.halo_interior(s):

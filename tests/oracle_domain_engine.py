@@ -146,11 +146,11 @@ class OracleDomainEngine:
         d2_plan, d2_prune = red[0], red[1]
         k = max(1, (step - self.prune_step) // self.every)
         if not (math.isinf(d2_prune) or 2.0 * math.sqrt(d2_prune) * (k + 1) / k > 0.98 * self.skin):
-            return 0
+            return 0, 0
         if 2.0 * math.sqrt(d2_plan) > 0.95 * self.ghost_margin:
-            return 2
+            return 2, 0
         self.request_prune(); self.prune_step = step
-        return 1
+        return 1, 0
 
     def _disp2(self, ref):
         d = self.x - ref

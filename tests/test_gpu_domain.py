@@ -92,7 +92,7 @@ def test_long_lived_ghost_plans_with_dual_list(world, dtype_name, gm, n_steps, s
         assert np.abs(d).max() < 1e-9 and np.abs(res["v"] - o.vel).max() < 1e-8
     else:
         assert np.abs(d).mean() < 1e-5 and np.abs(d).max() < 2e-3
-    assert int(res["checks"]) == n_steps // 10 and int(res["fused"]) == 1
+    assert int(res["checks"]) >= n_steps // 10 and int(res["fused"]) == 1      # (plus the extra checks the engine asks for when a list is good for a few more steps only)
     if gm >= 0.2:
         assert int(res["plans"]) == 1 and int(res["outer"]) == 1                                      # one plan, one search
         assert int(res["prunes"]) >= 1 and int(res["host_prunes"]) <= int(res["prunes"]) <= 1 + int(res["host_prunes"])   # (a prune requested after the last step is never run)
