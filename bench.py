@@ -139,18 +139,37 @@ def main():
         if equil:
             run(0, equil)
         run(equil, args.warmup)                                      # untimed warm-up
+        first = equil + args.warmup
+        # A window shorter than the life of an outer pair list (≈ 100 steps at 1M atoms; its search costs 2.5 ms = 17 steps) would
+        # measure whether a search happens to fall into it — 0.15 or 0.30 ms/step for the same code.  Short windows are therefore
+        # placed at a defined point of the list cycle: mid-cycle, 16 steps after a prune of the inner list, so that they contain the
+        # next prune (every ≈ 25 steps: their fair share is 0.8) and no outer search (fair share 0.2 × 2.5 ms, in the record under
+        # roofline.stage_ms_per_call).  The record says so; the 2000-step default contains twenty whole cycles.
+        window = "as scheduled"
+        if args.steps < 100 and equil > 0:
+            def wait_for(key):
+                nonlocal first
+                n0 = s.stats()[key]
+                for _ in range(200):
+                    if s.stats()[key] != n0:
+                        return True
+                    run(first, 2); first += 2
+                return False
+            if wait_for("n_outer_builds") and wait_for("n_filter_passes"):
+                run(first, 16); first += 16
+                window = "mid-cycle: starts 16-18 steps after a prune of the inner pair list (contains the next prune, no outer search)"
         s._check(L.mhip_synchronize(ctx))
         t0 = time.perf_counter()
-        run(equil + args.warmup, args.steps)                         # timed: exactly K steps; returns after a stream sync
+        run(first, args.steps)                                       # timed: exactly K steps; returns after a stream sync
         s._check(L.mhip_synchronize(ctx))
         ms_per_step = (time.perf_counter() - t0) * 1e3 / args.steps
         # separate pass with hipEvent stage timers on the engine's stream (never mixed into the timed region)
         s._check(L.mhip_set_profiling(ctx, 1))
-        run(equil + args.warmup + args.steps, args.profile_steps)
+        run(first + args.steps, args.profile_steps)
         st = s.stats()
         s._check(L.mhip_set_profiling(ctx, 0))
         s._check(L.mhip_check_finite(ctx))
-        extra = {}
+        extra = {"timed_window": window}
 
     steps_s = 1e3 / ms_per_step
     ns_day = steps_s * (dt * 1e3) * 86400 * 1e-6        # dt [ps] → fs
@@ -182,12 +201,13 @@ def main():
                                 "6mrr_rf64": "6mrr reaction-field Coulomb + LJ + bonded, Float64, dt 0.5 fs"}[args.workload],
                    "name": args.workload, "integrator": args.integrator, "n_atoms": n_atoms, "dt_fs": dt * 1e3, "rebuild_every": case.rebuild_every,
                    "parallelism": "single domain" if world == 1 else extra.get("parallelism"),
-                   "block_atoms": st["block_atoms"], "j_split": st["j_split"], "pairs_half_list": st["n_pairs_full"] // 2},
+                   "block_atoms": st["block_atoms"], "j_split": st["j_split"], "pairs_half_list": st["n_pairs_full"] // 2,
+                   "timed_window": extra.get("timed_window", "as scheduled")},
         "roofline": roofline,
         "engine": {k: st[k] for k in ("n_blocks", "block_atoms", "j_split", "max_tile_atoms", "tile_atoms_total", "lds_bytes",
                                       "n_list_slots", "n_pairs_full", "minimg_mode", "n_rebuilds", "n_outer_builds", "n_filter_passes", "last_rebuild_ms")},
     }
-    line.update({k: v for k, v in extra.items() if k != "parallelism"})
+    line.update({k: v for k, v in extra.items() if k not in ("parallelism", "timed_window")})
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(case, dtype, dt)
     os.write(json_fd, (json.dumps(line) + "\n").encode())

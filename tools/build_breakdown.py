@@ -9,7 +9,11 @@ if len(sys.argv) > 1:
     import molly_loader
     from tests import systems as S
     m = molly_loader.load()
-    case = S.lj_fluid(int(sys.argv[1]), seed=4, dtype=np.float32)
+    if sys.argv[1] == "6mrr":
+        from tests import golden6mrr
+        case = golden6mrr.case("ewald", dtype=np.float32, bonded=False, pme=False)
+    else:
+        case = S.lj_fluid(int(sys.argv[1]), seed=4, dtype=np.float32)
     s = case.system(m, np.float32)
     s.push_state(velocities=True)
     L = m.lib(); ctx = s.engine()
@@ -29,5 +33,5 @@ if len(sys.argv) > 1:
 else:
     for dbg in ("0", "1", "2", "3", "8", "7", "4"):
         env = dict(os.environ, MOLLYHIP_BUILD_DEBUG=dbg, MOLLYHIP_SET_STATE_REBUILDS="1")
-        r = subprocess.run([sys.executable, __file__, "100"], env=env, capture_output=True, text=True)
+        r = subprocess.run([sys.executable, __file__, os.environ.get("BUILD_BREAKDOWN_CASE", "100")], env=env, capture_output=True, text=True)
         print(r.stdout.strip().split("\n")[-1] if r.stdout.strip() else ("ERR " + r.stderr[-300:]))
