@@ -15,9 +15,10 @@ def pytest_configure(config):
 def pytest_collection_modifyitems(config, items):
     """The multi-process tests (several ranks sharing the one GPU, spawned children, gloo rendezvous) run LAST: a spawn hiccup
     under `-x` must not hide the single-process parity tests behind it."""
-    late = [it for it in items if "test_gpu_domain" in it.nodeid]
+    is_late = lambda it: "test_gpu_domain" in it.nodeid or "test_gpu_bench_cli" in it.nodeid
+    late = [it for it in items if is_late(it)]
     if late:
-        rest = [it for it in items if "test_gpu_domain" not in it.nodeid]
+        rest = [it for it in items if not is_late(it)]
         items[:] = rest + late
 
 

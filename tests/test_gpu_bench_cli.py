@@ -1,0 +1,53 @@
+"""bench.py as the driver runs it: one JSON line on stdout with the contract's fields — on one GPU, and as
+`python -m torch.distributed.run --nproc-per-node 2 … bench.py --gpus 2` (both ranks on the one GPU of the test box, gloo with host
+staging instead of RCCL — MOLLYHIP_DIST_BACKEND / MOLLYHIP_FORCE_DEVICE — so everything but the RCCL transport is the production path)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _record(cmd, env=None):
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, **(env or {})), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]          # stdout carries exactly one line
+    return json.loads(lines[0])
+
+
+def _check_contract(d, n_gpus, steps, warmup):
+    assert d["metric"] == "ns_per_day" and d["unit"] == "ns/day" and d["higher_is_better"] is True
+    assert d["n_gpus"] == n_gpus and d["steps"] == steps and d["warmup"] == warmup
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["dtype"] == "f32" and d["data"] == "synthetic" and d["scaling"] == "strong"
+    assert d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["achieved"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert "workload" in d["config"] and "timed_window" in d["config"]
+
+
+def test_bench_single_gpu_record():
+    d = _record([sys.executable, "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--workload", "lj256k", "--equil", "300", "--no-cpu-baseline"])
+    _check_contract(d, 1, 20, 5)
+    assert d["config"]["parallelism"] == "single domain"
+    assert d["config"]["timed_window"].startswith("mid-cycle")        # a 20-step window is placed in the list cycle
+
+
+def test_bench_two_ranks_record():
+    port = _free_port()
+    d = _record([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                 "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--workload", "lj256k", "--equil", "300"],
+                env={"MOLLYHIP_DIST_BACKEND": "gloo", "MOLLYHIP_FORCE_DEVICE": "0"})
+    _check_contract(d, 2, 20, 5)
+    assert "spatial bricks 2x1x1" in d["config"]["parallelism"]
+    assert "cpu_baseline" not in d                                     # rank 0 at N = 1 only
