@@ -35,4 +35,10 @@ if __name__ == "__main__":
     from tests import systems as S
     out = [run(G.case("rf", np.float64, bonded=True), np.float64, 0.0005, 20000, 100, "6mrr reaction field + LJ + bonded (BASELINE configs[4])"),
            run(S.lj_fluid(14, dtype=np.float64), np.float64, 0.002, 20000, 100, "LJ fluid 2744 atoms (test/energy_conservation.jl kind)")]
+    if "--lj1m" in sys.argv:   # the benchmark system itself, fp32, after equilibration: what the list upkeep (inner skin, extra checks) does to the energy
+        case = S.lj_fluid(100, dtype=np.float32)
+        sy = case.system(m, np.float32)
+        m.simulate(sy, m.VelocityVerlet(dt=0.002, remove_CM_motion=1), 2000)
+        case.coords, case.velocities = np.array(sy.coords, dtype=np.float64), np.array(sy.velocities, dtype=np.float64)
+        out.append(run(case, np.float32, 0.002, 10000, 500, "1M-atom LJ fluid, fp32, equilibrated 2000 steps first (bench.py's lj1m)"))
     print(json.dumps(out, indent=1))
