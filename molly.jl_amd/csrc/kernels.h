@@ -453,15 +453,15 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
     //    change the outcome — are re-evaluated with the reference's exact arithmetic, so the emitted pair SET is
     //    bit-identical to the reference's.
     const uint32_t SENT = (uint32_t)tile_n;
-    uint32_t pack[2] = {0, 0};
+    // four 16-bit entries per row and lane, collected in a 64-bit shift register: the newest entry enters at the top, after four
+    // of them the oldest sits in bits 0-15 (two shifts and an OR per entry instead of indexed sub-word inserts)
+    uint64_t pack = 0;
     int cnt = 0;
     uint2* my_rows = A.nbr + (((int64_t)b * A.JS + js) * A.R_cap) * A.BI + li;
     auto emit = [&](uint32_t e) {
-        int k = cnt & 3;
-        if (k == 0) { pack[0] = 0; pack[1] = 0; }
-        pack[k >> 1] |= e << (16 * (k & 1));
+        pack = (pack >> 16) | ((uint64_t)e << 48);
         ++cnt;
-        if (k == 3) { int row = (cnt >> 2) - 1; if (row < A.R_cap) my_rows[(int64_t)row * A.BI] = make_uint2(pack[0], pack[1]); }
+        if ((cnt & 3) == 0) { int row = (cnt >> 2) - 1; if (row < A.R_cap) my_rows[(int64_t)row * A.BI] = make_uint2((uint32_t)pack, (uint32_t)(pack >> 32)); }
     };
     __syncthreads();
     {
@@ -937,7 +937,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_forces(ForceArg
     T fx = T(0), fy = T(0), fz = T(0), pe = T(0);
     [[maybe_unused]] T vir[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};   // ENERGY: Σ fr·(dx², dy², dz², dx·dy, dx·dz, dy·dz), the pair virial dr ⊗ f (force.jl:848-852)
     // PRUNE: inner-list emission state (same row format as k_build)
-    uint32_t pk[2] = {0, 0};
+    uint64_t pk = 0;        // (64-bit shift register, as in k_build)
     int kept = 0;
     uint2* out_rows = nullptr;
     if constexpr (PRUNE) out_rows = A.nbr_dst + (((int64_t)b * A.JS + js) * A.R_cap) * A.BI + li;
@@ -947,11 +947,9 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_forces(ForceArg
         for (int w = tid; w < ((tile_n + 3) >> 2); w += nthr) reinterpret_cast<uint32_t*>(l_mark)[w] = 0u;   // ordered before the marks by the staging barrier
     }
     auto emit = [&](uint32_t e) {
-        int k = kept & 3;
-        if (k == 0) { pk[0] = 0; pk[1] = 0; }
-        pk[k >> 1] |= e << (16 * (k & 1));
+        pk = (pk >> 16) | ((uint64_t)e << 48);
         ++kept;
-        if (k == 3) out_rows[(int64_t)((kept >> 2) - 1) * A.BI] = make_uint2(pk[0], pk[1]);
+        if ((kept & 3) == 0) out_rows[(int64_t)((kept >> 2) - 1) * A.BI] = make_uint2((uint32_t)pk, (uint32_t)(pk >> 32));
     };
 
     // The tile normally fits the LDS carve-up in one piece.  SEG: a tile larger than the LDS budget is
@@ -1018,9 +1016,9 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_forces(ForceArg
                         const float *pa = l_p3 + sa, *pb = l_p3 + sb;
                         const v2f dx = (v2f){pa[0], pb[0]} - pix, dy = (v2f){pa[SOA_STRIDE], pb[SOA_STRIDE]} - piy, dz = (v2f){pa[2 * SOA_STRIDE], pb[2 * SOA_STRIDE]} - piz;
                         const v2f r2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-                        if constexpr (PRUNE) {
-                            if (sa < (uint32_t)tile_n && valid && r2.x <= rp2) { emit(w & 0xffffu); l_mark[sa] = 1; }
-                            if (sb < (uint32_t)tile_n && valid && r2.y <= rp2) { emit(w >> 16); l_mark[sb] = 1; }
+                        if constexpr (PRUNE) {   // (no slot test: the sentinel slot — padding, and everything a lane without an atom holds — lies 10⁴ nm away)
+                            if (r2.x <= rp2) { emit(w & 0xffffu); l_mark[sa] = 1; }
+                            if (r2.y <= rp2) { emit(w >> 16); l_mark[sb] = 1; }
                         }
                         const float t = __builtin_amdgcn_rcpf(r2.x * r2.y);
                         const v2f inv = (v2f){r2.y, r2.x} * t;
