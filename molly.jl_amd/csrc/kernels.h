@@ -490,6 +490,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
         //     group of the tile that any of them can reach, about 10 per neighbour, and moves every hit through the scalar unit.
         //     Periodic axes never wrap inside a block's cell box here: a box that spans a whole periodic axis is an exact_only block.
         if (WALK && !exact_only) {
+            const bool js_pow2 = (A.JS & (A.JS - 1)) == 0;
             if (valid) {
                 int qc[3], lo[3], hi[3], mycell[3];
                 cell_coords(my[0], my[1], my[2], G, mycell);
@@ -502,31 +503,43 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
                 for (int qz = lo[2]; qz <= hi[2]; ++qz) for (int qy = lo[1]; qy <= hi[1]; ++qy) {
                     const int row = (qz * ly + qy) * lx;
                     const int t0 = t_off[row + lo[0]], t1 = t_off[row + hi[0] + 1];
-                    int t = t0 + (A.JS > 1 ? ((js - t0) % A.JS + A.JS) % A.JS : 0);          // this j-split takes the slots ≡ js (mod JS)
-                    for (; t < t1; t += A.JS) {
-                        const float4 pl = t_pos[t];
+                    // this j-split takes the slots ≡ js (mod JS); JS is a power of two unless MOLLYHIP_J_SPLIT says otherwise (two integer
+                    // divisions per row of cells otherwise: 25 rows per atom)
+                    int t = t0 + (js_pow2 ? ((js - t0) & (A.JS - 1)) : ((js - t0) % A.JS + A.JS) % A.JS);
+                    auto consider = [&](int tc, const float4 pl) {
                         const float dx = pl.x - ml[0], dy = pl.y - ml[1], dz = pl.z - ml[2];
                         const float r2 = dx * dx + dy * dy + dz * dz;
                         bool in = A.approx ? r2 <= band_hi : r2 < band_lo;
                         if (!A.approx && !in && r2 <= band_hi) {   // rare: decide with the reference's exact arithmetic on the stored coordinates
-                            T4 pj = A.pos[A.tile_idx[(int64_t)b * A.T_cap + t]];
+                            T4 pj = A.pos[A.tile_idx[(int64_t)b * A.T_cap + tc]];
                             T ex, ey, ez;
                             min_image_exact<T>(my[0], my[1], my[2], pj.x, pj.y, pj.z, G, ex, ey, ez);
                             in = norm2_exact(ex, ey, ez) <= G.r_list2;
                         }
-                        if (!in || (uint32_t)t == self_t) continue;
+                        if (!in || (uint32_t)tc == self_t) return;
                         uint32_t sp = 0;
-                        const int oj = nxl > 0 ? t_orig[t] : 0;
+                        const int oj = nxl > 0 ? t_orig[tc] : 0;
                         if (nxl > 0 && (unsigned)(oj - oi + A.xl_span) <= (unsigned)(2 * A.xl_span)) {
                             uint32_t hit = 0;
                             for (int k = 0; k < nxl; ++k) {
                                 uint32_t e = k < A.X_cap ? x_part[k * A.BI + li] : A.xl_list[xl0 + k];
                                 hit = ((e & XL_INDEX) == (uint32_t)oj) ? e : hit;
                             }
-                            if (hit & XL_EXCLUDED) continue;
+                            if (hit & XL_EXCLUDED) return;
                             sp = hit >> 31;
                         }
-                        emit((uint32_t)t | (sp << 15));
+                        emit((uint32_t)tc | (sp << 15));
+                    };
+                    // four candidates per round, their coordinates fetched together: with four waves per SIMD the LDS latency of one
+                    // dependent read per candidate was what the walk waited for
+                    const int last = t1 - 1;
+                    for (; t < t1; t += 4 * A.JS) {
+                        const int ta = t, tb = t + A.JS, tc = t + 2 * A.JS, td = t + 3 * A.JS;
+                        const float4 pa = t_pos[ta], pb = t_pos[min(tb, last)], pc = t_pos[min(tc, last)], pd = t_pos[min(td, last)];
+                        consider(ta, pa);
+                        if (tb < t1) consider(tb, pb);
+                        if (tc < t1) consider(tc, pc);
+                        if (td < t1) consider(td, pd);
                     }
                 }
                 (void)qc;
