@@ -256,7 +256,10 @@ __device__ inline int block_excl_scan(int32_t* a, int n, int32_t* part, int tid,
 // lanes (128 VGPRs) every fp64 pair-kernel variant spilled to scratch.
 template <class T> struct BlockLimits { static constexpr int max_threads = sizeof(T) == 8 ? 512 : 1024; };
 
-template <class T, bool WALK>
+// APPROX (the outer list of the dual pair list, a candidate set): everything inside r_list·(1 + 1e-4) is taken and the band is never
+// re-decided with the reference's exact arithmetic — that path (a 27-image search, inlined per candidate) is then not even compiled:
+// the kernel is half the size, and the walk variant fits its registers without spilling.
+template <class T, bool WALK, bool APPROX>
 __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs<T> A) {
     using T4 = typename Vec<T>::T4;
     extern __shared__ __align__(32) unsigned char smem[];
@@ -509,8 +512,8 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
                     auto consider = [&](int tc, const float4 pl) {
                         const float dx = pl.x - ml[0], dy = pl.y - ml[1], dz = pl.z - ml[2];
                         const float r2 = dx * dx + dy * dy + dz * dz;
-                        bool in = A.approx ? r2 <= band_hi : r2 < band_lo;
-                        if (!A.approx && !in && r2 <= band_hi) {   // rare: decide with the reference's exact arithmetic on the stored coordinates
+                        bool in = APPROX ? r2 <= band_hi : r2 < band_lo;
+                        if (!APPROX && !in && r2 <= band_hi) {   // rare: decide with the reference's exact arithmetic on the stored coordinates
                             T4 pj = A.pos[A.tile_idx[(int64_t)b * A.T_cap + tc]];
                             T ex, ey, ez;
                             min_image_exact<T>(my[0], my[1], my[2], pj.x, pj.y, pj.z, G, ex, ey, ez);
@@ -577,7 +580,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
                 unsigned long long im = __ballot(valid && acc <= reach2f);
                 // candidates out of reach (or past the tile's end) are parked at infinity: no lane mask in the loop
                 const float qx = near ? pl.x : __builtin_inff();
-                if (A.approx) {
+                if (APPROX) {
                     while (im) {
                         const int i = __builtin_ctzll(im);
                         im &= im - 1;
