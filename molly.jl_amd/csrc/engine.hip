@@ -500,7 +500,8 @@ template <class T> class Engine final : public EngineBase {
             prof.begin(1, stream);
             tr("k_build");
             auto go = [&](auto kern) { set_lds_limit(kern, lds); hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(BI * JS), lds, stream, A); };
-            if (A.walk) { if (A.approx) go(k_build<T, true, true>); else go(k_build<T, true, false>); }
+            if (A.walk && A.approx && !A.xl_start) go(k_build<T, true, true, false>);       // one-type fluids: neither exact re-decisions nor exception lookups
+            else if (A.walk) { if (A.approx) go(k_build<T, true, true>); else go(k_build<T, true, false>); }
             else { if (A.approx) go(k_build<T, false, true>); else go(k_build<T, false, false>); }
             hipLaunchKernelGGL(k_build_summary, dim3(std::min(64, cdiv(n_blocks * JS * (BI / WAVE), 256))), dim3(256), 0, stream, n_blocks, n_blocks * JS * (BI / WAVE), R_cap, (const int32_t*)tile_cnt.p, wave_rows.p, (const float*)nullptr, flags.p);
             prof.end(1, stream);

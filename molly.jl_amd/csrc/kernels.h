@@ -259,7 +259,8 @@ template <class T> struct BlockLimits { static constexpr int max_threads = sizeo
 // APPROX (the outer list of the dual pair list, a candidate set): everything inside r_list·(1 + 1e-4) is taken and the band is never
 // re-decided with the reference's exact arithmetic — that path (a 27-image search, inlined per candidate) is then not even compiled:
 // the kernel is half the size, and the walk variant fits its registers without spilling.
-template <class T, bool WALK, bool APPROX>
+// XL: the system has exception lists (excluded / special pairs).  Without them the per-candidate lookup is not compiled either.
+template <class T, bool WALK, bool APPROX, bool XL = true>
 __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs<T> A) {
     using T4 = typename Vec<T>::T4;
     extern __shared__ __align__(32) unsigned char smem[];
@@ -470,11 +471,11 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
     {
         const int oi = valid ? A.orig[si] : -1;
         int xl0 = 0, nxl = 0;
-        if (A.xl_start && valid) {   // my exception list: into LDS once (shared by the j-split group), scanned only for
+        if (XL && A.xl_start && valid) {   // my exception list: into LDS once (shared by the j-split group), scanned only for
             xl0 = A.xl_start[oi]; nxl = A.xl_start[oi + 1] - xl0;   // candidates close in caller index
             if (js == 0) for (int k = 0; k < min(nxl, A.X_cap); ++k) x_part[k * A.BI + li] = A.xl_list[xl0 + k];
         }
-        if (A.xl_start) __syncthreads();
+        if (XL && A.xl_start) __syncthreads();
         T my_loc[3], my_ub[3]; localise3(my[0], my[1], my[2], my_loc, my_ub);
         const float ml[3] = {(float)my_loc[0], (float)my_loc[1], (float)my_loc[2]};
         const float rl2 = G.no_list ? 3.0e38f : (float)G.r_list2;
@@ -521,8 +522,8 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
                         }
                         if (!in || (uint32_t)tc == self_t) return;
                         uint32_t sp = 0;
-                        const int oj = nxl > 0 ? t_orig[tc] : 0;
-                        if (nxl > 0 && (unsigned)(oj - oi + A.xl_span) <= (unsigned)(2 * A.xl_span)) {
+                        const int oj = (XL && nxl > 0) ? t_orig[tc] : 0;
+                        if (XL && nxl > 0 && (unsigned)(oj - oi + A.xl_span) <= (unsigned)(2 * A.xl_span)) {
                             uint32_t hit = 0;
                             for (int k = 0; k < nxl; ++k) {
                                 uint32_t e = k < A.X_cap ? x_part[k * A.BI + li] : A.xl_list[xl0 + k];
@@ -627,8 +628,8 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
                 const uint32_t t = (uint32_t)(((w << 6) + bit) * A.JS + js);
                 if (t == self_t) continue;                       // the atom itself (no LDS lookup on the common path)
                 uint32_t sp = 0;
-                const int oj = nxl > 0 ? t_orig[t] : 0;
-                if (nxl > 0 && (unsigned)(oj - oi + A.xl_span) <= (unsigned)(2 * A.xl_span)) {
+                const int oj = (XL && nxl > 0) ? t_orig[t] : 0;
+                if (XL && nxl > 0 && (unsigned)(oj - oi + A.xl_span) <= (unsigned)(2 * A.xl_span)) {
                     uint32_t hit = 0;
                     for (int k = 0; k < nxl; ++k) {
                         uint32_t e = k < A.X_cap ? x_part[k * A.BI + li] : A.xl_list[xl0 + k];
