@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
     int32_t* t_off = reinterpret_cast<int32_t*>(x_part + (A.xl_start ? A.X_cap * A.BI : 0));   // C_cap + 1: first tile slot of each box cell (walk)
     __shared__ T s_sub[4][6];                                 // per-wave bounding boxes of the i-atoms
     __shared__ T s_ctr[3], s_half[3];
-    __shared__ int s_boxlo[3], s_boxlen[3], s_full[3], s_exact, s_wtot[16];
+    __shared__ int s_boxlo[3], s_boxlen[3], s_full[3], s_exact, s_wtot[4 * 16];
     __shared__ int s_self[256];                                // tile slot of each i-atom itself (BI <= 256)
 
     // 0. bounding boxes: one per wave of i-atoms (tight pruning for elongated blocks) and their union
@@ -407,35 +407,54 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
     // 2. atom-level pruning + ordered compaction into the LDS tile (cell-major, sorted order inside a cell)
     if constexpr (WALK) { for (int q = tid; q <= ncb; q += nthr) t_off[q] = 0; __syncthreads(); }
     int tile_n = 0;
-    for (int base = 0; base < nraw; base += nthr) {
-        const int t = base + tid;
-        bool keep = false; T4 p; int s = 0, q = 0;
-        if (t < nraw) {
-            int lo_q = 0, hi_q = ncb;             // largest q with c_raw[q] <= t
-            while (hi_q - lo_q > 1) { int mid = (lo_q + hi_q) >> 1; if (c_raw[mid] <= t) lo_q = mid; else hi_q = mid; }
-            q = lo_q;
-            int k = t - c_raw[q], r = c_rank[q];
-            int own = A.cell_start[r + 1] - A.cell_start[r];
-            s = k < own ? A.cell_start[r] + k : A.cell_start[G.ncell + r] + (k - own);
-            p = A.pos[s];
-            T loc[3], ub[3]; localise3(p.x, p.y, p.z, loc, ub);
-            // exact_only blocks (small boxes): images are ambiguous, keep the whole cell-pruned set
-            keep = exact_only ? true : sub_dist2(ub[0], ub[1], ub[2]) <= reach2;
-            p.x = loc[0]; p.y = loc[1]; p.z = loc[2];
+    // Four raw atoms per lane and round, their (dependent) lookups issued together: cell by binary search in LDS, its first atom, the
+    // atom's coordinates — three latencies in a row that, one atom per lane and two barriers per 512 atoms, made staging a quarter of
+    // the whole search.  The compaction below keeps the raw order (sub-round by sub-round).
+    constexpr int SUB = 4;
+    for (int base = 0; base < nraw; base += SUB * nthr) {
+        bool keep[SUB]; T4 p[SUB]; int s[SUB], q[SUB], og[SUB];
+#pragma unroll
+        for (int u = 0; u < SUB; ++u) {
+            const int t = base + u * nthr + tid;
+            keep[u] = false; s[u] = 0; q[u] = 0; og[u] = 0;
+            if (t < nraw) {
+                int lo_q = 0, hi_q = ncb;             // largest q with c_raw[q] <= t
+                while (hi_q - lo_q > 1) { int mid = (lo_q + hi_q) >> 1; if (c_raw[mid] <= t) lo_q = mid; else hi_q = mid; }
+                q[u] = lo_q;
+                int k = t - c_raw[lo_q], r = c_rank[lo_q];
+                int own = A.cell_start[r + 1] - A.cell_start[r];
+                s[u] = k < own ? A.cell_start[r] + k : A.cell_start[G.ncell + r] + (k - own);
+            }
         }
-        unsigned long long m = __ballot(keep);
-        if (lane == 0) s_wtot[wv_all] = __popcll(m);
+#pragma unroll
+        for (int u = 0; u < SUB; ++u) if (base + u * nthr + tid < nraw) { p[u] = A.pos[s[u]]; og[u] = A.orig[s[u]]; }
+#pragma unroll
+        for (int u = 0; u < SUB; ++u) {
+            if (base + u * nthr + tid < nraw) {
+                T loc[3], ub[3]; localise3(p[u].x, p[u].y, p[u].z, loc, ub);
+                // exact_only blocks (small boxes): images are ambiguous, keep the whole cell-pruned set
+                keep[u] = exact_only ? true : sub_dist2(ub[0], ub[1], ub[2]) <= reach2;
+                p[u].x = loc[0]; p[u].y = loc[1]; p[u].z = loc[2];
+            }
+            const unsigned long long m = __ballot(keep[u]);
+            if (lane == 0) s_wtot[u * NW_ALL + wv_all] = __popcll(m);
+            q[u] = (int)((uint32_t)q[u] | ((uint32_t)__popcll(m & ((1ull << lane) - 1ull)) << 16));   // my rank inside the wave rides in the upper half
+        }
         __syncthreads();
-        int dst = tile_n + __popcll(m & ((1ull << lane) - 1ull));
-        int tot = 0;
-        for (int w = 0; w < NW_ALL; ++w) { if (w < wv_all) dst += s_wtot[w]; tot += s_wtot[w]; }
-        if (keep && dst < A.T_cap) {
-            t_pos[dst] = make_float4((float)p.x, (float)p.y, (float)p.z, 0.f); t_orig[dst] = A.orig[s]; A.tile_idx[(int64_t)b * A.T_cap + dst] = s;
-            const int64_t rel = (int64_t)s - (int64_t)b * A.BI;
-            if (rel >= 0 && rel < A.BI) s_self[rel] = dst;     // an i-atom always survives the pruning of its own block
-            if constexpr (WALK) atomicAdd(&t_off[q], 1);       // tile atoms per box cell (the compaction keeps the cell-major order)
+#pragma unroll
+        for (int u = 0; u < SUB; ++u) {
+            int dst = tile_n + (int)((uint32_t)q[u] >> 16);
+            const int qc = q[u] & 0xffff;
+            int tot = 0;
+            for (int w = 0; w < NW_ALL; ++w) { const int c = s_wtot[u * NW_ALL + w]; if (w < wv_all) dst += c; tot += c; }
+            if (keep[u] && dst < A.T_cap) {
+                t_pos[dst] = make_float4((float)p[u].x, (float)p[u].y, (float)p[u].z, 0.f); t_orig[dst] = og[u]; A.tile_idx[(int64_t)b * A.T_cap + dst] = s[u];
+                const int64_t rel = (int64_t)s[u] - (int64_t)b * A.BI;
+                if (rel >= 0 && rel < A.BI) s_self[rel] = dst;     // an i-atom always survives the pruning of its own block
+                if constexpr (WALK) atomicAdd(&t_off[qc], 1);      // tile atoms per box cell (the compaction keeps the cell-major order)
+            }
+            tile_n += tot;
         }
-        tile_n += tot;
         __syncthreads();
     }
     if (tile_n > A.T_cap || tile_n > TILE_SLOT_MAX - 1) {
