@@ -1156,8 +1156,10 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_forces(ForceArg
         }
         __syncthreads();
         const uint32_t n_in = (uint32_t)l_scan[nthr];
+        uint2 e_nx = rows_wave > 0 ? out_rows[0] : make_uint2(0, 0);   // (row r + 1 is in flight while row r is renumbered: the stores below alias the loads for the compiler)
         for (int r = 0; r < rows_wave; ++r) {
-            uint2 e4 = out_rows[(int64_t)r * A.BI];
+            const uint2 e4 = e_nx;
+            if (r + 1 < rows_wave) e_nx = out_rows[(int64_t)(r + 1) * A.BI];
             uint32_t o2[2] = {0, 0};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
