@@ -16,7 +16,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, n_side, n_steps, out_dir, gm=0.0, skin=0.2):
+def _worker(rank, world, port, n_side, n_steps, out_dir, gm=0.0, skin=0.2, msg_dtype=torch.float64):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import molly_loader
@@ -28,7 +28,7 @@ def _worker(rank, world, port, n_side, n_steps, out_dir, gm=0.0, skin=0.2):
     bg = domain.BrickGrid(case.box, grid, rank, case.r_list + gm)
     box, origin, periodic = bg.engine_box(pad=0.3)
     eng = OracleDomainEngine(case.inter_dict(np.float64), case.box, periodic, case.r_list, ghost_margin=gm, skin=skin, every=case.rebuild_every)
-    run = domain.DomainRun(bg, eng, torch.float64, torch.device("cpu"), case.rebuild_every, ghost_margin=gm, skin=skin)
+    run = domain.DomainRun(bg, eng, msg_dtype, torch.device("cpu"), case.rebuild_every, ghost_margin=gm, skin=skin)
     run.setup_from_global(case.coords, case.velocities, np.zeros(case.n), case.sigma, case.eps, case.mass)
     # every atom is owned exactly once
     n_tot = torch.tensor([run.n_owned]); dist.all_reduce(n_tot)
@@ -56,6 +56,57 @@ def test_decomposed_run_matches_single_domain_oracle(world, tmp_path):
     assert np.abs(d).max() < 1e-9 and np.abs(res["v"] - o.vel).max() < 1e-8
     assert int(res["ghosts"]) > 0
     assert tuple(res["grid"]) == {2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}[world]      # 8 ranks: every axis cut, seven peers each
+
+
+def test_float32_messages_carry_the_momentum_sums_exactly(tmp_path):
+    """fp32 runs: the ghost message is float32, the four doubles of Σ m v ride in three rows of it as raw words (mhip_halo_plan,
+    cm_rows = 3).  The stand-in engine computes in float64, so coordinates lose precision on the wire, the momentum sums must not:
+    with remove_CM_motion on, the total momentum after the run is zero to double rounding."""
+    world, n_side, n_steps = 2, 10, 12
+    mp.spawn(_worker, args=(world, _free_port(), n_side, n_steps, str(tmp_path), 0.3, 0.2, torch.float32), nprocs=world, join=True)
+    res = np.load(os.path.join(tmp_path, "result.npz"))
+    case = S.lj_fluid(n_side, dtype=np.float64, rebuild_every=5)
+    o = case.oracle(np.float64)
+    o.vv_run(n_steps, 0.002, remove_cm_every=1)
+    d = res["x"] - o.coords
+    d -= np.round(d / case.box) * case.box
+    assert np.abs(d).max() < 2e-5 and int(res["fused"]) == 1          # float32 ghost coordinates: 1e-7 relative per exchange
+    mv = res["v"] * case.mass[:, None]
+    assert np.abs(mv.sum(axis=0)).max() < 1e-6 * np.abs(mv).sum(axis=0).max()   # (v comes back through float32 tensors: 1e-7 per atom, random signs)
+
+
+def test_halo_layout_of_a_ghost_plan(tmp_path):
+    """the index lists of mhip_halo_plan built by DomainRun._halo_layout: each peer's rows followed by cm_rows momentum rows, on both sides"""
+    world = 2
+    mp.spawn(_layout_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = np.load(os.path.join(tmp_path, "layout.npz"))
+    n_send, n_recv, cr = int(r["n_send"]), int(r["n_ghost"]), int(r["cm_rows"])
+    idx, dst, pos = r["send_idx"], r["recv_dst"], r["cm_pos"]
+    assert cr == 2 and len(idx) == n_send + cr and len(dst) == n_recv + cr          # one peer: its rows, then the momentum rows
+    assert (idx[:n_send] >= 0).all() and list(idx[n_send:]) == [-1, -2] and list(pos) == [n_send, n_send + 1]
+    assert list(dst[:n_recv]) == list(range(n_recv)) and list(dst[n_recv:]) == [-1, -2]
+    assert list(r["sc3"]) == [0, 3 * (n_send + cr)] and list(r["rc3"]) == [0, 3 * (n_recv + cr)]
+
+
+def _layout_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import molly_loader
+    molly_loader.load()
+    from molly_jl_amd import domain
+    from tests.oracle_domain_engine import OracleDomainEngine
+    case = S.lj_fluid(10, dtype=np.float64, rebuild_every=5)
+    grid = domain.choose_grid(world, case.box)
+    bg = domain.BrickGrid(case.box, grid, rank, case.r_list + 0.3)
+    box, origin, periodic = bg.engine_box(pad=0.3)
+    eng = OracleDomainEngine(case.inter_dict(np.float64), case.box, periodic, case.r_list, ghost_margin=0.3, skin=0.2, every=5)
+    run = domain.DomainRun(bg, eng, torch.float64, torch.device("cpu"), 5, ghost_margin=0.3, skin=0.2)
+    run.setup_from_global(case.coords, case.velocities, np.zeros(case.n), case.sigma, case.eps, case.mass)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "layout.npz"), n_send=run.send_idx.numel(), n_ghost=run.n_ghost, cm_rows=run.cm_rows, send_idx=run.f_send_idx.numpy(),
+                 recv_dst=run.f_recv_dst.numpy(), cm_pos=run.f_cm_pos.numpy(), sc3=np.array(run._fsc3), rc3=np.array(run._frc3))
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def test_stepwise_host_loop_matches_single_domain_oracle(tmp_path, monkeypatch):
