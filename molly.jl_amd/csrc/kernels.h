@@ -376,6 +376,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
     };
 
     // 1. cell-level pruning: per box cell the number of candidate atoms (0 if the cell is out of reach)
+    const bool ghosts = A.n_tot > A.n_owned;
     for (int q = tid; q < ncb; q += nthr) {
         int qx = q % lx, qy = (q / lx) % ly, qz = q / (lx * ly);
         int g[3] = {s_boxlo[0] + qx, s_boxlo[1] + qy, s_boxlo[2] + qz};
@@ -398,7 +399,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
         int r = (int)A.cell_rank[(gw[2] * G.nc[1] + gw[1]) * G.nc[0] + gw[0]];
         bool keep = best <= reach2 * T(1.0001) + T(1e-12);
         int cnt = keep ? (A.cell_start[r + 1] - A.cell_start[r]) + (A.cell_start[G.ncell + r + 1] - A.cell_start[G.ncell + r]) : 0;
-        c_raw[q] = cnt; c_rank[q] = r;
+        c_raw[q] = cnt; c_rank[q] = ghosts ? r : A.cell_start[r];   // (no ghost atoms: the cell's first atom itself — the staging below then needs no lookup in global memory)
     }
     __syncthreads();
     const int nraw = block_excl_scan(c_raw, ncb, part, tid, nthr);
@@ -422,8 +423,11 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
                 while (hi_q - lo_q > 1) { int mid = (lo_q + hi_q) >> 1; if (c_raw[mid] <= t) lo_q = mid; else hi_q = mid; }
                 q[u] = lo_q;
                 int k = t - c_raw[lo_q], r = c_rank[lo_q];
-                int own = A.cell_start[r + 1] - A.cell_start[r];
-                s[u] = k < own ? A.cell_start[r] + k : A.cell_start[G.ncell + r] + (k - own);
+                if (!ghosts) s[u] = r + k;
+                else {
+                    int own = A.cell_start[r + 1] - A.cell_start[r];
+                    s[u] = k < own ? A.cell_start[r] + k : A.cell_start[G.ncell + r] + (k - own);
+                }
             }
         }
 #pragma unroll
