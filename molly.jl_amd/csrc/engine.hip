@@ -251,6 +251,8 @@ template <class T> class Engine final : public EngineBase {
         for (int k = 0; k < 2; ++k) { if (side[k]) { (void)hipStreamSynchronize(side[k]); (void)hipStreamDestroy(side[k]); } if (ev_side[k]) (void)hipEventDestroy(ev_side[k]); frc_side[k].release(); }
         if (ev_pos) (void)hipEventDestroy(ev_pos);
         if (h_flags) (void)hipHostFree(h_flags);
+        if (h_trk) (void)hipHostFree(h_trk);
+        if (ev_trk) (void)hipEventDestroy(ev_trk);
         if (h_red) (void)hipHostFree(h_red);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
@@ -632,6 +634,39 @@ template <class T> class Engine final : public EngineBase {
         return last_vmax * growth * cur_dt * every;
     }
 
+    // Validity checks without a kernel or a pipeline drain of their own (mhip_vv_run's fused loop, dual list, no ghosts).  At a check
+    // step s the displacement maxima are taken by the force pass itself (k_forces, per block; the speed maximum by the integrator launch
+    // before it), reduced by one tiny launch and copied to pinned memory behind an event.  The host reads them at step s + 1 — by then
+    // the GPU has the integrator launch of step s still queued, so it does not run dry — and applies the decision there: the pass of
+    // step s was covered by the previous decision's horizon (it reached up to the check step), a prune or a search that the
+    // measurement asks for happens at s + 1 (one step of headroom in the outer-list test).
+    DBuf<float> trk_blk, trk_v2, trk_out; float* h_trk = nullptr; hipEvent_t ev_trk = nullptr;
+    bool trk_want = false, trk_issued = false; int64_t trk_step = -1, trk_v2_step = -1; int trk_v2_n = 0; double trk_prev_vmax = 0;   // trk_v2_step: the step whose pass the recorded speeds belong to
+    const bool async_checks = env_int("MOLLYHIP_ASYNC_CHECKS", 1) != 0;
+    bool in_vv_fused = false;
+    bool async_ok() const { return async_checks && in_vv_fused && dual && n_ghost == 0 && !host_prune && !strict_cadence && inner_valid && !stale; }
+    void resolve_track(int64_t step) {
+        if (!trk_issued) return;
+        MHIP_HIP(hipEventSynchronize(ev_trk));
+        trk_issued = false;
+        const double d = std::sqrt((double)h_trk[0]), d_outer = std::sqrt((double)h_trk[1]);
+        prev_vmax = trk_prev_vmax; last_vmax = std::sqrt((double)h_trk[2]);   // (the speed of the check before, as it was when this one was issued: a run cut into chunks decides alike)
+        ++n_disp_checks;
+        if (!dual || stale || !inner_valid || n_ghost > 0) return;          // something else has dealt with the lists meanwhile
+        const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
+        const int64_t so_far = trk_step - last_prune_step;
+        const double ahead = drift_ahead(d, so_far, every);
+        if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] step %lld: measured at %lld: d %.5f d_outer %.5f v_max %.4f\n", (long long)step, (long long)trk_step, d, d_outer, last_vmax);
+        adapt_inner_skin(ahead);
+        bool reprune = !inner_valid || 2.0 * (d + ahead) > skin_in * 0.98;
+        next_check_step = -1;
+        if (reprune && inner_valid)
+            if (const int k = steps_within(d, 0.49 * skin_in, so_far, every, true)) { next_check_step = trk_step + k; reprune = false; }
+        if (!reprune) return;
+        if (2.0 * (d_outer + last_vmax * cur_dt * 1.25 * (double)(step - trk_step)) > prune_margin() * 0.98) { rebuild(step); return; }
+        inner_valid = false;
+    }
+
     // Checks between the cadence steps.  A list that cannot be vouched for over a whole interval (the fastest atom could use up the
     // remaining slack in `every` steps) may still be good for k < every steps: instead of giving it up now, look again in k steps.
     // Light, fast atoms (hydrogens at 0.5 fs: 0.06 nm of possible drift per 10 steps against 0.1 nm of slack) otherwise cost a
@@ -672,6 +707,10 @@ template <class T> class Engine final : public EngineBase {
         // the next force pass) only when it is about to fail.  mhip_export_neighbors always returns the exact list of NOW.
         if (host_prune && inner_valid && !strict_cadence) { last_build_step = step_n; ++n_rebuilds; return; }   // the host calls mhip_request_prune
         bool reprune = strict_cadence || !inner_valid;
+        if (!reprune && async_ok() && trk_v2_step == step_n && !trk_issued) {   // measured inside this step's force pass, decided one step later
+            trk_want = true; trk_step = step_n; trk_prev_vmax = last_vmax; last_build_step = step_n; ++n_rebuilds;
+            return;
+        }
         if (!reprune) {
             const float d2 = max_disp2_since(pos_snap_in);
             // headroom for the drift until the next check: the displacement so far, extrapolated one more interval
@@ -718,6 +757,7 @@ template <class T> class Engine final : public EngineBase {
 
     void ensure_built(int64_t step_n) {
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
+        resolve_track(step_n);
         lists_after_set_state();
         if (stale) rebuild(step_n);
         else if (check_due(step_n, every) && step_n != last_build_step) refresh(step_n);
@@ -761,6 +801,13 @@ template <class T> class Engine final : public EngineBase {
             for (int k = 2; k >= 0; --k) if ((use_inner ? max_tile_in : max_tile) + 1 < SOA_STRIDES[k]) A.soa = SOA_STRIDES[k];   // the smallest stride that holds tile + sentinel
         if (A.soa) lds_force = std::max(lds_force, (size_t)3 * A.soa * sizeof(float) + 64);
         A.part = 0; A.blk_ghost = nullptr;
+        const bool track = trk_want && use_inner && !prune && !energy && part == 0;
+        A.trk_blk = nullptr; A.trk_snap_in = nullptr; A.trk_snap_out = nullptr;
+        if (track) {
+            trk_blk.reserve(2 * (size_t)n_blocks); trk_out.reserve(4);
+            MHIP_HIP(hipMemsetAsync(trk_blk.p, 0, 2 * (size_t)n_blocks * sizeof(float), stream));
+            A.trk_blk = trk_blk.p; A.trk_snap_in = pos_snap_in.p; A.trk_snap_out = pos_snap.p;
+        }
         if (part != 0 && !prune) {   // blocks without / with ghost atoms in their tile (flags of the tile this pass stages)
             DBuf<int32_t>& fl = use_inner ? blk_ghost_in : blk_ghost; bool& ok = use_inner ? ghost_flags_in_ok : ghost_flags_ok;
             if (!ok) {
@@ -792,6 +839,15 @@ template <class T> class Engine final : public EngineBase {
         prof.end(prune ? 4 : 0, stream);
         MHIP_HIP(hipGetLastError());
         ++n_force_calls;
+        if (trk_want && !track) { trk_want = false; if (!prune) next_check_step = trk_step; }   // (not a plain pass after all: the check is repeated, the usual way, before the next pass; a prune needs none)
+        if (track) {
+            if (!h_trk) MHIP_HIP(hipHostMalloc((void**)&h_trk, 4 * sizeof(float)));
+            if (!ev_trk) MHIP_HIP(hipEventCreateWithFlags(&ev_trk, hipEventDisableTiming));
+            hipLaunchKernelGGL(k_track_reduce, dim3(1), dim3(256), 0, stream, n_blocks, (const float*)trk_blk.p, trk_v2_n, (const float*)trk_v2.p, trk_out.p);
+            MHIP_HIP(hipMemcpyAsync(h_trk, trk_out.p, 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
+            MHIP_HIP(hipEventRecord(ev_trk, stream));
+            trk_want = false; trk_issued = true; trk_v2_step = -1;
+        }
         if (prune) {   // validity of the pruned list: nobody moved more than half the margin since the outer search
             MHIP_HIP(hipMemsetAsync(flags.p, 0, N_FLAGS * sizeof(int32_t), stream));
             if (n_ghost > 0)   // the blocks record the displacement of the owned atoms; the ghosts' comes on top
@@ -933,7 +989,7 @@ template <class T> class Engine final : public EngineBase {
         hipLaunchKernelGGL(k_iota2, dim3(std::min(cdiv(n_tot, 256), 1024)), dim3(256), 0, stream, n_tot, orig[cur].p, inv.p);
         MHIP_HIP(hipMemsetAsync(frc[cur].p, 0, n_tot * sizeof(T4), stream));
         MHIP_HIP(hipGetLastError());
-        stale = true; cm_pending = 0; cm_ext = nullptr; frc_valid = false; hp_set = false; halo_cm_in = false;
+        stale = true; cm_pending = 0; cm_ext = nullptr; frc_valid = false; hp_set = false; halo_cm_in = false; trk_issued = false; trk_want = false; trk_v2_step = -1;
         // the search radius depends on whether there are ghosts and on the ghost margin, the blocking on the size class: a re-plan
         // that changes neither keeps the grid, its Hilbert table and the (already adapted) capacities
         const int size_class = n_owned >= 100000 ? 2 : (n_owned >= 40000 ? 1 : 0);
@@ -1290,6 +1346,7 @@ template <class T> class Engine final : public EngineBase {
     // (set_atom_counts / set_state → stale) by the host at every rebuild step instead.
     void stage2_cadenced(int64_t step_n, double dt, bool cm, double* cm_parts_ext = nullptr, int n_parts_ext = 0) {
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
+        resolve_track(step_n);
         const bool due = check_due(step_n, every) && step_n != last_build_step && (n_ghost == 0 || dual);
         if (due && dual) refresh(step_n);
         stage2_impl(step_n, dt, cm, cm_parts_ext, n_parts_ext);
@@ -1439,7 +1496,7 @@ template <class T> class Engine final : public EngineBase {
         tr("k_vv_mid");
         auto go = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, stream, n_owned, pos[cur].p, vel[cur].p, (const T4*)frc[cur].p, T(dt), T(dt) / T(2),
-                               cm_in, n_in, cm_out, (const T4*)pend_a, (const T4*)pend_b, G);
+                               cm_in, n_in, cm_out, (const T4*)pend_a, (const T4*)pend_b, G, (float*)nullptr);
         };
         if (last) { if (cm) go(k_vv_mid<T, true, true>); else go(k_vv_mid<T, false, true>); }
         else { if (cm) go(k_vv_mid<T, true, false>); else go(k_vv_mid<T, false, false>); }
@@ -1480,7 +1537,7 @@ template <class T> class Engine final : public EngineBase {
         }
         MHIP_HIP(hipGetLastError());
     }
-    void rebuild_now(int64_t step_n) override { flush_cm(); lists_after_set_state(); if (stale) rebuild(step_n); else refresh(step_n); }
+    void rebuild_now(int64_t step_n) override { flush_cm(); resolve_track(step_n); lists_after_set_state(); if (stale) rebuild(step_n); else refresh(step_n); }
 
     void vv_run(int64_t first_step, int64_t n_steps, double dt, int remove_cm_every) override {
         if (!state_set || !params_set) throw ApiError{MHIP_ERR_STATE, "set_atoms and set_state must be called before vv_run"};
@@ -1494,6 +1551,7 @@ template <class T> class Engine final : public EngineBase {
         // plain second kick at the end.  A thermostat needs v_n between the kicks: the two-launch form then.
         static const bool fuse_env = env_int("MOLLYHIP_VV_FUSE", 1) != 0;
         const bool fused = fuse_env && !(andersen_prob > 0);
+        InRun guard_fused(in_vv_fused); in_vv_fused = fused;
         const bool pre = dual;                                                    // without the dual list: the reference's order
         const int64_t last = first_step + n_steps;
         int half = 0;
@@ -1503,6 +1561,7 @@ template <class T> class Engine final : public EngineBase {
             // find_neighbors at step % n_steps == 0 (:645, neighbors.jl:396) builds the list from the coordinates of THIS step; it is
             // scheduled before the force pass so that, with the dual pair list, that pass can prune the outer list on the way.
             // Forces are unaffected: the pass walks a superset of the old list and every interaction has a cutoff <= r_list.
+            if (trk_issued && step > trk_step) resolve_track(step);
             if (pre && check_due(step, every)) refresh(step);
             const bool cm = remove_cm_every != 0 && step % remove_cm_every == 0;
             if (!fused) {
@@ -1517,9 +1576,12 @@ template <class T> class Engine final : public EngineBase {
             const double* cm_in = cm_pending == 2 ? cm_src() : (const double*)nullptr;
             double* cm_out = cm ? cm_step.p + (size_t)half * 4 * 1024 : (double*)nullptr;
             prof.begin(2, stream);
+            // the speeds for a check that the next step's force pass will measure (see resolve_track)
+            float* v2p = nullptr;
+            if (step != last && async_ok() && !trk_issued && check_due(step + 1, every)) { trk_v2.reserve(1024); v2p = trk_v2.p; trk_v2_step = step + 1; trk_v2_n = nb; }
             auto go = [&](auto kern) {
                 hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, stream, n_owned, pos[cur].p, vel[cur].p, (const T4*)frc[cur].p, T(dt), T(dt) / T(2),
-                                   cm_in, n_cm_step, cm_out, (const T4*)pend_a, (const T4*)pend_b, G);
+                                   cm_in, n_cm_step, cm_out, (const T4*)pend_a, (const T4*)pend_b, G, v2p);
             };
             if (step == last) { if (cm) go(k_vv_mid<T, true, true>); else go(k_vv_mid<T, false, true>); }
             else { if (cm) go(k_vv_mid<T, true, false>); else go(k_vv_mid<T, false, false>); }
@@ -1582,6 +1644,7 @@ template <class T> class Engine final : public EngineBase {
         const int nb = std::min(cdiv(n_owned, 256), 1024);
         int half = 0;
         for (int64_t step = first_step + 1; step <= first_step + n_steps; ++step) {
+            resolve_track(step);
             step_forces(step);                                                    // :1173
             fold_side_forces();
             const bool cm = remove_cm_every != 0 && step % remove_cm_every == 0;
