@@ -5,7 +5,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmollyhip.so")
+LIB_PATH = os.environ.get("MOLLYHIP_LIB_AB") or os.path.join(_HERE, "libmollyhip.so")   # (MOLLYHIP_LIB_AB: another build of the library, for A/B timing on one box)
 
 MEM_HOST, MEM_DEVICE = 0, 1
 CUTOFF_NONE, CUTOFF_DISTANCE, CUTOFF_SHIFTED_POTENTIAL, CUTOFF_SHIFTED_FORCE, CUTOFF_CUBIC_SPLINE, CUTOFF_POLYNOMIAL = range(6)

@@ -634,14 +634,15 @@ template <class T> class Engine final : public EngineBase {
         return last_vmax * growth * cur_dt * every;
     }
 
-    // Validity checks without a kernel or a pipeline drain of their own (mhip_vv_run's fused loop, dual list, no ghosts).  At a check
-    // step s the displacement maxima are taken by the force pass itself (k_forces, per block; the speed maximum by the integrator launch
-    // before it), reduced by one tiny launch and copied to pinned memory behind an event.  The host reads them at step s + 1 — by then
-    // the GPU has the integrator launch of step s still queued, so it does not run dry — and applies the decision there: the pass of
-    // step s was covered by the previous decision's horizon (it reached up to the check step), a prune or a search that the
-    // measurement asks for happens at s + 1 (one step of headroom in the outer-list test).
-    DBuf<float> trk_blk, trk_v2, trk_out; float* h_trk = nullptr; hipEvent_t ev_trk = nullptr;
-    bool trk_want = false, trk_issued = false; int64_t trk_step = -1, trk_v2_step = -1; int trk_v2_n = 0; double trk_prev_vmax = 0;   // trk_v2_step: the step whose pass the recorded speeds belong to
+    // Validity checks without a kernel or a pipeline drain of their own (mhip_vv_run's fused loop, dual list, no ghosts).  The integrator
+    // launch that makes the coordinates of a check step s also takes the maxima the check needs — |x − snapshot|² against the inner
+    // and the outer list's snapshot, |v|² — per block; one tiny launch reduces them into pinned memory behind an event.  The host
+    // reads them at step s + 1, when they have long arrived, and applies the decision there: the pass of step s was covered by the
+    // previous decision's horizon (it reached up to the check step), a prune or a search that the measurement asks for happens at
+    // s + 1 (with that step of headroom in the outer-list test).  (Taking the maxima inside k_forces instead cost its packed loop
+    // 14 % through a different register assignment, with the same instructions: measured, dropped.)
+    DBuf<float> trk_part, trk_out; float* h_trk = nullptr; hipEvent_t ev_trk = nullptr;
+    bool trk_issued = false; int64_t trk_step = -1, trk_prune_step = -1, trk_outer_step = -1; double trk_prev_vmax = 0;
     const bool async_checks = env_int("MOLLYHIP_ASYNC_CHECKS", 1) != 0;
     bool in_vv_fused = false;
     bool async_ok() const { return async_checks && in_vv_fused && dual && n_ghost == 0 && !host_prune && !strict_cadence && inner_valid && !stale; }
@@ -652,7 +653,7 @@ template <class T> class Engine final : public EngineBase {
         const double d = std::sqrt((double)h_trk[0]), d_outer = std::sqrt((double)h_trk[1]);
         prev_vmax = trk_prev_vmax; last_vmax = std::sqrt((double)h_trk[2]);   // (the speed of the check before, as it was when this one was issued: a run cut into chunks decides alike)
         ++n_disp_checks;
-        if (!dual || stale || !inner_valid || n_ghost > 0) return;          // something else has dealt with the lists meanwhile
+        if (!dual || stale || !inner_valid || n_ghost > 0 || last_prune_step != trk_prune_step || last_outer_step != trk_outer_step) return;   // the lists it measured have been replaced meanwhile
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         const int64_t so_far = trk_step - last_prune_step;
         const double ahead = drift_ahead(d, so_far, every);
@@ -707,8 +708,8 @@ template <class T> class Engine final : public EngineBase {
         // the next force pass) only when it is about to fail.  mhip_export_neighbors always returns the exact list of NOW.
         if (host_prune && inner_valid && !strict_cadence) { last_build_step = step_n; ++n_rebuilds; return; }   // the host calls mhip_request_prune
         bool reprune = strict_cadence || !inner_valid;
-        if (!reprune && async_ok() && trk_v2_step == step_n && !trk_issued) {   // measured inside this step's force pass, decided one step later
-            trk_want = true; trk_step = step_n; trk_prev_vmax = last_vmax; last_build_step = step_n; ++n_rebuilds;
+        if (!reprune && trk_issued && trk_step == step_n && async_ok()) {   // measured by the integrator launch that made these coordinates; decided one step later
+            last_build_step = step_n; ++n_rebuilds;
             return;
         }
         if (!reprune) {
@@ -801,13 +802,6 @@ template <class T> class Engine final : public EngineBase {
             for (int k = 2; k >= 0; --k) if ((use_inner ? max_tile_in : max_tile) + 1 < SOA_STRIDES[k]) A.soa = SOA_STRIDES[k];   // the smallest stride that holds tile + sentinel
         if (A.soa) lds_force = std::max(lds_force, (size_t)3 * A.soa * sizeof(float) + 64);
         A.part = 0; A.blk_ghost = nullptr;
-        const bool track = trk_want && use_inner && !prune && !energy && part == 0;
-        A.trk_blk = nullptr; A.trk_snap_in = nullptr; A.trk_snap_out = nullptr;
-        if (track) {
-            trk_blk.reserve(2 * (size_t)n_blocks); trk_out.reserve(4);
-            MHIP_HIP(hipMemsetAsync(trk_blk.p, 0, 2 * (size_t)n_blocks * sizeof(float), stream));
-            A.trk_blk = trk_blk.p; A.trk_snap_in = pos_snap_in.p; A.trk_snap_out = pos_snap.p;
-        }
         if (part != 0 && !prune) {   // blocks without / with ghost atoms in their tile (flags of the tile this pass stages)
             DBuf<int32_t>& fl = use_inner ? blk_ghost_in : blk_ghost; bool& ok = use_inner ? ghost_flags_in_ok : ghost_flags_ok;
             if (!ok) {
@@ -839,15 +833,6 @@ template <class T> class Engine final : public EngineBase {
         prof.end(prune ? 4 : 0, stream);
         MHIP_HIP(hipGetLastError());
         ++n_force_calls;
-        if (trk_want && !track) { trk_want = false; if (!prune) next_check_step = trk_step; }   // (not a plain pass after all: the check is repeated, the usual way, before the next pass; a prune needs none)
-        if (track) {
-            if (!h_trk) MHIP_HIP(hipHostMalloc((void**)&h_trk, 4 * sizeof(float)));
-            if (!ev_trk) MHIP_HIP(hipEventCreateWithFlags(&ev_trk, hipEventDisableTiming));
-            hipLaunchKernelGGL(k_track_reduce, dim3(1), dim3(256), 0, stream, n_blocks, (const float*)trk_blk.p, trk_v2_n, (const float*)trk_v2.p, trk_out.p);
-            MHIP_HIP(hipMemcpyAsync(h_trk, trk_out.p, 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
-            MHIP_HIP(hipEventRecord(ev_trk, stream));
-            trk_want = false; trk_issued = true; trk_v2_step = -1;
-        }
         if (prune) {   // validity of the pruned list: nobody moved more than half the margin since the outer search
             MHIP_HIP(hipMemsetAsync(flags.p, 0, N_FLAGS * sizeof(int32_t), stream));
             if (n_ghost > 0)   // the blocks record the displacement of the owned atoms; the ghosts' comes on top
@@ -989,7 +974,7 @@ template <class T> class Engine final : public EngineBase {
         hipLaunchKernelGGL(k_iota2, dim3(std::min(cdiv(n_tot, 256), 1024)), dim3(256), 0, stream, n_tot, orig[cur].p, inv.p);
         MHIP_HIP(hipMemsetAsync(frc[cur].p, 0, n_tot * sizeof(T4), stream));
         MHIP_HIP(hipGetLastError());
-        stale = true; cm_pending = 0; cm_ext = nullptr; frc_valid = false; hp_set = false; halo_cm_in = false; trk_issued = false; trk_want = false; trk_v2_step = -1;
+        stale = true; cm_pending = 0; cm_ext = nullptr; frc_valid = false; hp_set = false; halo_cm_in = false; trk_issued = false;
         // the search radius depends on whether there are ghosts and on the ghost margin, the blocking on the size class: a re-plan
         // that changes neither keeps the grid, its Hilbert table and the (already adapted) capacities
         const int size_class = n_owned >= 100000 ? 2 : (n_owned >= 40000 ? 1 : 0);
@@ -1496,7 +1481,7 @@ template <class T> class Engine final : public EngineBase {
         tr("k_vv_mid");
         auto go = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, stream, n_owned, pos[cur].p, vel[cur].p, (const T4*)frc[cur].p, T(dt), T(dt) / T(2),
-                               cm_in, n_in, cm_out, (const T4*)pend_a, (const T4*)pend_b, G, (float*)nullptr);
+                               cm_in, n_in, cm_out, (const T4*)pend_a, (const T4*)pend_b, G, (const T4*)nullptr, (const T4*)nullptr, (float*)nullptr);
         };
         if (last) { if (cm) go(k_vv_mid<T, true, true>); else go(k_vv_mid<T, false, true>); }
         else { if (cm) go(k_vv_mid<T, true, false>); else go(k_vv_mid<T, false, false>); }
@@ -1577,15 +1562,24 @@ template <class T> class Engine final : public EngineBase {
             double* cm_out = cm ? cm_step.p + (size_t)half * 4 * 1024 : (double*)nullptr;
             prof.begin(2, stream);
             // the speeds for a check that the next step's force pass will measure (see resolve_track)
-            float* v2p = nullptr;
-            if (step != last && async_ok() && !trk_issued && check_due(step + 1, every)) { trk_v2.reserve(1024); v2p = trk_v2.p; trk_v2_step = step + 1; trk_v2_n = nb; }
+            const bool measure = step != last && async_ok() && !trk_issued && check_due(step + 1, every);
+            if (measure) { trk_part.reserve(3 * 1024); trk_out.reserve(4); }
             auto go = [&](auto kern) {
                 hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, stream, n_owned, pos[cur].p, vel[cur].p, (const T4*)frc[cur].p, T(dt), T(dt) / T(2),
-                                   cm_in, n_cm_step, cm_out, (const T4*)pend_a, (const T4*)pend_b, G, v2p);
+                                   cm_in, n_cm_step, cm_out, (const T4*)pend_a, (const T4*)pend_b, G,
+                                   measure ? (const T4*)pos_snap_in.p : (const T4*)nullptr, measure ? (const T4*)pos_snap.p : (const T4*)nullptr, measure ? trk_part.p : (float*)nullptr);
             };
             if (step == last) { if (cm) go(k_vv_mid<T, true, true>); else go(k_vv_mid<T, false, true>); }
             else { if (cm) go(k_vv_mid<T, true, false>); else go(k_vv_mid<T, false, false>); }
             prof.end(2, stream);
+            if (measure) {   // the check of step + 1: reduce, copy, event — read by resolve_track at step + 2
+                if (!h_trk) MHIP_HIP(hipHostMalloc((void**)&h_trk, 4 * sizeof(float)));
+                if (!ev_trk) MHIP_HIP(hipEventCreateWithFlags(&ev_trk, hipEventDisableTiming));
+                hipLaunchKernelGGL(k_track_reduce, dim3(1), dim3(256), 0, stream, nb, (const float*)trk_part.p, trk_out.p);
+                MHIP_HIP(hipMemcpyAsync(h_trk, trk_out.p, 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
+                MHIP_HIP(hipEventRecord(ev_trk, stream));
+                trk_issued = true; trk_step = step + 1; trk_prev_vmax = last_vmax; trk_prune_step = last_prune_step; trk_outer_step = last_outer_step;
+            }
             pend_a = pend_b = nullptr;
             cm_pending = 0; cm_ext = nullptr;
             if (cm) { cm_pending = 2; cm_ext = cm_out; n_cm_step = nb; half ^= 1; }

@@ -692,16 +692,14 @@ __global__ void k_uniform_check(int64_t n, const T* __restrict__ sig, const T* _
 }
 
 // reduce the per-block / per-wave results of k_build or k_filter into the flag words the host reads (flags zeroed before)
-// out[0], out[1] = max over the blocks of blk2[2b], blk2[2b + 1]; out[2] = max of v2_part[0 .. n_v2) — one block, plain stores
-[[maybe_unused]] static __global__ void k_track_reduce(int n_blocks, const float* __restrict__ blk2, int n_v2, const float* __restrict__ v2_part, float* out) {
-    float a = 0.f, b = 0.f, c = 0.f;
-    for (int q = threadIdx.x; q < n_blocks; q += blockDim.x) { a = fmaxf(a, blk2[2 * q]); b = fmaxf(b, blk2[2 * q + 1]); }
-    for (int q = threadIdx.x; q < n_v2; q += blockDim.x) c = fmaxf(c, v2_part[q]);
-    a = wave_max(a); b = wave_max(b); c = wave_max(c);
+// out[c] = max of part[c·n .. (c + 1)·n), c = 0, 1, 2 — one block, plain stores (the three maxima of a validity check, k_vv_mid)
+[[maybe_unused]] static __global__ void k_track_reduce(int n, const float* __restrict__ part, float* out) {
+    float m[3] = {0.f, 0.f, 0.f};
+    for (int q = threadIdx.x; q < n; q += blockDim.x) { m[0] = fmaxf(m[0], part[q]); m[1] = fmaxf(m[1], part[n + q]); m[2] = fmaxf(m[2], part[2 * n + q]); }
     __shared__ float sh[3][16];
-    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = b; sh[2][threadIdx.x >> 6] = c; }
+    for (int c = 0; c < 3; ++c) { m[c] = wave_max(m[c]); if ((threadIdx.x & 63) == 0) sh[c][threadIdx.x >> 6] = m[c]; }
     __syncthreads();
-    if (threadIdx.x < 3) { float m = 0.f; for (int q = 0; q < (int)(blockDim.x >> 6); ++q) m = fmaxf(m, sh[threadIdx.x][q]); out[threadIdx.x] = m; }
+    if (threadIdx.x < 3) { float r = 0.f; for (int q = 0; q < (int)(blockDim.x >> 6); ++q) r = fmaxf(r, sh[threadIdx.x][q]); out[threadIdx.x] = r; }
 }
 
 [[maybe_unused]] static __global__ void k_build_summary(int n_blocks, int n_waves, int R_cap, const int32_t* __restrict__ tile_cnt, int32_t* wave_rows,
@@ -943,9 +941,6 @@ template <class T> struct ForceArgs {
     // ghosted sub-domains: a pass over only the blocks whose tile holds no ghost atom (part 1: they can run while the ghost coordinates
     // are still on the wire) or only the others (part 2); 0 = every block
     const int32_t* blk_ghost; int part;
-    // displacement tracking inside a plain pass (the validity check of the pair lists without a kernel of its own): per block the largest
-    // |x − snapshot|² of its atoms against the inner list's snapshot and the outer list's, trk_blk[2b], trk_blk[2b + 1] (zeroed by the caller)
-    const typename Vec<T>::T4* trk_snap_in; const typename Vec<T>::T4* trk_snap_out; float* trk_blk;
 };
 // strides the packed loop is compiled for (odd numbers of dwords): tiles of up to stride − 1 atoms, 12·stride bytes of LDS.  The
 // smallest that holds the tile is used: 36 KiB leaves room for four 512-lane blocks per CU, 48 KiB for three (measured: −12 % per pass).
@@ -1191,27 +1186,6 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_forces(ForceArg
         }
         __syncthreads();   // l_new overlays the region the j-split reduction is about to use
     }
-    if constexpr (!PRUNE && !ENERGY) {
-        if (A.trk_blk) {   // (uniform per launch)
-            float da = 0.f, db = 0.f;
-            if (valid && js == 0) {
-                const T4 p0 = A.pos[si];
-                T4 q = A.trk_snap_in[si];
-                T ex = p0.x - q.x, ey = p0.y - q.y, ez = p0.z - q.z;
-                disp_image(ex, ey, ez, G);
-                da = (float)(ex * ex + ey * ey + ez * ez);
-                q = A.trk_snap_out[si];
-                ex = p0.x - q.x; ey = p0.y - q.y; ez = p0.z - q.z;
-                disp_image(ex, ey, ez, G);
-                db = (float)(ex * ex + ey * ey + ez * ez);
-            }
-            da = wave_max(da); db = wave_max(db);
-            if (js == 0 && (tid & 63) == 0) {   // <= 4 waves per block and word
-                atomicMax(reinterpret_cast<unsigned int*>(A.trk_blk + 2 * b), __float_as_uint(da));
-                atomicMax(reinterpret_cast<unsigned int*>(A.trk_blk + 2 * b + 1), __float_as_uint(db));
-            }
-        }
-    }
     if (A.JS > 1) {   // deterministic reduction of the j-split partial sums through LDS
         __syncthreads();
         T* red = reinterpret_cast<T*>(smem);
@@ -1369,9 +1343,12 @@ __global__ void k_vv2(int64_t n, typename Vec<T>::T4* vel, typename Vec<T>::T4* 
 template <class T, bool CM, bool LAST>
 __global__ void k_vv_mid(int64_t n, typename Vec<T>::T4* pos, typename Vec<T>::T4* vel, const typename Vec<T>::T4* __restrict__ fr, T dt, T dt2,
                          const double* __restrict__ cm_in, int n_cm_in, double* cm_out,
-                         const typename Vec<T>::T4* __restrict__ fa, const typename Vec<T>::T4* __restrict__ fb, GridP<T> G, float* v2_part = nullptr) {
+                         const typename Vec<T>::T4* __restrict__ fa, const typename Vec<T>::T4* __restrict__ fb, GridP<T> G,
+                         const typename Vec<T>::T4* __restrict__ snap_a = nullptr, const typename Vec<T>::T4* __restrict__ snap_b = nullptr, float* trk_part = nullptr) {
     const typename Vec<T>::T4* __restrict__ frc = fr;
-    float v2m = 0.f;   // largest |v|² this block leaves behind (v2_part: the speed bound of the pair lists' validity check)
+    // trk_part (the validity check of the pair lists, taken where the new coordinates are made): per block the largest |x − snap_a|²,
+    // |x − snap_b|² and |v|² of what this launch leaves behind, trk_part[c·gridDim.x + block]
+    float v2m = 0.f, dam = 0.f, dbm = 0.f;
     T vc[3] = {T(0), T(0), T(0)};
     const bool sub = cm_in != nullptr;
     if (sub) block_vcm<T>(cm_in, n_cm_in, vc);
@@ -1400,14 +1377,24 @@ __global__ void k_vv_mid(int64_t n, typename Vec<T>::T4* pos, typename Vec<T>::T
         }
         if (LAST && (fa || fb)) const_cast<typename Vec<T>::T4*>(frc)[s] = f;  // the total force of the last step stays readable
         vel[s] = v;
-        v2m = fmaxf(v2m, (float)(v.x * v.x + v.y * v.y + v.z * v.z));
+        if (trk_part) {
+            v2m = fmaxf(v2m, (float)(v.x * v.x + v.y * v.y + v.z * v.z));
+            auto q = snap_a[s];
+            T ex = p.x - q.x, ey = p.y - q.y, ez = p.z - q.z;
+            disp_image(ex, ey, ez, G);
+            dam = fmaxf(dam, (float)(ex * ex + ey * ey + ez * ez));
+            q = snap_b[s];
+            ex = p.x - q.x; ey = p.y - q.y; ez = p.z - q.z;
+            disp_image(ex, ey, ez, G);
+            dbm = fmaxf(dbm, (float)(ex * ex + ey * ey + ez * ez));
+        }
     }
-    if (v2_part) {
-        __shared__ float shv[16];
-        v2m = wave_max(v2m);
-        if ((threadIdx.x & 63) == 0) shv[threadIdx.x >> 6] = v2m;
+    if (trk_part) {
+        __shared__ float sht[3][16];
+        dam = wave_max(dam); dbm = wave_max(dbm); v2m = wave_max(v2m);
+        if ((threadIdx.x & 63) == 0) { sht[0][threadIdx.x >> 6] = dam; sht[1][threadIdx.x >> 6] = dbm; sht[2][threadIdx.x >> 6] = v2m; }
         __syncthreads();
-        if (threadIdx.x == 0) { float m = 0.f; for (int q = 0; q < (int)(blockDim.x >> 6); ++q) m = fmaxf(m, shv[q]); v2_part[blockIdx.x] = m; }
+        if (threadIdx.x < 3) { float m = 0.f; for (int q = 0; q < (int)(blockDim.x >> 6); ++q) m = fmaxf(m, sht[threadIdx.x][q]); trk_part[threadIdx.x * gridDim.x + blockIdx.x] = m; }
     }
     if constexpr (CM) {
         __shared__ double shm[4][4];
