@@ -25,12 +25,26 @@ def test_library_exports_every_declared_symbol(pkg):
         assert getattr(lib, name) is not None
 
 
+def test_ctypes_signatures_have_the_header_arity(pkg):
+    """every binding passes as many arguments as the C declaration takes (a changed prototype must not go unnoticed in the ctypes layer)"""
+    text = open(os.path.join(ROOT, "include", "mollyhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    decls = dict(re.findall(r"\b(mhip_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S))
+    assert set(decls) == set(pkg.SIGNATURES)
+    for name, params in decls.items():
+        params = params.strip()
+        n = 0 if params in ("", "void") else params.count(",") + 1
+        assert n == len(pkg.SIGNATURES[name][1]), (name, params)
+
+
 def test_struct_layouts_match_header(pkg):
     import ctypes as C
     # sizes computed from the C declarations (LP64): see include/mollyhip.h
     assert C.sizeof(pkg.Interactions) == 4 * 2 + 8 * 3 + 4 * 2 + 8 * 6 + 4 * 2
     assert C.sizeof(pkg.Config) == 4 * 2 + 8 + 24 + 24 + 12 + 4 + 8 + C.sizeof(pkg.Interactions)
     assert C.sizeof(pkg.Stats) == 8 * 9 + 4 * 4 + 8 * 3 + 8 + 8 * 8 + 8 * 8 + 16
+    from molly_jl_amd import _lib
+    assert C.sizeof(_lib.HaloPlan) == 8 * 2 + 8 * 2 + 4 * 2 + 8 * 2 + 8 + 8 + 8 + 4 + 4     # mhip_halo_plan (…, n_send_cm + tail padding)
 
 
 def test_product_path_fails_loudly_without_gpu(pkg):
