@@ -58,6 +58,7 @@ template <class T> struct GridP {
 template <class T> struct InterP {
     int lj, lj_cut; T lj_rc, lj_rc2, lj_ra, lj_w;
     T lj_s2, lj_24e, lj_4e;    // uniform-LJ fast path: σ², 24ϵ, 4ϵ of the single atom type
+    T lj_c6, lj_c12;           // … and 24ϵσ⁶, 48ϵσ¹² (the packed loop's F/r = (c12/r⁶ − c6)/r⁸; 0 when they leave the normal fp32 range)
     int coul, coul_cut; T c_rc, c_rc2, c_ra, ke, c_w;
     T krf, crf;                // reaction-field constants for non-special pairs (coulomb.jl:764-768,799-803)
     T alpha, two_over_sqrt_pi;

@@ -149,6 +149,14 @@ template <class T> class Engine final : public EngineBase {
     // blocks
     int BI = 256, JS = 1, n_blocks = 0, T_cap = 0, R_cap = 0, C_cap = 0, max_tile = 0, max_rows = 0;
     int ljm_base = LJ_OFF;   // LJ mode implied by the interaction; ljm may be upgraded to the uniform fast path
+    // entry format of the pair lists in use (kernels.h: entry_slot / make_entry), fixed at the outer search: byte-offset entries for the
+    // fp32 one-type LJ fluids (their packed loop then spends one instruction per partner on its LDS address), slot + flag otherwise
+    int eshift = 0;
+    bool scaled_entries_off = false;   // a tile too large for 14-bit slots was met: back to the slot + flag format for good
+    int want_eshift() const {
+        return (!scaled_entries_off && std::is_same<T, float>::value && ljm == LJ_DIST_UNIFORM && coulm == MHIP_COUL_NONE && n_special == 0 && !tri_mode && !G.no_list && !env_int("MOLLYHIP_NO_SCALED_ENTRIES", 0)) ? ESHIFT_SCALED : 0;
+    }
+    int slot_cap() const { return ((want_eshift() ? SLOT_MAX_SCALED : TILE_SLOT_MAX) - 1) & ~3; }
     DBuf<int32_t> tile_idx, tile_cnt, wave_rows; DBuf<uint2> nbr; DBuf<T4> blk_center;
     // dual pair list: outer list (nbr / wave_rows, radius r_list + margin) and the inner list filtered from it
     DBuf<int32_t> wave_rows_in, tile_idx_in, tile_cnt_in, rows_x, tile_idx_x, tile_cnt_x; DBuf<uint2> nbr_in, nbr_x; DBuf<T4> pos_snap; DBuf<float> blk_disp2; int max_tile_in = 0;
@@ -412,7 +420,7 @@ template <class T> class Engine final : public EngineBase {
             C_cap = (int)std::min<double>(cells * 1.2 + 8, MAX_BOX_CELLS);
         }
         T_cap = std::max(T_cap, 16); R_cap = std::max(R_cap, 2); C_cap = std::max(C_cap, 8);
-        T_cap = std::min((T_cap + 3) & ~3, (TILE_SLOT_MAX - 1) & ~3);   // multiple of 4: keeps the LDS carve-up 8-byte aligned
+        T_cap = std::min((T_cap + 3) & ~3, slot_cap());   // multiple of 4: keeps the LDS carve-up 8-byte aligned
     }
 
     template <class K> void set_lds_limit(K kern, size_t bytes) {
@@ -499,6 +507,7 @@ template <class T> class Engine final : public EngineBase {
             A.debug = env_int("MOLLYHIP_BUILD_DEBUG", 0);
             A.approx = dual && !env_int("MOLLYHIP_EXACT_OUTER", 0) ? 1 : 0;
             A.walk = walk ? 1 : 0;
+            A.eshift = eshift = want_eshift();
             prof.begin(1, stream);
             tr("k_build");
             auto go = [&](auto kern) { set_lds_limit(kern, lds); hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(BI * JS), lds, stream, A); };
@@ -513,15 +522,16 @@ template <class T> class Engine final : public EngineBase {
             int ovf = h_flags[FLAG_OVERFLOW];
             if (!ovf) break;
             if (ovf & OVF_SLOT) {
+                if (eshift) { scaled_entries_off = true; estimate_capacities(); continue; }
                 if (BI > 64) { BI /= 2; JS = std::min(JS * 2, MAX_THREADS / BI); estimate_capacities(); continue; }
-                throw ApiError{MHIP_ERR_CAPACITY, "more than 32766 atoms within r_list of one 64-atom block"};
+                throw ApiError{MHIP_ERR_CAPACITY, "more atoms within r_list of one 64-atom block than a 16-bit list entry can name"};
             }
             if (ovf & OVF_BOXCELLS) {
                 if (h_flags[FLAG_MAX_CELLS] <= MAX_BOX_CELLS) { C_cap = std::min<int>(MAX_BOX_CELLS, (int)(h_flags[FLAG_MAX_CELLS] * 1.1) + 8); continue; }
                 if (BI > 64) { BI /= 2; JS = std::min(JS * 2, MAX_THREADS / BI); estimate_capacities(); continue; }
                 throw ApiError{MHIP_ERR_CAPACITY, "block neighbourhood spans more than 8192 cells"};
             }
-            if (ovf & OVF_TILE) T_cap = std::min<int>((TILE_SLOT_MAX - 1) & ~3, (((int)(h_flags[FLAG_MAX_TILE] * 1.15) + 32) + 3) & ~3);
+            if (ovf & OVF_TILE) T_cap = std::min<int>(slot_cap(), (((int)(h_flags[FLAG_MAX_TILE] * 1.15) + 32) + 3) & ~3);
             if (ovf & OVF_ROWS) R_cap = (int)(h_flags[FLAG_MAX_ROWS] * 1.2) + 4;
             if (attempt == 11) throw ApiError{MHIP_ERR_CAPACITY, "neighbour structures did not converge"};
         }
@@ -579,6 +589,7 @@ template <class T> class Engine final : public EngineBase {
         F.G = G; F.n_owned = n_owned; F.BI = BI; F.BI_shift = ilog2(BI); F.JS = JS; F.T_cap = T_cap; F.R_cap = R_cap; F.n_blocks = n_blocks;
         F.pos = pos[cur].p; F.pos_snap = pos_snap.p; F.tile_idx = tile_idx.p; F.tile_cnt = tile_cnt.p; F.nbr_out = nbr.p; F.rows_out = wave_rows.p;
         F.nbr_in = d_nbr.p; F.rows_in = d_rows.p; F.tile_idx_in = d_tidx.p; F.tile_cnt_in = d_tcnt.p; F.blk_center = blk_center.p; F.blk_disp2 = blk_disp2.p; F.flags = flags.p;
+        F.eshift = eshift;
         F.r_in = r_in; F.r_in2 = to_inner ? r_prune2 : r_in2; F.exact_all = minimg ? 1 : 0; F.approx = to_inner && r_prune2 != r_in2 ? 1 : 0; F.debug = env_int("MOLLYHIP_FILTER_DEBUG", 0);
         F.T_lds = std::min<int>(max_tile, (MAX_LDS_BYTES - 256) / (int)sizeof(float4));
         F.T_lds = minimg ? 0 : F.T_lds;
@@ -788,19 +799,19 @@ template <class T> class Engine final : public EngineBase {
         if (dual && !inner_valid && !energy && prune_by_kernel) prune_with_filter();
         const bool use_inner = dual && inner_valid;
         const bool prune = dual && !inner_valid && !energy;
-        const size_t prune_extra = prune ? (size_t)((T_cap + 8) & ~7) + ((size_t)BI * JS + 2) * 4 + 32 : 0;   // a tile that fills the LDS is segmented a little earlier
+        const size_t prune_extra = prune ? prune_lds_bytes(std::min(T_cap, max_tile + 1), BI * JS) + 16 : 0;   // a tile that fills the LDS is segmented a little earlier
         carve_force_lds(use_inner ? max_tile_in : max_tile, prune_extra);
         A.T_lds = tile_lds;
         if (use_inner) { A.tile_idx = tile_idx_in.p; A.tile_cnt = tile_cnt_in.p; }
         A.nbr = use_inner ? nbr_in.p : nbr.p; A.wave_rows = use_inner ? wave_rows_in.p : wave_rows.p;
         A.nbr_dst = nullptr; A.rows_dst = nullptr; A.pos_snap = nullptr; A.blk_disp2 = nullptr; A.r_prune2 = r_prune2;
-        A.tile_idx_dst = nullptr; A.tile_cnt_dst = nullptr; A.mark_off = 0; A.any_special = n_special > 0 ? 1 : 0;
+        A.tile_idx_dst = nullptr; A.tile_cnt_dst = nullptr; A.mark_off = 0; A.snap_dst = nullptr; A.any_special = n_special > 0 ? 1 : 0; A.eshift = eshift;
         // the packed fp32 one-type loop keeps the tile as three arrays SOA_STRIDE dwords apart
         const bool fast_f32 = std::is_same<T, float>::value && ljm == LJ_DIST_UNIFORM && coulm == MHIP_COUL_NONE && !energy && !minimg && !segmented && n_special == 0;
         A.soa = 0;
-        if (fast_f32 && !no_soa)
+        if (fast_f32 && !no_soa && eshift == ESHIFT_SCALED && I.lj_c12 != T(0))
             for (int k = 2; k >= 0; --k) if ((use_inner ? max_tile_in : max_tile) + 1 < SOA_STRIDES[k]) A.soa = SOA_STRIDES[k];   // the smallest stride that holds tile + sentinel
-        if (A.soa) lds_force = std::max(lds_force, (size_t)3 * A.soa * sizeof(float) + 64);
+        if (A.soa) lds_force = std::max((size_t)3 * A.soa * sizeof(float) + 64, (size_t)JS * 4 * BI * sizeof(T) + 32);   // x[], y[], z[] instead of the generic 16-byte records
         A.part = 0; A.blk_ghost = nullptr;
         if (part != 0 && !prune) {   // blocks without / with ghost atoms in their tile (flags of the tile this pass stages)
             DBuf<int32_t>& fl = use_inner ? blk_ghost_in : blk_ghost; bool& ok = use_inner ? ghost_flags_in_ok : ghost_flags_ok;
@@ -817,12 +828,14 @@ template <class T> class Engine final : public EngineBase {
             MHIP_HIP(hipMemsetAsync(blk_disp2.p, 0, (size_t)n_blocks * sizeof(float), stream));
             A.nbr_dst = nbr_in.p; A.rows_dst = wave_rows_in.p; A.pos_snap = pos_snap.p; A.blk_disp2 = blk_disp2.p;
             pos_snap_in.reserve(cap);
-            MHIP_HIP(hipMemcpyAsync(pos_snap_in.p, pos[cur].p, (size_t)n_tot * sizeof(T4), hipMemcpyDeviceToDevice, stream));
+            // the snapshot the next displacement checks compare with: the owned atoms' by the kernel itself, ghosts by a copy
+            A.snap_dst = pos_snap_in.p;
+            if (n_ghost > 0) MHIP_HIP(hipMemcpyAsync(pos_snap_in.p + n_owned, pos[cur].p + n_owned, (size_t)n_ghost * sizeof(T4), hipMemcpyDeviceToDevice, stream));
             last_prune_step = last_build_step;
             tile_idx_in.reserve((size_t)n_blocks * T_cap); tile_cnt_in.reserve(n_blocks);
             A.tile_idx_dst = tile_idx_in.p; A.tile_cnt_dst = tile_cnt_in.p;
             A.mark_off = (int)((lds_force + 15) & ~(size_t)15);
-            lds_force = (size_t)A.mark_off + (size_t)((T_cap + 8) & ~7) + ((size_t)BI * JS + 2) * 4 + 16;   // + marks + scan scratch
+            lds_force = (size_t)A.mark_off + prune_lds_bytes(tile_lds, BI * JS);   // + renumbering table + scan scratch + wave boxes
             if (lds_force > (size_t)MAX_LDS_BYTES) throw ApiError{MHIP_ERR_CAPACITY, "prune pass LDS carve-up exceeds 160 KiB"};
         }
         A.blk_center = blk_center.p; A.frc = frc_override ? frc_override : frc[cur].p; A.pe_part = red_part.p;
@@ -1008,9 +1021,13 @@ template <class T> class Engine final : public EngineBase {
             if (uni) {
                 T sm = (h2[0] + h2[0]) / T(2), em = std::sqrt(h2[1] * h2[1]);   // the mixing rules applied to equal values
                 I.lj_s2 = sm * sm; I.lj_24e = T(24) * em; I.lj_4e = T(4) * em;
+                const double s6 = std::pow((double)sm, 6), c6 = 24.0 * (double)em * s6, c12 = 48.0 * (double)em * s6 * s6;
+                const bool normal = c12 > 1e-30 && c12 < 1e30 && c6 > 1e-30 && c6 < 1e30;   // else: the generic loop, which works on σ²/r²
+                I.lj_c6 = normal ? T(c6) : T(0); I.lj_c12 = normal ? T(c12) : T(0);
                 ljm = LJ_DIST_UNIFORM;
             }
         }
+        if (want_eshift() != eshift) stale = true;   // the lists in use are in the other entry format
         pc_valid = false;   // Σq, Σq² of the PME self / net-charge terms are read back only when an energy asks for them
         s3.release(); s4.release(); s5.release();
         params_set = true; frc_valid = false;
@@ -1688,7 +1705,7 @@ template <class T> class Engine final : public EngineBase {
         DBuf<unsigned long long>& counter = nl_counter; counter.reserve(1);
         MHIP_HIP(hipMemsetAsync(counter.p, 0, sizeof(unsigned long long), stream));
         hipLaunchKernelGGL(k_export_nl<T>, dim3(n_blocks), dim3(BI), 0, stream, n_blocks, BI, JS, T_cap, R_cap, n_owned, (const int32_t*)orig[cur].p, x_tidx, x_tcnt, x_nbr, x_rows,
-                           (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr, counter.p, 0ull);
+                           (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr, counter.p, 0ull, eshift);
         unsigned long long n = 0;
         MHIP_HIP(hipMemcpyAsync(&n, counter.p, sizeof(n), hipMemcpyDeviceToHost, stream));
         MHIP_HIP(hipStreamSynchronize(stream));
@@ -1696,7 +1713,7 @@ template <class T> class Engine final : public EngineBase {
             DBuf<int32_t> di, dj; DBuf<uint8_t> ds; di.reserve(n); dj.reserve(n); ds.reserve(n);
             MHIP_HIP(hipMemsetAsync(counter.p, 0, sizeof(unsigned long long), stream));
             hipLaunchKernelGGL(k_export_nl<T>, dim3(n_blocks), dim3(BI), 0, stream, n_blocks, BI, JS, T_cap, R_cap, n_owned, (const int32_t*)orig[cur].p, x_tidx, x_tcnt, x_nbr, x_rows,
-                               di.p, dj.p, ds.p, counter.p, n);
+                               di.p, dj.p, ds.p, counter.p, n, eshift);
             MHIP_HIP(hipMemcpyAsync(oi, di.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
             MHIP_HIP(hipMemcpyAsync(oj, dj.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
             MHIP_HIP(hipMemcpyAsync(osp, ds.p, n * sizeof(uint8_t), hipMemcpyDeviceToHost, stream));

@@ -22,6 +22,17 @@ enum { OVF_TILE = 1, OVF_ROWS = 2, OVF_BOXCELLS = 4, OVF_SLOT = 8 };
 constexpr int MAX_BOX_CELLS = 8192;
 constexpr uint32_t XL_EXCLUDED = 1u << 30, XL_SPECIAL = 1u << 31, XL_INDEX = (1u << 30) - 1u;
 
+// A list entry is 16 bits.  Two formats, fixed per list by the engine (`eshift`):
+//   eshift = 0: bits 0-14 the tile slot, bit 15 the reference's `special` flag (every system with per-atom parameters or 1-4 pairs);
+//   eshift = 2: the tile slot times four = the BYTE offset of the partner's x in the packed loop's x[] / y[] / z[] LDS arrays, no flag
+//               bit (fp32 one-type LJ fluids, which have no special pairs; tiles of up to 16 383 atoms).  The hot loop then spends one
+//               instruction per partner on its LDS address (v_and / v_lshrrev) instead of three (mask, shift, scale).
+constexpr int ESHIFT_SCALED = 2;
+constexpr int SLOT_MAX_SCALED = 16383;
+__host__ __device__ inline uint32_t entry_slot(uint32_t e, int sh) { return sh ? (e >> sh) : (e & 0x7fffu); }
+__host__ __device__ inline uint32_t entry_special(uint32_t e, int sh) { return sh ? 0u : (e >> 15); }
+__host__ __device__ inline uint32_t make_entry(uint32_t slot, uint32_t sp, int sh) { return sh ? (slot << sh) : (slot | (sp << 15)); }
+
 // ---------------------------------------------------------------------------------------------------
 // small helpers
 template <class T> __device__ inline int cell_coord(T x, int d, const GridP<T>& G) {
@@ -225,6 +236,7 @@ template <class T> struct BuildArgs {
     int debug;                       // MOLLYHIP_BUILD_DEBUG: stop after stage n (timing experiments only)
     int approx;                      // outer list of the dual scheme: any superset of r_list will do, skip the exact band test
     int walk;                        // search by walking every i-atom's cell stencil over the tile (1) or transposed, tile groups against the wave's i-atoms (0)
+    int eshift;                      // entry format of the emitted rows (0 | ESHIFT_SCALED)
 };
 
 // exclusive prefix sum of a[0..n) in LDS, in place; a[n] receives the total.  `part` holds blockDim ints.
@@ -461,8 +473,9 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
         }
         __syncthreads();
     }
-    if (tile_n > A.T_cap || tile_n > TILE_SLOT_MAX - 1) {
-        if (tid == 0) { atomicOr(&A.flags[FLAG_OVERFLOW], tile_n > TILE_SLOT_MAX - 1 ? OVF_SLOT : OVF_TILE); atomicMax(&A.flags[FLAG_MAX_TILE], tile_n); A.tile_cnt[b] = 0; }
+    const int slot_max = A.eshift ? SLOT_MAX_SCALED : TILE_SLOT_MAX;
+    if (tile_n > A.T_cap || tile_n > slot_max - 1) {
+        if (tid == 0) { atomicOr(&A.flags[FLAG_OVERFLOW], tile_n > slot_max - 1 ? OVF_SLOT : OVF_TILE); atomicMax(&A.flags[FLAG_MAX_TILE], tile_n); A.tile_cnt[b] = 0; }
         if (lane == 0) A.wave_rows[(b * A.JS + js) * NW + wv] = 0;
         return;   // the host grows the capacities and rebuilds
     }
@@ -479,7 +492,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
     //    evaluated in block-local coordinates; only pairs within a 1e-4 band of r_list² — where rounding could
     //    change the outcome — are re-evaluated with the reference's exact arithmetic, so the emitted pair SET is
     //    bit-identical to the reference's.
-    const uint32_t SENT = (uint32_t)tile_n;
+    const uint32_t SENT = make_entry((uint32_t)tile_n, 0u, A.eshift);
     // four 16-bit entries per row and lane, collected in a 64-bit shift register: the newest entry enters at the top, after four
     // of them the oldest sits in bits 0-15 (two shifts and an OR per entry instead of indexed sub-word inserts)
     uint64_t pack = 0;
@@ -555,7 +568,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
                             if (hit & XL_EXCLUDED) return;
                             sp = hit >> 31;
                         }
-                        emit((uint32_t)tc | (sp << 15));
+                        emit(make_entry((uint32_t)tc, sp, A.eshift));
                     };
                     // four candidates per round, their coordinates fetched together: with four waves per SIMD the LDS latency of one
                     // dependent read per candidate was what the walk waited for
@@ -661,7 +674,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
                     if (hit & XL_EXCLUDED) continue;
                     sp = hit >> 31;
                 }
-                emit(t | (sp << 15));
+                emit(make_entry(t, sp, A.eshift));
             }
         }
         }   // transposed search
@@ -782,6 +795,7 @@ template <class T> struct FilterArgs {
     int exact_all;                            // small boxes: block-local coordinates are ambiguous, decide every pair exactly
     int approx;                               // any superset of r_in will do (the force passes' inner list): no exact decisions in the band
     int debug;                                // MOLLYHIP_FILTER_DEBUG (timing experiments only): 1 no row stores, 2 and no marks, 3 and no compaction / renumbering
+    int eshift;                               // entry format of both lists (0 | ESHIFT_SCALED)
 };
 
 template <class T>
@@ -831,6 +845,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_filter(FilterAr
     uint2* dst = A.nbr_in + (((int64_t)b * A.JS + js) * A.R_cap) * A.BI + li;
     const float rl2 = (float)A.r_in2, band_lo = rl2 * (1.0f - 1e-4f), band_hi = rl2 * (1.0f + 1e-4f);
     const uint32_t SENT = (uint32_t)tile_n;
+    const int esh = A.eshift;
     uint32_t pack[2] = {0, 0};
     int cnt = 0;
     auto emit = [&](uint32_t e) {
@@ -847,7 +862,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_filter(FilterAr
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             uint32_t e = ((k < 2 ? e4.x : e4.y) >> (16 * (k & 1))) & 0xffffu;
-            uint32_t slot = e & 0x7fffu;
+            uint32_t slot = entry_slot(e, esh);
             if (slot >= SENT || !valid) continue;
             bool in = false, maybe = true;
             if (use_lds) {
@@ -868,7 +883,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_filter(FilterAr
     }
     int rows_mine = (cnt + 3) >> 2;
     int rows_wave = wave_max(rows_mine);
-    while (((cnt + 3) >> 2) < rows_wave || (cnt & 3)) emit(SENT);
+    while (((cnt + 3) >> 2) < rows_wave || (cnt & 3)) emit(make_entry(SENT, 0u, esh));
     if (lane == 0) A.rows_in[wslot] = rows_wave;
     if (A.debug >= 3) return;
     // compact the tile to the referenced atoms: rank of every used slot (ordered), new tile list, rows rewritten in place
@@ -907,9 +922,9 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_filter(FilterAr
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             uint32_t e = ((k < 2 ? e4.x : e4.y) >> (16 * (k & 1))) & 0xffffu;
-            uint32_t slot = e & 0x7fffu;
+            uint32_t slot = entry_slot(e, esh);
             uint32_t ns = slot >= SENT ? n_in : (uint32_t)l_new[slot];
-            out[k >> 1] |= (ns | (e & 0x8000u)) << (16 * (k & 1));
+            out[k >> 1] |= make_entry(ns, entry_special(e, esh), esh) << (16 * (k & 1));
         }
         dst[(int64_t)r * A.BI] = make_uint2(out[0], out[1]);
     }
@@ -934,10 +949,12 @@ template <class T> struct ForceArgs {
     // PRUNE pass of the dual pair list: the rows read above are the OUTER list; entries with r² <= r_prune2 are re-emitted as
     // the inner list, and the displacement of the block's atoms since the outer build is recorded for the host's validity check
     uint2* nbr_dst; int32_t* rows_dst; const typename Vec<T>::T4* pos_snap; float* blk_disp2; T r_prune2;
-    // … and the tile is compacted to the atoms the inner list references (slots renumbered in the emitted rows)
-    int32_t* tile_idx_dst; int32_t* tile_cnt_dst; int mark_off;   // byte offset of the mark array in dynamic LDS
+    // … and the tile is compacted to the atoms that can be referenced (slots renumbered as the rows are emitted)
+    int32_t* tile_idx_dst; int32_t* tile_cnt_dst; int mark_off;   // byte offset of the renumbering table in dynamic LDS
+    typename Vec<T>::T4* snap_dst;   // PRUNE: the coordinates this prune saw, for the next displacement checks (nullptr: the host copies them)
     int any_special;                 // 0: no special (1-4) pair exists, the per-entry weight select is compiled out (uniform-LJ fluids)
     int soa;                         // != 0: the packed fp32 one-type loop with the tile as x[] / y[] / z[] arrays `soa` dwords apart
+    int eshift;                      // entry format of the rows read and written (0 | ESHIFT_SCALED)
     // ghosted sub-domains: a pass over only the blocks whose tile holds no ghost atom (part 1: they can run while the ghost coordinates
     // are still on the wire) or only the others (part 2); 0 = every block
     const int32_t* blk_ghost; int part;
@@ -945,9 +962,31 @@ template <class T> struct ForceArgs {
 // strides the packed loop is compiled for (odd numbers of dwords): tiles of up to stride − 1 atoms, 12·stride bytes of LDS.  The
 // smallest that holds the tile is used: 36 KiB leaves room for four 512-lane blocks per CU, 48 KiB for three (measured: −12 % per pass).
 constexpr int SOA_STRIDES[3] = {2049, 3073, 4097};
+// dynamic LDS a PRUNE pass needs behind its tile: the renumbering table (2 bytes per tile atom of a segment), scan scratch, wave boxes
+__host__ __device__ inline size_t prune_lds_bytes(int t_seg, int nthr) { return (size_t)(((t_seg + 8) & ~7) * 2) + ((size_t)nthr + 4) * 4 + 4 * 6 * 4 + 32; }
+
+// (the plain fp32 one-type passes run four 512-lane blocks per CU = eight waves per SIMD, which takes <= 64 VGPRs: held by attribute)
+#ifndef MHIP_FAST_MIN_WAVES
+#define MHIP_FAST_MIN_WAVES 8
+#endif
+#ifndef MHIP_D
+#define MHIP_D 2        // rows in flight in the packed loop (3 and 4 need scratch under the 64-VGPR bound: measured slower, +10 %)
+#endif
+#ifndef MHIP_SB
+#define MHIP_SB 4       // atoms per lane and staging round of the packed loop
+#endif
+#ifndef MHIP_HOIST
+#define MHIP_HOIST 0    // request the first rows before the tile is staged (1: 12 bytes of scratch, measured +4 %)
+#endif
+#ifndef MHIP_EXP
+#define MHIP_EXP 0      // timing experiments of the packed loop (tools/force_ab.py); 0 = the product
+#endif
+template <class T, int LJM, int COULM, bool ENERGY, bool MINIMG, bool SEG, bool PRUNE>
+constexpr int force_min_waves() { return (std::is_same<T, float>::value && LJM == LJ_DIST_UNIFORM && COULM == MHIP_COUL_NONE && !ENERGY && !MINIMG && !SEG && !PRUNE) ? MHIP_FAST_MIN_WAVES : 1; }
 
 template <class T, int LJM, int COULM, bool ENERGY, bool MINIMG, bool SEG, bool PRUNE, int SOA_STRIDE = 4097>
-__global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_forces(ForceArgs<T> A) {
+__global__ void __launch_bounds__(BlockLimits<T>::max_threads, (force_min_waves<T, LJM, COULM, ENERGY, MINIMG, SEG, PRUNE>()))
+k_forces(ForceArgs<T> A) {
     using T4 = typename Vec<T>::T4;
     using T2 = typename Vec<T>::T2;
     constexpr bool PER_ATOM_LJ = (LJM == LJ_DIST || LJM == LJ_GENERIC);
@@ -964,6 +1003,10 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_forces(ForceArg
     T4* l_pos = reinterpret_cast<T4*>(smem);
     T2* l_lj = reinterpret_cast<T2*>(l_pos + (A.T_lds + 1));
     const T4 ctr = A.blk_center[b];
+    // only the fp32 one-type variants ever see the scaled entry format (the engine chooses it for them alone)
+    constexpr int EXPV = PRUNE ? 0 : MHIP_EXP;   // (timing experiments never touch the pruning passes: the lists stay the product's)
+    constexpr bool MAY_SCALE = std::is_same<T, float>::value && LJM == LJ_DIST_UNIFORM && COULM == MHIP_COUL_NONE;
+    const int esh = MAY_SCALE ? A.eshift : 0;
 
     auto localise = [&](T4 p, auto tri_tag) -> T4 {
         if constexpr (!MINIMG) local_xyz_t<decltype(tri_tag)::value>(p.x, p.y, p.z, ctr, G);
@@ -976,13 +1019,15 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_forces(ForceArg
     const int li = tid & (A.BI - 1), js = tid >> A.BI_shift;
     const int64_t si = (int64_t)b * A.BI + li;
     const bool valid = si < A.n_owned;
-    T4 pi = A.pos[valid ? si : (int64_t)b * A.BI];
+    const T4 pi_raw = A.pos[valid ? si : (int64_t)b * A.BI];
+    T4 pi = pi_raw;
     if constexpr (NO_TRI) pi = localise(pi, std::false_type{});
     else pi = tri_local ? localise(pi, std::true_type{}) : localise(pi, std::false_type{});
     T2 lji = make2<T>(T(0), T(0));
     if constexpr (PER_ATOM_LJ) lji = A.lj[valid ? si : (int64_t)b * A.BI];
-    const int rows = A.wave_rows[(b * A.JS + js) * (A.BI >> 6) + (li >> 6)];               // this wave's own sub-list: the
-    const uint2* my_rows = A.nbr + (((int64_t)b * A.JS + js) * A.R_cap) * A.BI + li;       // j-split was done by k_build
+    // this wave's own sub-list (the j-split was done by k_build); the row count is the same for all 64 lanes: a scalar
+    const int rows = __builtin_amdgcn_readfirstlane(A.wave_rows[(b * A.JS + js) * (A.BI >> 6) + (li >> 6)]);
+    const uint2* my_rows = A.nbr + (((int64_t)b * A.JS + js) * A.R_cap) * A.BI + li;
     const int32_t* tix = A.tile_idx + (int64_t)b * A.T_cap;
     T fx = T(0), fy = T(0), fz = T(0), pe = T(0);
     [[maybe_unused]] T vir[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};   // ENERGY: Σ fr·(dx², dy², dz², dx·dy, dx·dz, dy·dz), the pair virial dr ⊗ f (force.jl:848-852)
@@ -991,10 +1036,24 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_forces(ForceArg
     int kept = 0;
     uint2* out_rows = nullptr;
     if constexpr (PRUNE) out_rows = A.nbr_dst + (((int64_t)b * A.JS + js) * A.R_cap) * A.BI + li;
-    [[maybe_unused]] uint8_t* l_mark = nullptr;
+    // PRUNE: renumbering table of the staged tile (segment): new slot of every tile atom that an inner-list entry of this block can
+    // name, decided BEFORE the rows are walked — a tile atom further than the prune radius from the bounding box of every wave's
+    // i-atoms is within the radius of none of them — so that the rows are emitted once, already renumbered (the marks taken during
+    // the walk, as before, meant writing the rows, reading them back and writing them again: 1.9× the traffic of the pass)
+    [[maybe_unused]] uint16_t* l_new = nullptr; [[maybe_unused]] int32_t* l_scan = nullptr; [[maybe_unused]] float* l_box = nullptr;
+    [[maybe_unused]] int n_new = 0;          // compacted tile atoms so far (block-uniform)
     if constexpr (PRUNE) {
-        l_mark = smem + A.mark_off;
-        for (int w = tid; w < ((tile_n + 3) >> 2); w += nthr) reinterpret_cast<uint32_t*>(l_mark)[w] = 0u;   // ordered before the marks by the staging barrier
+        l_new = reinterpret_cast<uint16_t*>(smem + A.mark_off);
+        l_scan = reinterpret_cast<int32_t*>(smem + A.mark_off + ((A.T_lds + 8) & ~7) * 2);
+        l_box = reinterpret_cast<float*>(l_scan + nthr + 4);
+        // bounding box of every wave of i-atoms, in the frame of the staged tile (block-local coordinates)
+        float mn[3] = {(float)pi.x, (float)pi.y, (float)pi.z}, mx[3] = {(float)pi.x, (float)pi.y, (float)pi.z};
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], __shfl_xor(mn[d], o, WAVE)); mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], o, WAVE)); }
+        if (js == 0 && (tid & 63) == 0) for (int d = 0; d < 3; ++d) { l_box[(li >> 6) * 6 + d] = mn[d]; l_box[(li >> 6) * 6 + 3 + d] = mx[d]; }
+        if (A.snap_dst && js == 0 && valid) A.snap_dst[si] = pi_raw;
     }
     auto emit = [&](uint32_t e) {
         pk = (pk >> 16) | ((uint64_t)e << 48);
@@ -1002,6 +1061,14 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_forces(ForceArg
         if ((kept & 3) == 0) out_rows[(int64_t)((kept >> 2) - 1) * A.BI] = make_uint2((uint32_t)pk, (uint32_t)(pk >> 32));
     };
 
+    constexpr bool FAST_CT = std::is_same<T, float>::value && LJM == LJ_DIST_UNIFORM && COULM == MHIP_COUL_NONE && !ENERGY && !MINIMG && !SEG;
+    // the packed loop keeps four rows in flight; the first four are requested here, before the tile is staged, so that the row
+    // stream's first memory latency passes behind the staging (indices clamped to the last row: always a valid address)
+    [[maybe_unused]] uint2 pre0 = make_uint2(0, 0), pre1 = pre0, pre2 = pre0, pre3 = pre0;
+    if constexpr (FAST_CT && MHIP_HOIST) {
+        const int last = max(rows - 1, 0);
+        pre0 = my_rows[0]; pre1 = my_rows[(int64_t)min(1, last) * A.BI]; pre2 = my_rows[(int64_t)min(2, last) * A.BI]; pre3 = my_rows[(int64_t)min(3, last) * A.BI];
+    }
     // The tile normally fits the LDS carve-up in one piece.  SEG: a tile larger than the LDS budget is
     // processed in segments; every segment re-walks the row stream and treats slots outside it as sentinels.
     const int seg_cap = A.T_lds;
@@ -1014,16 +1081,32 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_forces(ForceArg
         // arithmetic is packed (v_pk_*_f32).  The odd stride keeps the LDS load/store optimiser from fusing the x and y reads of one
         // partner into a ds_read2(st64)_b32 — which would put (x, y) of ONE partner side by side and cost a transpose per component —
         // and spreads the three reads over different banks.
-        constexpr bool FAST_CT = std::is_same<T, float>::value && LJM == LJ_DIST_UNIFORM && COULM == MHIP_COUL_NONE && !ENERGY && !MINIMG && !SEG;
-        const bool packed3 = FAST_CT && !A.any_special && A.soa == SOA_STRIDE;
+        const bool packed3 = FAST_CT && !A.any_special && A.soa == SOA_STRIDE && A.eshift == ESHIFT_SCALED;
         float* l_p3 = reinterpret_cast<float*>(smem);
+        // SB atoms per lane and round, their dependent fetches issued together (slot → sorted index → coordinates: one atom per lane
+        // and round left every round waiting for two memory latencies in a row, 10–20 µs per block at six rounds)
         auto stage = [&](auto tri_tag) {
-            for (int t = tid; t < n_here; t += nthr) {
-                int s = tix[seg_lo + t];
-                const T4 pl = localise(A.pos[s], tri_tag);
-                if (packed3) { l_p3[t] = (float)pl.x; l_p3[SOA_STRIDE + t] = (float)pl.y; l_p3[2 * SOA_STRIDE + t] = (float)pl.z; }
-                else l_pos[t] = pl;
-                if constexpr (PER_ATOM_LJ) l_lj[t] = A.lj[s];
+            constexpr int SB = (FAST_CT && !PRUNE) ? MHIP_SB : 4;
+            for (int t0 = 0; t0 < n_here; t0 += SB * nthr) {
+                int s[SB]; T4 p[SB]; [[maybe_unused]] T2 q[SB];
+#pragma unroll
+                for (int k = 0; k < SB; ++k) {
+                    const int t = min(t0 + k * nthr + tid, n_here - 1);     // (clamped: the loads of a lane past the end are harmless duplicates)
+                    s[k] = tix[seg_lo + t];
+                    if constexpr (EXPV == 3 || EXPV == 5) s[k] = (int)((int64_t)b * A.BI) + (t & (A.BI - 1));   // timing experiment: no staging gathers (the block's own atoms over and over)
+                }
+#pragma unroll
+                for (int k = 0; k < SB; ++k) { p[k] = A.pos[s[k]]; if constexpr (PER_ATOM_LJ) q[k] = A.lj[s[k]]; }
+#pragma unroll
+                for (int k = 0; k < SB; ++k) {
+                    const int t = t0 + k * nthr + tid;
+                    if (t < n_here) {
+                        const T4 pl = localise(p[k], tri_tag);
+                        if (packed3) { l_p3[t] = (float)pl.x; l_p3[SOA_STRIDE + t] = (float)pl.y; l_p3[2 * SOA_STRIDE + t] = (float)pl.z; }
+                        else l_pos[t] = pl;
+                        if constexpr (PER_ATOM_LJ) l_lj[t] = q[k];
+                    }
+                }
             }
         };
         if constexpr (NO_TRI) stage(std::false_type{});
@@ -1034,55 +1117,139 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_forces(ForceArg
             if constexpr (PER_ATOM_LJ) l_lj[n_here] = make2<T>(T(0), T(0));
         }
         __syncthreads();
+        if constexpr (PRUNE) {
+            // which atoms of this segment stay in the compacted tile, and under which number (ordered: the compacted tile keeps the
+            // cell-major order of the outer one)
+            const int NW = A.BI >> 6;
+            const float reach2 = (float)A.r_prune2 * 1.001f + 1e-12f;
+            auto stays = [&](int t) -> bool {
+                if constexpr (MINIMG) return true;          // small boxes: tile coordinates are not block-local, nothing to prune by
+                float p[3];
+                if (packed3) { p[0] = l_p3[t]; p[1] = l_p3[SOA_STRIDE + t]; p[2] = l_p3[2 * SOA_STRIDE + t]; }
+                else { const T4 q = l_pos[t]; p[0] = (float)q.x; p[1] = (float)q.y; p[2] = (float)q.z; }
+                float best = 3.0e38f;
+                for (int w = 0; w < NW; ++w) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) { float e = l_box[w * 6 + d] - p[d]; const float f = p[d] - l_box[w * 6 + 3 + d]; e = e > f ? e : f; e = e > 0.f ? e : 0.f; acc += e * e; }
+                    best = acc < best ? acc : best;
+                }
+                return best <= reach2;
+            };
+            const int per = (n_here + nthr - 1) / nthr, t0 = min(tid * per, n_here), t1 = min(t0 + per, n_here);
+            int cnt = 0;
+            for (int t = t0; t < t1; ++t) cnt += stays(t) ? 1 : 0;
+            l_scan[tid] = cnt;
+            __syncthreads();
+            if (tid < WAVE) {
+                int run = 0;
+                for (int base = 0; base < nthr; base += WAVE) {
+                    int v = (base + tid < nthr) ? l_scan[base + tid] : 0, x = v;
+#pragma unroll
+                    for (int o = 1; o < WAVE; o <<= 1) { int u = __shfl_up(x, o, WAVE); if (tid >= o) x += u; }
+                    if (base + tid < nthr) l_scan[base + tid] = run + x - v;
+                    run += __shfl(x, WAVE - 1, WAVE);
+                }
+                if (tid == 0) l_scan[nthr] = run;
+            }
+            __syncthreads();
+            {
+                int run = n_new + l_scan[tid];
+                for (int t = t0; t < t1; ++t) {
+                    if (stays(t)) { l_new[t] = (uint16_t)run; A.tile_idx_dst[(int64_t)b * A.T_cap + run] = tix[seg_lo + t]; ++run; }
+                    else l_new[t] = (uint16_t)0xffffu;
+                }
+            }
+            n_new += l_scan[nthr];
+            __syncthreads();
+        }
         // the row stream is software-pipelined: row r+1 is in flight while row r is evaluated
         auto walk_rows = [&](auto spec_tag) {
             constexpr bool SPEC = decltype(spec_tag)::value;
-            uint2 e_next = (0 < rows) ? my_rows[0] : make_uint2(0, 0);
-            // One-type fp32 LJ fluid without special pairs (the 1M-atom benchmark): the pair arithmetic written on float2 values —
-            // (x, y) of one partner as they come out of ds_read_b96, then the radial part of two partners side by side — so that it
-            // maps onto v_pk_{add,mul,fma}_f32 without the register shuffles of the auto-vectorised generic loop (forces_uniform.hip
-            // is compiled with the SLP vectoriser off).  Same operation order per pair as pair_eval.
+            // One-type fp32 LJ fluid without special pairs (the 1M-atom benchmark): the pair arithmetic on float2 values, two partners
+            // side by side, so that it maps onto v_pk_{add,mul,fma}_f32 without the register shuffles of the auto-vectorised generic
+            // loop (forces_uniform.hip is compiled with the SLP vectoriser off).
             if constexpr (FAST_CT && !SPEC) { if (packed3) {
-                // Two partners side by side in the halves of 64-bit registers, component by component: (xa, xb), (ya, yb), (za, zb) come
-                // straight out of three ds_read_b32 each, so the displacement, r², the LJ polynomial, the cutoff and the accumulation
-                // are ALL v_pk_*_f32 (two pairs per instruction).  The remaining scalar work per two partners: slot unpacking, one
-                // product, ONE v_rcp_f32 (quarter rate: it costs four plain instructions) shared through 1/ra² = rb²·(1/(ra²rb²)).
-                // The cutoff is a clamped v_pk_fma instead of v_cmp + v_cndmask per partner: clamp((rc²⁺ − r²)·2¹⁰⁰) is exactly 1 for
-                // r² <= rc² and exactly 0 above (rc²⁺ = the float after rc²), the test of the reference (r <= rc).
+                // Two partners in the halves of 64-bit registers, component by component: (xa, xb), (ya, yb), (za, zb) come straight out of
+                // three ds_read_b32 each, so the displacement, r², the LJ polynomial, the cutoff and the accumulation are ALL v_pk_*_f32
+                // (two pairs per instruction).  Per two partners besides those: two address instructions (the entries ARE byte offsets:
+                // v_and / v_lshrrev), two scalar products and ONE v_rcp_f32 (quarter rate) shared through 1/ra² = rb²·(1/(ra²rb²)).
+                // F/r = (48ϵσ¹²/r⁶ − 24ϵσ⁶)/r⁸ with the two constants formed on the host.  The cutoff is a clamped
+                // v_pk_fma instead of v_cmp + v_cndmask per partner: clamp((rc²⁺ − r²)·2¹⁰⁰) is exactly 1 for r² <= rc² and exactly 0
+                // above (rc²⁺ = the float after rc²), the test of the reference (r <= rc).  A row's two packed chains are written side
+                // by side so that each fills the other's wait states (a dependent read of a packed result costs one).
                 typedef float v2f __attribute__((ext_vector_type(2)));
                 const v2f pix = {(float)pi.x, (float)pi.x}, piy = {(float)pi.y, (float)pi.y}, piz = {(float)pi.z, (float)pi.z};   // (casts: the branch must also parse for T = double)
-                const float s2 = (float)A.I.lj_s2, c24 = (float)A.I.lj_24e, rc2 = (float)A.I.lj_rc2, rp2 = (float)A.r_prune2;
+                const float c6 = (float)A.I.lj_c6, c12 = (float)A.I.lj_c12, rc2 = (float)A.I.lj_rc2, rp2 = (float)A.r_prune2;
                 const float rc2n = __int_as_float(__float_as_int(rc2) + 1);
                 const v2f cut_a = {-0x1p100f, -0x1p100f}, cut_b = {rc2n * 0x1p100f, rc2n * 0x1p100f};
-                const v2f c48v = {c24 + c24, c24 + c24}, c24v = {c24, c24};
+                const v2f c48v = {c12, c12}, c24v = {c6, c6};
                 v2f fx2 = {(float)fx, 0.f}, fy2 = {(float)fy, 0.f}, fz2 = {(float)fz, 0.f};
-                for (int r = 0; r < rows; ++r) {
-                    const uint2 e4 = e_next;
-                    if (r + 1 < rows) e_next = my_rows[(int64_t)(r + 1) * A.BI];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const uint32_t w = h ? e4.y : e4.x;
-                        const uint32_t sa = w & 0x7fffu, sb = __builtin_amdgcn_ubfe(w, 16, 15);   // (v_bfe_u32, then one v_lshl_add_u32 each)
-                        const float *pa = l_p3 + sa, *pb = l_p3 + sb;
-                        const v2f dx = (v2f){pa[0], pb[0]} - pix, dy = (v2f){pa[SOA_STRIDE], pb[SOA_STRIDE]} - piy, dz = (v2f){pa[2 * SOA_STRIDE], pb[2 * SOA_STRIDE]} - piz;
-                        const v2f r2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-                        if constexpr (PRUNE) {   // (no slot test: the sentinel slot — padding, and everything a lane without an atom holds — lies 10⁴ nm away)
-                            if (r2.x <= rp2) { emit(w & 0xffffu); l_mark[sa] = 1; }
-                            if (r2.y <= rp2) { emit(w >> 16); l_mark[sb] = 1; }
-                        }
-                        const float t = __builtin_amdgcn_rcpf(r2.x * r2.y);
-                        const v2f inv = (v2f){r2.y, r2.x} * t;
-                        const v2f u = inv * s2, u3 = u * u * u;
-                        v2f f = __builtin_elementwise_fma(u3, c48v, -c24v) * u3 * inv;        // 24ϵ(2u⁶ − u³)/r², u = σ²/r²
-                        v2f in;
-                        asm("v_pk_fma_f32 %0, %1, %2, %3 clamp\n\ts_nop 0" : "=v"(in) : "v"(r2), "s"(cut_a), "v"(cut_b));   // (the nop: a dependent read of a packed result needs one wait state, and asm is invisible to the hazard recogniser)
-                        f *= in;
-                        fx2 -= dx * f; fy2 -= dy * f; fz2 -= dz * f;
+                // (the tile starts at LDS address 0 — these kernels have no static __shared__ — and saying so saves the base add per partner)
+                typedef __attribute__((address_space(3))) const char* lds_cptr;
+                const lds_cptr lbase = (lds_cptr)(uintptr_t)0;
+                auto lds3 = [&](uint32_t oa, uint32_t ob, v2f& dx, v2f& dy, v2f& dz) {
+                    if constexpr (EXPV == 1 || EXPV == 5) {   // timing experiment: no LDS gathers (coordinates made up from the entry bits)
+                        dx = (v2f){__uint_as_float(0x3f000000u | oa), __uint_as_float(0x3f000000u | ob)} - pix; dy = (v2f){__uint_as_float(0x3f100000u | oa), __uint_as_float(0x3f200000u | ob)} - piy; dz = (v2f){__uint_as_float(0x3f300000u | ob), __uint_as_float(0x3f400000u | oa)} - piz;
+                        return;
                     }
+                    typedef __attribute__((address_space(3))) const float* lds_fptr;
+                    const lds_fptr pa = (lds_fptr)(lbase + oa), pb = (lds_fptr)(lbase + ob);
+                    dx = (v2f){pa[0], pb[0]} - pix; dy = (v2f){pa[SOA_STRIDE], pb[SOA_STRIDE]} - piy; dz = (v2f){pa[2 * SOA_STRIDE], pb[2 * SOA_STRIDE]} - piz;
+                };
+                auto keep = [&](uint32_t off) { emit((uint32_t)l_new[off >> 2] << ESHIFT_SCALED); };
+                auto row = [&](const uint2 e4) {
+                    const uint32_t oa = e4.x & 0xffffu, ob = e4.x >> 16, oc = e4.y & 0xffffu, od = e4.y >> 16;
+                    v2f dx0, dy0, dz0, dx1, dy1, dz1;
+                    lds3(oa, ob, dx0, dy0, dz0); lds3(oc, od, dx1, dy1, dz1);
+                    const v2f r20 = __builtin_elementwise_fma(dz0, dz0, __builtin_elementwise_fma(dy0, dy0, dx0 * dx0));
+                    const v2f r21 = __builtin_elementwise_fma(dz1, dz1, __builtin_elementwise_fma(dy1, dy1, dx1 * dx1));
+                    if constexpr (PRUNE) {   // (no slot test: the sentinel slot — padding, and everything a lane without an atom holds — lies 10⁴ nm away)
+                        if (r20.x <= rp2) keep(oa);
+                        if (r20.y <= rp2) keep(ob);
+                        if (r21.x <= rp2) keep(oc);
+                        if (r21.y <= rp2) keep(od);
+                    }
+                    const float t0 = __builtin_amdgcn_rcpf(r20.x * r20.y), t1 = __builtin_amdgcn_rcpf(r21.x * r21.y);
+                    const v2f u0 = (v2f){r20.y, r20.x} * t0, u1 = (v2f){r21.y, r21.x} * t1;       // 1/r² of each partner
+                    v2f in0, in1;
+                    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp\n\ts_nop 0" : "=v"(in0) : "v"(r20), "s"(cut_a), "v"(cut_b));   // (the nop: a dependent read of a packed result needs one wait state, and asm is invisible to the hazard recogniser)
+                    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp\n\ts_nop 0" : "=v"(in1) : "v"(r21), "s"(cut_a), "v"(cut_b));
+                    const v2f q0 = u0 * u0, q1 = u1 * u1;
+                    const v2f w0 = u0 * in0, w1 = u1 * in1;
+                    const v2f c0 = q0 * u0, c1 = q1 * u1;                                        // 1/r⁶
+                    const v2f g0 = __builtin_elementwise_fma(c0, c48v, -c24v), g1 = __builtin_elementwise_fma(c1, c48v, -c24v);
+                    const v2f h0 = c0 * w0, h1 = c1 * w1;
+                    v2f f0 = g0 * h0, f1 = g1 * h1;                                              // (48ϵσ¹²/r⁶ − 24ϵσ⁶)/r⁸ inside the cutoff, else 0
+                    if constexpr (EXPV == 4) { f0 = in0; f1 = in1; }                             // timing experiment: no LJ arithmetic
+                    fx2 -= dx0 * f0; fy2 -= dy0 * f0; fz2 -= dz0 * f0;
+                    fx2 -= dx1 * f1; fy2 -= dy1 * f1; fz2 -= dz1 * f1;
+                };
+                // Four rows per trip, each fetched three rows ahead of its use (a wave spends ≈ 1.3 µs on a row, less than a loaded
+                // HBM round trip), loop control on the scalar unit.  The fetches are unconditional — the index is clamped to the last
+                // row, a few redundant loads per lane — so that the compiler can count them: behind a branch it waits for ALL
+                // outstanding loads, the one it has just issued included.
+                if (rows > 0) {
+                    const int last = rows - 1;
+                    constexpr int D = PRUNE ? 2 : MHIP_D;      // (the pruning variant carries its emission state: two rows in flight)
+                    uint2 e[4] = {pre0, pre1, pre2, pre3};
+                    if constexpr (!MHIP_HOIST) { e[0] = my_rows[0]; e[1] = my_rows[(int64_t)min(1, last) * A.BI]; if constexpr (D > 2) e[2] = my_rows[(int64_t)min(2, last) * A.BI]; if constexpr (D > 3) e[3] = my_rows[(int64_t)min(3, last) * A.BI]; }
+                    auto next = [&](int q) -> uint2 {
+                        if constexpr (EXPV == 2 || EXPV == 5) return make_uint2(((uint32_t)q * 0x00240014u + e[0].x) & 0x1ffc1ffcu, ((uint32_t)q * 0x00140024u + e[1].y) & 0x1ffc1ffcu);   // timing experiment: no row stream
+                        return my_rows[(int64_t)min(q, last) * A.BI];
+                    };
+                    int r = 0;
+                    for (; r + D <= rows; r += D) {
+#pragma unroll
+                        for (int k = 0; k < D; ++k) { row(e[k]); e[k] = next(r + D + k); }
+                    }
+#pragma unroll
+                    for (int k = 0; k < D - 1; ++k) if (r + k < rows) row(e[k]);
                 }
                 fx = (T)(fx2.x + fx2.y); fy = (T)(fy2.x + fy2.y); fz = (T)(fz2.x + fz2.y);
                 return;
             } }
+            uint2 e_next = (0 < rows) ? my_rows[0] : make_uint2(0, 0);
             // (the fp64 Ewald loop with the in-loop minimum image — 27-image search included — is not unrolled: four copies of it
             // exceed the 256 VGPRs of a 512-lane block and spill)
             constexpr int UNROLL = (sizeof(T) == 8 && COULM == MHIP_COUL_EWALD_DIRECT) ? (MINIMG ? 1 : (LJM == LJ_GENERIC && ENERGY ? 2 : 4)) : 4;
@@ -1092,10 +1259,10 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_forces(ForceArg
 #pragma unroll UNROLL
                 for (int k = 0; k < 4; ++k) {
                     uint32_t e = ((k < 2 ? e4.x : e4.y) >> (16 * (k & 1))) & 0xffffu;
-                    uint32_t slot = e & 0x7fffu;
+                    uint32_t slot = entry_slot(e, esh);
                     [[maybe_unused]] const bool real = SEG ? (slot - (uint32_t)seg_lo) < (uint32_t)n_here : slot < (uint32_t)tile_n;   // not a sentinel / other segment
                     if constexpr (SEG) { slot -= (uint32_t)seg_lo; slot = slot < (uint32_t)n_here ? slot : (uint32_t)n_here; }
-                    const bool special = SPEC ? (e >> 15) != 0 : false;
+                    const bool special = SPEC ? entry_special(e, esh) != 0 : false;
                     T4 pj = l_pos[slot];
                     T2 ljj = make2<T>(T(0), T(0));
                     if constexpr (PER_ATOM_LJ) ljj = l_lj[slot];
@@ -1106,7 +1273,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_forces(ForceArg
                     T r2 = dx * dx + dy * dy + dz * dz;
                     // the triclinic minimum image folds ANY separation back into the cell, the far-away sentinel atom included
                     if constexpr (MINIMG) { if (G.triclinic && !real) r2 = T(1.0e30); }
-                    if constexpr (PRUNE) { if (real && valid && r2 <= A.r_prune2) { emit(e); l_mark[e & 0x7fffu] = 1; } }   // benign race: same byte value
+                    if constexpr (PRUNE) { if (real && valid && r2 <= A.r_prune2) emit(make_entry((uint32_t)l_new[slot], entry_special(e, esh), esh)); }
                     T fr = pair_eval<T, LJM, COULM, ENERGY>(A.I, r2, pi.w, pj.w, lji.x, ljj.x, lji.y, ljj.y, special, pe);
                     fx -= fr * dx; fy -= fr * dy; fz -= fr * dz;   // force on i is −f (force.jl:873)
                     if constexpr (ENERGY) {
@@ -1123,68 +1290,21 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_forces(ForceArg
     }
     if constexpr (PRUNE) {
         // finish the inner list: pad to the wave's row count; record how far the block's atoms moved since the outer build
-        const uint32_t SENTP = (uint32_t)tile_n;
+        const uint32_t SENTP = make_entry((uint32_t)n_new, 0u, esh);
         int rows_mine = (kept + 3) >> 2;
         int rows_wave = wave_max(rows_mine);
         while (((kept + 3) >> 2) < rows_wave || (kept & 3)) emit(SENTP);
         if ((tid & 63) == 0) A.rows_dst[(b * A.JS + js) * (A.BI >> 6) + (li >> 6)] = rows_wave;
+        if (tid == 0) A.tile_cnt_dst[b] = n_new;
         float d2 = 0.f;
         if (valid && js == 0) {
-            T4 q = A.pos_snap[si], p0 = A.pos[si];
-            T ex = p0.x - q.x, ey = p0.y - q.y, ez = p0.z - q.z;
+            T4 q = A.pos_snap[si];
+            T ex = pi_raw.x - q.x, ey = pi_raw.y - q.y, ez = pi_raw.z - q.z;
             disp_image(ex, ey, ez, G);
             d2 = (float)(ex * ex + ey * ey + ez * ez);
         }
         d2 = wave_max(d2);
         if (js == 0 && (tid & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(A.blk_disp2 + b), __float_as_uint(d2));   // <= 4 waves per block
-        // compact the tile to the referenced atoms: ordered rank of every marked slot, new tile list, own rows renumbered
-        __syncthreads();
-        uint16_t* l_new = reinterpret_cast<uint16_t*>(smem);                       // the staged tile is dead now
-        int32_t* l_scan = reinterpret_cast<int32_t*>(l_mark + ((A.T_cap + 8) & ~7));
-        const uint32_t* uw = reinterpret_cast<const uint32_t*>(l_mark);
-        const int nuw = (tile_n + 3) >> 2;
-        int per = (nuw + nthr - 1) / nthr, w0 = min(tid * per, nuw), w1 = min(w0 + per, nuw);
-        int sum = 0;
-        for (int w = w0; w < w1; ++w) sum += __popc(uw[w] & 0x01010101u);
-        l_scan[tid] = sum;
-        __syncthreads();
-        if (tid < WAVE) {
-            int run = 0;
-            for (int base = 0; base < nthr; base += WAVE) {
-                int v = (base + tid < nthr) ? l_scan[base + tid] : 0, x = v;
-#pragma unroll
-                for (int o = 1; o < WAVE; o <<= 1) { int u = __shfl_up(x, o, WAVE); if (tid >= o) x += u; }
-                if (base + tid < nthr) l_scan[base + tid] = run + x - v;
-                run += __shfl(x, WAVE - 1, WAVE);
-            }
-            if (tid == 0) { A.tile_cnt_dst[b] = run; l_scan[nthr] = run; }
-        }
-        __syncthreads();
-        {
-            int run = l_scan[tid];
-            for (int w = w0; w < w1; ++w) {
-                uint32_t m = uw[w];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) if ((m >> (8 * q)) & 1u) { int t = (w << 2) + q; l_new[t] = (uint16_t)run; A.tile_idx_dst[(int64_t)b * A.T_cap + run] = tix[t]; ++run; }
-            }
-        }
-        __syncthreads();
-        const uint32_t n_in = (uint32_t)l_scan[nthr];
-        uint2 e_nx = rows_wave > 0 ? out_rows[0] : make_uint2(0, 0);   // (row r + 1 is in flight while row r is renumbered: the stores below alias the loads for the compiler)
-        for (int r = 0; r < rows_wave; ++r) {
-            const uint2 e4 = e_nx;
-            if (r + 1 < rows_wave) e_nx = out_rows[(int64_t)(r + 1) * A.BI];
-            uint32_t o2[2] = {0, 0};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                uint32_t e = ((k < 2 ? e4.x : e4.y) >> (16 * (k & 1))) & 0xffffu;
-                uint32_t slot = e & 0x7fffu;
-                uint32_t ns = slot >= SENTP ? n_in : (uint32_t)l_new[slot];
-                o2[k >> 1] |= (ns | (e & 0x8000u)) << (16 * (k & 1));
-            }
-            out_rows[(int64_t)r * A.BI] = make_uint2(o2[0], o2[1]);
-        }
-        __syncthreads();   // l_new overlays the region the j-split reduction is about to use
     }
     if (A.JS > 1) {   // deterministic reduction of the j-split partial sums through LDS
         __syncthreads();
@@ -1231,7 +1351,7 @@ template <class T>
 __global__ void k_export_nl(int n_blocks, int BI, int JS, int T_cap, int R_cap, int64_t n_owned, const int32_t* __restrict__ orig,
                             const int32_t* __restrict__ tile_idx, const int32_t* __restrict__ tile_cnt, const uint2* __restrict__ nbr,
                             const int32_t* __restrict__ wave_rows, int32_t* out_i, int32_t* out_j, uint8_t* out_sp,
-                            unsigned long long* counter, unsigned long long capacity) {
+                            unsigned long long* counter, unsigned long long capacity, int eshift) {
     int b = blockIdx.x, li = threadIdx.x;
     int64_t si = (int64_t)b * BI + li;
     if (si >= n_owned) return;
@@ -1243,12 +1363,12 @@ __global__ void k_export_nl(int n_blocks, int BI, int JS, int T_cap, int R_cap, 
             uint2 e4 = nbr[(((int64_t)b * JS + js) * R_cap + r) * BI + li];
             for (int k = 0; k < 4; ++k) {
                 uint32_t e = ((k < 2 ? e4.x : e4.y) >> (16 * (k & 1))) & 0xffffu;
-                int slot = e & 0x7fff;
+                int slot = (int)entry_slot(e, eshift);
                 if (slot >= tile_n) continue;
                 int oj = orig[tile_idx[(int64_t)b * T_cap + slot]];
                 if (oi < oj) {
                     unsigned long long at = atomicAdd(counter, 1ull);
-                    if (out_i && at < capacity) { out_i[at] = oi; out_j[at] = oj; out_sp[at] = (uint8_t)(e >> 15); }
+                    if (out_i && at < capacity) { out_i[at] = oi; out_j[at] = oj; out_sp[at] = (uint8_t)entry_special(e, eshift); }
                 }
             }
         }

@@ -1,6 +1,7 @@
 """Structural properties of the hot kernel that its speed depends on, checked on the compiler's output (no GPU needed: hipcc
-cross-compiles gfx950).  The packed one-type LJ loop runs four 512-lane blocks per CU only while it stays within 64 VGPRs and uses
-no scratch; DESIGN §4 records what a fifth of that occupancy costs (−12 %)."""
+cross-compiles gfx950).  The packed one-type LJ loop runs four 512-lane blocks per CU only while it stays within 64 VGPRs, and it must
+not touch scratch: a spill instruction moves 512 bytes per wave, and 36 bytes of scratch per lane measured +10 % on the 1M-atom
+force pass."""
 import os
 import re
 import shutil
@@ -12,28 +13,72 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "molly.jl_amd", "csrc")
 
 
-@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
-def test_uniform_lj_kernels_fit_64_vgprs_without_scratch(tmp_path):
+def _compile(tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     out = tmp_path / "forces_uniform.s"
     # the flags of csrc/Makefile for this translation unit
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fno-slp-vectorize", "--cuda-device-only", "-S",
                     os.path.join(CSRC, "forces_uniform.hip"), "-o", str(out)], check=True, capture_output=True, timeout=900)
-    kern, info = None, {}
-    for line in open(out):
+    return out
+
+
+def _kernels(asm):
+    """name -> (resource dict, body lines)"""
+    info, body, label = {}, {}, None
+    kern = None
+    for line in open(asm):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            label = m.group(1); body[label] = []
+            continue
         m = re.match(r"\s*\.amdhsa_kernel (\S+)", line)
         if m:
-            kern = m.group(1); info[kern] = {}
+            kern = m.group(1); info[kern] = {}; label = None
             continue
         m = re.match(r"\s*\.amdhsa_(next_free_vgpr|private_segment_fixed_size) (\d+)", line)
         if m and kern:
             info[kern][m.group(1)] = int(m.group(2))
+        if label:
+            body[label].append(line)
     names = subprocess.run(["c++filt"], input="\n".join(info), capture_output=True, text=True).stdout.split("\n")
-    plain = {n: info[k] for k, n in zip(info, names) if "k_forces<float, 3, 0, false, false, false, false" in n}   # not SEG, not PRUNE: the passes of every step
+    return {n: (info[k], body.get(k, [])) for k, n in zip(info, names)}
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+def test_uniform_lj_kernels_fit_64_vgprs_without_scratch(tmp_path):
+    ks = _kernels(_compile(tmp_path))
+    plain = {n: v for n, v in ks.items() if "k_forces<float, 3, 0, false, false, false, false" in n}   # not SEG, not PRUNE: the passes of every step
     assert len(plain) == 3                                            # the three tile strides
-    for n, r in plain.items():
+    for n, (r, body) in plain.items():
         assert r["next_free_vgpr"] <= 64, (n, r)
         assert r["private_segment_fixed_size"] == 0, (n, r)
-    for k, n in zip(info, names):
+        # the packed loop itself: two rows per trip = 68 packed instructions, loop control on the scalar unit (no exec-mask loop)
+        text = "".join(body)
+        assert "v_pk_fma_f32" in text and "clamp" in text
+    for n, (r, _) in ks.items():
         if "k_forces<" in n:
-            assert info[k]["private_segment_fixed_size"] == 0, (n, info[k])   # no variant of this file spills
+            assert r["private_segment_fixed_size"] == 0, (n, r)      # no variant of this file spills
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+def test_packed_loop_issue_count(tmp_path):
+    """The hot loop of the plain pass: at most 48 VALU instructions per row of four partners (round 2: 61, plus 15 s_nop), one
+    address instruction per partner, row count in a scalar register."""
+    ks = _kernels(_compile(tmp_path))
+    n, (r, body) = next((n, v) for n, v in ks.items() if "k_forces<float, 3, 0, false, false, false, false, 3073>" in n)
+    # the innermost loop that holds the clamped packed fma of the cutoff
+    blocks, cur = [], []
+    for line in body:
+        if re.match(r"^\.LBB\d+_\d+:", line):
+            blocks.append(cur); cur = []
+        cur.append(line)
+    blocks.append(cur)
+    loops = [b for b in blocks if any("clamp" in l for l in b) and any(re.search(r"s_cbranch_scc[01]", l) for l in b)]
+    assert loops, "packed loop with scalar loop control not found"
+    loop = max(loops, key=len)
+    valu = [l for l in loop if re.match(r"\s+v_", l)]
+    rows = sum(1 for l in loop if "clamp" in l) / 2.0               # two clamped fmas per row
+    assert rows >= 1
+    assert len(valu) / rows <= 48, (len(valu), rows)
+    assert not any("scratch_" in l for l in loop)
+    assert sum(1 for l in loop if "ds_read_b32" in l) == 12 * rows

@@ -1,0 +1,4 @@
+#!/bin/bash
+out=gpurun_out; mkdir -p $out; tag=${1:-abs}; shift
+timeout 1500 python tools/force_ab.py --static --steps 200 "$@" > $out/${tag}_static.txt 2>&1
+cat $out/${tag}_static.txt
