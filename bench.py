@@ -1,16 +1,17 @@
 #!/usr/bin/env python3
 """bench.py — ns/day (and Matom-steps/s) of the MI355X nonbonded engine on BASELINE.json's workloads.
 
-    python bench.py --gpus N --steps K --warmup W [--workload lj1m|lj256k|6mrr_pme|6mrr_rf64]
+    python bench.py --gpus N --steps K --warmup W [--workload lj1m|lj256k|6mrr_pme|6mrr_direct|6mrr_rf64]
 
-One "step" = one velocity-Verlet MD step (forces + integration + amortised neighbour rebuild) of the whole
+One "step" = one velocity-Verlet MD step (forces + integration + amortised neighbour-list upkeep) of the whole
 system, state resident in HBM.  N = 1: the whole box on one GPU.  N > 1 (launched by torch.distributed.run,
 one rank per GPU): the same box cut into spatial bricks with RCCL ghost-coordinate exchange — total work is
-fixed, so scaling is "strong".  Rank 0 prints ONE JSON line.
+fixed, so scaling is "strong".  Rank 0 prints ONE JSON line.  At N = 1 with the default workload (the 1M-atom LJ
+fluid) the line also carries, under "secondary", complete records of the metric's other configurations that fit
+one GPU: 6mrr with PME (BASELINE.json configs[2]) and the 256k-atom LJ fluid (configs[1]).
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time
@@ -23,8 +24,17 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
+WORKLOADS = {
+    "lj1m": "1M-atom LJ fluid (argon, rho=21.1/nm3), cubic PBC, DistanceCutoff 1.0 nm, r_list 1.2 nm, dt 2 fs, VelocityVerlet, remove_CM_motion=1",
+    "lj256k": "256k-atom LJ fluid, DistanceCutoff 1.0 nm, cell-list neighbours, Float32",
+    "6mrr_pme": "6mrr (15954 atoms) Amber99SB-ILDN/TIP3P, LJ + Ewald direct space + PME reciprocal space (order 5, mesh 46x46x51, every step) + bonded + EwaldExclusion, Float32, dt 0.5 fs",
+    "6mrr_direct": "6mrr (15954 atoms) Amber99SB-ILDN/TIP3P, LJ + Ewald direct space only (no reciprocal PME) + bonded + EwaldExclusion, Float32, dt 0.5 fs",
+    "6mrr_rf64": "6mrr reaction-field Coulomb + LJ + bonded, Float64, dt 0.5 fs",
+}
+
 
 def make_case(workload):
+    """The synthetic inputs of SURVEY §8(d): generators and the 6mrr parameter file live with the test fixtures (inputs only)."""
     from tests import systems as S
     if workload == "lj1m":
         return S.lj_fluid(100, seed=4, dtype=np.float32), np.float32, 0.002
@@ -48,6 +58,7 @@ def cpu_baseline(case, dtype, dt, budget_s=20.0):
     o.native = True
     specific = case.bonds is not None
     general = case.pme is not None
+    every = case.rebuild_every
     t0 = time.perf_counter()
     o.vv_run(1, dt, nthreads=nthreads, specific=specific, general=general)   # one step incl. the initial neighbour build + force pass
     t1 = time.perf_counter() - t0
@@ -57,31 +68,126 @@ def cpu_baseline(case, dtype, dt, budget_s=20.0):
     o.vv_run(n, dt, first_step=1, nthreads=nthreads, specific=specific, general=general)
     t = time.perf_counter() - t0
     steps_s = n / t
-    # the same algorithm on ONE core (the reference's 1-thread pair loop, src/force.jl:828-884): a couple of steps that avoid the
-    # rebuild cadence (the list of the run above is rebuilt at the first step of a run, so that cost is reported on its own)
-    n1 = int(max(1, min(4, (budget_s / 2.0) / max(t / n * nthreads * 0.6, 1e-3))))
+    # The same algorithm on ONE core (the reference's 1-thread pair loop, src/force.jl:828-884), steady state: two runs of 1 and 3 steps
+    # that start behind a rebuild step and contain none; every run begins with a neighbour search and a force pass (simulate! does),
+    # so the difference of the two is two plain steps.  Their share of the rebuild every `every` steps is added from the threaded run's
+    # cost model: the search is the serial part of both.
+    base = ((n + 1) // every + 1) * every + 1
     t0 = time.perf_counter()
-    o.vv_run(n1, dt, first_step=n + 1, nthreads=1, specific=specific, general=general)
-    t1c = time.perf_counter() - t0
-    steps_s1 = n1 / t1c
+    o.vv_run(1, dt, first_step=base, nthreads=1, specific=specific, general=general)
+    ta = time.perf_counter() - t0
+    nb = 3 if ta < budget_s else 2
+    t0 = time.perf_counter()
+    o.vv_run(nb, dt, first_step=base + 1, nthreads=1, specific=specific, general=general)
+    tb = time.perf_counter() - t0
+    per_step = max((tb - ta) / (nb - 1), 1e-9)
+    start_cost = max(ta - per_step, 0.0)                       # neighbour search + first force pass of a run
+    steps_s1 = 1.0 / (per_step + max(start_cost - per_step, 0.0) / every)   # + the search's share (a search every `every` steps)
     return {"value": steps_s * dt * 1e3 * 86400 * 1e-6, "unit": "ns/day", "cores": nthreads, "kind": "port",
             "matom_steps_per_s": steps_s * case.n / 1e6,
             "sample": f"{n} velocity-Verlet steps of the full {case.n}-atom system (threaded pair loop of src/force.jl:886-969 + "
-                      f"cell-list rebuild every {case.rebuild_every} steps" + (", PME reciprocal space on ONE thread (the restatement's mesh code is serial)" if general else "") + f"), {nthreads} threads, -O3 -march=native",
+                      f"cell-list rebuild every {every} steps" + (", PME reciprocal space on ONE thread (the restatement's mesh code is serial)" if general else "") + f"), {nthreads} threads, -O3 -march=native",
             "one_core": {"value": steps_s1 * dt * 1e3 * 86400 * 1e-6, "unit": "ns/day", "cores": 1, "matom_steps_per_s": steps_s1 * case.n / 1e6,
-                         "sample": f"{n1} step(s) incl. the neighbour search at the start of the run (1-thread pair loop of src/force.jl:828-884), same system"}}
+                         "sample": f"steady state: ({nb}-step run − 1-step run) / {nb - 1} = {per_step:.3f} s per plain step (1-thread pair loop of src/force.jl:828-884, same system), "
+                                   f"plus 1/{every} of the {max(start_cost - per_step, 0.0):.3f} s neighbour search"}}
 
 
 def load_traffic(workload):
     """HBM bytes per force-kernel launch from the rocprofv3 PMC passes committed under profiles/ (collected by
     profiles/collect.sh: separate FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE×2 gfx950 correction)."""
-    p = os.path.join(ROOT, "profiles", f"traffic_{workload}.json")
-    if os.path.exists(p):
-        try:
-            return json.load(open(p)).get("hbm_bytes_per_force_launch")
-        except Exception:
-            return None
-    return None
+    for tag in ("r03_", ""):
+        p = os.path.join(ROOT, "profiles", f"{tag}traffic_{workload}.json")
+        if os.path.exists(p):
+            try:
+                return json.load(open(p)).get("hbm_bytes_per_force_launch"), os.path.relpath(p, ROOT)
+            except Exception:
+                pass
+    return None, None
+
+
+def run_single(m, workload, args, steps, warmup, profile_steps):
+    """One workload on one GPU → (record, case, dtype, dt).  Timed region: exactly `steps` steps per window, inputs resident in HBM,
+    stream drained on both sides."""
+    L = m.lib()
+    case, dtype, dt = make_case(workload)
+    s = case.system(m, dtype)
+    s.push_state(velocities=True)
+    ctx = s.engine()
+    if args.integrator == "langevin":   # thermostatted at the LJ fluid's 85 K / the protein's 300 K, friction 1 / ps
+        kT = m.BOLTZMANN * (85.0 if workload.startswith("lj") else 300.0)
+        run = lambda first, n: s._check(L.mhip_langevin_run(ctx, first, n, dt, kT, 1.0, 1, 0x9E3779B97F4A7C15, first))
+    else:
+        run = lambda first, n: s._check(L.mhip_vv_run(ctx, first, n, dt, 1))
+    # untimed setup: the LJ fluids start from a jittered lattice and are equilibrated first (SURVEY §8(d) cfg 2 / 4: "equilibrate
+    # 2 000 steps before timing"), so that the timed steps see the list lifetimes of the liquid, not of a melting lattice
+    equil = args.equil if args.equil is not None else (2000 if workload.startswith("lj") else 0)
+    if equil:
+        run(0, equil)
+    run(equil, warmup)                                           # untimed warm-up: exactly --warmup steps
+    first = equil + warmup
+    # The K timed steps are taken AS SCHEDULED — wherever searches and prunes of the pair lists happen to fall.  A window shorter than
+    # the life of an outer pair list (≈ 100 steps at 1M atoms; a search costs ≈ 10 plain steps) measures 0.14 or 0.22 ms/step for the
+    # same code depending on whether a search falls into it, so short windows are repeated back to back until they cover at least
+    # 100 steps (one whole list cycle) and the headline is their mean; every window is K steps between two stream syncs.
+    n_win = 1 if steps >= 100 else -(-100 // steps)
+    win_ms = []
+    for _ in range(n_win):
+        s._check(L.mhip_synchronize(ctx))
+        t0 = time.perf_counter()
+        run(first, steps)                                        # timed: exactly K steps; returns after a stream sync
+        s._check(L.mhip_synchronize(ctx))
+        win_ms.append((time.perf_counter() - t0) * 1e3 / steps)
+        first += steps
+    ms_per_step = float(np.mean(win_ms))
+    # separate pass with hipEvent stage timers on the engine's stream (never mixed into the timed region)
+    st0 = s.stats()
+    s._check(L.mhip_set_profiling(ctx, 1))
+    run(first, profile_steps)
+    st = s.stats()
+    s._check(L.mhip_set_profiling(ctx, 0))
+    s._check(L.mhip_check_finite(ctx))
+    s.close()
+    extra = {"timed_window": "as scheduled" if n_win == 1 else f"as scheduled: mean of {n_win} consecutive windows of {steps} steps (one whole pair-list cycle)",
+             "window_ms_per_step": {"n": n_win, "mean": ms_per_step, "min": float(min(win_ms)), "max": float(max(win_ms))},
+             "list_upkeep_in_profile_pass": {"outer_searches": st["n_outer_builds"] - st0["n_outer_builds"], "prunes": st["n_filter_passes"] - st0["n_filter_passes"], "steps": profile_steps}}
+    return ms_per_step, st, extra, case, dtype, dt
+
+
+def make_record(workload, case, dtype, dt, ms_per_step, st, extra, world, args, steps, warmup, profile_steps):
+    steps_s = 1e3 / ms_per_step
+    ns_day = steps_s * (dt * 1e3) * 86400 * 1e-6        # dt [ps] → fs
+    n_atoms = case.n
+    force_ms = st["prof_ms"][0] / max(st["prof_calls"][0], 1)
+    fbytes = st["force_pass_bytes"]
+    achieved = fbytes / (force_ms * 1e-3) / 1e9 if force_ms > 0 else None
+    traffic, traffic_src = load_traffic(workload)
+    per_step = lambda k: st["prof_ms"][k] / max(profile_steps, 1)
+    roofline = {"bound": "hbm", "kernel": "k_forces", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                "traffic_source": (f"{traffic_src}: rocprofv3 PMC passes of an earlier run of this command (FETCH_SIZE x2 + WRITE_SIZE), not measured in this run" if traffic_src else None),
+                "algorithmic_bytes_per_launch": fbytes, "avg_launch_ms": force_ms,
+                "avg_launch_source": "hipEvents on the engine's stream around every plain force pass of a separate profiling pass in this run",
+                "step_bytes": st["algorithmic_bytes_step"],
+                "step_frac": st["algorithmic_bytes_step"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "stage_ms_per_step": {"forces": per_step(0), "build_kernel": per_step(1), "list_filter": per_step(4), "integrator": per_step(2),
+                                      "sort_permute": per_step(3), "bonded": per_step(5), "pme_reciprocal": per_step(6)},
+                "stage_ms_per_call": {"build_kernel": st["prof_ms"][1] / max(st["prof_calls"][1], 1), "list_filter": st["prof_ms"][4] / max(st["prof_calls"][4], 1)}}
+    line = {
+        "metric": "ns_per_day", "value": ns_day, "unit": "ns/day", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32" if dtype == np.float32 else "f64", "data": "synthetic",
+        "matom_steps_per_s": steps_s * n_atoms / 1e6,
+        "config": {"workload": WORKLOADS[workload],
+                   "name": workload, "integrator": args.integrator, "n_atoms": n_atoms, "dt_fs": dt * 1e3, "rebuild_every": case.rebuild_every,
+                   "parallelism": "single domain" if world == 1 else extra.get("parallelism"),
+                   "block_atoms": st["block_atoms"], "j_split": st["j_split"], "pairs_half_list": st["n_pairs_full"] // 2,
+                   "timed_window": extra.get("timed_window", "as scheduled")},
+        "roofline": roofline,
+        "engine": {k: st[k] for k in ("n_blocks", "block_atoms", "j_split", "max_tile_atoms", "tile_atoms_total", "lds_bytes",
+                                      "n_list_slots", "n_pairs_full", "minimg_mode", "n_rebuilds", "n_outer_builds", "n_filter_passes", "last_rebuild_ms")},
+    }
+    line.update({k: v for k, v in extra.items() if k not in ("parallelism", "timed_window")})
+    return line
 
 
 def main():
@@ -91,6 +197,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--workload", default=os.environ.get("MOLLYHIP_BENCH_WORKLOAD", "lj1m"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the 6mrr_pme and lj256k records that the default single-GPU run appends")
     ap.add_argument("--integrator", default="vv", choices=["vv", "langevin"], help="vv = the headline VelocityVerlet step; langevin = Langevin middle integrator (single GPU)")
     ap.add_argument("--profile-steps", type=int, default=200, help="steps of the separate hipEvent-timed pass")
     ap.add_argument("--equil", type=int, default=None, help="untimed equilibration steps before the warm-up (SURVEY §8(d): 2000 for the LJ fluids, which start from a jittered lattice; 0 for 6mrr, which starts from an equilibrated structure)")
@@ -115,101 +222,29 @@ def main():
     if m.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
 
-    case, dtype, dt = make_case(args.workload)
     if world > 1 or os.environ.get("MOLLYHIP_FORCE_DOMAIN"):   # the env hook drives the N = 1 box through the multi-GPU host loop (overhead checks)
+        case, dtype, dt = make_case(args.workload)
         from molly_jl_amd import domain   # spatial decomposition + RCCL halo exchange
         result = domain.bench_distributed(m, case, dtype, dt, args, rank, local_rank, world)
         if rank != 0:
             return
         ms_per_step, st, extra = result
+        line = make_record(args.workload, case, dtype, dt, ms_per_step, st, extra, world, args, args.steps, args.warmup, args.profile_steps)
     else:
-        import ctypes as C
-        L = m.lib()
-        s = case.system(m, dtype)
-        s.push_state(velocities=True)
-        ctx = s.engine()
-        if args.integrator == "langevin":   # thermostatted at the LJ fluid's 85 K / the protein's 300 K, friction 1 / ps
-            kT = m.BOLTZMANN * (85.0 if args.workload.startswith("lj") else 300.0)
-            run = lambda first, n: s._check(L.mhip_langevin_run(ctx, first, n, dt, kT, 1.0, 1, 0x9E3779B97F4A7C15, first))
-        else:
-            run = lambda first, n: s._check(L.mhip_vv_run(ctx, first, n, dt, 1))
-        # untimed setup: the LJ fluids start from a jittered lattice and are equilibrated first (SURVEY §8(d) cfg 2 / 4: "equilibrate
-        # 2 000 steps before timing"), so that the timed steps see the list lifetimes of the liquid, not of a melting lattice
-        equil = args.equil if args.equil is not None else (2000 if args.workload.startswith("lj") else 0)
-        if equil:
-            run(0, equil)
-        run(equil, args.warmup)                                      # untimed warm-up
-        first = equil + args.warmup
-        # A window shorter than the life of an outer pair list (≈ 100 steps at 1M atoms; its search costs 2.5 ms = 17 steps) would
-        # measure whether a search happens to fall into it — 0.15 or 0.30 ms/step for the same code.  Short windows are therefore
-        # placed at a defined point of the list cycle: mid-cycle, 16 steps after a prune of the inner list, so that they contain the
-        # next prune (every ≈ 25 steps: their fair share is 0.8) and no outer search (fair share 0.2 × 2.5 ms, in the record under
-        # roofline.stage_ms_per_call).  The record says so; the 2000-step default contains twenty whole cycles.
-        window = "as scheduled"
-        if args.steps < 100 and equil > 0:
-            def wait_for(key):
-                nonlocal first
-                n0 = s.stats()[key]
-                for _ in range(200):
-                    if s.stats()[key] != n0:
-                        return True
-                    run(first, 2); first += 2
-                return False
-            if wait_for("n_outer_builds") and wait_for("n_filter_passes"):
-                run(first, 16); first += 16
-                window = "mid-cycle: starts 16-18 steps after a prune of the inner pair list (contains the next prune, no outer search)"
-        s._check(L.mhip_synchronize(ctx))
-        t0 = time.perf_counter()
-        run(first, args.steps)                                       # timed: exactly K steps; returns after a stream sync
-        s._check(L.mhip_synchronize(ctx))
-        ms_per_step = (time.perf_counter() - t0) * 1e3 / args.steps
-        # separate pass with hipEvent stage timers on the engine's stream (never mixed into the timed region)
-        s._check(L.mhip_set_profiling(ctx, 1))
-        run(first + args.steps, args.profile_steps)
-        st = s.stats()
-        s._check(L.mhip_set_profiling(ctx, 0))
-        s._check(L.mhip_check_finite(ctx))
-        extra = {"timed_window": window}
-
-    steps_s = 1e3 / ms_per_step
-    ns_day = steps_s * (dt * 1e3) * 86400 * 1e-6        # dt [ps] → fs
-    n_atoms = case.n
-    force_ms = st["prof_ms"][0] / max(st["prof_calls"][0], 1)
-    fbytes = st["force_pass_bytes"]
-    achieved = fbytes / (force_ms * 1e-3) / 1e9 if force_ms > 0 else None
-    roofline = {"bound": "hbm", "kernel": "k_forces", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": load_traffic(args.workload),
-                "algorithmic_bytes_per_launch": fbytes, "avg_launch_ms": force_ms,
-                "step_bytes": st["algorithmic_bytes_step"],
-                "step_frac": st["algorithmic_bytes_step"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "stage_ms_per_step": {"forces": force_ms, "build_kernel": st["prof_ms"][1] / max(args.profile_steps, 1),
-                                      "list_filter": st["prof_ms"][4] / max(args.profile_steps, 1),
-                                      "integrator": st["prof_ms"][2] / max(args.profile_steps, 1),
-                                      "sort_permute": st["prof_ms"][3] / max(args.profile_steps, 1),
-                                      "bonded": st["prof_ms"][5] / max(args.profile_steps, 1),
-                                      "pme_reciprocal": st["prof_ms"][6] / max(args.profile_steps, 1)},
-                "stage_ms_per_call": {"build_kernel": st["prof_ms"][1] / max(st["prof_calls"][1], 1), "list_filter": st["prof_ms"][4] / max(st["prof_calls"][4], 1)}}
-    line = {
-        "metric": "ns_per_day", "value": ns_day, "unit": "ns/day", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32" if dtype == np.float32 else "f64", "data": "synthetic",
-        "matom_steps_per_s": steps_s * n_atoms / 1e6,
-        "config": {"workload": {"lj1m": "1M-atom LJ fluid (argon, rho=21.1/nm3), cubic PBC, DistanceCutoff 1.0 nm, r_list 1.2 nm, dt 2 fs, VelocityVerlet, remove_CM_motion=1",
-                                "lj256k": "256k-atom LJ fluid, DistanceCutoff 1.0 nm, cell-list neighbours, Float32",
-                                "6mrr_pme": "6mrr (15954 atoms) Amber99SB-ILDN/TIP3P, LJ + Ewald direct space + PME reciprocal space (order 5, mesh 46x46x51, every step) + bonded + EwaldExclusion, Float32, dt 0.5 fs",
-                                "6mrr_direct": "6mrr (15954 atoms) Amber99SB-ILDN/TIP3P, LJ + Ewald direct space only (no reciprocal PME) + bonded + EwaldExclusion, Float32, dt 0.5 fs",
-                                "6mrr_rf64": "6mrr reaction-field Coulomb + LJ + bonded, Float64, dt 0.5 fs"}[args.workload],
-                   "name": args.workload, "integrator": args.integrator, "n_atoms": n_atoms, "dt_fs": dt * 1e3, "rebuild_every": case.rebuild_every,
-                   "parallelism": "single domain" if world == 1 else extra.get("parallelism"),
-                   "block_atoms": st["block_atoms"], "j_split": st["j_split"], "pairs_half_list": st["n_pairs_full"] // 2,
-                   "timed_window": extra.get("timed_window", "as scheduled")},
-        "roofline": roofline,
-        "engine": {k: st[k] for k in ("n_blocks", "block_atoms", "j_split", "max_tile_atoms", "tile_atoms_total", "lds_bytes",
-                                      "n_list_slots", "n_pairs_full", "minimg_mode", "n_rebuilds", "n_outer_builds", "n_filter_passes", "last_rebuild_ms")},
-    }
-    line.update({k: v for k, v in extra.items() if k not in ("parallelism", "timed_window")})
-    if world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(case, dtype, dt)
+        ms_per_step, st, extra, case, dtype, dt = run_single(m, args.workload, args, args.steps, args.warmup, args.profile_steps)
+        line = make_record(args.workload, case, dtype, dt, ms_per_step, st, extra, world, args, args.steps, args.warmup, args.profile_steps)
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(case, dtype, dt)
+        if args.workload == "lj1m" and not args.no_secondary and args.integrator == "vv":
+            # the metric's other single-GPU configurations (BASELINE.json: "6mrr PME fp32 and 1M-atom LJ"; configs[1] = 256k LJ): same
+            # protocol, their own step counts (both run in seconds), complete records
+            line["secondary"] = []
+            for wl, k_steps, k_warm in (("6mrr_pme", 2000, 300), ("lj256k", 2000, 300)):
+                ms2, st2, ex2, case2, dtype2, dt2 = run_single(m, wl, args, k_steps, k_warm, 400)
+                rec = make_record(wl, case2, dtype2, dt2, ms2, st2, ex2, 1, args, k_steps, k_warm, 400)
+                if not args.no_cpu_baseline:
+                    rec["cpu_baseline"] = cpu_baseline(case2, dtype2, dt2, budget_s=8.0)
+                line["secondary"].append(rec)
     os.write(json_fd, (json.dumps(line) + "\n").encode())
 
 

@@ -163,6 +163,7 @@ template <class T> class Engine final : public EngineBase {
     bool inner_valid = false, prune_disp_exceeded = false;
     DBuf<int32_t> blk_ghost, blk_ghost_in; bool ghost_flags_ok = false, ghost_flags_in_ok = false, interior_done = false;
     int64_t last_prune_step = 0;
+    int64_t pass_step = 0;       // the MD step whose coordinates the pair pass being launched sees (recorded as the step of a prune)
     DBuf<T4> pos_snap_in;        // coordinates at the last prune (validity of the inner list: 2·displacement <= skin)
     double skin = 0; bool strict_cadence = false; int64_t n_disp_checks = 0;
     // The inner list of the dual scheme only has to hold every pair inside the CUTOFFS (mhip_export_neighbors filters the outer list to
@@ -254,7 +255,7 @@ template <class T> class Engine final : public EngineBase {
         pos_snap_in.release();
         wave_rows_in.release(); nbr_in.release(); pos_snap.release(); blk_disp2.release(); tile_idx_in.release(); tile_cnt_in.release(); rows_x.release(); nbr_x.release(); tile_idx_x.release(); tile_cnt_x.release(); blk_ghost.release(); blk_ghost_in.release();
         xl_start.release(); xl_list.release(); tile_idx.release(); tile_cnt.release(); wave_rows.release(); nbr.release(); blk_center.release();
-        flags.release(); red_part.release(); red_out.release(); cm_step.release(); vcm.release(); stage_a.release(); stage_b.release(); stage_i.release(); bonded.release(); pme.release(); frc_scratch.release(); nl_counter.release();
+        flags.release(); red_part.release(); red_out.release(); cm_step.release(); vcm.release(); stage_a.release(); stage_b.release(); stage_i.release(); bonded.release(); pme.release(); frc_scratch.release(); nl_counter.release(); state_changed.release();
         prof.release();
         for (int k = 0; k < 2; ++k) { if (side[k]) { (void)hipStreamSynchronize(side[k]); (void)hipStreamDestroy(side[k]); } if (ev_side[k]) (void)hipEventDestroy(ev_side[k]); frc_side[k].release(); }
         if (ev_pos) (void)hipEventDestroy(ev_pos);
@@ -453,7 +454,10 @@ template <class T> class Engine final : public EngineBase {
         catch (const ApiError& e) {
             if (e.code != MHIP_ERR_CAPACITY || !dual) throw;
             // dense small systems (a 64-atom block of water with a 1.4 nm shell is half of 6mrr): halve the outer margin before giving up on it
-            if (outer_margin > 0.06) ++margin_halvings; else if (!margin_zero && n_ghost == 0) margin_zero = true; else dual_disabled = true;
+            // (a sub-domain of a multi-GPU run never shrinks its margin on its own: the ranks decide prunes and re-plans from the same
+            // numbers, mhip_plan_decide — without the dual list mhip_plan_state_dev reports +inf and every rank re-plans at every rebuild step)
+            if (n_ghost > 0 || ghost_margin > 0 || host_prune) dual_disabled = true;
+            else if (outer_margin > 0.06) ++margin_halvings; else if (!margin_zero) margin_zero = true; else dual_disabled = true;
             if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] dual list %s (capacity): %s\n", dual_disabled ? "off" : (margin_zero ? "without outer margin" : "margin halved"), e.msg.c_str());
             setup_grid(); choose_blocking(); stale = true;
             rebuild(step_n);
@@ -653,7 +657,7 @@ template <class T> class Engine final : public EngineBase {
     // s + 1 (with that step of headroom in the outer-list test).  (Taking the maxima inside k_forces instead cost its packed loop
     // 14 % through a different register assignment, with the same instructions: measured, dropped.)
     DBuf<float> trk_part, trk_out; float* h_trk = nullptr; hipEvent_t ev_trk = nullptr;
-    bool trk_issued = false; int64_t trk_step = -1, trk_prune_step = -1, trk_outer_step = -1; double trk_prev_vmax = 0;
+    bool trk_issued = false; int64_t trk_step = -1, trk_prune_id = -1, trk_outer_id = -1; double trk_prev_vmax = 0;   // (ids: the running counts of prunes / outer searches)
     const bool async_checks = env_int("MOLLYHIP_ASYNC_CHECKS", 1) != 0;
     bool in_vv_fused = false;
     bool async_ok() const { return async_checks && in_vv_fused && dual && n_ghost == 0 && !host_prune && !strict_cadence && inner_valid && !stale; }
@@ -664,7 +668,7 @@ template <class T> class Engine final : public EngineBase {
         const double d = std::sqrt((double)h_trk[0]), d_outer = std::sqrt((double)h_trk[1]);
         prev_vmax = trk_prev_vmax; last_vmax = std::sqrt((double)h_trk[2]);   // (the speed of the check before, as it was when this one was issued: a run cut into chunks decides alike)
         ++n_disp_checks;
-        if (!dual || stale || !inner_valid || n_ghost > 0 || last_prune_step != trk_prune_step || last_outer_step != trk_outer_step) return;   // the lists it measured have been replaced meanwhile
+        if (!dual || stale || !inner_valid || n_ghost > 0 || n_filters != trk_prune_id || n_outer != trk_outer_id) return;   // the lists it measured have been replaced meanwhile
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         const int64_t so_far = trk_step - last_prune_step;
         const double ahead = drift_ahead(d, so_far, every);
@@ -760,17 +764,19 @@ template <class T> class Engine final : public EngineBase {
     // searches afresh there; a fresh search changes results only where list MEMBERSHIP matters (an interaction without a cutoff
     // inside r_list).  Lists that carry a skin are kept if the displacement checks say they still cover every cutoff sphere: a run
     // continued in chunks then walks the same lists in the same order as the uncut run and reproduces it bit for bit.
+    bool vel_check_due = false;   // velocities were replaced since the last validity check of the lists
     void start_lists(int64_t first_step) {
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         lists_after_set_state();
-        if (stale || !(dual || lazy_single) || !keep_lists_on_set_state) { rebuild(first_step); return; }
-        if (check_due(first_step, every) && first_step != last_build_step) refresh(first_step);
+        if (stale || !(dual || lazy_single) || !keep_lists_on_set_state) { vel_check_due = false; rebuild(first_step); return; }
+        if ((check_due(first_step, every) && first_step != last_build_step) || vel_check_due) { vel_check_due = false; refresh(first_step); }
     }
 
     void ensure_built(int64_t step_n) {
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         resolve_track(step_n);
         lists_after_set_state();
+        vel_check_due = false;   // (driven from outside there is no time step: the displacement checks of set_state are all there is)
         if (stale) rebuild(step_n);
         else if (check_due(step_n, every) && step_n != last_build_step) refresh(step_n);
     }
@@ -831,7 +837,7 @@ template <class T> class Engine final : public EngineBase {
             // the snapshot the next displacement checks compare with: the owned atoms' by the kernel itself, ghosts by a copy
             A.snap_dst = pos_snap_in.p;
             if (n_ghost > 0) MHIP_HIP(hipMemcpyAsync(pos_snap_in.p + n_owned, pos[cur].p + n_owned, (size_t)n_ghost * sizeof(T4), hipMemcpyDeviceToDevice, stream));
-            last_prune_step = last_build_step;
+            last_prune_step = pass_step;
             tile_idx_in.reserve((size_t)n_blocks * T_cap); tile_cnt_in.reserve(n_blocks);
             A.tile_idx_dst = tile_idx_in.p; A.tile_cnt_dst = tile_cnt_in.p;
             A.mark_off = (int)((lds_force + 15) & ~(size_t)15);
@@ -875,7 +881,7 @@ template <class T> class Engine final : public EngineBase {
     void prune_with_filter() {
         pos_snap_in.reserve(cap);
         MHIP_HIP(hipMemcpyAsync(pos_snap_in.p, pos[cur].p, (size_t)n_tot * sizeof(T4), hipMemcpyDeviceToDevice, stream));
-        last_prune_step = last_build_step;
+        last_prune_step = pass_step;
         launch_filter(true);
         if (n_ghost > 0)   // the blocks record the displacement of the owned atoms; the ghosts' comes on top
             hipLaunchKernelGGL(k_max_disp<T>, dim3(std::min(cdiv(n_ghost, 256), 1024)), dim3(256), 0, stream, n_ghost, (const T4*)pos[cur].p + n_owned, (const T4*)pos_snap.p + n_owned,
@@ -914,6 +920,7 @@ template <class T> class Engine final : public EngineBase {
     // reciprocal part — independent, latency-bound chains of small kernels — run next to it on the side streams into
     // frc_side[]; the consumer (second kick, or fold_side_forces) adds them
     void step_forces(int64_t step_n) {
+        pass_step = step_n;
         const bool side_b = overlap && bonded.any(), side_p = overlap && pme.on();
         if (side_p && n_ghost > 0) throw ApiError{MHIP_ERR_UNSUPPORTED, "PME runs on a single domain (SURVEY §8(e): 6mrr-size systems are replicas only)"};
         if (side_b || side_p) MHIP_HIP(hipEventRecord(ev_pos, stream));
@@ -1071,11 +1078,16 @@ template <class T> class Engine final : public EngineBase {
     }
     void set_ewald_exclusions(int64_t n, const int32_t* i, const int32_t* j) override { bonded.set_ewx(cap, n, i, j); }
 
+    // set_state raises these words on the device when a coordinate / a velocity really differs from what the engine held
+    DBuf<int32_t> state_changed; bool state_pending = false;
     void set_state(const void* xyz, const void* v, int mem_kind) override {
         flush_cm();
         const T* dx = to_device(xyz, 3 * (size_t)n_tot, mem_kind, stage_a);
         const T* dv = to_device(v, 3 * (size_t)n_owned, mem_kind, stage_b);
-        hipLaunchKernelGGL(k_scatter_state<T>, dim3(cdiv(n_tot, 256)), dim3(256), 0, stream, n_tot, n_owned, (const int32_t*)inv.p, dx, dv, pos[cur].p, vel[cur].p, G);
+        state_changed.reserve(2);
+        if (!state_pending) MHIP_HIP(hipMemsetAsync(state_changed.p, 0, 2 * sizeof(int32_t), stream));
+        state_pending = true;
+        hipLaunchKernelGGL(k_scatter_state<T>, dim3(cdiv(n_tot, 256)), dim3(256), 0, stream, n_tot, n_owned, (const int32_t*)inv.p, dx, dv, pos[cur].p, vel[cur].p, G, state_changed.p);
         MHIP_HIP(hipGetLastError());
         if (mem_kind == MHIP_MEM_HOST) MHIP_HIP(hipStreamSynchronize(stream));
         if (xyz) {
@@ -1090,9 +1102,26 @@ template <class T> class Engine final : public EngineBase {
 
     // after set_state handed over moved coordinates: keep the lists if nobody outran their margins, else prune / search again
     void lists_after_set_state() {
+        bool vel_new = false;
+        if (state_pending) {   // what did set_state really change?  (a state handed back as it was — a run continued in chunks — changes nothing)
+            state_pending = false;
+            int32_t h[2] = {1, 1};
+            MHIP_HIP(hipMemcpyAsync(h, state_changed.p, sizeof(h), hipMemcpyDeviceToHost, stream));
+            MHIP_HIP(hipStreamSynchronize(stream));
+            if (!h[0]) coords_moved = false;
+            vel_new = h[1] != 0;
+            if (h[0] || h[1]) trk_issued = false;      // a measurement in flight describes the state that was replaced
+        }
+        if (vel_new && !stale && (dual || lazy_single) && !coords_moved) {
+            // New velocities on old coordinates (re-thermalisation, a temperature ramp, a replica-exchange swap): the inner skin was
+            // sized for the speeds of the run before.  Look at the new ones now — the drift bound of the checks — instead of at the
+            // next cadence step.
+            vel_check_due = true;
+        }
         if (!coords_moved) return;
         coords_moved = false;
         if (stale) return;
+        vel_check_due = vel_check_due || vel_new;
         if (dual) {
             const double d_outer = std::sqrt((double)max_disp2_since(pos_snap));
             if (!(2.0 * d_outer <= prune_margin() * 0.98)) { stale = true; return; }
@@ -1125,6 +1154,7 @@ template <class T> class Engine final : public EngineBase {
     void forces(int64_t step_n, int accumulate, void* f_xyz, int mem_kind) override {
         cur_dt = 0;   // driven from outside: no time step to bound the drift with
         ensure_built(step_n);
+        pass_step = step_n;
         launch_pair_kernel(false);
         frc_valid = false;   // frc holds the pairwise part only
         if (prune_disp_exceeded) { after_forces(step_n); launch_pair_kernel(false); }
@@ -1595,7 +1625,7 @@ template <class T> class Engine final : public EngineBase {
                 hipLaunchKernelGGL(k_track_reduce, dim3(1), dim3(256), 0, stream, nb, (const float*)trk_part.p, trk_out.p);
                 MHIP_HIP(hipMemcpyAsync(h_trk, trk_out.p, 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
                 MHIP_HIP(hipEventRecord(ev_trk, stream));
-                trk_issued = true; trk_step = step + 1; trk_prev_vmax = last_vmax; trk_prune_step = last_prune_step; trk_outer_step = last_outer_step;
+                trk_issued = true; trk_step = step + 1; trk_prev_vmax = last_vmax; trk_prune_id = n_filters; trk_outer_id = n_outer;
             }
             pend_a = pend_b = nullptr;
             cm_pending = 0; cm_ext = nullptr;

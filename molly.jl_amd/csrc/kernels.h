@@ -130,18 +130,32 @@ template <class T> __device__ inline void disp_image(T& ex, T& ey, T& ez, const 
 
 // ---------------------------------------------------------------------------------------------------
 // set_state / set_atoms: caller order → current sorted slots
+// changed[0] / changed[1] (nullable) are raised when some coordinate / velocity differs from the one the engine holds: a state that
+// is handed back unchanged (a run continued in chunks through get_state / set_state) then leaves lists and checks alone
 template <class T>
 __global__ void k_scatter_state(int64_t n_tot, int64_t n_owned, const int32_t* __restrict__ inv, const T* __restrict__ xyz,
-                                const T* __restrict__ vxyz, typename Vec<T>::T4* pos, typename Vec<T>::T4* vel, GridP<T> G) {
+                                const T* __restrict__ vxyz, typename Vec<T>::T4* pos, typename Vec<T>::T4* vel, GridP<T> G, int32_t* changed) {
     int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (o >= n_tot) return;
-    int s = inv[o];
-    if (xyz) {
-        T c[3] = {xyz[3 * o], xyz[3 * o + 1], xyz[3 * o + 2]};
-        wrap_point(c[0], c[1], c[2], G);   // wrap_coords, simulators.jl:561
-        pos[s].x = c[0]; pos[s].y = c[1]; pos[s].z = c[2];
+    bool dx = false, dv = false;
+    if (o < n_tot) {
+        int s = inv[o];
+        if (xyz) {
+            T c[3] = {xyz[3 * o], xyz[3 * o + 1], xyz[3 * o + 2]};
+            wrap_point(c[0], c[1], c[2], G);   // wrap_coords, simulators.jl:561
+            const auto p = pos[s];
+            dx = !(p.x == c[0] && p.y == c[1] && p.z == c[2]);
+            pos[s].x = c[0]; pos[s].y = c[1]; pos[s].z = c[2];
+        }
+        if (vxyz && o < n_owned) {
+            const auto v = vel[s];
+            dv = !(v.x == vxyz[3 * o] && v.y == vxyz[3 * o + 1] && v.z == vxyz[3 * o + 2]);
+            vel[s].x = vxyz[3 * o]; vel[s].y = vxyz[3 * o + 1]; vel[s].z = vxyz[3 * o + 2];
+        }
     }
-    if (vxyz && o < n_owned) { vel[s].x = vxyz[3 * o]; vel[s].y = vxyz[3 * o + 1]; vel[s].z = vxyz[3 * o + 2]; }
+    if (changed) {
+        if (__any(dx) && (threadIdx.x & 63) == 0) atomicOr(&changed[0], 1);
+        if (__any(dv) && (threadIdx.x & 63) == 0) atomicOr(&changed[1], 1);
+    }
 }
 
 template <class T>

@@ -1,6 +1,7 @@
 """CPU stand-in for molly_jl_amd.domain.HipDomainEngine, backed by the oracle — TEST INFRASTRUCTURE ONLY.  It lets the
 world_size > 1 host logic (ownership, ghost plan, all_to_all exchange, migration) run under gloo without a GPU."""
 import math
+import os
 
 import numpy as np
 import torch
@@ -13,6 +14,9 @@ class OracleDomainEngine:
         self.inter, self.r_list, self.dtype = inter_dict, r_list, dtype
         self.ghost_margin, self.n_prunes = ghost_margin, 0
         self.skin, self.every, self.prune_step = skin, every, 0     # what plan_decide schedules with (the HIP engine: its inner skin)
+        # MOLLYHIP_TEST_EXTRA_CHECK=k: a cadence decision that keeps the lists asks for one more look k steps later, as the HIP engine
+        # does when the inner list is good for k < rebuild_every steps only (mhip_plan_decide's check_in); every decision is logged
+        self.extra_check = int(os.environ.get("MOLLYHIP_TEST_EXTRA_CHECK", "0")); self.decide_steps = []
         self.box = np.array([b if p else math.inf for b, p in zip(box, periodic)])   # open axes: no minimum image
         self.periodic = periodic
 
@@ -144,9 +148,10 @@ class OracleDomainEngine:
 
     def plan_decide(self, step, red):
         d2_plan, d2_prune = red[0], red[1]
+        self.decide_steps.append(int(step))
         k = max(1, (step - self.prune_step) // self.every)
         if not (math.isinf(d2_prune) or 2.0 * math.sqrt(d2_prune) * (k + 1) / k > 0.98 * self.skin):
-            return 0, 0
+            return 0, (self.extra_check if step % self.every == 0 else 0)
         if 2.0 * math.sqrt(d2_plan) > 0.95 * self.ghost_margin:
             return 2, 0
         self.request_prune(); self.prune_step = step

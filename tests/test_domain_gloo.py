@@ -37,7 +37,8 @@ def _worker(rank, world, port, n_side, n_steps, out_dir, gm=0.0, skin=0.2, msg_d
     xs, vs = run.gather_global(case.n)
     if rank == 0:
         np.savez(os.path.join(out_dir, "result.npz"), x=xs, v=vs, ghosts=run.n_ghost, migrated=run.stats["migrated"], grid=np.array(grid),
-                 plans=run.stats["plans"], checks=run.stats["plan_checks"], prunes=run.stats["prunes"], fused=int(run.fused))
+                 plans=run.stats["plans"], checks=run.stats["plan_checks"], prunes=run.stats["prunes"], fused=int(run.fused),
+                 decide_steps=np.array(eng.decide_steps, dtype=np.int64))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -123,6 +124,25 @@ def test_stepwise_host_loop_matches_single_domain_oracle(tmp_path, monkeypatch):
     d -= np.round(d / case.box) * case.box
     assert np.abs(d).max() < 1e-9 and np.abs(res["v"] - o.vel).max() < 1e-8
     assert int(res["fused"]) == 0 and int(res["prunes"]) >= 1
+
+
+@pytest.mark.parametrize("fused", [0, 1])
+def test_extra_checks_between_cadence_steps_are_honoured(fused, tmp_path, monkeypatch):
+    """mhip_plan_decide may keep the lists but vouch for them for k < rebuild_every steps only (check_in = k): the host loop then has to
+    come back k steps later — the fused loop AND the two-call loop that grids with more than two bricks per axis use (round 2: the latter
+    only looked at the cadence steps and would have walked an inner list past the horizon it was validated for)."""
+    monkeypatch.setenv("MOLLYHIP_HALO_FUSED", str(fused)); monkeypatch.setenv("MOLLYHIP_HOST_PRUNE", "0"); monkeypatch.setenv("MOLLYHIP_TEST_EXTRA_CHECK", "3")
+    world, n_side, n_steps = 2, 10, 17
+    mp.spawn(_worker, args=(world, _free_port(), n_side, n_steps, str(tmp_path), 0.3, 0.2), nprocs=world, join=True)
+    res = np.load(os.path.join(tmp_path, "result.npz"))
+    assert int(res["fused"]) == fused
+    assert list(res["decide_steps"]) == [5, 8, 10, 13, 15]           # cadence 5, and three steps after each decision that asked for it
+    case = S.lj_fluid(n_side, dtype=np.float64, rebuild_every=5)
+    o = case.oracle(np.float64)
+    o.vv_run(n_steps, 0.002, remove_cm_every=1)
+    d = res["x"] - o.coords
+    d -= np.round(d / case.box) * case.box
+    assert np.abs(d).max() < 1e-9
 
 
 @pytest.mark.parametrize("gm,skin,expect", [(0.3, 0.2, "one plan"), (0.3, 0.012, "prunes"), (0.012, 0.012, "replans")])

@@ -40,7 +40,22 @@ def test_bench_single_gpu_record():
     d = _record([sys.executable, "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--workload", "lj256k", "--equil", "300", "--no-cpu-baseline"])
     _check_contract(d, 1, 20, 5)
     assert d["config"]["parallelism"] == "single domain"
-    assert d["config"]["timed_window"].startswith("mid-cycle")        # a 20-step window is placed in the list cycle
+    assert d["config"]["timed_window"].startswith("as scheduled: mean of 5 consecutive windows of 20 steps")   # never placed
+    w = d["window_ms_per_step"]
+    assert w["n"] == 5 and w["min"] <= d["ms_per_step"] <= w["max"] and abs(w["mean"] - d["ms_per_step"]) < 1e-12
+    assert "secondary" not in d                                        # only the default workload appends the other configurations
+
+
+def test_bench_default_workload_carries_the_other_configurations():
+    """`python bench.py --gpus 1` as the driver runs it (shortened: no equilibration, no CPU legs): the 1M-atom record plus complete
+    records of 6mrr with PME and of the 256k-atom fluid under `secondary`."""
+    d = _record([sys.executable, "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--equil", "100", "--no-cpu-baseline", "--profile-steps", "50"])
+    _check_contract(d, 1, 20, 5)
+    assert d["config"]["name"] == "lj1m" and [r["config"]["name"] for r in d["secondary"]] == ["6mrr_pme", "lj256k"]
+    for r in d["secondary"]:
+        assert r["metric"] == "ns_per_day" and r["value"] > 0 and r["roofline"]["achieved"] > 0 and r["roofline"]["step_frac"] > 0
+        assert r["n_gpus"] == 1 and r["dtype"] == "f32" and r["config"]["timed_window"] == "as scheduled"
+    assert d["secondary"][0]["roofline"]["stage_ms_per_step"]["pme_reciprocal"] > 0
 
 
 def test_bench_two_ranks_record():

@@ -162,3 +162,33 @@ def test_full_size_1m_lj_against_oracle(pkg):
     o32 = case.oracle(np.float32)
     assert st["n_pairs_full"] == 2 * len(o32.neighbors("cell", nthreads=16)[0])
     assert st["minimg_mode"] == 0 and st["block_atoms"] * st["j_split"] <= 1024
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_new_velocities_on_old_coordinates_are_looked_at_before_the_lists_are_trusted(pkg, dtype):
+    """A velocity-only change between two runs (re-thermalisation, a temperature ramp, a replica-exchange swap): the inner pair list was
+    pruned with a skin sized for the speeds of the run before.  The continuation must check the new speeds at its first step — not at
+    the next cadence step — and still follow the reference, which searches afresh at the start of every simulate! (simulators.jl:564).
+    Handing the SAME state back, on the other hand, changes nothing: the chunked run stays bit-identical to the uncut one."""
+    case = S.lj_fluid(14, dtype=dtype)
+    dt = 0.002
+    s = case.system(pkg, dtype)
+    pkg.simulate(s, pkg.VelocityVerlet(dt=dt, remove_CM_motion=0), 13)             # ends off the cadence (13 % 10 != 0), lists alive
+    n_outer = s.stats()["n_outer_builds"]
+    o = case.oracle(np.float64, coords=s.coords.astype(np.float64), velocities=s.velocities.astype(np.float64) * 6.0)
+    s.velocities[:] = (s.velocities.astype(np.float64) * 6.0).astype(dtype)      # 36x the temperature: 0.1 nm of inner skin goes in a few steps
+    pkg.simulate(s, pkg.VelocityVerlet(dt=dt, remove_CM_motion=0), 12, init_step=13)
+    o.vv_run(12, dt, first_step=13, remove_cm_every=0)
+    d = s.coords.astype(np.float64) - o.coords
+    d -= np.round(d / case.box) * case.box
+    assert np.abs(d).max() < (2e-4 if dtype == np.float32 else 1e-8), np.abs(d).max()    # a pair lost from the list shows as 1e-2 nm here
+    assert s.stats()["n_outer_builds"] + s.stats()["n_filter_passes"] > n_outer + 1          # the hot atoms forced list work
+    # unchanged state handed back: no search, no prune, same bits
+    a = case.system(pkg, dtype); b = case.system(pkg, dtype)
+    pkg.simulate(a, pkg.VelocityVerlet(dt=dt, remove_CM_motion=0), 16)
+    pkg.simulate(b, pkg.VelocityVerlet(dt=dt, remove_CM_motion=0), 7)
+    before = b.stats()
+    pkg.simulate(b, pkg.VelocityVerlet(dt=dt, remove_CM_motion=0), 9, init_step=7)
+    after = b.stats()
+    assert np.array_equal(a.coords, b.coords) and np.array_equal(a.velocities, b.velocities)
+    assert after["n_outer_builds"] == before["n_outer_builds"]
