@@ -353,6 +353,44 @@ int32_t mhip_vv_halo_mid(mhip_ctx* ctx, int64_t step_n, double dt, int32_t flags
 int32_t mhip_plan_state_dev(mhip_ctx* ctx, float* out3_dev);
 int32_t mhip_plan_decide(mhip_ctx* ctx, int64_t step_n, const float* reduced3, int32_t* action, int32_t* check_in);
 
+
+/* ---- the ghost exchange INSIDE the engine: peer stores over xGMI, the step loop in C++ (the reference has no
+ * multi-device path, README.md:54) ---------------------------------------------------------------------------------------------------
+ * One process per GPU.  Every rank owns a receive region in fine-grained device memory (two halves of rows_capacity rows of 3 reals,
+ * used alternately by the parity of the exchange number, behind a small header of sequence words) and maps every peer's region
+ * through its IPC handle.  After a step's coordinates are packed ONE kernel stores each peer's rows straight into that peer's region
+ * and raises this rank's sequence word there; the receiving side's next step waits for its senders' words on the device (bounded:
+ * 2 s, then MHIP_ERR_STATE at the end of the call instead of a hung GPU).  No host call and no collective per step.
+ *
+ *   mhip_halo_region     : allocate (or reuse) this rank's region; ipc_handle_out receives MHIP_IPC_HANDLE_BYTES bytes to hand to
+ *                          the peers (any transport: the decomposition is set up by the host once)
+ *   mhip_halo_open_peer  : map rank r's region from its handle (every rank that sends to or receives from this one; for the
+ *                          collective validity check: every rank)
+ *   mhip_set_halo_routes : per ghost plan, after mhip_set_halo_plan: the send buffer's consecutive segments → (peer, first row in the
+ *                          peer's half); the receive buffer of the plan is the region half itself, peer by peer in the same order
+ *   mhip_domain_run      : a run of ghosted velocity-Verlet steps in one call — mhip_vv_halo_start, then per step interior blocks →
+ *                          wait → mhip_vv_halo_mid → peer stores, with the collective prune / re-plan decision (mhip_plan_state_dev →
+ *                          MAX over the ranks → mhip_plan_decide) taken every rebuild interval from numbers that are read one step
+ *                          after they were measured, so that nothing drains the stream.  Returns after n_steps (*reason = 0) or
+ *                          behind the second kick of the step after which ownership and ghosts must be re-planned (*reason = 1);
+ *                          *steps_done steps were taken.  If the last step taken removes the centre-of-mass motion, cm_parts_dev
+ *                          holds its n_parts partials for the all-reduce (mhip_remove_cm_parts_dev).  counters3 (nullable) is
+ *                          incremented by {checks, prunes arranged, re-plans asked}.  A sub-domain without peers (one rank) needs
+ *                          no region and no routes. */
+#define MHIP_IPC_HANDLE_BYTES 64
+typedef struct {
+    int32_t n_peers;
+    const int32_t* peer_rank;      /* [n_peers] host: the ranks, in the order of the send / receive buffer segments */
+    const int64_t* send_rows;      /* [n_peers] host: rows of the send buffer for each peer (consecutive segments, momentum rows included) */
+    const int64_t* dst_row;        /* [n_peers] host: first row in the PEER's region half where this rank's segment lands */
+    const int64_t* recv_rows;      /* [n_peers] host: rows received from each peer (consecutive in this rank's half, same order) */
+} mhip_halo_routes;
+int32_t mhip_halo_region(mhip_ctx* ctx, int64_t rows_capacity, int32_t world, int32_t rank, void* ipc_handle_out);
+int32_t mhip_halo_open_peer(mhip_ctx* ctx, int32_t rank, const void* ipc_handle);
+int32_t mhip_set_halo_routes(mhip_ctx* ctx, const mhip_halo_routes* routes);
+int32_t mhip_domain_run(mhip_ctx* ctx, int64_t first_step, int64_t n_steps, double dt, int32_t remove_cm_every, double* cm_parts_dev, int32_t n_parts,
+                        int64_t* steps_done, int32_t* reason, int64_t* counters3);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,14 @@ class HaloPlan(C.Structure):
                 ("n_send_rows", C.c_int64), ("send", C.c_void_p), ("send_cm_pos", C.c_void_p), ("n_send_cm", C.c_int32)]
 
 
+class HaloRoutes(C.Structure):
+    """mhip_halo_routes: where the segments of a ghost plan's send buffer land (host arrays)"""
+    _fields_ = [("n_peers", C.c_int32), ("peer_rank", C.POINTER(C.c_int32)), ("send_rows", C.POINTER(C.c_int64)),
+                ("dst_row", C.POINTER(C.c_int64)), ("recv_rows", C.POINTER(C.c_int64))]
+
+
+IPC_HANDLE_BYTES = 64
+
 # every entry point of include/mollyhip.h: name -> (restype, argtypes)
 _P, _I32, _I64, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_double
 SIGNATURES = {
@@ -124,6 +132,10 @@ SIGNATURES = {
     "mhip_vv_halo_mid": (_I32, [_P, _I64, _D, _I32, _P, _I32]),
     "mhip_plan_state_dev": (_I32, [_P, _P]),
     "mhip_plan_decide": (_I32, [_P, _I64, C.POINTER(C.c_float), C.POINTER(_I32), C.POINTER(_I32)]),
+    "mhip_halo_region": (_I32, [_P, _I64, _I32, _I32, _P]),
+    "mhip_halo_open_peer": (_I32, [_P, _I32, _P]),
+    "mhip_set_halo_routes": (_I32, [_P, C.POINTER(HaloRoutes)]),
+    "mhip_domain_run": (_I32, [_P, _I64, _I64, _D, _I32, _P, _I32, C.POINTER(_I64), C.POINTER(_I32), C.POINTER(_I64)]),
 }
 
 

@@ -16,6 +16,7 @@
 #include "stochastic.h"
 #include "pme.h"
 #include "step_fused.h"
+#include "halo_xfer.h"
 #include "hilbert.h"
 #include "kernels.h"
 #include "forces_launch.h"
@@ -90,6 +91,10 @@ struct EngineBase {
     virtual void halo_end(int64_t, double, int64_t, int64_t, const void*, double*) = 0;
     virtual void halo_end_parts(int64_t, double, int64_t, int64_t, const void*, double*, int32_t) = 0;
     virtual void remove_cm_parts_dev(const double*, int32_t) = 0;
+    virtual void halo_region(int64_t, int32_t, int32_t, void*) = 0;
+    virtual void halo_open_peer(int32_t, const void*) = 0;
+    virtual void set_halo_routes(const mhip_halo_routes*) = 0;
+    virtual void domain_run(int64_t, int64_t, double, int32_t, double*, int32_t, int64_t*, int32_t*, int64_t*) = 0;
 };
 
 // hipEvent stage timers (only active while profiling is on)
@@ -256,6 +261,7 @@ template <class T> class Engine final : public EngineBase {
         wave_rows_in.release(); nbr_in.release(); pos_snap.release(); blk_disp2.release(); tile_idx_in.release(); tile_cnt_in.release(); rows_x.release(); nbr_x.release(); tile_idx_x.release(); tile_cnt_x.release(); blk_ghost.release(); blk_ghost_in.release();
         xl_start.release(); xl_list.release(); tile_idx.release(); tile_cnt.release(); wave_rows.release(); nbr.release(); blk_center.release();
         flags.release(); red_part.release(); red_out.release(); cm_step.release(); vcm.release(); stage_a.release(); stage_b.release(); stage_i.release(); bonded.release(); pme.release(); frc_scratch.release(); nl_counter.release(); state_changed.release();
+        xf_release();
         prof.release();
         for (int k = 0; k < 2; ++k) { if (side[k]) { (void)hipStreamSynchronize(side[k]); (void)hipStreamDestroy(side[k]); } if (ev_side[k]) (void)hipEventDestroy(ev_side[k]); frc_side[k].release(); }
         if (ev_pos) (void)hipEventDestroy(ev_pos);
@@ -1444,7 +1450,10 @@ template <class T> class Engine final : public EngineBase {
     // single-domain engine (refresh): 0 = the inner list lives on, 1 = the next force pass re-prunes the outer list, 2 = the ghost
     // plan cannot vouch for a prune any more (or there is no margin): re-plan.  The inner list is pruned with the tight inner skin
     // (rc + skin_in, grown when the fastest atoms would outrun a third of it between two checks) as in mhip_vv_run.
-    int plan_decide(int64_t step_n, const float* red3, int32_t* check_in) override {
+    int plan_decide(int64_t step_n, const float* red3, int32_t* check_in) override { return plan_decide_late(step_n, red3, check_in, 0); }
+    // late: the decision is applied `late` steps after the measurement (mhip_domain_run reads the reduced numbers one step later, so
+    // that nothing waits for them): the drift bounds then reach that much further
+    int plan_decide_late(int64_t step_n, const float* red3, int32_t* check_in, int late) {
         if (check_in) *check_in = 0;
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         if (!engine_sched) {   // first use: from now on the inner list may be tighter than r_list
@@ -1458,16 +1467,16 @@ template <class T> class Engine final : public EngineBase {
         ++n_disp_checks;
         bool reprune = !inner_valid || std::isinf(red3[1]);
         if (!reprune) {
-            const double d = std::sqrt((double)red3[1]), ahead = drift_ahead(d, step_n - last_prune_step, every);
+            const double d = std::sqrt((double)red3[1]), ahead = drift_ahead(d, step_n - last_prune_step, every + late);
             adapt_inner_skin(ahead);
             reprune = !inner_valid || 2.0 * (d + ahead) > skin_in * 0.98;
             // not good for a whole interval, but for k steps: the host looks again then (it owns the step loop)
             if (reprune && inner_valid && check_in)
-                if (const int k = steps_within(d, 0.49 * skin_in, step_n - last_prune_step, every, true)) { *check_in = k; return 0; }
+                if (const int k = steps_within(d, 0.49 * skin_in, step_n - last_prune_step, every, true)) { if (k > late + 1) { *check_in = k; return 0; } }
         }
         if (!reprune) return 0;
-        // the prune runs inside the NEXT force pass, one step from now: leave it that step of headroom
-        if (2.0 * (std::sqrt((double)red3[0]) + last_vmax * cur_dt * 1.25) > prune_margin() * 0.98) return 2;
+        // the prune runs inside the NEXT force pass, one step from now (+ late): leave it that much headroom
+        if (2.0 * (std::sqrt((double)red3[0]) + last_vmax * cur_dt * 1.25 * (1 + late)) > prune_margin() * 0.98) return 2;
         inner_valid = false;
         return 1;
     }
@@ -1482,7 +1491,7 @@ template <class T> class Engine final : public EngineBase {
         if ((p->n_recv_rows > 0 && (!p->recv || !p->recv_dst)) || (p->n_send_rows > 0 && (!p->send || !p->send_idx || !p->send_shift)) || (p->n_send_cm > 0 && !p->send_cm_pos))
             throw ApiError{MHIP_ERR_INVALID, "halo plan: null buffer"};
         if (p->cm_rows > 0 && p->cm_rows * 3 * (int)sizeof(T) < 32) throw ApiError{MHIP_ERR_INVALID, "halo plan: cm_rows rows cannot hold four doubles"};
-        hp = *p; hp_set = true; halo_cm_in = false;
+        hp = *p; hp_set = true; halo_cm_in = false; xf.routes = false;
         cm_all.reserve(4 * 28);
         MHIP_HIP(hipMemsetAsync(cm_all.p, 0, 4 * 28 * sizeof(double), stream));
     }
@@ -1510,7 +1519,7 @@ template <class T> class Engine final : public EngineBase {
         if (hp.n_recv_rows > 0) {
             if (hp.first_ghost < 0 || hp.first_ghost > n_tot) throw ApiError{MHIP_ERR_INVALID, "halo plan: ghost range out of bounds"};
             tr("k_halo_unpack");
-            hipLaunchKernelGGL(k_halo_unpack<T>, dim3(cdiv(hp.n_recv_rows, 256)), dim3(256), 0, stream, hp.n_recv_rows, (const T*)hp.recv, hp.recv_dst, hp.first_ghost, (const int32_t*)inv.p,
+            hipLaunchKernelGGL(k_halo_unpack<T>, dim3(cdiv(hp.n_recv_rows, 256)), dim3(256), 0, stream, hp.n_recv_rows, xf_unpack_src ? (const T*)xf_unpack_src : (const T*)hp.recv, hp.recv_dst, hp.first_ghost, (const int32_t*)inv.p,
                                pos[cur].p, cm_all.p, std::max(hp.cm_rows, 1));
         }
         cur_dt = dt;
@@ -1543,6 +1552,162 @@ template <class T> class Engine final : public EngineBase {
         } else halo_cm_in = false;
         MHIP_HIP(hipGetLastError());
     }
+    // ---- the ghost exchange inside the engine (halo_xfer.h): peer stores into IPC-mapped receive regions, the step loop in C++ --------
+    struct Xfer {
+        unsigned char* region = nullptr; int64_t rows_cap = 0; int world = 0, rank = 0;
+        XferPeers peers{}; bool opened[XFER_MAX_RANKS] = {};
+        bool routes = false; int n_peers = 0; std::vector<int32_t> peer_rank;
+        DBuf<int32_t> row_peer, row_dst, d_peers; DBuf<unsigned int> done; DBuf<int32_t> err; DBuf<float> mine3, red3;
+        uint32_t seq = 0, plan_seq = 0;
+        float* h_red3 = nullptr; int32_t* h_err = nullptr; hipEvent_t ev_plan = nullptr;
+        bool plan_pending = false; int64_t plan_step = -1, next_check = -1;
+    } xf;
+    const void* xf_unpack_src = nullptr;
+    T* xf_rows(int parity) const { return reinterpret_cast<T*>(xf.region + XFER_ROWS_OFF) + (size_t)parity * xf.rows_cap * 3; }
+    void xf_release() {
+        for (int r = 0; r < XFER_MAX_RANKS; ++r) if (xf.opened[r] && xf.peers.region[r]) { (void)hipIpcCloseMemHandle(xf.peers.region[r]); xf.opened[r] = false; }
+        if (xf.region) (void)hipFree(xf.region);
+        xf.region = nullptr;
+        xf.row_peer.release(); xf.row_dst.release(); xf.d_peers.release(); xf.done.release(); xf.err.release(); xf.mine3.release(); xf.red3.release();
+        if (xf.h_red3) (void)hipHostFree(xf.h_red3); if (xf.h_err) (void)hipHostFree(xf.h_err); if (xf.ev_plan) (void)hipEventDestroy(xf.ev_plan);
+        xf.h_red3 = nullptr; xf.h_err = nullptr; xf.ev_plan = nullptr;
+    }
+    // this rank's receive region: two halves of rows_cap rows of 3 reals behind the header, fine-grained device memory (peers write it,
+    // this device polls it); its IPC handle goes to every peer
+    void halo_region(int64_t rows_cap, int32_t world, int32_t my_rank, void* handle_out) override {
+        if (rows_cap <= 0 || world < 1 || world > XFER_MAX_RANKS || my_rank < 0 || my_rank >= world) throw ApiError{MHIP_ERR_INVALID, "halo region: rows / world / rank out of range"};
+        MHIP_HIP(hipStreamSynchronize(stream));
+        if (!xf.region || xf.rows_cap < rows_cap || xf.world != world || xf.rank != my_rank) {
+            if (xf.region) xf_release();
+            const size_t bytes = XFER_ROWS_OFF + 2 * (size_t)rows_cap * 3 * sizeof(T);
+            MHIP_HIP(hipExtMallocWithFlags((void**)&xf.region, bytes, hipDeviceMallocFinegrained));
+            MHIP_HIP(hipMemset(xf.region, 0, bytes));
+            xf.rows_cap = rows_cap; xf.world = world; xf.rank = my_rank; xf.seq = 0; xf.plan_seq = 0; xf.routes = false;
+            for (int r = 0; r < XFER_MAX_RANKS; ++r) xf.peers.region[r] = nullptr;
+            xf.peers.region[my_rank] = xf.region;
+            xf.done.reserve(1); xf.err.reserve(1); xf.mine3.reserve(4); xf.red3.reserve(4);
+            MHIP_HIP(hipMemset(xf.done.p, 0, sizeof(unsigned int))); MHIP_HIP(hipMemset(xf.err.p, 0, sizeof(int32_t)));
+            if (!xf.h_red3) MHIP_HIP(hipHostMalloc((void**)&xf.h_red3, 4 * sizeof(float)));
+            if (!xf.h_err) MHIP_HIP(hipHostMalloc((void**)&xf.h_err, sizeof(int32_t)));
+            if (!xf.ev_plan) MHIP_HIP(hipEventCreateWithFlags(&xf.ev_plan, hipEventDisableTiming));
+        }
+        if (handle_out) {
+            hipIpcMemHandle_t h;
+            MHIP_HIP(hipIpcGetMemHandle(&h, xf.region));
+            static_assert(sizeof(hipIpcMemHandle_t) == MHIP_IPC_HANDLE_BYTES, "hipIpcMemHandle_t is 64 bytes");
+            std::memcpy(handle_out, &h, sizeof(h));
+        }
+    }
+    void halo_open_peer(int32_t rank, const void* handle) override {
+        if (!xf.region) throw ApiError{MHIP_ERR_STATE, "mhip_halo_region first"};
+        if (rank < 0 || rank >= xf.world || !handle) throw ApiError{MHIP_ERR_INVALID, "halo peer: rank out of range or null handle"};
+        if (rank == xf.rank) return;
+        if (xf.opened[rank]) { (void)hipIpcCloseMemHandle(xf.peers.region[rank]); xf.opened[rank] = false; }
+        hipIpcMemHandle_t h; std::memcpy(&h, handle, sizeof(h));
+        void* base = nullptr;
+        MHIP_HIP(hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess));
+        xf.peers.region[rank] = (unsigned char*)base; xf.opened[rank] = true;
+    }
+    // where the rows of the current ghost plan travel: consecutive segments of the send buffer → (peer, first row in the peer's half)
+    void set_halo_routes(const mhip_halo_routes* rt) override {
+        if (!rt) { xf.routes = false; return; }
+        if (!hp_set) throw ApiError{MHIP_ERR_STATE, "mhip_set_halo_plan first"};
+        if (rt->n_peers < 0 || rt->n_peers >= XFER_MAX_RANKS) throw ApiError{MHIP_ERR_INVALID, "halo routes: peer count out of range"};
+        if (rt->n_peers > 0 && !xf.region) throw ApiError{MHIP_ERR_STATE, "mhip_halo_region first"};
+        std::vector<int32_t> rp, rd; rp.reserve((size_t)hp.n_send_rows); rd.reserve((size_t)hp.n_send_rows);
+        int64_t recv_total = 0;
+        xf.peer_rank.assign(rt->peer_rank, rt->peer_rank + rt->n_peers);
+        for (int q = 0; q < rt->n_peers; ++q) {
+            const int r = rt->peer_rank[q];
+            if (r < 0 || r >= xf.world || r == xf.rank || !xf.peers.region[r]) throw ApiError{MHIP_ERR_INVALID, "halo routes: peer not opened (mhip_halo_open_peer)"};
+            if (rt->send_rows[q] < 0 || rt->dst_row[q] < 0 || rt->dst_row[q] + rt->send_rows[q] > xf.rows_cap) throw ApiError{MHIP_ERR_CAPACITY, "halo routes: segment does not fit the peer's region"};
+            for (int64_t k = 0; k < rt->send_rows[q]; ++k) { rp.push_back(r); rd.push_back((int32_t)(rt->dst_row[q] + k)); }
+            recv_total += rt->recv_rows[q];
+        }
+        if ((int64_t)rp.size() != hp.n_send_rows || recv_total != hp.n_recv_rows || recv_total > xf.rows_cap) throw ApiError{MHIP_ERR_INVALID, "halo routes do not match the halo plan"};
+        xf.n_peers = rt->n_peers;
+        MHIP_HIP(hipStreamSynchronize(stream));
+        xf.row_peer.reserve(std::max<size_t>(rp.size(), 1)); xf.row_dst.reserve(std::max<size_t>(rd.size(), 1)); xf.d_peers.reserve(std::max(rt->n_peers, 1));
+        if (!rp.empty()) { MHIP_HIP(hipMemcpy(xf.row_peer.p, rp.data(), rp.size() * sizeof(int32_t), hipMemcpyHostToDevice)); MHIP_HIP(hipMemcpy(xf.row_dst.p, rd.data(), rd.size() * sizeof(int32_t), hipMemcpyHostToDevice)); }
+        if (rt->n_peers) MHIP_HIP(hipMemcpy(xf.d_peers.p, rt->peer_rank, rt->n_peers * sizeof(int32_t), hipMemcpyHostToDevice));
+        xf.routes = true; xf.plan_pending = false; xf.next_check = -1;
+    }
+    void xf_push() {        // the packed rows of this step → the peers' regions, exchange number ++seq
+        if (xf.n_peers == 0) return;
+        ++xf.seq;
+        tr("k_halo_push");
+        hipLaunchKernelGGL(k_halo_push<T>, dim3(cdiv(std::max<int64_t>(hp.n_send_rows, 1), 256)), dim3(256), 0, stream, hp.n_send_rows, (const T*)hp.send, (const int32_t*)xf.row_peer.p, (const int32_t*)xf.row_dst.p,
+                           xf.peers, xf.rows_cap, (int)(xf.seq & 1u), xf.seq, xf.rank, (const int32_t*)xf.d_peers.p, xf.n_peers, xf.done.p);
+        MHIP_HIP(hipGetLastError());
+    }
+    void xf_wait() {        // the peers' rows of exchange seq are in my half seq & 1
+        if (xf.n_peers == 0) return;
+        tr("k_halo_wait");
+        hipLaunchKernelGGL(k_halo_wait, dim3(1), dim3(64), 0, stream, reinterpret_cast<const XferHeader*>(xf.region), (int)(xf.seq & 1u), xf.seq, (const int32_t*)xf.d_peers.p, xf.n_peers, xf.err.p);
+        xf_unpack_src = xf_rows((int)(xf.seq & 1u));
+    }
+    void xf_check_errors() {
+        if (!xf.region) return;
+        MHIP_HIP(hipMemcpyAsync(xf.h_err, xf.err.p, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        MHIP_HIP(hipStreamSynchronize(stream));
+        if (*xf.h_err) { MHIP_HIP(hipMemset(xf.err.p, 0, sizeof(int32_t))); throw ApiError{MHIP_ERR_STATE, "ghost exchange timed out: a peer's rows (or its validity triple) did not arrive within 2 s"}; }
+    }
+    // the collective validity check of the pair lists, issued at step s and read one step later (nothing waits for it)
+    void xf_issue_plan_check(int64_t s) {
+        plan_state_dev(xf.mine3.p);
+        ++xf.plan_seq;
+        if (xf.world > 1) {
+            hipLaunchKernelGGL(k_plan_push, dim3(1), dim3(64), 0, stream, (const float*)xf.mine3.p, xf.peers, xf.world, xf.rank, (int)(xf.plan_seq & 1u), xf.plan_seq);
+            hipLaunchKernelGGL(k_plan_reduce, dim3(1), dim3(64), 0, stream, reinterpret_cast<const XferHeader*>(xf.region), xf.world, (int)(xf.plan_seq & 1u), xf.plan_seq, xf.red3.p, xf.h_red3, xf.err.p);
+        } else MHIP_HIP(hipMemcpyAsync(xf.h_red3, xf.mine3.p, 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
+        MHIP_HIP(hipEventRecord(xf.ev_plan, stream));
+        xf.plan_pending = true; xf.plan_step = s;
+    }
+    // A run of ghosted steps in ONE call (≙ DomainRun.run of domain.py, fused form): returns after n_steps (reason 0) or behind the second
+    // kick of the step after which ownership and ghosts have to be re-planned (reason 1); *steps_done steps were taken.  When the last
+    // step taken removes the centre-of-mass motion, cm_parts_dev holds its n_parts partials for the all-reduce over the ranks
+    // (mhip_remove_cm_parts_dev), as after mhip_vv_halo_mid with the stop flag.  counters[0..2] += checks, prunes arranged, re-plans asked.
+    void domain_run(int64_t first_step, int64_t n_steps, double dt, int32_t remove_cm_every, double* cm_parts_dev, int32_t n_parts, int64_t* steps_done, int32_t* reason, int64_t* counters) override {
+        if (!hp_set) throw ApiError{MHIP_ERR_STATE, "mhip_set_halo_plan first"};
+        const bool solo = hp.n_cm_peers == 0 && hp.n_send_rows == 0;
+        if (!solo && !xf.routes) throw ApiError{MHIP_ERR_STATE, "mhip_set_halo_routes first"};
+        if (!xf.h_red3) { MHIP_HIP(hipHostMalloc((void**)&xf.h_red3, 4 * sizeof(float))); MHIP_HIP(hipEventCreateWithFlags(&xf.ev_plan, hipEventDisableTiming)); xf.mine3.reserve(4); xf.world = std::max(xf.world, 1); }
+        *steps_done = 0; *reason = 0;
+        if (n_steps <= 0) return;
+        const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
+        const int64_t last = first_step + n_steps;
+        InRun guard_in_run(in_run);
+        halo_start(dt);
+        xf_push();
+        for (int64_t s = first_step + 1; s <= last; ++s) {
+            const bool cm = remove_cm_every != 0 && s % remove_cm_every == 0;
+            bool replan = false;
+            if (xf.plan_pending && s > xf.plan_step) {          // the numbers of the check issued a step ago have long arrived
+                MHIP_HIP(hipEventSynchronize(xf.ev_plan));
+                xf.plan_pending = false;
+                int32_t check_in = 0;
+                const float red[3] = {xf.h_red3[0], xf.h_red3[1], xf.h_red3[2]};
+                const int action = std::isinf(red[0]) ? 2 : plan_decide_late(xf.plan_step, red, &check_in, (int)(s - xf.plan_step));
+                if (counters) { counters[1] += action == 1; counters[2] += action == 2; }
+                xf.next_check = check_in > 0 ? xf.plan_step + check_in : -1;
+                replan = action == 2;
+            }
+            if (!replan && !xf.plan_pending) {      // (a check issued at the last step of this call is read at the first step of the next one)
+                if (ghost_margin <= 0 && n_ghost > 0) replan = s % every == 0;      // no margin: ownership and ghosts are redone at every rebuild step
+                else if (s % every == 0 || (xf.next_check >= 0 && s >= xf.next_check)) { xf.next_check = -1; xf_issue_plan_check(s); if (counters) counters[0] += 1; }
+            }
+            const bool stop = replan || s == last;
+            if (n_ghost > 0 && xf.n_peers > 0) (void)halo_interior(s);          // the blocks that need no ghost, while the peers' rows arrive
+            xf_wait();
+            halo_mid(s, dt, (cm ? 1 : 0) | (stop ? 2 : 0), (cm && stop) ? cm_parts_dev : nullptr, (cm && stop) ? n_parts : 0);
+            xf_unpack_src = nullptr;
+            ++*steps_done;
+            if (stop) { *reason = replan ? 1 : 0; xf.plan_pending = false; break; }
+            xf_push();
+        }
+        xf_check_errors();      // (one stream sync per call: a chunk is ≈ 100 steps)
+    }
+
     // one MD step of a ghosted sub-domain in two calls around the ghost exchange
     void halo_begin(double dt, const int32_t* idx_dev, const void* shift_dev, int64_t n, void* out_dev) override {
         vv_stage1(dt);
@@ -1940,6 +2105,16 @@ int32_t mhip_set_halo_plan(mhip_ctx* ctx, const mhip_halo_plan* plan) { NEED_CTX
 int32_t mhip_vv_halo_start(mhip_ctx* ctx, double dt) { NEED_CTX(); return guard(ctx, [&] { ctx->e->halo_start(dt); }); }
 int32_t mhip_vv_halo_mid(mhip_ctx* ctx, int64_t step_n, double dt, int32_t flags, double* cm_parts, int32_t n_parts) {
     NEED_CTX(); return guard(ctx, [&] { ctx->e->halo_mid(step_n, dt, flags, cm_parts, n_parts); });
+}
+int32_t mhip_halo_region(mhip_ctx* ctx, int64_t rows_capacity, int32_t world, int32_t rank, void* ipc_handle_out) { NEED_CTX(); return guard(ctx, [&] { ctx->e->halo_region(rows_capacity, world, rank, ipc_handle_out); }); }
+int32_t mhip_halo_open_peer(mhip_ctx* ctx, int32_t rank, const void* ipc_handle) { NEED_CTX(); return guard(ctx, [&] { ctx->e->halo_open_peer(rank, ipc_handle); }); }
+int32_t mhip_set_halo_routes(mhip_ctx* ctx, const mhip_halo_routes* routes) { NEED_CTX(); return guard(ctx, [&] { ctx->e->set_halo_routes(routes); }); }
+int32_t mhip_domain_run(mhip_ctx* ctx, int64_t first_step, int64_t n_steps, double dt, int32_t remove_cm_every, double* cm_parts_dev, int32_t n_parts,
+                        int64_t* steps_done, int32_t* reason, int64_t* counters3) {
+    NEED_CTX(); return guard(ctx, [&] {
+        if (!steps_done || !reason || !(dt > 0) || n_steps < 0) throw mhip::ApiError{MHIP_ERR_INVALID, "mhip_domain_run: null output, dt <= 0 or n_steps < 0"};
+        if (remove_cm_every != 0 && (!cm_parts_dev || n_parts < 1 || n_parts > 1024)) throw mhip::ApiError{MHIP_ERR_INVALID, "mhip_domain_run: n_parts must be 1..1024 when the centre-of-mass motion is removed"};
+        ctx->e->domain_run(first_step, n_steps, dt, remove_cm_every, cm_parts_dev, n_parts, steps_done, reason, counters3); });
 }
 int32_t mhip_vv_halo_begin(mhip_ctx* ctx, double dt, const int32_t* idx, const void* shift, int64_t n, void* out) { NEED_CTX(); return guard(ctx, [&] { ctx->e->halo_begin(dt, idx, shift, n, out); }); }
 int32_t mhip_vv_halo_interior(mhip_ctx* ctx, int64_t step_n, int32_t* launched) { NEED_CTX(); return guard(ctx, [&] { int r = ctx->e->halo_interior(step_n); if (launched) *launched = r; }); }

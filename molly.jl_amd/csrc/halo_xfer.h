@@ -1,0 +1,97 @@
+// halo_xfer.h — the ghost exchange INSIDE the engine ("direct peer stores into pre-exchanged IPC buffers").
+//
+// Every rank owns a RECEIVE REGION in fine-grained device memory and, through hipIpcOpenMemHandle, a pointer to every peer's region
+// (one process per GPU; the pointers are exchanged once, when the decomposition is set up).  After a step's coordinates are packed,
+// ONE kernel stores each peer's rows straight into that peer's region — over xGMI, no host call, no collective — and then raises a
+// sequence word there; the unpack kernel of the receiving side spins on its senders' words (bounded: a peer that never arrives raises
+// an error flag instead of hanging the GPU) before it scatters the rows into its ghost slots.  A region has two halves used by the
+// parity of the exchange number: a fast peer may deliver exchange e + 1 while this rank still reads exchange e, never e + 2 (that
+// needs this rank's own e + 1, which it sends after reading e).  The collective validity check of the pair lists (MAX over the ranks
+// of three floats every rebuild interval) travels the same way into a small table of the region.
+#pragma once
+#include "common.h"
+
+namespace mhip {
+
+constexpr int XFER_MAX_RANKS = 64;
+// header of a receive region (the row halves follow at rows_off)
+struct XferHeader {
+    uint32_t seq_in[2][XFER_MAX_RANKS];        // [parity][sender rank]: number of the last exchange whose rows are complete in that half
+    uint32_t plan_seq[2][XFER_MAX_RANKS];      // [parity][rank]: number of the last validity check whose triple is in plan_val
+    float plan_val[2][XFER_MAX_RANKS][4];      // {max |x − x_plan|², max |x − x_prune|², max |v|², –} of that rank
+};
+constexpr size_t XFER_ROWS_OFF = (sizeof(XferHeader) + 255) & ~(size_t)255;
+
+__device__ inline void xfer_store_release(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ inline uint32_t xfer_load_acquire(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
+// wait until *p has reached `want` (sequence numbers only grow; wrap-safe compare); false after ~2 s of wall clock (100 MHz counter)
+__device__ inline bool xfer_wait(const uint32_t* p, uint32_t want) {
+    const unsigned long long t0 = wall_clock64();
+    while ((int32_t)(xfer_load_acquire(p) - want) < 0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > 200000000ull) return false;
+    }
+    return true;
+}
+
+struct XferPeers {                              // by value to the kernels: the mapped regions, indexed by rank
+    unsigned char* region[XFER_MAX_RANKS];
+};
+
+// rows [0, n_rows) of the packed send buffer → the peers' regions: row k goes to rank row_peer[k], row row_dst[k] of that rank's half
+// `parity`.  The last block to finish raises seq_in[parity][my_rank] = seq at every peer (done: a zeroed counter, left zero again).
+template <class T>
+__global__ void __launch_bounds__(256) k_halo_push(int64_t n_rows, const T* __restrict__ send, const int32_t* __restrict__ row_peer, const int32_t* __restrict__ row_dst,
+                                                   XferPeers P, int64_t rows_cap, int parity, uint32_t seq, int my_rank, const int32_t* __restrict__ peers, int n_peers, unsigned int* done) {
+    const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (k < n_rows) {
+        T* base = reinterpret_cast<T*>(P.region[row_peer[k]] + XFER_ROWS_OFF) + (size_t)parity * rows_cap * 3;
+        T* d = base + 3 * (size_t)row_dst[k];
+        d[0] = send[3 * k]; d[1] = send[3 * k + 1]; d[2] = send[3 * k + 2];
+    }
+    __threadfence_system();                       // this block's rows are on their way before it checks out
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int before = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (before == gridDim.x - 1) {            // every block has checked out: the exchange is complete at every peer
+            __threadfence_system();
+            for (int q = 0; q < n_peers; ++q)
+                xfer_store_release(&reinterpret_cast<XferHeader*>(P.region[peers[q]])->seq_in[parity][my_rank], seq);
+            __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// one block: waits until every peer has delivered exchange `seq` into half `parity` of MY region; raises *err on a time-out
+[[maybe_unused]] static __global__ void k_halo_wait(const XferHeader* mine, int parity, uint32_t seq, const int32_t* __restrict__ peers, int n_peers, int32_t* err) {
+    const int q = threadIdx.x;
+    if (q < n_peers && !xfer_wait(&mine->seq_in[parity][peers[q]], seq)) atomicOr(err, 1);
+}
+
+// validity check of the pair lists over all ranks: my triple into every rank's table (my own included) …
+[[maybe_unused]] static __global__ void k_plan_push(const float* __restrict__ mine3, XferPeers P, int world, int my_rank, int parity, uint32_t seq) {
+    const int r = threadIdx.x;
+    if (r >= world) return;
+    XferHeader* h = reinterpret_cast<XferHeader*>(P.region[r]);
+    h->plan_val[parity][my_rank][0] = mine3[0]; h->plan_val[parity][my_rank][1] = mine3[1]; h->plan_val[parity][my_rank][2] = mine3[2];
+    __threadfence_system();
+    xfer_store_release(&h->plan_seq[parity][my_rank], seq);
+}
+// … and, once every rank's has arrived, their maximum → out3 (device) and host3 (pinned host memory, read behind an event)
+[[maybe_unused]] static __global__ void k_plan_reduce(const XferHeader* mine, int world, int parity, uint32_t seq, float* out3, float* host3, int32_t* err) {
+    __shared__ float sh[XFER_MAX_RANKS][3];
+    const int r = threadIdx.x;
+    if (r < world) {
+        if (!xfer_wait(&mine->plan_seq[parity][r], seq)) atomicOr(err, 2);
+        for (int c = 0; c < 3; ++c) sh[r][c] = __hip_atomic_load(&mine->plan_val[parity][r][c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+    if (r < 3) {
+        float m = sh[0][r];
+        for (int q = 1; q < world; ++q) m = fmaxf(m, sh[q][r]);        // (+inf propagates: a rank that must re-plan makes everybody re-plan)
+        if (out3) out3[r] = m;
+        if (host3) host3[r] = m;
+    }
+}
+
+}  // namespace mhip

@@ -976,8 +976,8 @@ template <class T> struct ForceArgs {
 // strides the packed loop is compiled for (odd numbers of dwords): tiles of up to stride − 1 atoms, 12·stride bytes of LDS.  The
 // smallest that holds the tile is used: 36 KiB leaves room for four 512-lane blocks per CU, 48 KiB for three (measured: −12 % per pass).
 constexpr int SOA_STRIDES[3] = {2049, 3073, 4097};
-// dynamic LDS a PRUNE pass needs behind its tile: the renumbering table (2 bytes per tile atom of a segment), scan scratch, wave boxes
-__host__ __device__ inline size_t prune_lds_bytes(int t_seg, int nthr) { return (size_t)(((t_seg + 8) & ~7) * 2) + ((size_t)nthr + 4) * 4 + 4 * 6 * 4 + 32; }
+// dynamic LDS a PRUNE pass needs behind its tile: the renumbering table (2 bytes per tile atom of a segment), scan scratch, eight boxes
+__host__ __device__ inline size_t prune_lds_bytes(int t_seg, int nthr) { return (size_t)(((t_seg + 8) & ~7) * 2) + ((size_t)nthr + 4) * 4 + 8 * 8 * 4 + 32; }
 
 // (the plain fp32 one-type passes run four 512-lane blocks per CU = eight waves per SIMD, which takes <= 64 VGPRs: held by attribute)
 #ifndef MHIP_FAST_MIN_WAVES
@@ -1060,13 +1060,17 @@ k_forces(ForceArgs<T> A) {
         l_new = reinterpret_cast<uint16_t*>(smem + A.mark_off);
         l_scan = reinterpret_cast<int32_t*>(smem + A.mark_off + ((A.T_lds + 8) & ~7) * 2);
         l_box = reinterpret_cast<float*>(l_scan + nthr + 4);
-        // bounding box of every wave of i-atoms, in the frame of the staged tile (block-local coordinates)
+        // bounding boxes of the i-atoms, eight per block (runs of BI/8 consecutive atoms: compact along the Hilbert curve), in the frame
+        // of the staged tile (block-local coordinates).  One box per wave let half of a 64-atom water block's outer tile through.
+        const int lpb = A.BI >> 3;
         float mn[3] = {(float)pi.x, (float)pi.y, (float)pi.z}, mx[3] = {(float)pi.x, (float)pi.y, (float)pi.z};
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
+        for (int o = lpb >> 1; o > 0; o >>= 1)
 #pragma unroll
             for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], __shfl_xor(mn[d], o, WAVE)); mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], o, WAVE)); }
-        if (js == 0 && (tid & 63) == 0) for (int d = 0; d < 3; ++d) { l_box[(li >> 6) * 6 + d] = mn[d]; l_box[(li >> 6) * 6 + 3 + d] = mx[d]; }
+        if (js == 0 && (li & (lpb - 1)) == 0) {    // a box = two 16-byte LDS words {lo.xyz, –}, {hi.xyz, –}
+            reinterpret_cast<float4*>(l_box)[(li / lpb) * 2] = make_float4(mn[0], mn[1], mn[2], 0.f);
+            reinterpret_cast<float4*>(l_box)[(li / lpb) * 2 + 1] = make_float4(mx[0], mx[1], mx[2], 0.f);
+        }
         if (A.snap_dst && js == 0 && valid) A.snap_dst[si] = pi_raw;
     }
     auto emit = [&](uint32_t e) {
@@ -1103,18 +1107,24 @@ k_forces(ForceArgs<T> A) {
             constexpr int SB = (FAST_CT && !PRUNE) ? MHIP_SB : 4;
             for (int t0 = 0; t0 < n_here; t0 += SB * nthr) {
                 int s[SB]; T4 p[SB]; [[maybe_unused]] T2 q[SB];
+                // rounds of this batch that hold an atom at all (block-uniform; the packed plain pass goes without the test: with it the
+                // register allocator spills 80 bytes per lane, and its tiles fill the rounds anyway)
+                constexpr bool GUARD = !(FAST_CT && !PRUNE);
+                const int kmax = GUARD ? min(SB, (n_here - t0 + nthr - 1) / nthr) : SB;
 #pragma unroll
                 for (int k = 0; k < SB; ++k) {
-                    const int t = min(t0 + k * nthr + tid, n_here - 1);     // (clamped: the loads of a lane past the end are harmless duplicates)
-                    s[k] = tix[seg_lo + t];
-                    if constexpr (EXPV == 3 || EXPV == 5) s[k] = (int)((int64_t)b * A.BI) + (t & (A.BI - 1));   // timing experiment: no staging gathers (the block's own atoms over and over)
+                    if (k < kmax) {
+                        const int t = min(t0 + k * nthr + tid, n_here - 1);     // (clamped: the loads of a lane past the end are harmless duplicates)
+                        s[k] = tix[seg_lo + t];
+                        if constexpr (EXPV == 3 || EXPV == 5) s[k] = (int)((int64_t)b * A.BI) + (t & (A.BI - 1));   // timing experiment: no staging gathers (the block's own atoms over and over)
+                    }
                 }
 #pragma unroll
-                for (int k = 0; k < SB; ++k) { p[k] = A.pos[s[k]]; if constexpr (PER_ATOM_LJ) q[k] = A.lj[s[k]]; }
+                for (int k = 0; k < SB; ++k) if (k < kmax) { p[k] = A.pos[s[k]]; if constexpr (PER_ATOM_LJ) q[k] = A.lj[s[k]]; }
 #pragma unroll
                 for (int k = 0; k < SB; ++k) {
                     const int t = t0 + k * nthr + tid;
-                    if (t < n_here) {
+                    if (k < kmax && t < n_here) {
                         const T4 pl = localise(p[k], tri_tag);
                         if (packed3) { l_p3[t] = (float)pl.x; l_p3[SOA_STRIDE + t] = (float)pl.y; l_p3[2 * SOA_STRIDE + t] = (float)pl.z; }
                         else l_pos[t] = pl;
@@ -1134,7 +1144,7 @@ k_forces(ForceArgs<T> A) {
         if constexpr (PRUNE) {
             // which atoms of this segment stay in the compacted tile, and under which number (ordered: the compacted tile keeps the
             // cell-major order of the outer one)
-            const int NW = A.BI >> 6;
+            constexpr int NW = 8;                      // boxes per block
             const float reach2 = (float)A.r_prune2 * 1.001f + 1e-12f;
             auto stays = [&](int t) -> bool {
                 if constexpr (MINIMG) return true;          // small boxes: tile coordinates are not block-local, nothing to prune by
@@ -1142,17 +1152,18 @@ k_forces(ForceArgs<T> A) {
                 if (packed3) { p[0] = l_p3[t]; p[1] = l_p3[SOA_STRIDE + t]; p[2] = l_p3[2 * SOA_STRIDE + t]; }
                 else { const T4 q = l_pos[t]; p[0] = (float)q.x; p[1] = (float)q.y; p[2] = (float)q.z; }
                 float best = 3.0e38f;
+#pragma unroll 1                                   // (unrolled, the sixteen box words are hoisted into 64 registers and the pruning variants spill)
                 for (int w = 0; w < NW; ++w) {
-                    float acc = 0.f;
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) { float e = l_box[w * 6 + d] - p[d]; const float f = p[d] - l_box[w * 6 + 3 + d]; e = e > f ? e : f; e = e > 0.f ? e : 0.f; acc += e * e; }
-                    best = acc < best ? acc : best;
+                    const float4 lo = reinterpret_cast<const float4*>(l_box)[2 * w], hi = reinterpret_cast<const float4*>(l_box)[2 * w + 1];
+                    float ex = fmaxf(fmaxf(lo.x - p[0], p[0] - hi.x), 0.f), ey = fmaxf(fmaxf(lo.y - p[1], p[1] - hi.y), 0.f), ez = fmaxf(fmaxf(lo.z - p[2], p[2] - hi.z), 0.f);
+                    best = fminf(best, ex * ex + ey * ey + ez * ez);
                 }
                 return best <= reach2;
             };
             const int per = (n_here + nthr - 1) / nthr, t0 = min(tid * per, n_here), t1 = min(t0 + per, n_here);
             int cnt = 0;
-            for (int t = t0; t < t1; ++t) cnt += stays(t) ? 1 : 0;
+            uint32_t keep_bits = 0;                    // the verdicts of this lane's first 32 atoms (every lane has fewer in practice), for the second walk below
+            for (int t = t0; t < t1; ++t) { const bool k = stays(t); cnt += k ? 1 : 0; if (t - t0 < 32) keep_bits |= (k ? 1u : 0u) << (t - t0); }
             l_scan[tid] = cnt;
             __syncthreads();
             if (tid < WAVE) {
@@ -1170,7 +1181,7 @@ k_forces(ForceArgs<T> A) {
             {
                 int run = n_new + l_scan[tid];
                 for (int t = t0; t < t1; ++t) {
-                    if (stays(t)) { l_new[t] = (uint16_t)run; A.tile_idx_dst[(int64_t)b * A.T_cap + run] = tix[seg_lo + t]; ++run; }
+                    if ((t - t0 < 32) ? ((keep_bits >> (t - t0)) & 1u) != 0u : stays(t)) { l_new[t] = (uint16_t)run; A.tile_idx_dst[(int64_t)b * A.T_cap + run] = tix[seg_lo + t]; ++run; }
                     else l_new[t] = (uint16_t)0xffffu;
                 }
             }
@@ -1211,7 +1222,6 @@ k_forces(ForceArgs<T> A) {
                     const lds_fptr pa = (lds_fptr)(lbase + oa), pb = (lds_fptr)(lbase + ob);
                     dx = (v2f){pa[0], pb[0]} - pix; dy = (v2f){pa[SOA_STRIDE], pb[SOA_STRIDE]} - piy; dz = (v2f){pa[2 * SOA_STRIDE], pb[2 * SOA_STRIDE]} - piz;
                 };
-                auto keep = [&](uint32_t off) { emit((uint32_t)l_new[off >> 2] << ESHIFT_SCALED); };
                 auto row = [&](const uint2 e4) {
                     const uint32_t oa = e4.x & 0xffffu, ob = e4.x >> 16, oc = e4.y & 0xffffu, od = e4.y >> 16;
                     v2f dx0, dy0, dz0, dx1, dy1, dz1;
@@ -1219,10 +1229,13 @@ k_forces(ForceArgs<T> A) {
                     const v2f r20 = __builtin_elementwise_fma(dz0, dz0, __builtin_elementwise_fma(dy0, dy0, dx0 * dx0));
                     const v2f r21 = __builtin_elementwise_fma(dz1, dz1, __builtin_elementwise_fma(dy1, dy1, dx1 * dx1));
                     if constexpr (PRUNE) {   // (no slot test: the sentinel slot — padding, and everything a lane without an atom holds — lies 10⁴ nm away)
-                        if (r20.x <= rp2) keep(oa);
-                        if (r20.y <= rp2) keep(ob);
-                        if (r21.x <= rp2) keep(oc);
-                        if (r21.y <= rp2) keep(od);
+                        // the four new slot numbers are fetched up front, with the coordinates: looked up inside the branches, each kept
+                        // entry waited for an LDS round trip of its own
+                        const uint32_t na = l_new[oa >> 2], nb = l_new[ob >> 2], nc = l_new[oc >> 2], nd = l_new[od >> 2];
+                        if (r20.x <= rp2) emit(na << ESHIFT_SCALED);
+                        if (r20.y <= rp2) emit(nb << ESHIFT_SCALED);
+                        if (r21.x <= rp2) emit(nc << ESHIFT_SCALED);
+                        if (r21.y <= rp2) emit(nd << ESHIFT_SCALED);
                     }
                     const float t0 = __builtin_amdgcn_rcpf(r20.x * r20.y), t1 = __builtin_amdgcn_rcpf(r21.x * r21.y);
                     const v2f u0 = (v2f){r20.y, r20.x} * t0, u1 = (v2f){r21.y, r21.x} * t1;       // 1/r² of each partner
@@ -1485,15 +1498,29 @@ __global__ void k_vv_mid(int64_t n, typename Vec<T>::T4* pos, typename Vec<T>::T
     float v2m = 0.f, dam = 0.f, dbm = 0.f;
     T vc[3] = {T(0), T(0), T(0)};
     const bool sub = cm_in != nullptr;
+    // A lane's first atom is requested BEFORE the centre-of-mass partials are re-summed (32 KB of L2 reads, two barriers): the
+    // streaming part of the launch then starts behind that latency instead of after it.
+    using T4q = typename Vec<T>::T4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, sn = s;
+    T4q vq = make4<T>(T(0), T(0), T(0), T(1)), fq = vq, pq = vq, gaq = vq, gbq = vq;
+    auto fetch = [&](int64_t a) {
+        vq = vel[a]; fq = frc[a];
+        if (!LAST || sub) pq = pos[a];
+        if (fa) gaq = fa[a];
+        if (fb) gbq = fb[a];
+    };
+    if (s < n) fetch(s);
     if (sub) block_vcm<T>(cm_in, n_cm_in, vc);
     const T sh[3] = {M<T>::mul(vc[0], dt), M<T>::mul(vc[1], dt), M<T>::mul(vc[2], dt)};
     double px = 0, py = 0, pz = 0, m = 0;
-    for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
-        auto v = vel[s]; auto f = frc[s];
-        typename Vec<T>::T4 p;
-        if (!LAST || sub) p = pos[s];
-        if (fa) { const auto g = fa[s]; f.x += g.x; f.y += g.y; f.z += g.z; }
-        if (fb) { const auto g = fb[s]; f.x += g.x; f.y += g.y; f.z += g.z; }
+    for (; s < n; s = sn) {
+        sn = s + stride;
+        const auto v0 = vq, f0 = fq, p0 = pq, ga0 = gaq, gb0 = gbq;
+        if (sn < n) fetch(sn);                                                 // the next atom's data travel while this one is integrated
+        auto v = v0; auto f = f0; auto p = p0;
+        if (fa) { f.x += ga0.x; f.y += ga0.y; f.z += ga0.z; }
+        if (fb) { f.x += gb0.x; f.y += gb0.y; f.z += gb0.z; }
         if (sub) {                                                             // remove_CM_motion! of the previous step, one launch late
             v.x -= vc[0]; v.y -= vc[1]; v.z -= vc[2];
             p.x = M<T>::sub(p.x, sh[0]); p.y = M<T>::sub(p.y, sh[1]); p.z = M<T>::sub(p.z, sh[2]);

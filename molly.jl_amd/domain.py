@@ -215,6 +215,32 @@ class HipDomainEngine:
         if rc != 0:
             self._chk(rc)
 
+    # -- the exchange inside the engine (include/mollyhip.h: mhip_halo_region … mhip_domain_run) ---------------------------------
+    def halo_region(self, rows_capacity, world, rank):
+        """allocate this rank's receive region; returns its IPC handle (bytes) for the peers"""
+        h = (C.c_ubyte * _lib.IPC_HANDLE_BYTES)()
+        self._chk(self.L.mhip_halo_region(self.ctx, rows_capacity, world, rank, C.cast(h, C.c_void_p)))
+        return bytes(h)
+
+    def halo_open_peer(self, rank, handle):
+        buf = (C.c_ubyte * _lib.IPC_HANDLE_BYTES).from_buffer_copy(handle)
+        self._chk(self.L.mhip_halo_open_peer(self.ctx, rank, C.cast(buf, C.c_void_p)))
+
+    def set_halo_routes(self, peer_rank, send_rows, dst_row, recv_rows):
+        n = len(peer_rank)
+        rt = _lib.HaloRoutes()
+        a = ((C.c_int32 * max(n, 1))(*peer_rank), (C.c_int64 * max(n, 1))(*send_rows), (C.c_int64 * max(n, 1))(*dst_row), (C.c_int64 * max(n, 1))(*recv_rows))
+        rt.n_peers, rt.peer_rank, rt.send_rows, rt.dst_row, rt.recv_rows = n, a[0], a[1], a[2], a[3]
+        self._chk(self.L.mhip_set_halo_routes(self.ctx, C.byref(rt)))
+
+    def domain_run(self, first_step, n_steps, dt, remove_cm_every, cm_parts, counters):
+        """(steps_done, reason): reason 1 = stopped behind the step after which the host has to re-plan"""
+        done, reason = C.c_int64(0), C.c_int32(0)
+        rc = self.L.mhip_domain_run(self.ctx, first_step, n_steps, dt, int(remove_cm_every), self._p(cm_parts), cm_parts.numel() // 4, C.byref(done), C.byref(reason), counters)
+        if rc != 0:
+            self._chk(rc)
+        return done.value, reason.value
+
     def plan_state(self, out3_f32):       # device float[3]: max displacement² since the plan / since the last prune, max speed²
         self._chk(self.L.mhip_plan_state_dev(self.ctx, self._p(out3_f32)))
 
@@ -282,6 +308,13 @@ class DomainRun:
         peers = {p for (p, _, _) in grid.dirs}
         self.fused = (_os.environ.get("MOLLYHIP_HALO_FUSED", "1") != "0" and hasattr(engine, "halo_mid") and len(peers) == grid.world - 1)
         self.cm_rows = (3 if tdtype == torch.float32 else 2) if self.fused else 0
+        # the whole step loop inside the engine, ghost rows stored straight into the peers' IPC-mapped regions (mhip_domain_run): the
+        # fused layout + an engine that has the entry points + every rank on a GPU of this node; MOLLYHIP_ENGINE_LOOP=0 keeps the
+        # host loop with torch.distributed collectives below (which is also what the CPU stand-in of the tests runs)
+        self.engine_loop = (self.fused and hasattr(engine, "domain_run") and _os.environ.get("MOLLYHIP_ENGINE_LOOP", "1") != "0"
+                            and _os.environ.get("MOLLYHIP_HOST_PRUNE", "0") == "0")
+        self._ipc_ready = False
+        self._counters = (C.c_int64 * 3)(0, 0, 0)
         self.stats = {"exchange_calls": 0, "ghost_atoms": 0, "migrated": 0, "plans": 0, "plan_checks": 0, "prunes": 0, "interior_passes": 0}
         self.overlap = _os.environ.get("MOLLYHIP_HALO_OVERLAP", "1") != "0" and hasattr(engine, "halo_interior")
         # gloo cannot move device memory: stage through the host (used by the multi-process tests that share ONE GPU;
@@ -311,6 +344,26 @@ class DomainRun:
             c = t.cpu(); dist.all_reduce(c, op=op, group=self.group); t.copy_(c)
         else:
             dist.all_reduce(t, op=op, group=self.group)
+
+    def _all_gather_cpu(self, t):
+        """all_gather of a small CPU tensor over whatever backend the group has"""
+        if dist.get_backend(self.group) == "nccl":
+            d = t.to(self.device); out = [torch.empty_like(d) for _ in range(self.world)]
+            dist.all_gather(out, d, group=self.group)
+            return [o.cpu() for o in out]
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t, group=self.group)
+        return out
+
+    def _a2a_cpu(self, t):
+        """all_to_all of one element per rank (CPU tensor in, CPU tensor out)"""
+        if dist.get_backend(self.group) == "nccl":
+            d = t.to(self.device); r = torch.empty_like(d)
+            dist.all_to_all_single(r, d, group=self.group)
+            return r.cpu()
+        r = torch.empty_like(t)
+        dist.all_to_all_single(r, t, group=self.group)
+        return r
 
     def _all_gather(self, t):
         if self.stage_host:
@@ -406,6 +459,33 @@ class DomainRun:
         self.f_recv = torch.zeros((self.f_recv_dst.numel(), 3), dtype=self.tdtype, device=dev)
         self._fsc3, self._frc3 = [c * 3 for c in sc], [c * 3 for c in rc]
         self.e.set_halo_plan(self.n_owned, self.f_recv, self.f_recv_dst, len(peers), cr, self.f_send_idx, self.f_send_shift, self.f_send, self.f_cm_pos)
+        if self.engine_loop:
+            self._engine_routes(peers, sc, rc)
+
+    def _engine_routes(self, peers, sc, rc):
+        """Once: every rank's receive region, its IPC handle to everybody.  Per plan: tell every peer where in MY region its segment
+        starts (one small all_to_all), hand the engine the routes."""
+        if self.world > 1 and not self._ipc_ready:
+            ok = 1
+            try:
+                cap = int(getattr(self.e, "capacity", 0)) + 8 * 64
+                mine = self.e.halo_region(cap, self.world, self.rank)
+            except Exception:                             # (no IPC for fine-grained memory on this stack: everybody falls back together)
+                ok, mine = 0, bytes(64)
+            allh = self._all_gather_cpu(torch.tensor(list(mine) + [ok], dtype=torch.uint8))
+            if not all(int(a[-1]) for a in allh):
+                self.engine_loop = False
+                return
+            for r, a in enumerate(allh):
+                if r != self.rank:
+                    self.e.halo_open_peer(r, bytes(a[:-1].tolist()))
+            self._ipc_ready = True
+        # my receive layout: peers in sorted order, rc[p] rows each → the offset of p's segment, told to p
+        off, r_off = torch.zeros(self.world, dtype=torch.int64), 0
+        for p in peers:
+            off[p] = r_off; r_off += rc[p]
+        theirs = self._a2a_cpu(off) if self.world > 1 else off
+        self.e.set_halo_routes(list(peers), [sc[p] for p in peers], [int(theirs[p]) for p in peers], [rc[p] for p in peers])
 
     def _a2a_rows(self, recv, send):
         w = recv.shape[1]
@@ -474,6 +554,21 @@ class DomainRun:
         return False
 
     def run(self, first_step, n_steps, dt, remove_cm_every=1):
+        if self.engine_loop and n_steps > 0:
+            # the steps, the ghost exchange and the prune decisions all happen inside the engine; the host comes back only when
+            # ownership has to be re-planned (≈ every 100 steps at 1M atoms) and at the end of the run
+            s, last = first_step, first_step + n_steps
+            while s < last:
+                done, reason = self.e.domain_run(s, last - s, dt, remove_cm_every, self.cm_buf, self._counters)
+                s += done
+                self.stats["exchange_calls"] += done
+                if bool(remove_cm_every) and s % remove_cm_every == 0:
+                    self._all_reduce(self.cm_buf)
+                    self.e.remove_cm(self.cm_buf)          # applied by the next first kick (or any read of the state)
+                if reason == 1:
+                    self.migrate(s)
+            self.stats["plan_checks"], self.stats["prunes"] = int(self._counters[0]), int(self._counters[1])
+            return
         if not self.fused:
             for s in range(first_step + 1, first_step + n_steps + 1):
                 self.step(s, dt, remove_cm_every)
