@@ -183,6 +183,25 @@ def charged_fluid(n_side, coul, seed=5, spacing=0.31, r_list=1.2, dtype=np.float
                 name=f"charged{n}", pme=pme)
 
 
+def pair_keys(i, j):
+    """sorted uint64 keys lo << 32 | hi of a pair list: set comparison of tens of millions of pairs in seconds"""
+    lo, hi = np.minimum(i, j).astype(np.uint64), np.maximum(i, j).astype(np.uint64)
+    k = (lo << np.uint64(32)) | hi
+    k.sort()
+    return k
+
+
+def export_keys(pkg, s):
+    """the engine's neighbour list (mhip_export_neighbors) as sorted pair keys, + the special flags' count"""
+    import ctypes as C
+    L = pkg.lib()
+    n = C.c_int64(0)
+    s._check(L.mhip_export_neighbors(s.engine(), None, None, None, 0, C.byref(n)))
+    i = np.empty(n.value, np.int32); j = np.empty(n.value, np.int32); sp = np.empty(n.value, np.uint8)
+    s._check(L.mhip_export_neighbors(s.engine(), s._ptr(i), s._ptr(j), s._ptr(sp), n.value, C.byref(n)))
+    return pair_keys(i, j), int(sp.sum())
+
+
 def sorted_pairs(i, j, sp):
     lo, hi = np.minimum(i, j).astype(np.int64), np.maximum(i, j).astype(np.int64)
     order = np.lexsort((hi, lo))

@@ -160,8 +160,11 @@ def test_full_size_1m_lj_against_oracle(pkg):
     assert np.abs(f.sum(axis=0)).max() < 1e-6 * o.pair_force_scale.sum()
     st = s.stats()
     o32 = case.oracle(np.float32)
-    assert st["n_pairs_full"] == 2 * len(o32.neighbors("cell", nthreads=16)[0])
+    oi, oj, _ = o32.neighbors("cell", nthreads=16)
+    assert st["n_pairs_full"] == 2 * len(oi)
     assert st["minimg_mode"] == 0 and st["block_atoms"] * st["j_split"] <= 1024
+    keys, n_special = S.export_keys(pkg, s)                      # 76 M pairs: the same SET as the fp32 reference search
+    assert n_special == 0 and np.array_equal(keys, S.pair_keys(oi, oj))
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

@@ -329,11 +329,29 @@ def test_full_size_256k_lj_against_oracle(pkg):
     assert np.abs(f.sum(axis=0)).max() < 1e-6 * o.pair_force_scale.sum()
     st = s.stats()
     o32 = case.oracle(np.float32)
-    n_half = len(o32.neighbors("cell", nthreads=8)[0])
-    assert st["n_pairs_full"] == 2 * n_half
+    oi, oj, _ = o32.neighbors("cell", nthreads=8)
+    assert st["n_pairs_full"] == 2 * len(oi)
     assert st["minimg_mode"] == 0
+    # the pair SET, not only its size: 20 M pairs bit-identical to the fp32 reference search
+    keys, n_special = S.export_keys(pkg, s)
+    assert n_special == 0 and np.array_equal(keys, S.pair_keys(oi, oj))
+    # the pass above walked the OUTER list and pruned it on the way (the PRUNE variant of the kernel); the next one walks the inner
+    # list with the packed loop: the same partners inside the cutoff in the same order, each rounded together with another list
+    # neighbour (two partners share one reciprocal) — same bar, and the two passes agree far inside it
+    f2 = pkg.forces(s).astype(np.float64)
+    assert s.stats()["n_filter_passes"] == st["n_filter_passes"]
+    err2 = np.linalg.norm(f2 - f_ref, axis=1)
+    assert np.all(err2 <= tol) and np.all(np.linalg.norm(f2 - f, axis=1) <= 0.25 * tol)
     e_ref = o.potential_energy(nl)
     assert pkg.potential_energy(s) == pytest.approx(e_ref, rel=2e-5)
+    # … and after dynamics: 40 steps (prunes of the inner list on the way), then forces through the lists in use against a fresh
+    # reference evaluation of the coordinates reached
+    pkg.simulate(s, pkg.VelocityVerlet(dt=0.002), 40)
+    assert s.stats()["n_filter_passes"] > st["n_filter_passes"]
+    tol3, o3, nl3 = S.fp32_force_tolerance(case, coords=s.coords.astype(np.float64))
+    f3 = pkg.forces(s, step_n=40).astype(np.float64)
+    err3 = np.linalg.norm(f3 - o3.forces(nl3, nthreads=8), axis=1)
+    assert np.all(err3 <= tol3), f"after a prune: worst err/tol {(err3 / tol3).max():.3f}"
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

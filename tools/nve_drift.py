@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import molly_loader  # noqa: E402
 
 m = molly_loader.load()
+UPKEEP = []
 
 
 def run(case, dtype, dt, n_steps, every, label):
@@ -20,6 +21,8 @@ def run(case, dtype, dt, n_steps, every, label):
     for k in range(n_steps // every):
         m.simulate(s, sim, every, init_step=k * every)
         es.append(m.total_energy(s))
+    st = s.stats()
+    UPKEEP.append({"outer_searches": st["n_outer_builds"], "prunes": st["n_filter_passes"], "steps": n_steps})
     es = np.array(es)
     t_ns = np.arange(len(es)) * every * dt * 1e-3
     slope = np.polyfit(t_ns, es, 1)[0]
@@ -41,4 +44,8 @@ if __name__ == "__main__":
         m.simulate(sy, m.VelocityVerlet(dt=0.002, remove_CM_motion=1), 2000)
         case.coords, case.velocities = np.array(sy.coords, dtype=np.float64), np.array(sy.velocities, dtype=np.float64)
         out.append(run(case, np.float32, 0.002, 10000, 500, "1M-atom LJ fluid, fp32, equilibrated 2000 steps first (bench.py's lj1m)"))
+        # the list upkeep the energy figure was obtained with — and a guard: a list that silently over-searches is a performance
+        # regression (one outer search per ≈ 100 steps, one prune per ≈ 25 at 85 K, dt 2 fs)
+        out[-1]["list_upkeep"] = UPKEEP[-1]
+        assert UPKEEP[-1]["outer_searches"] <= 10000 // 60 and UPKEEP[-1]["prunes"] <= 10000 // 15, UPKEEP[-1]
     print(json.dumps(out, indent=1))
