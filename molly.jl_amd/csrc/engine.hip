@@ -17,6 +17,7 @@
 #include "pme.h"
 #include "step_fused.h"
 #include "halo_xfer.h"
+#include "prune_lean.h"
 #include "hilbert.h"
 #include "kernels.h"
 #include "forces_launch.h"
@@ -808,7 +809,7 @@ template <class T> class Engine final : public EngineBase {
         A.pos = pos[cur].p; A.lj = lj[cur].p; A.tile_idx = tile_idx.p; A.tile_cnt = tile_cnt.p;
         // dual pair list: a force pass whose inner list is stale walks the OUTER list (always a valid superset — the cutoff is
         // applied per pair) and, if it is a plain force call, prunes it into the inner list on the way
-        if (dual && !inner_valid && !energy && prune_by_kernel) prune_with_filter();
+        if (dual && !inner_valid && !energy && (prune_by_kernel || prune_lean_ok())) prune_with_filter();
         const bool use_inner = dual && inner_valid;
         const bool prune = dual && !inner_valid && !energy;
         const size_t prune_extra = prune ? prune_lds_bytes(std::min(T_cap, max_tile + 1), BI * JS) + 16 : 0;   // a tile that fills the LDS is segmented a little earlier
@@ -836,8 +837,7 @@ template <class T> class Engine final : public EngineBase {
         }
         lds_force += (size_t)lds_pad_kb * 1024;   // occupancy experiments (MOLLYHIP_LDS_PAD_KB)
         if (prune) {
-            wave_rows_in.reserve((size_t)n_blocks * JS * (BI / WAVE)); nbr_in.reserve((size_t)n_blocks * JS * R_cap * BI); blk_disp2.reserve(n_blocks);
-            MHIP_HIP(hipMemsetAsync(blk_disp2.p, 0, (size_t)n_blocks * sizeof(float), stream));
+            wave_rows_in.reserve((size_t)n_blocks * JS * (BI / WAVE)); nbr_in.reserve((size_t)n_blocks * JS * R_cap * BI); blk_disp2.reserve((size_t)n_blocks * (BI / WAVE));
             A.nbr_dst = nbr_in.p; A.rows_dst = wave_rows_in.p; A.pos_snap = pos_snap.p; A.blk_disp2 = blk_disp2.p;
             pos_snap_in.reserve(cap);
             // the snapshot the next displacement checks compare with: the owned atoms' by the kernel itself, ghosts by a copy
@@ -859,13 +859,14 @@ template <class T> class Engine final : public EngineBase {
         MHIP_HIP(hipGetLastError());
         ++n_force_calls;
         if (prune) {   // validity of the pruned list: nobody moved more than half the margin since the outer search
-            MHIP_HIP(hipMemsetAsync(flags.p, 0, N_FLAGS * sizeof(int32_t), stream));
-            if (n_ghost > 0)   // the blocks record the displacement of the owned atoms; the ghosts' comes on top
+            // one single-block launch that leaves its figures in pinned host memory (no zeroing launch, no copy launch) …
+            hipLaunchKernelGGL(k_prune_summary, dim3(1), dim3(1024), 0, stream, n_blocks, n_blocks * JS * (BI / WAVE), n_blocks * (BI / WAVE), R_cap,
+                               (const int32_t*)tile_cnt_in.p, wave_rows_in.p, (const float*)blk_disp2.p, flags.p, h_flags);
+            if (n_ghost > 0) {   // … the blocks recorded the displacement of the owned atoms; the ghosts' comes on top
                 hipLaunchKernelGGL(k_max_disp<T>, dim3(std::min(cdiv(n_ghost, 256), 1024)), dim3(256), 0, stream, n_ghost, (const T4*)pos[cur].p + n_owned, (const T4*)pos_snap.p + n_owned,
                                    reinterpret_cast<unsigned int*>(flags.p + FLAG_MAX_DISP2), G);
-            hipLaunchKernelGGL(k_build_summary, dim3(std::min(64, cdiv(n_blocks * JS * (BI / WAVE), 256))), dim3(256), 0, stream, n_blocks, n_blocks * JS * (BI / WAVE), R_cap,
-                               (const int32_t*)tile_cnt_in.p, wave_rows_in.p, (const float*)blk_disp2.p, flags.p);
-            MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+                MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            }
             MHIP_HIP(hipStreamSynchronize(stream));
             float d2; std::memcpy(&d2, &h_flags[FLAG_MAX_DISP2], sizeof(float));
             total_rows = h_flags[FLAG_TOTAL_ROWS]; max_tile_in = h_flags[FLAG_MAX_TILE];
@@ -884,15 +885,48 @@ template <class T> class Engine final : public EngineBase {
     const bool inner_skin_fixed = env_int("MOLLYHIP_INNER_SKIN_FIXED", 0) != 0;
     const bool fuse_small = env_int("MOLLYHIP_FUSE_SMALL", 1) != 0;
     const bool no_soa = env_int("MOLLYHIP_NO_SOA", 0) != 0; const int lds_pad_kb = env_int("MOLLYHIP_LDS_PAD_KB", 0);
+    // the fp32 one-type fluids prune with a kernel of their own (prune_lean.h): 16-bit fixed-point tile, integer distance test, no forces
+    const bool prune_lean_on = env_int("MOLLYHIP_PRUNE_LEAN", 0) != 0;   // (measured equal to the fused pass at 1M atoms: its emission costs what the fused pass hides, DESIGN §4 — off unless asked for)
+    bool prune_lean_ok() const {
+        return prune_lean_on && std::is_same<T, float>::value && ljm == LJ_DIST_UNIFORM && coulm == MHIP_COUL_NONE && n_special == 0 && eshift == ESHIFT_SCALED && !minimg && !tri_mode
+               && prune_lean_lds_bytes(max_tile + 1, BI * JS) <= (size_t)MAX_LDS_BYTES;
+    }
+    void launch_prune_lean() {
+        if constexpr (std::is_same<T, float>::value) {
+            wave_rows_in.reserve((size_t)n_blocks * JS * (BI / WAVE)); nbr_in.reserve((size_t)n_blocks * JS * R_cap * BI); blk_disp2.reserve((size_t)n_blocks * (BI / WAVE));
+            tile_idx_in.reserve((size_t)n_blocks * T_cap); tile_cnt_in.reserve(n_blocks); pos_snap_in.reserve(cap);
+            ForceArgs<float> A;
+            std::memset(&A, 0, sizeof(A));
+            A.G = G; A.I = I; A.n_owned = n_owned; A.BI = BI; A.BI_shift = ilog2(BI); A.JS = JS; A.T_cap = T_cap; A.T_lds = max_tile + 1; A.R_cap = R_cap;
+            A.n_blocks = n_blocks; A.blocks_per_xcd = cdiv(n_blocks, 8);
+            A.pos = pos[cur].p; A.tile_idx = tile_idx.p; A.tile_cnt = tile_cnt.p; A.nbr = nbr.p; A.wave_rows = wave_rows.p; A.blk_center = blk_center.p;
+            A.nbr_dst = nbr_in.p; A.rows_dst = wave_rows_in.p; A.pos_snap = pos_snap.p; A.blk_disp2 = blk_disp2.p; A.r_prune2 = r_prune2;
+            A.tile_idx_dst = tile_idx_in.p; A.tile_cnt_dst = tile_cnt_in.p; A.snap_dst = pos_snap_in.p; A.eshift = eshift;
+            if (n_ghost > 0) MHIP_HIP(hipMemcpyAsync(pos_snap_in.p + n_owned, pos[cur].p + n_owned, (size_t)n_ghost * sizeof(T4), hipMemcpyDeviceToDevice, stream));
+            const size_t lds = prune_lean_lds_bytes(A.T_lds, BI * JS);
+            set_lds_limit(k_prune_lean, lds);
+            prof.begin(4, stream);
+            tr("k_prune_lean");
+            hipLaunchKernelGGL(k_prune_lean, dim3(A.blocks_per_xcd * 8), dim3(BI * JS), lds, stream, A);
+            hipLaunchKernelGGL(k_prune_summary, dim3(1), dim3(1024), 0, stream, n_blocks, n_blocks * JS * (BI / WAVE), n_blocks * (BI / WAVE), R_cap,
+                               (const int32_t*)tile_cnt_in.p, wave_rows_in.p, (const float*)blk_disp2.p, flags.p, h_flags);
+            prof.end(4, stream);
+            MHIP_HIP(hipGetLastError());
+        }
+    }
     void prune_with_filter() {
-        pos_snap_in.reserve(cap);
-        MHIP_HIP(hipMemcpyAsync(pos_snap_in.p, pos[cur].p, (size_t)n_tot * sizeof(T4), hipMemcpyDeviceToDevice, stream));
+        const bool lean = prune_lean_ok();
         last_prune_step = pass_step;
-        launch_filter(true);
+        if (lean) launch_prune_lean();
+        else {
+            pos_snap_in.reserve(cap);
+            MHIP_HIP(hipMemcpyAsync(pos_snap_in.p, pos[cur].p, (size_t)n_tot * sizeof(T4), hipMemcpyDeviceToDevice, stream));
+            launch_filter(true);
+        }
         if (n_ghost > 0)   // the blocks record the displacement of the owned atoms; the ghosts' comes on top
             hipLaunchKernelGGL(k_max_disp<T>, dim3(std::min(cdiv(n_ghost, 256), 1024)), dim3(256), 0, stream, n_ghost, (const T4*)pos[cur].p + n_owned, (const T4*)pos_snap.p + n_owned,
                                reinterpret_cast<unsigned int*>(flags.p + FLAG_MAX_DISP2), G);
-        MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        if (!lean || n_ghost > 0) MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         MHIP_HIP(hipStreamSynchronize(stream));
         float d2; std::memcpy(&d2, &h_flags[FLAG_MAX_DISP2], sizeof(float));
         total_rows = h_flags[FLAG_TOTAL_ROWS]; max_tile_in = h_flags[FLAG_MAX_TILE];
@@ -1787,8 +1821,7 @@ template <class T> class Engine final : public EngineBase {
             if (measure) {   // the check of step + 1: reduce, copy, event — read by resolve_track at step + 2
                 if (!h_trk) MHIP_HIP(hipHostMalloc((void**)&h_trk, 4 * sizeof(float)));
                 if (!ev_trk) MHIP_HIP(hipEventCreateWithFlags(&ev_trk, hipEventDisableTiming));
-                hipLaunchKernelGGL(k_track_reduce, dim3(1), dim3(256), 0, stream, nb, (const float*)trk_part.p, trk_out.p);
-                MHIP_HIP(hipMemcpyAsync(h_trk, trk_out.p, 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
+                hipLaunchKernelGGL(k_track_reduce, dim3(1), dim3(256), 0, stream, nb, (const float*)trk_part.p, trk_out.p, h_trk);   // (straight into pinned host memory)
                 MHIP_HIP(hipEventRecord(ev_trk, stream));
                 trk_issued = true; trk_step = step + 1; trk_prev_vmax = last_vmax; trk_prune_id = n_filters; trk_outer_id = n_outer;
             }

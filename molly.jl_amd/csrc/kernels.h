@@ -720,13 +720,37 @@ __global__ void k_uniform_check(int64_t n, const T* __restrict__ sig, const T* _
 
 // reduce the per-block / per-wave results of k_build or k_filter into the flag words the host reads (flags zeroed before)
 // out[c] = max of part[c·n .. (c + 1)·n), c = 0, 1, 2 — one block, plain stores (the three maxima of a validity check, k_vv_mid)
-[[maybe_unused]] static __global__ void k_track_reduce(int n, const float* __restrict__ part, float* out) {
+// (host: pinned host memory, nullable — the host reads it behind an event, no copy kernel in between)
+[[maybe_unused]] static __global__ void k_track_reduce(int n, const float* __restrict__ part, float* out, float* host = nullptr) {
     float m[3] = {0.f, 0.f, 0.f};
     for (int q = threadIdx.x; q < n; q += blockDim.x) { m[0] = fmaxf(m[0], part[q]); m[1] = fmaxf(m[1], part[n + q]); m[2] = fmaxf(m[2], part[2 * n + q]); }
     __shared__ float sh[3][16];
     for (int c = 0; c < 3; ++c) { m[c] = wave_max(m[c]); if ((threadIdx.x & 63) == 0) sh[c][threadIdx.x >> 6] = m[c]; }
     __syncthreads();
-    if (threadIdx.x < 3) { float r = 0.f; for (int q = 0; q < (int)(blockDim.x >> 6); ++q) r = fmaxf(r, sh[threadIdx.x][q]); out[threadIdx.x] = r; }
+    if (threadIdx.x < 3) { float r = 0.f; for (int q = 0; q < (int)(blockDim.x >> 6); ++q) r = fmaxf(r, sh[threadIdx.x][q]); out[threadIdx.x] = r; if (host) host[threadIdx.x] = r; }
+}
+
+// The figures the host needs after a PRUNE pass — largest compacted tile, longest wave, rows in total, largest displacement since
+// the outer search — by ONE block with plain stores, into the flag words AND into pinned host memory: no zeroing launch before it
+// (k_build_summary accumulates with atomics), no copy launch behind it.  A wave whose rows overflowed R_cap is zeroed as there.
+[[maybe_unused]] static __global__ void __launch_bounds__(1024) k_prune_summary(int n_blocks, int n_waves, int n_disp, int R_cap, const int32_t* __restrict__ tile_cnt, int32_t* wave_rows,
+                                                                                const float* __restrict__ blk_disp2, int32_t* flags, int32_t* host_flags) {
+    __shared__ int sh_t[16], sh_r[16], sh_s[16]; __shared__ float sh_d[16];
+    int mt = 0, mr = 0, tot = 0; float md = 0.f;
+    for (int q = threadIdx.x; q < n_blocks; q += blockDim.x) mt = max(mt, tile_cnt[q]);
+    for (int q = threadIdx.x; q < n_disp; q += blockDim.x) md = fmaxf(md, blk_disp2[q]);
+    for (int q = threadIdx.x; q < n_waves; q += blockDim.x) { const int r = wave_rows[q]; mr = max(mr, r); if (r > R_cap) wave_rows[q] = 0; else tot += r; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mt = max(mt, __shfl_xor(mt, o, 64)); mr = max(mr, __shfl_xor(mr, o, 64)); tot += __shfl_xor(tot, o, 64); md = fmaxf(md, __shfl_xor(md, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { sh_t[threadIdx.x >> 6] = mt; sh_r[threadIdx.x >> 6] = mr; sh_s[threadIdx.x >> 6] = tot; sh_d[threadIdx.x >> 6] = md; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 1; q < (int)(blockDim.x >> 6); ++q) { mt = max(mt, sh_t[q]); mr = max(mr, sh_r[q]); tot += sh_s[q]; md = fmaxf(md, sh_d[q]); }
+        int32_t out[N_FLAGS];
+        for (int q = 0; q < N_FLAGS; ++q) out[q] = 0;
+        out[FLAG_MAX_TILE] = mt; out[FLAG_MAX_ROWS] = mr; out[FLAG_TOTAL_ROWS] = tot; out[FLAG_MAX_DISP2] = (int32_t)__float_as_uint(md);
+        for (int q = 0; q < N_FLAGS; ++q) { flags[q] = out[q]; host_flags[q] = out[q]; }
+    }
 }
 
 [[maybe_unused]] static __global__ void k_build_summary(int n_blocks, int n_waves, int R_cap, const int32_t* __restrict__ tile_cnt, int32_t* wave_rows,
@@ -992,6 +1016,9 @@ __host__ __device__ inline size_t prune_lds_bytes(int t_seg, int nthr) { return 
 #ifndef MHIP_HOIST
 #define MHIP_HOIST 0    // request the first rows before the tile is staged (1: 12 bytes of scratch, measured +4 %)
 #endif
+#ifndef MHIP_PEXP
+#define MHIP_PEXP 0     // timing experiments of the pruning pass
+#endif
 #ifndef MHIP_EXP
 #define MHIP_EXP 0      // timing experiments of the packed loop (tools/force_ab.py); 0 = the product
 #endif
@@ -1232,10 +1259,12 @@ k_forces(ForceArgs<T> A) {
                         // the four new slot numbers are fetched up front, with the coordinates: looked up inside the branches, each kept
                         // entry waited for an LDS round trip of its own
                         const uint32_t na = l_new[oa >> 2], nb = l_new[ob >> 2], nc = l_new[oc >> 2], nd = l_new[od >> 2];
+                        if constexpr (MHIP_PEXP != 1) {    // (MHIP_PEXP: timing experiments of the pruning pass, 1 = no emission, 2 = no LJ arithmetic)
                         if (r20.x <= rp2) emit(na << ESHIFT_SCALED);
                         if (r20.y <= rp2) emit(nb << ESHIFT_SCALED);
                         if (r21.x <= rp2) emit(nc << ESHIFT_SCALED);
                         if (r21.y <= rp2) emit(nd << ESHIFT_SCALED);
+                        }
                     }
                     const float t0 = __builtin_amdgcn_rcpf(r20.x * r20.y), t1 = __builtin_amdgcn_rcpf(r21.x * r21.y);
                     const v2f u0 = (v2f){r20.y, r20.x} * t0, u1 = (v2f){r21.y, r21.x} * t1;       // 1/r² of each partner
@@ -1248,7 +1277,7 @@ k_forces(ForceArgs<T> A) {
                     const v2f g0 = __builtin_elementwise_fma(c0, c48v, -c24v), g1 = __builtin_elementwise_fma(c1, c48v, -c24v);
                     const v2f h0 = c0 * w0, h1 = c1 * w1;
                     v2f f0 = g0 * h0, f1 = g1 * h1;                                              // (48ϵσ¹²/r⁶ − 24ϵσ⁶)/r⁸ inside the cutoff, else 0
-                    if constexpr (EXPV == 4) { f0 = in0; f1 = in1; }                             // timing experiment: no LJ arithmetic
+                    if constexpr (EXPV == 4 || (PRUNE && MHIP_PEXP == 2)) { f0 = in0; f1 = in1; }   // timing experiment: no LJ arithmetic
                     fx2 -= dx0 * f0; fy2 -= dy0 * f0; fz2 -= dz0 * f0;
                     fx2 -= dx1 * f1; fy2 -= dy1 * f1; fz2 -= dz1 * f1;
                 };
@@ -1331,7 +1360,7 @@ k_forces(ForceArgs<T> A) {
             d2 = (float)(ex * ex + ey * ey + ez * ez);
         }
         d2 = wave_max(d2);
-        if (js == 0 && (tid & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(A.blk_disp2 + b), __float_as_uint(d2));   // <= 4 waves per block
+        if (js == 0 && (tid & 63) == 0) A.blk_disp2[b * (A.BI >> 6) + (li >> 6)] = d2;   // one word per wave of i-atoms: plain stores, nothing to zero beforehand
     }
     if (A.JS > 1) {   // deterministic reduction of the j-split partial sums through LDS
         __syncthreads();
