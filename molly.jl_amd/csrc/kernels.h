@@ -198,7 +198,7 @@ __global__ void k_export_forces(int64_t n_owned, const int32_t* __restrict__ ori
 // not of the history of earlier re-sorts.
 template <class T>
 __global__ void k_cell_keys(int64_t n_tot, int64_t n_owned, const typename Vec<T>::T4* __restrict__ pos, const int32_t* __restrict__ inv,
-                            const uint32_t* __restrict__ cell_rank, uint32_t* key, int32_t* idx, int32_t* cell_cnt, GridP<T> G) {
+                            const uint32_t* __restrict__ cell_rank, uint32_t* key, int32_t* idx, int32_t* cell_cnt, GridP<T> G, int sub_bits) {
     int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (o >= n_tot) return;
     int s = inv[o];
@@ -206,7 +206,19 @@ __global__ void k_cell_keys(int64_t n_tot, int64_t n_owned, const typename Vec<T
     int cc[3]; cell_coords(p.x, p.y, p.z, G, cc);
     uint32_t k = cell_rank[(cc[2] * G.nc[1] + cc[1]) * G.nc[0] + cc[0]];
     if (o >= n_owned) k += (uint32_t)G.ncell;
-    key[o] = k; idx[o] = s;
+    // sub_bits (0 | 6): inside a cell the atoms are ordered along a 4×4×4 Morton curve instead of by caller index, so that neighbouring
+    // lanes — and neighbouring tile slots — are neighbours in space (fewer distinct LDS banks per gather of the pair kernel)
+    uint32_t sub = 0;
+    if (sub_bits && !G.tri_grid) {
+        const T xyz[3] = {p.x, p.y, p.z};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const T rel = (G.periodic[d] ? xyz[d] : xyz[d] - G.origin[d]) * G.inv_cs[d] - T(cc[d]);
+            const int q = min(max((int)(rel * T(4)), 0), 3);
+            sub |= (uint32_t)(q & 1) << d | (uint32_t)(q >> 1) << (3 + d);
+        }
+    }
+    key[o] = (k << sub_bits) | sub; idx[o] = s;
     atomicAdd(&cell_cnt[k], 1);
 }
 
@@ -251,6 +263,7 @@ template <class T> struct BuildArgs {
     int approx;                      // outer list of the dual scheme: any superset of r_list will do, skip the exact band test
     int walk;                        // search by walking every i-atom's cell stencil over the tile (1) or transposed, tile groups against the wave's i-atoms (0)
     int eshift;                      // entry format of the emitted rows (0 | ESHIFT_SCALED)
+    uint16_t* cnt_out;               // [n_blocks][JS][BI] entries emitted per (j-split, atom), nullable (first lane order of the inner list)
 };
 
 // exclusive prefix sum of a[0..n) in LDS, in place; a[n] receives the total.  `part` holds blockDim ints.
@@ -695,6 +708,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
     }
     if (A.debug == 4) return;
     // 4. pad every lane to the wave's row count with the sentinel slot (a far-away dummy atom)
+    if (A.cnt_out) A.cnt_out[((int64_t)b * A.JS + js) * A.BI + li] = (uint16_t)min(cnt, 65535);
     int rows_mine = (cnt + 3) >> 2;
     int rows_wave = wave_max(rows_mine);
     if (rows_wave > A.R_cap) { if (lane == 0) atomicOr(&A.flags[FLAG_OVERFLOW], OVF_ROWS); }
@@ -993,6 +1007,14 @@ template <class T> struct ForceArgs {
     int any_special;                 // 0: no special (1-4) pair exists, the per-entry weight select is compiled out (uniform-LJ fluids)
     int soa;                         // != 0: the packed fp32 one-type loop with the tile as x[] / y[] / z[] arrays `soa` dwords apart
     int eshift;                      // entry format of the rows read and written (0 | ESHIFT_SCALED)
+    // Lanes sorted by row count.  A wave walks as many rows as its longest lane: 17 % of the slots of the 1M-atom inner list are
+    // padding, most of it because the split of an atom's neighbours over the j-split waves (tile slot mod JS) is uneven.  A PRUNE pass
+    // therefore emits, per j-split group, the rows of the block's atoms ordered by the number of entries they had at the prune before
+    // (cnt_src; right after a search: the length of their outer rows) — lane position perm⁻¹(atom) — and leaves the permutation in
+    // perm_dst; the passes over that list take it as lane_atom: lane L of group js works for atom lane_atom[js][L].  Each atom's own
+    // entries keep their order and the group sums are added per atom, so its force is the same sum as before.
+    const uint16_t* lane_atom;       // [n_blocks][JS][BI] (nullptr: lane = atom)
+    const uint16_t* cnt_src; uint16_t* cnt_dst; uint16_t* perm_dst;   // PRUNE: [n_blocks][JS][BI] entries kept per (j-split, atom); the permutation written
     // ghosted sub-domains: a pass over only the blocks whose tile holds no ghost atom (part 1: they can run while the ghost coordinates
     // are still on the wire) or only the others (part 2); 0 = every block
     const int32_t* blk_ghost; int part;
@@ -1000,8 +1022,9 @@ template <class T> struct ForceArgs {
 // strides the packed loop is compiled for (odd numbers of dwords): tiles of up to stride − 1 atoms, 12·stride bytes of LDS.  The
 // smallest that holds the tile is used: 36 KiB leaves room for four 512-lane blocks per CU, 48 KiB for three (measured: −12 % per pass).
 constexpr int SOA_STRIDES[3] = {2049, 3073, 4097};
-// dynamic LDS a PRUNE pass needs behind its tile: the renumbering table (2 bytes per tile atom of a segment), scan scratch, eight boxes
-__host__ __device__ inline size_t prune_lds_bytes(int t_seg, int nthr) { return (size_t)(((t_seg + 8) & ~7) * 2) + ((size_t)nthr + 4) * 4 + 8 * 8 * 4 + 32; }
+// dynamic LDS a PRUNE pass needs behind its tile: the renumbering table (2 bytes per tile atom of a segment), scan scratch, eight boxes,
+// the atoms' row counts (lane order) and the destination waves' row counts
+__host__ __device__ inline size_t prune_lds_bytes(int t_seg, int nthr) { return (size_t)(((t_seg + 8) & ~7) * 2) + ((size_t)nthr + 4) * 4 + 8 * 8 * 4 + ((size_t)nthr + 64) * 4 + 32; }
 
 // (the plain fp32 one-type passes run four 512-lane blocks per CU = eight waves per SIMD, which takes <= 64 VGPRs: held by attribute)
 #ifndef MHIP_FAST_MIN_WAVES
@@ -1058,7 +1081,9 @@ k_forces(ForceArgs<T> A) {
     constexpr bool NO_TRI = std::is_same<T, float>::value && LJM == LJ_DIST_UNIFORM && COULM == MHIP_COUL_NONE && !ENERGY;
     const bool tri_local = !MINIMG && !NO_TRI && G.tri_grid;
     const int li = tid & (A.BI - 1), js = tid >> A.BI_shift;
-    const int64_t si = (int64_t)b * A.BI + li;
+    int ai = li;                                         // the atom of the block this lane works for
+    if constexpr (!PRUNE) { if (A.lane_atom) ai = (int)A.lane_atom[((int64_t)b * A.JS + js) * A.BI + li]; }
+    const int64_t si = (int64_t)b * A.BI + ai;
     const bool valid = si < A.n_owned;
     const T4 pi_raw = A.pos[valid ? si : (int64_t)b * A.BI];
     T4 pi = pi_raw;
@@ -1082,11 +1107,26 @@ k_forces(ForceArgs<T> A) {
     // i-atoms is within the radius of none of them — so that the rows are emitted once, already renumbered (the marks taken during
     // the walk, as before, meant writing the rows, reading them back and writing them again: 1.9× the traffic of the pass)
     [[maybe_unused]] uint16_t* l_new = nullptr; [[maybe_unused]] int32_t* l_scan = nullptr; [[maybe_unused]] float* l_box = nullptr;
+    [[maybe_unused]] int32_t* l_cnt = nullptr; [[maybe_unused]] int32_t* l_wmax = nullptr;
     [[maybe_unused]] int n_new = 0;          // compacted tile atoms so far (block-uniform)
+    [[maybe_unused]] int pos_l = li;         // PRUNE: the lane position this atom's rows are emitted at
     if constexpr (PRUNE) {
         l_new = reinterpret_cast<uint16_t*>(smem + A.mark_off);
         l_scan = reinterpret_cast<int32_t*>(smem + A.mark_off + ((A.T_lds + 8) & ~7) * 2);
         l_box = reinterpret_cast<float*>(l_scan + nthr + 4);
+        l_wmax = reinterpret_cast<int32_t*>(l_box + 64); l_cnt = l_wmax + 64;
+        if (tid < 64) l_wmax[tid] = 0;
+        if (A.cnt_src) {     // rank of my atom among its j-split group's atoms by (entries last time, index): its lane position in the rows emitted now
+            l_cnt[tid] = ((int)A.cnt_src[((int64_t)b * A.JS + js) * A.BI + li] << 9) | li;
+            __syncthreads();
+            const int mine = l_cnt[tid];
+            const int32_t* grp = l_cnt + js * A.BI;
+            int rank = 0;
+            for (int q = 0; q < A.BI; q += 4) { const int4 v = *reinterpret_cast<const int4*>(grp + q); rank += (v.x < mine) + (v.y < mine) + (v.z < mine) + (v.w < mine); }
+            pos_l = rank;
+            A.perm_dst[((int64_t)b * A.JS + js) * A.BI + pos_l] = (uint16_t)li;
+            out_rows = A.nbr_dst + (((int64_t)b * A.JS + js) * A.R_cap) * A.BI + pos_l;
+        }
         // bounding boxes of the i-atoms, eight per block (runs of BI/8 consecutive atoms: compact along the Hilbert curve), in the frame
         // of the staged tile (block-local coordinates).  One box per wave let half of a 64-atom water block's outer tile through.
         const int lpb = A.BI >> 3;
@@ -1347,10 +1387,14 @@ k_forces(ForceArgs<T> A) {
     if constexpr (PRUNE) {
         // finish the inner list: pad to the wave's row count; record how far the block's atoms moved since the outer build
         const uint32_t SENTP = make_entry((uint32_t)n_new, 0u, esh);
-        int rows_mine = (kept + 3) >> 2;
-        int rows_wave = wave_max(rows_mine);
+        if (A.cnt_dst) A.cnt_dst[((int64_t)b * A.JS + js) * A.BI + li] = (uint16_t)min(kept, 65535);
+        // every lane pads to the row count of the wave its rows go to (its own wave unless the lanes are being sorted)
+        const int NWB = A.BI >> 6;
+        atomicMax(&l_wmax[js * NWB + (pos_l >> 6)], (kept + 3) >> 2);
+        __syncthreads();
+        const int rows_wave = l_wmax[js * NWB + (pos_l >> 6)];
         while (((kept + 3) >> 2) < rows_wave || (kept & 3)) emit(SENTP);
-        if ((tid & 63) == 0) A.rows_dst[(b * A.JS + js) * (A.BI >> 6) + (li >> 6)] = rows_wave;
+        if (tid < A.JS * NWB) A.rows_dst[b * A.JS * NWB + tid] = l_wmax[tid];
         if (tid == 0) A.tile_cnt_dst[b] = n_new;
         float d2 = 0.f;
         if (valid && js == 0) {
@@ -1364,14 +1408,14 @@ k_forces(ForceArgs<T> A) {
     }
     if (A.JS > 1) {   // deterministic reduction of the j-split partial sums through LDS
         __syncthreads();
-        T* red = reinterpret_cast<T*>(smem);
-        red[(js * 4 + 0) * A.BI + li] = fx; red[(js * 4 + 1) * A.BI + li] = fy;
-        red[(js * 4 + 2) * A.BI + li] = fz; red[(js * 4 + 3) * A.BI + li] = pe;
+        T* red = reinterpret_cast<T*>(smem);     // (indexed by ATOM: the groups' lane orders may differ)
+        red[(js * 4 + 0) * A.BI + ai] = fx; red[(js * 4 + 1) * A.BI + ai] = fy;
+        red[(js * 4 + 2) * A.BI + ai] = fz; red[(js * 4 + 3) * A.BI + ai] = pe;
         __syncthreads();
         if (js == 0) {
             for (int q = 1; q < A.JS; ++q) {
-                fx += red[(q * 4 + 0) * A.BI + li]; fy += red[(q * 4 + 1) * A.BI + li];
-                fz += red[(q * 4 + 2) * A.BI + li]; pe += red[(q * 4 + 3) * A.BI + li];
+                fx += red[(q * 4 + 0) * A.BI + ai]; fy += red[(q * 4 + 1) * A.BI + ai];
+                fz += red[(q * 4 + 2) * A.BI + ai]; pe += red[(q * 4 + 3) * A.BI + ai];
             }
         }
     }
@@ -1383,9 +1427,9 @@ k_forces(ForceArgs<T> A) {
             for (int half = 0; half < 2; ++half) {
                 __syncthreads();
 #pragma unroll
-                for (int c = 0; c < 3; ++c) red[(js * 4 + c) * A.BI + li] = vir[3 * half + c];
+                for (int c = 0; c < 3; ++c) red[(js * 4 + c) * A.BI + ai] = vir[3 * half + c];
                 __syncthreads();
-                if (js == 0) for (int q = 1; q < A.JS; ++q) for (int c = 0; c < 3; ++c) vir[3 * half + c] += red[(q * 4 + c) * A.BI + li];
+                if (js == 0) for (int q = 1; q < A.JS; ++q) for (int c = 0; c < 3; ++c) vir[3 * half + c] += red[(q * 4 + c) * A.BI + ai];
             }
         }
         // block sums of the energy and the six virial components, each halved (every pair is visited from both ends);
@@ -1393,7 +1437,7 @@ k_forces(ForceArgs<T> A) {
         __syncthreads();
         double* dred = reinterpret_cast<double*>(smem);
         for (int c = 0; c < 7; ++c) {
-            if (js == 0) dred[li] = valid ? 0.5 * (double)(c == 0 ? pe : vir[c - 1]) : 0.0;
+            if (js == 0) dred[ai] = valid ? 0.5 * (double)(c == 0 ? pe : vir[c - 1]) : 0.0;
             __syncthreads();
             if (tid == 0) { double s = 0; for (int q = 0; q < A.BI; ++q) s += dred[q]; A.pe_part[(int64_t)c * A.n_blocks + b] = s; }
             __syncthreads();

@@ -153,7 +153,32 @@ def test_triclinic_cell_grid_trajectory(pkg):
     d = np.linalg.solve(basis.T, (s.coords - o.coords).T).T
     d -= np.round(d)
     assert np.abs(d @ basis).max() < 1e-9 and np.abs(s.velocities - o.vel).max() < 1e-8
-    assert s.stats()["minimg_mode"] == 0
+    st = s.stats()
+    assert st["minimg_mode"] == 0
+    # the dual pair list works in the sheared cell too: searches with r_list + margin when the displacement bounds (nearest image) ask
+    # for them — the lattice is melting: three in these 60 steps —, the inner list pruned from the outer one in between; the fixed
+    # cadence of the one-cell form searches at the start and at each of the six rebuild steps
+    assert st["n_outer_builds"] <= 4 and st["n_filter_passes"] >= 1, st
+    # … and what the engine hands out after those 60 steps is still exactly the reference's list of the coordinates reached
+    got = pkg.find_neighbors(s)
+    ref = case.oracle(np.float64, coords=s.coords).neighbors("brute", nthreads=8)
+    assert got.n == len(ref[0])
+    assert all(np.array_equal(u, v) for u, v in zip(S.sorted_pairs(got.i, got.j, got.special), S.sorted_pairs(*ref)))
+
+
+def test_triclinic_fp32_fluid_trajectory_with_pruned_lists(pkg):
+    """the same fluid in fp32, 120 steps: prunes of the inner list on the way, trajectory within the fp32 bar of the reference's own
+    test (mean deviation below 5e-4 nm after 100 steps, test/simulation.jl:625)"""
+    basis, case = sheared_fluid(np.float32, n_side=20)
+    o = case.oracle(np.float64)
+    o.vv_run(120, 0.002, remove_cm_every=1, nthreads=8)
+    s = case.system(pkg, np.float32)
+    pkg.simulate(s, pkg.VelocityVerlet(dt=0.002), 120)
+    d = np.linalg.solve(basis.T, (s.coords.astype(np.float64) - o.coords).T).T
+    d -= np.round(d)
+    assert np.linalg.norm(d @ basis, axis=1).mean() < 5e-4
+    st = s.stats()
+    assert st["n_outer_builds"] <= 7 and st["n_filter_passes"] >= 2, st      # (13 searches at the fixed cadence)
 
 
 def test_triclinic_bonded_terms(pkg):
