@@ -16,7 +16,6 @@
 #include "stochastic.h"
 #include "pme.h"
 #include "step_fused.h"
-#include "halo_xfer.h"
 #include "prune_lean.h"
 #include "hilbert.h"
 #include "kernels.h"
@@ -1553,8 +1552,14 @@ template <class T> class Engine final : public EngineBase {
     void halo_pack(bool with_cm) {
         if (hp.n_send_rows <= 0 && !with_cm) return;
         tr("k_halo_pack");
+        XferSend X{};        // inside mhip_domain_run with peers: the rows go straight into the peers' regions, exchange number ++seq
+        if (xf_direct && xf.n_peers > 0) {
+            ++xf.seq;
+            X.row_peer = xf.row_peer.p; X.row_dst = xf.row_dst.p; X.P = xf.peers; X.rows_cap = xf.rows_cap; X.parity = (int)(xf.seq & 1u); X.seq = xf.seq; X.my_rank = xf.rank;
+            X.peers = xf.d_peers.p; X.n_peers = xf.n_peers; X.done = xf.done.p;
+        }
         hipLaunchKernelGGL(k_halo_pack<T>, dim3(cdiv(std::max<int64_t>(hp.n_send_rows, 1), 256) + 1), dim3(256), 0, stream, hp.n_send_rows, hp.send_idx, (const T*)hp.send_shift, (const int32_t*)inv.p,
-                           (const T4*)pos[cur].p, (T*)hp.send, with_cm ? (const double*)cm_step.p : (const double*)nullptr, n_cm_step, hp.send_cm_pos, hp.n_send_cm, std::max(hp.cm_rows, 1), cm_all.p);
+                           (const T4*)pos[cur].p, (T*)hp.send, with_cm ? (const double*)cm_step.p : (const double*)nullptr, n_cm_step, hp.send_cm_pos, hp.n_send_cm, std::max(hp.cm_rows, 1), cm_all.p, X);
         MHIP_HIP(hipGetLastError());
     }
     // first kick + drift + pack: after vv_init, after a step that stopped behind its second kick, after a re-plan
@@ -1574,8 +1579,10 @@ template <class T> class Engine final : public EngineBase {
         if (hp.n_recv_rows > 0) {
             if (hp.first_ghost < 0 || hp.first_ghost > n_tot) throw ApiError{MHIP_ERR_INVALID, "halo plan: ghost range out of bounds"};
             tr("k_halo_unpack");
-            hipLaunchKernelGGL(k_halo_unpack<T>, dim3(cdiv(hp.n_recv_rows, 256)), dim3(256), 0, stream, hp.n_recv_rows, xf_unpack_src ? (const T*)xf_unpack_src : (const T*)hp.recv, hp.recv_dst, hp.first_ghost, (const int32_t*)inv.p,
-                               pos[cur].p, cm_all.p, std::max(hp.cm_rows, 1));
+            XferWait W{};    // inside mhip_domain_run with peers: wait for exchange xf.seq, read my region's half
+            if (xf_direct && xf.n_peers > 0) { W.mine = reinterpret_cast<const XferHeader*>(xf.region); W.parity = (int)(xf.seq & 1u); W.seq = xf.seq; W.peers = xf.d_peers.p; W.n_peers = xf.n_peers; W.err = xf.err.p; }
+            hipLaunchKernelGGL(k_halo_unpack<T>, dim3(cdiv(hp.n_recv_rows, 256)), dim3(256), 0, stream, hp.n_recv_rows, W.n_peers > 0 ? (const T*)xf_rows(W.parity) : (const T*)hp.recv, hp.recv_dst, hp.first_ghost, (const int32_t*)inv.p,
+                               pos[cur].p, cm_all.p, std::max(hp.cm_rows, 1), W);
         }
         cur_dt = dt;
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
@@ -1617,7 +1624,7 @@ template <class T> class Engine final : public EngineBase {
         float* h_red3 = nullptr; int32_t* h_err = nullptr; hipEvent_t ev_plan = nullptr;
         bool plan_pending = false; int64_t plan_step = -1, next_check = -1;
     } xf;
-    const void* xf_unpack_src = nullptr;
+    bool xf_direct = false;      // inside mhip_domain_run: k_halo_pack stores into the peers' regions, k_halo_unpack waits for theirs
     T* xf_rows(int parity) const { return reinterpret_cast<T*>(xf.region + XFER_ROWS_OFF) + (size_t)parity * xf.rows_cap * 3; }
     void xf_release() {
         for (int r = 0; r < XFER_MAX_RANKS; ++r) if (xf.opened[r] && xf.peers.region[r]) { (void)hipIpcCloseMemHandle(xf.peers.region[r]); xf.opened[r] = false; }
@@ -1687,20 +1694,6 @@ template <class T> class Engine final : public EngineBase {
         if (rt->n_peers) MHIP_HIP(hipMemcpy(xf.d_peers.p, rt->peer_rank, rt->n_peers * sizeof(int32_t), hipMemcpyHostToDevice));
         xf.routes = true; xf.plan_pending = false; xf.next_check = -1;
     }
-    void xf_push() {        // the packed rows of this step → the peers' regions, exchange number ++seq
-        if (xf.n_peers == 0) return;
-        ++xf.seq;
-        tr("k_halo_push");
-        hipLaunchKernelGGL(k_halo_push<T>, dim3(cdiv(std::max<int64_t>(hp.n_send_rows, 1), 256)), dim3(256), 0, stream, hp.n_send_rows, (const T*)hp.send, (const int32_t*)xf.row_peer.p, (const int32_t*)xf.row_dst.p,
-                           xf.peers, xf.rows_cap, (int)(xf.seq & 1u), xf.seq, xf.rank, (const int32_t*)xf.d_peers.p, xf.n_peers, xf.done.p);
-        MHIP_HIP(hipGetLastError());
-    }
-    void xf_wait() {        // the peers' rows of exchange seq are in my half seq & 1
-        if (xf.n_peers == 0) return;
-        tr("k_halo_wait");
-        hipLaunchKernelGGL(k_halo_wait, dim3(1), dim3(64), 0, stream, reinterpret_cast<const XferHeader*>(xf.region), (int)(xf.seq & 1u), xf.seq, (const int32_t*)xf.d_peers.p, xf.n_peers, xf.err.p);
-        xf_unpack_src = xf_rows((int)(xf.seq & 1u));
-    }
     void xf_check_errors() {
         if (!xf.region) return;
         MHIP_HIP(hipMemcpyAsync(xf.h_err, xf.err.p, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
@@ -1732,8 +1725,8 @@ template <class T> class Engine final : public EngineBase {
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         const int64_t last = first_step + n_steps;
         InRun guard_in_run(in_run);
+        struct Direct { bool& f; explicit Direct(bool& b) : f(b) { f = true; } ~Direct() { f = false; } } guard_direct(xf_direct);   // packs send, unpacks wait
         halo_start(dt);
-        xf_push();
         for (int64_t s = first_step + 1; s <= last; ++s) {
             const bool cm = remove_cm_every != 0 && s % remove_cm_every == 0;
             bool replan = false;
@@ -1753,12 +1746,9 @@ template <class T> class Engine final : public EngineBase {
             }
             const bool stop = replan || s == last;
             if (n_ghost > 0 && xf.n_peers > 0) (void)halo_interior(s);          // the blocks that need no ghost, while the peers' rows arrive
-            xf_wait();
-            halo_mid(s, dt, (cm ? 1 : 0) | (stop ? 2 : 0), (cm && stop) ? cm_parts_dev : nullptr, (cm && stop) ? n_parts : 0);
-            xf_unpack_src = nullptr;
+            halo_mid(s, dt, (cm ? 1 : 0) | (stop ? 2 : 0), (cm && stop) ? cm_parts_dev : nullptr, (cm && stop) ? n_parts : 0);   // waits + unpacks … packs + sends
             ++*steps_done;
             if (stop) { *reason = replan ? 1 : 0; xf.plan_pending = false; break; }
-            xf_push();
         }
         xf_check_errors();      // (one stream sync per call: a chunk is ≈ 100 steps)
     }

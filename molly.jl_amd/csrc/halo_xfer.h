@@ -1,8 +1,8 @@
 // halo_xfer.h — the ghost exchange INSIDE the engine ("direct peer stores into pre-exchanged IPC buffers").
 //
 // Every rank owns a RECEIVE REGION in fine-grained device memory and, through hipIpcOpenMemHandle, a pointer to every peer's region
-// (one process per GPU; the pointers are exchanged once, when the decomposition is set up).  After a step's coordinates are packed,
-// ONE kernel stores each peer's rows straight into that peer's region — over xGMI, no host call, no collective — and then raises a
+// (one process per GPU; the pointers are exchanged once, when the decomposition is set up).  The kernel that packs a step's coordinates
+// stores each peer's rows straight into that peer's region — over xGMI, no host call, no collective — and its last block raises a
 // sequence word there; the unpack kernel of the receiving side spins on its senders' words (bounded: a peer that never arrives raises
 // an error flag instead of hanging the GPU) before it scatters the rows into its ghost slots.  A region has two halves used by the
 // parity of the exchange number: a fast peer may deliver exchange e + 1 while this rank still reads exchange e, never e + 2 (that
@@ -38,34 +38,32 @@ struct XferPeers {                              // by value to the kernels: the 
     unsigned char* region[XFER_MAX_RANKS];
 };
 
-// rows [0, n_rows) of the packed send buffer → the peers' regions: row k goes to rank row_peer[k], row row_dst[k] of that rank's half
-// `parity`.  The last block to finish raises seq_in[parity][my_rank] = seq at every peer (done: a zeroed counter, left zero again).
-template <class T>
-__global__ void __launch_bounds__(256) k_halo_push(int64_t n_rows, const T* __restrict__ send, const int32_t* __restrict__ row_peer, const int32_t* __restrict__ row_dst,
-                                                   XferPeers P, int64_t rows_cap, int parity, uint32_t seq, int my_rank, const int32_t* __restrict__ peers, int n_peers, unsigned int* done) {
-    const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (k < n_rows) {
-        T* base = reinterpret_cast<T*>(P.region[row_peer[k]] + XFER_ROWS_OFF) + (size_t)parity * rows_cap * 3;
-        T* d = base + 3 * (size_t)row_dst[k];
-        d[0] = send[3 * k]; d[1] = send[3 * k + 1]; d[2] = send[3 * k + 2];
-    }
-    __threadfence_system();                       // this block's rows are on their way before it checks out
+// what a kernel needs to store rows into the peers' regions and to announce them (k_halo_pack), or to wait for the peers' rows
+// (k_halo_unpack) — so that packing + sending, and waiting + unpacking, are ONE launch each
+struct XferSend {
+    const int32_t* row_peer; const int32_t* row_dst;     // per send row: destination rank, row in that rank's half (nullptr: plain local pack)
+    XferPeers P; int64_t rows_cap; int parity; uint32_t seq; int my_rank; const int32_t* peers; int n_peers; unsigned int* done;
+};
+struct XferWait { const XferHeader* mine; int parity; uint32_t seq; const int32_t* peers; int n_peers; int32_t* err; };
+
+// the last block of a launch to get here raises this rank's sequence word at every peer (all blocks have fenced their stores before)
+__device__ inline void xfer_announce(const XferSend& X) {
+    __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned int before = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (before == gridDim.x - 1) {            // every block has checked out: the exchange is complete at every peer
+        const unsigned int before = __hip_atomic_fetch_add(X.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (before == gridDim.x - 1) {
             __threadfence_system();
-            for (int q = 0; q < n_peers; ++q)
-                xfer_store_release(&reinterpret_cast<XferHeader*>(P.region[peers[q]])->seq_in[parity][my_rank], seq);
-            __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int q = 0; q < X.n_peers; ++q)
+                xfer_store_release(&reinterpret_cast<XferHeader*>(X.P.region[X.peers[q]])->seq_in[X.parity][X.my_rank], X.seq);
+            __hip_atomic_store(X.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
-
-// one block: waits until every peer has delivered exchange `seq` into half `parity` of MY region; raises *err on a time-out
-[[maybe_unused]] static __global__ void k_halo_wait(const XferHeader* mine, int parity, uint32_t seq, const int32_t* __restrict__ peers, int n_peers, int32_t* err) {
-    const int q = threadIdx.x;
-    if (q < n_peers && !xfer_wait(&mine->seq_in[parity][peers[q]], seq)) atomicOr(err, 1);
+// every block waits for the senders' words itself (a handful of uncached loads), then all its threads go on
+__device__ inline void xfer_wait_block(const XferWait& W) {
+    if ((int)threadIdx.x < W.n_peers && !xfer_wait(&W.mine->seq_in[W.parity][W.peers[threadIdx.x]], W.seq)) atomicOr(W.err, 1);
+    __syncthreads();
 }
 
 // validity check of the pair lists over all ranks: my triple into every rank's table (my own included) …

@@ -13,6 +13,7 @@
 #pragma once
 #include <type_traits>
 #include "physics.h"
+#include "halo_xfer.h"
 
 namespace mhip {
 
@@ -1761,10 +1762,16 @@ __global__ void k_scatter_coords(int64_t first, int64_t n, const T* __restrict__
 // row) — the centre-of-mass sum rides on the ghost exchange instead of an all-reduce of its own.  idx < 0 marks those rows; they are
 // written by ONE extra block that re-sums the per-block partials of the integrator launch (cm_part, n_part; nullptr: zeros) and
 // also leaves the total in cm_own, the first slot of the table the next integrator launch sums.
+// X.row_peer != nullptr: the rows do not go to the local send buffer but straight into the peers' receive regions (halo_xfer.h), and
+// the last block to finish raises this rank's sequence word there — packing and sending in one launch.
 template <class T>
 __global__ void __launch_bounds__(256) k_halo_pack(int64_t n, const int32_t* __restrict__ idx, const T* __restrict__ shift, const int32_t* __restrict__ inv,
                                                    const typename Vec<T>::T4* __restrict__ pos, T* out, const double* __restrict__ cm_part, int n_part,
-                                                   const int32_t* __restrict__ cm_pos, int n_cm_pos, int cm_rows, double* cm_own) {
+                                                   const int32_t* __restrict__ cm_pos, int n_cm_pos, int cm_rows, double* cm_own, XferSend X) {
+    auto row_ptr = [&](int64_t k) -> T* {
+        if (!X.row_peer) return out + 3 * k;
+        return reinterpret_cast<T*>(X.P.region[X.row_peer[k]] + XFER_ROWS_OFF) + (size_t)X.parity * X.rows_cap * 3 + 3 * (size_t)X.row_dst[k];
+    };
     if (blockIdx.x == gridDim.x - 1) {
         __shared__ double tot[4];
         __shared__ double sh_cm[4][4];
@@ -1780,22 +1787,30 @@ __global__ void __launch_bounds__(256) k_halo_pack(int64_t n, const int32_t* __r
         const T* w = reinterpret_cast<const T*>(tot);
         for (int q = threadIdx.x; q < n_cm_pos; q += blockDim.x) {
             const int r = q % cm_rows; const int64_t k = cm_pos[q];
-            for (int c = 0; c < 3; ++c) out[3 * k + c] = (3 * r + c < NW) ? w[3 * r + c] : T(0);
+            T* o = row_ptr(k);
+            for (int c = 0; c < 3; ++c) o[c] = (3 * r + c < NW) ? w[3 * r + c] : T(0);
         }
+        if (X.row_peer) xfer_announce(X);
         return;
     }
     const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    const int i = idx[k];
-    if (i < 0) return;
-    const auto p = pos[inv[i]];
-    out[3 * k] = p.x + shift[3 * k]; out[3 * k + 1] = p.y + shift[3 * k + 1]; out[3 * k + 2] = p.z + shift[3 * k + 2];
+    if (k < n) {
+        const int i = idx[k];
+        if (i >= 0) {
+            const auto p = pos[inv[i]];
+            T* o = row_ptr(k);
+            o[0] = p.x + shift[3 * k]; o[1] = p.y + shift[3 * k + 1]; o[2] = p.z + shift[3 * k + 2];
+        }
+    }
+    if (X.row_peer) xfer_announce(X);
 }
 // the receiving side: dst >= 0 → coordinates of ghost slot first + dst; dst = −1 − (peer·cm_rows + r) → row r of that peer's sums,
 // collected in cm_all[1 + peer] (slot 0 is this rank's own, k_halo_pack)
+// W.n_peers > 0: the rows come from this rank's receive region; every block first waits for the senders' sequence words (halo_xfer.h)
 template <class T>
 __global__ void k_halo_unpack(int64_t n, const T* __restrict__ in, const int32_t* __restrict__ dst, int64_t first, const int32_t* __restrict__ inv,
-                              typename Vec<T>::T4* pos, double* cm_all, int cm_rows) {
+                              typename Vec<T>::T4* pos, double* cm_all, int cm_rows, XferWait W) {
+    if (W.n_peers > 0) xfer_wait_block(W);
     const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (k >= n) return;
     const int d = dst[k];
