@@ -1099,7 +1099,8 @@ k_forces(ForceArgs<T> A) {
     T fx = T(0), fy = T(0), fz = T(0), pe = T(0);
     [[maybe_unused]] T vir[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};   // ENERGY: Σ fr·(dx², dy², dz², dx·dy, dx·dz, dy·dz), the pair virial dr ⊗ f (force.jl:848-852)
     // PRUNE: inner-list emission state (same row format as k_build)
-    uint64_t pk = 0;        // (64-bit shift register, as in k_build)
+    // PRUNE: the last eight entries kept, 16 bits each, newest in the top half of w3 (a 128-bit shift register: four v_alignbit per entry)
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
     int kept = 0;
     uint2* out_rows = nullptr;
     if constexpr (PRUNE) out_rows = A.nbr_dst + (((int64_t)b * A.JS + js) * A.R_cap) * A.BI + li;
@@ -1141,11 +1142,24 @@ k_forces(ForceArgs<T> A) {
         }
         if (A.snap_dst && js == 0 && valid) A.snap_dst[si] = pi_raw;
     }
-    auto emit = [&](uint32_t e) {
-        pk = (pk >> 16) | ((uint64_t)e << 48);
-        ++kept;
-        if ((kept & 3) == 0) out_rows[(int64_t)((kept >> 2) - 1) * A.BI] = make_uint2((uint32_t)pk, (uint32_t)(pk >> 32));
+    // push: append entry e if k — no branch: the packed loop calls it for all four entries of a row and stores at most once per row
+    // (row_out) — four dependent exec-mask branches per row, each around a store test, were a quarter of the pruning pass
+    auto push = [&](uint32_t e, bool k) {
+        const uint32_t n0 = __builtin_amdgcn_alignbit(w1, w0, 16), n1 = __builtin_amdgcn_alignbit(w2, w1, 16), n2 = __builtin_amdgcn_alignbit(w3, w2, 16), n3 = __builtin_amdgcn_alignbit(e, w3, 16);
+        w0 = k ? n0 : w0; w1 = k ? n1 : w1; w2 = k ? n2 : w2; w3 = k ? n3 : w3;
+        kept += k ? 1 : 0;
     };
+    // after up to four pushes since `before`: if a row of four was completed, store it (the kept & 3 newest entries belong to the next row)
+    auto row_out = [&](int before) {
+        if ((kept >> 2) != (before >> 2)) {
+            const int r = kept & 3;
+            const bool up = r < 2, odd = (r & 1) != 0;
+            const uint32_t b0 = up ? w1 : w0, b1 = up ? w2 : w1, b2 = up ? w3 : w2;
+            const uint32_t lo = odd ? __builtin_amdgcn_alignbit(b1, b0, 16) : b1, hi = odd ? __builtin_amdgcn_alignbit(b2, b1, 16) : b2;
+            out_rows[(int64_t)((kept >> 2) - 1) * A.BI] = make_uint2(lo, hi);
+        }
+    };
+    auto emit = [&](uint32_t e) { const int before = kept; push(e, true); row_out(before); };
 
     constexpr bool FAST_CT = std::is_same<T, float>::value && LJM == LJ_DIST_UNIFORM && COULM == MHIP_COUL_NONE && !ENERGY && !MINIMG && !SEG;
     // the packed loop keeps four rows in flight; the first four are requested here, before the tile is staged, so that the row
@@ -1301,10 +1315,10 @@ k_forces(ForceArgs<T> A) {
                         // entry waited for an LDS round trip of its own
                         const uint32_t na = l_new[oa >> 2], nb = l_new[ob >> 2], nc = l_new[oc >> 2], nd = l_new[od >> 2];
                         if constexpr (MHIP_PEXP != 1) {    // (MHIP_PEXP: timing experiments of the pruning pass, 1 = no emission, 2 = no LJ arithmetic)
-                        if (r20.x <= rp2) emit(na << ESHIFT_SCALED);
-                        if (r20.y <= rp2) emit(nb << ESHIFT_SCALED);
-                        if (r21.x <= rp2) emit(nc << ESHIFT_SCALED);
-                        if (r21.y <= rp2) emit(nd << ESHIFT_SCALED);
+                            const int before = kept;
+                            push(na << ESHIFT_SCALED, r20.x <= rp2); push(nb << ESHIFT_SCALED, r20.y <= rp2);
+                            push(nc << ESHIFT_SCALED, r21.x <= rp2); push(nd << ESHIFT_SCALED, r21.y <= rp2);
+                            row_out(before);
                         }
                     }
                     const float t0 = __builtin_amdgcn_rcpf(r20.x * r20.y), t1 = __builtin_amdgcn_rcpf(r21.x * r21.y);

@@ -121,9 +121,8 @@ __global__ void __launch_bounds__(1024) k_prune_lean(ForceArgs<float> A) {
         }
         __syncthreads();
         int run = l_scan[tid];
-        for (int t = t0; t < t1; ++t) {
-            if (l_new[t]) { l_new[t] = (uint16_t)run; A.tile_idx_dst[(int64_t)b * A.T_cap + run] = tix[t]; ++run; }
-            else l_new[t] = (uint16_t)0xffffu;
+        for (int t = t0; t < t1; ++t) {      // the new entry value (slot · 4) rides in the spare half of the atom's second LDS word: no lookup of its own in the walk
+            if (l_new[t]) { l_q[t].y |= (uint32_t)(run << ESHIFT_SCALED) << 16; A.tile_idx_dst[(int64_t)b * A.T_cap + run] = tix[t]; ++run; }
         }
         n_new = l_scan[nthr];
         __syncthreads();
@@ -132,32 +131,40 @@ __global__ void __launch_bounds__(1024) k_prune_lean(ForceArgs<float> A) {
     const s16x2 pxy = {(short)quant(pi.x), (short)quant(pi.y)}, pz0 = {(short)quant(pi.z), 0};
     const float rq = sqrtf(A.r_prune2) * PRUNE_Q + 2.f;                            // two units of slack: both ends of a pair were rounded
     const int rp2q = (int)(rq * rq) + 1;
-    uint64_t pk = 0; int kept = 0;
-    auto emit = [&](uint32_t e) {
-        pk = (pk >> 16) | ((uint64_t)e << 48);
-        ++kept;
-        if ((kept & 3) == 0) out_rows[(int64_t)((kept >> 2) - 1) * A.BI] = make_uint2((uint32_t)pk, (uint32_t)(pk >> 32));
+    // the last eight entries kept, newest in the top half of w3; appended without branches, a row of four stored at most once per walked row
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0; int kept = 0;
+    auto push = [&](uint32_t e, bool k) {
+        const uint32_t n0 = __builtin_amdgcn_alignbit(w1, w0, 16), n1 = __builtin_amdgcn_alignbit(w2, w1, 16), n2 = __builtin_amdgcn_alignbit(w3, w2, 16), n3 = __builtin_amdgcn_alignbit(e, w3, 16);
+        w0 = k ? n0 : w0; w1 = k ? n1 : w1; w2 = k ? n2 : w2; w3 = k ? n3 : w3;
+        kept += k ? 1 : 0;
     };
+    auto row_out = [&](int before) {
+        if ((kept >> 2) != (before >> 2)) {
+            const int r = kept & 3;
+            const bool up = r < 2, odd = (r & 1) != 0;
+            const uint32_t b0 = up ? w1 : w0, b1 = up ? w2 : w1, b2 = up ? w3 : w2;
+            const uint32_t lo = odd ? __builtin_amdgcn_alignbit(b1, b0, 16) : b1, hi = odd ? __builtin_amdgcn_alignbit(b2, b1, 16) : b2;
+            out_rows[(int64_t)((kept >> 2) - 1) * A.BI] = make_uint2(lo, hi);
+        }
+    };
+    auto emit = [&](uint32_t e) { const int before = kept; push(e, true); row_out(before); };
     typedef __attribute__((address_space(3))) const unsigned char* lds_bptr;
     const lds_bptr qbase = (lds_bptr)(uintptr_t)0;                                 // (l_q starts at LDS address 0: no static __shared__ here)
-    const uint32_t new_off = (uint32_t)(((A.T_lds + 3) & ~1) * 8);
     auto row = [&](const uint2 e4) {
         const uint32_t oa = e4.x & 0xffffu, ob = e4.x >> 16, oc = e4.y & 0xffffu, od = e4.y >> 16;     // byte offsets slot·4
-        typedef __attribute__((address_space(3))) const uint64_t* lds_q; typedef __attribute__((address_space(3))) const uint16_t* lds_h;
+        typedef __attribute__((address_space(3))) const uint64_t* lds_q;
         const uint64_t qa = *(lds_q)(qbase + 2 * oa), qb = *(lds_q)(qbase + 2 * ob), qc = *(lds_q)(qbase + 2 * oc), qd = *(lds_q)(qbase + 2 * od);
-        const uint32_t na = *(lds_h)(qbase + new_off + (oa >> 1)), nb = *(lds_h)(qbase + new_off + (ob >> 1)), nc = *(lds_h)(qbase + new_off + (oc >> 1)), nd = *(lds_h)(qbase + new_off + (od >> 1));
         auto r2 = [&](const uint64_t q) -> int {
-            const s16x2 dxy = __builtin_bit_cast(s16x2, (uint32_t)q) - pxy, dz = __builtin_bit_cast(s16x2, (uint32_t)(q >> 32)) - pz0;
+            const s16x2 dxy = __builtin_bit_cast(s16x2, (uint32_t)q) - pxy, dz = __builtin_bit_cast(s16x2, (uint32_t)(q >> 32) & 0xffffu) - pz0;
             return __builtin_amdgcn_sdot2(dxy, dxy, __builtin_amdgcn_sdot2(dz, dz, 0, false), false);
         };
         const int ra = r2(qa), rb = r2(qb), rc = r2(qc), rd = r2(qd);
 #if MHIP_LEXP == 1     // timing experiment: no emission
-        if (((ra <= rp2q) + (rb <= rp2q) + (rc <= rp2q) + (rd <= rp2q)) == 77) emit(na + nb + nc + nd);
+        if (((ra <= rp2q) + (rb <= rp2q) + (rc <= rp2q) + (rd <= rp2q)) == 77) emit((uint32_t)(qa >> 48));
 #else
-        if (ra <= rp2q) emit(na << ESHIFT_SCALED);
-        if (rb <= rp2q) emit(nb << ESHIFT_SCALED);
-        if (rc <= rp2q) emit(nc << ESHIFT_SCALED);
-        if (rd <= rp2q) emit(nd << ESHIFT_SCALED);
+        const int before = kept;
+        push((uint32_t)(qa >> 48), ra <= rp2q); push((uint32_t)(qb >> 48), rb <= rp2q); push((uint32_t)(qc >> 48), rc <= rp2q); push((uint32_t)(qd >> 48), rd <= rp2q);
+        row_out(before);
 #endif
     };
     if (rows > 0 && valid) {
