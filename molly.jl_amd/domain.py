@@ -746,7 +746,9 @@ def bench_distributed(m, case, dtype, dt, args, rank, local_rank, world):
         return None
     agg = torch.stack(per_rank).sum(0).tolist()
     st["n_pairs_full"] = int(agg[0])
-    extra = {"parallelism": f"spatial bricks {grid[0]}x{grid[1]}x{grid[2]}, full-shell ghost coordinates via all_to_all_single (RCCL), "
+    transport = ("peer stores into IPC-mapped receive regions, step loop inside the engine (mhip_domain_run)" if run.engine_loop
+                 else "all_to_all_single (RCCL) from the host loop")
+    extra = {"parallelism": f"spatial bricks {grid[0]}x{grid[1]}x{grid[2]}, full-shell ghost coordinates via {transport}, "
                             f"{int(agg[3] / world)} ghosts / {int(agg[4] / world)} owned atoms per GPU, ghost margin {gm:.2f} nm "
                             f"({run.stats['plans']} ghost plans, {run.stats['prunes']} prunes in {run.stats['plan_checks']} checks)",
              "per_gpu_force_pass_bytes": st["force_pass_bytes"], "ghost_fraction": agg[3] / max(agg[4], 1), "timed_window": window,
