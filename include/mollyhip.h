@@ -366,6 +366,7 @@ int32_t mhip_plan_decide(mhip_ctx* ctx, int64_t step_n, const float* reduced3, i
  *                          the peers (any transport: the decomposition is set up by the host once)
  *   mhip_halo_open_peer  : map rank r's region from its handle (every rank that sends to or receives from this one; for the
  *                          collective validity check: every rank)
+ *   mhip_halo_selftest  : collective check of the mapped regions before the first run (see below)
  *   mhip_set_halo_routes : per ghost plan, after mhip_set_halo_plan: the send buffer's consecutive segments → (peer, first row in the
  *                          peer's half); the receive buffer of the plan is the region half itself, peer by peer in the same order
  *   mhip_domain_run      : a run of ghosted velocity-Verlet steps in one call — mhip_vv_halo_start, then per step interior blocks →
@@ -387,6 +388,9 @@ typedef struct {
 } mhip_halo_routes;
 int32_t mhip_halo_region(mhip_ctx* ctx, int64_t rows_capacity, int32_t world, int32_t rank, void* ipc_handle_out);
 int32_t mhip_halo_open_peer(mhip_ctx* ctx, int32_t rank, const void* ipc_handle);
+/* Collective (every rank, once every region is mapped): one round of stores into every rank's region and a bounded wait for theirs.
+ * *ok = 0: a peer's store did not become visible here within 2 s — keep the ghost exchange on the host (torch.distributed) then. */
+int32_t mhip_halo_selftest(mhip_ctx* ctx, int32_t* ok);
 int32_t mhip_set_halo_routes(mhip_ctx* ctx, const mhip_halo_routes* routes);
 int32_t mhip_domain_run(mhip_ctx* ctx, int64_t first_step, int64_t n_steps, double dt, int32_t remove_cm_every, double* cm_parts_dev, int32_t n_parts,
                         int64_t* steps_done, int32_t* reason, int64_t* counters3);

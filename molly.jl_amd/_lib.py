@@ -134,6 +134,7 @@ SIGNATURES = {
     "mhip_plan_decide": (_I32, [_P, _I64, C.POINTER(C.c_float), C.POINTER(_I32), C.POINTER(_I32)]),
     "mhip_halo_region": (_I32, [_P, _I64, _I32, _I32, _P]),
     "mhip_halo_open_peer": (_I32, [_P, _I32, _P]),
+    "mhip_halo_selftest": (_I32, [_P, C.POINTER(_I32)]),
     "mhip_set_halo_routes": (_I32, [_P, C.POINTER(HaloRoutes)]),
     "mhip_domain_run": (_I32, [_P, _I64, _I64, _D, _I32, _P, _I32, C.POINTER(_I64), C.POINTER(_I32), C.POINTER(_I64)]),
 }

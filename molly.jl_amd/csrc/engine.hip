@@ -94,6 +94,7 @@ struct EngineBase {
     virtual void halo_region(int64_t, int32_t, int32_t, void*) = 0;
     virtual void halo_open_peer(int32_t, const void*) = 0;
     virtual void set_halo_routes(const mhip_halo_routes*) = 0;
+    virtual int halo_selftest() = 0;
     virtual void domain_run(int64_t, int64_t, double, int32_t, double*, int32_t, int64_t*, int32_t*, int64_t*) = 0;
 };
 
@@ -1694,6 +1695,23 @@ template <class T> class Engine final : public EngineBase {
         if (rt->n_peers) MHIP_HIP(hipMemcpy(xf.d_peers.p, rt->peer_rank, rt->n_peers * sizeof(int32_t), hipMemcpyHostToDevice));
         xf.routes = true; xf.plan_pending = false; xf.next_check = -1;
     }
+    // One round of the collective number exchange over the mapped regions, before any step depends on it: every rank stores a token
+    // into every rank's table and waits (bounded) for all of theirs.  0 = some rank's store did not become visible here within 2 s —
+    // the host then keeps its own loop with torch.distributed collectives (every rank must call this at the same point).
+    int halo_selftest() override {
+        if (!xf.region) throw ApiError{MHIP_ERR_STATE, "mhip_halo_region first"};
+        for (int r = 0; r < xf.world; ++r) if (!xf.peers.region[r]) throw ApiError{MHIP_ERR_STATE, "mhip_halo_open_peer for every rank first"};
+        const float token[4] = {(float)(xf.rank + 1), 0.f, 0.f, 0.f};
+        MHIP_HIP(hipMemcpyAsync(xf.mine3.p, token, 3 * sizeof(float), hipMemcpyHostToDevice, stream));
+        ++xf.plan_seq;
+        hipLaunchKernelGGL(k_plan_push, dim3(1), dim3(64), 0, stream, (const float*)xf.mine3.p, xf.peers, xf.world, xf.rank, (int)(xf.plan_seq & 1u), xf.plan_seq);
+        hipLaunchKernelGGL(k_plan_reduce, dim3(1), dim3(64), 0, stream, reinterpret_cast<const XferHeader*>(xf.region), xf.world, (int)(xf.plan_seq & 1u), xf.plan_seq, xf.red3.p, xf.h_red3, xf.err.p);
+        MHIP_HIP(hipMemcpyAsync(xf.h_err, xf.err.p, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        MHIP_HIP(hipStreamSynchronize(stream));
+        const bool ok = *xf.h_err == 0 && xf.h_red3[0] == (float)xf.world;      // the MAX of the tokens is the highest rank's
+        if (*xf.h_err) MHIP_HIP(hipMemset(xf.err.p, 0, sizeof(int32_t)));
+        return ok ? 1 : 0;
+    }
     void xf_check_errors() {
         if (!xf.region) return;
         MHIP_HIP(hipMemcpyAsync(xf.h_err, xf.err.p, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
@@ -2152,6 +2170,7 @@ int32_t mhip_vv_halo_mid(mhip_ctx* ctx, int64_t step_n, double dt, int32_t flags
 }
 int32_t mhip_halo_region(mhip_ctx* ctx, int64_t rows_capacity, int32_t world, int32_t rank, void* ipc_handle_out) { NEED_CTX(); return guard(ctx, [&] { ctx->e->halo_region(rows_capacity, world, rank, ipc_handle_out); }); }
 int32_t mhip_halo_open_peer(mhip_ctx* ctx, int32_t rank, const void* ipc_handle) { NEED_CTX(); return guard(ctx, [&] { ctx->e->halo_open_peer(rank, ipc_handle); }); }
+int32_t mhip_halo_selftest(mhip_ctx* ctx, int32_t* ok) { NEED_CTX(); return guard(ctx, [&] { if (!ok) throw mhip::ApiError{MHIP_ERR_INVALID, "null output"}; *ok = ctx->e->halo_selftest(); }); }
 int32_t mhip_set_halo_routes(mhip_ctx* ctx, const mhip_halo_routes* routes) { NEED_CTX(); return guard(ctx, [&] { ctx->e->set_halo_routes(routes); }); }
 int32_t mhip_domain_run(mhip_ctx* ctx, int64_t first_step, int64_t n_steps, double dt, int32_t remove_cm_every, double* cm_parts_dev, int32_t n_parts,
                         int64_t* steps_done, int32_t* reason, int64_t* counters3) {

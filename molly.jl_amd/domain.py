@@ -226,6 +226,11 @@ class HipDomainEngine:
         buf = (C.c_ubyte * _lib.IPC_HANDLE_BYTES).from_buffer_copy(handle)
         self._chk(self.L.mhip_halo_open_peer(self.ctx, rank, C.cast(buf, C.c_void_p)))
 
+    def halo_selftest(self):
+        ok = C.c_int32(0)
+        self._chk(self.L.mhip_halo_selftest(self.ctx, C.byref(ok)))
+        return bool(ok.value)
+
     def set_halo_routes(self, peer_rank, send_rows, dst_row, recv_rows):
         n = len(peer_rank)
         rt = _lib.HaloRoutes()
@@ -476,9 +481,25 @@ class DomainRun:
             if not all(int(a[-1]) for a in allh):
                 self.engine_loop = False
                 return
-            for r, a in enumerate(allh):
-                if r != self.rank:
-                    self.e.halo_open_peer(r, bytes(a[:-1].tolist()))
+            ok = 1
+            try:
+                for r, a in enumerate(allh):
+                    if r != self.rank:
+                        self.e.halo_open_peer(r, bytes(a[:-1].tolist()))
+            except Exception:
+                ok = 0
+            if not all(int(a[0]) for a in self._all_gather_cpu(torch.tensor([ok], dtype=torch.uint8))):
+                self.engine_loop = False                  # some rank could not map some region: the host loop for everybody
+                return
+            # one round over the mapped regions before anything depends on them (a store that never becomes visible on the other
+            # side would otherwise surface as a time-out in the middle of a run)
+            try:
+                ok = 1 if self.e.halo_selftest() else 0
+            except Exception:
+                ok = 0
+            if not all(int(a[0]) for a in self._all_gather_cpu(torch.tensor([ok], dtype=torch.uint8))):
+                self.engine_loop = False
+                return
             self._ipc_ready = True
         # my receive layout: peers in sorted order, rc[p] rows each → the offset of p's segment, told to p
         off, r_off = torch.zeros(self.world, dtype=torch.int64), 0
