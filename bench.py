@@ -34,16 +34,16 @@ WORKLOADS = {
 
 
 def make_case(workload):
-    """The synthetic inputs of SURVEY §8(d): generators and the 6mrr parameter file live with the test fixtures (inputs only)."""
-    from tests import systems as S
+    """The synthetic inputs of SURVEY §8(d) (molly.jl_amd/workloads.py; the 6mrr parameter file is tests/golden/6mrr.npz)."""
+    import importlib
+    W = importlib.import_module("molly_jl_amd.workloads")
     if workload == "lj1m":
-        return S.lj_fluid(100, seed=4, dtype=np.float32), np.float32, 0.002
+        return W.lj_fluid(100, seed=4, dtype=np.float32), np.float32, 0.002
     if workload == "lj256k":
-        return S.lj_fluid(64, seed=2, dtype=np.float32), np.float32, 0.002
+        return W.lj_fluid(64, seed=2, dtype=np.float32), np.float32, 0.002
     if workload in ("6mrr_pme", "6mrr_direct", "6mrr_rf64"):
-        from tests import golden6mrr
         dtype = np.float64 if workload == "6mrr_rf64" else np.float32
-        return golden6mrr.case("rf" if workload == "6mrr_rf64" else "ewald", dtype=dtype, bonded=True, pme=(workload == "6mrr_pme")), dtype, 0.0005
+        return W.protein_6mrr("rf" if workload == "6mrr_rf64" else "ewald", dtype=dtype, bonded=True, pme=(workload == "6mrr_pme")), dtype, 0.0005
     raise SystemExit(f"unknown workload {workload}")
 
 
@@ -54,7 +54,7 @@ def cpu_baseline(case, dtype, dt, budget_s=20.0):
     orc.build(native=True)
     cores = os.cpu_count() or 1
     nthreads = min(cores, 64)
-    o = case.oracle(dtype)
+    o = orc.from_case(case, dtype)
     o.native = True
     specific = case.bonds is not None
     general = case.pme is not None

@@ -307,3 +307,13 @@ def philox4x32_10(ctr4, key2):
     c = np.asarray(ctr4, np.uint32); k = np.asarray(key2, np.uint32); out = np.zeros(4, np.uint32)
     lib().orc_philox4x32_10(_ptr(c), _ptr(k), _ptr(out))
     return out
+
+
+def from_case(case, dtype=np.float64, coords=None, velocities=None):
+    """OracleSystem of a workload description (molly.jl_amd/workloads.py `Case`: plain numpy inputs)."""
+    return OracleSystem(case.coords if coords is None else coords, case.box, case.inter_dict(dtype), dtype=dtype,
+                        velocities=case.velocities if velocities is None else velocities,
+                        charge=case.charge, sigma=case.sigma, eps=case.eps, mass=case.mass, r_list=case.r_list,
+                        rebuild_every=case.rebuild_every, excluded=case.excluded, special=case.special,
+                        bonds=case.bonds, angles=case.angles, torsions=None if case.torsions is None else dict(case.torsions),
+                        ewald_excl=case.ewald_excl, pme=case.pme_params(dtype), triclinic=case.triclinic)

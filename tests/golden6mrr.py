@@ -1,50 +1,19 @@
 """Loader of tests/golden/6mrr.npz (built by tools/param_6mrr.py from the reference's data files): the solvated
 protein 6mrr, 15 954 atoms, Amber ff99SB-ILDN + TIP3P, with the OpenMM Reference-platform forces and energies."""
-import os
-
 import numpy as np
 
 from tests import systems as S
 
-_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "6mrr.npz")
-_cache = {}
+_W = S._W
 
 
 def data():
-    if "d" not in _cache:
-        _cache["d"] = dict(np.load(_PATH))
-    return _cache["d"]
+    return _W.protein_6mrr_data()
 
 
-def case(coulomb="rf", dtype=np.float64, bonded=True, lj=True, which_bonded=("bonds", "angles", "proper", "improper"), r_list=1.2,
-         approx_erfc=True, rebuild_every=10, pme=False):
-    """coulomb: None | "rf" (CoulombReactionField rc 1.0, ε 78.3 — OpenMM CutoffPeriodic) | "ewald" (CoulombEwald rc 1.0,
-    tol 5e-4 + EwaldExclusion list), as setup.jl:1852-1913 wires them for nonbonded_method :cutoff / :pme."""
-    d = data()
-    T = np.dtype(dtype).type
-    r = lambda a: np.asarray(a, dtype=np.float64).astype(dtype).astype(np.float64)   # inputs rounded to the working precision
-    coords = r(d["coords"]); box = r(d["box"])
-    coords = np.where(coords >= box, 0.0, coords)
-    coul = None
-    if coulomb == "rf":
-        coul = dict(kind="rf", rc=1.0, eps_rf=78.3, weight_special=float(d["weight_14_coulomb"]))
-    elif coulomb == "ewald":
-        coul = dict(kind="ewald", rc=1.0, tol=5e-4, approx=approx_erfc, weight_special=float(d["weight_14_coulomb"]))
-    kw = {}
-    if bonded:
-        if "bonds" in which_bonded:
-            kw["bonds"] = dict(i=d["bonds_i"], j=d["bonds_j"], k=d["bonds_k"], r0=d["bonds_r0"])
-        if "angles" in which_bonded:
-            kw["angles"] = dict(i=d["angles_i"], j=d["angles_j"], k=d["angles_k"], kth=d["angles_kth"], th0=d["angles_th0"])
-        parts = [p for p in ("proper", "improper") if p in which_bonded]
-        if parts:
-            kw["torsions"] = {k: np.concatenate([d[f"{p}_{k}"] for p in parts]) for k in ("i", "j", "k", "l", "periodicity", "phase", "k0")}
-        if coulomb == "ewald":
-            kw["ewald_excl"] = d["ewald_excl"]
-    return S.Case(coords, box, lj=dict(cutoff=("distance", 1.0), weight_special=float(d["weight_14_lj"])) if lj else None, coul=coul,
-                  r_list=r_list, rebuild_every=rebuild_every, velocities=r(d["velocities_300K"]), charge=r(d["charge"]), sigma=r(d["sigma"]),
-                  eps=r(d["eps"]), mass=r(d["mass"]), excluded=d["excluded"], special=d["special"], name="6mrr",
-                  pme=dict(order=5, error_tol=5e-4, eps_r=1.0) if (pme and coulomb == "ewald") else None, **kw)
+def case(*args, **kw):
+    """the 6mrr workload (molly.jl_amd/workloads.py `protein_6mrr`: same arguments) with the checker's side attached by tests/systems.py"""
+    return _W.protein_6mrr(*args, **kw)
 
 
 def lj_dispersion_correction(d=None, rc=1.0):
