@@ -68,6 +68,45 @@ def evaluate(x, L, clusters, c, R):
     return evals / n, listed / n, float(np.linalg.norm(hi - lo, axis=1).mean())
 
 
+def j_groups(x, L, tree, R):
+    """The space between one partner per list entry and 4 x 4 clusters (round-2 review, item 1): an entry names an ALIGNED GROUP of g
+    consecutive tile slots and every member of a listed group is evaluated (one 64-bit LDS read per component would return two
+    partners).  The tile order is what the engine's tile has: cell-major on the search grid (cell 0.709 nm here), optionally with a
+    Morton order of sub-cells inside a cell.  Best case for g = 2: greedy nearest-neighbour matching, pairs as compact as the fluid
+    allows."""
+    n = len(x)
+    nb = tree.query_ball_point(x, R)
+    single = np.mean([len(v) - 1 for v in nb])
+    print(f"1 x g j-groups at list radius {R} nm (single entries per atom: {single:.1f}):")
+    nc = int(np.floor(L / 0.709)); cs = L / nc
+    c = np.minimum((x / cs).astype(int), nc - 1)
+    key = (c[:, 2] * nc + c[:, 1]) * nc + c[:, 0]
+
+    def count(grp):
+        return sum(len({grp[j] for j in nb[i] if j != i}) for i in range(n)) / n
+
+    orders = [("cell-major", np.lexsort((np.arange(n), key)))]
+    for sub in (2, 3):
+        f = np.minimum(((x / cs - c) * sub).astype(int), sub - 1)
+        orders.append((f"cell-major + {sub}^3 sub-cells", np.lexsort((np.arange(n), (f[:, 2] * sub + f[:, 1]) * sub + f[:, 0], key))))
+    orders.append(("cell-major, z-sorted in the cell", np.lexsort((x[:, 2], key))))
+    for label, order in orders:
+        rank = np.empty(n, int); rank[order] = np.arange(n)
+        for g in (2, 4):
+            e = count(rank // g)
+            print(f"  {label:34s} 1x{g}: {e:6.1f} entries per atom, {e * g:6.1f} evaluations = {e * g / single:.2f} x the single-entry list")
+    d, j = tree.query(x, k=6)
+    mate = -np.ones(n, int)
+    for dist, a, b in sorted((d[i, k], i, j[i, k]) for i in range(n) for k in range(1, 6)):
+        if mate[a] < 0 and mate[b] < 0:
+            mate[a] = b; mate[b] = a
+    left = np.flatnonzero(mate < 0)
+    for a, b in zip(left[0::2], left[1::2]):
+        mate[a] = b; mate[b] = a
+    e = count(np.minimum(np.arange(n), mate))
+    print(f"  {'greedy nearest-neighbour pairs':34s} 1x2: {e:6.1f} entries per atom, {2 * e:6.1f} evaluations = {2 * e / single:.2f} x the single-entry list")
+
+
 def main():
     case = S.lj_fluid(20, dtype=np.float64)              # 8000 atoms, box 7.24 nm
     o = case.oracle(np.float64)
@@ -89,6 +128,7 @@ def main():
                 ev, cp, diag = evaluate(x, L, cl, c, R)
                 print(f"  {name:12s} {c}x{c} R {R}: {ev:5.0f} evaluations per atom, {cp:4.1f} cluster pairs per atom, bounding-box diagonal {diag:.2f} nm, "
                       f"{half_rc / ev:.2f} of the evaluations within the cutoff")
+    j_groups(x, L, tree, 1.1)
 
 
 if __name__ == "__main__":
