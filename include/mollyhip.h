@@ -264,6 +264,24 @@ int32_t mhip_export_neighbors(mhip_ctx* ctx, int32_t* i, int32_t* j, uint8_t* sp
 int32_t mhip_export_order(mhip_ctx* ctx, int32_t* perm, int64_t capacity);
 int32_t mhip_get_stats(mhip_ctx* ctx, mhip_stats* out);
 
+/* ---- launch shape of the search and pair kernels (≙ CUDALaunchConfig, src/cuda_config.jl:1-62) --------------------------------
+ * A workgroup handles `block_atoms` consecutive (Hilbert-sorted) atoms with `j_split` waves sharing every atom's list
+ * (block_atoms * j_split lanes, at most 1024 in fp32 / 512 in fp64).  The automatic choice goes by the atom count.
+ *   mhip_set_launch_config       ≙ set_cuda_launch_config! / reset_cuda_launch_config! (src/cuda_config.jl:17-47): block_atoms in
+ *                                  {64, 128, 256}, j_split a power of two; (0, 0) = automatic again.  The lists are rebuilt.
+ *   mhip_optimize_launch_config  ≙ optimize_cuda_launch_config! (ext/MollyCUDAExt.jl:594-642; src/cuda_config.jl:53-62): times
+ *                                  n_passes plain force passes for each of a small candidate set on the context's own atoms
+ *                                  (lists rebuilt per shape, untimed), installs the fastest and reports every trial
+ *                                  (us_per_pass < 0: the shape's tile does not fit the LDS).  *n_trials = trials made (may exceed
+ *                                  max_trials; only the first max_trials are written).  Single-domain contexts only. */
+typedef struct mhip_launch_trial {
+    int32_t block_atoms;
+    int32_t j_split;
+    float us_per_pass;
+} mhip_launch_trial;
+int32_t mhip_set_launch_config(mhip_ctx* ctx, int32_t block_atoms, int32_t j_split);
+int32_t mhip_optimize_launch_config(mhip_ctx* ctx, int32_t n_passes, mhip_launch_trial* trials, int32_t max_trials, int32_t* n_trials);
+
 /* ---- multi-GPU halo helpers (device pointers; run on the context's stream) ------------------ */
 /* out[3k..3k+2] = coords[idx[k]] + shift[3k..]  (idx: caller indices of owned atoms; shift NULL ok) */
 int32_t mhip_gather_coords(mhip_ctx* ctx, const int32_t* idx_dev, const void* shift_dev,

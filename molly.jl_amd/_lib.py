@@ -66,6 +66,11 @@ class HaloRoutes(C.Structure):
                 ("dst_row", C.POINTER(C.c_int64)), ("recv_rows", C.POINTER(C.c_int64))]
 
 
+class LaunchTrial(C.Structure):
+    """mhip_launch_trial: one timed workgroup shape of mhip_optimize_launch_config"""
+    _fields_ = [("block_atoms", C.c_int32), ("j_split", C.c_int32), ("us_per_pass", C.c_float)]
+
+
 IPC_HANDLE_BYTES = 64
 
 # every entry point of include/mollyhip.h: name -> (restype, argtypes)
@@ -134,6 +139,8 @@ SIGNATURES = {
     "mhip_plan_decide": (_I32, [_P, _I64, C.POINTER(C.c_float), C.POINTER(_I32), C.POINTER(_I32)]),
     "mhip_halo_region": (_I32, [_P, _I64, _I32, _I32, _P]),
     "mhip_halo_open_peer": (_I32, [_P, _I32, _P]),
+    "mhip_set_launch_config": (_I32, [_P, _I32, _I32]),
+    "mhip_optimize_launch_config": (_I32, [_P, _I32, C.POINTER(LaunchTrial), _I32, C.POINTER(_I32)]),
     "mhip_halo_selftest": (_I32, [_P, C.POINTER(_I32)]),
     "mhip_set_halo_routes": (_I32, [_P, C.POINTER(HaloRoutes)]),
     "mhip_domain_run": (_I32, [_P, _I64, _I64, _D, _I32, _P, _I32, C.POINTER(_I64), C.POINTER(_I32), C.POINTER(_I64)]),

@@ -559,6 +559,22 @@ def find_neighbors(sys, step_n=0):
     return NeighborList(i, j, sp)
 
 
+def optimize_launch_config(sys, n_passes=20):
+    """optimize_cuda_launch_config!(sys) (src/cuda_config.jl:53-62, ext/MollyCUDAExt.jl:594-642): time the candidate workgroup shapes of the
+    search / pair kernels on this system, keep the fastest; returns [(block_atoms, j_split, µs per force pass), …] (µs < 0: not launchable)."""
+    L = _lib.lib()
+    sys.push_state(velocities=False)
+    tr = (_lib.LaunchTrial * 16)()
+    n = C.c_int32(0)
+    sys._check(L.mhip_optimize_launch_config(sys.engine(), int(n_passes), tr, 16, C.byref(n)))
+    return [(t.block_atoms, t.j_split, float(t.us_per_pass)) for t in tr[: min(n.value, 16)]]
+
+
+def set_launch_config(sys, block_atoms=0, j_split=0):
+    """set_cuda_launch_config!(sys; …) / reset_cuda_launch_config!(sys) with the defaults (src/cuda_config.jl:17-47)."""
+    sys._check(_lib.lib().mhip_set_launch_config(sys.engine(), int(block_atoms), int(j_split)))
+
+
 def remove_CM_motion(sys):
     """remove_CM_motion!(sys) (spatial.jl:901-929)."""
     L = _lib.lib()

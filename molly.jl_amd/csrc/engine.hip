@@ -95,6 +95,8 @@ struct EngineBase {
     virtual void halo_open_peer(int32_t, const void*) = 0;
     virtual void set_halo_routes(const mhip_halo_routes*) = 0;
     virtual int halo_selftest() = 0;
+    virtual void set_launch_config(int, int) = 0;
+    virtual int tune_launch(int, mhip_launch_trial*, int) = 0;
     virtual void domain_run(int64_t, int64_t, double, int32_t, double*, int32_t, int64_t*, int32_t*, int64_t*) = 0;
 };
 
@@ -414,11 +416,72 @@ template <class T> class Engine final : public EngineBase {
         else if (n_owned >= 40000) { bi = 128; js = 4; }
         else { bi = 64; js = 16; }
         bi = env_int("MOLLYHIP_BLOCK_I", bi); js = env_int("MOLLYHIP_J_SPLIT", js);
+        if (user_bi) { bi = user_bi; js = user_js; }         // mhip_set_launch_config / the winner of mhip_optimize_launch_config
         if (bi != 64 && bi != 128 && bi != 256) throw ApiError{MHIP_ERR_INVALID, "MOLLYHIP_BLOCK_I must be 64, 128 or 256"};
         js = std::min(js, MAX_THREADS / bi);                // the block kernels' launch bound (fp64: 512 lanes, 256 VGPRs per lane)
         if (js < 1) throw ApiError{MHIP_ERR_INVALID, "MOLLYHIP_J_SPLIT must be positive"};
         BI = bi; JS = js;
         estimate_capacities();
+    }
+
+    // ≙ set_cuda_launch_config! / reset_cuda_launch_config! (src/cuda_config.jl:17-47): the workgroup shape of the search and pair
+    // kernels, block_atoms i-atoms × j_split waves per atom's list; (0, 0) returns to the automatic choice.  Lists are rebuilt.
+    int user_bi = 0, user_js = 0;
+    void set_launch_config(int bi, int js) override {
+        if (bi == 0 && js == 0) { user_bi = user_js = 0; }
+        else {
+            if (bi != 64 && bi != 128 && bi != 256) throw ApiError{MHIP_ERR_INVALID, "block_atoms must be 64, 128 or 256 (or 0, 0 for the automatic choice)"};
+            if (js < 1 || (js & (js - 1)) || bi * js > MAX_THREADS) throw ApiError{MHIP_ERR_INVALID, "j_split must be a power of two with block_atoms * j_split within the launch bound (1024 lanes in fp32, 512 in fp64)"};
+            user_bi = bi; user_js = js;
+        }
+        flush_cm();
+        choose_blocking(); stale = true;
+    }
+
+    // ≙ optimize_cuda_launch_config! (ext/MollyCUDAExt.jl:594-642, src/cuda_config.jl:53-62): time a small candidate set on THIS system
+    // and keep the winner.  A trial = lists rebuilt in that shape (search + prune, untimed), then n_passes plain force passes between
+    // two HIP events.  Shapes whose tile does not fit the LDS, or that the build had to shrink, are reported with us_per_pass < 0 /
+    // under the shape they ended in.  A shape set by mhip_set_launch_config is replaced by the winner.
+    int tune_launch(int n_passes, mhip_launch_trial* trials, int max_trials) override {
+        if (!state_set || !params_set) throw ApiError{MHIP_ERR_STATE, "set_atoms and set_state must be called before tuning"};
+        if (n_ghost > 0) throw ApiError{MHIP_ERR_UNSUPPORTED, "launch shapes are tuned on single-domain contexts (the ranks of a decomposition must agree on one)"};
+        if (n_passes < 1) throw ApiError{MHIP_ERR_INVALID, "n_passes must be positive"};
+        static const int cand[][2] = {{256, 4}, {256, 2}, {128, 8}, {128, 4}, {128, 2}, {64, 16}, {64, 8}};
+        flush_cm();
+        const int64_t step = last_build_step == std::numeric_limits<int64_t>::min() ? 0 : last_build_step;
+        hipEvent_t e0, e1;
+        MHIP_HIP(hipEventCreate(&e0)); MHIP_HIP(hipEventCreate(&e1));
+        int n = 0, best_bi = 0, best_js = 0; float best = 0;
+        for (auto& c : cand) {
+            if (c[0] * c[1] > MAX_THREADS || (int64_t)c[0] > std::max<int64_t>(n_owned, 64)) continue;
+            bool seen = false;
+            for (int k = 0; k < n && k < max_trials; ++k) seen |= trials[k].block_atoms == c[0] && trials[k].j_split == c[1];
+            if (seen) continue;                                // an earlier candidate was shrunk to this shape
+            float us = -1.f;
+            try {
+                user_bi = c[0]; user_js = c[1];
+                choose_blocking(); stale = true; cur_dt = 0;
+                ensure_built(step); pass_step = step;
+                launch_pair_kernel(false);                     // with a dual list: the pruning pass
+                if (prune_disp_exceeded) { after_forces(step); launch_pair_kernel(false); }
+                launch_pair_kernel(false);
+                MHIP_HIP(hipEventRecord(e0, stream));
+                for (int k = 0; k < n_passes; ++k) launch_pair_kernel(false);
+                MHIP_HIP(hipEventRecord(e1, stream));
+                MHIP_HIP(hipEventSynchronize(e1));
+                float ms = 0; MHIP_HIP(hipEventElapsedTime(&ms, e0, e1));
+                us = ms * 1000.f / (float)n_passes;
+            } catch (const ApiError& err) {
+                if (err.code != MHIP_ERR_CAPACITY) { user_bi = user_js = 0; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); throw; }
+            }
+            if (n < max_trials && trials) { trials[n].block_atoms = us < 0 ? c[0] : BI; trials[n].j_split = us < 0 ? c[1] : JS; trials[n].us_per_pass = us; }
+            ++n;
+            if (us > 0 && (best_bi == 0 || us < best)) { best = us; best_bi = BI; best_js = JS; }
+        }
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        user_bi = best_bi; user_js = best_js;                  // (0, 0 = automatic, when nothing could be timed)
+        choose_blocking(); stale = true; frc_valid = false;
+        return n;
     }
 
     void estimate_capacities() {
@@ -2170,6 +2233,15 @@ int32_t mhip_vv_halo_mid(mhip_ctx* ctx, int64_t step_n, double dt, int32_t flags
 }
 int32_t mhip_halo_region(mhip_ctx* ctx, int64_t rows_capacity, int32_t world, int32_t rank, void* ipc_handle_out) { NEED_CTX(); return guard(ctx, [&] { ctx->e->halo_region(rows_capacity, world, rank, ipc_handle_out); }); }
 int32_t mhip_halo_open_peer(mhip_ctx* ctx, int32_t rank, const void* ipc_handle) { NEED_CTX(); return guard(ctx, [&] { ctx->e->halo_open_peer(rank, ipc_handle); }); }
+int32_t mhip_set_launch_config(mhip_ctx* ctx, int32_t block_atoms, int32_t j_split) { NEED_CTX(); return guard(ctx, [&] { ctx->e->set_launch_config(block_atoms, j_split); }); }
+int32_t mhip_optimize_launch_config(mhip_ctx* ctx, int32_t n_passes, mhip_launch_trial* trials, int32_t max_trials, int32_t* n_trials) {
+    NEED_CTX();
+    return guard(ctx, [&] {
+        if (max_trials < 0 || (max_trials > 0 && !trials)) throw mhip::ApiError{MHIP_ERR_INVALID, "trials / max_trials"};
+        const int n = ctx->e->tune_launch(n_passes, trials, max_trials);
+        if (n_trials) *n_trials = n;
+    });
+}
 int32_t mhip_halo_selftest(mhip_ctx* ctx, int32_t* ok) { NEED_CTX(); return guard(ctx, [&] { if (!ok) throw mhip::ApiError{MHIP_ERR_INVALID, "null output"}; *ok = ctx->e->halo_selftest(); }); }
 int32_t mhip_set_halo_routes(mhip_ctx* ctx, const mhip_halo_routes* routes) { NEED_CTX(); return guard(ctx, [&] { ctx->e->set_halo_routes(routes); }); }
 int32_t mhip_domain_run(mhip_ctx* ctx, int64_t first_step, int64_t n_steps, double dt, int32_t remove_cm_every, double* cm_parts_dev, int32_t n_parts,

@@ -1,7 +1,7 @@
 """INTEGRATION.md is the reference-side binding (Julia `ccall`s); Julia is not installed here, so nothing executes it.  This guard
 keeps the text from drifting: every `ccall((:mhip_…, libmollyhip), Ret, (ArgTypes…), …)` of the file is checked against the
 prototype of include/mollyhip.h — the symbol exists, the argument count matches, every Julia argument type is compatible with
-the C parameter type, the return type matches — and the two `struct Mhip…` mirror the C structs field by field."""
+the C parameter type, the return type matches — and the `struct Mhip…` definitions mirror the C structs field by field."""
 import os
 import re
 
@@ -58,10 +58,10 @@ JULIA_TO_C = {
     "Ptr{Int32}": {"int32_t*"}, "Ptr{UInt8}": {"uint8_t*"}, "Ptr{Float64}": {"double*", "void*"}, "Ptr{UInt32}": {"uint32_t*"},
     "Ptr{T}": {"void*"},                                     # arrays of the working precision travel as const void*
     "Ref{Float64}": {"double*"}, "Ref{Int64}": {"int64_t*"}, "Ref{Int32}": {"int32_t*"},
-    "Ref{Ptr{Cvoid}}": {"mhip_ctx**"}, "Ref{MhipConfig}": {"mhip_config*"},
+    "Ref{Ptr{Cvoid}}": {"mhip_ctx**"}, "Ref{MhipConfig}": {"mhip_config*"}, "Ptr{MhipLaunchTrial}": {"mhip_launch_trial*"},
     "Cstring": {"char*"},
 }
-JULIA_FIELD = {"Int32": "int32_t", "Int64": "int64_t", "Float64": "double"}
+JULIA_FIELD = {"Int32": "int32_t", "Int64": "int64_t", "Float64": "double", "Float32": "float"}
 
 
 def julia_ccalls(text):
@@ -113,7 +113,7 @@ def test_every_ccall_matches_the_header():
 
 def test_julia_structs_mirror_the_c_structs():
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    for jname, cname in (("MhipInteractions", "mhip_interactions"), ("MhipConfig", "mhip_config")):
+    for jname, cname in (("MhipInteractions", "mhip_interactions"), ("MhipConfig", "mhip_config"), ("MhipLaunchTrial", "mhip_launch_trial")):
         m = re.search(r"struct " + jname + r"\n(.*?)\nend", text, flags=re.S)
         assert m, jname
         jfields = []
