@@ -133,6 +133,7 @@ typedef struct mhip_stats {
     int64_t prof_calls[8];
     int64_t n_outer_builds;        /* searches with the outer radius (dual pair list)             */
     int64_t n_filter_passes;
+    int64_t tile_segments;         /* LDS segments the largest tile of the last force pass was walked in (1: resident as a whole) */
 } mhip_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */

@@ -215,7 +215,7 @@ template <class T> class Engine final : public EngineBase {
     const bool keep_lists_on_set_state = env_int("MOLLYHIP_SET_STATE_REBUILDS", 0) == 0;
     int64_t last_build_step = std::numeric_limits<int64_t>::min();
     int64_t n_rebuilds = 0, n_force_calls = 0; double last_rebuild_ms = 0;
-    size_t lds_force = 0; int tile_lds = 0; bool segmented = false;
+    size_t lds_force = 0; int tile_lds = 0; bool segmented = false; int last_pass_tile = 0;
     Prof prof;
     // MOLLYHIP_TRACE=1: drain the stream, then name the launch that follows on stderr — the last name a dying process printed is the
     // kernel that faulted (a GPU fault aborts the process from the runtime's callback, no status ever comes back)
@@ -890,6 +890,7 @@ template <class T> class Engine final : public EngineBase {
         const bool prune = dual && !inner_valid && !energy;
         const size_t prune_extra = prune ? prune_lds_bytes(std::min(T_cap, max_tile + 1), BI * JS) + 16 : 0;   // a tile that fills the LDS is segmented a little earlier
         carve_force_lds(use_inner ? max_tile_in : max_tile, prune_extra);
+        last_pass_tile = use_inner ? max_tile_in : max_tile;
         A.T_lds = tile_lds;
         if (use_inner) { A.tile_idx = tile_idx_in.p; A.tile_cnt = tile_cnt_in.p; }
         A.nbr = use_inner ? nbr_in.p : nbr.p; A.wave_rows = use_inner ? wave_rows_in.p : wave_rows.p;
@@ -2054,6 +2055,7 @@ template <class T> class Engine final : public EngineBase {
         s->n_atoms = n_tot; s->n_owned = n_owned; s->n_ghost = n_ghost; s->n_rebuilds = n_rebuilds; s->n_force_calls = n_force_calls;
         s->n_blocks = n_blocks; s->block_atoms = BI; s->j_split = JS; s->minimg_mode = minimg ? 1 : 0; s->max_tile_atoms = max_tile;
         s->last_rebuild_ms = last_rebuild_ms; s->lds_bytes = (int64_t)lds_force;
+        s->tile_segments = segmented ? cdiv(std::max(last_pass_tile, 1), std::max(tile_lds, 1)) : 1;
         s->n_list_slots = total_rows * 4 * WAVE;
         if (!stale) {
             std::vector<int32_t> tc(n_blocks);
