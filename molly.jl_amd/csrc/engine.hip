@@ -400,7 +400,7 @@ template <class T> class Engine final : public EngineBase {
     size_t build_lds_bytes(int tcap, int bi, int ccap, bool walk = true) const {
         // tile (coords + slot) | max(cell tables, per-wave candidate bit masks) | scan scratch
         // tile (coords + caller index) | cell tables | scan scratch | per-lane exception lists
-        return (size_t)tcap * (sizeof(float4) + 4) + (2 * (size_t)ccap + 2) * 4 + 8 + (size_t)bi * JS * 4 + (has_exc ? (size_t)X_CAP * bi * 4 : 0) + (walk ? ((size_t)ccap + 2) * 4 : 0) + 64;   // … | first tile slot per box cell (walk)
+        return (size_t)tcap * (3 * sizeof(float) + (has_exc ? 4 : 0)) + (2 * (size_t)ccap + 2) * 4 + 8 + (size_t)bi * JS * 4 + (has_exc ? (size_t)X_CAP * bi * 4 : 0) + (walk ? ((size_t)ccap + 2) * 4 : 0) + 64;   // … | first tile slot per box cell (walk)
     }
     size_t force_lds_bytes(int tlds) const {
         const bool per_atom_lj = (ljm == LJ_DIST || ljm == LJ_GENERIC);

@@ -310,9 +310,14 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
     const int wv = li >> 6, NW = A.BI >> 6;                    // i-wave of my atom, i-waves per block
     // tile atoms in block-local coordinates, ALWAYS fp32: the search only needs them for the cheap pre-test, whose
     // 1e-4 band absorbs the rounding; decisions inside the band use the stored T coordinates from HBM
-    float4* t_pos = reinterpret_cast<float4*>(smem);
-    int32_t* t_orig = reinterpret_cast<int32_t*>(t_pos + A.T_cap);   // caller index of each tile atom
-    int32_t* c_raw = t_orig + A.T_cap;                        // C_cap + 1: offsets of the cell-pruned candidate stream
+    // Three arrays, 12 bytes per tile atom (+ 4 for the caller index where exception lists need it): with 16-byte records + index the
+    // 4 300-atom tile of the 1M-atom fluid's outer search took 104 KB and ONE 512-lane block fitted a CU — two waves per SIMD.
+    float* t_x = reinterpret_cast<float*>(smem);
+    float* t_y = t_x + A.T_cap;
+    float* t_z = t_y + A.T_cap;
+    int32_t* t_orig = reinterpret_cast<int32_t*>(t_z + A.T_cap);     // caller index of each tile atom (only with exception lists)
+    int32_t* c_raw = t_orig + ((XL && A.xl_start) ? A.T_cap : 0);    // C_cap + 1: offsets of the cell-pruned candidate stream
+    auto t_pos = [&](int t) { return make_float4(t_x[t], t_y[t], t_z[t], 0.f); };
     int32_t* c_rank = c_raw + (A.C_cap + 1);                  // C_cap: Hilbert rank of each box cell
     int32_t* part = c_rank + A.C_cap + 1;                     // nthr
     uint32_t* x_part = reinterpret_cast<uint32_t*>(part + nthr);   // [X_cap][BI] per-atom exception lists (only if xl_start)
@@ -471,7 +476,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
             }
         }
 #pragma unroll
-        for (int u = 0; u < SUB; ++u) if (base + u * nthr + tid < nraw) { p[u] = A.pos[s[u]]; og[u] = A.orig[s[u]]; }
+        for (int u = 0; u < SUB; ++u) if (base + u * nthr + tid < nraw) { p[u] = A.pos[s[u]]; og[u] = (XL && A.xl_start) ? A.orig[s[u]] : 0; }
 #pragma unroll
         for (int u = 0; u < SUB; ++u) {
             if (base + u * nthr + tid < nraw) {
@@ -492,7 +497,9 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
             int tot = 0;
             for (int w = 0; w < NW_ALL; ++w) { const int c = s_wtot[u * NW_ALL + w]; if (w < wv_all) dst += c; tot += c; }
             if (keep[u] && dst < A.T_cap) {
-                t_pos[dst] = make_float4((float)p[u].x, (float)p[u].y, (float)p[u].z, 0.f); t_orig[dst] = og[u]; A.tile_idx[(int64_t)b * A.T_cap + dst] = s[u];
+                t_x[dst] = (float)p[u].x; t_y[dst] = (float)p[u].y; t_z[dst] = (float)p[u].z;
+                if (XL && A.xl_start) t_orig[dst] = og[u];
+                A.tile_idx[(int64_t)b * A.T_cap + dst] = s[u];
                 const int64_t rel = (int64_t)s[u] - (int64_t)b * A.BI;
                 if (rel >= 0 && rel < A.BI) s_self[rel] = dst;     // an i-atom always survives the pruning of its own block
                 if constexpr (WALK) atomicAdd(&t_off[qc], 1);      // tile atoms per box cell (the compaction keeps the cell-major order)
@@ -603,7 +610,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
                     const int last = t1 - 1;
                     for (; t < t1; t += 4 * A.JS) {
                         const int ta = t, tb = t + A.JS, tc = t + 2 * A.JS, td = t + 3 * A.JS;
-                        const float4 pa = t_pos[ta], pb = t_pos[min(tb, last)], pc = t_pos[min(tc, last)], pd = t_pos[min(td, last)];
+                        const float4 pa = t_pos(ta), pb = t_pos(min(tb, last)), pc = t_pos(min(tc, last)), pd = t_pos(min(td, last));
                         consider(ta, pa);
                         if (tb < t1) consider(tb, pb);
                         if (tc < t1) consider(tc, pc);
@@ -619,7 +626,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
             float4 pl = make_float4(0.f, 0.f, 0.f, 0.f); bool near = false;
             T4 px = make4<T>(T(0), T(0), T(0), T(0));      // stored coordinates of my candidate (exact_only blocks)
             if (jl < tile_n) {
-                pl = t_pos[jl];
+                pl = t_pos(jl);
                 if (exact_only) { near = true; px = A.pos[A.tile_idx[(int64_t)b * A.T_cap + jl]]; }
                 else {
                     float pc[3] = {pl.x, pl.y, pl.z}, acc = 0.f;
