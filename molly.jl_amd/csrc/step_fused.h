@@ -36,10 +36,13 @@ inline void launch_pme_bonded_fused(hipStream_t s, Pme<T>& pme, Bonded<T>& bonde
     bonded.ensure_roles(s, cap);
     const BondedArgs<T> B = bonded.slot_args(G, I, pos, inv);
     const int n_term_wg = cdiv(bonded.n_blocks(), 4);
-    const int n_spread = (int)std::min<int64_t>(cdiv(n_owned, (int64_t)64), 2048);
+    static const int sb = [] { const char* v = std::getenv("MOLLYHIP_PME_SPREAD_BATCH"); return v && *v ? std::atoi(v) : 64; }();   // atoms per spreading batch
+    const int n_spread = (int)std::min<int64_t>(cdiv(n_owned, (int64_t)(sb <= 16 ? 16 : sb <= 32 ? 32 : 64)), 4096);
     auto spread = [&](auto order_tag) {
         constexpr int ORDER = decltype(order_tag)::value;
-        hipLaunchKernelGGL((k_spread_bonded<T, ORDER, 64>), dim3(n_spread + n_term_wg), dim3(256), 0, s, n_owned, pos, pme.rgrid.p, pme.P, n_spread, B);
+        if (sb <= 16) hipLaunchKernelGGL((k_spread_bonded<T, ORDER, 16>), dim3(n_spread + n_term_wg), dim3(256), 0, s, n_owned, pos, pme.rgrid.p, pme.P, n_spread, B);
+        else if (sb <= 32) hipLaunchKernelGGL((k_spread_bonded<T, ORDER, 32>), dim3(n_spread + n_term_wg), dim3(256), 0, s, n_owned, pos, pme.rgrid.p, pme.P, n_spread, B);
+        else hipLaunchKernelGGL((k_spread_bonded<T, ORDER, 64>), dim3(n_spread + n_term_wg), dim3(256), 0, s, n_owned, pos, pme.rgrid.p, pme.P, n_spread, B);
     };
     if (pme.order == 4) spread(std::integral_constant<int, 4>{}); else if (pme.order == 5) spread(std::integral_constant<int, 5>{}); else spread(std::integral_constant<int, 6>{});
     pme.z_r2c(s);
