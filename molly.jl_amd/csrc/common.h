@@ -15,6 +15,8 @@ constexpr int WAVE = 64;
 // dynamic LDS a kernel may ask for: the 160 KiB of a gfx950 CU (MI355X_MICROARCH.md) minus room for the kernels' static __shared__
 // arrays (k_build: ≈ 1.6 KB) — the sum is what hipFuncSetAttribute / the launch are checked against
 constexpr int MAX_LDS_BYTES = 160 * 1024 - 2048;
+constexpr int COUL_EWALD_EXACT = 4;        // pair-kernel variant of MHIP_COUL_EWALD_DIRECT with the libm erfc (approximate_erfc = false): a template value, so that
+                                           // the default Abramowitz-Stegun form is straight-line code in the loop
 constexpr int TILE_SLOT_MAX = 32767;        // 15-bit tile slot + 1-bit special flag per list entry
 
 template <class T> struct Vec;

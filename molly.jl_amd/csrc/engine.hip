@@ -874,7 +874,10 @@ template <class T> class Engine final : public EngineBase {
         case MHIP_COUL_NONE: launch_forces_tc<T, MHIP_COUL_NONE>(A, ljm, energy, minimg, segmented, prune, lds_force, threads, stream); break;
         case MHIP_COUL_PLAIN: launch_forces_tc<T, MHIP_COUL_PLAIN>(A, ljm, energy, minimg, segmented, prune, lds_force, threads, stream); break;
         case MHIP_COUL_REACTION_FIELD: launch_forces_tc<T, MHIP_COUL_REACTION_FIELD>(A, ljm, energy, minimg, segmented, prune, lds_force, threads, stream); break;
-        default: launch_forces_tc<T, MHIP_COUL_EWALD_DIRECT>(A, ljm, energy, minimg, segmented, prune, lds_force, threads, stream); break;
+        default:
+            if (I.approx_erfc) launch_forces_tc<T, MHIP_COUL_EWALD_DIRECT>(A, ljm, energy, minimg, segmented, prune, lds_force, threads, stream);
+            else launch_forces_tc<T, COUL_EWALD_EXACT>(A, ljm, energy, minimg, segmented, prune, lds_force, threads, stream);
+            break;
         }
     }
     // pairwise forces of the current coordinates into frc[cur] (overwrites); energy → red_part[0..n_blocks)

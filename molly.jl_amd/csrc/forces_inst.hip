@@ -1,12 +1,12 @@
 // forces_inst.hip — the k_forces instantiations of ONE (precision, Coulomb kind), chosen with -DMHIP_INST_T=float|double and
-// -DMHIP_INST_COUL=0..3: eight small translation units instead of one that takes minutes (the pair kernel has 48 variants per
+// -DMHIP_INST_COUL=0..4 (4 = Ewald with the libm erfc): ten small translation units instead of one that takes minutes (the pair kernel has 48 variants per
 // precision and Coulomb kind: LJ mode × {forces, forces + prune, energy} × minimum-image mode × segmented tile).  The fp32 one-type
 // LJ variants live in forces_uniform.hip (SLP vectoriser off).
 #include "kernels.h"
 #include "forces_launch.h"
 
 #ifndef MHIP_INST_T
-#error "compile with -DMHIP_INST_T=float|double -DMHIP_INST_COUL=0|1|2|3"
+#error "compile with -DMHIP_INST_T=float|double -DMHIP_INST_COUL=0|1|2|3|4"
 #endif
 
 namespace mhip {

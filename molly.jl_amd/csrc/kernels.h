@@ -1099,6 +1099,10 @@ k_forces(ForceArgs<T> A) {
     else pi = tri_local ? localise(pi, std::true_type{}) : localise(pi, std::false_type{});
     T2 lji = make2<T>(T(0), T(0));
     if constexpr (PER_ATOM_LJ) lji = A.lj[valid ? si : (int64_t)b * A.BI];
+    // fp32: the tile (and this lane's own record) carries √ϵ, 0 where σ = 0 — GeometricMixing + LJZeroShortcut become one product per pair
+    constexpr bool PRE_E = PER_ATOM_LJ && sizeof(T) == 4;
+    auto pre_e = [](T2 v) { if constexpr (PRE_E) v.y = v.x == T(0) ? T(0) : M<T>::sqrt(v.y); return v; };
+    lji = pre_e(lji);
     // this wave's own sub-list (the j-split was done by k_build); the row count is the same for all 64 lanes: a scalar
     const int rows = __builtin_amdgcn_readfirstlane(A.wave_rows[(b * A.JS + js) * (A.BI >> 6) + (li >> 6)]);
     const uint2* my_rows = A.nbr + (((int64_t)b * A.JS + js) * A.R_cap) * A.BI + li;
@@ -1217,7 +1221,7 @@ k_forces(ForceArgs<T> A) {
                         const T4 pl = localise(p[k], tri_tag);
                         if (packed3) { l_p3[t] = (float)pl.x; l_p3[SOA_STRIDE + t] = (float)pl.y; l_p3[2 * SOA_STRIDE + t] = (float)pl.z; }
                         else l_pos[t] = pl;
-                        if constexpr (PER_ATOM_LJ) l_lj[t] = q[k];
+                        if constexpr (PER_ATOM_LJ) l_lj[t] = pre_e(q[k]);
                     }
                 }
             }
@@ -1370,7 +1374,7 @@ k_forces(ForceArgs<T> A) {
             uint2 e_next = (0 < rows) ? my_rows[0] : make_uint2(0, 0);
             // (the fp64 Ewald loop with the in-loop minimum image — 27-image search included — is not unrolled: four copies of it
             // exceed the 256 VGPRs of a 512-lane block and spill)
-            constexpr int UNROLL = (sizeof(T) == 8 && COULM == MHIP_COUL_EWALD_DIRECT) ? (MINIMG ? 1 : (LJM == LJ_GENERIC && ENERGY ? 2 : 4)) : 4;
+            constexpr int UNROLL = (sizeof(T) == 8 && (COULM == MHIP_COUL_EWALD_DIRECT || COULM == COUL_EWALD_EXACT)) ? (MINIMG ? 1 : (LJM == LJ_GENERIC && ENERGY ? 2 : 4)) : 4;
             for (int r = 0; r < rows; ++r) {
                 const uint2 e4 = e_next;
                 if (r + 1 < rows) e_next = my_rows[(int64_t)(r + 1) * A.BI];
@@ -1392,7 +1396,7 @@ k_forces(ForceArgs<T> A) {
                     // the triclinic minimum image folds ANY separation back into the cell, the far-away sentinel atom included
                     if constexpr (MINIMG) { if (G.triclinic && !real) r2 = T(1.0e30); }
                     if constexpr (PRUNE) { if (real && valid && r2 <= A.r_prune2) emit(make_entry((uint32_t)l_new[slot], entry_special(e, esh), esh)); }
-                    T fr = pair_eval<T, LJM, COULM, ENERGY>(A.I, r2, pi.w, pj.w, lji.x, ljj.x, lji.y, ljj.y, special, pe);
+                    T fr = pair_eval<T, LJM, COULM, ENERGY, PRE_E>(A.I, r2, pi.w, pj.w, lji.x, ljj.x, lji.y, ljj.y, special, pe);
                     fx -= fr * dx; fy -= fr * dy; fz -= fr * dz;   // force on i is −f (force.jl:873)
                     if constexpr (ENERGY) {
                         vir[0] += fr * dx * dx; vir[1] += fr * dy * dy; vir[2] += fr * dz * dz;

@@ -13,6 +13,7 @@ template <class T> struct M;
 template <> struct M<float> {
     __device__ static inline float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
     __device__ static inline float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+    __device__ static inline float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
     __device__ static inline float exp(float x) { return __expf(x); }
     __device__ static inline float erfc(float x) { return ::erfcf(x); }
     __device__ static inline float erf(float x) { return ::erff(x); }
@@ -37,6 +38,7 @@ template <> struct M<float> {
 template <> struct M<double> {
     __device__ static inline double rcp(double x) { return 1.0 / x; }
     __device__ static inline double sqrt(double x) { return ::sqrt(x); }
+    __device__ static inline double rsq(double x) { return 1.0 / ::sqrt(x); }
     __device__ static inline double exp(double x) { return ::exp(x); }
     __device__ static inline double erfc(double x) { return ::erfc(x); }
     __device__ static inline double erf(double x) { return ::erf(x); }
@@ -196,10 +198,15 @@ enum { LJ_OFF = 0, LJ_DIST = 1, LJ_GENERIC = 2, LJ_DIST_UNIFORM = 3 };   // UNIF
 
 // Sum over pairwise_inters for one pair (force.jl:79-92 / kernels.jl:3-17).  Returns `fr` such that the
 // force on atom j is fr·dr (and −fr·dr on atom i, force.jl:873-874) and, if ENERGY, adds the pair energy.
-template <class T, int LJM, int COULM, bool ENERGY>
+// PRE_E (the fp32 loops): ei, ej arrive as √ϵ — 0 for an atom with σ = 0 —, taken once per staged atom instead of once per pair.
+template <class T, int LJM, int COULM, bool ENERGY, bool PRE_E = false>
 __device__ inline T pair_eval(const InterP<T>& I, T r2, T qi, T qj, T si, T sj, T ei, T ej, bool special, T& pe) {
     T fr = T(0);
-    T inv_r2 = M<T>::rcp(r2);
+    // fp32 with a reaction field or Ewald needs 1/r as well: one v_rsq_f32 and a product instead of v_rcp_f32 + v_sqrt_f32
+    constexpr bool RSQ = sizeof(T) == 4 && (COULM == MHIP_COUL_REACTION_FIELD || COULM == MHIP_COUL_EWALD_DIRECT || COULM == COUL_EWALD_EXACT);
+    [[maybe_unused]] T inv_r1 = T(0);
+    T inv_r2;
+    if constexpr (RSQ) { inv_r1 = M<T>::rsq(r2); inv_r2 = inv_r1 * inv_r1; } else inv_r2 = M<T>::rcp(r2);
     if constexpr (LJM == LJ_DIST_UNIFORM) {
         // one atom type: σ_mix = σ, ϵ_mix = ϵ (Lorentz / geometric mixing of equal values), hoisted to the host
         T six = I.lj_s2 * inv_r2; six = six * six * six;
@@ -210,8 +217,12 @@ __device__ inline T pair_eval(const InterP<T>& I, T r2, T qi, T qj, T si, T sj, 
         if constexpr (ENERGY) pe += in ? I.lj_4e * (six * six - six) * w : T(0);
     } else if constexpr (LJM != LJ_OFF) {
         T s = (si + sj) * T(0.5);                                   // LorentzMixing
-        T e = M<T>::sqrt(ei * ej);                                  // GeometricMixing
-        e = (si == T(0) || sj == T(0)) ? T(0) : e;                  // LJZeroShortcut (ϵ == 0 already yields 0)
+        T e;
+        if constexpr (PRE_E) e = ei * ej;                           // √ϵi·√ϵj, either factor 0 where σ = 0
+        else {
+            e = M<T>::sqrt(ei * ej);                                // GeometricMixing
+            e = (si == T(0) || sj == T(0)) ? T(0) : e;              // LJZeroShortcut (ϵ == 0 already yields 0)
+        }
         T w = special ? I.lj_w : T(1);
         if constexpr (LJM == LJ_DIST) {
             // DistanceCutoff: F/r = 24ϵ(2 s6² − s6)/r², zero past the cutoff (r ≤ rc ⇔ r² ≤ rc²)
@@ -234,7 +245,7 @@ __device__ inline T pair_eval(const InterP<T>& I, T r2, T qi, T qj, T si, T sj, 
         fr += cut_force(I.coul_cut, I.c_rc, I.c_ra, p, r) * M<T>::rcp(r) * w;
         if constexpr (ENERGY) pe += cut_pe(I.coul_cut, I.c_rc, I.c_ra, p, r) * w;
     } else if constexpr (COULM == MHIP_COUL_REACTION_FIELD) {
-        T inv_r = M<T>::sqrt(inv_r2);
+        T inv_r = RSQ ? inv_r1 : M<T>::sqrt(inv_r2);
         T kqq = I.ke * qi * qj;
         T krf = special ? T(0) : I.krf;                              // 1-4 pairs: no reaction field
         T crf = special ? T(0) : I.crf;
@@ -242,12 +253,12 @@ __device__ inline T pair_eval(const InterP<T>& I, T r2, T qi, T qj, T si, T sj, 
         bool in = r2 <= I.c_rc2;
         fr += in ? kqq * (inv_r - T(2) * krf * r2) * inv_r2 * w : T(0);
         if constexpr (ENERGY) pe += in ? kqq * (inv_r + krf * r2 - crf) * w : T(0);
-    } else if constexpr (COULM == MHIP_COUL_EWALD_DIRECT) {
-        T inv_r = M<T>::sqrt(inv_r2);
+    } else if constexpr (COULM == MHIP_COUL_EWALD_DIRECT || COULM == COUL_EWALD_EXACT) {
+        T inv_r = RSQ ? inv_r1 : M<T>::sqrt(inv_r2);
         T r = r2 * inv_r;
         T ar = I.alpha * r;
         T ex = M<T>::exp(-(ar * ar));
-        T ec = ewald_erfc(ar, ex, I.approx_erfc);
+        T ec = ewald_erfc(ar, ex, COULM == MHIP_COUL_EWALD_DIRECT ? 1 : 0);   // (the engine picks the variant by approximate_erfc)
         T kqq = I.ke * qi * qj;
         bool in = r2 <= I.c_rc2;
         T f3 = kqq * inv_r * inv_r2;
