@@ -643,6 +643,7 @@ template <class T> class Engine final : public EngineBase {
             last_prune_step = step_n;
         }
         stale = false; coords_moved = false; export_needs_search = false; ghost_flags_ok = false; ghost_flags_in_ok = false; last_build_step = step_n; ++n_rebuilds;
+        frc_run_total = false;   // the sort moved the atoms
         last_rebuild_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
 
@@ -1208,12 +1209,13 @@ template <class T> class Engine final : public EngineBase {
 
     // set_state raises these words on the device when a coordinate / a velocity really differs from what the engine held
     DBuf<int32_t> state_changed; bool state_pending = false;
+    bool frc_before_set_state = false;   // were the forces current when the (possibly identical) coordinates came in?
     void set_state(const void* xyz, const void* v, int mem_kind) override {
         flush_cm();
         const T* dx = to_device(xyz, 3 * (size_t)n_tot, mem_kind, stage_a);
         const T* dv = to_device(v, 3 * (size_t)n_owned, mem_kind, stage_b);
         state_changed.reserve(2);
-        if (!state_pending) MHIP_HIP(hipMemsetAsync(state_changed.p, 0, 2 * sizeof(int32_t), stream));
+        if (!state_pending) { MHIP_HIP(hipMemsetAsync(state_changed.p, 0, 2 * sizeof(int32_t), stream)); frc_before_set_state = frc_valid; }
         state_pending = true;
         hipLaunchKernelGGL(k_scatter_state<T>, dim3(cdiv(n_tot, 256)), dim3(256), 0, stream, n_tot, n_owned, (const int32_t*)inv.p, dx, dv, pos[cur].p, vel[cur].p, G, state_changed.p);
         MHIP_HIP(hipGetLastError());
@@ -1236,7 +1238,8 @@ template <class T> class Engine final : public EngineBase {
             int32_t h[2] = {1, 1};
             MHIP_HIP(hipMemcpyAsync(h, state_changed.p, sizeof(h), hipMemcpyDeviceToHost, stream));
             MHIP_HIP(hipStreamSynchronize(stream));
-            if (!h[0]) coords_moved = false;
+            if (!h[0]) { coords_moved = false; if (frc_before_set_state && !stale) frc_valid = true; }   // the same coordinates again: what was computed for them stands
+            frc_before_set_state = false;
             vel_new = h[1] != 0;
             if (h[0] || h[1]) trk_issued = false;      // a measurement in flight describes the state that was replaced
         }
@@ -1471,9 +1474,21 @@ template <class T> class Engine final : public EngineBase {
     }
 
     // simulators.jl:561-571: wrap (done by set_state / the integrator), neighbours, forces at first_step
+    // frc[cur] holds the TOTAL force of the coordinates the engine holds, in the current order (left there by the last step of a run
+    // that had no side arrays pending).  A run that continues from exactly that state — the chunked simulate! of test/simulation.jl:16-57,
+    // a benchmark's consecutive windows — finds the forces of its first step already there: the reference recomputes them
+    // (simulators.jl:564-571), which yields the same numbers from the same lists in the same order.
+    bool frc_run_total = false;
+    const bool reuse_run_forces = env_int("MOLLYHIP_REUSE_RUN_FORCES", 1) != 0;
+    int64_t n_reused_starts = 0;
     void vv_init(int64_t first_step) override {
         if (!state_set) throw ApiError{MHIP_ERR_STATE, "set_state must be called before vv_run"};
+        lists_after_set_state();           // (a set_state that brought the SAME coordinates leaves the forces valid)
+        const bool had = frc_run_total && frc_valid && reuse_run_forces && !stale && !coords_moved;
+        const int64_t reb0 = n_outer, fil0 = n_filters; const bool inner0 = inner_valid;   // (searches re-sort, prunes change the list walked)
+        frc_run_total = false;
         start_lists(first_step);
+        if (had && n_outer == reb0 && n_filters == fil0 && inner_valid == inner0 && (inner_valid || !dual) && !prune_disp_exceeded) { ++n_reused_starts; return; }
         step_forces(first_step);
         fold_side_forces();
     }
@@ -1921,6 +1936,7 @@ template <class T> class Engine final : public EngineBase {
                 MHIP_HIP(hipEventRecord(ev_trk, stream));
                 trk_issued = true; trk_step = step + 1; trk_prev_vmax = last_vmax; trk_prune_id = n_filters; trk_outer_id = n_outer;
             }
+            if (step == last) frc_run_total = pend_a == nullptr && pend_b == nullptr && n_ghost == 0;   // (side arrays are added by the kick, not folded)
             pend_a = pend_b = nullptr;
             cm_pending = 0; cm_ext = nullptr;
             if (cm) { cm_pending = 2; cm_ext = cm_out; n_cm_step = nb; half ^= 1; }

@@ -195,3 +195,26 @@ def test_new_velocities_on_old_coordinates_are_looked_at_before_the_lists_are_tr
     after = b.stats()
     assert np.array_equal(a.coords, b.coords) and np.array_equal(a.velocities, b.velocities)
     assert after["n_outer_builds"] == before["n_outer_builds"]
+
+
+def test_a_continued_run_finds_its_first_forces_already_there(pkg):
+    """simulate!(sys, sim, n) recomputes the forces of its first step (simulators.jl:564-571); a run that continues from exactly the
+    state the previous one left — same coordinates, same order, same lists — gets the same numbers from the force array of that run's
+    last step.  Anything that could change them (new coordinates, a search, a prune) makes the first pass happen as before."""
+    case = S.lj_fluid(12, dtype=np.float32)
+    a = case.system(pkg, np.float32)
+    sim = pkg.VelocityVerlet(dt=0.002, remove_CM_motion=0)    # (with it a chunk end applies v_cm at another point of the launch sequence: equal to rounding only, DESIGN §5)
+    pkg.simulate(a, sim, 7)
+    c0 = a.stats()["n_force_calls"]
+    pkg.simulate(a, sim, 6, init_step=7)                      # steps 8 … 13: the pass at the start is not needed
+    c1 = a.stats()["n_force_calls"]
+    assert c1 - c0 <= 6 + 1 and c1 - c0 >= 6                 # (+1 only if step 10's check asked for a second pass)
+    b = case.system(pkg, np.float32)
+    pkg.simulate(b, sim, 13)
+    assert np.array_equal(a.coords, b.coords) and np.array_equal(a.velocities, b.velocities)   # bit for bit the uncut run
+    # new coordinates: the forces of the first step are computed again
+    a.coords = a.coords + np.float32(1e-4)
+    c2 = a.stats()["n_force_calls"]
+    pkg.simulate(a, sim, 3, init_step=13)
+    assert a.stats()["n_force_calls"] - c2 >= 4
+
