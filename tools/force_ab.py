@@ -41,6 +41,11 @@ def child(workload, steps, equil, static=False):
                                          "n_list_slots": st["n_list_slots"], "max_tile": st["max_tile_atoms"], "lds": st["lds_bytes"], "n_outer": st["n_outer_builds"], "n_prunes": st["n_filter_passes"]}))
         return
     run = lambda first, n: s._check(L.mhip_vv_run(ctx, first, n, dt, 1))
+    if os.environ.get("AB_STATS_FIRST"):
+        s._check(L.mhip_rebuild(ctx, 0)); s.stats()
+    if os.environ.get("AB_ALLOC_GB"):
+        import torch
+        keep = torch.empty(int(float(os.environ["AB_ALLOC_GB"]) * 2**30), dtype=torch.uint8, device="cuda"); keep.zero_()
     if equil:
         run(0, equil)
     run(equil, 200)
@@ -50,6 +55,8 @@ def child(workload, steps, equil, static=False):
     run(first, steps)
     s._check(L.mhip_synchronize(ctx))
     ms = (time.perf_counter() - t0) * 1e3 / steps
+    if os.environ.get("AB_STATS_BEFORE"):
+        s.stats()
     s._check(L.mhip_set_profiling(ctx, 1))
     run(first + steps, steps)
     st = s.stats()
