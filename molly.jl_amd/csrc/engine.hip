@@ -1921,7 +1921,11 @@ template <class T> class Engine final : public EngineBase {
             }
             step_forces(step);
             if (!pre && check_due(step, every)) { fold_side_forces(); refresh(step); }   // the sort permutes vel / frc with the atoms; Σ m v does not care
-            const int nb = std::min(cdiv(n_owned, 256), 1024);
+            // every block re-sums the previous step's per-block Σ m v partials (32 bytes each), so fewer, longer blocks pay: 1024 blocks
+            // re-read 32 MB from L2 per launch — more than the 21 MB of atoms of the 256k-atom fluid (13.0 → 10.0 µs with 256 blocks;
+            // 1M atoms: 21.2 → 20.2 µs with 512, 21.8 with 256)
+            static const int vv_blocks = env_int("MOLLYHIP_VV_BLOCKS", 0);
+            const int nb = std::min(cdiv(n_owned, 256), vv_blocks > 0 ? std::min(vv_blocks, 1024) : (int)std::max<int64_t>(256, std::min<int64_t>(512, n_owned / 2048)));
             const double* cm_in = cm_pending == 2 ? cm_src() : (const double*)nullptr;
             double* cm_out = cm ? cm_step.p + (size_t)half * 4 * 1024 : (double*)nullptr;
             prof.begin(2, stream);
