@@ -1032,7 +1032,7 @@ template <class T> struct ForceArgs {
 constexpr int SOA_STRIDES[3] = {2049, 3073, 4097};
 // dynamic LDS a PRUNE pass needs behind its tile: the renumbering table (2 bytes per tile atom of a segment), scan scratch, eight boxes,
 // the atoms' row counts (lane order) and the destination waves' row counts
-__host__ __device__ inline size_t prune_lds_bytes(int t_seg, int nthr) { return (size_t)(((t_seg + 8) & ~7) * 2) + ((size_t)nthr + 4) * 4 + 8 * 8 * 4 + ((size_t)nthr + 64) * 4 + 32; }
+__host__ __device__ inline size_t prune_lds_bytes(int t_seg, int nthr) { return (size_t)(((t_seg + 8) & ~7) * 2) + ((size_t)nthr + 4) * 4 + 8 * 8 * 4 + ((size_t)nthr + 64) * 4 + 16 * 8 + 32; }   // (+ the 16 byte-permute selectors of the row compaction)
 
 // (the plain fp32 one-type passes run four 512-lane blocks per CU = eight waves per SIMD, which takes <= 64 VGPRs: held by attribute)
 #ifndef MHIP_FAST_MIN_WAVES
@@ -1110,8 +1110,7 @@ k_forces(ForceArgs<T> A) {
     T fx = T(0), fy = T(0), fz = T(0), pe = T(0);
     [[maybe_unused]] T vir[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};   // ENERGY: Σ fr·(dx², dy², dz², dx·dy, dx·dz, dy·dz), the pair virial dr ⊗ f (force.jl:848-852)
     // PRUNE: inner-list emission state (same row format as k_build)
-    // PRUNE: the last eight entries kept, 16 bits each, newest in the top half of w3 (a 128-bit shift register: four v_alignbit per entry)
-    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    uint64_t acc = 0;          // the kept & 3 entries of the row being filled, oldest in the low 16 bits
     int kept = 0;
     uint2* out_rows = nullptr;
     if constexpr (PRUNE) out_rows = A.nbr_dst + (((int64_t)b * A.JS + js) * A.R_cap) * A.BI + li;
@@ -1120,7 +1119,7 @@ k_forces(ForceArgs<T> A) {
     // i-atoms is within the radius of none of them — so that the rows are emitted once, already renumbered (the marks taken during
     // the walk, as before, meant writing the rows, reading them back and writing them again: 1.9× the traffic of the pass)
     [[maybe_unused]] uint16_t* l_new = nullptr; [[maybe_unused]] int32_t* l_scan = nullptr; [[maybe_unused]] float* l_box = nullptr;
-    [[maybe_unused]] int32_t* l_cnt = nullptr; [[maybe_unused]] int32_t* l_wmax = nullptr;
+    [[maybe_unused]] int32_t* l_cnt = nullptr; [[maybe_unused]] int32_t* l_wmax = nullptr; [[maybe_unused]] const uint2* l_lut = nullptr;
     [[maybe_unused]] int n_new = 0;          // compacted tile atoms so far (block-uniform)
     [[maybe_unused]] int pos_l = li;         // PRUNE: the lane position this atom's rows are emitted at
     if constexpr (PRUNE) {
@@ -1129,6 +1128,19 @@ k_forces(ForceArgs<T> A) {
         l_box = reinterpret_cast<float*>(l_scan + nthr + 4);
         l_wmax = reinterpret_cast<int32_t*>(l_box + 64); l_cnt = l_wmax + 64;
         if (tid < 64) l_wmax[tid] = 0;
+        // selectors of the row compaction: for each keep mask of a row's four entries, the v_perm_b32 byte selectors that move the kept
+        // 16-bit entries, in order, to the low end of a 64-bit word (0x0c = a zero byte)
+        l_lut = reinterpret_cast<const uint2*>(l_cnt + nthr);
+        if (tid < 16) {
+            uint32_t sel[2] = {0x0c0c0c0cu, 0x0c0c0c0cu};
+            int p = 0;
+            for (int j = 0; j < 4; ++j) if ((tid >> j) & 1) {
+                const int sh = (p & 1) * 16;
+                sel[p >> 1] = (sel[p >> 1] & ~(0xffffu << sh)) | ((uint32_t)((2 * j) | ((2 * j + 1) << 8)) << sh);
+                ++p;
+            }
+            reinterpret_cast<uint2*>(l_cnt + nthr)[tid] = make_uint2(sel[0], sel[1]);
+        }
         if (A.cnt_src) {     // rank of my atom among its j-split group's atoms by (entries last time, index): its lane position in the rows emitted now
             l_cnt[tid] = ((int)A.cnt_src[((int64_t)b * A.JS + js) * A.BI + li] << 9) | li;
             __syncthreads();
@@ -1153,24 +1165,28 @@ k_forces(ForceArgs<T> A) {
         }
         if (A.snap_dst && js == 0 && valid) A.snap_dst[si] = pi_raw;
     }
-    // push: append entry e if k — no branch: the packed loop calls it for all four entries of a row and stores at most once per row
-    // (row_out) — four dependent exec-mask branches per row, each around a store test, were a quarter of the pruning pass
-    auto push = [&](uint32_t e, bool k) {
-        const uint32_t n0 = __builtin_amdgcn_alignbit(w1, w0, 16), n1 = __builtin_amdgcn_alignbit(w2, w1, 16), n2 = __builtin_amdgcn_alignbit(w3, w2, 16), n3 = __builtin_amdgcn_alignbit(e, w3, 16);
-        w0 = k ? n0 : w0; w1 = k ? n1 : w1; w2 = k ? n2 : w2; w3 = k ? n3 : w3;
-        kept += k ? 1 : 0;
+    // emit4: the four entries of an input row at once — keep mask → byte-permute selectors (LDS table) → the kept entries compacted to the
+    // low end of a 64-bit word → appended behind the kept & 3 entries pending; a row is stored when four are complete (at most one
+    // store per input row).  A 128-bit shift register with four v_alignbit + selects per ENTRY was 40 VALU instructions per row here.
+    [[maybe_unused]] auto emit4 = [&](uint32_t n0, uint32_t n1, uint32_t n2, uint32_t n3, bool k0, bool k1, bool k2, bool k3) {
+        const uint32_t m = (k0 ? 1u : 0u) | (k1 ? 2u : 0u) | (k2 ? 4u : 0u) | (k3 ? 8u : 0u);
+        const uint2 sel = l_lut[m];
+        const uint32_t x = __builtin_amdgcn_perm(n1, n0, 0x05040100u), y = __builtin_amdgcn_perm(n3, n2, 0x05040100u);   // the low halves only: a slot that is not kept may carry anything
+        const uint64_t p = ((uint64_t)__builtin_amdgcn_perm(y, x, sel.y) << 32) | __builtin_amdgcn_perm(y, x, sel.x);
+        const int np = kept & 3, sh = np * 16;
+        const uint64_t c_lo = acc | (p << sh), c_hi = (p >> 1) >> (63 - sh);     // (p >> (64 − sh), 0 for sh = 0)
+        const int cnt = __builtin_popcount(m);
+        const bool flush = np + cnt >= 4;
+        if (flush) out_rows[(int64_t)(kept >> 2) * A.BI] = make_uint2((uint32_t)c_lo, (uint32_t)(c_lo >> 32));
+        acc = flush ? c_hi : c_lo;
+        kept += cnt;
     };
-    // after up to four pushes since `before`: if a row of four was completed, store it (the kept & 3 newest entries belong to the next row)
-    auto row_out = [&](int before) {
-        if ((kept >> 2) != (before >> 2)) {
-            const int r = kept & 3;
-            const bool up = r < 2, odd = (r & 1) != 0;
-            const uint32_t b0 = up ? w1 : w0, b1 = up ? w2 : w1, b2 = up ? w3 : w2;
-            const uint32_t lo = odd ? __builtin_amdgcn_alignbit(b1, b0, 16) : b1, hi = odd ? __builtin_amdgcn_alignbit(b2, b1, 16) : b2;
-            out_rows[(int64_t)((kept >> 2) - 1) * A.BI] = make_uint2(lo, hi);
-        }
+    auto emit = [&](uint32_t e) {
+        const int np = kept & 3;
+        acc |= (uint64_t)e << (np * 16);
+        if (np == 3) { out_rows[(int64_t)(kept >> 2) * A.BI] = make_uint2((uint32_t)acc, (uint32_t)(acc >> 32)); acc = 0; }
+        ++kept;
     };
-    auto emit = [&](uint32_t e) { const int before = kept; push(e, true); row_out(before); };
 
     constexpr bool FAST_CT = std::is_same<T, float>::value && LJM == LJ_DIST_UNIFORM && COULM == MHIP_COUL_NONE && !ENERGY && !MINIMG && !SEG;
     // the packed loop keeps four rows in flight; the first four are requested here, before the tile is staged, so that the row
@@ -1326,10 +1342,7 @@ k_forces(ForceArgs<T> A) {
                         // entry waited for an LDS round trip of its own
                         const uint32_t na = l_new[oa >> 2], nb = l_new[ob >> 2], nc = l_new[oc >> 2], nd = l_new[od >> 2];
                         if constexpr (MHIP_PEXP != 1) {    // (MHIP_PEXP: timing experiments of the pruning pass, 1 = no emission, 2 = no LJ arithmetic)
-                            const int before = kept;
-                            push(na << ESHIFT_SCALED, r20.x <= rp2); push(nb << ESHIFT_SCALED, r20.y <= rp2);
-                            push(nc << ESHIFT_SCALED, r21.x <= rp2); push(nd << ESHIFT_SCALED, r21.y <= rp2);
-                            row_out(before);
+                            emit4(na << ESHIFT_SCALED, nb << ESHIFT_SCALED, nc << ESHIFT_SCALED, nd << ESHIFT_SCALED, r20.x <= rp2, r20.y <= rp2, r21.x <= rp2, r21.y <= rp2);
                         }
                     }
                     const float t0 = __builtin_amdgcn_rcpf(r20.x * r20.y), t1 = __builtin_amdgcn_rcpf(r21.x * r21.y);
