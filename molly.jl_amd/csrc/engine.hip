@@ -1207,12 +1207,14 @@ template <class T> class Engine final : public EngineBase {
         stale = true;   // ≙ cache invalidation after append_excluded_pairs! (test/gpu_consistency.jl:494-527)
     }
 
-    void set_bonds(int64_t n, const int32_t* i, const int32_t* j, const void* k, const void* r0) override { bonded.set_bonds(cap, n, i, j, (const T*)k, (const T*)r0); }
-    void set_angles(int64_t n, const int32_t* i, const int32_t* j, const int32_t* k, const void* kth, const void* th0) override { bonded.set_angles(cap, n, i, j, k, (const T*)kth, (const T*)th0); }
+    // (new terms change the total force: what a finished run left in frc[cur] is not the next run's first force any more)
+    void set_bonds(int64_t n, const int32_t* i, const int32_t* j, const void* k, const void* r0) override { frc_run_total = false; bonded.set_bonds(cap, n, i, j, (const T*)k, (const T*)r0); }
+    void set_angles(int64_t n, const int32_t* i, const int32_t* j, const int32_t* k, const void* kth, const void* th0) override { frc_run_total = false; bonded.set_angles(cap, n, i, j, k, (const T*)kth, (const T*)th0); }
     void set_torsions(int64_t n, const int32_t* i, const int32_t* j, const int32_t* k, const int32_t* l, const int32_t* per, const void* ph, const void* kt) override {
+        frc_run_total = false;
         bonded.set_torsions(cap, n, i, j, k, l, per, (const T*)ph, (const T*)kt);
     }
-    void set_ewald_exclusions(int64_t n, const int32_t* i, const int32_t* j) override { bonded.set_ewx(cap, n, i, j); }
+    void set_ewald_exclusions(int64_t n, const int32_t* i, const int32_t* j) override { frc_run_total = false; bonded.set_ewx(cap, n, i, j); }
 
     // set_state raises these words on the device when a coordinate / a velocity really differs from what the engine held
     DBuf<int32_t> state_changed; bool state_pending = false;
@@ -1390,6 +1392,7 @@ template <class T> class Engine final : public EngineBase {
     }
     void set_pme(int32_t order, const int32_t* mesh, double alpha, double eps_r) override {
         if (order && tri_mode) throw ApiError{MHIP_ERR_UNSUPPORTED, "PME on a TriclinicBoundary is outside the scope"};
+        frc_run_total = false;
         MHIP_HIP(hipStreamSynchronize(stream));
         int32_t none[3] = {0, 0, 0};
         pme.setup(order, order ? mesh : none, alpha, cfg.inter.coul_ke, eps_r, cfg.box, cfg.periodic);

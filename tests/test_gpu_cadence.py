@@ -218,3 +218,23 @@ def test_a_continued_run_finds_its_first_forces_already_there(pkg):
     pkg.simulate(a, sim, 3, init_step=13)
     assert a.stats()["n_force_calls"] - c2 >= 4
 
+
+def test_terms_added_between_two_runs_count_from_the_first_step(pkg):
+    """a run, then bonds added, then the run continued: the continued run must not take the previous run's last forces for its first
+    step (they lack the new terms) — same trajectory as a system that had the bonds from the start of the second leg"""
+    case = S.lj_fluid(10, dtype=np.float64)
+    sim = pkg.VelocityVerlet(dt=0.002, remove_CM_motion=0)
+    a = case.system(pkg, np.float64)
+    pkg.simulate(a, sim, 7)
+    x7, v7 = a.coords.copy(), a.velocities.copy()
+    n = case.n
+    bi, bj = np.arange(0, n - 1, 2, dtype=np.int32), np.arange(1, n, 2, dtype=np.int32)
+    bk, br = np.full(n // 2, 3.0e4), np.full(n // 2, 0.35)
+    a.specific_inter_lists = (pkg.HarmonicBonds(bi, bj, bk, br),)
+    a._check(pkg.lib().mhip_set_bonds(a.engine(), len(bi), a._ptr(bi), a._ptr(bj), a._ptr(bk), a._ptr(br)))      # straight through the C ABI, as a Julia caller would
+    pkg.simulate(a, sim, 5, init_step=7)
+    b = S.Case(x7, case.box, lj=case.lj, r_list=case.r_list, rebuild_every=case.rebuild_every, velocities=v7, sigma=case.sigma, eps=case.eps, mass=case.mass,
+               bonds=dict(i=bi, j=bj, k=bk, r0=br)).system(pkg, np.float64)
+    pkg.simulate(b, sim, 5, init_step=7)
+    assert np.abs(a.coords - b.coords).max() < 1e-9 and np.abs(a.velocities - b.velocities).max() < 1e-7
+
