@@ -224,7 +224,11 @@ int32_t mhip_check_finite(mhip_ctx* ctx);          /* check_nans, simulators.jl:
  *   step % rebuild_every == 0                                            (simulators.jl:589-666).
  * Like simulate!, the call first wraps the coordinates, removes CM motion when first_step == 0,
  * force-rebuilds the neighbour structures and recomputes the forces at first_step
- * (simulators.jl:561-571), so chunked calls continue a run (test/simulation.jl:16-57). */
+ * (simulators.jl:561-571), so chunked calls continue a run (test/simulation.jl:16-57).
+ * The work behind that contract is done only where its result could differ: lists that are provably still valid are kept (DESIGN §4,
+ * "list lifetime at the boundary"), and a call that continues from exactly the state the previous mhip_vv_run left — no other
+ * coordinates, no new parameters or terms, no search or prune due — takes that run's last forces for its first step (the same
+ * numbers the recomputation yields: same lists, same order).  MOLLYHIP_REUSE_RUN_FORCES=0 always recomputes. */
 int32_t mhip_vv_run(mhip_ctx* ctx, int64_t first_step, int64_t n_steps, double dt,
                     int32_t remove_cm_every);
 /* The same step split at the point where a multi-GPU host exchanges ghost coordinates:
