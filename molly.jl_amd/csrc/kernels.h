@@ -1255,8 +1255,12 @@ k_forces(ForceArgs<T> A) {
             // cell-major order of the outer one)
             constexpr int NW = 8;                      // boxes per block
             const float reach2 = (float)A.r_prune2 * 1.001f + 1e-12f;
+            // MINIMG passes (a block whose neighbourhood reaches half the box): tile and boxes are in stored, wrapped coordinates; the gap
+            // to a box is taken per axis through the nearest image of the box centre (orthorhombic boxes: exact; the far-away sentinel
+            // folds back into the box and is kept, which costs a slot).  Triclinic exact-image blocks keep everything, as before.
+            const float bL[3] = {(float)G.L[0], (float)G.L[1], (float)G.L[2]}, biL[3] = {(float)G.invL[0], (float)G.invL[1], (float)G.invL[2]};
             auto stays = [&](int t) -> bool {
-                if constexpr (MINIMG) return true;          // small boxes: tile coordinates are not block-local, nothing to prune by
+                if constexpr (MINIMG) { if (G.triclinic) return true; }
                 float p[3];
                 if (packed3) { p[0] = l_p3[t]; p[1] = l_p3[SOA_STRIDE + t]; p[2] = l_p3[2 * SOA_STRIDE + t]; }
                 else { const T4 q = l_pos[t]; p[0] = (float)q.x; p[1] = (float)q.y; p[2] = (float)q.z; }
@@ -1264,7 +1268,20 @@ k_forces(ForceArgs<T> A) {
 #pragma unroll 1                                   // (unrolled, the sixteen box words are hoisted into 64 registers and the pruning variants spill)
                 for (int w = 0; w < NW; ++w) {
                     const float4 lo = reinterpret_cast<const float4*>(l_box)[2 * w], hi = reinterpret_cast<const float4*>(l_box)[2 * w + 1];
-                    float ex = fmaxf(fmaxf(lo.x - p[0], p[0] - hi.x), 0.f), ey = fmaxf(fmaxf(lo.y - p[1], p[1] - hi.y), 0.f), ez = fmaxf(fmaxf(lo.z - p[2], p[2] - hi.z), 0.f);
+                    float ex, ey, ez;
+                    if constexpr (MINIMG) {
+                        const float blo[3] = {lo.x, lo.y, lo.z}, bhi[3] = {hi.x, hi.y, hi.z};
+                        float e[3];
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) {
+                            float dd = p[d] - 0.5f * (blo[d] + bhi[d]);
+                            if (G.periodic[d]) dd -= bL[d] * rintf(dd * biL[d]);
+                            e[d] = fmaxf(fabsf(dd) - 0.5f * (bhi[d] - blo[d]) - 1e-5f * bL[d], 0.f);    // (a few ulp of the box length of slack: fp32 on stored coordinates)
+                        }
+                        ex = e[0]; ey = e[1]; ez = e[2];
+                    } else {
+                        ex = fmaxf(fmaxf(lo.x - p[0], p[0] - hi.x), 0.f); ey = fmaxf(fmaxf(lo.y - p[1], p[1] - hi.y), 0.f); ez = fmaxf(fmaxf(lo.z - p[2], p[2] - hi.z), 0.f);
+                    }
                     best = fminf(best, ex * ex + ey * ey + ez * ez);
                 }
                 return best <= reach2;
