@@ -191,14 +191,20 @@ __device__ inline void pme_spread_blocks(int bid, int nblk, int64_t n_atoms, con
             int base[3];
 #pragma unroll
             for (int d = 0; d < 3; ++d) { int v = (ref[d] + lo3[d]) % P.n[d]; base[d] = v < 0 ? v + P.n[d] : v; }
-            for (int c = tid; c < ex * ey * ez; c += 256) {
-                const T v = l_box[c];
-                if (v == T(0)) continue;
-                const int cx = c / (ey * ez), r = c - cx * ey * ez, cy = r / ez, cz = r - cy * ez;
-                int xi = base[0] + cx; xi -= xi >= P.n[0] ? P.n[0] : 0;
+            // a thread owns a (cy, cz) column of the box and walks it along x: one division pair per column instead of two per cell
+            // (the divisors are run-time values: ≈ 70 instructions per cell, a quarter of the kernel at 6 000 cells per batch)
+            const int pl = ey * ez;
+            for (int pc = tid; pc < pl; pc += 256) {
+                const int cy = pc / ez, cz = pc - cy * ez;
                 int yi = base[1] + cy; yi -= yi >= P.n[1] ? P.n[1] : 0;
                 int zi = base[2] + cz; zi -= zi >= P.n[2] ? P.n[2] : 0;
-                atomicAdd(mesh + ((int64_t)xi * P.n[1] + yi) * P.n[2] + zi, v);
+                T* col = mesh + (int64_t)yi * P.n[2] + zi;
+                int xi = base[0];
+                for (int cx = 0; cx < ex; ++cx) {
+                    const T v = l_box[cx * pl + pc];
+                    if (v != T(0)) atomicAdd(col + (int64_t)xi * P.n[1] * P.n[2], v);
+                    ++xi; xi -= xi >= P.n[0] ? P.n[0] : 0;
+                }
             }
         }
     }
