@@ -97,13 +97,30 @@ __device__ inline void pme_atom_tables(int64_t a0, int64_t n_atoms, const typena
 // several times fewer than one per (atom, point).  A batch whose box does not fit the LDS sub-mesh (a jump of the curve) falls
 // back to direct global atomics.  (One mesh per XCD, selected by the hardware XCC id, was measured too: the spread did not get
 // faster and the first transform pass paid for summing and re-zeroing eight copies.)
-constexpr int PME_BOX_BYTES = 24 * 1024;   // LDS sub-mesh
+// The LDS sub-mesh accumulates in 64-bit FIXED POINT: on gfx950 ds_add_f32 runs at a tenth of the rate of ds_add_u32 / ds_add_u64
+// (tools/micro/lds_atomic_rate.hip: 8 000 adds of this access pattern per block take 22.6 µs as floats, 6.7 µs — launch included — as
+// 64-bit integers), and the LDS adds were half of the spreading kernel.  A contribution q·w (|w| ≤ 0.3 for orders 4–6) is scaled by
+// 2²⁸ (fp32: resolution 3.7e-9, |q| < 26 e) or 2⁴⁴ (fp64: 5.7e-14), rounded once, sign-extended and added as an unsigned 64-bit word
+// (two's complement: no overflow within 2³⁵ such terms); the sums themselves are then exact and independent of the order of the adds.
+constexpr int PME_BOX_BYTES = 48 * 1024;   // LDS sub-mesh, 8 bytes per point
+template <class T> struct PmeFix;
+template <> struct PmeFix<float> {
+    static constexpr float scale = 268435456.f, inv = 1.f / 268435456.f;            // 2^28
+    __device__ static inline unsigned long long enc(float v) { return (unsigned long long)(long long)__float2int_rn(v * scale); }
+};
+template <> struct PmeFix<double> {
+    static constexpr double scale = 17592186044416.0, inv = 1.0 / 17592186044416.0;  // 2^44
+    __device__ static inline unsigned long long enc(double v) { return (unsigned long long)__double2ll_rn(v * scale); }
+};
+#ifndef MHIP_SPREAD_EXP
+#define MHIP_SPREAD_EXP 0                  // timing experiments: 1 = stop behind the B-splines, 2 = behind the zeroed sub-mesh, 3 = behind the LDS adds (no flush)
+#endif
 
 template <class T, int ORDER, int PME_SB>
 __device__ inline void pme_spread_blocks(int bid, int nblk, int64_t n_atoms, const typename Vec<T>::T4* __restrict__ pos, T* rgrid, const PmeP<T>& P) {
     __shared__ T l_w[3 * ORDER * PME_SB]; __shared__ int l_i[3 * PME_SB]; __shared__ T l_q[PME_SB];
-    constexpr int PME_BOX = PME_BOX_BYTES / (int)sizeof(T);
-    __shared__ T l_box[PME_BOX]; __shared__ int l_lo[3], l_hi[3];
+    constexpr int PME_BOX = PME_BOX_BYTES / 8;
+    __shared__ unsigned long long l_box[PME_BOX]; __shared__ int l_lo[3], l_hi[3];
     const int tid = threadIdx.x, sub = tid & 31, hw = tid >> 5;
     T* mesh = rgrid;
     for (int64_t a0 = (int64_t)bid * PME_SB; a0 < n_atoms; a0 += (int64_t)nblk * PME_SB) {
@@ -129,6 +146,7 @@ __device__ inline void pme_spread_blocks(int bid, int nblk, int64_t n_atoms, con
         }
         if (tid < 3) { l_lo[tid] = 1 << 30; l_hi[tid] = -(1 << 30); }
         __syncthreads();
+        if constexpr (MHIP_SPREAD_EXP == 1) continue;
         // bounding box of the first indices, relative to the batch's first atom and folded into [−n/2, n/2)
         const int ref[3] = {l_i[0], l_i[PME_SB], l_i[2 * PME_SB]};
         int rel[3];
@@ -151,10 +169,11 @@ __device__ inline void pme_spread_blocks(int bid, int nblk, int64_t n_atoms, con
         const int ex = l_hi[0] - lo3[0] + ORDER, ey = l_hi[1] - lo3[1] + ORDER, ez = l_hi[2] - lo3[2] + ORDER;
         const bool fits = !empty && ex <= P.n[0] && ey <= P.n[1] && ez <= P.n[2] && (int64_t)ex * ey * ez <= PME_BOX;
         if (fits) {   // the atoms' offsets inside the box replace their absolute first indices (everybody has read `ref` by now)
-            for (int c = tid; c < ex * ey * ez; c += 256) l_box[c] = T(0);
+            for (int c = tid; c < ex * ey * ez; c += 256) l_box[c] = 0ull;
             if (tid < PME_SB) { l_i[tid] = rel[0] - lo3[0]; l_i[PME_SB + tid] = rel[1] - lo3[1]; l_i[2 * PME_SB + tid] = rel[2] - lo3[2]; }
         }
         __syncthreads();
+        if constexpr (MHIP_SPREAD_EXP == 2) continue;
         if (!empty) {
             // the two half-waves of a wave take atoms half a batch apart: neighbours in the sorted order overlap in the sub-mesh and
             // their ds_add_f32 would hit the same addresses in the same instruction
@@ -169,9 +188,9 @@ __device__ inline void pme_spread_blocks(int bid, int nblk, int64_t n_atoms, con
 #pragma unroll
                     for (int ix = 0; ix < ORDER; ++ix) wx[ix] = l_w[ix * PME_SB + t] * qyz;
                     if (fits) {
-                        T* col = l_box + (by + iy) * ez + (bz + iz);
+                        unsigned long long* col = l_box + (by + iy) * ez + (bz + iz);
 #pragma unroll
-                        for (int ix = 0; ix < ORDER; ++ix) atomicAdd(col + (bx + ix) * ey * ez, wx[ix]);
+                        for (int ix = 0; ix < ORDER; ++ix) atomicAdd(col + (bx + ix) * ey * ez, PmeFix<T>::enc(wx[ix]));
                     } else {
                         int yi = by + iy; yi -= yi >= P.n[1] ? P.n[1] : 0;
                         int zi = bz + iz; zi -= zi >= P.n[2] ? P.n[2] : 0;
@@ -185,6 +204,7 @@ __device__ inline void pme_spread_blocks(int bid, int nblk, int64_t n_atoms, con
                 }
             }
         }
+        if constexpr (MHIP_SPREAD_EXP == 3) continue;
         if (fits) {
             __syncthreads();
             // phase 3: box cell (cx, cy, cz) is mesh point (first index of the batch's first atom + l_lo + c) mod n
@@ -201,8 +221,8 @@ __device__ inline void pme_spread_blocks(int bid, int nblk, int64_t n_atoms, con
                 T* col = mesh + (int64_t)yi * P.n[2] + zi;
                 int xi = base[0];
                 for (int cx = 0; cx < ex; ++cx) {
-                    const T v = l_box[cx * pl + pc];
-                    if (v != T(0)) atomicAdd(col + (int64_t)xi * P.n[1] * P.n[2], v);
+                    const long long w = (long long)l_box[cx * pl + pc];
+                    if (w != 0) atomicAdd(col + (int64_t)xi * P.n[1] * P.n[2], (T)w * PmeFix<T>::inv);
                     ++xi; xi -= xi >= P.n[0] ? P.n[0] : 0;
                 }
             }
