@@ -100,7 +100,7 @@ __device__ inline void pme_atom_tables(int64_t a0, int64_t n_atoms, const typena
 // The LDS sub-mesh accumulates in 64-bit FIXED POINT: on gfx950 ds_add_f32 runs at a tenth of the rate of ds_add_u32 / ds_add_u64
 // (tools/micro/lds_atomic_rate.hip: 8 000 adds of this access pattern per block take 22.6 µs as floats, 6.7 µs — launch included — as
 // 64-bit integers), and the LDS adds were half of the spreading kernel.  A contribution q·w (|w| ≤ 0.3 for orders 4–6) is scaled by
-// 2²⁸ (fp32: resolution 3.7e-9, |q| < 26 e) or 2⁴⁴ (fp64: 5.7e-14), rounded once, sign-extended and added as an unsigned 64-bit word
+// 2²⁸ (fp32: resolution 3.7e-9; a batch with a charge beyond 24 e takes the direct path) or 2⁴⁴ (fp64: 5.7e-14), rounded once, sign-extended and added as an unsigned 64-bit word
 // (two's complement: no overflow within 2³⁵ such terms); the sums themselves are then exact and independent of the order of the adds.
 constexpr int PME_BOX_BYTES = 48 * 1024;   // LDS sub-mesh, 8 bytes per point
 template <class T> struct PmeFix;
@@ -147,6 +147,8 @@ __device__ inline void pme_spread_blocks(int bid, int nblk, int64_t n_atoms, con
         if (tid < 3) { l_lo[tid] = 1 << 30; l_hi[tid] = -(1 << 30); }
         __syncthreads();
         if constexpr (MHIP_SPREAD_EXP == 1) continue;
+        // (a charge beyond the fixed-point range of the sub-mesh — 2²⁸·q·w must fit 32 bits in fp32 — sends its batch down the direct path)
+        const bool q_fix_ok = __syncthreads_and(tid >= PME_SB || !(M<T>::fabs(l_q[tid]) > T(24)));
         // bounding box of the first indices, relative to the batch's first atom and folded into [−n/2, n/2)
         const int ref[3] = {l_i[0], l_i[PME_SB], l_i[2 * PME_SB]};
         int rel[3];
@@ -167,7 +169,7 @@ __device__ inline void pme_spread_blocks(int bid, int nblk, int64_t n_atoms, con
         const int lo3[3] = {l_lo[0], l_lo[1], l_lo[2]};
         const bool empty = l_hi[0] < lo3[0];
         const int ex = l_hi[0] - lo3[0] + ORDER, ey = l_hi[1] - lo3[1] + ORDER, ez = l_hi[2] - lo3[2] + ORDER;
-        const bool fits = !empty && ex <= P.n[0] && ey <= P.n[1] && ez <= P.n[2] && (int64_t)ex * ey * ez <= PME_BOX;
+        const bool fits = !empty && q_fix_ok && ex <= P.n[0] && ey <= P.n[1] && ez <= P.n[2] && (int64_t)ex * ey * ez <= PME_BOX;
         if (fits) {   // the atoms' offsets inside the box replace their absolute first indices (everybody has read `ref` by now)
             for (int c = tid; c < ex * ey * ez; c += 256) l_box[c] = 0ull;
             if (tid < PME_SB) { l_i[tid] = rel[0] - lo3[0]; l_i[PME_SB + tid] = rel[1] - lo3[1]; l_i[2 * PME_SB + tid] = rel[2] - lo3[2]; }

@@ -28,6 +28,22 @@ def test_reciprocal_forces_and_energy_vs_oracle(pkg, dtype, order, box_scale, me
     assert abs(e - e_ref) < rel_e * abs(e_ref)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_reciprocal_forces_with_a_charge_beyond_the_fixed_point_range(pkg, dtype):
+    """the spreading kernel accumulates its LDS sub-mesh in fixed point (2^28 per unit of q·w in fp32: |q| < 26); a batch holding a larger
+    charge must take the direct path and still be right"""
+    case = S.charged_fluid(8, dict(kind="ewald", rc=0.9, tol=5e-4), dtype=dtype, pme=dict(order=5, error_tol=5e-4), r_list=1.0, with_exceptions=False)
+    q = np.array(case.charge, dtype=np.float64)
+    q[7] += 40.0; q[300] -= 40.0                                              # two ions far beyond the range, neutral in sum
+    case.charge = q.astype(dtype).astype(np.float64)
+    o = case.oracle(np.float64)
+    f_ref = o.forces(None, pairwise=False, specific=False, general=True)
+    s = case.system(pkg, dtype)
+    f = pkg.forces(s, pairwise=False, specific=False).astype(np.float64)
+    scale = np.linalg.norm(f_ref, axis=1).max()
+    assert np.linalg.norm(f - f_ref, axis=1).max() < (1e-10 if dtype == np.float64 else 2e-4) * scale
+
+
 def test_6mrr_reciprocal_fp32_vs_fp64_oracle(pkg):
     case = G.case("ewald", np.float32, bonded=False, lj=False, pme=True)
     o = case.oracle(np.float64)
