@@ -82,3 +82,22 @@ def test_packed_loop_issue_count(tmp_path):
     assert len(valu) / rows <= 48, (len(valu), rows)
     assert not any("scratch_" in l for l in loop)
     assert sum(1 for l in loop if "ds_read_b32" in l) == 12 * rows
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+def test_charge_spreading_uses_integer_lds_atomics(tmp_path):
+    """ds_add_f32 runs at a tenth of the rate of ds_add_u64 on gfx950 (tools/micro/lds_atomic_rate.hip): the PME charge
+    spreading accumulates its LDS sub-mesh in 64-bit fixed point.  Checked on the compiler's output so that a float atomic cannot slip
+    back into that loop unnoticed; the flush to the global mesh stays a float atomic."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    out = tmp_path / "pme_spread.s"
+    src = tmp_path / "pme_spread.hip"
+    src.write_text('#include "pme.h"\nnamespace mhip { template __global__ void k_pme_spread<float, 5, 64>(int64_t, const Vec<float>::T4*, float*, PmeP<float>);\n'
+                   'template __global__ void k_pme_spread<double, 5, 64>(int64_t, const Vec<double>::T4*, double*, PmeP<double>); }\n')
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "--cuda-device-only", "-S", "-I", CSRC, str(src), "-o", str(out)],
+                   check=True, capture_output=True, timeout=900)
+    text = open(out).read()
+    assert text.count(".amdhsa_kernel") == 2
+    assert "ds_add_u64" in text and "ds_add_f32" not in text and "ds_add_rtn_f32" not in text and "ds_add_f64" not in text
+    assert "global_atomic_add_f32" in text
+
