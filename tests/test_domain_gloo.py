@@ -169,6 +169,74 @@ def test_long_lived_ghost_plan_matches_single_domain_oracle(gm, skin, expect, tm
         assert int(res["plans"]) > 1                                   # small margin: a due prune finds the plan stale → re-plan
 
 
+def _fallback_worker(rank, world, port, mode, out_dir):
+    """an engine that HAS the in-engine exchange entry points but where one rank cannot use them: every rank must end up on the host loop"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import molly_loader
+    molly_loader.load()
+    from molly_jl_amd import domain
+    from tests.oracle_domain_engine import OracleDomainEngine
+
+    class Flaky(OracleDomainEngine):
+        calls = []
+
+        def halo_region(self, rows, w, r):
+            self.calls.append("region")
+            if mode == 0 and r == 1:
+                raise RuntimeError("no IPC here")
+            return bytes(64)
+
+        def halo_open_peer(self, r, handle):
+            self.calls.append("open")
+            if mode == 1 and self.my_rank == 0:
+                raise RuntimeError("cannot map")
+
+        def halo_selftest(self):
+            self.calls.append("selftest")
+            return not (mode == 2 and self.my_rank == 1)
+
+        def set_halo_routes(self, *a):
+            raise AssertionError("routes must not be set once a rank has fallen back")
+
+        def domain_run(self, *a):
+            raise AssertionError("the engine loop must not run once a rank has fallen back")
+
+    case = S.lj_fluid(10, dtype=np.float64, rebuild_every=5)
+    grid = domain.choose_grid(world, case.box)
+    bg = domain.BrickGrid(case.box, grid, rank, case.r_list + 0.3)
+    box, origin, periodic = bg.engine_box(pad=0.3)
+    eng = Flaky(case.inter_dict(np.float64), case.box, periodic, case.r_list, ghost_margin=0.3, skin=0.2, every=case.rebuild_every)
+    eng.my_rank = rank
+    run = domain.DomainRun(bg, eng, torch.float64, torch.device("cpu"), case.rebuild_every, ghost_margin=0.3, skin=0.2)
+    assert run.engine_loop                                     # the entry points are there: it starts out wanting the engine loop
+    run.setup_from_global(case.coords, case.velocities, np.zeros(case.n), case.sigma, case.eps, case.mass)
+    fell = torch.tensor([0 if run.engine_loop else 1]); dist.all_reduce(fell)
+    assert int(fell) == world, (mode, rank, run.engine_loop)   # EVERY rank fell back, also the ones whose own calls succeeded
+    run.run(0, 12, 0.002, remove_cm_every=1)
+    xs, vs = run.gather_global(case.n)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "result.npz"), x=xs, v=vs)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_engine_loop_falls_back_collectively(mode, tmp_path):
+    """mhip_halo_region / mhip_halo_open_peer / mhip_halo_selftest failing on ONE rank (no IPC for fine-grained memory, a peer that cannot
+    be mapped, a store that never becomes visible) keeps EVERY rank on the host loop with torch.distributed collectives — decided by
+    all_gathers at setup, so no rank waits in a kernel for a peer that went the other way; the run is the same run"""
+    world = 2
+    mp.spawn(_fallback_worker, args=(world, _free_port(), mode, str(tmp_path)), nprocs=world, join=True)
+    res = np.load(os.path.join(tmp_path, "result.npz"))
+    case = S.lj_fluid(10, dtype=np.float64, rebuild_every=5)
+    o = case.oracle(np.float64)
+    o.vv_run(12, 0.002, remove_cm_every=1)
+    d = res["x"] - o.coords
+    d -= np.round(d / case.box) * case.box
+    assert np.abs(d).max() < 1e-9 and np.abs(res["v"] - o.vel).max() < 1e-8
+
+
 def test_brick_grid_geometry():
     import molly_loader
     molly_loader.load()
