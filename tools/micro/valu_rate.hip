@@ -6,7 +6,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 template <int MODE> __global__ void __launch_bounds__(512) k(float* out, int iters, float seed) {
     v2f a[8]; float s[8]; unsigned u[8];
     for (int i = 0; i < 8; ++i) { a[i] = (v2f){seed + i + threadIdx.x, seed * 0.5f + i}; s[i] = seed + i * 0.25f + threadIdx.x; u[i] = threadIdx.x * 7u + i; }
-    const v2f m = {1.0000001f, 0.9999999f}, c = {1e-7f, -1e-7f};
+    const v2f m = {1.0000001f, 0.9999999f}, c = {1e-7f, -1e-7f}; const unsigned seed_u = (unsigned)seed * 977u + threadIdx.x;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -18,6 +18,17 @@ template <int MODE> __global__ void __launch_bounds__(512) k(float* out, int ite
             if (MODE == 5) asm volatile("v_and_b32 %0, 0xffff, %0" : "+v"(u[i]));
             if (MODE == 6) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(s[i]) : "v"(m.x));
             if (MODE == 7) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+            if (MODE == 8) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) & 7]), "v"(0x05040100u));
+            if (MODE == 9) { unsigned long long w = ((unsigned long long)u[i] << 32) | u[(i + 1) & 7]; asm volatile("v_lshlrev_b64 %0, %1, %0" : "+v"(w) : "v"(u[(i + 2) & 7] & 31u)); u[i] = (unsigned)(w >> 32); }
+            if (MODE == 10) asm volatile("v_rsq_f32 %0, %0" : "+v"(s[i]));
+            if (MODE == 11) asm volatile("v_exp_f32 %0, %0" : "+v"(s[i]));
+            if (MODE == 12) asm volatile("v_alignbit_b32 %0, %0, %1, 16" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+            if (MODE == 13) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+            if (MODE == 14) asm volatile("v_bcnt_u32_b32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+            if (MODE == 15) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) & 7]), "s"(0x5555555555555555ull));
+            if (MODE == 16) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(seed_u) : );       // second operand loop-invariant: independent chains
+            if (MODE == 17) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(seed_u) : "vcc");
+            if (MODE == 18) asm volatile("v_max_u32 %0, %0, %1" : "+v"(u[i]) : "v"(seed_u));
         }
     }
     float r = 0; for (int i = 0; i < 8; ++i) r += a[i].x + a[i].y + s[i] + (float)u[i];
@@ -41,6 +52,11 @@ int main() {
     for (int bpc : {4, 2, 1}) {
         run(k<0>, "v_pk_fma_f32", bpc); run(k<4>, "v_pk_mul_f32", bpc); run(k<7>, "v_pk_add_f32", bpc); run(k<1>, "v_fma_f32", bpc); run(k<6>, "v_mul_f32", bpc);
         run(k<2>, "v_rcp_f32", bpc); run(k<3>, "v_add_u32_sdwa", bpc); run(k<5>, "v_and_b32", bpc);
+        if (bpc == 4) {
+            run(k<8>, "v_perm_b32", bpc); run(k<9>, "v_lshlrev_b64 (+ pack)", bpc); run(k<10>, "v_rsq_f32", bpc); run(k<11>, "v_exp_f32", bpc);
+            run(k<12>, "v_alignbit_b32", bpc); run(k<13>, "v_cndmask_b32 (vcc)", bpc); run(k<14>, "v_bcnt_u32_b32", bpc);
+            run(k<15>, "v_cndmask_b32_e64 (sgpr)", bpc); run(k<16>, "v_cndmask_b32 indep.", bpc); run(k<17>, "v_cmp + v_cndmask (2 instr)", bpc); run(k<18>, "v_max_u32", bpc);
+        }
     }
     return 0;
 }
