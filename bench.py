@@ -86,7 +86,7 @@ def cpu_baseline(case, dtype, dt, budget_s=20.0):
     return {"value": steps_s * dt * 1e3 * 86400 * 1e-6, "unit": "ns/day", "cores": nthreads, "kind": "port",
             "matom_steps_per_s": steps_s * case.n / 1e6,
             "sample": f"{n} velocity-Verlet steps of the full {case.n}-atom system (threaded pair loop of src/force.jl:886-969 + "
-                      f"cell-list rebuild every {every} steps" + (", PME reciprocal space on ONE thread (the restatement's mesh code is serial)" if general else "") + f"), {nthreads} threads, -O3 -march=native",
+                      f"cell-list rebuild every {every} steps" + (", PME reciprocal space threaded as ewald.jl's n_threads > 1 methods (spreading on min(n, 4) private meshes, the rest over all threads)" if general else "") + f"), {nthreads} threads, -O3 -march=native",
             "one_core": {"value": steps_s1 * dt * 1e3 * 86400 * 1e-6, "unit": "ns/day", "cores": 1, "matom_steps_per_s": steps_s1 * case.n / 1e6,
                          "sample": f"steady state: ({nb}-step run − 1-step run) / {nb - 1} = {per_step:.3f} s per plain step (1-thread pair loop of src/force.jl:828-884, same system), "
                                    f"plus 1/{every} of the {max(start_cost - per_step, 0.0):.3f} s neighbour search"}}
@@ -247,6 +247,20 @@ def main():
                 if not args.no_cpu_baseline:
                     rec["cpu_baseline"] = cpu_baseline(case2, dtype2, dt2, budget_s=8.0)
                 line["secondary"].append(rec)
+    # the LAST key of the line: every configuration's headline in a few hundred bytes, so that a reader who keeps only the tail of
+    # stdout still sees all of them (round 3's driver record lost the 6mrr_pme figure inside the 14 KB line)
+    recs = [line] + list(line.get("secondary", []))
+    summ = {}
+    for r in recs:
+        nm = r["config"]["name"]
+        summ[nm + "_ms_per_step"] = round(r["ms_per_step"], 5)
+        summ[nm + "_ns_day"] = round(r["value"], 1)
+        if r.get("roofline", {}).get("frac") is not None:
+            summ[nm + "_k_forces_us"] = round(r["roofline"]["avg_launch_ms"] * 1e3, 2)
+            summ[nm + "_roofline_frac"] = round(r["roofline"]["frac"], 4)
+        if r.get("cpu_baseline"):
+            summ[nm + "_cpu_ns_day"] = round(r["cpu_baseline"]["value"], 3)
+    line["summary"] = summ
     os.write(json_fd, (json.dumps(line) + "\n").encode())
 
 

@@ -2,6 +2,7 @@
 // C ABI of include/mollyhip.h.  One context = one GPU = one HIP stream (one process per GPU).
 #include <algorithm>
 #include <chrono>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -1140,6 +1141,7 @@ template <class T> class Engine final : public EngineBase {
 
     void set_atoms(const void* q, const void* sg, const void* ep, const void* ms, const void* lam, int mem_kind) override {
         flush_cm();
+        frc_run_total = false; frc_before_set_state = false;   // new charges / σ / ϵ / masses: neither a finished run's forces nor those held before a set_state stand
         DBuf<T> s3, s4, s5;
         const T* dq = to_device(q, n_tot, mem_kind, stage_a);
         const T* ds = to_device(sg, n_tot, mem_kind, stage_b);
@@ -1177,6 +1179,7 @@ template <class T> class Engine final : public EngineBase {
     }
 
     void set_exceptions(const int32_t* ei, const int32_t* ej, int64_t ne, const int32_t* si, const int32_t* sj, int64_t ns) override {
+        frc_run_total = false; frc_before_set_state = false;
         // one CSR over caller indices holding both kinds; excluded beats special (neighbors.jl:410-411 tests eligible first)
         std::vector<std::vector<uint32_t>> adj(cap);
         int span = 0;
@@ -1673,7 +1676,7 @@ template <class T> class Engine final : public EngineBase {
             if (hp.first_ghost < 0 || hp.first_ghost > n_tot) throw ApiError{MHIP_ERR_INVALID, "halo plan: ghost range out of bounds"};
             tr("k_halo_unpack");
             XferWait W{};    // inside mhip_domain_run with peers: wait for exchange xf.seq, read my region's half
-            if (xf_direct && xf.n_peers > 0) { W.mine = reinterpret_cast<const XferHeader*>(xf.region); W.parity = (int)(xf.seq & 1u); W.seq = xf.seq; W.peers = xf.d_peers.p; W.n_peers = xf.n_peers; W.err = xf.err.p; }
+            if (xf_direct && xf.n_peers > 0) { W.mine = reinterpret_cast<const XferHeader*>(xf.region); W.parity = (int)(xf.seq & 1u); W.seq = xf.seq; W.peers = xf.d_peers.p; W.n_peers = xf.n_peers; W.err = xf.err.p; W.ticks = xf_ticks(); }
             hipLaunchKernelGGL(k_halo_unpack<T>, dim3(cdiv(hp.n_recv_rows, 256)), dim3(256), 0, stream, hp.n_recv_rows, W.n_peers > 0 ? (const T*)xf_rows(W.parity) : (const T*)hp.recv, hp.recv_dst, hp.first_ghost, (const int32_t*)inv.p,
                                pos[cur].p, cm_all.p, std::max(hp.cm_rows, 1), W);
         }
@@ -1710,7 +1713,7 @@ template <class T> class Engine final : public EngineBase {
     // ---- the ghost exchange inside the engine (halo_xfer.h): peer stores into IPC-mapped receive regions, the step loop in C++ --------
     struct Xfer {
         unsigned char* region = nullptr; int64_t rows_cap = 0; int world = 0, rank = 0;
-        XferPeers peers{}; bool opened[XFER_MAX_RANKS] = {};
+        XferPeers peers{}; bool opened[XFER_MAX_RANKS] = {}; int64_t peer_cap[XFER_MAX_RANKS] = {};   // peer_cap: rows per half of each peer's region (its header says)
         bool routes = false; int n_peers = 0; std::vector<int32_t> peer_rank;
         DBuf<int32_t> row_peer, row_dst, d_peers; DBuf<unsigned int> done; DBuf<int32_t> err; DBuf<float> mine3, red3;
         uint32_t seq = 0, plan_seq = 0;
@@ -1737,6 +1740,7 @@ template <class T> class Engine final : public EngineBase {
             const size_t bytes = XFER_ROWS_OFF + 2 * (size_t)rows_cap * 3 * sizeof(T);
             MHIP_HIP(hipExtMallocWithFlags((void**)&xf.region, bytes, hipDeviceMallocFinegrained));
             MHIP_HIP(hipMemset(xf.region, 0, bytes));
+            MHIP_HIP(hipMemcpy(xf.region + offsetof(XferHeader, rows_cap), &rows_cap, sizeof(int64_t), hipMemcpyHostToDevice));
             xf.rows_cap = rows_cap; xf.world = world; xf.rank = my_rank; xf.seq = 0; xf.plan_seq = 0; xf.routes = false;
             for (int r = 0; r < XFER_MAX_RANKS; ++r) xf.peers.region[r] = nullptr;
             xf.peers.region[my_rank] = xf.region;
@@ -1762,6 +1766,8 @@ template <class T> class Engine final : public EngineBase {
         void* base = nullptr;
         MHIP_HIP(hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess));
         xf.peers.region[rank] = (unsigned char*)base; xf.opened[rank] = true;
+        // the peer may have been created with another capacity than this rank: its own header is the authority on what fits there
+        MHIP_HIP(hipMemcpy(&xf.peer_cap[rank], (unsigned char*)base + offsetof(XferHeader, rows_cap), sizeof(int64_t), hipMemcpyDeviceToHost));
     }
     // where the rows of the current ghost plan travel: consecutive segments of the send buffer → (peer, first row in the peer's half)
     void set_halo_routes(const mhip_halo_routes* rt) override {
@@ -1775,7 +1781,7 @@ template <class T> class Engine final : public EngineBase {
         for (int q = 0; q < rt->n_peers; ++q) {
             const int r = rt->peer_rank[q];
             if (r < 0 || r >= xf.world || r == xf.rank || !xf.peers.region[r]) throw ApiError{MHIP_ERR_INVALID, "halo routes: peer not opened (mhip_halo_open_peer)"};
-            if (rt->send_rows[q] < 0 || rt->dst_row[q] < 0 || rt->dst_row[q] + rt->send_rows[q] > xf.rows_cap) throw ApiError{MHIP_ERR_CAPACITY, "halo routes: segment does not fit the peer's region"};
+            if (rt->send_rows[q] < 0 || rt->dst_row[q] < 0 || rt->dst_row[q] + rt->send_rows[q] > xf.peer_cap[r]) throw ApiError{MHIP_ERR_CAPACITY, "halo routes: segment does not fit the peer's region"};
             for (int64_t k = 0; k < rt->send_rows[q]; ++k) { rp.push_back(r); rd.push_back((int32_t)(rt->dst_row[q] + k)); }
             recv_total += rt->recv_rows[q];
         }
@@ -1797,18 +1803,24 @@ template <class T> class Engine final : public EngineBase {
         MHIP_HIP(hipMemcpyAsync(xf.mine3.p, token, 3 * sizeof(float), hipMemcpyHostToDevice, stream));
         ++xf.plan_seq;
         hipLaunchKernelGGL(k_plan_push, dim3(1), dim3(64), 0, stream, (const float*)xf.mine3.p, xf.peers, xf.world, xf.rank, (int)(xf.plan_seq & 1u), xf.plan_seq);
-        hipLaunchKernelGGL(k_plan_reduce, dim3(1), dim3(64), 0, stream, reinterpret_cast<const XferHeader*>(xf.region), xf.world, (int)(xf.plan_seq & 1u), xf.plan_seq, xf.red3.p, xf.h_red3, xf.err.p);
+        hipLaunchKernelGGL(k_plan_reduce, dim3(1), dim3(64), 0, stream, reinterpret_cast<const XferHeader*>(xf.region), xf.world, (int)(xf.plan_seq & 1u), xf.plan_seq, xf.red3.p, xf.h_red3, xf.err.p, xf_ticks());
         MHIP_HIP(hipMemcpyAsync(xf.h_err, xf.err.p, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         MHIP_HIP(hipStreamSynchronize(stream));
         const bool ok = *xf.h_err == 0 && xf.h_red3[0] == (float)xf.world;      // the MAX of the tokens is the highest rank's
         if (*xf.h_err) MHIP_HIP(hipMemset(xf.err.p, 0, sizeof(int32_t)));
         return ok ? 1 : 0;
     }
+    // bound of every in-kernel wait for a peer, in ticks of the 100 MHz wall clock (MOLLYHIP_XFER_TIMEOUT_MS; 2 s unless set: a peer may be
+    // held up on its host by a capacity-retry rebuild, a profiler or first-use code loading)
+    static unsigned long long xf_ticks() {
+        static const unsigned long long t = (unsigned long long)std::max(1, env_int("MOLLYHIP_XFER_TIMEOUT_MS", 2000)) * 100000ull;
+        return t;
+    }
     void xf_check_errors() {
         if (!xf.region) return;
         MHIP_HIP(hipMemcpyAsync(xf.h_err, xf.err.p, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         MHIP_HIP(hipStreamSynchronize(stream));
-        if (*xf.h_err) { MHIP_HIP(hipMemset(xf.err.p, 0, sizeof(int32_t))); throw ApiError{MHIP_ERR_STATE, "ghost exchange timed out: a peer's rows (or its validity triple) did not arrive within 2 s"}; }
+        if (*xf.h_err) { MHIP_HIP(hipMemset(xf.err.p, 0, sizeof(int32_t))); throw ApiError{MHIP_ERR_STATE, "ghost exchange timed out: a peer's rows (or its validity triple) did not arrive in time (MOLLYHIP_XFER_TIMEOUT_MS)"}; }
     }
     // the collective validity check of the pair lists, issued at step s and read one step later (nothing waits for it)
     void xf_issue_plan_check(int64_t s) {
@@ -1816,7 +1828,7 @@ template <class T> class Engine final : public EngineBase {
         ++xf.plan_seq;
         if (xf.world > 1) {
             hipLaunchKernelGGL(k_plan_push, dim3(1), dim3(64), 0, stream, (const float*)xf.mine3.p, xf.peers, xf.world, xf.rank, (int)(xf.plan_seq & 1u), xf.plan_seq);
-            hipLaunchKernelGGL(k_plan_reduce, dim3(1), dim3(64), 0, stream, reinterpret_cast<const XferHeader*>(xf.region), xf.world, (int)(xf.plan_seq & 1u), xf.plan_seq, xf.red3.p, xf.h_red3, xf.err.p);
+            hipLaunchKernelGGL(k_plan_reduce, dim3(1), dim3(64), 0, stream, reinterpret_cast<const XferHeader*>(xf.region), xf.world, (int)(xf.plan_seq & 1u), xf.plan_seq, xf.red3.p, xf.h_red3, xf.err.p, xf_ticks());
         } else MHIP_HIP(hipMemcpyAsync(xf.h_red3, xf.mine3.p, 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
         MHIP_HIP(hipEventRecord(xf.ev_plan, stream));
         xf.plan_pending = true; xf.plan_step = s;
@@ -1837,12 +1849,18 @@ template <class T> class Engine final : public EngineBase {
         InRun guard_in_run(in_run);
         struct Direct { bool& f; explicit Direct(bool& b) : f(b) { f = true; } ~Direct() { f = false; } } guard_direct(xf_direct);   // packs send, unpacks wait
         halo_start(dt);
+        // a check carried over from the previous call belongs to that call's last step; a caller that continues somewhere else gets a
+        // fresh one at its first step instead
+        if (xf.plan_pending && xf.plan_step != first_step) { xf.plan_pending = false; xf.next_check = first_step + 1; }
         for (int64_t s = first_step + 1; s <= last; ++s) {
             const bool cm = remove_cm_every != 0 && s % remove_cm_every == 0;
             bool replan = false;
             if (xf.plan_pending && s > xf.plan_step) {          // the numbers of the check issued a step ago have long arrived
                 MHIP_HIP(hipEventSynchronize(xf.ev_plan));
                 xf.plan_pending = false;
+                // an exchange timed out somewhere before this check: the steps since ran on stale ghost rows and the triple may be partial
+                // (ranks could decide differently) — give the chunk up here instead of queueing the rest of it
+                if (xf.world > 1 && xf.h_red3[3] != 0.f) { xf_check_errors(); throw ApiError{MHIP_ERR_STATE, "ghost exchange timed out"}; }
                 int32_t check_in = 0;
                 const float red[3] = {xf.h_red3[0], xf.h_red3[1], xf.h_red3[2]};
                 const int action = std::isinf(red[0]) ? 2 : plan_decide_late(xf.plan_step, red, &check_in, (int)(s - xf.plan_step));
@@ -1858,7 +1876,10 @@ template <class T> class Engine final : public EngineBase {
             if (n_ghost > 0 && xf.n_peers > 0) (void)halo_interior(s);          // the blocks that need no ghost, while the peers' rows arrive
             halo_mid(s, dt, (cm ? 1 : 0) | (stop ? 2 : 0), (cm && stop) ? cm_parts_dev : nullptr, (cm && stop) ? n_parts : 0);   // waits + unpacks … packs + sends
             ++*steps_done;
-            if (stop) { *reason = replan ? 1 : 0; xf.plan_pending = false; break; }
+            // (a check issued at the LAST step of this call stays pending: the first step of the next call reads it, one step late like any
+            // other — dropping it here left the inner list unvouched for until the next multiple of `every`, up to 2·every steps after the
+            // check before.  A re-plan makes it moot; set_halo_routes clears it then.)
+            if (stop) { *reason = replan ? 1 : 0; if (replan) xf.plan_pending = false; break; }
         }
         xf_check_errors();      // (one stream sync per call: a chunk is ≈ 100 steps)
     }

@@ -19,17 +19,22 @@ struct XferHeader {
     uint32_t seq_in[2][XFER_MAX_RANKS];        // [parity][sender rank]: number of the last exchange whose rows are complete in that half
     uint32_t plan_seq[2][XFER_MAX_RANKS];      // [parity][rank]: number of the last validity check whose triple is in plan_val
     float plan_val[2][XFER_MAX_RANKS][4];      // {max |x − x_plan|², max |x − x_prune|², max |v|², –} of that rank
+    int64_t rows_cap;                          // rows per half of THIS region, written by its owner: a sender checks its segments against it
 };
 constexpr size_t XFER_ROWS_OFF = (sizeof(XferHeader) + 255) & ~(size_t)255;
 
 __device__ inline void xfer_store_release(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ inline uint32_t xfer_load_acquire(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
-// wait until *p has reached `want` (sequence numbers only grow; wrap-safe compare); false after ~2 s of wall clock (100 MHz counter)
-__device__ inline bool xfer_wait(const uint32_t* p, uint32_t want) {
+// wait until *p has reached `want` (sequence numbers only grow; wrap-safe compare); false after `ticks` of the 100 MHz wall clock
+// (MOLLYHIP_XFER_TIMEOUT_MS, 2 s unless set) — or AT ONCE when the error word is already raised: after one time-out every later
+// launch of the chunk is queued already, and each of them waiting its own full time-out turned one lost peer into minutes of stall
+__device__ inline bool xfer_wait(const uint32_t* p, uint32_t want, const int32_t* err, unsigned long long ticks) {
+    if ((int32_t)(xfer_load_acquire(p) - want) >= 0) return true;
+    if (err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
     const unsigned long long t0 = wall_clock64();
     while ((int32_t)(xfer_load_acquire(p) - want) < 0) {
         __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > 200000000ull) return false;
+        if (wall_clock64() - t0 > ticks) return false;
     }
     return true;
 }
@@ -44,7 +49,7 @@ struct XferSend {
     const int32_t* row_peer; const int32_t* row_dst;     // per send row: destination rank, row in that rank's half (nullptr: plain local pack)
     XferPeers P; int64_t rows_cap; int parity; uint32_t seq; int my_rank; const int32_t* peers; int n_peers; unsigned int* done;
 };
-struct XferWait { const XferHeader* mine; int parity; uint32_t seq; const int32_t* peers; int n_peers; int32_t* err; };
+struct XferWait { const XferHeader* mine; int parity; uint32_t seq; const int32_t* peers; int n_peers; int32_t* err; unsigned long long ticks; };
 
 // the last block of a launch to get here raises this rank's sequence word at every peer (all blocks have fenced their stores before)
 __device__ inline void xfer_announce(const XferSend& X) {
@@ -62,7 +67,7 @@ __device__ inline void xfer_announce(const XferSend& X) {
 }
 // every block waits for the senders' words itself (a handful of uncached loads), then all its threads go on
 __device__ inline void xfer_wait_block(const XferWait& W) {
-    if ((int)threadIdx.x < W.n_peers && !xfer_wait(&W.mine->seq_in[W.parity][W.peers[threadIdx.x]], W.seq)) atomicOr(W.err, 1);
+    if ((int)threadIdx.x < W.n_peers && !xfer_wait(&W.mine->seq_in[W.parity][W.peers[threadIdx.x]], W.seq, W.err, W.ticks)) atomicOr(W.err, 1);
     __syncthreads();
 }
 
@@ -75,12 +80,13 @@ __device__ inline void xfer_wait_block(const XferWait& W) {
     __threadfence_system();
     xfer_store_release(&h->plan_seq[parity][my_rank], seq);
 }
-// … and, once every rank's has arrived, their maximum → out3 (device) and host3 (pinned host memory, read behind an event)
-[[maybe_unused]] static __global__ void k_plan_reduce(const XferHeader* mine, int world, int parity, uint32_t seq, float* out3, float* host3, int32_t* err) {
+// … and, once every rank's has arrived, their maximum → out3 (device) and host3 (pinned host memory, read behind an event).  host3[3]
+// carries the error word (a time-out here or in any exchange before): the host reads it with the triple and gives the chunk up there
+[[maybe_unused]] static __global__ void k_plan_reduce(const XferHeader* mine, int world, int parity, uint32_t seq, float* out3, float* host3, int32_t* err, unsigned long long ticks) {
     __shared__ float sh[XFER_MAX_RANKS][3];
     const int r = threadIdx.x;
     if (r < world) {
-        if (!xfer_wait(&mine->plan_seq[parity][r], seq)) atomicOr(err, 2);
+        if (!xfer_wait(&mine->plan_seq[parity][r], seq, err, ticks)) atomicOr(err, 2);
         for (int c = 0; c < 3; ++c) sh[r][c] = __hip_atomic_load(&mine->plan_val[parity][r][c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __syncthreads();
@@ -90,6 +96,7 @@ __device__ inline void xfer_wait_block(const XferWait& W) {
         if (out3) out3[r] = m;
         if (host3) host3[r] = m;
     }
+    if (r == 3 && host3) host3[3] = (float)__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace mhip

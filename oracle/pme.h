@@ -13,10 +13,16 @@
 // CubicBoundary only: recip_box = diag(1/Lx, 1/Ly, 1/Lz).  The two FFTs (plan_fft!, plan_bfft!: unnormalised forward
 // e^{-2πi jk/n} / backward e^{+2πi jk/n}) are evaluated as separable direct DFTs with double-precision twiddles —
 // the meshes here are ~50³, and a direct sum needs no FFT library.
+// Threads (nthreads > 1, ewald.jl's n_threads > 1 methods): the B-splines and the force interpolation run over blocks of atoms
+// (Threads.@threads over atoms, :570, :854-859), the spreading into one private real mesh per thread over atoms chunk:n_threads:N with the
+// serial sum of the buffers behind it (:632-646), the convolution over kx with per-thread energy / virial sums (:739-750).  The two
+// transforms are threaded over lines (the reference calls FFTW there; a line's arithmetic does not depend on the thread count, so the
+// results of this file are the same for every nthreads except for the order of the mesh and energy sums).
 #pragma once
 #include <cmath>
 #include <complex>
 #include <cstdint>
+#include <thread>
 #include <vector>
 
 namespace orc_pme {
@@ -90,38 +96,52 @@ template <class T> struct Pme {
         }
     }
 
+    template <class F> static void par_for(int64_t n, int nthreads, F body) {      // body(t, lo, hi) on contiguous blocks
+        nthreads = (int)std::max<int64_t>(1, std::min<int64_t>(nthreads, n));
+        if (nthreads == 1) { body(0, (int64_t)0, n); return; }
+        std::vector<std::thread> th;
+        const int64_t per = (n + nthreads - 1) / nthreads;
+        for (int t = 0; t < nthreads; ++t) th.emplace_back([=, &body] { body(t, std::min(n, t * per), std::min(n, (t + 1) * per)); });
+        for (auto& x : th) x.join();
+    }
+
     // unnormalised DFT along every axis, sign = -1 forward / +1 backward; grid index (x*ny + y)*nz + z
-    void dft3(std::vector<std::complex<T>>& g, int sign) const {
-        std::vector<std::complex<double>> line, out, w;
+    void dft3(std::vector<std::complex<T>>& g, int sign, int nthreads = 1) const {
         const int64_t stride[3] = {(int64_t)n[1] * n[2], n[2], 1};
         for (int a = 0; a < 3; ++a) {
             const int na = n[a];
-            w.resize(na); line.resize(na); out.resize(na);
+            std::vector<std::complex<double>> w(na);
             for (int m = 0; m < na; ++m) { double ang = sign * 2.0 * M_PI * m / na; w[m] = {std::cos(ang), std::sin(ang)}; }
             const int b = (a + 1) % 3, c = (a + 2) % 3;
-            for (int ib = 0; ib < n[b]; ++ib) for (int ic = 0; ic < n[c]; ++ic) {
-                const int64_t base = ib * stride[b] + ic * stride[c];
-                for (int j = 0; j < na; ++j) line[j] = std::complex<double>(g[base + j * stride[a]]);
-                for (int k = 0; k < na; ++k) {
-                    std::complex<double> s = 0; int m = 0;
-                    for (int j = 0; j < na; ++j) { s += line[j] * w[m]; m += k; if (m >= na) m -= na; }
-                    out[k] = s;
+            par_for((int64_t)n[b] * n[c], nthreads, [&](int, int64_t lo, int64_t hi) {
+                std::vector<std::complex<double>> line(na), out(na);
+                for (int64_t l = lo; l < hi; ++l) {
+                    const int ib = (int)(l / n[c]), ic = (int)(l - (int64_t)ib * n[c]);
+                    const int64_t base = ib * stride[b] + ic * stride[c];
+                    for (int j = 0; j < na; ++j) line[j] = std::complex<double>(g[base + j * stride[a]]);
+                    for (int k = 0; k < na; ++k) {
+                        std::complex<double> s = 0; int m = 0;
+                        for (int j = 0; j < na; ++j) { s += line[j] * w[m]; m += k; if (m >= na) m -= na; }
+                        out[k] = s;
+                    }
+                    for (int k = 0; k < na; ++k) g[base + k * stride[a]] = std::complex<T>((T)out[k].real(), (T)out[k].imag());
                 }
-                for (int k = 0; k < na; ++k) g[base + k * stride[a]] = std::complex<T>((T)out[k].real(), (T)out[k].imag());
-            }
+            });
         }
     }
 
     // ewald_pe_forces! :873-929.  x: 3n coords, q: n charges; fs (nullable): 3n forces, the PME force is ADDED (Fs[i] -= f, :838)
     // vir (nullable, 9 entries, ADDED): reciprocal-space virial of recip_conv_inner! (:701-723), halved like the energy (:747-750), plus the
     // net-charge term charge_E·I (:925-927)
-    T run(int64_t natoms, const T* x, const T* q, T* fs, T* vir = nullptr) const {
+    T run(int64_t natoms, const T* x, const T* q, T* fs, T* vir = nullptr, int nthreads = 1) const {
         const int nx = n[0], ny = n[1], nz = n[2];
-        std::vector<std::complex<T>> grid((size_t)nx * ny * nz, std::complex<T>(0, 0));
+        const size_t nmesh = (size_t)nx * ny * nz;
+        nthreads = std::max(1, nthreads);
+        std::vector<std::complex<T>> grid(nmesh, std::complex<T>(0, 0));
         std::vector<int> idx(3 * (size_t)natoms);
         std::vector<T> th(3 * (size_t)order * natoms), dth(3 * (size_t)order * natoms);
-        for (int64_t i = 0; i < natoms; ++i) place(x + 3 * i, &idx[3 * i], &th[3 * order * i], &dth[3 * order * i]);
-        for (int64_t i = 0; i < natoms; ++i) {   // spread_charge_inner! :598-621
+        par_for(natoms, nthreads, [&](int, int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; ++i) place(x + 3 * i, &idx[3 * i], &th[3 * order * i], &dth[3 * order * i]); });
+        auto spread_one = [&](int64_t i, auto add) {   // spread_charge_inner! :598-621
             const T* t = &th[3 * order * i];
             for (int ix = 0; ix < order; ++ix) {
                 int xi = (idx[3 * i] + ix) % nx; T qx = q[i] * t[ix];
@@ -129,18 +149,35 @@ template <class T> struct Pme {
                     int yi = (idx[3 * i + 1] + iy) % ny; T qxy = qx * t[order + iy];
                     for (int iz = 0; iz < order; ++iz) {
                         int zi = (idx[3 * i + 2] + iz) % nz;
-                        grid[((size_t)xi * ny + yi) * nz + zi] += std::complex<T>(qxy * t[2 * order + iz], T(0));
+                        add(((size_t)xi * ny + yi) * nz + zi, qxy * t[2 * order + iz]);
                     }
                 }
             }
+        };
+        const int n_spread = std::min(nthreads, 4);       // n_spread_thr = min(n_threads, 4) (:888)
+        if (n_spread == 1) {                              // :623-630
+            for (int64_t i = 0; i < natoms; ++i) spread_one(i, [&](size_t at, T v) { grid[at] += std::complex<T>(v, T(0)); });
+        } else {                                          // :632-646: a private real mesh per thread, atoms chunk : n_threads : N, then summed in order
+            std::vector<std::vector<T>> buf(n_spread);
+            std::vector<std::thread> tt;
+            for (int c = 0; c < n_spread; ++c) tt.emplace_back([&, c] {
+                buf[c].assign(nmesh, T(0));
+                for (int64_t i = c; i < natoms; i += n_spread) spread_one(i, [&](size_t at, T v) { buf[c][at] += v; });
+            });
+            for (auto& t : tt) t.join();
+            par_for((int64_t)nmesh, nthreads, [&](int, int64_t lo, int64_t hi) {
+                for (int64_t at = lo; at < hi; ++at) { T s = buf[0][at]; for (int c = 1; c < n_spread; ++c) s += buf[c][at]; grid[at] = std::complex<T>(s, T(0)); }
+            });
         }
-        dft3(grid, -1);
-        // recip_conv! :727-751
+        dft3(grid, -1, nthreads);
+        // recip_conv! :727-751 (threaded over kx with per-thread sums, :739-750)
         const T V = L[0] * L[1] * L[2];
         const T factor = T(M_PI) * T(M_PI) / (alpha * alpha), boxfactor = T(M_PI) * V;
         const T maxk[3] = {T(0.5) * T(nx + 1), T(0.5) * T(ny + 1), T(0.5) * T(nz + 1)};
-        T esum = T(0);
-        for (int kx = 0; kx < nx; ++kx) for (int ky = 0; ky < ny; ++ky) for (int kz = 0; kz < nz; ++kz) {
+        std::vector<T> esum_t(nthreads, T(0)), vir_t((size_t)9 * nthreads, T(0));
+        par_for(nx, nthreads, [&](int tq, int64_t lo, int64_t hi) {
+          T esum = T(0); T* virq = &vir_t[(size_t)9 * tq];
+          for (int kx = (int)lo; kx < (int)hi; ++kx) for (int ky = 0; ky < ny; ++ky) for (int kz = 0; kz < nz; ++kz) {
             if (kx == 0 && ky == 0 && kz == 0) continue;
             T mx = T(kx) < maxk[0] ? T(kx) : T(kx - nx), my = T(ky) < maxk[1] ? T(ky) : T(ky - ny), mz = T(kz) < maxk[2] ? T(kz) : T(kz - nz);
             T mhx = mx * (T(1) / L[0]), mhy = my * (T(1) / L[1]), mhz = mz * (T(1) / L[2]);
@@ -154,13 +191,18 @@ template <class T> struct Pme {
             esum += eterm * (d1 * d1 + d2 * d2);
             if (vir) {   // V·P_k = E_k [I − 2(1 + factor·m²)(m ⊗ m)/m²]
                 const T Ek = eterm * (d1 * d1 + d2 * d2), coeff = T(2) * (T(1) + factor * m2) / m2, mh[3] = {mhx, mhy, mhz};
-                for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) vir[3 * a + b] += (Ek * ((a == b ? T(1) : T(0)) - coeff * mh[a] * mh[b])) / T(2);
+                for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) virq[3 * a + b] += (Ek * ((a == b ? T(1) : T(0)) - coeff * mh[a] * mh[b])) / T(2);
             }
-        }
+          }
+          esum_t[tq] = esum;
+        });
+        T esum = T(0);
+        for (int c = 0; c < nthreads; ++c) { esum += esum_t[c]; if (vir) for (int a = 0; a < 9; ++a) vir[a] += vir_t[(size_t)9 * c + a]; }
         const T recip_E = esum / T(2);
-        dft3(grid, +1);
+        dft3(grid, +1, nthreads);
         if (fs) {
-            for (int64_t i = 0; i < natoms; ++i) {   // interpolate_force_inner! :805-840
+          par_for(natoms, nthreads, [&](int, int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; ++i) {   // interpolate_force_inner! :805-840
                 const T *t = &th[3 * order * i], *dt = &dth[3 * order * i];
                 T fx = 0, fy = 0, fz = 0;
                 for (int ix = 0; ix < order; ++ix) {
@@ -179,6 +221,7 @@ template <class T> struct Pme {
                 fs[3 * i + 1] -= q[i] * (fy * T(ny) * (T(1) / L[1]));
                 fs[3 * i + 2] -= q[i] * (fz * T(nz) * (T(1) / L[2]));
             }
+          });
         }
         T pc_sum = 0, pc_abs2 = 0;
         for (int64_t i = 0; i < natoms; ++i) { pc_sum += q[i]; pc_abs2 += q[i] * q[i]; }

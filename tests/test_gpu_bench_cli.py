@@ -56,6 +56,11 @@ def test_bench_default_workload_carries_the_other_configurations():
         assert r["metric"] == "ns_per_day" and r["value"] > 0 and r["roofline"]["achieved"] > 0 and r["roofline"]["step_frac"] > 0
         assert r["n_gpus"] == 1 and r["dtype"] == "f32" and r["config"]["timed_window"] == "as scheduled"
     assert d["secondary"][0]["roofline"]["stage_ms_per_step"]["pme_reciprocal"] > 0
+    # the compact summary is the LAST key of the line and repeats every configuration's headline (a reader of the tail sees all three)
+    assert list(d.keys())[-1] == "summary"
+    for nm, r in (("lj1m", d), ("6mrr_pme", d["secondary"][0]), ("lj256k", d["secondary"][1])):
+        assert abs(d["summary"][nm + "_ms_per_step"] - r["ms_per_step"]) < 1e-5 and abs(d["summary"][nm + "_ns_day"] - r["value"]) < 0.06
+    assert len(json.dumps(d["summary"])) < 700
 
 
 def test_bench_two_ranks_record():

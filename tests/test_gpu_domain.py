@@ -20,7 +20,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, n_side, n_steps, dtype_name, out_dir, gm=0.0, host_skin=None):
+def _worker(rank, world, port, n_side, n_steps, dtype_name, out_dir, gm=0.0, host_skin=None, chunk=0, tag="result"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import molly_loader
@@ -37,11 +37,15 @@ def _worker(rank, world, port, n_side, n_steps, dtype_name, out_dir, gm=0.0, hos
     eng = domain.HipDomainEngine(domain.make_interactions(case, dtype), dtype, case.n, box, origin, periodic, case.r_list, case.rebuild_every, 0, ghost_margin=gm)
     run = domain.DomainRun(bg, eng, tdtype, dev, case.rebuild_every, ghost_margin=gm, skin=(case.r_list - 1.0) if host_skin is None else host_skin)
     run.setup_from_global(case.coords, case.velocities, np.zeros(case.n), case.sigma, case.eps, case.mass)
-    run.run(0, n_steps, 0.002, remove_cm_every=1)
+    if chunk > 0:      # the same steps in consecutive calls (chunk boundaries on multiples of the rebuild cadence when chunk % 10 == 0)
+        for first in range(0, n_steps, chunk):
+            run.run(first, min(chunk, n_steps - first), 0.002, remove_cm_every=1)
+    else:
+        run.run(0, n_steps, 0.002, remove_cm_every=1)
     xs, vs = run.gather_global(case.n)
     if rank == 0:
         st = eng.stats()
-        np.savez(os.path.join(out_dir, "result.npz"), x=xs, v=vs, ghosts=run.n_ghost, migrated=run.stats["migrated"], plans=run.stats["plans"],
+        np.savez(os.path.join(out_dir, tag + ".npz"), engine_loop=int(run.engine_loop), x=xs, v=vs, ghosts=run.n_ghost, migrated=run.stats["migrated"], plans=run.stats["plans"],
                  checks=run.stats["plan_checks"], outer=st["n_outer_builds"], prunes=st["n_filter_passes"], host_prunes=run.stats["prunes"], fused=int(run.fused))
     dist.barrier()
     eng.close()
@@ -100,3 +104,46 @@ def test_long_lived_ghost_plans_with_dual_list(world, dtype_name, gm, n_steps, s
             assert int(res["host_prunes"]) >= 2
     else:
         assert int(res["plans"]) > 1 and int(res["host_prunes"]) >= 1                                 # a due prune finds the plan stale
+
+
+def _run_variant(tmp_path, monkeypatch, tag, world, n_steps, engine_loop, chunk, gm=0.2, skin_pm=30):
+    monkeypatch.setenv("MOLLYHIP_ENGINE_LOOP", "1" if engine_loop else "0")
+    monkeypatch.setenv("MOLLYHIP_INNER_SKIN_PM", str(skin_pm)); monkeypatch.setenv("MOLLYHIP_INNER_SKIN_FIXED", "1")
+    mp.spawn(_worker, args=(world, _free_port(), 16, n_steps, "f64", str(tmp_path), gm, None, chunk, tag), nprocs=world, join=True)
+    return np.load(os.path.join(tmp_path, tag + ".npz"))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_engine_loop_chunked_on_cadence_boundaries_keeps_every_check(world, tmp_path, monkeypatch):
+    """Two / four ranks on the one GPU, the in-engine exchange (peer stores into IPC-mapped regions, mhip_domain_run).  A run cut into
+    calls whose boundaries fall on multiples of the rebuild cadence must take the same validity checks, arrange the same prunes and
+    end in the same state as the run in one call — a check issued at the last step of a call is read by the first step of the next
+    one, not dropped (the inner list then went unvouched for up to 2·every steps) — and both must agree with the host
+    loop (MOLLYHIP_ENGINE_LOOP=0: all_to_all + the synchronous collective decision)."""
+    n_steps = 60
+    whole = _run_variant(tmp_path, monkeypatch, "whole", world, n_steps, True, 0)
+    cut = _run_variant(tmp_path, monkeypatch, "cut", world, n_steps, True, 10)
+    cut7 = _run_variant(tmp_path, monkeypatch, "cut7", world, n_steps, True, 7)        # boundaries off the cadence
+    host = _run_variant(tmp_path, monkeypatch, "host", world, n_steps, False, 0)
+    assert int(whole["engine_loop"]) == 1 and int(cut["engine_loop"]) == 1 and int(host["engine_loop"]) == 0
+    for other in (cut, cut7):
+        assert int(other["checks"]) == int(whole["checks"]) and int(other["host_prunes"]) == int(whole["host_prunes"])
+        assert int(other["prunes"]) == int(whole["prunes"]) and int(other["plans"]) == int(whole["plans"]) and int(other["outer"]) == int(whole["outer"])
+        assert np.abs(other["x"] - whole["x"]).max() < 1e-11 and np.abs(other["v"] - whole["v"]).max() < 1e-10
+    assert int(whole["checks"]) >= n_steps // 10 and int(whole["host_prunes"]) >= 2
+    # the host loop decides at the check step itself, the engine loop one step later: the same physics within fp64 round-off of
+    # differently ordered sums, and the lists are pruned about as often
+    d = whole["x"] - host["x"]
+    assert np.abs(d).max() < 1e-9 and np.abs(whole["v"] - host["v"]).max() < 1e-8
+    assert abs(int(whole["host_prunes"]) - int(host["host_prunes"])) <= 1 and int(whole["plans"]) == int(host["plans"])
+
+
+def test_engine_loop_forced_replan_matches_host_loop(tmp_path, monkeypatch):
+    """A thin ghost margin makes the plan go stale inside the run (re-plans: migration + new ghost routes between engine calls); the
+    engine loop and the host loop must re-plan and end in the same state."""
+    n_steps = 60
+    eng = _run_variant(tmp_path, monkeypatch, "eng", 2, n_steps, True, 20, gm=0.03, skin_pm=20)
+    host = _run_variant(tmp_path, monkeypatch, "host", 2, n_steps, False, 20, gm=0.03, skin_pm=20)
+    assert int(eng["engine_loop"]) == 1 and int(host["engine_loop"]) == 0
+    assert int(eng["plans"]) > 1 and int(host["plans"]) > 1
+    assert np.abs(eng["x"] - host["x"]).max() < 1e-9 and np.abs(eng["v"] - host["v"]).max() < 1e-8

@@ -84,6 +84,44 @@ def test_100_step_pme_trajectory_vs_openmm_fp64(pkg):
     assert np.linalg.norm(s.velocities - d["openmm_velocities_100steps"], axis=1).max() < 1e-7
 
 
+def test_all_pme_fp32_total_force_vs_openmm(pkg):
+    """The configuration bench.py TIMES (6mrr_pme: Float32, LJ + Ewald direct space with the A&S erfc + bonded + EwaldExclusion + PME
+    reciprocal space) as ONE force evaluation against OpenMM's forces_all_pme.txt.  Bar per atom: the fp32 pair bar 4e-5·Σ_j‖f_ij‖
+    (tests/systems.py) + 2e-5 of the atom's bonded force scale + 2e-4 of the largest reciprocal-space force (the fp32 mesh sums) + the
+    reference's own fp64 bar for the approximate erfc against OpenMM, 1e-3 (test/protein.jl:274); relative RMS over all atoms 2e-5.
+    The energy: the reference's approximate-erfc bar, 0.2 kJ/mol, + 1e-6 of Σ|e| in fp32 (|E_pair| ≈ 2.7e5)."""
+    d = G.data()
+    case = G.case("ewald", np.float32, bonded=True, pme=True)                 # approximate_erfc = True: the default, and what is timed
+    tol, o, nl = S.fp32_force_tolerance(case)
+    bonded_scale = np.linalg.norm(o.forces(None, pairwise=False, specific=True), axis=1)
+    pme_scale = np.linalg.norm(o.forces(None, pairwise=False, specific=False, general=True), axis=1).max()
+    s = case.system(pkg, np.float32)
+    f = pkg.forces(s).astype(np.float64)
+    f_omm = d["openmm_forces_all_pme"]
+    err = np.linalg.norm(f - f_omm, axis=1)
+    bar = tol + 2e-5 * bonded_scale + 2e-4 * pme_scale + 1e-3
+    assert np.all(err <= bar), f"worst {err.max():.3e} at atom {err.argmax()} (bar {bar[err.argmax()]:.3e})"
+    assert S.rel_rms(err, f_omm) < 2e-5
+    e = pkg.potential_energy(s) + G.lj_dispersion_correction(d)
+    assert abs(e - float(d["openmm_energy_all_pme"])) < 0.2 + 0.6
+
+
+def test_100_step_pme_trajectory_vs_openmm_fp32(pkg):
+    """test/protein.jl:278-299 with the timed configuration's arithmetic (Float32, approximate erfc, the complete MD step) through
+    mhip_vv_run: 100 steps of 0.5 fs from OpenMM's start velocities against coordinates_100steps.txt at SURVEY §8(c)'s fp32 trajectory
+    bar, 5e-4 nm per atom (test/simulation.jl:625), mean displacement error 2e-5 nm; velocities 0.05 nm/ps (hydrogens move at ≈ 3)."""
+    d = G.data()
+    case = G.case("ewald", np.float32, bonded=True, pme=True)
+    s = case.system(pkg, np.float32)
+    pkg.simulate(s, pkg.VelocityVerlet(dt=0.0005), 100)
+    xo = d["openmm_coordinates_100steps"]; box = case.box
+    dx = s.coords.astype(np.float64) - (xo - np.floor(xo / box) * box)
+    dx -= np.round(dx / box) * box
+    dev = np.linalg.norm(dx, axis=1)
+    assert dev.max() < 5e-4 and dev.mean() < 2e-5, (dev.max(), dev.mean())
+    assert np.linalg.norm(s.velocities.astype(np.float64) - d["openmm_velocities_100steps"], axis=1).max() < 0.05
+
+
 def test_pme_rejects_what_it_does_not_cover(pkg):
     case = S.charged_fluid(6, dict(kind="ewald", rc=0.9, tol=5e-4), dtype=np.float32, pme=dict(order=7), r_list=0.9, with_exceptions=False)
     with pytest.raises(pkg.MollyHipError):

@@ -41,6 +41,21 @@ def test_pme_reciprocal_forces_sum_to_zero_and_energy_is_translation_invariant()
     assert abs(e1 - e0) < 5e-4 * abs(e0)                                     # mesh discretisation only
 
 
+def test_threaded_reciprocal_space_is_the_serial_one():
+    """oracle/pme.h with threads (the cpu_baseline leg of bench.py: B-splines, interpolation, transforms and convolution over all threads,
+    the spreading into min(n_threads, 4) private meshes as ewald.jl:888, 632-646) against the serial path: only the order of the mesh sums differs"""
+    case = G.case("ewald", np.float64, bonded=False, lj=False, pme=True)
+    o = case.oracle(np.float64)
+    f1 = o.forces(None, nthreads=1, pairwise=False, specific=False, general=True)
+    for nt in (2, 3, 8):
+        ft = o.forces(None, nthreads=nt, pairwise=False, specific=False, general=True)
+        assert np.abs(ft - f1).max() < 1e-10 * np.abs(f1).max()
+    o32 = case.oracle(np.float32)
+    g1 = o32.forces(None, nthreads=1, pairwise=False, specific=False, general=True).astype(np.float64)
+    g8 = o32.forces(None, nthreads=8, pairwise=False, specific=False, general=True).astype(np.float64)
+    assert np.abs(g8 - g1).max() < 1e-4 * np.abs(g1).max()
+
+
 def test_100_step_pme_trajectory_vs_openmm():
     """test/protein.jl:278-299: 100 velocity-Verlet steps of 0.5 fs with every interaction incl. PME"""
     d = G.data()

@@ -1,6 +1,7 @@
 """SURVEY §8(d) cfg 5: 6mrr reaction-field fp64 NVE, remove_CM_motion = 0, dt = 0.5 fs, 20 000 steps, KE + PE every 100 steps.
 Reports max |E − E0| and the least-squares linear drift per ns per atom (report, not a gate).  Also the LJ fluid of
-test/energy_conservation.jl's kind (2000+ atoms, fp64).  Needs an MI355X:   python tools/nve_drift.py > gpurun_out/nve_drift.json"""
+test/energy_conservation.jl's kind (2000+ atoms, fp64).  Needs an MI355X:   python tools/nve_drift.py > gpurun_out/nve_drift.json
+`--oracle [N]`: instead, N (2000) steps of the 6mrr system on the engine AND on the CPU oracle, both energy traces side by side."""
 import json
 import os
 import sys
@@ -33,7 +34,55 @@ def run(case, dtype, dt, n_steps, every, label):
             "kT_300K_kJ_mol": 2.494, "temperature_end_K": float(m.temperature(s))}
 
 
+def oracle_trace(case, dt, n_steps, every, nthreads):
+    """The ORACLE's energy trace (CPU restatement of the reference, fp64) over the same steps of the same system, next to the engine's: if
+    both show the same excursions and the same drift, the drift is the physics of the system and the time step (flexible TIP3P from a
+    constrained-equilibrated start, velocity Verlet at ω·dt ≈ 0.35), not a defect of the engine."""
+    o = case.oracle(np.float64)
+    o.native = True
+    specific = case.bonds is not None
+    def energy():
+        nl = o.neighbors("cell", nthreads=nthreads)
+        return o.kinetic_energy() + o.potential_energy(nl, specific=specific)
+    es = [energy()]
+    for k in range(n_steps // every):
+        o.vv_run(every, dt, first_step=k * every, remove_cm_every=0, nthreads=nthreads, specific=specific)
+        es.append(energy())
+    return np.array(es)
+
+
+def engine_trace(case, dtype, dt, n_steps, every):
+    s = case.system(m, dtype)
+    sim = m.VelocityVerlet(dt=dt, remove_CM_motion=0)
+    es = [m.total_energy(s)]
+    for k in range(n_steps // every):
+        m.simulate(s, sim, every, init_step=k * every)
+        es.append(m.total_energy(s))
+    return np.array(es)
+
+
+def compare_with_oracle(n_steps=2000, every=100):
+    from tests import golden6mrr as G
+    case = G.case("rf", np.float64, bonded=True)
+    nthreads = min(os.cpu_count() or 1, 64)
+    e_orc = oracle_trace(case, 0.0005, n_steps, every, nthreads)
+    e_eng = engine_trace(case, np.float64, 0.0005, n_steps, every)
+    t_ns = np.arange(len(e_orc)) * every * 0.0005 * 1e-3
+    return {"system": "6mrr reaction field + LJ + bonded (BASELINE configs[4]): engine against the oracle, same start, same steps",
+            "n_atoms": case.n, "steps": n_steps, "log_every": every, "dt_fs": 0.5, "oracle_threads": nthreads,
+            "E_engine_kJ_mol": [float(v) for v in e_eng], "E_oracle_kJ_mol": [float(v) for v in e_orc],
+            "max_abs_E_engine_minus_E_oracle_kJ_mol": float(np.abs(e_eng - e_orc).max()),
+            "max_abs_dE_engine_kJ_mol": float(np.abs(e_eng - e_eng[0]).max()), "max_abs_dE_oracle_kJ_mol": float(np.abs(e_orc - e_orc[0]).max()),
+            "linear_drift_engine_kJ_mol_per_ns_per_atom": float(np.polyfit(t_ns, e_eng, 1)[0] / case.n),
+            "linear_drift_oracle_kJ_mol_per_ns_per_atom": float(np.polyfit(t_ns, e_orc, 1)[0] / case.n)}
+
+
 if __name__ == "__main__":
+    if "--oracle" in sys.argv:      # only the engine-against-oracle comparison (≈ 1 min of CPU at 64 threads)
+        k = sys.argv.index("--oracle")
+        n = int(sys.argv[k + 1]) if len(sys.argv) > k + 1 and sys.argv[k + 1].isdigit() else 2000
+        print(json.dumps([compare_with_oracle(n)], indent=1))
+        sys.exit(0)
     from tests import golden6mrr as G
     from tests import systems as S
     out = [run(G.case("rf", np.float64, bonded=True), np.float64, 0.0005, 20000, 100, "6mrr reaction field + LJ + bonded (BASELINE configs[4])"),
