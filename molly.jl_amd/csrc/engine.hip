@@ -176,6 +176,11 @@ template <class T> class Engine final : public EngineBase {
     // lanes of the inner list sorted by row count (kernels.h, ForceArgs::lane_atom): the permutation of the list in use, the row counts
     // it was emitted with (the order of the next prune) and the outer rows' counts (the order of the first prune after a search)
     DBuf<uint16_t> lane_atom_in, cnt_in, cnt_outer; bool lanes_sorted = false, cnt_in_valid = false, cnt_outer_valid = false;
+    // the pruning pass writes into nbr_tmp / rows_tmp when its output is re-dealt over the j-split waves afterwards (k_rebalance)
+    DBuf<uint2> nbr_tmp; DBuf<int32_t> rows_tmp;
+    // (measured, profiles/r04_force_ab.txt §2: the 1M-atom plain pass gains 6.7 % — 136 M → 128 M slots — and the copy of the 272 MB list costs
+    // as much per prune as that saves in the ≈ 25 passes behind it; 6mrr: −6 % slots, −1.4 % time, the pass there is bound by its densest block. Off.)
+    const bool rebalance_on = env_int("MOLLYHIP_REBALANCE", 0) != 0;
     const bool sort_lanes_on = env_int("MOLLYHIP_SORT_LANES", 0) != 0;   // (measured: 5.6 % fewer slots, but the force pass 5 % SLOWER — lanes that are no longer neighbours in space gather from all over the tile, more LDS bank conflicts)
     DBuf<int32_t> blk_ghost, blk_ghost_in; bool ghost_flags_ok = false, ghost_flags_in_ok = false, interior_done = false;
     int64_t last_prune_step = 0;
@@ -212,7 +217,7 @@ template <class T> class Engine final : public EngineBase {
     // bonded terms and PME run on side streams while the pair kernel runs on the main one; their forces land in frc_side[] and
     // are folded in by the second kick
     hipStream_t side[2] = {nullptr, nullptr}; hipEvent_t ev_pos = nullptr, ev_side[2] = {nullptr, nullptr};
-    DBuf<T4> frc_side[2]; const T4* pend_a = nullptr; const T4* pend_b = nullptr; bool overlap = true;
+    DBuf<T4> frc_side[2]; const T4* pend_a = nullptr; const T4* pend_b = nullptr; bool overlap = true, chain_beside = false; hipStream_t stream_masked = nullptr;
 
     int cm_pending = 0; bool stale = true, minimg = false, params_set = false, state_set = false, frc_valid = false;
     bool coords_moved = false, export_needs_search = false; int64_t n_set_state_refresh = 0;
@@ -242,7 +247,28 @@ template <class T> class Engine final : public EngineBase {
         if (device < 0 || device >= ndev) throw ApiError{MHIP_ERR_INVALID, "device_id out of range"};
         MHIP_HIP(hipSetDevice(device));
         MHIP_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); own_stream = true;
-        overlap = env_int("MOLLYHIP_OVERLAP", 0) != 0;   // measured on MI355X (6mrr): side streams gain nothing, the small kernels do not co-run profitably
+        const int ov = env_int("MOLLYHIP_OVERLAP", 0);
+        overlap = ov == 1;   // measured on MI355X (6mrr): side streams gain nothing, the small kernels do not co-run profitably
+        chain_beside = ov == 2;   // the FUSED reciprocal + bonded chain on ONE side stream, the pair kernel on the main one (MOLLYHIP_SIDE_CUS: its compute units)
+        if (chain_beside) {
+            const int n_cu = env_int("MOLLYHIP_SIDE_CUS", 0);
+            if (n_cu > 0) {      // the side stream gets the LAST n_cu compute units of every group of 32 CU-mask bits … a plain contiguous range of the mask
+                hipDeviceProp_t prop; MHIP_HIP(hipGetDeviceProperties(&prop, device));
+                const int total = prop.multiProcessorCount, words = (total + 31) / 32;
+                std::vector<uint32_t> m_side(words, 0u), m_main(words, 0u);
+                const int stride = env_int("MOLLYHIP_SIDE_CU_STRIDE", 0);      // > 0: every stride-th CU goes to the side stream instead of the top n_cu
+                for (int c = 0; c < total; ++c) {
+                    const bool to_side = stride > 0 ? (c % stride == 0 && c / stride < n_cu) : c >= total - n_cu;
+                    (to_side ? m_side : m_main)[c >> 5] |= 1u << (c & 31);
+                }
+                MHIP_HIP(hipExtStreamCreateWithCUMask(&side[0], (uint32_t)words, m_side.data()));
+                if (env_int("MOLLYHIP_MAIN_MASKED", 1)) {      // … and everything else keeps off them: the main stream is recreated on the complement
+                    MHIP_HIP(hipExtStreamCreateWithCUMask(&stream_masked, (uint32_t)words, m_main.data()));
+                    (void)hipStreamDestroy(stream); stream = stream_masked; stream_masked = nullptr;
+                }
+            } else MHIP_HIP(hipStreamCreateWithFlags(&side[0], hipStreamNonBlocking));
+            MHIP_HIP(hipEventCreateWithFlags(&ev_side[0], hipEventDisableTiming)); MHIP_HIP(hipEventCreateWithFlags(&ev_pos, hipEventDisableTiming));
+        }
         if (overlap) {   // side streams only when asked for: every extra stream is a hardware queue
             for (int k = 0; k < 2; ++k) { MHIP_HIP(hipStreamCreateWithFlags(&side[k], hipStreamNonBlocking)); MHIP_HIP(hipEventCreateWithFlags(&ev_side[k], hipEventDisableTiming)); }
             MHIP_HIP(hipEventCreateWithFlags(&ev_pos, hipEventDisableTiming));
@@ -269,13 +295,14 @@ template <class T> class Engine final : public EngineBase {
         for (int k = 0; k < 2; ++k) { pos[k].release(); vel[k].release(); frc[k].release(); lj[k].release(); orig[k].release(); }
         inv.release(); key_in.release(); key_out.release(); cell_rank.release(); idx_in.release(); perm.release(); cell_cnt.release(); cell_start.release(); cub_tmp.release();
         pos_snap_in.release(); lane_atom_in.release(); cnt_in.release(); cnt_outer.release();
-        wave_rows_in.release(); nbr_in.release(); pos_snap.release(); blk_disp2.release(); tile_idx_in.release(); tile_cnt_in.release(); rows_x.release(); nbr_x.release(); tile_idx_x.release(); tile_cnt_x.release(); blk_ghost.release(); blk_ghost_in.release();
+        nbr_tmp.release(); rows_tmp.release(); wave_rows_in.release(); nbr_in.release(); pos_snap.release(); blk_disp2.release(); tile_idx_in.release(); tile_cnt_in.release(); rows_x.release(); nbr_x.release(); tile_idx_x.release(); tile_cnt_x.release(); blk_ghost.release(); blk_ghost_in.release();
         xl_start.release(); xl_list.release(); tile_idx.release(); tile_cnt.release(); wave_rows.release(); nbr.release(); blk_center.release();
         flags.release(); red_part.release(); red_out.release(); cm_step.release(); vcm.release(); stage_a.release(); stage_b.release(); stage_i.release(); bonded.release(); pme.release(); frc_scratch.release(); nl_counter.release(); state_changed.release();
         xf_release();
         prof.release();
         for (int k = 0; k < 2; ++k) { if (side[k]) { (void)hipStreamSynchronize(side[k]); (void)hipStreamDestroy(side[k]); } if (ev_side[k]) (void)hipEventDestroy(ev_side[k]); frc_side[k].release(); }
         if (ev_pos) (void)hipEventDestroy(ev_pos);
+        if (stream_masked) (void)hipStreamDestroy(stream_masked);
         if (h_flags) (void)hipHostFree(h_flags);
         if (h_trk) (void)hipHostFree(h_trk);
         if (ev_trk) (void)hipEventDestroy(ev_trk);
@@ -896,6 +923,7 @@ template <class T> class Engine final : public EngineBase {
         if (dual && !inner_valid && !energy && (prune_by_kernel || prune_lean_ok())) prune_with_filter();
         const bool use_inner = dual && inner_valid;
         const bool prune = dual && !inner_valid && !energy;
+        const bool rebalance = prune && rebalance_on && JS > 1 && !sort_lanes_on;
         const size_t prune_extra = prune ? prune_lds_bytes(std::min(T_cap, max_tile + 1), BI * JS) + 16 : 0;   // a tile that fills the LDS is segmented a little earlier
         carve_force_lds(use_inner ? max_tile_in : max_tile, prune_extra);
         last_pass_tile = use_inner ? max_tile_in : max_tile;
@@ -938,6 +966,10 @@ template <class T> class Engine final : public EngineBase {
                 A.cnt_src = cnt_in_valid ? cnt_in.p : cnt_outer.p; A.cnt_dst = cnt_in.p; A.perm_dst = lane_atom_in.p;
                 lanes_sorted = true; cnt_in_valid = true;
             }
+            if (rebalance && !lanes_sorted) {      // the kept entries go to a scratch list, with their number per (sub-list, lane); k_rebalance deals them into nbr_in
+                nbr_tmp.reserve((size_t)n_blocks * JS * R_cap * BI); rows_tmp.reserve((size_t)n_blocks * JS * (BI / WAVE)); cnt_in.reserve((size_t)n_blocks * JS * BI);
+                A.nbr_dst = nbr_tmp.p; A.rows_dst = rows_tmp.p; A.cnt_dst = cnt_in.p;
+            }
             A.mark_off = (int)((lds_force + 15) & ~(size_t)15);
             lds_force = (size_t)A.mark_off + prune_lds_bytes(tile_lds, BI * JS);   // + renumbering table + scan scratch + wave boxes
             if (lds_force > (size_t)MAX_LDS_BYTES) throw ApiError{MHIP_ERR_CAPACITY, "prune pass LDS carve-up exceeds 160 KiB"};
@@ -947,6 +979,12 @@ template <class T> class Engine final : public EngineBase {
         tr(prune ? "k_forces (prune)" : (energy ? "k_forces (energy)" : "k_forces"));
         launch_forces_any(A, energy);
         tr("after k_forces");
+        if (prune && rebalance && !lanes_sorted) {
+            RebalArgs R{BI, ilog2(BI), JS, R_cap, eshift, (const uint2*)nbr_tmp.p, (const uint16_t*)cnt_in.p, (const int32_t*)tile_cnt_in.p, nbr_in.p, wave_rows_in.p};
+            tr("k_rebalance");
+            hipLaunchKernelGGL(k_rebalance, dim3(n_blocks), dim3(BI * JS), (size_t)JS * BI * sizeof(int32_t), stream, R);
+            MHIP_HIP(hipGetLastError());
+        }
         prof.end(prune ? 4 : 0, stream);
         MHIP_HIP(hipGetLastError());
         ++n_force_calls;
@@ -1068,16 +1106,34 @@ template <class T> class Engine final : public EngineBase {
             prof.end(k == 0 ? 5 : 6, side[k]);
             MHIP_HIP(hipEventRecord(ev_side[k], side[k]));
         }
+        // the fused reciprocal + bonded chain beside the pair kernel: it reads positions only and leaves its forces in the two side arrays
+        const bool beside = chain_beside && fuse_small && bonded.any() && pme.on() && !Bonded<T>::use_atomics() && n_ghost == 0;
+        if (beside) {
+            frc_side[0].reserve(cap); frc_side[1].reserve(cap);
+            MHIP_HIP(hipEventRecord(ev_pos, stream));
+            MHIP_HIP(hipStreamWaitEvent(side[0], ev_pos, 0));
+            prof.begin(6, side[0]);
+            launch_pme_bonded_fused<T>(side[0], pme, bonded, G, I, n_owned, cap, pos[cur].p, inv.p, orig[cur].p, frc_side[1].p, frc_side[0].p, true);
+            prof.end(6, side[0]);
+            MHIP_HIP(hipEventRecord(ev_side[0], side[0]));
+        }
         launch_pair_kernel(false, interior_done ? 2 : 0);   // (the blocks without ghosts may have run already, while the ghosts were on the wire)
         interior_done = false;
         bool redo = false;
         if (prune_disp_exceeded) {   // the outer list could not vouch for this pass: search again and redo it on the fresh list
             for (int k = 0; k < 2; ++k) if (k == 0 ? side_b : side_p) MHIP_HIP(hipStreamWaitEvent(stream, ev_side[k], 0));   // they read the old order
+            if (beside) MHIP_HIP(hipStreamWaitEvent(stream, ev_side[0], 0));
             after_forces(step_n);
             launch_pair_kernel(false);
             redo = true;
         }
         pend_a = pend_b = nullptr;
+        if (beside && !redo) {      // (a redo re-sorted the atoms: the chain's side arrays are in the old order, the fused launches below repeat it)
+            MHIP_HIP(hipStreamWaitEvent(stream, ev_side[0], 0));
+            pend_a = frc_side[0].p; pend_b = frc_side[1].p;
+            frc_valid = true;
+            return;
+        }
         // small systems: charge spreading next to the bonded terms, force interpolation next to the bonded sums (step_fused.h)
         if (!overlap && fuse_small && bonded.any() && pme.on() && !Bonded<T>::use_atomics() && n_ghost == 0) {
             frc_side[0].reserve(cap);

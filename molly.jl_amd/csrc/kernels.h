@@ -1050,6 +1050,9 @@ __host__ __device__ inline size_t prune_lds_bytes(int t_seg, int nthr) { return 
 #ifndef MHIP_PEXP
 #define MHIP_PEXP 0     // timing experiments of the pruning pass
 #endif
+#ifndef MHIP_PK2
+#define MHIP_PK2 1      // the two-partner packed loop of the fp32 per-atom-parameter variants (0: the one-partner loop everywhere, for A/B runs)
+#endif
 #ifndef MHIP_EXP
 #define MHIP_EXP 0      // timing experiments of the packed loop (tools/force_ab.py); 0 = the product
 #endif
@@ -1101,10 +1104,10 @@ k_forces(ForceArgs<T> A) {
     if constexpr (PER_ATOM_LJ) lji = A.lj[valid ? si : (int64_t)b * A.BI];
     // fp32: the tile (and this lane's own record) carries √ϵ, 0 where σ = 0 — GeometricMixing + LJZeroShortcut become one product per pair
     constexpr bool PRE_E = PER_ATOM_LJ && sizeof(T) == 4;
-    auto pre_e = [](T2 v) { if constexpr (PRE_E) v.y = v.x == T(0) ? T(0) : M<T>::sqrt(v.y); return v; };
+    auto pre_e = [](T2 v) { if constexpr (PRE_E) { v.y = v.x == T(0) ? T(0) : M<T>::sqrt(v.y); v.x *= T(0.5); } return v; };   // (σ/2 as well: LorentzMixing becomes one add, and halving is exact)
     lji = pre_e(lji);
     // this wave's own sub-list (the j-split was done by k_build); the row count is the same for all 64 lanes: a scalar
-    const int rows = __builtin_amdgcn_readfirstlane(A.wave_rows[(b * A.JS + js) * (A.BI >> 6) + (li >> 6)]);
+    const int rows = (MHIP_EXP == 6 && !PRUNE) ? 0 : __builtin_amdgcn_readfirstlane(A.wave_rows[(b * A.JS + js) * (A.BI >> 6) + (li >> 6)]);   // (MHIP_EXP 6: timing experiment, staging and reduction only)
     const uint2* my_rows = A.nbr + (((int64_t)b * A.JS + js) * A.R_cap) * A.BI + li;
     const int32_t* tix = A.tile_idx + (int64_t)b * A.T_cap;
     T fx = T(0), fy = T(0), fz = T(0), pe = T(0);
@@ -1401,6 +1404,57 @@ k_forces(ForceArgs<T> A) {
                 fx = (T)(fx2.x + fx2.y); fy = (T)(fy2.x + fy2.y); fz = (T)(fz2.x + fz2.y);
                 return;
             } }
+            // fp32, per-atom σ / ϵ with the distance cutoff, reaction field or Ewald direct space (A&S erfc) — the solvated-protein loops:
+            // two entries of a row side by side (pair_eval2, physics.h).  The gathers stay 16- and 8-byte records (a random
+            // ds_read_b128 + ds_read_b64 costs 2.7 units of LDS time per partner, six ds_read_b32 of a structure-of-arrays tile 6): the
+            // displacement is taken per partner — (dx, dy) as one packed subtraction out of the record's first register pair —, r² and
+            // the per-partner parameters land in the halves of register pairs, and everything behind them is packed.  A row that names a
+            // special (1-4) pair in any lane of the wave takes the one-partner loop below (3 094 of 4.6 M pairs in 6mrr).
+            constexpr bool PK2 = std::is_same<T, float>::value && LJM == LJ_DIST && (COULM == MHIP_COUL_EWALD_DIRECT || COULM == MHIP_COUL_REACTION_FIELD) && !ENERGY && MHIP_PK2;
+            [[maybe_unused]] bool pk2_ok = false;
+            if constexpr (PK2) pk2_ok = Pk2Consts::usable(reinterpret_cast<const InterP<float>&>(A.I));
+            [[maybe_unused]] auto row_pk2 = [&](const uint2 e4) {
+                if constexpr (PK2) {
+                    const Pk2Consts K(A.I);
+                    const float kqi = (float)A.I.ke * (float)pi.w, si = (float)lji.x, ei24 = 24.f * (float)lji.y;
+                    v2f fxy = {0.f, 0.f}; float fzs = 0.f;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t ew = h ? e4.y : e4.x;
+                        uint32_t sa = ew & 0x7fffu, sb = (ew >> 16) & 0x7fffu;
+                        [[maybe_unused]] const bool real_a = SEG ? (sa - (uint32_t)seg_lo) < (uint32_t)n_here : sa < (uint32_t)tile_n, real_b = SEG ? (sb - (uint32_t)seg_lo) < (uint32_t)n_here : sb < (uint32_t)tile_n;
+                        if constexpr (SEG) { sa = real_a ? sa - (uint32_t)seg_lo : (uint32_t)n_here; sb = real_b ? sb - (uint32_t)seg_lo : (uint32_t)n_here; }   // slots of other segments: the sentinel
+                        float4 pa, pb; float2 la, lb;
+                        if constexpr (EXPV == 7) {   // timing experiment: no LDS gathers (records made up from the entry bits)
+                            pa = make_float4(__uint_as_float(0x3f000000u | sa), __uint_as_float(0x3f100000u | sa), __uint_as_float(0x3f200000u | sa), 0.4f); pb = make_float4(__uint_as_float(0x3f300000u | sb), __uint_as_float(0x3f400000u | sb), __uint_as_float(0x3f000000u | sb), -0.8f);
+                            la = make_float2(0.15f, 0.8f); lb = make_float2(0.f, 0.f);
+                        } else {
+                            pa = *reinterpret_cast<const float4*>(&l_pos[sa]); pb = *reinterpret_cast<const float4*>(&l_pos[sb]);
+                            la = *reinterpret_cast<const float2*>(&l_lj[sa]); lb = *reinterpret_cast<const float2*>(&l_lj[sb]);
+                        }
+                        v2f da, db; float dza, dzb;
+                        if constexpr (MINIMG) {
+                            float x, y, z;
+                            min_image_exact<float>((float)pi.x, (float)pi.y, (float)pi.z, pa.x, pa.y, pa.z, reinterpret_cast<const GridP<float>&>(G), x, y, z); da = (v2f){x, y}; dza = z;
+                            min_image_exact<float>((float)pi.x, (float)pi.y, (float)pi.z, pb.x, pb.y, pb.z, reinterpret_cast<const GridP<float>&>(G), x, y, z); db = (v2f){x, y}; dzb = z;
+                        } else {
+                            const v2f pixy = {(float)pi.x, (float)pi.y};
+                            da = (v2f){pa.x, pa.y} - pixy; db = (v2f){pb.x, pb.y} - pixy; dza = pa.z - (float)pi.z; dzb = pb.z - (float)pi.z;
+                        }
+                        const v2f qa = da * da, qb = db * db;
+                        v2f r2 = {__builtin_fmaf(dza, dza, qa.x + qa.y), __builtin_fmaf(dzb, dzb, qb.x + qb.y)};
+                        if constexpr (MINIMG) { if (G.triclinic) { if (!real_a) r2.x = 1.0e30f; if (!real_b) r2.y = 1.0e30f; } }
+                        if constexpr (PRUNE) {
+                            if (valid && real_a && r2.x <= (float)A.r_prune2) emit(make_entry((uint32_t)l_new[sa], 0u, 0));
+                            if (valid && real_b && r2.y <= (float)A.r_prune2) emit(make_entry((uint32_t)l_new[sb], 0u, 0));
+                        }
+                        const v2f fr = pair_eval2<COULM>(reinterpret_cast<const InterP<float>&>(A.I), K, r2, kqi, (v2f){pa.w, pb.w}, si, (v2f){la.x, lb.x}, ei24, (v2f){la.y, lb.y});
+                        fxy += da * (v2f){fr.x, fr.x}; fxy += db * (v2f){fr.y, fr.y};
+                        fzs = __builtin_fmaf(dza, fr.x, __builtin_fmaf(dzb, fr.y, fzs));
+                    }
+                    fx -= (T)fxy.x; fy -= (T)fxy.y; fz -= (T)fzs;   // force on i is −f (force.jl:873)
+                }
+            };
             uint2 e_next = (0 < rows) ? my_rows[0] : make_uint2(0, 0);
             // (the fp64 Ewald loop with the in-loop minimum image — 27-image search included — is not unrolled: four copies of it
             // exceed the 256 VGPRs of a 512-lane block and spill)
@@ -1408,6 +1462,9 @@ k_forces(ForceArgs<T> A) {
             for (int r = 0; r < rows; ++r) {
                 const uint2 e4 = e_next;
                 if (r + 1 < rows) e_next = my_rows[(int64_t)(r + 1) * A.BI];
+                if constexpr (PK2) {
+                    if (pk2_ok && (!SPEC || __builtin_amdgcn_ballot_w64(((e4.x | e4.y) & 0x80008000u) != 0u) == 0ull)) { row_pk2(e4); continue; }
+                }
 #pragma unroll UNROLL
                 for (int k = 0; k < 4; ++k) {
                     uint32_t e = ((k < 2 ? e4.x : e4.y) >> (16 * (k & 1))) & 0xffffu;
@@ -1499,6 +1556,52 @@ k_forces(ForceArgs<T> A) {
             __syncthreads();
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Dealing an atom's inner-list entries evenly over its j-split waves.  k_build gives wave js of a block the tile atoms t ≡ js (mod JS), and
+// the pruning pass keeps that split; how many of an atom's n neighbours fall to one wave is then binomial(n, 1/JS), and a wave walks as many
+// rows as its longest lane: with 16 sub-lists of ≈ 28 entries (6mrr: 64-atom blocks × 16 waves) the longest of 64 lanes holds ≈ 40, and 38 %
+// of the slots a pass evaluates are padding (1M-atom fluid, two sub-lists of ≈ 58: 17 %).  Nothing in the force pass depends on WHICH
+// entries a wave holds — every wave sees the whole tile — so after each prune this kernel re-deals them: the atom's entries, in the order
+// sub-list 0, 1, …, are cut into JS runs of ⌈n/JS⌉ and run js becomes the new sub-list js (same row format; the order of an atom's
+// entries and hence the set per wave changes, the set per atom does not: the force is the same sum in another, still fixed, order).
+// src / cnt: what the prune wrote (rows [b][js][r][lane], kept entries per (b, js, lane)); dst / rows_dst: the balanced list.
+struct RebalArgs { int BI, BI_shift, JS, R_cap, eshift; const uint2* src; const uint16_t* cnt; const int32_t* tile_cnt; uint2* dst; int32_t* rows_dst; };
+[[maybe_unused]] static __global__ void __launch_bounds__(1024) k_rebalance(RebalArgs A) {
+    extern __shared__ __align__(16) unsigned char rb_smem[];
+    int32_t* l_cnt = reinterpret_cast<int32_t*>(rb_smem);                 // [JS][BI]
+    const int b = blockIdx.x, tid = threadIdx.x, li = tid & (A.BI - 1), js = tid >> A.BI_shift;
+    const int64_t sub0 = (int64_t)b * A.JS;
+    l_cnt[js * A.BI + li] = (int)A.cnt[(sub0 + js) * A.BI + li];
+    __syncthreads();
+    int total = 0;
+    for (int q = 0; q < A.JS; ++q) total += l_cnt[q * A.BI + li];
+    const int per = (total + A.JS - 1) / A.JS;                              // entries of this atom per destination wave
+    const int k0 = min(js * per, total), k1 = min(k0 + per, total);
+    int rows = (k1 - k0 + 3) >> 2;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) rows = max(rows, __shfl_xor(rows, o, WAVE));
+    if ((tid & (WAVE - 1)) == 0) A.rows_dst[(sub0 + js) * (A.BI >> 6) + (li >> 6)] = rows;
+    uint2* out = A.dst + ((sub0 + js) * A.R_cap) * A.BI + li;
+    uint64_t acc = 0; int n = 0;
+    auto put = [&](uint32_t e) {
+        acc |= (uint64_t)e << ((n & 3) * 16);
+        if ((n & 3) == 3) { out[(int64_t)(n >> 2) * A.BI] = make_uint2((uint32_t)acc, (uint32_t)(acc >> 32)); acc = 0; }
+        ++n;
+    };
+    int sj = 0, base = 0, c = l_cnt[li];                                    // source sub-list, its first entry's number, its length
+    for (int k = k0; k < k1;) {
+        const int idx = k - base;
+        if (idx >= c) { base += c; ++sj; c = l_cnt[sj * A.BI + li]; continue; }
+        const uint2 row = A.src[((sub0 + sj) * A.R_cap + (idx >> 2)) * A.BI + li];
+        const uint64_t w = (uint64_t)row.x | ((uint64_t)row.y << 32);
+        const int sub = idx & 3, take = min(4 - sub, min(c - idx, k1 - k));
+        for (int t = 0; t < take; ++t) put((uint32_t)(w >> ((sub + t) * 16)) & 0xffffu);
+        k += take;
+    }
+    const uint32_t SENT = make_entry((uint32_t)A.tile_cnt[b], 0u, A.eshift);
+    while ((n & 3) != 0 || (n >> 2) < rows) put(SENT);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -216,7 +216,7 @@ __device__ inline T pair_eval(const InterP<T>& I, T r2, T qi, T qj, T si, T sj, 
         fr += in ? f * w : T(0);
         if constexpr (ENERGY) pe += in ? I.lj_4e * (six * six - six) * w : T(0);
     } else if constexpr (LJM != LJ_OFF) {
-        T s = (si + sj) * T(0.5);                                   // LorentzMixing
+        T s = PRE_E ? si + sj : (si + sj) * T(0.5);                 // LorentzMixing (PRE_E: both arrive halved — exact, so the sum is the same number)
         T e;
         if constexpr (PRE_E) e = ei * ej;                           // √ϵi·√ϵj, either factor 0 where σ = 0
         else {
@@ -267,6 +267,66 @@ __device__ inline T pair_eval(const InterP<T>& I, T r2, T qi, T qj, T si, T sj, 
         if constexpr (ENERGY) pe += in ? kqq * inv_r * (special ? I.c_w : ec) : T(0);
     }
     return fr;
+}
+
+// ---- two partners side by side (fp32) -------------------------------------------------------------------------------------------
+// The per-atom-parameter fp32 loops evaluate two list entries at once in the halves of 64-bit registers: everything between r² and the
+// force factor is v_pk_*_f32 (two pairs per instruction; the packed pipe issues at 5.4 cycles per wave-instruction against 4.2 for a
+// plain one: 1.55× per pair), the transcendental unit is asked three times per pair instead of five or six — v_rsq per partner, v_exp
+// per partner, and ONE v_rcp per two partners for the Abramowitz–Stegun t = 1/(1 + p·αr): t_a = d_b/(d_a d_b), t_b = d_a/(d_a d_b),
+// both d in [1, 2] inside the cutoff — and the cutoffs are a clamped packed FMA, clamp((rc²⁺ − r²)·2¹⁰⁰) ∈ {0, 1} exactly
+// (rc²⁺ = the float after rc²: r² <= rc² as the reference tests r <= rc), instead of v_cmp + v_cndmask per partner.
+// Same formulas as pair_eval<float, LJ_DIST, EWALD / RF, false, PRE_E = true> (lennard_jones.jl:106-109, coulomb.jl:764-803, 1384-1441,
+// mixing.jl:3-34); neither partner may be a special (1-4) pair — rows that hold one take the one-partner path.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ inline v2f pk_clamp01(v2f r2, v2f neg_big, v2f rc2n_big) {      // {r2.x <= rc2, r2.y <= rc2} as 1.0f / 0.0f
+    v2f in;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp\n\ts_nop 0" : "=v"(in) : "v"(r2), "v"(neg_big), "v"(rc2n_big));   // (the nop: a dependent read of a packed result needs a wait state the hazard recogniser cannot see)
+    return in;
+}
+struct Pk2Consts {           // per launch, wave-uniform
+    v2f cut_a, cut_b;
+    __device__ inline explicit Pk2Consts(const InterP<float>& I) {
+        const float a = __int_as_float(__float_as_int(I.lj_rc2) + 1);
+        cut_a = (v2f){-0x1p100f, -0x1p100f}; cut_b = (v2f){a * 0x1p100f, a * 0x1p100f};
+    }
+    // (one cutoff for both interactions — what setup.jl's dist_cutoff gives; a launch with two different ones keeps the one-partner loop)
+    __device__ static inline bool usable(const InterP<float>& I) { return I.lj_rc2 == I.c_rc2; }
+};
+// kqi = ke·q_i, si = σ_i/2, ei24 = 24·√ϵ_i (0 where σ_i = 0); qj, sj (= σ_j/2), ej (= √ϵ_j) of the two partners.
+// F/r = [24ϵ(2 s6² − s6) + kqq·g(r)/r] / r² inside the cutoff, g = erfc(αr) + 2αr/√π·exp(−α²r²) (Ewald) or 1 − 2 krf r³ (reaction field)
+template <int COULM>
+__device__ inline v2f pair_eval2(const InterP<float>& I, const Pk2Consts& K, v2f r2, float kqi, v2f qj, float si, v2f sj, float ei24, v2f ej) {
+    const v2f inv_r = {__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+    const v2f inv_r2 = inv_r * inv_r;
+    const v2f in = pk_clamp01(r2, K.cut_a, K.cut_b);
+    const v2f s = sj + (v2f){si, si};
+    v2f six = (s * s) * inv_r2; six = six * six * six;
+    const v2f t6 = __builtin_elementwise_fma(six, (v2f){2.f, 2.f}, (v2f){-1.f, -1.f}) * six;
+    const v2f lj = (ej * (v2f){ei24, ei24}) * t6;
+    const v2f kq_ir = (qj * (v2f){kqi, kqi}) * inv_r;
+    v2f sum;
+    if constexpr (COULM == MHIP_COUL_REACTION_FIELD) {
+        const v2f r3 = r2 * (r2 * inv_r);
+        const v2f g = __builtin_elementwise_fma(r3, (v2f){-2.f * I.krf, -2.f * I.krf}, (v2f){1.f, 1.f});
+        sum = __builtin_elementwise_fma(kq_ir, g, lj);
+    } else {
+        const v2f r = r2 * inv_r;
+        const float na2 = -1.4426950408889634f * I.alpha * I.alpha, pa = 0.3275911f * I.alpha, ca = I.two_over_sqrt_pi * I.alpha;
+        const v2f x2 = r2 * (v2f){na2, na2};                                                     // exp(−(αr)²) = 2^(−α² r² log2 e)
+        const v2f ex = {__builtin_amdgcn_exp2f(x2.x), __builtin_amdgcn_exp2f(x2.y)};
+        const v2f d = __builtin_elementwise_fma(r, (v2f){pa, pa}, (v2f){1.f, 1.f});
+        const float invd = __builtin_amdgcn_rcpf(d.x * d.y);
+        const v2f t = (v2f){d.y, d.x} * (v2f){invd, invd};
+        v2f pl = __builtin_elementwise_fma(t, (v2f){1.061405429f, 1.061405429f}, (v2f){-1.453152027f, -1.453152027f});
+        pl = __builtin_elementwise_fma(pl, t, (v2f){1.421413741f, 1.421413741f});
+        pl = __builtin_elementwise_fma(pl, t, (v2f){-0.284496736f, -0.284496736f});
+        pl = __builtin_elementwise_fma(pl, t, (v2f){0.254829592f, 0.254829592f});
+        const v2f ec = (pl * t) * ex;                                                             // calc_erfc, coulomb.jl:1384-1393
+        const v2f g = __builtin_elementwise_fma(r * ex, (v2f){ca, ca}, ec);
+        sum = __builtin_elementwise_fma(kq_ir, g, lj);
+    }
+    return sum * (inv_r2 * in);
 }
 
 }  // namespace mhip

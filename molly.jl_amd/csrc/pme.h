@@ -238,7 +238,9 @@ __global__ void __launch_bounds__(256) k_pme_spread(int64_t n_atoms, const typen
 }
 
 // interpolate_force_inner! (:805-840): Fs[i] -= q (∂θ/∂r ⊗ θ ⊗ θ) · φ, same two phases, shuffle reduction inside the half-wave
-template <class T, int ORDER>
+// STORE: the reciprocal-space force of EVERY atom is written to frc (zero for an uncharged one) instead of being added to what is there —
+// for the chain that runs beside the pair kernel on a stream of its own and must not touch the array that kernel writes
+template <class T, int ORDER, bool STORE = false>
 __device__ inline void pme_gather_blocks(int bid, int nblk, int64_t n_atoms, const typename Vec<T>::T4* __restrict__ pos, const T* __restrict__ grid,
                                          typename Vec<T>::T4* frc, const PmeP<T>& P) {
     __shared__ T l_w[6 * ORDER * PME_AB]; __shared__ int l_i[3 * PME_AB]; __shared__ T l_q[PME_AB];
@@ -275,7 +277,9 @@ __device__ inline void pme_gather_blocks(int bid, int nblk, int64_t n_atoms, con
             }
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) { fx += __shfl_xor(fx, o, 64); fy += __shfl_xor(fy, o, 64); fz += __shfl_xor(fz, o, 64); }   // stays inside the 32-lane half
-            if (sub == 0 && q != T(0)) {
+            if constexpr (STORE) {
+                if (sub == 0 && a0 + t < n_atoms) frc[a0 + t] = make4<T>(-(q * (fx * P.n_over_L[0])), -(q * (fy * P.n_over_L[1])), -(q * (fz * P.n_over_L[2])), T(0));
+            } else if (sub == 0 && q != T(0)) {
                 auto f = frc[a0 + t];
                 f.x -= q * (fx * P.n_over_L[0]); f.y -= q * (fy * P.n_over_L[1]); f.z -= q * (fz * P.n_over_L[2]);
                 frc[a0 + t] = f;

@@ -21,18 +21,18 @@ __global__ void __launch_bounds__(256) k_spread_bonded(int64_t n_atoms, const ty
     bonded_terms<T, false, true>(B, ((int)blockIdx.x - n_spread) * 4 + (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), 64, e);   // four 64-lane term blocks per workgroup
 }
 
-template <class T, int ORDER>
+template <class T, int ORDER, bool STORE = false>
 __global__ void __launch_bounds__(256) k_gather_collect(int64_t n_atoms, const typename Vec<T>::T4* __restrict__ pos, const T* __restrict__ phi, typename Vec<T>::T4* frc, PmeP<T> P,
                                                         int n_gather, const int32_t* __restrict__ orig, const int32_t* __restrict__ role_start, const int32_t* __restrict__ role_slot,
                                                         const typename Vec<T>::T4* __restrict__ slots, typename Vec<T>::T4* side) {
-    if ((int)blockIdx.x < n_gather) { pme_gather_blocks<T, ORDER>((int)blockIdx.x, n_gather, n_atoms, pos, phi, frc, P); return; }
+    if ((int)blockIdx.x < n_gather) { pme_gather_blocks<T, ORDER, STORE>((int)blockIdx.x, n_gather, n_atoms, pos, phi, frc, P); return; }
     bonded_collect_lane<T, true>(((int64_t)blockIdx.x - n_gather) * blockDim.x + threadIdx.x, n_atoms, orig, role_start, role_slot, slots, side);
 }
 
-// reciprocal-space PME forces added to frc, bonded forces left in `side` (every owned atom written)
+// reciprocal-space PME forces added to frc (store: written to frc, every owned atom), bonded forces left in `side` (every owned atom written)
 template <class T>
 inline void launch_pme_bonded_fused(hipStream_t s, Pme<T>& pme, Bonded<T>& bonded, const GridP<T>& G, const InterP<T>& I, int64_t n_owned, int64_t cap,
-                                    const typename Vec<T>::T4* pos, const int32_t* inv, const int32_t* orig, typename Vec<T>::T4* frc, typename Vec<T>::T4* side) {
+                                    const typename Vec<T>::T4* pos, const int32_t* inv, const int32_t* orig, typename Vec<T>::T4* frc, typename Vec<T>::T4* side, bool store = false) {
     bonded.ensure_roles(s, cap);
     const BondedArgs<T> B = bonded.slot_args(G, I, pos, inv);
     const int n_term_wg = cdiv(bonded.n_blocks(), 4);
@@ -54,7 +54,9 @@ inline void launch_pme_bonded_fused(hipStream_t s, Pme<T>& pme, Bonded<T>& bonde
     const int n_collect = (int)cdiv(n_owned * COLLECT_LANES, (int64_t)256);
     auto gather = [&](auto order_tag) {
         constexpr int ORDER = decltype(order_tag)::value;
-        hipLaunchKernelGGL((k_gather_collect<T, ORDER>), dim3(n_gather + n_collect), dim3(256), 0, s, n_owned, pos, (const T*)pme.phi.p, frc, pme.P, n_gather, orig,
+        if (store) hipLaunchKernelGGL((k_gather_collect<T, ORDER, true>), dim3(n_gather + n_collect), dim3(256), 0, s, n_owned, pos, (const T*)pme.phi.p, frc, pme.P, n_gather, orig,
+                           (const int32_t*)bonded.role_start.p, (const int32_t*)bonded.role_slot.p, (const typename Vec<T>::T4*)bonded.slots, side);
+        else hipLaunchKernelGGL((k_gather_collect<T, ORDER>), dim3(n_gather + n_collect), dim3(256), 0, s, n_owned, pos, (const T*)pme.phi.p, frc, pme.P, n_gather, orig,
                            (const int32_t*)bonded.role_start.p, (const int32_t*)bonded.role_slot.p, (const typename Vec<T>::T4*)bonded.slots, side);
     };
     if (pme.order == 4) gather(std::integral_constant<int, 4>{}); else if (pme.order == 5) gather(std::integral_constant<int, 5>{}); else gather(std::integral_constant<int, 6>{});

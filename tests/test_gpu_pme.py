@@ -86,22 +86,31 @@ def test_100_step_pme_trajectory_vs_openmm_fp64(pkg):
 
 def test_all_pme_fp32_total_force_vs_openmm(pkg):
     """The configuration bench.py TIMES (6mrr_pme: Float32, LJ + Ewald direct space with the A&S erfc + bonded + EwaldExclusion + PME
-    reciprocal space) as ONE force evaluation against OpenMM's forces_all_pme.txt.  Bar per atom: the fp32 pair bar 4e-5·Σ_j‖f_ij‖
-    (tests/systems.py) + 2e-5 of the atom's bonded force scale + 2e-4 of the largest reciprocal-space force (the fp32 mesh sums) + the
-    reference's own fp64 bar for the approximate erfc against OpenMM, 1e-3 (test/protein.jl:274); relative RMS over all atoms 2e-5.
-    The energy: the reference's approximate-erfc bar, 0.2 kJ/mol, + 1e-6 of Σ|e| in fp32 (|E_pair| ≈ 2.7e5)."""
+    reciprocal space) as ONE force evaluation against OpenMM's forces_all_pme.txt.
+    Two parts, because two things separate an fp32 engine from that file.  (a) The INPUTS: coordinates rounded to fp32 (ulp/2 = 2.4e-7 nm
+    at 5 nm) under bond constants of 4e5 kJ mol⁻¹ nm⁻² move a force by ≈ 0.1 per bond whatever the arithmetic — the fp64 oracle on the
+    rounded inputs is 0.31 kJ mol⁻¹ nm⁻¹ off OpenMM at the worst atom (on forces of up to 6 300).  (b) The ARITHMETIC: the engine against
+    that fp64 oracle on the same rounded inputs, per atom within the fp32 pair bar 4e-5·Σ_j‖f_ij‖ (tests/systems.py) + 2e-5 of the atom's
+    bonded force scale + 2e-4 of the largest reciprocal-space force (fp32 mesh sums) + 1e-3 (the reference's approximate-erfc bar
+    against OpenMM, test/protein.jl:274).  Against OpenMM itself: (a) + (b) per atom, 1 kJ mol⁻¹ nm⁻¹ at the worst atom, relative RMS 2e-5.
+    Energy: the reference's approximate-erfc bar 0.2 kJ/mol + 1e-6 of Σ|e_ij| ≈ 6e5 in fp32."""
     d = G.data()
     case = G.case("ewald", np.float32, bonded=True, pme=True)                 # approximate_erfc = True: the default, and what is timed
     tol, o, nl = S.fp32_force_tolerance(case)
     bonded_scale = np.linalg.norm(o.forces(None, pairwise=False, specific=True), axis=1)
     pme_scale = np.linalg.norm(o.forces(None, pairwise=False, specific=False, general=True), axis=1).max()
+    f_ref = o.forces(nl, nthreads=8, specific=True, general=True)             # fp64 arithmetic on the fp32-rounded inputs
+    f_omm = d["openmm_forces_all_pme"]
+    input_term = np.linalg.norm(f_ref - f_omm, axis=1)
+    assert input_term.max() < 0.5
     s = case.system(pkg, np.float32)
     f = pkg.forces(s).astype(np.float64)
-    f_omm = d["openmm_forces_all_pme"]
-    err = np.linalg.norm(f - f_omm, axis=1)
     bar = tol + 2e-5 * bonded_scale + 2e-4 * pme_scale + 1e-3
-    assert np.all(err <= bar), f"worst {err.max():.3e} at atom {err.argmax()} (bar {bar[err.argmax()]:.3e})"
-    assert S.rel_rms(err, f_omm) < 2e-5
+    err = np.linalg.norm(f - f_ref, axis=1)
+    assert np.all(err <= bar), f"worst ratio {(err / bar).max():.2f} at atom {(err / bar).argmax()}"
+    err_omm = np.linalg.norm(f - f_omm, axis=1)
+    assert np.all(err_omm <= bar + input_term) and err_omm.max() < 1.0
+    assert S.rel_rms(err_omm, f_omm) < 2e-5
     e = pkg.potential_energy(s) + G.lj_dispersion_correction(d)
     assert abs(e - float(d["openmm_energy_all_pme"])) < 0.2 + 0.6
 
