@@ -205,9 +205,12 @@ __global__ void k_bonded_virial(BondedArgs<T> A, int n_blocks_total) {
 constexpr int COLLECT_LANES = 8;
 // gt = global lane number (COLLECT_LANES per atom).  ASSIGN: out[s] = the sum (zero for atoms without terms) instead of out[s] += it —
 // for a launch that runs next to another writer of the force array (step_fused.h) and leaves its share in a side array.
+// parts (nullable): n_parts more force arrays, part_stride atoms apart, whose entry of the atom is added in fixed order — the partial pair
+// forces of the group-split pass (forces_gs.hip), folded in by the one launch that visits every atom anyway.
 template <class T, bool ASSIGN>
 __device__ inline void bonded_collect_lane(int64_t gt, int64_t n_owned, const int32_t* __restrict__ orig, const int32_t* __restrict__ role_start, const int32_t* __restrict__ role_slot,
-                                           const typename Vec<T>::T4* __restrict__ slots, typename Vec<T>::T4* out) {
+                                           const typename Vec<T>::T4* __restrict__ slots, typename Vec<T>::T4* out,
+                                           const typename Vec<T>::T4* __restrict__ parts = nullptr, int n_parts = 0, int64_t part_stride = 0) {
     const int64_t s = gt / COLLECT_LANES;
     const int l = (int)(gt % COLLECT_LANES);
     const bool live = s < n_owned;
@@ -217,9 +220,10 @@ __device__ inline void bonded_collect_lane(int64_t gt, int64_t n_owned, const in
     for (int r = r0 + l; r < r1; r += COLLECT_LANES) { const auto v = slots[role_slot[r]]; fx += v.x; fy += v.y; fz += v.z; }
 #pragma unroll
     for (int o = COLLECT_LANES / 2; o > 0; o >>= 1) { fx += __shfl_xor(fx, o, 64); fy += __shfl_xor(fy, o, 64); fz += __shfl_xor(fz, o, 64); }
+    if (parts && live && l == 0) for (int q = 0; q < n_parts; ++q) { const auto v = parts[(int64_t)q * part_stride + s]; fx += v.x; fy += v.y; fz += v.z; }
     if constexpr (ASSIGN) {
         if (live && l == 0) out[s] = make4<T>(fx, fy, fz, T(0));
-    } else if (live && l == 0 && r1 > r0) {
+    } else if (live && l == 0 && (r1 > r0 || parts)) {
         auto f = out[s];
         f.x += fx; f.y += fy; f.z += fz;
         out[s] = f;
@@ -227,8 +231,9 @@ __device__ inline void bonded_collect_lane(int64_t gt, int64_t n_owned, const in
 }
 template <class T>
 __global__ void k_bonded_collect(int64_t n_owned, const int32_t* __restrict__ orig, const int32_t* __restrict__ role_start, const int32_t* __restrict__ role_slot,
-                                 const typename Vec<T>::T4* __restrict__ slots, typename Vec<T>::T4* frc) {
-    bonded_collect_lane<T, false>(blockIdx.x * (int64_t)blockDim.x + threadIdx.x, n_owned, orig, role_start, role_slot, slots, frc);
+                                 const typename Vec<T>::T4* __restrict__ slots, typename Vec<T>::T4* frc,
+                                 const typename Vec<T>::T4* __restrict__ parts, int n_parts, int64_t part_stride) {
+    bonded_collect_lane<T, false>(blockIdx.x * (int64_t)blockDim.x + threadIdx.x, n_owned, orig, role_start, role_slot, slots, frc, parts, n_parts, part_stride);
 }
 
 template <class U> struct HBuf {   // device array filled from a host array once
@@ -321,9 +326,14 @@ template <class T> struct Bonded {
         }
         if (roles_dirty || roles_cap != cap) { MHIP_HIP(hipStreamSynchronize(s)); build_roles(cap); }
         hipLaunchKernelGGL((k_bonded<T, false, true>), dim3(nb), dim3(BT), 0, s, args(G, I, pos, inv, slots, nullptr));
-        hipLaunchKernelGGL(k_bonded_collect<T>, dim3((unsigned)cdiv(n_owned * COLLECT_LANES, (int64_t)256)), dim3(256), 0, s, n_owned, orig, (const int32_t*)role_start.p, (const int32_t*)role_slot.p, (const T4*)slots, frc);
+        hipLaunchKernelGGL(k_bonded_collect<T>, dim3((unsigned)cdiv(n_owned * COLLECT_LANES, (int64_t)256)), dim3(256), 0, s, n_owned, orig, (const int32_t*)role_start.p, (const int32_t*)role_slot.p, (const T4*)slots, frc,
+                           fold_parts, fold_n, fold_stride);
+        fold_parts = nullptr; fold_n = 0;
         MHIP_HIP(hipGetLastError());
     }
+    // partial force arrays the NEXT collect launch adds per atom (the group-split pair pass, forces_gs.hip); consumed by that launch
+    const T4* fold_parts = nullptr; int fold_n = 0; int64_t fold_stride = 0;
+    void fold(const T4* parts, int n, int64_t stride) { fold_parts = n > 0 ? parts : nullptr; fold_n = n; fold_stride = stride; }
     // nine component-major runs of per-block partial sums of the specific interactions' virial; returns the run length
     template <class DB> int launch_virial(hipStream_t s, const GridP<T>& G, const InterP<T>& I, const T4* pos, const int32_t* inv, DB& part) {
         int nb = n_blocks();

@@ -178,6 +178,18 @@ template <class T> class Engine final : public EngineBase {
     DBuf<uint16_t> lane_atom_in, cnt_in, cnt_outer; bool lanes_sorted = false, cnt_in_valid = false, cnt_outer_valid = false;
     // the pruning pass writes into nbr_tmp / rows_tmp when its output is re-dealt over the j-split waves afterwards (k_rebalance)
     DBuf<uint2> nbr_tmp; DBuf<int32_t> rows_tmp;
+    // the group-split pair pass of small systems (forces_gs.hip): the inner list re-dealt into GS groups per block after every prune, the
+    // partial forces of groups 1 .. GS − 1 (group 0 writes the force array), and which prune the list belongs to
+    DBuf<uint2> nbr_gs; DBuf<int32_t> rows_gs; DBuf<T4> frc_parts; int64_t gs_list_id = -1; bool gs_used = false;
+    const int gs_env = env_int("MOLLYHIP_GROUP_SPLIT", -1);      // 0: off; 2 / 4: groups per block; −1: automatic
+    int gs_groups() const {
+        if (!std::is_same<T, float>::value || ljm != LJ_DIST || !(coulm == MHIP_COUL_REACTION_FIELD || (coulm == MHIP_COUL_EWALD_DIRECT && I.approx_erfc))) return 0;
+        if (!dual || tri_mode || n_ghost > 0 || G.no_list || sort_lanes_on || gs_env == 0) return 0;
+        const int want = gs_env > 0 ? gs_env : 4;
+        if (want != 4 || JS % want != 0 || BI * (JS / want) != 256) return 0;      // (k_forces_gs is a 256-lane workgroup: 64 atoms × 4 waves of a 16-way j-split)
+        if (gs_env < 0 && (int64_t)n_blocks * JS * (BI / WAVE) > 2 * 4096) return 0;      // enough workgroups already: large systems balance themselves
+        return want;
+    }
     // (measured, profiles/r04_force_ab.txt §2: the 1M-atom plain pass gains 6.7 % — 136 M → 128 M slots — and the copy of the 272 MB list costs
     // as much per prune as that saves in the ≈ 25 passes behind it; 6mrr: −6 % slots, −1.4 % time, the pass there is bound by its densest block. Off.)
     const bool rebalance_on = env_int("MOLLYHIP_REBALANCE", 0) != 0;
@@ -295,7 +307,7 @@ template <class T> class Engine final : public EngineBase {
         for (int k = 0; k < 2; ++k) { pos[k].release(); vel[k].release(); frc[k].release(); lj[k].release(); orig[k].release(); }
         inv.release(); key_in.release(); key_out.release(); cell_rank.release(); idx_in.release(); perm.release(); cell_cnt.release(); cell_start.release(); cub_tmp.release();
         pos_snap_in.release(); lane_atom_in.release(); cnt_in.release(); cnt_outer.release();
-        nbr_tmp.release(); rows_tmp.release(); wave_rows_in.release(); nbr_in.release(); pos_snap.release(); blk_disp2.release(); tile_idx_in.release(); tile_cnt_in.release(); rows_x.release(); nbr_x.release(); tile_idx_x.release(); tile_cnt_x.release(); blk_ghost.release(); blk_ghost_in.release();
+        nbr_tmp.release(); rows_tmp.release(); nbr_gs.release(); rows_gs.release(); frc_parts.release(); wave_rows_in.release(); nbr_in.release(); pos_snap.release(); blk_disp2.release(); tile_idx_in.release(); tile_cnt_in.release(); rows_x.release(); nbr_x.release(); tile_idx_x.release(); tile_cnt_x.release(); blk_ghost.release(); blk_ghost_in.release();
         xl_start.release(); xl_list.release(); tile_idx.release(); tile_cnt.release(); wave_rows.release(); nbr.release(); blk_center.release();
         flags.release(); red_part.release(); red_out.release(); cm_step.release(); vcm.release(); stage_a.release(); stage_b.release(); stage_i.release(); bonded.release(); pme.release(); frc_scratch.release(); nl_counter.release(); state_changed.release();
         xf_release();
@@ -913,7 +925,8 @@ template <class T> class Engine final : public EngineBase {
         }
     }
     // pairwise forces of the current coordinates into frc[cur] (overwrites); energy → red_part[0..n_blocks)
-    void launch_pair_kernel(bool energy, int part = 0) {
+    void launch_pair_kernel(bool energy, int part = 0, bool allow_gs = false) {
+        gs_used = false;
         ForceArgs<T> A;
         A.G = G; A.I = I; A.n_owned = n_owned; A.BI = BI; A.BI_shift = ilog2(BI); A.JS = JS; A.T_cap = T_cap; A.T_lds = tile_lds; A.R_cap = R_cap;
         A.n_blocks = n_blocks; A.blocks_per_xcd = cdiv(n_blocks, 8);
@@ -924,6 +937,29 @@ template <class T> class Engine final : public EngineBase {
         const bool use_inner = dual && inner_valid;
         const bool prune = dual && !inner_valid && !energy;
         const bool rebalance = prune && rebalance_on && JS > 1 && !sort_lanes_on;
+        const int GS = gs_groups();
+        // a plain pass over an inner list that has its group-split form (made right behind the prune that wrote it)
+        if constexpr (std::is_same<T, float>::value) {
+            if (allow_gs && GS > 0 && use_inner && !energy && part == 0 && gs_list_id == n_filters && !frc_override) {
+                const int q_lds = (max_tile_in + GS - 1) / GS + 1;
+                if (gs_lds_bytes(q_lds, BI, JS / GS) <= (size_t)MAX_LDS_BYTES / GS) {
+                    frc_parts.reserve((size_t)(GS - 1) * cap);
+                    GsArgs Z;
+                    Z.G = G; Z.I = I; Z.n_owned = n_owned; Z.BI = BI; Z.BI_shift = ilog2(BI); Z.JS = JS; Z.GS = GS; Z.lgGS = ilog2(GS); Z.R_cap = R_cap; Z.T_cap = T_cap; Z.Q_lds = q_lds;
+                    Z.n_blocks = n_blocks; Z.spread = std::max(1, n_blocks / GS + 5);
+                    Z.pos = pos[cur].p; Z.lj = lj[cur].p; Z.tile_idx = tile_idx_in.p; Z.tile_cnt = tile_cnt_in.p; Z.nbr = nbr_gs.p; Z.wave_rows = rows_gs.p; Z.blk_center = blk_center.p;
+                    Z.frc = frc[cur].p; Z.parts = frc_parts.p; Z.part_stride = cap;
+                    last_pass_tile = max_tile_in;
+                    prof.begin(0, stream);
+                    tr("k_forces_gs");
+                    launch_forces_gs(Z, coulm, minimg, stream);
+                    prof.end(0, stream);
+                    MHIP_HIP(hipGetLastError());
+                    ++n_force_calls; gs_used = true;
+                    return;
+                }
+            }
+        }
         const size_t prune_extra = prune ? prune_lds_bytes(std::min(T_cap, max_tile + 1), BI * JS) + 16 : 0;   // a tile that fills the LDS is segmented a little earlier
         carve_force_lds(use_inner ? max_tile_in : max_tile, prune_extra);
         last_pass_tile = use_inner ? max_tile_in : max_tile;
@@ -966,6 +1002,7 @@ template <class T> class Engine final : public EngineBase {
                 A.cnt_src = cnt_in_valid ? cnt_in.p : cnt_outer.p; A.cnt_dst = cnt_in.p; A.perm_dst = lane_atom_in.p;
                 lanes_sorted = true; cnt_in_valid = true;
             }
+            if (GS > 0 && !lanes_sorted && !rebalance) { cnt_in.reserve((size_t)n_blocks * JS * BI); A.cnt_dst = cnt_in.p; }   // (k_regroup wants the real entries per (sub-list, lane))
             if (rebalance && !lanes_sorted) {      // the kept entries go to a scratch list, with their number per (sub-list, lane); k_rebalance deals them into nbr_in
                 nbr_tmp.reserve((size_t)n_blocks * JS * R_cap * BI); rows_tmp.reserve((size_t)n_blocks * JS * (BI / WAVE)); cnt_in.reserve((size_t)n_blocks * JS * BI);
                 A.nbr_dst = nbr_tmp.p; A.rows_dst = rows_tmp.p; A.cnt_dst = cnt_in.p;
@@ -975,6 +1012,9 @@ template <class T> class Engine final : public EngineBase {
             if (lds_force > (size_t)MAX_LDS_BYTES) throw ApiError{MHIP_ERR_CAPACITY, "prune pass LDS carve-up exceeds 160 KiB"};
         }
         A.blk_center = blk_center.p; A.frc = frc_override ? frc_override : frc[cur].p; A.pe_part = red_part.p;
+        A.dbg = nullptr;
+        static const int dbg_times = env_int("MOLLYHIP_DBG_TIMES", 0);
+        if (dbg_times && !prune && !energy) { dbg_buf.reserve((size_t)n_blocks * 16 * 8); MHIP_HIP(hipMemsetAsync(dbg_buf.p, 0, (size_t)n_blocks * 16 * 8 * sizeof(unsigned long long), stream)); A.dbg = dbg_buf.p; }
         prof.begin(prune ? 4 : 0, stream);   // stage 4 = force passes that also prune the outer list
         tr(prune ? "k_forces (prune)" : (energy ? "k_forces (energy)" : "k_forces"));
         launch_forces_any(A, energy);
@@ -985,9 +1025,19 @@ template <class T> class Engine final : public EngineBase {
             hipLaunchKernelGGL(k_rebalance, dim3(n_blocks), dim3(BI * JS), (size_t)JS * BI * sizeof(int32_t), stream, R);
             MHIP_HIP(hipGetLastError());
         }
+        if constexpr (std::is_same<T, float>::value) {
+            if (prune && GS > 0 && !lanes_sorted && !rebalance) {      // the list this prune wrote, dealt to the groups (it stays as it is for every other kind of pass)
+                nbr_gs.reserve((size_t)n_blocks * JS * R_cap * BI); rows_gs.reserve((size_t)n_blocks * JS * (BI / WAVE));
+                RegroupArgs R{BI, ilog2(BI), JS, GS, ilog2(GS), R_cap, (const uint2*)nbr_in.p, (const uint16_t*)cnt_in.p, (const int32_t*)tile_cnt_in.p, nbr_gs.p, rows_gs.p};
+                tr("k_regroup");
+                launch_regroup(R, n_blocks, stream);
+                gs_list_id = n_filters + 1;      // (n_filters counts this prune below)
+            }
+        }
         prof.end(prune ? 4 : 0, stream);
         MHIP_HIP(hipGetLastError());
         ++n_force_calls;
+        if (A.dbg && (n_force_calls % dbg_times) == 0) dbg_report();
         if (prune) {   // validity of the pruned list: nobody moved more than half the margin since the outer search
             // one single-block launch that leaves its figures in pinned host memory (no zeroing launch, no copy launch) …
             hipLaunchKernelGGL(k_prune_summary, dim3(1), dim3(1024), 0, stream, n_blocks, n_blocks * JS * (BI / WAVE), n_blocks * (BI / WAVE), R_cap,
@@ -1006,6 +1056,28 @@ template <class T> class Engine final : public EngineBase {
         }
     }
 
+    // timing experiment (library built with -DMHIP_EXP=11, MOLLYHIP_DBG_TIMES=n: every n-th plain pass): per-wave phase times of the pair kernel
+    DBuf<unsigned long long> dbg_buf;
+    void dbg_report() {
+        const int nw = BI * JS / WAVE;
+        std::vector<unsigned long long> h((size_t)n_blocks * nw * 8);
+        MHIP_HIP(hipStreamSynchronize(stream));
+        MHIP_HIP(hipMemcpy(h.data(), dbg_buf.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long w0 = ~0ull, w3 = 0; double sum[3] = {0, 0, 0}, mx[3] = {0, 0, 0}, clk = 0; int n = 0;
+        std::vector<double> loop_us;
+        for (size_t q = 0; q < (size_t)n_blocks * nw; ++q) {
+            const unsigned long long* d = &h[q * 8];
+            if (!d[7]) continue;
+            w0 = std::min(w0, d[4]); w3 = std::max(w3, d[7]);
+            for (int k = 0; k < 3; ++k) { const double us = (double)(d[5 + k] - d[4 + k]) * 0.01; sum[k] += us; mx[k] = std::max(mx[k], us); }
+            loop_us.push_back((double)(d[6] - d[5]) * 0.01);
+            if (d[7] > d[4]) clk += (double)(d[3] - d[0]) / ((double)(d[7] - d[4]) * 10.0);   // shader cycles per ns
+            ++n;
+        }
+        std::sort(loop_us.begin(), loop_us.end());
+        std::fprintf(stderr, "[mhip dbg] pair kernel: %d waves, first entry -> last exit %.2f us | per wave mean (max) us: staging %.2f (%.2f) row walk %.2f (%.2f) reduce+store %.2f (%.2f) | row walk p10 %.2f p50 %.2f p90 %.2f | shader clock %.3f GHz\n",
+                     n, (double)(w3 - w0) * 0.01, sum[0] / n, mx[0], sum[1] / n, mx[1], sum[2] / n, mx[2], loop_us[n / 10], loop_us[n / 2], loop_us[(size_t)n * 9 / 10], clk / n);
+    }
     // How far atoms may have moved since the outer search for a prune to be trustworthy: the outer list holds every pair within
     // r_list + outer_margin of then, the prune wants every pair within rc_max + skin_in of now.
     double prune_margin() const { return outer_margin + (skin - skin_in); }
@@ -1117,7 +1189,9 @@ template <class T> class Engine final : public EngineBase {
             prof.end(6, side[0]);
             MHIP_HIP(hipEventRecord(ev_side[0], side[0]));
         }
-        launch_pair_kernel(false, interior_done ? 2 : 0);   // (the blocks without ghosts may have run already, while the ghosts were on the wire)
+        // (group-split passes leave partial forces that the per-atom sums of the bonded slots fold in: only where such a launch follows)
+        const bool gs_ok = bonded.any() && !overlap && !chain_beside && !Bonded<T>::use_atomics() && n_ghost == 0;
+        launch_pair_kernel(false, interior_done ? 2 : 0, gs_ok);   // (the blocks without ghosts may have run already, while the ghosts were on the wire)
         interior_done = false;
         bool redo = false;
         if (prune_disp_exceeded) {   // the outer list could not vouch for this pass: search again and redo it on the fresh list
@@ -1127,6 +1201,7 @@ template <class T> class Engine final : public EngineBase {
             launch_pair_kernel(false);
             redo = true;
         }
+        if (gs_used) bonded.fold(frc_parts.p, gs_groups() - 1, cap);      // the next collect launch adds the groups' partial forces
         pend_a = pend_b = nullptr;
         if (beside && !redo) {      // (a redo re-sorted the atoms: the chain's side arrays are in the old order, the fused launches below repeat it)
             MHIP_HIP(hipStreamWaitEvent(stream, ev_side[0], 0));

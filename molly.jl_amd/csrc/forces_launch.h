@@ -11,4 +11,20 @@ void launch_forces_tc(const ForceArgs<T>& A, int ljm, bool energy, bool minimg, 
 // the fp32 one-type LJ variants (forces only, block-local coordinates)
 void launch_forces_uniform_f32(const ForceArgs<float>& A, bool seg, bool prune, size_t lds, unsigned threads, hipStream_t stream);
 
+// ---- the group-split pair pass of small systems (forces_gs.hip) ----
+struct RegroupArgs {
+    int BI, BI_shift, JS, GS, lgGS, R_cap;
+    const uint2* src; const uint16_t* cnt; const int32_t* tile_cnt;      // the inner list as the prune wrote it, entries per (sub-list, lane), compacted tile sizes
+    uint2* dst; int32_t* rows_dst;                                        // the group-split list
+};
+struct GsArgs {
+    GridP<float> G; InterP<float> I;
+    int64_t n_owned; int BI, BI_shift, JS, GS, lgGS, R_cap, T_cap, Q_lds, n_blocks, spread;
+    const float4* pos; const float2* lj; const int32_t* tile_idx; const int32_t* tile_cnt; const uint2* nbr; const int32_t* wave_rows; const float4* blk_center;
+    float4* frc; float4* parts; int64_t part_stride;                      // group 0 → frc, group g → parts + (g − 1)·part_stride
+};
+size_t gs_lds_bytes(int q_lds, int BI, int JSW);
+void launch_regroup(const RegroupArgs& A, int n_blocks, hipStream_t stream);
+void launch_forces_gs(const GsArgs& A, int coulm, bool minimg, hipStream_t stream);
+
 }  // namespace mhip

@@ -1026,6 +1026,9 @@ template <class T> struct ForceArgs {
     // ghosted sub-domains: a pass over only the blocks whose tile holds no ghost atom (part 1: they can run while the ghost coordinates
     // are still on the wire) or only the others (part 2); 0 = every block
     const int32_t* blk_ghost; int part;
+    // MOLLYHIP_DBG_TIMES (builds with -DMHIP_EXP=11 only): [n_blocks][waves][8] — shader clock and 100 MHz wall clock at kernel entry, behind the
+    // staging barrier, behind the row walk and at the end, per wave
+    unsigned long long* dbg;
 };
 // strides the packed loop is compiled for (odd numbers of dwords): tiles of up to stride − 1 atoms, 12·stride bytes of LDS.  The
 // smallest that holds the tile is used: 36 KiB leaves room for four 512-lane blocks per CU, 48 KiB for three (measured: −12 % per pass).
@@ -1074,6 +1077,12 @@ k_forces(ForceArgs<T> A) {
     if (b >= A.n_blocks) return;
     if (A.part != 0 && (A.blk_ghost[b] != 0) != (A.part == 2)) return;
     const int tid = threadIdx.x, nthr = blockDim.x;
+    [[maybe_unused]] auto stamp = [&](int k) {
+        if constexpr (MHIP_EXP == 11 && !PRUNE) {
+            if (A.dbg && (tid & 63) == 0) { unsigned long long* d = A.dbg + ((size_t)b * (nthr >> 6) + (tid >> 6)) * 8; d[k] = __builtin_readcyclecounter(); d[4 + k] = wall_clock64(); }
+        }
+    };
+    stamp(0);
     const int tile_n = A.tile_cnt[b];
     T4* l_pos = reinterpret_cast<T4*>(smem);
     T2* l_lj = reinterpret_cast<T2*>(l_pos + (A.T_lds + 1));
@@ -1107,7 +1116,9 @@ k_forces(ForceArgs<T> A) {
     auto pre_e = [](T2 v) { if constexpr (PRE_E) { v.y = v.x == T(0) ? T(0) : M<T>::sqrt(v.y); v.x *= T(0.5); } return v; };   // (σ/2 as well: LorentzMixing becomes one add, and halving is exact)
     lji = pre_e(lji);
     // this wave's own sub-list (the j-split was done by k_build); the row count is the same for all 64 lanes: a scalar
-    const int rows = (MHIP_EXP == 6 && !PRUNE) ? 0 : __builtin_amdgcn_readfirstlane(A.wave_rows[(b * A.JS + js) * (A.BI >> 6) + (li >> 6)]);   // (MHIP_EXP 6: timing experiment, staging and reduction only)
+    // (timing experiments — MHIP_EXP 6: staging and reduction only; 8 / 9: no wave walks more than 8 / 4 rows, i.e. every block as light as an average / a half one)
+    const int rows_all = (MHIP_EXP == 6 && !PRUNE) ? 0 : __builtin_amdgcn_readfirstlane(A.wave_rows[(b * A.JS + js) * (A.BI >> 6) + (li >> 6)]);
+    const int rows = (MHIP_EXP == 8 && !PRUNE) ? min(rows_all, 8) : (MHIP_EXP == 9 && !PRUNE) ? min(rows_all, 4) : rows_all;
     const uint2* my_rows = A.nbr + (((int64_t)b * A.JS + js) * A.R_cap) * A.BI + li;
     const int32_t* tix = A.tile_idx + (int64_t)b * A.T_cap;
     T fx = T(0), fy = T(0), fz = T(0), pe = T(0);
@@ -1317,6 +1328,7 @@ k_forces(ForceArgs<T> A) {
             n_new += l_scan[nthr];
             __syncthreads();
         }
+        stamp(1);
         // the row stream is software-pipelined: row r+1 is in flight while row r is evaluated
         auto walk_rows = [&](auto spec_tag) {
             constexpr bool SPEC = decltype(spec_tag)::value;
@@ -1461,6 +1473,10 @@ k_forces(ForceArgs<T> A) {
             constexpr int UNROLL = (sizeof(T) == 8 && (COULM == MHIP_COUL_EWALD_DIRECT || COULM == COUL_EWALD_EXACT)) ? (MINIMG ? 1 : (LJM == LJ_GENERIC && ENERGY ? 2 : 4)) : 4;
             for (int r = 0; r < rows; ++r) {
                 const uint2 e4 = e_next;
+                if constexpr (EXPV == 10) {   // timing experiment: no row stream (slots made up from the row number)
+                    const uint32_t m = (uint32_t)max(tile_n - 1, 1), q = ((uint32_t)r * 0x9E3779B1u + (uint32_t)li * 4u);
+                    e_next = make_uint2(((q % m) | (((q + 1) % m) << 16)), (((q + 2) % m) | (((q + 3) % m) << 16)));
+                } else
                 if (r + 1 < rows) e_next = my_rows[(int64_t)(r + 1) * A.BI];
                 if constexpr (PK2) {
                     if (pk2_ok && (!SPEC || __builtin_amdgcn_ballot_w64(((e4.x | e4.y) & 0x80008000u) != 0u) == 0ull)) { row_pk2(e4); continue; }
@@ -1519,6 +1535,7 @@ k_forces(ForceArgs<T> A) {
         d2 = wave_max(d2);
         if (js == 0 && (tid & 63) == 0) A.blk_disp2[b * (A.BI >> 6) + (li >> 6)] = d2;   // one word per wave of i-atoms: plain stores, nothing to zero beforehand
     }
+    stamp(2);
     if (A.JS > 1) {   // deterministic reduction of the j-split partial sums through LDS
         __syncthreads();
         T* red = reinterpret_cast<T*>(smem);     // (indexed by ATOM: the groups' lane orders may differ)
@@ -1533,6 +1550,7 @@ k_forces(ForceArgs<T> A) {
         }
     }
     if (js == 0 && valid) A.frc[si] = make4<T>(fx, fy, fz, T(0));
+    stamp(3);
     if constexpr (ENERGY) {
         if (A.JS > 1) {   // j-split partial sums of the virial, two rounds through the same four LDS slots
             T* red = reinterpret_cast<T*>(smem);

@@ -24,9 +24,10 @@ __global__ void __launch_bounds__(256) k_spread_bonded(int64_t n_atoms, const ty
 template <class T, int ORDER, bool STORE = false>
 __global__ void __launch_bounds__(256) k_gather_collect(int64_t n_atoms, const typename Vec<T>::T4* __restrict__ pos, const T* __restrict__ phi, typename Vec<T>::T4* frc, PmeP<T> P,
                                                         int n_gather, const int32_t* __restrict__ orig, const int32_t* __restrict__ role_start, const int32_t* __restrict__ role_slot,
-                                                        const typename Vec<T>::T4* __restrict__ slots, typename Vec<T>::T4* side) {
+                                                        const typename Vec<T>::T4* __restrict__ slots, typename Vec<T>::T4* side,
+                                                        const typename Vec<T>::T4* __restrict__ parts, int n_parts, int64_t part_stride) {
     if ((int)blockIdx.x < n_gather) { pme_gather_blocks<T, ORDER, STORE>((int)blockIdx.x, n_gather, n_atoms, pos, phi, frc, P); return; }
-    bonded_collect_lane<T, true>(((int64_t)blockIdx.x - n_gather) * blockDim.x + threadIdx.x, n_atoms, orig, role_start, role_slot, slots, side);
+    bonded_collect_lane<T, true>(((int64_t)blockIdx.x - n_gather) * blockDim.x + threadIdx.x, n_atoms, orig, role_start, role_slot, slots, side, parts, n_parts, part_stride);
 }
 
 // reciprocal-space PME forces added to frc (store: written to frc, every owned atom), bonded forces left in `side` (every owned atom written)
@@ -55,11 +56,12 @@ inline void launch_pme_bonded_fused(hipStream_t s, Pme<T>& pme, Bonded<T>& bonde
     auto gather = [&](auto order_tag) {
         constexpr int ORDER = decltype(order_tag)::value;
         if (store) hipLaunchKernelGGL((k_gather_collect<T, ORDER, true>), dim3(n_gather + n_collect), dim3(256), 0, s, n_owned, pos, (const T*)pme.phi.p, frc, pme.P, n_gather, orig,
-                           (const int32_t*)bonded.role_start.p, (const int32_t*)bonded.role_slot.p, (const typename Vec<T>::T4*)bonded.slots, side);
+                           (const int32_t*)bonded.role_start.p, (const int32_t*)bonded.role_slot.p, (const typename Vec<T>::T4*)bonded.slots, side, bonded.fold_parts, bonded.fold_n, bonded.fold_stride);
         else hipLaunchKernelGGL((k_gather_collect<T, ORDER>), dim3(n_gather + n_collect), dim3(256), 0, s, n_owned, pos, (const T*)pme.phi.p, frc, pme.P, n_gather, orig,
-                           (const int32_t*)bonded.role_start.p, (const int32_t*)bonded.role_slot.p, (const typename Vec<T>::T4*)bonded.slots, side);
+                           (const int32_t*)bonded.role_start.p, (const int32_t*)bonded.role_slot.p, (const typename Vec<T>::T4*)bonded.slots, side, bonded.fold_parts, bonded.fold_n, bonded.fold_stride);
     };
     if (pme.order == 4) gather(std::integral_constant<int, 4>{}); else if (pme.order == 5) gather(std::integral_constant<int, 5>{}); else gather(std::integral_constant<int, 6>{});
+    bonded.fold_parts = nullptr; bonded.fold_n = 0;      // (consumed)
     MHIP_HIP(hipGetLastError());
 }
 
