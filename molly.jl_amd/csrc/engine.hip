@@ -181,6 +181,7 @@ template <class T> class Engine final : public EngineBase {
     // the group-split pair pass of small systems (forces_gs.hip): the inner list re-dealt into GS groups per block after every prune, the
     // partial forces of groups 1 .. GS − 1 (group 0 writes the force array), and which prune the list belongs to
     DBuf<uint2> nbr_gs; DBuf<int32_t> rows_gs; DBuf<T4> frc_parts; int64_t gs_list_id = -1; bool gs_used = false;
+    bool fuse_spread_next = false, spread_fused = false; const bool gs_fuse_spread = env_int("MOLLYHIP_GS_FUSE_SPREAD", 1) != 0;
     const int gs_env = env_int("MOLLYHIP_GROUP_SPLIT", -1);      // 0: off; 2 / 4: groups per block; −1: automatic
     int gs_groups() const {
         if (!std::is_same<T, float>::value || ljm != LJ_DIST || !(coulm == MHIP_COUL_REACTION_FIELD || (coulm == MHIP_COUL_EWALD_DIRECT && I.approx_erfc))) return 0;
@@ -952,7 +953,16 @@ template <class T> class Engine final : public EngineBase {
                     last_pass_tile = max_tile_in;
                     prof.begin(0, stream);
                     tr("k_forces_gs");
-                    launch_forces_gs(Z, coulm, minimg, stream);
+                    spread_fused = false;
+                    if (fuse_spread_next && gs_fuse_spread) {      // … with the charge spreading and the bonded terms of the step as further workgroups of the same launch
+                        bonded.ensure_roles(stream, cap);
+                        const size_t lds = std::max(gs_lds_bytes(q_lds, BI, JS / GS), std::min<size_t>((size_t)MAX_LDS_BYTES / GS, spread_head_bytes_f32(pme.order) + (size_t)PME_BOX_BYTES)) & ~(size_t)15;
+                        const int n_spread = (int)std::min<int64_t>(cdiv(n_owned, (int64_t)64), 4096);
+                        launch_pair_spread_bonded(Z, n_blocks * GS, coulm, minimg, pme.order, n_owned, reinterpret_cast<float*>(pme.rgrid.p), reinterpret_cast<const PmeP<float>&>(pme.P), n_spread,
+                                                  reinterpret_cast<const BondedArgs<float>&>(static_cast<const BondedArgs<T>&>(bonded.slot_args(G, I, pos[cur].p, inv.p))), cdiv(bonded.n_blocks(), 4), lds, stream);
+                        spread_fused = true;
+                    } else launch_forces_gs(Z, coulm, minimg, stream);
+                    fuse_spread_next = false;
                     prof.end(0, stream);
                     MHIP_HIP(hipGetLastError());
                     ++n_force_calls; gs_used = true;
@@ -1028,7 +1038,8 @@ template <class T> class Engine final : public EngineBase {
         if constexpr (std::is_same<T, float>::value) {
             if (prune && GS > 0 && !lanes_sorted && !rebalance) {      // the list this prune wrote, dealt to the groups (it stays as it is for every other kind of pass)
                 nbr_gs.reserve((size_t)n_blocks * JS * R_cap * BI); rows_gs.reserve((size_t)n_blocks * JS * (BI / WAVE));
-                RegroupArgs R{BI, ilog2(BI), JS, GS, ilog2(GS), R_cap, (const uint2*)nbr_in.p, (const uint16_t*)cnt_in.p, (const int32_t*)tile_cnt_in.p, nbr_gs.p, rows_gs.p};
+                RegroupArgs R{BI, ilog2(BI), JS, GS, ilog2(GS), R_cap, (const uint2*)nbr_in.p, (const uint16_t*)cnt_in.p, (const int32_t*)tile_cnt_in.p, nbr_gs.p, rows_gs.p,
+                              (int)std::min<size_t>((size_t)MAX_LDS_BYTES - (size_t)JS * BI * 8 - 64, (size_t)JS * R_cap * BI * 8)};
                 tr("k_regroup");
                 launch_regroup(R, n_blocks, stream);
                 gs_list_id = n_filters + 1;      // (n_filters counts this prune below)
@@ -1191,7 +1202,12 @@ template <class T> class Engine final : public EngineBase {
         }
         // (group-split passes leave partial forces that the per-atom sums of the bonded slots fold in: only where such a launch follows)
         const bool gs_ok = bonded.any() && !overlap && !chain_beside && !Bonded<T>::use_atomics() && n_ghost == 0;
+        const bool small_fused = !overlap && !chain_beside && fuse_small && bonded.any() && pme.on() && !Bonded<T>::use_atomics() && n_ghost == 0;
+        // (with the stage timers on, every job keeps its own launch: a stage's time is then that job's — bench.py's profiling pass, never its timed region)
+        fuse_spread_next = gs_ok && small_fused && pme.order >= 4 && pme.order <= 6 && !(prof.on && env_int("MOLLYHIP_PROF_FUSED", 0) == 0);
+        spread_fused = false;
         launch_pair_kernel(false, interior_done ? 2 : 0, gs_ok);   // (the blocks without ghosts may have run already, while the ghosts were on the wire)
+        fuse_spread_next = false;
         interior_done = false;
         bool redo = false;
         if (prune_disp_exceeded) {   // the outer list could not vouch for this pass: search again and redo it on the fresh list
@@ -1213,7 +1229,7 @@ template <class T> class Engine final : public EngineBase {
         if (!overlap && fuse_small && bonded.any() && pme.on() && !Bonded<T>::use_atomics() && n_ghost == 0) {
             frc_side[0].reserve(cap);
             prof.begin(6, stream);
-            launch_pme_bonded_fused<T>(stream, pme, bonded, G, I, n_owned, cap, pos[cur].p, inv.p, orig[cur].p, frc[cur].p, frc_side[0].p);
+            launch_pme_bonded_fused<T>(stream, pme, bonded, G, I, n_owned, cap, pos[cur].p, inv.p, orig[cur].p, frc[cur].p, frc_side[0].p, false, spread_fused);
             prof.end(6, stream);
             pend_a = frc_side[0].p;
             frc_valid = true;

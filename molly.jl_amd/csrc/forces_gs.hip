@@ -19,6 +19,7 @@
 // Same arithmetic per pair as k_forces (pair_eval2 / pair_eval of physics.h); same lists (the inner list of the dual scheme, re-dealt).
 #include "kernels.h"
 #include "forces_launch.h"
+#include "step_fused.h"
 
 namespace mhip {
 
@@ -64,8 +65,21 @@ __global__ void __launch_bounds__(1024) k_regroup(RegroupArgs A) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) rows_w = max(rows_w, __shfl_xor(rows_w, o, WAVE));
     if ((tid & (WAVE - 1)) == 0) A.rows_dst[(sub0 + js) * (A.BI >> 6) + (li >> 6)] = rows_w;
-    uint16_t* dst16 = reinterpret_cast<uint16_t*>(A.dst);
-    auto at = [&](int sub, int p) -> int64_t { return ((((sub0 + sub) * A.R_cap + (p >> 2)) * A.BI + li) << 2) + (p & 3); };
+    // The scatter goes through LDS when the block's new list fits behind the counters (rows of the longest wave × sub-lists × 512 bytes:
+    // ≈ 100 KB for a 6mrr block) and leaves as whole 8-byte rows, a wave's 512 bytes at a time; 2-byte stores scattered straight into
+    // global memory cost 45 µs per prune where the prune itself takes 61.
+    int* l_rmax = reinterpret_cast<int*>(l_c + (size_t)A.JS * A.BI);
+    if (tid == 0) *l_rmax = 0;
+    __syncthreads();
+    if ((tid & (WAVE - 1)) == 0) atomicMax(l_rmax, rows_w);
+    __syncthreads();
+    const int R_l = *l_rmax;
+    uint16_t* l_dst = reinterpret_cast<uint16_t*>(l_rmax + 4);
+    const bool via_lds = (size_t)A.JS * R_l * A.BI * 8 <= (size_t)A.lds_list_bytes;
+    uint16_t* dst16 = via_lds ? l_dst : reinterpret_cast<uint16_t*>(A.dst);
+    auto at = [&](int sub, int p) -> int64_t {
+        return via_lds ? (int64_t)(((((sub * R_l) + (p >> 2)) * A.BI + li) << 2) + (p & 3)) : ((((sub0 + sub) * A.R_cap + (p >> 2)) * A.BI + li) << 2) + (p & 3);
+    };
     // scatter my entries
     for (int r0 = 0; r0 < nrow; r0 += NB) {
         uint2 rw[NB];
@@ -88,14 +102,18 @@ __global__ void __launch_bounds__(1024) k_regroup(RegroupArgs A) {
     // pad my destination sub-list (positions nobody else writes)
     const uint16_t SENT = (uint16_t)((A.tile_cnt[b] + GS - 1) >> A.lgGS);
     for (int p = n_mine; p < 4 * rows_w; ++p) dst16[at(js, p)] = SENT;
+    if (via_lds) {
+        __syncthreads();
+        const uint2* l_rows = reinterpret_cast<const uint2*>(l_dst);
+        uint2* out = A.dst + ((sub0 + js) * A.R_cap) * A.BI + li;
+        for (int r = 0; r < rows_w; ++r) out[(int64_t)r * A.BI] = l_rows[(js * R_l + r) * A.BI + li];
+    }
 }
 
 // ---- k_forces_gs: one group of one block ----------------------------------------------------------------------------------------------------
 template <int COULM, bool MINIMG>
-__global__ void __launch_bounds__(256, 4) k_forces_gs(GsArgs A) {     // (four workgroups per compute unit: at most 128 registers)
-    extern __shared__ __align__(32) unsigned char smem[];
+__device__ inline void forces_gs_body(const GsArgs& A, int wg, unsigned char* smem) {
     const GridP<float>& G = A.G;
-    const int wg = blockIdx.x;
     const int g = wg / A.n_blocks, bq = wg - g * A.n_blocks;
     int b = bq + g * A.spread; b -= b >= A.n_blocks ? A.n_blocks : 0;
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -187,10 +205,34 @@ __global__ void __launch_bounds__(256, 4) k_forces_gs(GsArgs A) {     // (four w
     }
 }
 
+template <int COULM, bool MINIMG>
+__global__ void __launch_bounds__(256, 4) k_forces_gs(GsArgs A) {     // (four workgroups per compute unit: at most 128 registers)
+    extern __shared__ __align__(32) unsigned char smem[];
+    forces_gs_body<COULM, MINIMG>(A, (int)blockIdx.x, smem);
+}
+
+// The pair pass, the charge spreading and the bonded terms of one MD step in ONE launch (cf. step_fused.h, which pairs the last two): none of
+// the three depends on another, all are 256-lane workgroups, and the pair workgroups — first in the grid, the longest — leave the
+// arithmetic units idle half of the time (latency of the row walk) while the spreading is bound by LDS atomics and latency.  The hardware
+// hands a compute unit's free slot to the next workgroup of the grid, so the short jobs fill in behind the pair groups as they finish.
+// Every role carves its LDS from the launch's dynamic pool (the spreading: its tables and whatever is left as the sub-mesh).
+template <int COULM, bool MINIMG, int ORDER>
+__global__ void __launch_bounds__(256, 4) k_pair_spread_bonded(GsArgs A, int n_pair, int64_t n_atoms, float* rgrid, PmeP<float> P, int n_spread, int lds_bytes, BondedArgs<float> B) {
+    extern __shared__ __align__(32) unsigned char smem[];
+    const int wg = (int)blockIdx.x;
+    if (wg < n_pair) { forces_gs_body<COULM, MINIMG>(A, wg, smem); return; }
+    if (wg < n_pair + n_spread) { pme_spread_blocks<float, ORDER, 64, true>(wg - n_pair, n_spread, n_atoms, A.pos, rgrid, P, smem, lds_bytes); return; }
+    double e = 0;
+    bonded_terms<float, false, true>(B, (wg - n_pair - n_spread) * 4 + (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), 64, e);   // four 64-lane term blocks per workgroup
+}
+
 size_t gs_lds_bytes(int q_lds, int BI, int JSW) { return std::max((size_t)(q_lds + 1) * (sizeof(float4) + sizeof(float2)), (size_t)JSW * 3 * BI * sizeof(float)) + 64; }
 
 void launch_regroup(const RegroupArgs& A, int n_blocks, hipStream_t stream) {
-    hipLaunchKernelGGL(k_regroup, dim3(n_blocks), dim3(A.BI * A.JS), (size_t)A.JS * A.BI * sizeof(unsigned long long), stream, A);
+    const size_t lds = (size_t)A.JS * A.BI * sizeof(unsigned long long) + 16 + (size_t)A.lds_list_bytes;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) { MHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_regroup), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+    hipLaunchKernelGGL(k_regroup, dim3(n_blocks), dim3(A.BI * A.JS), lds, stream, A);
 }
 
 void launch_forces_gs(const GsArgs& A, int coulm, bool minimg, hipStream_t stream) {
@@ -203,5 +245,23 @@ void launch_forces_gs(const GsArgs& A, int coulm, bool minimg, hipStream_t strea
     if (coulm == MHIP_COUL_REACTION_FIELD) { if (minimg) go(k_forces_gs<MHIP_COUL_REACTION_FIELD, true>); else go(k_forces_gs<MHIP_COUL_REACTION_FIELD, false>); }
     else { if (minimg) go(k_forces_gs<MHIP_COUL_EWALD_DIRECT, true>); else go(k_forces_gs<MHIP_COUL_EWALD_DIRECT, false>); }
 }
+
+// the fused form: pair groups + spreading + bonded terms; lds_bytes >= the pair groups' need and the spreading's head + a useful sub-mesh
+void launch_pair_spread_bonded(const GsArgs& A, int n_pair, int coulm, bool minimg, int order, int64_t n_atoms, float* rgrid, const PmeP<float>& P, int n_spread, const BondedArgs<float>& B, int n_term_wg,
+                               size_t lds_bytes, hipStream_t stream) {
+    const dim3 grid((unsigned)(n_pair + n_spread + n_term_wg)), block(256);
+    auto go = [&](auto kern) {
+        if (lds_bytes > 64 * 1024) MHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, A, n_pair, n_atoms, rgrid, P, n_spread, (int)lds_bytes, B);
+    };
+    auto by_order = [&](auto coul_tag, auto mi_tag) {
+        constexpr int C = decltype(coul_tag)::value; constexpr bool M = decltype(mi_tag)::value;
+        if (order == 4) go(k_pair_spread_bonded<C, M, 4>); else if (order == 5) go(k_pair_spread_bonded<C, M, 5>); else go(k_pair_spread_bonded<C, M, 6>);
+    };
+    using RF = std::integral_constant<int, MHIP_COUL_REACTION_FIELD>; using EW = std::integral_constant<int, MHIP_COUL_EWALD_DIRECT>;
+    if (coulm == MHIP_COUL_REACTION_FIELD) { if (minimg) by_order(RF{}, std::true_type{}); else by_order(RF{}, std::false_type{}); }
+    else { if (minimg) by_order(EW{}, std::true_type{}); else by_order(EW{}, std::false_type{}); }
+}
+size_t spread_head_bytes_f32(int order) { return order == 4 ? pme_spread_head_bytes<float, 4, 64>() : order == 5 ? pme_spread_head_bytes<float, 5, 64>() : pme_spread_head_bytes<float, 6, 64>(); }
 
 }  // namespace mhip

@@ -16,6 +16,7 @@ struct RegroupArgs {
     int BI, BI_shift, JS, GS, lgGS, R_cap;
     const uint2* src; const uint16_t* cnt; const int32_t* tile_cnt;      // the inner list as the prune wrote it, entries per (sub-list, lane), compacted tile sizes
     uint2* dst; int32_t* rows_dst;                                        // the group-split list
+    int lds_list_bytes;                                                    // LDS the launch sets aside for staging a block's new list (the scatter goes to global memory if it does not fit)
 };
 struct GsArgs {
     GridP<float> G; InterP<float> I;
@@ -26,5 +27,9 @@ struct GsArgs {
 size_t gs_lds_bytes(int q_lds, int BI, int JSW);
 void launch_regroup(const RegroupArgs& A, int n_blocks, hipStream_t stream);
 void launch_forces_gs(const GsArgs& A, int coulm, bool minimg, hipStream_t stream);
+template <class T> struct PmeP; template <class T> struct BondedArgs;
+void launch_pair_spread_bonded(const GsArgs& A, int n_pair, int coulm, bool minimg, int order, int64_t n_atoms, float* rgrid, const PmeP<float>& P, int n_spread, const BondedArgs<float>& B, int n_term_wg,
+                               size_t lds_bytes, hipStream_t stream);
+size_t spread_head_bytes_f32(int order);
 
 }  // namespace mhip

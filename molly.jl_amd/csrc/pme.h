@@ -116,11 +116,23 @@ template <> struct PmeFix<double> {
 #define MHIP_SPREAD_EXP 0                  // timing experiments: 1 = stop behind the B-splines, 2 = behind the zeroed sub-mesh, 3 = behind the LDS adds (no flush)
 #endif
 
-template <class T, int ORDER, int PME_SB>
-__device__ inline void pme_spread_blocks(int bid, int nblk, int64_t n_atoms, const typename Vec<T>::T4* __restrict__ pos, T* rgrid, const PmeP<T>& P) {
-    __shared__ T l_w[3 * ORDER * PME_SB]; __shared__ int l_i[3 * PME_SB]; __shared__ T l_q[PME_SB];
-    constexpr int PME_BOX = PME_BOX_BYTES / 8;
-    __shared__ unsigned long long l_box[PME_BOX]; __shared__ int l_lo[3], l_hi[3];
+// bytes of LDS a spreading workgroup needs in front of its sub-mesh (DYN: carved from the launch's dynamic LDS)
+template <class T, int ORDER, int PME_SB> constexpr int pme_spread_head_bytes() { return ((3 * ORDER * PME_SB + PME_SB) * (int)sizeof(T) + (3 * PME_SB + 8) * (int)sizeof(int) + 15) & ~15; }
+// DYN: the tables and the sub-mesh live in `dyn_lds` (dyn_bytes of it), not in static arrays — for a launch that shares its workgroups with
+// jobs that have an LDS carve-up of their own (forces_gs.hip: the pair pass of a small system beside the spreading)
+template <class T, int ORDER, int PME_SB, bool DYN = false>
+__device__ inline void pme_spread_blocks(int bid, int nblk, int64_t n_atoms, const typename Vec<T>::T4* __restrict__ pos, T* rgrid, const PmeP<T>& P,
+                                         unsigned char* dyn_lds = nullptr, int dyn_bytes = 0) {
+    T* l_w; int* l_i; T* l_q; unsigned long long* l_box; int* l_lo; int* l_hi; int PME_BOX;
+    if constexpr (DYN) {
+        l_box = reinterpret_cast<unsigned long long*>(dyn_lds + pme_spread_head_bytes<T, ORDER, PME_SB>());
+        PME_BOX = (dyn_bytes - pme_spread_head_bytes<T, ORDER, PME_SB>()) / 8;
+        l_w = reinterpret_cast<T*>(dyn_lds); l_q = l_w + 3 * ORDER * PME_SB; l_i = reinterpret_cast<int*>(l_q + PME_SB); l_lo = l_i + 3 * PME_SB; l_hi = l_lo + 4;
+    } else {
+        __shared__ T s_w[3 * ORDER * PME_SB]; __shared__ int s_i[3 * PME_SB]; __shared__ T s_q[PME_SB];
+        __shared__ unsigned long long s_box[PME_BOX_BYTES / 8]; __shared__ int s_lo[3], s_hi[3];
+        l_w = s_w; l_i = s_i; l_q = s_q; l_box = s_box; l_lo = s_lo; l_hi = s_hi; PME_BOX = PME_BOX_BYTES / 8;
+    }
     const int tid = threadIdx.x, sub = tid & 31, hw = tid >> 5;
     T* mesh = rgrid;
     for (int64_t a0 = (int64_t)bid * PME_SB; a0 < n_atoms; a0 += (int64_t)nblk * PME_SB) {
@@ -316,14 +328,15 @@ template <class T> struct DftArgs {
     int axis, sign, C, nzh;               // sign −1: forward (plan_fft!), +1: backward (plan_bfft!), both unnormalised
 };
 
+// (the three transform kernels as device bodies: bid = workgroup of the pass, pme_smem = its dynamic LDS — forces_gs.hip runs them beside
+// slices of the pair pass in one launch)
 template <class T>
-__global__ void __launch_bounds__(PME_THREADS) k_pme_z_r2c(DftArgs<T> A) {
+__device__ inline void pme_z_r2c_body(const DftArgs<T>& A, int bid, unsigned char* pme_smem) {
     using T2 = typename Vec<T>::T2;
-    extern __shared__ __align__(16) unsigned char pme_smem[];
     const int nz = A.P.n[2], nzh = A.nzh, C = A.C, tid = threadIdx.x;
     T2* l_tw = reinterpret_cast<T2*>(pme_smem);
     T* l_a = reinterpret_cast<T*>(l_tw + nz);                          // [j][c] real
-    const int64_t n_mesh = (int64_t)A.P.n[0] * A.P.n[1] * nz, n_lines = n_mesh / nz, q0 = (int64_t)blockIdx.x * C;
+    const int64_t n_mesh = (int64_t)A.P.n[0] * A.P.n[1] * nz, n_lines = n_mesh / nz, q0 = (int64_t)bid * C;
     const int n_here = (int)min((int64_t)C, n_lines - q0);
     for (int m = tid; m < nz; m += PME_THREADS) l_tw[m] = A.tw[m];
     for (int e = tid; e < nz * C; e += PME_THREADS) {
@@ -353,13 +366,18 @@ __global__ void __launch_bounds__(PME_THREADS) k_pme_z_r2c(DftArgs<T> A) {
 }
 
 template <class T>
-__global__ void __launch_bounds__(PME_THREADS) k_pme_z_c2r(DftArgs<T> A) {
-    using T2 = typename Vec<T>::T2;
+__global__ void __launch_bounds__(PME_THREADS) k_pme_z_r2c(DftArgs<T> A) {
     extern __shared__ __align__(16) unsigned char pme_smem[];
+    pme_z_r2c_body<T>(A, (int)blockIdx.x, pme_smem);
+}
+
+template <class T>
+__device__ inline void pme_z_c2r_body(const DftArgs<T>& A, int bid, unsigned char* pme_smem) {
+    using T2 = typename Vec<T>::T2;
     const int nz = A.P.n[2], nzh = A.nzh, C = A.C, tid = threadIdx.x;
     T2* l_tw = reinterpret_cast<T2*>(pme_smem);
     T2* l_a = l_tw + nz;                                               // [k][c] complex, k < nzh
-    const int64_t n_lines = (int64_t)A.P.n[0] * A.P.n[1], q0 = (int64_t)blockIdx.x * C;
+    const int64_t n_lines = (int64_t)A.P.n[0] * A.P.n[1], q0 = (int64_t)bid * C;
     const int n_here = (int)min((int64_t)C, n_lines - q0);
     for (int m = tid; m < nz; m += PME_THREADS) { T2 w = A.tw[m]; w.y = -w.y; l_tw[m] = w; }      // e^{+2πi m/n}
     for (int e = tid; e < nzh * C; e += PME_THREADS) {
@@ -389,16 +407,21 @@ __global__ void __launch_bounds__(PME_THREADS) k_pme_z_c2r(DftArgs<T> A) {
     }
 }
 
-template <class T, bool CONV, bool ENERGY>
-__global__ void __launch_bounds__(PME_THREADS) k_pme_dft(DftArgs<T> A) {
-    using T2 = typename Vec<T>::T2;
+template <class T>
+__global__ void __launch_bounds__(PME_THREADS) k_pme_z_c2r(DftArgs<T> A) {
     extern __shared__ __align__(16) unsigned char pme_smem[];
+    pme_z_c2r_body<T>(A, (int)blockIdx.x, pme_smem);
+}
+
+template <class T, bool CONV, bool ENERGY>
+__device__ inline void pme_dft_body(const DftArgs<T>& A, int bid, int n_blocks_pass, unsigned char* pme_smem) {
+    using T2 = typename Vec<T>::T2;
     const int n = A.P.n[A.axis], nx = A.P.n[0], ny = A.P.n[1], nz = A.P.n[2], nzh = A.nzh, C = A.C;
     T2* l_tw = reinterpret_cast<T2*>(pme_smem);
     T2* l_a = l_tw + n;
     [[maybe_unused]] T2* l_b = l_a + n * C;
     const int tid = threadIdx.x;
-    const int64_t n_lines = (int64_t)nx * ny * nzh / n, q0 = (int64_t)blockIdx.x * C;
+    const int64_t n_lines = (int64_t)nx * ny * nzh / n, q0 = (int64_t)bid * C;
     const int n_here = (int)min((int64_t)C, n_lines - q0);
     const int64_t stride = A.axis == 1 ? nzh : (int64_t)ny * nzh;
     auto line_base = [&](int64_t q) -> int64_t {
@@ -488,11 +511,17 @@ __global__ void __launch_bounds__(PME_THREADS) k_pme_dft(DftArgs<T> A) {
                 for (int o = 32; o > 0; o >>= 1) val += __shfl_xor(val, o, 64);
                 if ((tid & 63) == 0) sh_e[tid >> 6] = val;
                 __syncthreads();
-                if (tid == 0) { double s = 0; for (int w = 0; w < PME_THREADS / 64; ++w) s += sh_e[w]; A.e_part[(int64_t)c * gridDim.x + blockIdx.x] = s; }
+                if (tid == 0) { double s = 0; for (int w = 0; w < PME_THREADS / 64; ++w) s += sh_e[w]; A.e_part[(int64_t)c * n_blocks_pass + bid] = s; }
                 __syncthreads();
             }
         }
     }
+}
+
+template <class T, bool CONV, bool ENERGY>
+__global__ void __launch_bounds__(PME_THREADS) k_pme_dft(DftArgs<T> A) {
+    extern __shared__ __align__(16) unsigned char pme_smem[];
+    pme_dft_body<T, CONV, ENERGY>(A, (int)blockIdx.x, (int)gridDim.x, pme_smem);
 }
 
 template <class U> struct PBuf {
@@ -617,6 +646,11 @@ template <class T> struct Pme {
         const int64_t n_lines = (int64_t)P.n[0] * P.n[1] * nzh / P.n[axis];
         hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(n_lines, (int64_t)C)), dim3(PME_THREADS), lds, s, dft_args(axis, sign, C, e_part));
     }
+    // geometry of the passes, for launches that run them beside other jobs (forces_gs.hip)
+    size_t lds_r2c() const { return (size_t)P.n[2] * sizeof(T2) + (size_t)P.n[2] * c_r2c() * sizeof(T); }
+    int blocks_r2c() const { return cdiv((int64_t)P.n[0] * P.n[1], (int64_t)c_r2c()); }
+    size_t lds_xy(int axis, bool conv) const { return (size_t)P.n[axis] * sizeof(T2) * (1 + c_xy(axis) * (conv ? 2 : 1)); }
+    int blocks_xy(int axis) const { return cdiv((int64_t)P.n[0] * P.n[1] * nzh / P.n[axis], (int64_t)c_xy(axis)); }
     void z_r2c(hipStream_t s) {
         const int C = c_r2c();
         const size_t lds = (size_t)P.n[2] * sizeof(T2) + (size_t)P.n[2] * C * sizeof(T);

@@ -33,7 +33,8 @@ __global__ void __launch_bounds__(256) k_gather_collect(int64_t n_atoms, const t
 // reciprocal-space PME forces added to frc (store: written to frc, every owned atom), bonded forces left in `side` (every owned atom written)
 template <class T>
 inline void launch_pme_bonded_fused(hipStream_t s, Pme<T>& pme, Bonded<T>& bonded, const GridP<T>& G, const InterP<T>& I, int64_t n_owned, int64_t cap,
-                                    const typename Vec<T>::T4* pos, const int32_t* inv, const int32_t* orig, typename Vec<T>::T4* frc, typename Vec<T>::T4* side, bool store = false) {
+                                    const typename Vec<T>::T4* pos, const int32_t* inv, const int32_t* orig, typename Vec<T>::T4* frc, typename Vec<T>::T4* side, bool store = false,
+                                    bool spread_done = false) {      // spread_done: the charges are on the mesh and the terms in their slots already (forces_gs.hip's fused launch)
     bonded.ensure_roles(s, cap);
     const BondedArgs<T> B = bonded.slot_args(G, I, pos, inv);
     const int n_term_wg = cdiv(bonded.n_blocks(), 4);
@@ -45,7 +46,7 @@ inline void launch_pme_bonded_fused(hipStream_t s, Pme<T>& pme, Bonded<T>& bonde
         else if (sb <= 32) hipLaunchKernelGGL((k_spread_bonded<T, ORDER, 32>), dim3(n_spread + n_term_wg), dim3(256), 0, s, n_owned, pos, pme.rgrid.p, pme.P, n_spread, B);
         else hipLaunchKernelGGL((k_spread_bonded<T, ORDER, 64>), dim3(n_spread + n_term_wg), dim3(256), 0, s, n_owned, pos, pme.rgrid.p, pme.P, n_spread, B);
     };
-    if (pme.order == 4) spread(std::integral_constant<int, 4>{}); else if (pme.order == 5) spread(std::integral_constant<int, 5>{}); else spread(std::integral_constant<int, 6>{});
+    if (!spread_done) { if (pme.order == 4) spread(std::integral_constant<int, 4>{}); else if (pme.order == 5) spread(std::integral_constant<int, 5>{}); else spread(std::integral_constant<int, 6>{}); }
     pme.z_r2c(s);
     pme.template dft_xy<false, false>(s, 1, -1, nullptr);
     pme.template dft_xy<true, false>(s, 0, -1, nullptr);
