@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — ns/day (and Matom-steps/s) of the MI355X nonbonded engine on BASELINE.json's workloads.
 
-    python bench.py --gpus N --steps K --warmup W [--workload lj1m|lj256k|6mrr_pme|6mrr_direct|6mrr_rf64]
+    python bench.py --gpus N --steps K --warmup W [--workload lj1m|lj256k|6mrr_pme|6mrr_direct|6mrr_rf64|6mrr_rf32|argon4096]
 
 One "step" = one velocity-Verlet MD step (forces + integration + amortised neighbour-list upkeep) of the whole
 system, state resident in HBM.  N = 1: the whole box on one GPU.  N > 1 (launched by torch.distributed.run,
@@ -30,7 +30,11 @@ WORKLOADS = {
     "6mrr_pme": "6mrr (15954 atoms) Amber99SB-ILDN/TIP3P, LJ + Ewald direct space + PME reciprocal space (order 5, mesh 46x46x51, every step) + bonded + EwaldExclusion, Float32, dt 0.5 fs",
     "6mrr_direct": "6mrr (15954 atoms) Amber99SB-ILDN/TIP3P, LJ + Ewald direct space only (no reciprocal PME) + bonded + EwaldExclusion, Float32, dt 0.5 fs",
     "6mrr_rf64": "6mrr reaction-field Coulomb + LJ + bonded, Float64, dt 0.5 fs",
+    "6mrr_rf32": "6mrr reaction-field Coulomb + LJ + bonded, Float32, dt 0.5 fs, remove_CM_motion=false: the reference's benchmark/protein.jl:14-62 (nonbonded_method=:cutoff, 'CUDA f32')",
+    "argon4096": "4096 argon atoms at uniformly random positions, 1400 kg/m3 (box 5.79 nm), LennardJones DistanceCutoff 1.2 nm, Float32: forces! and potential_energy call medians "
+                 "with an advancing step counter — the reference's benchmark/benchmark_gpu_tiles.jl:13-165 'dense_f32' (and 'sparse_f32': the box four times as wide)",
 }
+FORCE_CALL_WORKLOADS = ("argon4096",)
 
 
 def make_case(workload):
@@ -41,9 +45,9 @@ def make_case(workload):
         return W.lj_fluid(100, seed=4, dtype=np.float32), np.float32, 0.002
     if workload == "lj256k":
         return W.lj_fluid(64, seed=2, dtype=np.float32), np.float32, 0.002
-    if workload in ("6mrr_pme", "6mrr_direct", "6mrr_rf64"):
+    if workload in ("6mrr_pme", "6mrr_direct", "6mrr_rf64", "6mrr_rf32"):
         dtype = np.float64 if workload == "6mrr_rf64" else np.float32
-        return W.protein_6mrr("rf" if workload == "6mrr_rf64" else "ewald", dtype=dtype, bonded=True, pme=(workload == "6mrr_pme")), dtype, 0.0005
+        return W.protein_6mrr("rf" if workload.startswith("6mrr_rf") else "ewald", dtype=dtype, bonded=True, pme=(workload == "6mrr_pme")), dtype, 0.0005
     raise SystemExit(f"unknown workload {workload}")
 
 
@@ -117,7 +121,7 @@ def run_single(m, workload, args, steps, warmup, profile_steps):
         kT = m.BOLTZMANN * (85.0 if workload.startswith("lj") else 300.0)
         run = lambda first, n: s._check(L.mhip_langevin_run(ctx, first, n, dt, kT, 1.0, 1, 0x9E3779B97F4A7C15, first))
     else:
-        run = lambda first, n: s._check(L.mhip_vv_run(ctx, first, n, dt, 1))
+        run = lambda first, n: s._check(L.mhip_vv_run(ctx, first, n, dt, 0 if workload == "6mrr_rf32" else 1))   # (benchmark/protein.jl: remove_CM_motion=false)
     # untimed setup: the LJ fluids start from a jittered lattice and are equilibrated first (SURVEY §8(d) cfg 2 / 4: "equilibrate
     # 2 000 steps before timing"), so that the timed steps see the list lifetimes of the liquid, not of a melting lattice
     equil = args.equil if args.equil is not None else (2000 if workload.startswith("lj") else 0)
@@ -152,6 +156,67 @@ def run_single(m, workload, args, steps, warmup, profile_steps):
              "window_ms_per_step": {"n": n_win, "mean": ms_per_step, "min": float(min(win_ms)), "max": float(max(win_ms))},
              "list_upkeep_in_profile_pass": {"outer_searches": st["prof_calls"][1], "prunes": st["prof_calls"][4], "steps": profile_steps}}   # launches counted by the stage timers
     return ms_per_step, st, extra, case, dtype, dt
+
+
+def run_force_calls(m, workload, args):
+    """The reference's own GPU benchmark shape (benchmark/benchmark_gpu_tiles.jl:103-165): the median wall time of one forces! call and of
+    one potential_energy call — each drained — with a step counter that advances by one per call, so that every tenth call is a rebuild step
+    of the GPU neighbour finder.  --steps = the samples (the reference: 10).  One record per case (dense, sparse)."""
+    import ctypes as C
+    import importlib
+    import torch
+    W = importlib.import_module("molly_jl_amd.workloads")
+    L = m.lib()
+    out = []
+    for name, mult, seed in (("dense_f32", 1.0, 42), ("sparse_f32", 4.0, 43)):
+        case = W.argon_random(4096, mult, seed)
+        s = case.system(m, np.float32)
+        s.push_state(velocities=True)
+        ctx = s.engine()
+        f = torch.empty((case.n, 3), dtype=torch.float32, device="cuda")
+        pe = C.c_double(0)
+        def forces(k): s._check(L.mhip_forces(ctx, k, 0, f.data_ptr(), None, 1)); s._check(L.mhip_synchronize(ctx))
+        def energy(k): s._check(L.mhip_potential_energy(ctx, k, C.byref(pe))); s._check(L.mhip_synchronize(ctx))
+        for k in range(max(args.warmup, 2)):
+            forces(k); energy(k)
+        tf, te = [], []
+        for k in range(args.steps):
+            t0 = time.perf_counter(); forces(k); tf.append((time.perf_counter() - t0) * 1e3)
+        for k in range(args.steps):
+            t0 = time.perf_counter(); energy(k); te.append((time.perf_counter() - t0) * 1e3)
+        s._check(L.mhip_set_profiling(ctx, 1))
+        for k in range(args.steps, args.steps + 50):
+            forces(k)
+        st = s.stats()
+        s._check(L.mhip_set_profiling(ctx, 0))
+        kern_ms = st["prof_ms"][0] / max(st["prof_calls"][0], 1)
+        rec = {"case": name, "box_nm": float(case.box[0]), "n_atoms": case.n, "forces_call_ms_median": float(np.median(tf)), "forces_call_ms_min": float(min(tf)),
+               "potential_energy_call_ms_median": float(np.median(te)), "samples": args.steps,
+               "pairs_half_list": st["n_pairs_full"] // 2, "k_forces_us": kern_ms * 1e3, "force_pass_bytes": st["force_pass_bytes"],
+               "roofline_frac": (st["force_pass_bytes"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kern_ms > 0 else None,
+               "rebuilds": st["n_rebuilds"], "block_atoms": st["block_atoms"], "j_split": st["j_split"]}
+        if not args.no_cpu_baseline:      # the oracle's forces over its own list, all cores (the reference's forces! minus the neighbour search)
+            from oracle import pyoracle as orc
+            orc.build(native=True)
+            o = orc.from_case(case, np.float32); o.native = True
+            nt = min(os.cpu_count() or 1, 64)
+            nl = o.neighbors("cell", nthreads=nt)
+            o.forces(nl, nthreads=nt)
+            t0 = time.perf_counter(); n_rep = 5
+            for _ in range(n_rep):
+                o.forces(nl, nthreads=nt)
+            rec["cpu_forces_call_ms"] = (time.perf_counter() - t0) * 1e3 / n_rep; rec["cpu_cores"] = nt
+        s.close()
+        out.append(rec)
+    d = out[0]
+    return {"metric": "forces_call_ms_median", "value": d["forces_call_ms_median"], "unit": "ms", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": d["forces_call_ms_median"], "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": WORKLOADS[workload], "name": workload, "n_atoms": 4096, "parallelism": "single domain", "timed_window": "median of --steps drained calls"},
+            "roofline": {"bound": "hbm", "kernel": "k_forces", "achieved": d["force_pass_bytes"] / (d["k_forces_us"] * 1e-6) / 1e9 if d["k_forces_us"] else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": d["roofline_frac"], "traffic": None, "algorithmic_bytes_per_launch": d["force_pass_bytes"], "avg_launch_ms": d["k_forces_us"] * 1e-3},
+            "cpu_baseline": ({"value": d["cpu_forces_call_ms"], "unit": "ms per forces call", "cores": d["cpu_cores"], "kind": "port",
+                              "sample": "5 calls of the oracle's threaded pair loop over its own neighbour list, same system"} if "cpu_forces_call_ms" in d else None),
+            "cases": out}
 
 
 def make_record(workload, case, dtype, dt, ms_per_step, st, extra, world, args, steps, warmup, profile_steps):
@@ -231,6 +296,12 @@ def main():
             return
         ms_per_step, st, extra = result
         line = make_record(args.workload, case, dtype, dt, ms_per_step, st, extra, world, args, args.steps, args.warmup, args.profile_steps)
+    elif args.workload in FORCE_CALL_WORKLOADS:
+        if args.steps > 500:
+            args.steps, args.warmup = 100, 10            # (the defaults are sized for MD steps; the reference takes 10 samples)
+        line = run_force_calls(m, args.workload, args)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+        return
     else:
         ms_per_step, st, extra, case, dtype, dt = run_single(m, args.workload, args, args.steps, args.warmup, args.profile_steps)
         line = make_record(args.workload, case, dtype, dt, ms_per_step, st, extra, world, args, args.steps, args.warmup, args.profile_steps)

@@ -134,6 +134,9 @@ typedef struct mhip_stats {
     int64_t n_outer_builds;        /* searches with the outer radius (dual pair list)             */
     int64_t n_filter_passes;
     int64_t tile_segments;         /* LDS segments the largest tile of the last force pass was walked in (1: resident as a whole) */
+    int64_t n_group_split_passes;  /* plain force passes that ran as the group-split launch of small systems (csrc/forces_gs.hip) */
+    int32_t group_split;           /* groups per block of that launch (0: not in use for this system)                             */
+    int32_t reserved0;
 } mhip_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */

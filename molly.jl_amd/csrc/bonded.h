@@ -315,7 +315,8 @@ template <class T> struct Bonded {
 
     // forces ADDED to frc (sorted order; `orig` = sorted→caller map of the n_owned owned atoms, `cap` = context capacity).
     // MOLLYHIP_BONDED_ATOMICS=1: the one-launch scatter with float atomics.
-    void launch_forces(hipStream_t s, const GridP<T>& G, const InterP<T>& I, const T4* pos, const int32_t* inv, T4* frc, const int32_t* orig, int64_t n_owned, int64_t cap) {
+    // terms_done: the term kernel's work was done by another launch already (forces_gs.hip runs the terms beside the pair groups): only the per-atom sums
+    void launch_forces(hipStream_t s, const GridP<T>& G, const InterP<T>& I, const T4* pos, const int32_t* inv, T4* frc, const int32_t* orig, int64_t n_owned, int64_t cap, bool terms_done = false) {
         int nb = n_blocks();
         if (!nb) return;
         static const bool atomics = [] { const char* v = std::getenv("MOLLYHIP_BONDED_ATOMICS"); return v && *v && std::atoi(v) != 0; }();
@@ -325,7 +326,7 @@ template <class T> struct Bonded {
             return;
         }
         if (roles_dirty || roles_cap != cap) { MHIP_HIP(hipStreamSynchronize(s)); build_roles(cap); }
-        hipLaunchKernelGGL((k_bonded<T, false, true>), dim3(nb), dim3(BT), 0, s, args(G, I, pos, inv, slots, nullptr));
+        if (!terms_done) hipLaunchKernelGGL((k_bonded<T, false, true>), dim3(nb), dim3(BT), 0, s, args(G, I, pos, inv, slots, nullptr));
         hipLaunchKernelGGL(k_bonded_collect<T>, dim3((unsigned)cdiv(n_owned * COLLECT_LANES, (int64_t)256)), dim3(256), 0, s, n_owned, orig, (const int32_t*)role_start.p, (const int32_t*)role_slot.p, (const T4*)slots, frc,
                            fold_parts, fold_n, fold_stride);
         fold_parts = nullptr; fold_n = 0;

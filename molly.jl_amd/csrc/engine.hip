@@ -181,7 +181,7 @@ template <class T> class Engine final : public EngineBase {
     // the group-split pair pass of small systems (forces_gs.hip): the inner list re-dealt into GS groups per block after every prune, the
     // partial forces of groups 1 .. GS − 1 (group 0 writes the force array), and which prune the list belongs to
     DBuf<uint2> nbr_gs; DBuf<int32_t> rows_gs; DBuf<T4> frc_parts; int64_t gs_list_id = -1; bool gs_used = false;
-    bool fuse_spread_next = false, spread_fused = false; const bool gs_fuse_spread = env_int("MOLLYHIP_GS_FUSE_SPREAD", 1) != 0;
+    bool fuse_spread_next = false, spread_fused = false, fuse_terms_next = false, terms_fused = false; const bool gs_fuse_spread = env_int("MOLLYHIP_GS_FUSE_SPREAD", 1) != 0;
     const int gs_env = env_int("MOLLYHIP_GROUP_SPLIT", -1);      // 0: off; 2 / 4: groups per block; −1: automatic
     int gs_groups() const {
         if (!std::is_same<T, float>::value || ljm != LJ_DIST || !(coulm == MHIP_COUL_REACTION_FIELD || (coulm == MHIP_COUL_EWALD_DIRECT && I.approx_erfc))) return 0;
@@ -236,7 +236,7 @@ template <class T> class Engine final : public EngineBase {
     bool coords_moved = false, export_needs_search = false; int64_t n_set_state_refresh = 0;
     const bool keep_lists_on_set_state = env_int("MOLLYHIP_SET_STATE_REBUILDS", 0) == 0;
     int64_t last_build_step = std::numeric_limits<int64_t>::min();
-    int64_t n_rebuilds = 0, n_force_calls = 0; double last_rebuild_ms = 0;
+    int64_t n_rebuilds = 0, n_force_calls = 0, n_gs_passes = 0; double last_rebuild_ms = 0;
     size_t lds_force = 0; int tile_lds = 0; bool segmented = false; int last_pass_tile = 0;
     Prof prof;
     // MOLLYHIP_TRACE=1: drain the stream, then name the launch that follows on stderr — the last name a dying process printed is the
@@ -596,8 +596,8 @@ template <class T> class Engine final : public EngineBase {
         const int o = cur, n = 1 - cur;
         const int ncell2 = 2 * G.ncell + 1;
         prof.begin(3, stream);
-        MHIP_HIP(hipMemsetAsync(cell_cnt.p, 0, (size_t)ncell2 * sizeof(int32_t), stream));
         const int nb256 = cdiv(n_tot, 256);
+        MHIP_HIP(hipMemsetAsync(cell_cnt.p, 0, (size_t)ncell2 * sizeof(int32_t), stream));
         tr("k_cell_keys");
         hipLaunchKernelGGL(k_cell_keys<T>, dim3(nb256), dim3(256), 0, stream, n_tot, n_owned, (const T4*)pos[o].p, (const int32_t*)inv.p,
                            (const uint32_t*)cell_rank.p, key_in.p, idx_in.p, cell_cnt.p, G, sub_bits);
@@ -954,18 +954,20 @@ template <class T> class Engine final : public EngineBase {
                     prof.begin(0, stream);
                     tr("k_forces_gs");
                     spread_fused = false;
-                    if (fuse_spread_next && gs_fuse_spread) {      // … with the charge spreading and the bonded terms of the step as further workgroups of the same launch
+                    if ((fuse_spread_next || fuse_terms_next) && gs_fuse_spread) {      // … with the charge spreading (PME) and the bonded terms of the step as further workgroups of the same launch
                         bonded.ensure_roles(stream, cap);
-                        const size_t lds = std::max(gs_lds_bytes(q_lds, BI, JS / GS), std::min<size_t>((size_t)MAX_LDS_BYTES / GS, spread_head_bytes_f32(pme.order) + (size_t)PME_BOX_BYTES)) & ~(size_t)15;
-                        const int n_spread = (int)std::min<int64_t>(cdiv(n_owned, (int64_t)64), 4096);
-                        launch_pair_spread_bonded(Z, n_blocks * GS, coulm, minimg, pme.order, n_owned, reinterpret_cast<float*>(pme.rgrid.p), reinterpret_cast<const PmeP<float>&>(pme.P), n_spread,
+                        const bool with_spread = fuse_spread_next;
+                        const int order = with_spread ? pme.order : 5;
+                        const size_t lds = (with_spread ? std::max(gs_lds_bytes(q_lds, BI, JS / GS), std::min<size_t>((size_t)MAX_LDS_BYTES / GS, spread_head_bytes_f32(order) + (size_t)PME_BOX_BYTES)) : gs_lds_bytes(q_lds, BI, JS / GS)) & ~(size_t)15;
+                        const int n_spread = with_spread ? (int)std::min<int64_t>(cdiv(n_owned, (int64_t)64), 4096) : 0;
+                        launch_pair_spread_bonded(Z, n_blocks * GS, coulm, minimg, order, n_owned, reinterpret_cast<float*>(pme.rgrid.p), reinterpret_cast<const PmeP<float>&>(pme.P), n_spread,
                                                   reinterpret_cast<const BondedArgs<float>&>(static_cast<const BondedArgs<T>&>(bonded.slot_args(G, I, pos[cur].p, inv.p))), cdiv(bonded.n_blocks(), 4), lds, stream);
-                        spread_fused = true;
+                        spread_fused = with_spread; terms_fused = !with_spread;
                     } else launch_forces_gs(Z, coulm, minimg, stream);
-                    fuse_spread_next = false;
+                    fuse_spread_next = fuse_terms_next = false;
                     prof.end(0, stream);
                     MHIP_HIP(hipGetLastError());
-                    ++n_force_calls; gs_used = true;
+                    ++n_force_calls; ++n_gs_passes; gs_used = true;
                     return;
                 }
             }
@@ -1205,9 +1207,10 @@ template <class T> class Engine final : public EngineBase {
         const bool small_fused = !overlap && !chain_beside && fuse_small && bonded.any() && pme.on() && !Bonded<T>::use_atomics() && n_ghost == 0;
         // (with the stage timers on, every job keeps its own launch: a stage's time is then that job's — bench.py's profiling pass, never its timed region)
         fuse_spread_next = gs_ok && small_fused && pme.order >= 4 && pme.order <= 6 && !(prof.on && env_int("MOLLYHIP_PROF_FUSED", 0) == 0);
-        spread_fused = false;
+        fuse_terms_next = gs_ok && !small_fused && !pme.on() && !(prof.on && env_int("MOLLYHIP_PROF_FUSED", 0) == 0);      // (no PME: the bonded terms alone ride with the pair groups)
+        spread_fused = terms_fused = false;
         launch_pair_kernel(false, interior_done ? 2 : 0, gs_ok);   // (the blocks without ghosts may have run already, while the ghosts were on the wire)
-        fuse_spread_next = false;
+        fuse_spread_next = fuse_terms_next = false;
         interior_done = false;
         bool redo = false;
         if (prune_disp_exceeded) {   // the outer list could not vouch for this pass: search again and redo it on the fresh list
@@ -1235,7 +1238,7 @@ template <class T> class Engine final : public EngineBase {
             frc_valid = true;
             return;
         }
-        if (redo || !side_b) { if (bonded.any()) { prof.begin(5, stream); bonded.launch_forces(stream, G, I, pos[cur].p, inv.p, frc[cur].p, orig[cur].p, n_owned, cap); prof.end(5, stream); } }
+        if (redo || !side_b) { if (bonded.any()) { prof.begin(5, stream); bonded.launch_forces(stream, G, I, pos[cur].p, inv.p, frc[cur].p, orig[cur].p, n_owned, cap, terms_fused); prof.end(5, stream); } }
         else { MHIP_HIP(hipStreamWaitEvent(stream, ev_side[0], 0)); pend_a = frc_side[0].p; }
         if (redo || !side_p) launch_pme_forces();
         else { MHIP_HIP(hipStreamWaitEvent(stream, ev_side[1], 0)); pend_b = frc_side[1].p; }
@@ -2257,6 +2260,7 @@ template <class T> class Engine final : public EngineBase {
         s->n_blocks = n_blocks; s->block_atoms = BI; s->j_split = JS; s->minimg_mode = minimg ? 1 : 0; s->max_tile_atoms = max_tile;
         s->last_rebuild_ms = last_rebuild_ms; s->lds_bytes = (int64_t)lds_force;
         s->tile_segments = segmented ? cdiv(std::max(last_pass_tile, 1), std::max(tile_lds, 1)) : 1;
+        s->n_group_split_passes = n_gs_passes; s->group_split = gs_groups(); s->reserved0 = 0;
         s->n_list_slots = total_rows * 4 * WAVE;
         if (!stale) {
             std::vector<int32_t> tc(n_blocks);

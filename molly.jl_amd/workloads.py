@@ -144,6 +144,20 @@ def lj_fluid(n_side, seed=2, temperature=85.0, jitter=0.02, r_cut=1.0, r_list=1.
                 name=f"lj{n}")
 
 
+def argon_random(n_atoms=4096, box_multiplier=1.0, seed=42, r_cut=1.2, dtype=np.float32):
+    """The system of the reference's own GPU benchmark (benchmark/benchmark_gpu_tiles.jl:13-40): n argon atoms at UNIFORMLY RANDOM positions in a
+    cubic box of 1400 kg/m³ (× box_multiplier per side, at least 2.5 r_cut), LennardJones with DistanceCutoff(1.2 nm), zero velocities; the list
+    radius is the cutoff (GPUNeighborFinder(dist_cutoff = r_cut)).  dense_f32: multiplier 1 (5.79 nm), sparse_f32: multiplier 4."""
+    vol = n_atoms * ARGON["mass"] / (1400.0 * 6.02214076e23) * 1e24          # nm³ (g/mol ÷ (kg/m³ · mol⁻¹) = 1e-3 m³ → ·1e27 nm³/m³)
+    box = max(vol ** (1.0 / 3.0) * box_multiplier, 2.5 * r_cut)
+    rng = np.random.default_rng(seed)
+    x = (rng.random((n_atoms, 3)) * box).astype(dtype).astype(np.float64)
+    x = np.where(x >= np.float64(dtype(box)), 0.0, x)
+    return Case(x, float(dtype(box)), lj=dict(cutoff=("distance", r_cut)), r_list=r_cut, rebuild_every=10, velocities=np.zeros((n_atoms, 3)),
+                sigma=np.full(n_atoms, ARGON["sigma"]), eps=np.full(n_atoms, ARGON["eps"]), mass=np.full(n_atoms, ARGON["mass"]),
+                name=f"argon{n_atoms}_x{box_multiplier:g}")
+
+
 def charged_fluid(n_side, coul, seed=5, spacing=0.31, r_list=1.2, dtype=np.float32, with_exceptions=True, stable=False, pme=None, box_scale=(1.0, 1.0, 1.0)):
     """A water-like-density mixed LJ + Coulomb fluid with per-atom σ, ϵ, q (two species + some LJ-less
     'hydrogens' with ϵ = 0) and random excluded / special pairs between close atoms.  The ϵ = 0 species exercises the

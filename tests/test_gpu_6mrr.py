@@ -99,3 +99,38 @@ def test_velocity_verlet_rf_fp64_tracks_oracle_and_conserves_energy(pkg):
         es.append(pkg.total_energy(s))
     assert max(abs(e - e0) for e in es) < 0.06 * abs(e0)            # bounded
     assert abs(es[4] - e0) < 2e-3 * abs(e0) and abs(es[-1] - e0) < 5e-3 * abs(e0)   # returns at equal phase (steps 100, 200): no secular drift
+
+
+def test_group_split_pair_pass_is_the_same_run(pkg, monkeypatch):
+    """The pair pass of this system class runs as four 256-lane workgroups per block over tile quarters, with the charge spreading and the
+    bonded terms as further workgroups of the same launch (csrc/forces_gs.hip), the partial forces folded by the bonded sums.  It walks the
+    same inner list re-dealt (k_regroup, after every prune) with the same arithmetic per pair, so a run with it and a run with the one-block
+    launch (MOLLYHIP_GROUP_SPLIT=0) may differ by the order of an atom's partial sums only: 12 steps of 0.5 fs across a rebuild (search,
+    prune, regroup at step 10) agree to fp32 round-off, and the launch is reproducible bit for bit."""
+    def run(gs):
+        if gs is None: monkeypatch.delenv("MOLLYHIP_GROUP_SPLIT", raising=False)
+        else: monkeypatch.setenv("MOLLYHIP_GROUP_SPLIT", gs)
+        case = G.case("ewald", np.float32, bonded=True, pme=True)
+        s = case.system(pkg, np.float32)
+        pkg.simulate(s, pkg.VelocityVerlet(dt=0.0005), 12)
+        return np.array(s.coords, dtype=np.float64), np.array(s.velocities, dtype=np.float64), s.stats()
+    x1, v1, st1 = run(None)
+    x0, v0, st0 = run("0")
+    assert st1["group_split"] == 4 and st1["n_group_split_passes"] >= 8 and st0["n_group_split_passes"] == 0
+    d = x1 - x0; d -= np.round(d / G.data()["box"]) * G.data()["box"]
+    assert np.abs(d).max() < 2e-6 and np.abs(v1 - v0).max() < 2e-3           # (ulp of a 5 nm coordinate: 4.8e-7 nm; hydrogens move at 3 nm/ps)
+    # reaction field, no PME: the bonded terms alone ride with the pair groups.  No atomics anywhere on this path (the PME mesh above is
+    # flushed with float atomics): the run repeats bit for bit.
+    monkeypatch.delenv("MOLLYHIP_GROUP_SPLIT", raising=False)
+    case = G.case("rf", np.float32, bonded=True)
+    o = case.oracle(np.float64)
+    o.vv_run(12, 0.0005, remove_cm_every=1, nthreads=8, specific=True)
+    runs = []
+    for _ in range(2):
+        s = case.system(pkg, np.float32)
+        pkg.simulate(s, pkg.VelocityVerlet(dt=0.0005), 12)
+        assert s.stats()["n_group_split_passes"] >= 8
+        runs.append((np.array(s.coords), np.array(s.velocities)))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+    d = runs[0][0].astype(np.float64) - o.coords; d -= np.round(d / case.box) * case.box
+    assert np.abs(d).max() < 5e-6
