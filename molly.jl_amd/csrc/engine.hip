@@ -1024,6 +1024,8 @@ template <class T> class Engine final : public EngineBase {
             if (lds_force > (size_t)MAX_LDS_BYTES) throw ApiError{MHIP_ERR_CAPACITY, "prune pass LDS carve-up exceeds 160 KiB"};
         }
         A.blk_center = blk_center.p; A.frc = frc_override ? frc_override : frc[cur].p; A.pe_part = red_part.p;
+        static const int level_env = env_int("MOLLYHIP_LEVEL_PAIRS", 1);
+        A.level_pairs = (prune && level_env && JS == 2 && !lanes_sorted && !rebalance) ? 1 : 0;
         A.dbg = nullptr;
         static const int dbg_times = env_int("MOLLYHIP_DBG_TIMES", 0);
         if (dbg_times && !prune && !energy) { dbg_buf.reserve((size_t)n_blocks * 16 * 8); MHIP_HIP(hipMemsetAsync(dbg_buf.p, 0, (size_t)n_blocks * 16 * 8 * sizeof(unsigned long long), stream)); A.dbg = dbg_buf.p; }

@@ -1026,6 +1026,7 @@ template <class T> struct ForceArgs {
     // ghosted sub-domains: a pass over only the blocks whose tile holds no ghost atom (part 1: they can run while the ghost coordinates
     // are still on the wire) or only the others (part 2); 0 = every block
     const int32_t* blk_ghost; int part;
+    int level_pairs;                 // PRUNE, two sub-lists per atom: level the two lanes' entry counts before padding
     // MOLLYHIP_DBG_TIMES (builds with -DMHIP_EXP=11 only): [n_blocks][waves][8] — shader clock and 100 MHz wall clock at kernel entry, behind the
     // staging barrier, behind the row walk and at the end, per wave
     unsigned long long* dbg;
@@ -1516,12 +1517,39 @@ k_forces(ForceArgs<T> A) {
     if constexpr (PRUNE) {
         // finish the inner list: pad to the wave's row count; record how far the block's atoms moved since the outer build
         const uint32_t SENTP = make_entry((uint32_t)n_new, 0u, esh);
+        const int NWB = A.BI >> 6;
+        // Two sub-lists per atom (the 256 × 2 shape of the large fluids): which of an atom's kept entries fall to which is a coin toss per
+        // entry (tile slot parity), a wave walks as many rows as its longest lane, and 17 % of the slots of a 1M-atom pass were padding.
+        // Before the lists are padded the two lanes of an atom level their counts: the longer one hands its LAST entries to the shorter
+        // one's tail (2-byte stores into rows both have flushed; the positions written are the receiver's alone, the padding below comes
+        // after a barrier).  Every wave of a pass sees the whole tile, so which sub-list holds an entry changes nothing but the order of
+        // the atom's sum — fixed, as before — and the pass walks 6 % fewer slots for a few stores per atom and prune (a separate
+        // re-dealing pass over the 272 MB list cost what it saved, profiles/r04_force_ab.txt §2).
+        const bool level = A.level_pairs && A.JS == 2 && !A.cnt_src;
+        if (level) {
+            if (kept & 3) out_rows[(int64_t)(kept >> 2) * A.BI] = make_uint2((uint32_t)acc, (uint32_t)(acc >> 32));      // my pending entries: the row goes out as it is
+            l_cnt[tid] = kept;
+            __syncthreads();
+            const int kp = l_cnt[tid ^ A.BI], total = kept + kp, mine = js == 0 ? (total + 1) >> 1 : total >> 1;
+            if (kept > mine) {
+                uint16_t* to = reinterpret_cast<uint16_t*>(A.nbr_dst + (((int64_t)b * A.JS + (js ^ 1)) * A.R_cap) * A.BI + li);
+                const uint16_t* from = reinterpret_cast<const uint16_t*>(out_rows);
+                for (int q = 0; q < kept - mine; ++q) {
+                    const int ps = mine + q, pd = kp + q;
+                    to[(((int64_t)(pd >> 2) * A.BI) << 2) + (pd & 3)] = from[(((int64_t)(ps >> 2) * A.BI) << 2) + (ps & 3)];
+                }
+            }
+            kept = mine;
+        }
         if (A.cnt_dst) A.cnt_dst[((int64_t)b * A.JS + js) * A.BI + li] = (uint16_t)min(kept, 65535);
         // every lane pads to the row count of the wave its rows go to (its own wave unless the lanes are being sorted)
-        const int NWB = A.BI >> 6;
         atomicMax(&l_wmax[js * NWB + (pos_l >> 6)], (kept + 3) >> 2);
         __syncthreads();
         const int rows_wave = l_wmax[js * NWB + (pos_l >> 6)];
+        if (level) {      // (the rows are in memory already: the padding goes there too, entry by entry)
+            uint16_t* mine16 = reinterpret_cast<uint16_t*>(out_rows);
+            for (int p2 = kept; p2 < 4 * rows_wave; ++p2) mine16[(((int64_t)(p2 >> 2) * A.BI) << 2) + (p2 & 3)] = (uint16_t)SENTP;
+        } else
         while (((kept + 3) >> 2) < rows_wave || (kept & 3)) emit(SENTP);
         if (tid < A.JS * NWB) A.rows_dst[b * A.JS * NWB + tid] = l_wmax[tid];
         if (tid == 0) A.tile_cnt_dst[b] = n_new;
