@@ -99,7 +99,7 @@ def cpu_baseline(case, dtype, dt, budget_s=20.0):
 def load_traffic(workload):
     """HBM bytes per force-kernel launch from the rocprofv3 PMC passes committed under profiles/ (collected by
     profiles/collect.sh: separate FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE×2 gfx950 correction)."""
-    for tag in ("r03_", ""):
+    for tag in ("r04_", "r03_", ""):
         p = os.path.join(ROOT, "profiles", f"{tag}traffic_{workload}.json")
         if os.path.exists(p):
             try:
