@@ -115,7 +115,7 @@ template <int COULM, bool MINIMG>
 __device__ inline void forces_gs_body(const GsArgs& A, int wg, unsigned char* smem) {
     const GridP<float>& G = A.G;
     const int g = wg / A.n_blocks, bq = wg - g * A.n_blocks;
-    int b = bq + g * A.spread; b -= b >= A.n_blocks ? A.n_blocks : 0;
+    const int b = (bq + g * A.spread) % A.n_blocks;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int li = tid & (A.BI - 1), jw = tid >> A.BI_shift, JSW = A.JS >> A.lgGS, js = g * JSW + jw;
     const int tile_n = A.tile_cnt[b], qmax = (tile_n + A.GS - 1) >> A.lgGS;        // group-local slots 0 .. qmax − 1, sentinel qmax
