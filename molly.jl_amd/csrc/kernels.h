@@ -153,9 +153,12 @@ __global__ void k_scatter_state(int64_t n_tot, int64_t n_owned, const int32_t* _
             vel[s].x = vxyz[3 * o]; vel[s].y = vxyz[3 * o + 1]; vel[s].z = vxyz[3 * o + 2];
         }
     }
-    if (changed) {
-        if (__any(dx) && (threadIdx.x & 63) == 0) atomicOr(&changed[0], 1);
-        if (__any(dv) && (threadIdx.x & 63) == 0) atomicOr(&changed[1], 1);
+    if (changed) {      // (a word that is up already is left alone: 16 000 waves raising the same word one after the other took 0.3 of the launch's 0.36 ms at 1M atoms)
+        const bool ax = __any(dx), av = __any(dv);
+        if ((threadIdx.x & 63) == 0) {
+            if (ax && __hip_atomic_load(&changed[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(&changed[0], 1);
+            if (av && __hip_atomic_load(&changed[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(&changed[1], 1);
+        }
     }
 }
 
