@@ -35,7 +35,7 @@ def _kernels(asm):
         if m:
             kern = m.group(1); info[kern] = {}; label = None
             continue
-        m = re.match(r"\s*\.amdhsa_(next_free_vgpr|private_segment_fixed_size) (\d+)", line)
+        m = re.match(r"\s*\.amdhsa_(next_free_vgpr|private_segment_fixed_size|group_segment_fixed_size) (\d+)", line)
         if m and kern:
             info[kern][m.group(1)] = int(m.group(2))
         if label:
@@ -58,6 +58,9 @@ def test_uniform_lj_kernels_fit_64_vgprs_without_scratch(tmp_path):
     for n, (r, _) in ks.items():
         if "k_forces<" in n:
             assert r["private_segment_fixed_size"] == 0, (n, r)      # no variant of this file spills
+            # … and none has a __shared__ array: the packed loop addresses the tile from LDS address 0 (kernels.h, walk_rows), so the
+            # launch's dynamic LDS must start there (a helper with a static array, tried in an epilogue, moved the tile by 128 bytes: NaN forces)
+            assert r["group_segment_fixed_size"] == 0, (n, r)
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
