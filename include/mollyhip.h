@@ -136,7 +136,7 @@ typedef struct mhip_stats {
     int64_t tile_segments;         /* LDS segments the largest tile of the last force pass was walked in (1: resident as a whole) */
     int64_t n_group_split_passes;  /* plain force passes that ran as the group-split launch of small systems (csrc/forces_gs.hip) */
     int32_t group_split;           /* groups per block of that launch (0: not in use for this system)                             */
-    int32_t reserved0;
+    int32_t n_adopted_outer_lists; /* rebuilds whose outer list became the inner list without a pruning pass (nothing to prune: inner radius = r_list) */
 } mhip_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */

@@ -181,6 +181,11 @@ template <class T> class Engine final : public EngineBase {
     // the group-split pair pass of small systems (forces_gs.hip): the inner list re-dealt into GS groups per block after every prune, the
     // partial forces of groups 1 .. GS − 1 (group 0 writes the force array), and which prune the list belongs to
     DBuf<uint2> nbr_gs; DBuf<int32_t> rows_gs; DBuf<T4> frc_parts; int64_t gs_list_id = -1; bool gs_used = false;
+    // A prune that could drop nothing — the inner skin has grown to the reference's own r_list − cutoff, the outer list has no margin and was searched at
+    // this very step (6mrr at 0.5 fs: every rebuild) — is skipped: the outer list IS the inner list (inner_is_outer: the passes over the inner list read
+    // the outer arrays), and k_regroup deals it to the groups straight away.  It was a 61 µs pass (the PRUNE variant of k_forces, 1024-lane blocks) per
+    // rebuild where the group-split launch that now computes the same forces takes 25 µs, spreading and bonded terms included.
+    bool inner_is_outer = false; const bool adopt_env = env_int("MOLLYHIP_ADOPT_OUTER", 1) != 0; int64_t n_adopted = 0;
     bool fuse_spread_next = false, spread_fused = false, fuse_terms_next = false, terms_fused = false; const bool gs_fuse_spread = env_int("MOLLYHIP_GS_FUSE_SPREAD", 1) != 0;
     const int gs_env = env_int("MOLLYHIP_GROUP_SPLIT", -1);      // 0: off; 2 / 4: groups per block; −1: automatic
     int gs_groups() const {
@@ -638,7 +643,7 @@ template <class T> class Engine final : public EngineBase {
             A.walk = walk ? 1 : 0;
             A.eshift = eshift = want_eshift();
             A.cnt_out = nullptr; cnt_outer_valid = false;
-            if (sort_lanes_on && dual && BI > 64) { cnt_outer.reserve((size_t)n_blocks * JS * BI); A.cnt_out = cnt_outer.p; cnt_outer_valid = true; }
+            if ((sort_lanes_on && dual && BI > 64) || (gs_groups() > 0 && adopt_env)) { cnt_outer.reserve((size_t)n_blocks * JS * BI); A.cnt_out = cnt_outer.p; cnt_outer_valid = true; }
             prof.begin(1, stream);
             tr("k_build");
             auto go = [&](auto kern) { set_lds_limit(kern, lds); hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(BI * JS), lds, stream, A); };
@@ -675,7 +680,7 @@ template <class T> class Engine final : public EngineBase {
         if (dual) {   // remember where everybody was; the next force pass prunes the outer list into the inner one
             pos_snap.reserve(cap);
             MHIP_HIP(hipMemcpyAsync(pos_snap.p, pos[cur].p, (size_t)n_tot * sizeof(T4), hipMemcpyDeviceToDevice, stream));
-            inner_valid = false; prune_disp_exceeded = false; ghost_flags_in_ok = false; cnt_in_valid = false; lanes_sorted = false;
+            inner_valid = false; inner_is_outer = false; prune_disp_exceeded = false; ghost_flags_in_ok = false; cnt_in_valid = false; lanes_sorted = false;
             if (cur_dt > 0 && skin_in < skin && !host_prune) {   // inside a run: how fast is the fastest atom? (sizes the inner skin before the first prune)
                 (void)max_disp2_since(pos_snap);
                 adapt_inner_skin(drift_ahead(0.0, 1, cfg.rebuild_every > 0 ? cfg.rebuild_every : 10));
@@ -935,6 +940,10 @@ template <class T> class Engine final : public EngineBase {
         // dual pair list: a force pass whose inner list is stale walks the OUTER list (always a valid superset — the cutoff is
         // applied per pair) and, if it is a plain force call, prunes it into the inner list on the way
         if (dual && !inner_valid && !energy && (prune_by_kernel || prune_lean_ok())) prune_with_filter();
+        if constexpr (std::is_same<T, float>::value) {
+            if (dual && !inner_valid && !energy && allow_gs && part == 0 && !frc_override && adopt_env && gs_groups() > 0 && cnt_outer_valid && margin_zero && !(skin_in < skin)
+                && last_outer_step == pass_step && !lanes_sorted && !rebalance_on && n_ghost == 0 && !host_prune) adopt_outer_list();
+        }
         const bool use_inner = dual && inner_valid;
         const bool prune = dual && !inner_valid && !energy;
         const bool rebalance = prune && rebalance_on && JS > 1 && !sort_lanes_on;
@@ -942,13 +951,13 @@ template <class T> class Engine final : public EngineBase {
         // a plain pass over an inner list that has its group-split form (made right behind the prune that wrote it)
         if constexpr (std::is_same<T, float>::value) {
             if (allow_gs && GS > 0 && use_inner && !energy && part == 0 && gs_list_id == n_filters && !frc_override) {
-                const int q_lds = (max_tile_in + GS - 1) / GS + 1;
+                const int q_lds = (max_tile_in + GS - 1) / GS + 1;      // (max_tile_in = max_tile while the outer list stands in)
                 if (gs_lds_bytes(q_lds, BI, JS / GS) <= (size_t)MAX_LDS_BYTES / GS) {
                     frc_parts.reserve((size_t)(GS - 1) * cap);
                     GsArgs Z;
                     Z.G = G; Z.I = I; Z.n_owned = n_owned; Z.BI = BI; Z.BI_shift = ilog2(BI); Z.JS = JS; Z.GS = GS; Z.lgGS = ilog2(GS); Z.R_cap = R_cap; Z.T_cap = T_cap; Z.Q_lds = q_lds;
                     Z.n_blocks = n_blocks; Z.spread = std::max(1, n_blocks / GS + 5);
-                    Z.pos = pos[cur].p; Z.lj = lj[cur].p; Z.tile_idx = tile_idx_in.p; Z.tile_cnt = tile_cnt_in.p; Z.nbr = nbr_gs.p; Z.wave_rows = rows_gs.p; Z.blk_center = blk_center.p;
+                    Z.pos = pos[cur].p; Z.lj = lj[cur].p; Z.tile_idx = inner_is_outer ? tile_idx.p : tile_idx_in.p; Z.tile_cnt = inner_is_outer ? tile_cnt.p : tile_cnt_in.p; Z.nbr = nbr_gs.p; Z.wave_rows = rows_gs.p; Z.blk_center = blk_center.p;
                     Z.frc = frc[cur].p; Z.parts = frc_parts.p; Z.part_stride = cap;
                     last_pass_tile = max_tile_in;
                     prof.begin(0, stream);
@@ -976,8 +985,8 @@ template <class T> class Engine final : public EngineBase {
         carve_force_lds(use_inner ? max_tile_in : max_tile, prune_extra);
         last_pass_tile = use_inner ? max_tile_in : max_tile;
         A.T_lds = tile_lds;
-        if (use_inner) { A.tile_idx = tile_idx_in.p; A.tile_cnt = tile_cnt_in.p; }
-        A.nbr = use_inner ? nbr_in.p : nbr.p; A.wave_rows = use_inner ? wave_rows_in.p : wave_rows.p;
+        if (use_inner && !inner_is_outer) { A.tile_idx = tile_idx_in.p; A.tile_cnt = tile_cnt_in.p; }
+        A.nbr = (use_inner && !inner_is_outer) ? nbr_in.p : nbr.p; A.wave_rows = (use_inner && !inner_is_outer) ? wave_rows_in.p : wave_rows.p;
         A.nbr_dst = nullptr; A.rows_dst = nullptr; A.pos_snap = nullptr; A.blk_disp2 = nullptr; A.r_prune2 = r_prune2;
         A.tile_idx_dst = nullptr; A.tile_cnt_dst = nullptr; A.mark_off = 0; A.snap_dst = nullptr; A.any_special = n_special > 0 ? 1 : 0; A.eshift = eshift;
         A.lane_atom = (use_inner && lanes_sorted) ? lane_atom_in.p : nullptr; A.cnt_src = nullptr; A.cnt_dst = nullptr; A.perm_dst = nullptr;
@@ -1008,7 +1017,7 @@ template <class T> class Engine final : public EngineBase {
             last_prune_step = pass_step;
             tile_idx_in.reserve((size_t)n_blocks * T_cap); tile_cnt_in.reserve(n_blocks);
             A.tile_idx_dst = tile_idx_in.p; A.tile_cnt_dst = tile_cnt_in.p;
-            lanes_sorted = false;
+            lanes_sorted = false; inner_is_outer = false;
             if (sort_lanes_on && BI > 64 && cnt_outer_valid) {      // emit the rows ordered by the length they had last time (first prune: of the outer rows)
                 lane_atom_in.reserve((size_t)n_blocks * JS * BI); cnt_in.reserve((size_t)n_blocks * JS * BI);
                 A.cnt_src = cnt_in_valid ? cnt_in.p : cnt_outer.p; A.cnt_dst = cnt_in.p; A.perm_dst = lane_atom_in.p;
@@ -1069,6 +1078,26 @@ template <class T> class Engine final : public EngineBase {
             inner_valid = true; prune_disp_exceeded = 2.0 * std::sqrt((double)d2) > prune_margin() * 0.98;
             if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] prune: max disp %.5f nm (margin %.3f) rows %lld exceeded %d calls %lld\n", std::sqrt((double)d2), prune_margin(), (long long)total_rows, (int)prune_disp_exceeded, (long long)n_force_calls);
         }
+    }
+
+    // the outer list, searched at this step with the radius the inner list would be pruned to, becomes the inner list (see inner_is_outer)
+    void adopt_outer_list() {
+        const int GS = gs_groups();
+        prof.begin(4, stream);
+        pos_snap_in.reserve(cap);
+        MHIP_HIP(hipMemcpyAsync(pos_snap_in.p, pos[cur].p, (size_t)n_tot * sizeof(T4), hipMemcpyDeviceToDevice, stream));
+        nbr_gs.reserve((size_t)n_blocks * JS * R_cap * BI); rows_gs.reserve((size_t)n_blocks * JS * (BI / WAVE));
+        RegroupArgs R{BI, ilog2(BI), JS, GS, ilog2(GS), R_cap, (const uint2*)nbr.p, (const uint16_t*)cnt_outer.p, (const int32_t*)tile_cnt.p, nbr_gs.p, rows_gs.p,
+                      (int)std::min<size_t>((size_t)MAX_LDS_BYTES - (size_t)JS * BI * 8 - 64, (size_t)JS * R_cap * BI * 8)};
+        tr("k_regroup (outer list)");
+        launch_regroup(R, n_blocks, stream);
+        prof.end(4, stream);
+        MHIP_HIP(hipGetLastError());
+        inner_is_outer = true; max_tile_in = max_tile; last_prune_step = pass_step;
+        ++n_filters; ++n_adopted; gs_list_id = n_filters;
+        ghost_flags_in_ok = false; next_check_step = -1; lanes_sorted = false; cnt_in_valid = false;
+        inner_valid = true; prune_disp_exceeded = false;
+        if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] outer list adopted as the inner list (no prune): rows %lld calls %lld\n", (long long)total_rows, (long long)n_force_calls);
     }
 
     // timing experiment (library built with -DMHIP_EXP=11, MOLLYHIP_DBG_TIMES=n: every n-th plain pass): per-wave phase times of the pair kernel
@@ -1133,7 +1162,7 @@ template <class T> class Engine final : public EngineBase {
     }
     void prune_with_filter() {
         const bool lean = prune_lean_ok();
-        lanes_sorted = false; cnt_in_valid = false;      // (these kernels emit in atom order)
+        lanes_sorted = false; cnt_in_valid = false; inner_is_outer = false;      // (these kernels emit in atom order)
         last_prune_step = pass_step;
         if (lean) launch_prune_lean();
         else {
@@ -2262,7 +2291,7 @@ template <class T> class Engine final : public EngineBase {
         s->n_blocks = n_blocks; s->block_atoms = BI; s->j_split = JS; s->minimg_mode = minimg ? 1 : 0; s->max_tile_atoms = max_tile;
         s->last_rebuild_ms = last_rebuild_ms; s->lds_bytes = (int64_t)lds_force;
         s->tile_segments = segmented ? cdiv(std::max(last_pass_tile, 1), std::max(tile_lds, 1)) : 1;
-        s->n_group_split_passes = n_gs_passes; s->group_split = gs_groups(); s->reserved0 = 0;
+        s->n_group_split_passes = n_gs_passes; s->group_split = gs_groups(); s->n_adopted_outer_lists = (int32_t)std::min<int64_t>(n_adopted, INT32_MAX);
         s->n_list_slots = total_rows * 4 * WAVE;
         if (!stale) {
             std::vector<int32_t> tc(n_blocks);

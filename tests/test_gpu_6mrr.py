@@ -134,3 +134,24 @@ def test_group_split_pair_pass_is_the_same_run(pkg, monkeypatch):
     assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
     d = runs[0][0].astype(np.float64) - o.coords; d -= np.round(d / case.box) * case.box
     assert np.abs(d).max() < 5e-6
+
+
+def test_outer_list_adopted_when_the_prune_has_nothing_to_drop(pkg, monkeypatch):
+    """At 0.5 fs the hydrogens outrun a 0.1 nm inner skin within a check interval, the engine raises the skin to the reference's own r_list − cutoff
+    (0.2 nm) and drops the outer margin: every rebuild is then a search with r_list followed by a prune that keeps everything.  That prune is skipped —
+    the outer list is dealt to the groups directly and read wherever the inner list would be (engine.hip, inner_is_outer).  Same pairs, same
+    arithmetic: 120 steps with the adoption and without it (MOLLYHIP_ADOPT_OUTER=0) agree at the fp32 trajectory level."""
+    def run(adopt):
+        if adopt: monkeypatch.delenv("MOLLYHIP_ADOPT_OUTER", raising=False)
+        else: monkeypatch.setenv("MOLLYHIP_ADOPT_OUTER", "0")
+        case = G.case("rf", np.float32, bonded=True)
+        s = case.system(pkg, np.float32)
+        pkg.simulate(s, pkg.VelocityVerlet(dt=0.0005), 120)
+        return case, s, s.stats()
+    case, s1, st1 = run(True)
+    _, s0, st0 = run(False)
+    assert st1["n_adopted_outer_lists"] >= 2 and st0["n_adopted_outer_lists"] == 0, (st1, st0)
+    assert st1["n_group_split_passes"] > st0["n_group_split_passes"]          # the rebuild steps run as group-split passes too
+    d = np.array(s1.coords, dtype=np.float64) - np.array(s0.coords, dtype=np.float64); d -= np.round(d / case.box) * case.box
+    assert np.abs(d).max() < 2e-4, np.abs(d).max()                            # 120 steps of fp32 dynamics from different summation orders at the rebuild steps
+    assert np.abs(np.array(s1.velocities, dtype=np.float64) - np.array(s0.velocities, dtype=np.float64)).max() < 0.05
