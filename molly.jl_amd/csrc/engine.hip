@@ -959,6 +959,9 @@ template <class T> class Engine final : public EngineBase {
                     Z.n_blocks = n_blocks; Z.spread = std::max(1, n_blocks / GS + 5);
                     Z.pos = pos[cur].p; Z.lj = lj[cur].p; Z.tile_idx = inner_is_outer ? tile_idx.p : tile_idx_in.p; Z.tile_cnt = inner_is_outer ? tile_cnt.p : tile_cnt_in.p; Z.nbr = nbr_gs.p; Z.wave_rows = rows_gs.p; Z.blk_center = blk_center.p;
                     Z.frc = frc[cur].p; Z.parts = frc_parts.p; Z.part_stride = cap;
+                    Z.dbg = nullptr;
+                    static const int dbg_gs = env_int("MOLLYHIP_DBG_TIMES", 0);
+                    if (dbg_gs) { dbg_buf.reserve((size_t)n_blocks * GS * 4 * 8); MHIP_HIP(hipMemsetAsync(dbg_buf.p, 0, (size_t)n_blocks * GS * 4 * 8 * sizeof(unsigned long long), stream)); Z.dbg = dbg_buf.p; }
                     last_pass_tile = max_tile_in;
                     prof.begin(0, stream);
                     tr("k_forces_gs");
@@ -977,6 +980,12 @@ template <class T> class Engine final : public EngineBase {
                     prof.end(0, stream);
                     MHIP_HIP(hipGetLastError());
                     ++n_force_calls; ++n_gs_passes; gs_used = true;
+                    if (Z.dbg && (n_gs_passes % dbg_gs) == 0) {      // (experiment builds) the raw stamps of this pass → $MOLLYHIP_DBG_DUMP, for tools/gs_times.py
+                        std::vector<unsigned long long> h((size_t)n_blocks * GS * 4 * 8);
+                        MHIP_HIP(hipStreamSynchronize(stream));
+                        MHIP_HIP(hipMemcpy(h.data(), dbg_buf.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                        if (const char* path = std::getenv("MOLLYHIP_DBG_DUMP")) { if (FILE* f = std::fopen(path, "wb")) { std::fwrite(h.data(), sizeof(unsigned long long), h.size(), f); std::fclose(f); } }
+                    }
                     return;
                 }
             }

@@ -118,6 +118,14 @@ __device__ inline void forces_gs_body(const GsArgs& A, int wg, unsigned char* sm
     const int b = (bq + g * A.spread) % A.n_blocks;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int li = tid & (A.BI - 1), jw = tid >> A.BI_shift, JSW = A.JS >> A.lgGS, js = g * JSW + jw;
+    // timing experiment (-DMHIP_EXP=11): per wave — [0] shader clock at entry, [1] rows walked, [2] block | group << 20 | HW_ID << 32, [3] XCC_ID,
+    // [4..7] the 100 MHz wall clock at entry, behind the staging barrier, behind the row walk, at the end
+    [[maybe_unused]] auto stamp = [&](int k, unsigned long long v) {
+#if MHIP_EXP == 11
+        if (A.dbg && (tid & 63) == 0) A.dbg[((size_t)wg * (nthr >> 6) + (tid >> 6)) * 8 + k] = v;
+#endif
+    };
+    stamp(0, __builtin_readcyclecounter()); stamp(4, wall_clock64());
     const int tile_n = A.tile_cnt[b], qmax = (tile_n + A.GS - 1) >> A.lgGS;        // group-local slots 0 .. qmax − 1, sentinel qmax
     float4* l_pos = reinterpret_cast<float4*>(smem);
     float2* l_lj = reinterpret_cast<float2*>(l_pos + (A.Q_lds + 1));
@@ -149,6 +157,8 @@ __device__ inline void forces_gs_body(const GsArgs& A, int wg, unsigned char* sm
         }
     }
     __syncthreads();
+    stamp(5, wall_clock64()); stamp(1, (unsigned long long)rows);
+    stamp(2, (unsigned long long)b | ((unsigned long long)g << 20) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32)); stamp(3, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20));
     float fx = 0.f, fy = 0.f, fz = 0.f;
     const Pk2Consts K(A.I);
     const bool pk2_ok = Pk2Consts::usable(A.I);
@@ -193,6 +203,7 @@ __device__ inline void forces_gs_body(const GsArgs& A, int wg, unsigned char* sm
             fx -= fr * dx; fy -= fr * dy; fz -= fr * dz;
         }
     }
+    stamp(6, wall_clock64());
     // the group's waves through LDS, fixed order; the group's partial force of the block's atoms
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);
@@ -203,6 +214,7 @@ __device__ inline void forces_gs_body(const GsArgs& A, int wg, unsigned char* sm
         float4* dst = g == 0 ? A.frc : A.parts + (int64_t)(g - 1) * A.part_stride;
         dst[si] = make_float4(fx, fy, fz, 0.f);
     }
+    stamp(7, wall_clock64());
 }
 
 template <int COULM, bool MINIMG>

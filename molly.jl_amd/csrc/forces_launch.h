@@ -23,6 +23,7 @@ struct GsArgs {
     int64_t n_owned; int BI, BI_shift, JS, GS, lgGS, R_cap, T_cap, Q_lds, n_blocks, spread;
     const float4* pos; const float2* lj; const int32_t* tile_idx; const int32_t* tile_cnt; const uint2* nbr; const int32_t* wave_rows; const float4* blk_center;
     float4* frc; float4* parts; int64_t part_stride;                      // group 0 → frc, group g → parts + (g − 1)·part_stride
+    unsigned long long* dbg;                                              // builds with -DMHIP_EXP=11: [workgroup][wave][8] time stamps (engine: MOLLYHIP_DBG_TIMES, tools/gs_times.py)
 };
 size_t gs_lds_bytes(int q_lds, int BI, int JSW);
 void launch_regroup(const RegroupArgs& A, int n_blocks, hipStream_t stream);
