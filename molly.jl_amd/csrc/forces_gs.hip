@@ -225,13 +225,18 @@ __global__ void __launch_bounds__(256, 4) k_forces_gs(GsArgs A) {     // (four w
 
 // The pair pass, the charge spreading and the bonded terms of one MD step in ONE launch (cf. step_fused.h, which pairs the last two): none of
 // the three depends on another, all are 256-lane workgroups, and the pair workgroups — first in the grid, the longest — leave the
-// arithmetic units idle half of the time (latency of the row walk) while the spreading is bound by LDS atomics and latency.  The hardware
-// hands a compute unit's free slot to the next workgroup of the grid, so the short jobs fill in behind the pair groups as they finish.
+// arithmetic units idle half of the time (latency of the row walk) while the spreading is bound by LDS atomics and latency.  The short jobs
+// sit at the HEAD of the grid: every pair group is resident from the start anyway (3.9 per compute unit) and spends its first 4.8 µs staging its
+// tile quarter, so the spreading and the terms run through that phase instead of queueing behind the pair groups for a free slot.
 // Every role carves its LDS from the launch's dynamic pool (the spreading: its tables and whatever is left as the sub-mesh).
 template <int COULM, bool MINIMG, int ORDER>
-__global__ void __launch_bounds__(256, 4) k_pair_spread_bonded(GsArgs A, int n_pair, int64_t n_atoms, float* rgrid, PmeP<float> P, int n_spread, int lds_bytes, BondedArgs<float> B) {
+__global__ void __launch_bounds__(256, 4) k_pair_spread_bonded(GsArgs A, int n_pair, int64_t n_atoms, float* rgrid, PmeP<float> P, int n_spread, int lds_bytes, BondedArgs<float> B, int short_first) {
     extern __shared__ __align__(32) unsigned char smem[];
-    const int wg = (int)blockIdx.x;
+    int wg = (int)blockIdx.x;
+    if (short_first) {      // the short jobs at the head of the grid: they start with the pair groups and run through those groups' staging phase
+        const int n_short = (int)gridDim.x - n_pair;
+        wg = wg < n_short ? n_pair + wg : wg - n_short;
+    }
     if (wg < n_pair) { forces_gs_body<COULM, MINIMG>(A, wg, smem); return; }
     if (wg < n_pair + n_spread) { pme_spread_blocks<float, ORDER, 64, true>(wg - n_pair, n_spread, n_atoms, A.pos, rgrid, P, smem, lds_bytes); return; }
     double e = 0;
@@ -264,7 +269,8 @@ void launch_pair_spread_bonded(const GsArgs& A, int n_pair, int coulm, bool mini
     const dim3 grid((unsigned)(n_pair + n_spread + n_term_wg)), block(256);
     auto go = [&](auto kern) {
         if (lds_bytes > 64 * 1024) MHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, A, n_pair, n_atoms, rgrid, P, n_spread, (int)lds_bytes, B);
+        static const int short_first = [] { const char* v = std::getenv("MOLLYHIP_GS_SHORT_FIRST"); return v && *v ? std::atoi(v) : 1; }();      // (measured: 26.4 -> 25.8 us per launch, profiles/r04_force_ab.txt §16)
+        hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, A, n_pair, n_atoms, rgrid, P, n_spread, (int)lds_bytes, B, short_first);
     };
     auto by_order = [&](auto coul_tag, auto mi_tag) {
         constexpr int C = decltype(coul_tag)::value; constexpr bool M = decltype(mi_tag)::value;
