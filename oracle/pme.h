@@ -10,7 +10,8 @@
 //   recip_conv_inner!/recip_conv! :676-751
 //   interpolate_force_inner! :805-840
 //   ewald_pe_forces!      :873-929   (self and net-charge terms :917-927)
-// CubicBoundary only: recip_box = diag(1/Lx, 1/Ly, 1/Lz).  The two FFTs (plan_fft!, plan_bfft!: unnormalised forward
+// recip_box = invert_box_vectors(boundary) (spatial.jl:327-347): diag(1/Lx, 1/Ly, 1/Lz) for a CubicBoundary, the lower-triangular inverse of the basis for a
+// TriclinicBoundary; it enters the placement (:486), the wave vectors of the convolution (:688-694) and the force transform (:846-849).  The two FFTs (plan_fft!, plan_bfft!: unnormalised forward
 // e^{-2πi jk/n} / backward e^{+2πi jk/n}) are evaluated as separable direct DFTs with double-precision twiddles —
 // the meshes here are ~50³, and a direct sum needs no FFT library.
 // Threads (nthreads > 1, ewald.jl's n_threads > 1 methods): the B-splines and the force interpolation run over blocks of atoms
@@ -30,10 +31,22 @@ namespace orc_pme {
 template <class T> struct Pme {
     int order, n[3];
     T alpha, f_div_er, L[3];
+    T r[3][3];                       // recip_box, r[e][d] = recip_box[e+1][d+1]
     std::vector<T> bsm[3];
 
-    Pme(int order_, const int32_t* mesh, T alpha_, T ke, T eps_r, const T* box) : order(order_), alpha(alpha_), f_div_er(ke / eps_r) {
+    // box: side lengths (triclinic: v1.x, v2.y, v3.z — volume(boundary) is their product either way, spatial.jl:311-312); bv9 (nullable): the three basis
+    // vectors of a TriclinicBoundary, row-major
+    Pme(int order_, const int32_t* mesh, T alpha_, T ke, T eps_r, const T* box, const double* bv9 = nullptr) : order(order_), alpha(alpha_), f_div_er(ke / eps_r) {
         for (int d = 0; d < 3; ++d) { n[d] = mesh[d]; L[d] = box[d]; }
+        for (int e = 0; e < 3; ++e) for (int d = 0; d < 3; ++d) r[e][d] = T(0);
+        if (!bv9) { for (int d = 0; d < 3; ++d) r[d][d] = T(1) / L[d]; }            // :327-336
+        else {                                                                       // :338-347
+            T bv[3][3]; for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) bv[i][k] = T(bv9[3 * i + k]);
+            const T V = bv[0][0] * bv[1][1] * bv[2][2];
+            r[0][0] = (bv[1][1] * bv[2][2]) / V;
+            r[1][0] = (-bv[1][0] * bv[2][2]) / V; r[1][1] = (bv[0][0] * bv[2][2]) / V;
+            r[2][0] = (bv[1][0] * bv[2][1] - bv[1][1] * bv[2][0]) / V; r[2][1] = (-bv[0][0] * bv[2][1]) / V; r[2][2] = (bv[0][0] * bv[1][1]) / V;
+        }
         moduli();
     }
 
@@ -73,7 +86,7 @@ template <class T> struct Pme {
     // :484-493 and :518-556 for one atom; th/dth: [3][order]
     void place(const T* c, int* idx, T* th, T* dth) const {
         for (int d = 0; d < 3; ++d) {
-            T t = c[d] * (T(1) / L[d]);
+            T t = c[0] * r[0][d] + c[1] * r[1][d] + c[2] * r[2][d];      // sum(coords[i] .* recip_box[:, d]) (:486)
             t = (t - std::floor(t)) * T(n[d]);
             int ti = (int)std::floor(t);
             T dr = t - T(ti);
@@ -180,7 +193,7 @@ template <class T> struct Pme {
           for (int kx = (int)lo; kx < (int)hi; ++kx) for (int ky = 0; ky < ny; ++ky) for (int kz = 0; kz < nz; ++kz) {
             if (kx == 0 && ky == 0 && kz == 0) continue;
             T mx = T(kx) < maxk[0] ? T(kx) : T(kx - nx), my = T(ky) < maxk[1] ? T(ky) : T(ky - ny), mz = T(kz) < maxk[2] ? T(kz) : T(kz - nz);
-            T mhx = mx * (T(1) / L[0]), mhy = my * (T(1) / L[1]), mhz = mz * (T(1) / L[2]);
+            T mhx = mx * r[0][0], mhy = mx * r[1][0] + my * r[1][1], mhz = mx * r[2][0] + my * r[2][1] + mz * r[2][2];      // :688-694
             T bx = boxfactor * bsm[0][kx], by = bsm[1][ky], bz = bsm[2][kz];
             std::complex<T>& gv = grid[((size_t)kx * ny + ky) * nz + kz];
             T d1 = gv.real(), d2 = gv.imag();
@@ -217,9 +230,9 @@ template <class T> struct Pme {
                         }
                     }
                 }
-                fs[3 * i + 0] -= q[i] * (fx * T(nx) * (T(1) / L[0]));
-                fs[3 * i + 1] -= q[i] * (fy * T(ny) * (T(1) / L[1]));
-                fs[3 * i + 2] -= q[i] * (fz * T(nz) * (T(1) / L[2]));
+                fs[3 * i + 0] -= q[i] * (fx * T(nx) * r[0][0]);                                                          // :846-849
+                fs[3 * i + 1] -= q[i] * (fx * T(nx) * r[1][0] + fy * T(ny) * r[1][1]);
+                fs[3 * i + 2] -= q[i] * (fx * T(nx) * r[2][0] + fy * T(ny) * r[2][1] + fz * T(nz) * r[2][2]);
             }
           });
         }

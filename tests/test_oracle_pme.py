@@ -98,3 +98,42 @@ def test_specific_and_pme_virial_obey_the_scaling_identity():
     h = 1e-6
     assert np.trace(wp) == pytest.approx(-(e_pme(1 + h) - e_pme(1 - h)) / (2 * h), rel=1e-7)
     assert np.abs(wp - wp.T).max() < 1e-10 * np.abs(wp).max()
+
+
+def _charges_in_a_box(n=600, L=3.1, seed=11):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(0, L, (n, 3))
+    q = rng.uniform(-1, 1, n); q -= q.mean()
+    return x, q, L
+
+
+def _pme_case(x, q, L, basis=None, mesh=(32, 32, 32)):
+    from tests import systems as S
+    tri = None if basis is None else dict(basis=np.asarray(basis, dtype=np.float64), approx_images=False)
+    box = [L, L, L] if basis is None else list(np.diag(np.asarray(basis, dtype=np.float64)))
+    return S.Case(x, box, coul=dict(kind="ewald", rc=1.0, tol=5e-4), r_list=1.2, charge=q, sigma=np.zeros(len(x)), eps=np.zeros(len(x)), mass=np.ones(len(x)),
+                  pme=dict(order=5, mesh=mesh), triclinic=tri)
+
+
+def test_triclinic_reciprocal_space_zero_tilt_is_the_cubic_one_and_a_sheared_cell_of_the_same_lattice_agrees():
+    """PME on a TriclinicBoundary (recip_box = invert_box_vectors(boundary), spatial.jl:338-347, in ewald.jl:486, 688-694, 846-849).  No fixture of the
+    reference covers it (test/gradients.jl only differentiates it), so it is pinned by two properties: a basis without tilt reproduces the cubic
+    numbers bit for bit, and the cell (a, a + b, c) — another cell of the SAME lattice — gives the same reciprocal-space forces and energy up to
+    the discretisation error of its differently oriented mesh."""
+    x, q, L = _charges_in_a_box()
+    cubic = _pme_case(x, q, L).oracle(np.float64)
+    f0 = cubic.forces(None, pairwise=False, specific=False, general=True)
+    e0 = cubic.potential_energy(None, pairwise=False, general=True)
+    flat = _pme_case(x, q, L, basis=[[L, 0, 0], [0, L, 0], [0, 0, L]]).oracle(np.float64)
+    assert np.array_equal(flat.forces(None, pairwise=False, specific=False, general=True), f0)
+    assert flat.potential_energy(None, pairwise=False, general=True) == e0
+    # a sheared cell's mesh lines are longer: compared on a 64³ mesh, where the cubic cell's own result has settled to 1e-4 of the largest force
+    fine = _pme_case(x, q, L, mesh=(64, 64, 64)).oracle(np.float64)
+    f0 = fine.forces(None, pairwise=False, specific=False, general=True)
+    e0 = fine.potential_energy(None, pairwise=False, general=True)
+    for basis in ([[L, 0, 0], [L, L, 0], [0, 0, L]], [[L, 0, 0], [0, L, 0], [L, -L, L]], [[L, 0, 0], [-L, L, 0], [L, L, L]]):
+        sh = _pme_case(x, q, L, basis=basis, mesh=(64, 64, 64)).oracle(np.float64)
+        f1 = sh.forces(None, pairwise=False, specific=False, general=True)
+        e1 = sh.potential_energy(None, pairwise=False, general=True)
+        assert np.abs(f1 - f0).max() < 5e-5 * np.abs(f0).max(), (basis, np.abs(f1 - f0).max() / np.abs(f0).max())
+        assert abs(e1 - e0) < 0.1, (basis, e1 - e0)
