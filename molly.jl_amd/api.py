@@ -127,7 +127,7 @@ class PME:
         T = np.dtype(dtype).type
         self.dist_cutoff, self.error_tol, self.order, self.ϵr = float(dist_cutoff), float(error_tol), int(order), float(ϵr)
         self.α = float((T(1) / T(dist_cutoff)) * np.sqrt(-np.log(T(2) * T(error_tol))))
-        sides = boundary.side_lengths if isinstance(boundary, CubicBoundary) else tuple(boundary)
+        sides = boundary.side_lengths if isinstance(boundary, (CubicBoundary, TriclinicBoundary)) else tuple(boundary)      # box_sides(boundary), spatial.jl:357-360
         tol = T(error_tol)
         self.mesh_dims = tuple(max(int(np.ceil(T(2) * T(self.α) * T(L) / (T(3) * tol ** T(0.2)))), 6) for L in sides)   # pme_params
 
@@ -169,7 +169,7 @@ class CubicBoundary:
 
 class TriclinicBoundary:
     """TriclinicBoundary(v1, v2, v3; approx_images=true) (spatial.jl:131-220): v1 along x, v2 in the xy plane, v3.z > 0.  The engine
-    supports it on a single GPU without PME (include/mollyhip.h, mhip_set_triclinic)."""
+    supports it on a single GPU, PME included (reciprocal-space forces and energy; include/mollyhip.h, mhip_set_triclinic)."""
 
     def __init__(self, v1, v2, v3, approx_images=True):
         bv = np.array([v1, v2, v3], dtype=np.float64).reshape(3, 3)

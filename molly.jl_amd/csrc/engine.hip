@@ -1549,6 +1549,7 @@ template <class T> class Engine final : public EngineBase {
     void general_virial(double* out9) override {
         if (!state_set) throw ApiError{MHIP_ERR_STATE, "set_state must be called before general_virial"};
         if (!pme.on()) return;
+        if (tri_mode) throw ApiError{MHIP_ERR_UNSUPPORTED, "the reciprocal-space virial on a TriclinicBoundary is not implemented (forces and energy are)"};
         const double e = general_potential_energy();           // fills red_part with the 7 component-major runs (and Σq)
         (void)e;
         const int nb = pme.conv_blocks();
@@ -1566,29 +1567,31 @@ template <class T> class Engine final : public EngineBase {
         return read_sum(n_part);
     }
 
-    // TriclinicBoundary(v1, v2, v3; approx_images) (spatial.jl:131-220).  cfg.box must hold (v1.x, v2.y, v3.z).  Single domain, no PME,
+    // TriclinicBoundary(v1, v2, v3; approx_images) (spatial.jl:131-220).  cfg.box must hold (v1.x, v2.y, v3.z).  Single domain (PME: forces and energy, no reciprocal virial),
     // systems that fit one tile (every block sees every atom; all distances by the exact in-loop minimum image).
     void set_triclinic(const double* bv9, int32_t approx_images) override {
         if (!(bv9[0] > 0) || bv9[1] != 0 || bv9[2] != 0) throw ApiError{MHIP_ERR_INVALID, "first basis vector must be along the x-axis (no y or z component) and have a positive x component"};
         if (!(bv9[4] > 0) || bv9[5] != 0) throw ApiError{MHIP_ERR_INVALID, "second basis vector must be in the xy plane (no z component) and have a positive y component"};
         if (!(bv9[8] > 0)) throw ApiError{MHIP_ERR_INVALID, "third basis vector must have a positive z component"};
         for (int d = 0; d < 3; ++d) if (!cfg.periodic[d]) throw ApiError{MHIP_ERR_UNSUPPORTED, "TriclinicBoundary is periodic on all three axes"};
-        if (n_ghost > 0 || pme.on()) throw ApiError{MHIP_ERR_UNSUPPORTED, "TriclinicBoundary: single domain, no PME"};
+        if (n_ghost > 0) throw ApiError{MHIP_ERR_UNSUPPORTED, "TriclinicBoundary: single domain"};
         if (std::fabs(bv9[0] - cfg.box[0]) > 1e-12 * bv9[0] || std::fabs(bv9[4] - cfg.box[1]) > 1e-12 * bv9[4] || std::fabs(bv9[8] - cfg.box[2]) > 1e-12 * bv9[8])
             throw ApiError{MHIP_ERR_INVALID, "the context's box must be (v1.x, v2.y, v3.z) of the triclinic basis"};
         MHIP_HIP(hipStreamSynchronize(stream));
         std::memcpy(tri_bv, bv9, sizeof(tri_bv));
         tri_mode = approx_images ? 1 : 2;
         ljm = ljm_base;                          // the one-type LJ kernels are cubic-only
+        if (pme.on()) pme.setup(pme_order_, pme_mesh_, pme_alpha_, cfg.inter.coul_ke, pme_eps_r_, cfg.box, cfg.periodic, tri_bv);   // (PME set before the boundary: its recip_box again)
         setup_grid(); choose_blocking();
         stale = true; frc_valid = false; state_set = false;
     }
+    int32_t pme_order_ = 0, pme_mesh_[3] = {0, 0, 0}; double pme_alpha_ = 0, pme_eps_r_ = 1;      // (as last set: a TriclinicBoundary set afterwards rebuilds the reciprocal box)
     void set_pme(int32_t order, const int32_t* mesh, double alpha, double eps_r) override {
-        if (order && tri_mode) throw ApiError{MHIP_ERR_UNSUPPORTED, "PME on a TriclinicBoundary is outside the scope"};
         frc_run_total = false;
         MHIP_HIP(hipStreamSynchronize(stream));
         int32_t none[3] = {0, 0, 0};
-        pme.setup(order, order ? mesh : none, alpha, cfg.inter.coul_ke, eps_r, cfg.box, cfg.periodic);
+        pme_order_ = order; pme_alpha_ = alpha; pme_eps_r_ = eps_r; for (int d = 0; d < 3; ++d) pme_mesh_[d] = order ? mesh[d] : 0;
+        pme.setup(order, order ? mesh : none, alpha, cfg.inter.coul_ke, eps_r, cfg.box, cfg.periodic, tri_mode ? tri_bv : nullptr);
         frc_valid = false;
     }
     // ≙ AtomsCalculators.forces! of the general interaction (force.jl:792-795): forces added to / written into f_xyz

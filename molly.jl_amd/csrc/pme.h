@@ -22,6 +22,7 @@ template <class T> struct PmeP {
     int n[3];
     T invL[3], n_over_L[3];
     T f_div_er, factor, pi_V;        // ke/ϵr, π²/α², π·V
+    int tri; T r[3][3];              // TriclinicBoundary: recip_box = invert_box_vectors(boundary) (spatial.jl:338-347), r[e][d] = recip_box[e+1][d+1]; lower triangular
     int debug;                       // MOLLYHIP_PME_DEBUG: timing experiments only
 };
 
@@ -48,8 +49,10 @@ template <class T, int ORDER> __device__ inline void pme_bspline(T dr, T* b, T* 
     b[0] *= dv * (T(1) - dr);
 }
 // grid_placement_inner! (:484-493): first mesh index and fractional offset along one axis
-template <class T> __device__ inline void pme_place(T c, T invL, int n, int& idx, T& dr) {
-    T t = c * invL;
+template <class T> __device__ inline T pme_frac(const T* c, int d, const PmeP<T>& P) {      // sum(coords[i] .* recip_box[:, d]) (:486)
+    return P.tri ? c[0] * P.r[0][d] + c[1] * P.r[1][d] + c[2] * P.r[2][d] : c[d] * P.invL[d];
+}
+template <class T> __device__ inline void pme_place(T t, int n, int& idx, T& dr) {
     t = (t - M<T>::floor(t)) * T(n);
     const int ti = (int)M<T>::floor(t);
     dr = t - T(ti);
@@ -80,7 +83,7 @@ __device__ inline void pme_atom_tables(int64_t a0, int64_t n_atoms, const typena
             const T c[3] = {p.x, p.y, p.z};
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                pme_place<T>(c[d], P.invL[d], P.n[d], i0[d], dr);
+                pme_place<T>(pme_frac<T>(c, d, P), P.n[d], i0[d], dr);
                 pme_bspline<T, ORDER>(dr, th, dth);
 #pragma unroll
                 for (int k = 0; k < ORDER; ++k) { l_w[((d * ORDER + k) * (DERIV ? 2 : 1)) * PME_AB + t] = th[k]; if constexpr (DERIV) l_w[((d * ORDER + k) * 2 + 1) * PME_AB + t] = dth[k]; }
@@ -148,7 +151,7 @@ __device__ inline void pme_spread_blocks(int bid, int nblk, int64_t n_atoms, con
                 T th[ORDER], dth[ORDER], dr;
 #pragma unroll
                 for (int d = 0; d < 3; ++d) {
-                    pme_place<T>(c[d], P.invL[d], P.n[d], i0[d], dr);
+                    pme_place<T>(pme_frac<T>(c, d, P), P.n[d], i0[d], dr);
                     pme_bspline<T, ORDER>(dr, th, dth);
 #pragma unroll
                     for (int k = 0; k < ORDER; ++k) l_w[(d * ORDER + k) * PME_SB + tid] = th[k];
@@ -289,11 +292,17 @@ __device__ inline void pme_gather_blocks(int bid, int nblk, int64_t n_atoms, con
             }
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) { fx += __shfl_xor(fx, o, 64); fy += __shfl_xor(fy, o, 64); fz += __shfl_xor(fz, o, 64); }   // stays inside the 32-lane half
+            // mesh derivatives → Cartesian force per unit charge: (fx·nx, fy·ny, fz·nz) · recip_box (:846-849)
+            T sx = fx * P.n_over_L[0], sy = fy * P.n_over_L[1], sz = fz * P.n_over_L[2];
+            if (P.tri) {
+                const T gx = fx * T(P.n[0]), gy = fy * T(P.n[1]), gz = fz * T(P.n[2]);
+                sx = gx * P.r[0][0]; sy = gx * P.r[1][0] + gy * P.r[1][1]; sz = gx * P.r[2][0] + gy * P.r[2][1] + gz * P.r[2][2];
+            }
             if constexpr (STORE) {
-                if (sub == 0 && a0 + t < n_atoms) frc[a0 + t] = make4<T>(-(q * (fx * P.n_over_L[0])), -(q * (fy * P.n_over_L[1])), -(q * (fz * P.n_over_L[2])), T(0));
+                if (sub == 0 && a0 + t < n_atoms) frc[a0 + t] = make4<T>(-(q * sx), -(q * sy), -(q * sz), T(0));
             } else if (sub == 0 && q != T(0)) {
                 auto f = frc[a0 + t];
-                f.x -= q * (fx * P.n_over_L[0]); f.y -= q * (fy * P.n_over_L[1]); f.z -= q * (fz * P.n_over_L[2]);
+                f.x -= q * sx; f.y -= q * sy; f.z -= q * sz;
                 frc[a0 + t] = f;
             }
         }
@@ -469,10 +478,26 @@ __device__ inline void pme_dft_body(const DftArgs<T>& A, int bid, int n_blocks_p
             if (c < n_here) {
                 const int kx = k; const int64_t q = q0 + c; const int ky = (int)(q / nzh), kz = (int)(q - (int64_t)ky * nzh);
                 if (kx | ky | kz) {
-                    const T mhx = A.mh[0][kx], mhy = A.mh[1][ky], mhz = A.mh[2][kz];
+                    T mhx = A.mh[0][kx], mhy = A.mh[1][ky], mhz = A.mh[2][kz];
+                    if (A.P.tri) {      // m · recip_box (:688-694); mh[d] holds the signed integer frequency then
+                        const T mx = mhx, my = mhy, mz = mhz;
+                        mhx = mx * A.P.r[0][0]; mhy = mx * A.P.r[1][0] + my * A.P.r[1][1]; mhz = mx * A.P.r[2][0] + my * A.P.r[2][1] + mz * A.P.r[2][2];
+                    }
                     const T m2 = mhx * mhx + mhy * mhy + mhz * mhz;
-                    const T denom = m2 * (A.P.pi_V * A.bsm[0][kx]) * A.bsm[1][ky] * A.bsm[2][kz];
-                    const T eterm = A.P.f_div_er * M<T>::exp(-A.P.factor * m2) / denom;
+                    const T bprod = (A.P.pi_V * A.bsm[0][kx]) * A.bsm[1][ky] * A.bsm[2][kz];
+                    const T denom = m2 * bprod;
+                    T eterm = A.P.f_div_er * M<T>::exp(-A.P.factor * m2) / denom;
+                    if (A.P.tri && (2 * kx == nx || 2 * ky == ny || 2 * kz == nz)) {
+                        // The reference visits the full mesh and takes the real part of the backward transform.  The frequency of a Nyquist index keeps its
+                        // sign under the mirror k → −k (:685-693), so on a sheared cell |m|² — and the influence function — of k and of its mirror differ
+                        // there, the product mesh is not Hermitian, and its real part is the transform of the Hermitian part: S(k) · (eterm(k) + eterm(−k))/2.
+                        // The half spectrum carries that average (the energy's pair k, −k sums to the same).
+                        const int jx = kx ? nx - kx : 0, jy = ky ? ny - ky : 0, jz = kz ? nz - kz : 0;
+                        const T ux = A.mh[0][jx], uy = A.mh[1][jy], uz = A.mh[2][jz];
+                        const T vx = ux * A.P.r[0][0], vy = ux * A.P.r[1][0] + uy * A.P.r[1][1], vz = ux * A.P.r[2][0] + uy * A.P.r[2][1] + uz * A.P.r[2][2];
+                        const T n2 = vx * vx + vy * vy + vz * vz;
+                        eterm = T(0.5) * (eterm + A.P.f_div_er * M<T>::exp(-A.P.factor * n2) / (n2 * bprod));
+                    }
                     if constexpr (ENERGY) {
                         const bool twice = !(kz == 0 || 2 * kz == nz);           // stands for k and its mirror −k of the full mesh
                         const double Ek = (double)(eterm * (re * re + im * im)) * (twice ? 2.0 : 1.0);
@@ -572,7 +597,8 @@ template <class T> struct Pme {
         }
     }
 
-    void setup(int ord, const int32_t* mesh, double alpha, double ke, double eps_r, const double* box, const int* periodic) {
+    // bv9 (nullable): the basis vectors of a TriclinicBoundary, row-major; box = (v1.x, v2.y, v3.z) then (box_sides, spatial.jl:359: mesh sizes and volume come from it)
+    void setup(int ord, const int32_t* mesh, double alpha, double ke, double eps_r, const double* box, const int* periodic, const double* bv9 = nullptr) {
         release();
         if (ord == 0) return;
         if (ord != 4 && ord != 5 && ord != 6) throw ApiError{MHIP_ERR_UNSUPPORTED, "PME B-spline order must be 4, 5 or 6"};
@@ -591,6 +617,15 @@ template <class T> struct Pme {
         T V = T(1);
         for (int d = 0; d < 3; ++d) { P.n[d] = mesh[d]; P.invL[d] = T(1) / T(box[d]); P.n_over_L[d] = T(mesh[d]) * (T(1) / T(box[d])); V *= T(box[d]); }
         { const char* v = std::getenv("MOLLYHIP_PME_DEBUG"); P.debug = v && *v ? std::atoi(v) : 0; }
+        P.tri = bv9 ? 1 : 0;
+        for (int e = 0; e < 3; ++e) for (int d = 0; d < 3; ++d) P.r[e][d] = T(0);
+        if (bv9) {      // invert_box_vectors(::TriclinicBoundary), spatial.jl:338-347, in T
+            T bv[3][3]; for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) bv[i][k] = T(bv9[3 * i + k]);
+            const T vol = bv[0][0] * bv[1][1] * bv[2][2];
+            P.r[0][0] = (bv[1][1] * bv[2][2]) / vol;
+            P.r[1][0] = (-bv[1][0] * bv[2][2]) / vol; P.r[1][1] = (bv[0][0] * bv[2][2]) / vol;
+            P.r[2][0] = (bv[1][0] * bv[2][1] - bv[1][1] * bv[2][0]) / vol; P.r[2][1] = (-bv[0][0] * bv[2][1]) / vol; P.r[2][2] = (bv[0][0] * bv[1][1]) / vol;
+        } else for (int d = 0; d < 3; ++d) P.r[d][d] = P.invL[d];
         P.f_div_er = T(ke) / T(eps_r); P.factor = T(M_PI) * T(M_PI) / (a * a); P.pi_V = T(M_PI) * V;
         self_factor = -(double)P.f_div_er * (double)a / std::sqrt(M_PI);
         charge_factor = -(double)P.f_div_er * M_PI / (2.0 * (double)V * (double)a * (double)a);
@@ -603,7 +638,7 @@ template <class T> struct Pme {
             for (int k = 0; k < nd; ++k) {
                 const double ang = -2.0 * M_PI * k / nd;
                 w[k].x = (T)std::cos(ang); w[k].y = (T)std::sin(ang);
-                m[k] = (T(k) < maxk ? T(k) : T(k - nd)) * P.invL[d];
+                m[k] = (T(k) < maxk ? T(k) : T(k - nd)) * (bv9 ? T(1) : P.invL[d]);      // (triclinic: the signed integer frequency, the kernel multiplies by recip_box)
             }
             tw[d].set(w); mh[d].set(m); bsm[d].set(bm[d]);
         }

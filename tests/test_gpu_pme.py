@@ -172,3 +172,53 @@ def test_total_virial_and_pressure_6mrr_vs_oracle(pkg, dtype, rel):
     k = 0.5 * np.einsum("i,ia,ib->ab", case.mass, case.velocities, case.velocities)
     assert np.abs(p - (2 * k + w) / np.prod(case.box)).max() < rel * np.abs(p).max()
     assert pkg.scalar_pressure(s) == pytest.approx(np.trace(p) / 3, rel=rel)
+
+
+def _tri_pme_case(dtype, basis, mesh, n_side=9, stable=False):
+    """the charged fluid of the other tests in a sheared cell: atoms keep their places, the cell gets the tilt"""
+    case = S.charged_fluid(n_side, dict(kind="ewald", rc=0.9, tol=5e-4), dtype=dtype, pme=dict(order=5, mesh=mesh), r_list=1.0, with_exceptions=False, stable=stable)
+    L = float(case.box[0])
+    bv = np.array(basis, dtype=np.float64) * L
+    case.triclinic = dict(basis=bv.astype(dtype).astype(np.float64), approx_images=False)
+    case.box = np.diag(case.triclinic["basis"]).copy()
+    return case
+
+
+@pytest.mark.parametrize("dtype,basis,mesh", [
+    (np.float64, [[1, 0, 0], [0.3, 1, 0], [0.2, -0.25, 1]], (24, 24, 24)),        # even meshes: the Nyquist planes of a sheared cell (averaged influence function)
+    (np.float64, [[1, 0, 0], [0.45, 1, 0], [-0.3, 0.4, 1]], (21, 22, 25)),
+    (np.float32, [[1, 0, 0], [0.3, 1, 0], [0.2, -0.25, 1]], (24, 22, 26)),
+    (np.float64, [[1, 0, 0], [0, 1, 0], [0, 0, 1]], (24, 24, 24)),                # no tilt: the cubic numbers through the triclinic path
+])
+def test_triclinic_reciprocal_forces_and_energy_vs_oracle(pkg, dtype, basis, mesh):
+    """PME on a TriclinicBoundary (recip_box of spatial.jl:338-347 in the placement, the wave vectors and the force transform; ewald.jl:486, 688-694, 846-849).
+    The oracle visits the full mesh like the reference; the engine's half spectrum carries the mean of the influence function of k and −k where they
+    differ (Nyquist planes of a sheared cell)."""
+    case = _tri_pme_case(dtype, basis, mesh)
+    o = case.oracle(np.float64)
+    f_ref = o.forces(None, pairwise=False, specific=False, general=True)
+    e_ref = o.potential_energy(None, pairwise=False, general=True)
+    s = case.system(pkg, dtype)
+    f = pkg.forces(s, pairwise=False, specific=False).astype(np.float64)
+    e = pkg.potential_energy(s, pairwise=False, specific=False)
+    scale = np.linalg.norm(f_ref, axis=1).max()
+    rel_f, rel_e = (1e-10, 1e-11) if dtype == np.float64 else (2e-4, 2e-5)
+    assert np.linalg.norm(f - f_ref, axis=1).max() < rel_f * scale, np.linalg.norm(f - f_ref, axis=1).max() / scale
+    assert abs(e - e_ref) < rel_e * abs(e_ref)
+
+
+def test_triclinic_ewald_total_forces_and_short_run_vs_oracle(pkg):
+    """direct space (exact minimum image on the sheared cell) + reciprocal space together, and 20 velocity-Verlet steps of it"""
+    case = _tri_pme_case(np.float64, [[1, 0, 0], [0.3, 1, 0], [0.2, -0.25, 1]], (24, 24, 24), stable=True)
+    o = case.oracle(np.float64)
+    nl = o.neighbors("brute")
+    f_ref = o.forces(nl, pairwise=True, specific=False, general=True)
+    s = case.system(pkg, np.float64)
+    f = pkg.forces(s)
+    assert np.linalg.norm(f - f_ref, axis=1).max() < 1e-9 * np.linalg.norm(f_ref, axis=1).max()
+    o.vv_run(20, 0.0005, remove_cm_every=1, general=True)
+    pkg.simulate(s, pkg.VelocityVerlet(dt=0.0005), 20)
+    bv = case.triclinic["basis"]
+    d = np.asarray(s.coords, dtype=np.float64) - o.coords
+    d -= np.round(d @ np.linalg.inv(bv)) @ bv                                   # (the same point of the lattice, whichever image each side stores)
+    assert np.abs(d).max() < 1e-8, np.abs(d).max()
