@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "physics.h"
+#include "pme_fft.h"
 
 namespace mhip {
 
@@ -422,10 +423,52 @@ __global__ void __launch_bounds__(PME_THREADS) k_pme_z_c2r(DftArgs<T> A) {
     pme_z_c2r_body<T>(A, (int)blockIdx.x, pme_smem);
 }
 
+// recip_conv_inner! (ewald.jl:678-723) for one wave vector (kx, ky, kz) ≠ 0 of the half spectrum holding S = (re, im): the influence function, and (ENERGY) its
+// share of Σ eterm·|S|² and of the six components of the reciprocal virial.  mh[d][k]: signed frequency / L_d (triclinic: the signed integer frequency).
+template <class T, bool ENERGY>
+__device__ inline T pme_influence(const PmeP<T>& P, const T* const* mh, const T* const* bsm, int kx, int ky, int kz, T re, T im, double& e_loc, double* v_loc) {
+    const int nx = P.n[0], ny = P.n[1], nz = P.n[2];
+    T mhx = mh[0][kx], mhy = mh[1][ky], mhz = mh[2][kz];
+    if (P.tri) {      // m · recip_box (:688-694)
+        const T mx = mhx, my = mhy, mz = mhz;
+        mhx = mx * P.r[0][0]; mhy = mx * P.r[1][0] + my * P.r[1][1]; mhz = mx * P.r[2][0] + my * P.r[2][1] + mz * P.r[2][2];
+    }
+    const T m2 = mhx * mhx + mhy * mhy + mhz * mhz;
+    const T bprod = (P.pi_V * bsm[0][kx]) * bsm[1][ky] * bsm[2][kz];
+    const T denom = m2 * bprod;
+    T eterm = P.f_div_er * M<T>::exp(-P.factor * m2) / denom;
+    if (P.tri && (2 * kx == nx || 2 * ky == ny || 2 * kz == nz)) {
+        // The reference visits the full mesh and takes the real part of the backward transform.  The frequency of a Nyquist index keeps its
+        // sign under the mirror k → −k (:685-693), so on a sheared cell |m|² — and the influence function — of k and of its mirror differ
+        // there, the product mesh is not Hermitian, and its real part is the transform of the Hermitian part: S(k) · (eterm(k) + eterm(−k))/2.
+        // The half spectrum carries that average (the energy's pair k, −k sums to the same).
+        const int jx = kx ? nx - kx : 0, jy = ky ? ny - ky : 0, jz = kz ? nz - kz : 0;
+        const T ux = mh[0][jx], uy = mh[1][jy], uz = mh[2][jz];
+        const T vx = ux * P.r[0][0], vy = ux * P.r[1][0] + uy * P.r[1][1], vz = ux * P.r[2][0] + uy * P.r[2][1] + uz * P.r[2][2];
+        const T n2 = vx * vx + vy * vy + vz * vz;
+        eterm = T(0.5) * (eterm + P.f_div_er * M<T>::exp(-P.factor * n2) / (n2 * bprod));
+    }
+    if constexpr (ENERGY) {
+        const bool twice = !(kz == 0 || 2 * kz == nz);           // stands for k and its mirror −k of the full mesh
+        const double Ek = (double)(eterm * (re * re + im * im)) * (twice ? 2.0 : 1.0);
+        e_loc += Ek;
+        // V·P_k = E_k [I − 2(1 + factor·m²)(m ⊗ m)/m²]  (recip_conv_inner! :701-723), six independent components.
+        // The reference visits k and −k separately and an even mesh's Nyquist index keeps its sign of m under the mirror
+        // (:685-693), so there the mixed term of a Nyquist axis and a regular one cancels between the two.
+        const double coeff = 2.0 * (1.0 + (double)P.factor * (double)m2) / (double)m2;
+        const bool nqx = twice && 2 * kx == nx, nqy = twice && 2 * ky == ny;
+        v_loc[0] += Ek * (1.0 - coeff * mhx * mhx); v_loc[1] += Ek * (1.0 - coeff * mhy * mhy); v_loc[2] += Ek * (1.0 - coeff * mhz * mhz);
+        if (nqx == nqy) v_loc[3] -= Ek * coeff * mhx * mhy;
+        if (!nqx) v_loc[4] -= Ek * coeff * mhx * mhz;
+        if (!nqy) v_loc[5] -= Ek * coeff * mhy * mhz;
+    }
+    return eterm;
+}
+
 template <class T, bool CONV, bool ENERGY>
 __device__ inline void pme_dft_body(const DftArgs<T>& A, int bid, int n_blocks_pass, unsigned char* pme_smem) {
     using T2 = typename Vec<T>::T2;
-    const int n = A.P.n[A.axis], nx = A.P.n[0], ny = A.P.n[1], nz = A.P.n[2], nzh = A.nzh, C = A.C;
+    const int n = A.P.n[A.axis], nx = A.P.n[0], ny = A.P.n[1], nzh = A.nzh, C = A.C;
     T2* l_tw = reinterpret_cast<T2*>(pme_smem);
     T2* l_a = l_tw + n;
     [[maybe_unused]] T2* l_b = l_a + n * C;
@@ -478,40 +521,7 @@ __device__ inline void pme_dft_body(const DftArgs<T>& A, int bid, int n_blocks_p
             if (c < n_here) {
                 const int kx = k; const int64_t q = q0 + c; const int ky = (int)(q / nzh), kz = (int)(q - (int64_t)ky * nzh);
                 if (kx | ky | kz) {
-                    T mhx = A.mh[0][kx], mhy = A.mh[1][ky], mhz = A.mh[2][kz];
-                    if (A.P.tri) {      // m · recip_box (:688-694); mh[d] holds the signed integer frequency then
-                        const T mx = mhx, my = mhy, mz = mhz;
-                        mhx = mx * A.P.r[0][0]; mhy = mx * A.P.r[1][0] + my * A.P.r[1][1]; mhz = mx * A.P.r[2][0] + my * A.P.r[2][1] + mz * A.P.r[2][2];
-                    }
-                    const T m2 = mhx * mhx + mhy * mhy + mhz * mhz;
-                    const T bprod = (A.P.pi_V * A.bsm[0][kx]) * A.bsm[1][ky] * A.bsm[2][kz];
-                    const T denom = m2 * bprod;
-                    T eterm = A.P.f_div_er * M<T>::exp(-A.P.factor * m2) / denom;
-                    if (A.P.tri && (2 * kx == nx || 2 * ky == ny || 2 * kz == nz)) {
-                        // The reference visits the full mesh and takes the real part of the backward transform.  The frequency of a Nyquist index keeps its
-                        // sign under the mirror k → −k (:685-693), so on a sheared cell |m|² — and the influence function — of k and of its mirror differ
-                        // there, the product mesh is not Hermitian, and its real part is the transform of the Hermitian part: S(k) · (eterm(k) + eterm(−k))/2.
-                        // The half spectrum carries that average (the energy's pair k, −k sums to the same).
-                        const int jx = kx ? nx - kx : 0, jy = ky ? ny - ky : 0, jz = kz ? nz - kz : 0;
-                        const T ux = A.mh[0][jx], uy = A.mh[1][jy], uz = A.mh[2][jz];
-                        const T vx = ux * A.P.r[0][0], vy = ux * A.P.r[1][0] + uy * A.P.r[1][1], vz = ux * A.P.r[2][0] + uy * A.P.r[2][1] + uz * A.P.r[2][2];
-                        const T n2 = vx * vx + vy * vy + vz * vz;
-                        eterm = T(0.5) * (eterm + A.P.f_div_er * M<T>::exp(-A.P.factor * n2) / (n2 * bprod));
-                    }
-                    if constexpr (ENERGY) {
-                        const bool twice = !(kz == 0 || 2 * kz == nz);           // stands for k and its mirror −k of the full mesh
-                        const double Ek = (double)(eterm * (re * re + im * im)) * (twice ? 2.0 : 1.0);
-                        e_loc += Ek;
-                        // V·P_k = E_k [I − 2(1 + factor·m²)(m ⊗ m)/m²]  (recip_conv_inner! :701-723), six independent components.
-                        // The reference visits k and −k separately and an even mesh's Nyquist index keeps its sign of m under the mirror
-                        // (:685-693), so there the mixed term of a Nyquist axis and a regular one cancels between the two.
-                        const double coeff = 2.0 * (1.0 + (double)A.P.factor * (double)m2) / (double)m2;
-                        const bool nqx = twice && 2 * kx == nx, nqy = twice && 2 * ky == ny;
-                        v_loc[0] += Ek * (1.0 - coeff * mhx * mhx); v_loc[1] += Ek * (1.0 - coeff * mhy * mhy); v_loc[2] += Ek * (1.0 - coeff * mhz * mhz);
-                        if (nqx == nqy) v_loc[3] -= Ek * coeff * mhx * mhy;
-                        if (!nqx) v_loc[4] -= Ek * coeff * mhx * mhz;
-                        if (!nqy) v_loc[5] -= Ek * coeff * mhy * mhz;
-                    }
+                    const T eterm = pme_influence<T, ENERGY>(A.P, A.mh, A.bsm, kx, ky, kz, re, im, e_loc, v_loc);
                     v.x = re * eterm; v.y = im * eterm;
                 }
                 // k = 0: the reference leaves the DC term of the charge grid untouched (:681-683); it only adds a constant to the
@@ -549,6 +559,37 @@ __global__ void __launch_bounds__(PME_THREADS) k_pme_dft(DftArgs<T> A) {
     pme_dft_body<T, CONV, ENERGY>(A, (int)blockIdx.x, (int)gridDim.x, pme_smem);
 }
 
+// the influence function over the half spectrum as a pass of its own (meshes whose transforms run in the FFT library, pme_fft.h): S(k) *= eterm(k), and
+// (ENERGY) the per-block sums of the energy and the virial in the layout of k_pme_dft's
+template <class T, bool ENERGY>
+__global__ void __launch_bounds__(PME_THREADS) k_pme_conv(DftArgs<T> A) {
+    using T2 = typename Vec<T>::T2;
+    const int nx = A.P.n[0], ny = A.P.n[1], nzh = A.nzh, tid = threadIdx.x;
+    const int64_t n = (int64_t)nx * ny * nzh;
+    [[maybe_unused]] double e_loc = 0, v_loc[6] = {0, 0, 0, 0, 0, 0};
+    for (int64_t e = blockIdx.x * (int64_t)PME_THREADS + tid; e < n; e += (int64_t)gridDim.x * PME_THREADS) {
+        const int kz = (int)(e % nzh), ky = (int)((e / nzh) % ny), kx = (int)(e / ((int64_t)nzh * ny));
+        T2 v = A.grid[e];
+        if (kx | ky | kz) {
+            const T eterm = pme_influence<T, ENERGY>(A.P, A.mh, A.bsm, kx, ky, kz, v.x, v.y, e_loc, v_loc);
+            v.x *= eterm; v.y *= eterm;
+        } else { v.x = T(0); v.y = T(0); }      // (k = 0 zeroed: see k_pme_dft)
+        A.grid[e] = v;
+    }
+    if constexpr (ENERGY) {
+        __shared__ double sh_e[PME_THREADS / 64];
+        for (int c = 0; c < 7; ++c) {
+            double val = c == 0 ? e_loc : v_loc[c - 1];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) val += __shfl_xor(val, o, 64);
+            if ((tid & 63) == 0) sh_e[tid >> 6] = val;
+            __syncthreads();
+            if (tid == 0) { double s = 0; for (int w = 0; w < PME_THREADS / 64; ++w) s += sh_e[w]; A.e_part[(int64_t)c * gridDim.x + blockIdx.x] = s; }
+            __syncthreads();
+        }
+    }
+}
+
 template <class U> struct PBuf {
     U* p = nullptr; size_t n = 0;
     void set(const std::vector<U>& h) { release(); n = h.size(); if (n) { MHIP_HIP(hipMalloc((void**)&p, n * sizeof(U))); MHIP_HIP(hipMemcpy(p, h.data(), n * sizeof(U), hipMemcpyHostToDevice)); } }
@@ -564,10 +605,11 @@ template <class T> struct Pme {
     PBuf<T2> grid, tw[3];
     PBuf<T> mh[3], bsm[3], rgrid, phi; // rgrid: real charge mesh; phi: real potential mesh
     int nzh = 0;                       // half-spectrum length along z
+    bool fft = false; FftPlan3d plan;  // transforms by the FFT library: an axis longer than 512 points (MOLLYHIP_PME_FFT=1: always, =0: never)
     double self_factor = 0, charge_factor = 0;   // E_self = −f/ϵr·α/√π·Σq²  and  E_charge = −f/ϵr·π/(2Vα²)·(Σq)²   (:917-927)
 
     bool on() const { return order > 0; }
-    void release() { grid.release(); rgrid.release(); phi.release(); for (int d = 0; d < 3; ++d) { tw[d].release(); mh[d].release(); bsm[d].release(); } order = 0; }
+    void release() { plan.destroy(); fft = false; grid.release(); rgrid.release(); phi.release(); for (int d = 0; d < 3; ++d) { tw[d].release(); mh[d].release(); bsm[d].release(); } order = 0; }
 
     // pme_bspline_moduli (:311-358), in T like the reference
     static void moduli(int ord, const int* n, std::vector<T>* out) {
@@ -609,9 +651,14 @@ template <class T> struct Pme {
             // factors like 23 and 17): O(n) work per mesh point and pass.  That is the right trade for 6mrr-class meshes (46x46x51: each
             // pass sits at the launch floor) and the wrong one for the meshes of 100 nm boxes; past 512 points per axis the call is
             // refused instead of quietly taking tens of milliseconds per step (an FFT library path is not linked).
-            if (mesh[d] < ord || mesh[d] > 512) throw ApiError{MHIP_ERR_UNSUPPORTED, "PME mesh size out of range: B-spline order .. 512 points per axis (direct-DFT transforms, sized for protein-box meshes)"};
+            if (mesh[d] < ord || mesh[d] > 4096) throw ApiError{MHIP_ERR_UNSUPPORTED, "PME mesh size out of range: B-spline order .. 4096 points per axis"};
         }
-        if ((int64_t)mesh[0] * mesh[1] * mesh[2] > ((int64_t)1 << 28)) throw ApiError{MHIP_ERR_CAPACITY, "PME mesh too large"};
+        // Past 512 points on an axis the passes above would quietly take tens of milliseconds; such meshes (100 nm boxes) go through the FFT library instead
+        // (pme_fft.h: hipFFT real ↔ complex 3-D plans on the same half spectrum), with the influence function as a pass of its own.
+        static const int fft_env = [] { const char* v = std::getenv("MOLLYHIP_PME_FFT"); return v && *v ? std::atoi(v) : -1; }();
+        const bool long_axis = mesh[0] > 512 || mesh[1] > 512 || mesh[2] > 512;
+        if (long_axis && fft_env == 0) throw ApiError{MHIP_ERR_UNSUPPORTED, "PME mesh axis beyond 512 points needs the FFT path (MOLLYHIP_PME_FFT=0 turned it off)"};
+        if ((int64_t)mesh[0] * mesh[1] * mesh[2] > ((int64_t)1 << 30)) throw ApiError{MHIP_ERR_CAPACITY, "PME mesh too large"};
         order = ord;
         const T a = T(alpha);
         T V = T(1);
@@ -647,6 +694,8 @@ template <class T> struct Pme {
         rgrid.alloc((size_t)P.n[0] * P.n[1] * P.n[2]);
         MHIP_HIP(hipMemset(rgrid.p, 0, rgrid.n * sizeof(T)));     // from here on k_pme_z_r2c leaves the meshes zeroed behind it
         phi.alloc((size_t)P.n[0] * P.n[1] * P.n[2]);
+        fft = long_axis || fft_env == 1;
+        if (fft) plan.create(P.n[0], P.n[1], P.n[2], sizeof(T) == 8);
     }
 
     DftArgs<T> dft_args(int axis, int sign, int C, double* e_part) const {
@@ -659,7 +708,7 @@ template <class T> struct Pme {
     int c_r2c() const { return std::max(1, PME_THREADS / nzh); }
     int c_c2r() const { return std::max(1, PME_THREADS / P.n[2]); }
     int c_xy(int axis) const { return std::max(1, PME_THREADS / P.n[axis]); }
-    int conv_blocks() const { return (int)cdiv((int64_t)P.n[1] * nzh, (int64_t)c_xy(0)); }
+    int conv_blocks() const { return fft ? (int)std::min<int64_t>(cdiv((int64_t)P.n[0] * P.n[1] * nzh, (int64_t)PME_THREADS), 2048) : (int)cdiv((int64_t)P.n[1] * nzh, (int64_t)c_xy(0)); }
 
     // PME_AB atoms per 256-thread block and round; at most 2048 blocks (each then loops over its atom batches)
     static unsigned atom_blocks(int64_t n) { return (unsigned)std::min<int64_t>(cdiv(n, (int64_t)PME_AB), 2048); }
@@ -699,17 +748,31 @@ template <class T> struct Pme {
         hipLaunchKernelGGL(k_pme_z_c2r<T>, dim3((unsigned)cdiv((int64_t)P.n[0] * P.n[1], (int64_t)C)), dim3(PME_THREADS), lds, s, dft_args(2, +1, C, nullptr));
     }
 
+    // charge mesh → (energy sums, potential mesh): the direct-DFT passes, or the FFT library around the influence-function pass
+    void mesh_to_potential(hipStream_t s, double* e_part, bool want_phi) {
+        if (fft) {
+            plan.forward(s, rgrid.p, grid.p);
+            MHIP_HIP(hipMemsetAsync(rgrid.p, 0, rgrid.n * sizeof(T), s));      // (the passes leave the charge mesh zeroed for the next spreading; so does this path)
+            DftArgs<T> A = dft_args(0, -1, 1, e_part);
+            const int nb = conv_blocks();
+            if (e_part) hipLaunchKernelGGL((k_pme_conv<T, true>), dim3(nb), dim3(PME_THREADS), 0, s, A);
+            else hipLaunchKernelGGL((k_pme_conv<T, false>), dim3(nb), dim3(PME_THREADS), 0, s, A);
+            if (want_phi) plan.backward(s, grid.p, phi.p);
+            return;
+        }
+        z_r2c(s);
+        dft_xy<false, false>(s, 1, -1, nullptr);
+        if (e_part) dft_xy<true, true>(s, 0, -1, e_part); else dft_xy<true, false>(s, 0, -1, nullptr);
+        if (want_phi) { dft_xy<false, false>(s, 1, +1, nullptr); z_c2r(s); }
+    }
+
     // ewald_pe_forces! (:873-929) on the sorted arrays: frc (nullable) gets the reciprocal-space forces ADDED; e_part (nullable)
     // receives 7·conv_blocks() partial sums, component-major: Σ eterm·|S|² and the six components of the reciprocal virial (the caller halves
     // them and adds the self / net-charge terms).
     void run(hipStream_t s, int64_t n_atoms, const T4* pos, T4* frc, double* e_part) {
         if (order == 4) spread_t<4>(s, n_atoms, pos); else if (order == 5) spread_t<5>(s, n_atoms, pos); else spread_t<6>(s, n_atoms, pos);
-        z_r2c(s);
-        dft_xy<false, false>(s, 1, -1, nullptr);
-        if (e_part) dft_xy<true, true>(s, 0, -1, e_part); else dft_xy<true, false>(s, 0, -1, nullptr);
+        mesh_to_potential(s, e_part, frc != nullptr);
         if (frc) {
-            dft_xy<false, false>(s, 1, +1, nullptr);
-            z_c2r(s);
             if (order == 4) gather_t<4>(s, n_atoms, pos, frc); else if (order == 5) gather_t<5>(s, n_atoms, pos, frc); else gather_t<6>(s, n_atoms, pos, frc);
         }
         MHIP_HIP(hipGetLastError());

@@ -47,11 +47,7 @@ inline void launch_pme_bonded_fused(hipStream_t s, Pme<T>& pme, Bonded<T>& bonde
         else hipLaunchKernelGGL((k_spread_bonded<T, ORDER, 64>), dim3(n_spread + n_term_wg), dim3(256), 0, s, n_owned, pos, pme.rgrid.p, pme.P, n_spread, B);
     };
     if (!spread_done) { if (pme.order == 4) spread(std::integral_constant<int, 4>{}); else if (pme.order == 5) spread(std::integral_constant<int, 5>{}); else spread(std::integral_constant<int, 6>{}); }
-    pme.z_r2c(s);
-    pme.template dft_xy<false, false>(s, 1, -1, nullptr);
-    pme.template dft_xy<true, false>(s, 0, -1, nullptr);
-    pme.template dft_xy<false, false>(s, 1, +1, nullptr);
-    pme.z_c2r(s);
+    pme.mesh_to_potential(s, nullptr, true);
     const int n_gather = (int)Pme<T>::atom_blocks(n_owned);
     const int n_collect = (int)cdiv(n_owned * COLLECT_LANES, (int64_t)256);
     auto gather = [&](auto order_tag) {

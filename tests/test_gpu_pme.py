@@ -222,3 +222,31 @@ def test_triclinic_ewald_total_forces_and_short_run_vs_oracle(pkg):
     d = np.asarray(s.coords, dtype=np.float64) - o.coords
     d -= np.round(d @ np.linalg.inv(bv)) @ bv                                   # (the same point of the lattice, whichever image each side stores)
     assert np.abs(d).max() < 1e-8, np.abs(d).max()
+
+
+@pytest.mark.parametrize("dtype,mesh,force_fft", [(np.float64, (600, 6, 7), False), (np.float32, (8, 520, 6), False), (np.float64, (21, 22, 25), True), (np.float32, None, True)])
+def test_reciprocal_space_through_the_fft_library_vs_oracle(pkg, monkeypatch, dtype, mesh, force_fft):
+    """Meshes with more than 512 points on an axis (the direct-DFT passes stop there) take hipFFT's real ↔ complex 3-D transforms with the influence function
+    as a pass of its own (csrc/pme_fft.h, k_pme_conv; plan_fft! / plan_bfft!, ewald.jl:405-411).  Checked on long thin meshes the oracle's direct sums
+    still finish on, and — forced with MOLLYHIP_PME_FFT=1 — on the meshes of the other tests."""
+    if force_fft: monkeypatch.setenv("MOLLYHIP_PME_FFT", "1")
+    else: monkeypatch.delenv("MOLLYHIP_PME_FFT", raising=False)
+    pme = dict(order=5, error_tol=5e-4)
+    if mesh: pme["mesh"] = mesh
+    case = S.charged_fluid(9, dict(kind="ewald", rc=0.9, tol=5e-4), dtype=dtype, pme=pme, r_list=1.0, with_exceptions=False)
+    o = case.oracle(np.float64)
+    f_ref = o.forces(None, pairwise=False, specific=False, general=True, nthreads=8)
+    e_ref = o.potential_energy(None, pairwise=False, general=True)
+    s = case.system(pkg, dtype)
+    f = pkg.forces(s, pairwise=False, specific=False).astype(np.float64)
+    e = pkg.potential_energy(s, pairwise=False, specific=False)
+    w = pkg.virial(s, pairwise=False, specific=False)
+    scale = np.linalg.norm(f_ref, axis=1).max()
+    rel_f, rel_e = (1e-10, 1e-11) if dtype == np.float64 else (2e-4, 2e-5)
+    assert np.linalg.norm(f - f_ref, axis=1).max() < rel_f * scale, np.linalg.norm(f - f_ref, axis=1).max() / scale
+    assert abs(e - e_ref) < rel_e * abs(e_ref)
+    w_ref = o.virial(None, pairwise=False, specific=False, general=True)
+    assert np.abs(w - w_ref).max() < (1e-9 if dtype == np.float64 else 2e-4) * np.abs(w_ref).max()
+    # a second call: the charge mesh was left zeroed
+    f2 = pkg.forces(s, pairwise=False, specific=False).astype(np.float64)
+    assert np.linalg.norm(f2 - f_ref, axis=1).max() < rel_f * scale
