@@ -207,7 +207,7 @@ int32_t mhip_general_forces(mhip_ctx* ctx, int32_t accumulate, void* f_xyz, int3
 /* TriclinicBoundary(v1, v2, v3; approx_images) (spatial.jl:131-220; minimum image :528-551, wrap_coords :588-602): basis9 = the three
  * basis vectors row by row; v1 along x, v2 in the xy plane, v3.z > 0 (MHIP_ERR_INVALID otherwise, as the constructor's
  * ArgumentError).  The context must have been created with box = (v1.x, v2.y, v3.z), all axes periodic.  Call before mhip_set_state.
- * Single domain (MHIP_ERR_UNSUPPORTED otherwise); PME works on it (recip_box = invert_box_vectors, spatial.jl:338-347), its reciprocal virial does not.  The neighbour search runs on a cell grid in fractional coordinates scaled
+ * Single domain (MHIP_ERR_UNSUPPORTED otherwise); PME works on it (recip_box = invert_box_vectors, spatial.jl:338-347).  The neighbour search runs on a cell grid in fractional coordinates scaled
  * by the cell's perpendicular heights; a box too small for any grid (fewer than 6 cells of r_list / 2 on every axis) is handled as one
  * cell — every distance by the exact in-loop minimum image — and is then limited to 32 759 atoms.
  * approx_images != 0: the three-floor formula; 0: the search over the 27 neighbouring images. */

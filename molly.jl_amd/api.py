@@ -169,7 +169,7 @@ class CubicBoundary:
 
 class TriclinicBoundary:
     """TriclinicBoundary(v1, v2, v3; approx_images=true) (spatial.jl:131-220): v1 along x, v2 in the xy plane, v3.z > 0.  The engine
-    supports it on a single GPU, PME included (reciprocal-space forces and energy; include/mollyhip.h, mhip_set_triclinic)."""
+    supports it on a single GPU, PME included (include/mollyhip.h, mhip_set_triclinic)."""
 
     def __init__(self, v1, v2, v3, approx_images=True):
         bv = np.array([v1, v2, v3], dtype=np.float64).reshape(3, 3)

@@ -1549,7 +1549,6 @@ template <class T> class Engine final : public EngineBase {
     void general_virial(double* out9) override {
         if (!state_set) throw ApiError{MHIP_ERR_STATE, "set_state must be called before general_virial"};
         if (!pme.on()) return;
-        if (tri_mode) throw ApiError{MHIP_ERR_UNSUPPORTED, "the reciprocal-space virial on a TriclinicBoundary is not implemented (forces and energy are)"};
         const double e = general_potential_energy();           // fills red_part with the 7 component-major runs (and Σq)
         (void)e;
         const int nb = pme.conv_blocks();
@@ -1567,7 +1566,7 @@ template <class T> class Engine final : public EngineBase {
         return read_sum(n_part);
     }
 
-    // TriclinicBoundary(v1, v2, v3; approx_images) (spatial.jl:131-220).  cfg.box must hold (v1.x, v2.y, v3.z).  Single domain (PME: forces and energy, no reciprocal virial),
+    // TriclinicBoundary(v1, v2, v3; approx_images) (spatial.jl:131-220).  cfg.box must hold (v1.x, v2.y, v3.z).  Single domain,
     // systems that fit one tile (every block sees every atom; all distances by the exact in-loop minimum image).
     void set_triclinic(const double* bv9, int32_t approx_images) override {
         if (!(bv9[0] > 0) || bv9[1] != 0 || bv9[2] != 0) throw ApiError{MHIP_ERR_INVALID, "first basis vector must be along the x-axis (no y or z component) and have a positive x component"};

@@ -437,6 +437,8 @@ __device__ inline T pme_influence(const PmeP<T>& P, const T* const* mh, const T*
     const T bprod = (P.pi_V * bsm[0][kx]) * bsm[1][ky] * bsm[2][kz];
     const T denom = m2 * bprod;
     T eterm = P.f_div_er * M<T>::exp(-P.factor * m2) / denom;
+    [[maybe_unused]] const T eterm_own = eterm;
+    [[maybe_unused]] T wx = -mhx, wy = -mhy, wz = -mhz, eterm_mir = eterm;      // wave vector and influence function of the mirror −k (differ from −m, eterm on Nyquist planes of a sheared cell)
     if (P.tri && (2 * kx == nx || 2 * ky == ny || 2 * kz == nz)) {
         // The reference visits the full mesh and takes the real part of the backward transform.  The frequency of a Nyquist index keeps its
         // sign under the mirror k → −k (:685-693), so on a sheared cell |m|² — and the influence function — of k and of its mirror differ
@@ -446,10 +448,24 @@ __device__ inline T pme_influence(const PmeP<T>& P, const T* const* mh, const T*
         const T ux = mh[0][jx], uy = mh[1][jy], uz = mh[2][jz];
         const T vx = ux * P.r[0][0], vy = ux * P.r[1][0] + uy * P.r[1][1], vz = ux * P.r[2][0] + uy * P.r[2][1] + uz * P.r[2][2];
         const T n2 = vx * vx + vy * vy + vz * vz;
-        eterm = T(0.5) * (eterm + P.f_div_er * M<T>::exp(-P.factor * n2) / (n2 * bprod));
+        eterm_mir = P.f_div_er * M<T>::exp(-P.factor * n2) / (n2 * bprod);
+        wx = vx; wy = vy; wz = vz;
+        eterm = T(0.5) * (eterm + eterm_mir);
     }
     if constexpr (ENERGY) {
         const bool twice = !(kz == 0 || 2 * kz == nz);           // stands for k and its mirror −k of the full mesh
+        if (P.tri) {      // sheared cell: k with its own wave vector, and (if this entry stands for it) −k with its own — no sign bookkeeping
+            const double s2 = (double)(re * re + im * im);
+            auto add = [&](T ax, T ay, T az, T et) {
+                const double Ek = (double)et * s2, a2 = (double)ax * ax + (double)ay * ay + (double)az * az, coeff = 2.0 * (1.0 + (double)P.factor * a2) / a2;
+                e_loc += Ek;
+                v_loc[0] += Ek * (1.0 - coeff * ax * ax); v_loc[1] += Ek * (1.0 - coeff * ay * ay); v_loc[2] += Ek * (1.0 - coeff * az * az);
+                v_loc[3] -= Ek * coeff * ax * ay; v_loc[4] -= Ek * coeff * ax * az; v_loc[5] -= Ek * coeff * ay * az;
+            };
+            add(mhx, mhy, mhz, eterm_own);
+            if (twice) add(wx, wy, wz, eterm_mir);
+            return eterm;
+        }
         const double Ek = (double)(eterm * (re * re + im * im)) * (twice ? 2.0 : 1.0);
         e_loc += Ek;
         // V·P_k = E_k [I − 2(1 + factor·m²)(m ⊗ m)/m²]  (recip_conv_inner! :701-723), six independent components.

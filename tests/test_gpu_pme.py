@@ -205,6 +205,10 @@ def test_triclinic_reciprocal_forces_and_energy_vs_oracle(pkg, dtype, basis, mes
     rel_f, rel_e = (1e-10, 1e-11) if dtype == np.float64 else (2e-4, 2e-5)
     assert np.linalg.norm(f - f_ref, axis=1).max() < rel_f * scale, np.linalg.norm(f - f_ref, axis=1).max() / scale
     assert abs(e - e_ref) < rel_e * abs(e_ref)
+    # the reciprocal-space virial: every wave vector of the full mesh with its own m · recip_box (the mirror of a Nyquist index is not −m on a sheared cell)
+    w = pkg.virial(s, pairwise=False, specific=False)
+    w_ref = o.virial(None, pairwise=False, specific=False, general=True)
+    assert np.abs(w - w_ref).max() < (1e-9 if dtype == np.float64 else 2e-4) * np.abs(w_ref).max()
 
 
 def test_triclinic_ewald_total_forces_and_short_run_vs_oracle(pkg):
