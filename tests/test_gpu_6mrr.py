@@ -155,3 +155,31 @@ def test_outer_list_adopted_when_the_prune_has_nothing_to_drop(pkg, monkeypatch)
     d = np.array(s1.coords, dtype=np.float64) - np.array(s0.coords, dtype=np.float64); d -= np.round(d / case.box) * case.box
     assert np.abs(d).max() < 2e-4, np.abs(d).max()                            # 120 steps of fp32 dynamics from different summation orders at the rebuild steps
     assert np.abs(np.array(s1.velocities, dtype=np.float64) - np.array(s0.velocities, dtype=np.float64)).max() < 0.05
+
+
+def test_calls_behind_a_run_that_adopted_its_outer_list(pkg, monkeypatch):
+    """what reads "the inner list" while the outer list stands in for it (engine.hip, inner_is_outer): an energy pass, a force call through the drop-in
+    boundary and the exported pair list, on the state a 120-step run ended in — each against the fp64 oracle on the same coordinates"""
+    monkeypatch.delenv("MOLLYHIP_ADOPT_OUTER", raising=False)
+    case = G.case("rf", np.float32, bonded=True)
+    s = case.system(pkg, np.float32)
+    pkg.simulate(s, pkg.VelocityVerlet(dt=0.0005), 120)
+    assert s.stats()["n_adopted_outer_lists"] >= 2
+    L = pkg.lib()
+    x = np.array(s.coords, dtype=np.float64)
+    o = case.oracle(np.float64, coords=x)
+    nl = o.neighbors("cell", nthreads=8)
+    # straight through the C ABI, no new state: the lists of the run are the lists of these calls
+    import ctypes as C
+    f = np.zeros((case.n, 3), np.float32)
+    s._check(L.mhip_forces(s.engine(), 120, 0, s._ptr(f), None, 0))      # (MEM_HOST)
+    f_ref = o.forces(nl, nthreads=8, specific=False)
+    err = np.linalg.norm(f.astype(np.float64) - f_ref, axis=1)
+    assert err.max() < 2e-4 * np.linalg.norm(f_ref, axis=1).max(), err.max()
+    e = C.c_double(0)
+    s._check(L.mhip_potential_energy(s.engine(), 120, C.byref(e)))
+    e_ref = o.potential_energy(nl)
+    assert abs(e.value - e_ref) < 2e-5 * abs(e_ref), (e.value, e_ref)
+    keys, n_special = S.export_keys(pkg, s)
+    oi, oj, osp = case.oracle(np.float32, coords=x).neighbors("cell", nthreads=8)
+    assert np.array_equal(keys, S.pair_keys(oi, oj)) and n_special == int(np.asarray(osp).sum())
