@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of an experiment: the proportional dealing was removed afterwards, profiles/r04_force_ab.txt §13)
 # round 4, call r: lanes of a group dealt to the atoms in proportion to their entries (k_regroup) — parity, A/B, time stamps
 out=gpurun_out; mkdir -p $out
 timeout 1500 python -m pytest tests/test_gpu_6mrr.py tests/test_gpu_pme.py -q --timeout 900 -p no:cacheprovider -x 2>&1 | tail -6 | tee $out/r04_r_tests.log

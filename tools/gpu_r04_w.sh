@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of an experiment: the kernels it timed — k_pme_xy, k_pme_yx / k_pme_yz and their MOLLYHIP_PME_PLANES / MOLLYHIP_PME_DEBUG switches — were removed afterwards, profiles/r04_force_ab.txt §15)
 # round 4, call w: the reciprocal space between z r2c and the potential mesh as two plane kernels (k_pme_yx, k_pme_yz) — parity, A/B, timeline
 out=gpurun_out; mkdir -p $out
 timeout 1500 python -m pytest tests/test_gpu_pme.py tests/test_gpu_6mrr.py -q --timeout 900 -p no:cacheprovider -x 2>&1 | tail -6 | tee $out/r04_w_tests.log

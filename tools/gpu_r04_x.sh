@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of an experiment: the kernels it timed — k_pme_xy, k_pme_yx / k_pme_yz and their MOLLYHIP_PME_PLANES / MOLLYHIP_PME_DEBUG switches — were removed afterwards, profiles/r04_force_ab.txt §15)
 # round 4, call x: stages of k_pme_yx (MOLLYHIP_PME_DEBUG=11..13 stops the kernel behind a stage; timing only)
 out=gpurun_out; mkdir -p $out; R=$PWD
 for d in 11 12 13 0; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of experiments that were removed afterwards, profiles/r04_force_ab.txt §17; ab/lib_before.so / ab/lib_dbg.so are builds made for the comparison)
 # round 4, call z: the first staging round's indices requested before the tile's size is known (forces_gs.hip) — parity, A/B against the build before, time stamps
 out=gpurun_out; mkdir -p $out
 timeout 1500 python -m pytest tests/test_gpu_6mrr.py tests/test_gpu_pme.py -q --timeout 900 -p no:cacheprovider -x 2>&1 | tail -4 | tee $out/r04_z_tests.log
