@@ -643,6 +643,9 @@ template <class T> class Engine final : public EngineBase {
             A.walk = walk ? 1 : 0;
             A.eshift = eshift = want_eshift();
             A.cnt_out = nullptr; cnt_outer_valid = false;
+            A.dbg = nullptr;
+            static const int dbg_build = env_int("MOLLYHIP_DBG_TIMES", 0);
+            if (dbg_build) { dbg_buf.reserve((size_t)n_blocks * 16 * 8); MHIP_HIP(hipMemsetAsync(dbg_buf.p, 0, (size_t)n_blocks * 16 * 8 * sizeof(unsigned long long), stream)); A.dbg = dbg_buf.p; }
             if ((sort_lanes_on && dual && BI > 64) || (gs_groups() > 0 && adopt_env)) { cnt_outer.reserve((size_t)n_blocks * JS * BI); A.cnt_out = cnt_outer.p; cnt_outer_valid = true; }
             prof.begin(1, stream);
             tr("k_build");
@@ -655,6 +658,11 @@ template <class T> class Engine final : public EngineBase {
             MHIP_HIP(hipGetLastError());
             MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
             MHIP_HIP(hipStreamSynchronize(stream));
+            if (A.dbg) {      // (experiment builds) the raw stamps of this search → $MOLLYHIP_DBG_DUMP_BUILD, for tools/build_times.py
+                std::vector<unsigned long long> h((size_t)n_blocks * 16 * 8);
+                MHIP_HIP(hipMemcpy(h.data(), dbg_buf.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                if (const char* path = std::getenv("MOLLYHIP_DBG_DUMP_BUILD")) { if (FILE* f = std::fopen(path, "wb")) { std::fwrite(h.data(), sizeof(unsigned long long), h.size(), f); std::fclose(f); } }
+            }
             int ovf = h_flags[FLAG_OVERFLOW];
             if (!ovf) break;
             if (ovf & OVF_SLOT) {

@@ -268,6 +268,7 @@ template <class T> struct BuildArgs {
     int walk;                        // search by walking every i-atom's cell stencil over the tile (1) or transposed, tile groups against the wave's i-atoms (0)
     int eshift;                      // entry format of the emitted rows (0 | ESHIFT_SCALED)
     uint16_t* cnt_out;               // [n_blocks][JS][BI] entries emitted per (j-split, atom), nullable (first lane order of the inner list)
+    unsigned long long* dbg;         // builds with -DMHIP_EXP=11 (MOLLYHIP_DBG_TIMES): [block][wave][8] — wall clock at entry / behind the staging / behind the search / at the end, entries found, exception-list lengths
 };
 
 // exclusive prefix sum of a[0..n) in LDS, in place; a[n] receives the total.  `part` holds blockDim ints.
@@ -311,6 +312,9 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv_all = tid >> 6, NW_ALL = nthr >> 6;
     const int li = tid & (A.BI - 1), js = tid >> A.BI_shift;   // thread = (j-split, i-atom); every j-split group sees the same i-atoms
     const int wv = li >> 6, NW = A.BI >> 6;                    // i-wave of my atom, i-waves per block
+#if MHIP_EXP == 11
+    if (A.dbg && lane == 0) { unsigned long long* d = A.dbg + ((size_t)b * NW_ALL + wv_all) * 8; d[0] = wall_clock64(); }
+#endif
     // tile atoms in block-local coordinates, ALWAYS fp32: the search only needs them for the cheap pre-test, whose
     // 1e-4 band absorbs the rounding; decisions inside the band use the stored T coordinates from HBM
     // Three arrays, 12 bytes per tile atom (+ 4 for the caller index where exception lists need it): with 16-byte records + index the
@@ -520,6 +524,9 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
     if (tid == 0) A.tile_cnt[b] = tile_n;
     if (WALK && !exact_only) block_excl_scan(t_off, ncb, part, tid, nthr);   // → first tile slot of every box cell, t_off[ncb] = tile_n
     if (A.debug == 3) return;
+#if MHIP_EXP == 11
+    if (A.dbg && lane == 0) { unsigned long long* d = A.dbg + ((size_t)b * NW_ALL + wv_all) * 8; d[1] = wall_clock64(); }
+#endif
 
     // 3. neighbour search, transposed: the LANES hold 64 tile atoms (one coalesced LDS read per group), the wave
     //    loops over its own i-atoms on the scalar unit (coordinates broadcast with v_readlane), and one v_cmp per
@@ -550,6 +557,41 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
             if (js == 0) for (int k = 0; k < min(nxl, A.X_cap); ++k) x_part[k * A.BI + li] = A.xl_list[xl0 + k];
         }
         if (XL && A.xl_start) __syncthreads();
+        // My exceptions as two 128-bit masks over the caller-index offset oj − oi ∈ [−64, 63] (excluded / special): bonded partners sit next to each other in the
+        // topology, so a candidate's verdict is one shift instead of a scan of the list — the time stamps of a 6mrr search (tools/build_times.py) showed the search
+        // of a block growing with its atoms' list lengths (correlation 0.94: water 2 entries, 40 µs; protein interior 10, 93 µs), and the launch is one round of
+        // blocks.  Partners further away (disulphide bridges, ring closures) set `far`, and only then the list itself is scanned.
+        [[maybe_unused]] uint64_t mexc0 = 0, mexc1 = 0, mspc0 = 0, mspc1 = 0; [[maybe_unused]] bool far = false;
+        if constexpr (XL) {
+            for (int k = 0; k < nxl; ++k) {
+                const uint32_t e = k < A.X_cap ? x_part[k * A.BI + li] : A.xl_list[xl0 + k];
+                const int dl = (int)(e & XL_INDEX) - oi + 64;
+                if ((unsigned)dl < 128u) {
+                    const uint64_t bit = 1ull << (dl & 63);
+                    if (e & XL_EXCLUDED) { if (dl < 64) mexc0 |= bit; else mexc1 |= bit; }
+                    else if (e & XL_SPECIAL) { if (dl < 64) mspc0 |= bit; else mspc1 |= bit; }
+                } else far = true;
+            }
+            mspc0 &= ~mexc0; mspc1 &= ~mexc1;      // (a pair in both lists is excluded)
+        }
+        // verdict for the candidate with caller index oj: −1 excluded, else its special flag
+        [[maybe_unused]] auto exception_of = [&](int oj) -> int {
+            const int dl = oj - oi + 64;
+            if ((unsigned)dl < 128u) {
+                const uint64_t me = dl < 64 ? mexc0 : mexc1, ms = dl < 64 ? mspc0 : mspc1; const int sh = dl & 63;
+                return ((me >> sh) & 1ull) ? -1 : (int)((ms >> sh) & 1ull);
+            }
+            if (!far || (unsigned)(oj - oi + A.xl_span) > (unsigned)(2 * A.xl_span)) return 0;
+            uint32_t hit = 0;
+            for (int k = 0; k < nxl; ++k) {
+                const uint32_t e = k < A.X_cap ? x_part[k * A.BI + li] : A.xl_list[xl0 + k];
+                hit = ((e & XL_INDEX) == (uint32_t)oj) ? e : hit;
+            }
+            return (hit & XL_EXCLUDED) ? -1 : (int)(hit >> 31);
+        };
+#if MHIP_EXP == 11
+        if (A.dbg) { int x = nxl; for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, WAVE); if (lane == 0) A.dbg[((size_t)b * NW_ALL + wv_all) * 8 + 6] = (unsigned long long)x; }
+#endif
         T my_loc[3], my_ub[3]; localise3(my[0], my[1], my[2], my_loc, my_ub);
         const float ml[3] = {(float)my_loc[0], (float)my_loc[1], (float)my_loc[2]};
         const float rl2 = G.no_list ? 3.0e38f : (float)G.r_list2;
@@ -597,14 +639,8 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
                         if (!in || (uint32_t)tc == self_t) return;
                         uint32_t sp = 0;
                         const int oj = (XL && nxl > 0) ? t_orig[tc] : 0;
-                        if (XL && nxl > 0 && (unsigned)(oj - oi + A.xl_span) <= (unsigned)(2 * A.xl_span)) {
-                            uint32_t hit = 0;
-                            for (int k = 0; k < nxl; ++k) {
-                                uint32_t e = k < A.X_cap ? x_part[k * A.BI + li] : A.xl_list[xl0 + k];
-                                hit = ((e & XL_INDEX) == (uint32_t)oj) ? e : hit;
-                            }
-                            if (hit & XL_EXCLUDED) return;
-                            sp = hit >> 31;
+                        if constexpr (XL) {
+                            if (nxl > 0) { const int v = exception_of(oj); if (v < 0) return; sp = (uint32_t)v; }
                         }
                         emit(make_entry((uint32_t)tc, sp, A.eshift));
                     };
@@ -703,14 +739,8 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
                 if (t == self_t) continue;                       // the atom itself (no LDS lookup on the common path)
                 uint32_t sp = 0;
                 const int oj = (XL && nxl > 0) ? t_orig[t] : 0;
-                if (XL && nxl > 0 && (unsigned)(oj - oi + A.xl_span) <= (unsigned)(2 * A.xl_span)) {
-                    uint32_t hit = 0;
-                    for (int k = 0; k < nxl; ++k) {
-                        uint32_t e = k < A.X_cap ? x_part[k * A.BI + li] : A.xl_list[xl0 + k];
-                        hit = ((e & XL_INDEX) == (uint32_t)oj) ? e : hit;
-                    }
-                    if (hit & XL_EXCLUDED) continue;
-                    sp = hit >> 31;
+                if constexpr (XL) {
+                    if (nxl > 0) { const int v = exception_of(oj); if (v < 0) continue; sp = (uint32_t)v; }
                 }
                 emit(make_entry(t, sp, A.eshift));
             }
@@ -718,6 +748,13 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
         }   // transposed search
     }
     if (A.debug == 4) return;
+#if MHIP_EXP == 11
+    if (A.dbg) {
+        int c = cnt, x = 0;
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, WAVE);
+        if (lane == 0) { unsigned long long* d = A.dbg + ((size_t)b * NW_ALL + wv_all) * 8; d[2] = wall_clock64(); d[4] = (unsigned long long)c; d[5] = (unsigned long long)tile_n; (void)x; }
+    }
+#endif
     // 4. pad every lane to the wave's row count with the sentinel slot (a far-away dummy atom)
     if (A.cnt_out) A.cnt_out[((int64_t)b * A.JS + js) * A.BI + li] = (uint16_t)min(cnt, 65535);
     int rows_mine = (cnt + 3) >> 2;
@@ -726,6 +763,9 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
     const int rows_keep = rows_wave > A.R_cap ? 0 : rows_wave;
     while (((cnt + 3) >> 2) < rows_keep || (cnt & 3)) emit(SENT);
     if (lane == 0) A.wave_rows[(b * A.JS + js) * NW + wv] = rows_wave;   // > R_cap reports the required capacity; k_build_summary zeroes it
+#if MHIP_EXP == 11
+    if (A.dbg && lane == 0) { unsigned long long* d = A.dbg + ((size_t)b * NW_ALL + wv_all) * 8; d[3] = wall_clock64(); }
+#endif
 }
 
 // a[i] = b[i] = i
