@@ -217,10 +217,28 @@ __device__ inline void bonded_collect_lane(int64_t gt, int64_t n_owned, const in
     int r0 = 0, r1 = 0;
     if (live) { const int a = orig[s]; r0 = role_start[a]; r1 = role_start[a + 1]; }
     T fx = T(0), fy = T(0), fz = T(0);
-    for (int r = r0 + l; r < r1; r += COLLECT_LANES) { const auto v = slots[role_slot[r]]; fx += v.x; fy += v.y; fz += v.z; }
+    // four of a lane's slots per round, their (dependent) fetches issued together — index, then record: an atom of the protein interior has 40 slots, five per
+    // lane, and one after the other they were ten memory latencies in the one launch of the step that every atom waits for.  Same order of the adds as before.
+    for (int r = r0 + l; r < r1; r += 4 * COLLECT_LANES) {
+        int ix[4]; typename Vec<T>::T4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ix[k] = role_slot[min(r + k * COLLECT_LANES, r1 - 1)];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = slots[ix[k]];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (r + k * COLLECT_LANES < r1) { fx += v[k].x; fy += v[k].y; fz += v[k].z; }
+    }
 #pragma unroll
     for (int o = COLLECT_LANES / 2; o > 0; o >>= 1) { fx += __shfl_xor(fx, o, 64); fy += __shfl_xor(fy, o, 64); fz += __shfl_xor(fz, o, 64); }
-    if (parts && live && l == 0) for (int q = 0; q < n_parts; ++q) { const auto v = parts[(int64_t)q * part_stride + s]; fx += v.x; fy += v.y; fz += v.z; }
+    if (parts && live && l == 0) {      // (the group-split pass's partial forces: requested together, added in order)
+        for (int q0 = 0; q0 < n_parts; q0 += 4) {
+            typename Vec<T>::T4 pv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pv[k] = parts[(int64_t)min(q0 + k, n_parts - 1) * part_stride + s];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (q0 + k < n_parts) { fx += pv[k].x; fy += pv[k].y; fz += pv[k].z; }
+        }
+    }
     if constexpr (ASSIGN) {
         if (live && l == 0) out[s] = make4<T>(fx, fy, fz, T(0));
     } else if (live && l == 0 && (r1 > r0 || parts)) {
