@@ -1106,8 +1106,16 @@ template <class T> class Engine final : public EngineBase {
         nbr_gs.reserve((size_t)n_blocks * JS * R_cap * BI); rows_gs.reserve((size_t)n_blocks * JS * (BI / WAVE));
         RegroupArgs R{BI, ilog2(BI), JS, GS, ilog2(GS), R_cap, (const uint2*)nbr.p, (const uint16_t*)cnt_outer.p, (const int32_t*)tile_cnt.p, nbr_gs.p, rows_gs.p,
                       (int)std::min<size_t>((size_t)MAX_LDS_BYTES - (size_t)JS * BI * 8 - 64, (size_t)JS * R_cap * BI * 8)};
+        static const int dbg_rg = env_int("MOLLYHIP_DBG_TIMES", 0);
+        if (dbg_rg) { dbg_buf.reserve((size_t)n_blocks * 16 * 8); R.dbg = dbg_buf.p; }
         tr("k_regroup (outer list)");
         launch_regroup(R, n_blocks, stream);
+        if (R.dbg) {
+            std::vector<unsigned long long> h((size_t)n_blocks * 8);
+            MHIP_HIP(hipStreamSynchronize(stream));
+            MHIP_HIP(hipMemcpy(h.data(), dbg_buf.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            if (const char* path = std::getenv("MOLLYHIP_DBG_DUMP_REGROUP")) { if (FILE* f = std::fopen(path, "wb")) { std::fwrite(h.data(), sizeof(unsigned long long), h.size(), f); std::fclose(f); } }
+        }
         prof.end(4, stream);
         MHIP_HIP(hipGetLastError());
         inner_is_outer = true; max_tile_in = max_tile; last_prune_step = pass_step;

@@ -42,6 +42,10 @@ __global__ void __launch_bounds__(1024) k_regroup(RegroupArgs A) {
     const uint2* rows = A.src + ((sub0 + js) * A.R_cap) * A.BI + li;
     constexpr int NB = 8;
     unsigned long long C = 0;
+#if MHIP_EXP == 11
+    if (A.dbg && tid == 0) A.dbg[(size_t)b * 8 + 0] = wall_clock64();
+#endif
+
     for (int r0 = 0; r0 < nrow; r0 += NB) {
         uint2 rw[NB];
 #pragma unroll
@@ -54,6 +58,10 @@ __global__ void __launch_bounds__(1024) k_regroup(RegroupArgs A) {
         }
     }
     l_c[js * A.BI + li] = C;
+#if MHIP_EXP == 11
+    if (A.dbg && tid == 0) A.dbg[(size_t)b * 8 + 1] = wall_clock64();
+#endif
+
     __syncthreads();
     unsigned long long K = 0, TOT = 0;                                              // numbers of my first entries per group; the atom's totals
     for (int q = 0; q < A.JS; ++q) { const unsigned long long v = l_c[q * A.BI + li]; TOT += v; if (q < js) K += v; }
@@ -74,6 +82,10 @@ __global__ void __launch_bounds__(1024) k_regroup(RegroupArgs A) {
     if ((tid & (WAVE - 1)) == 0) atomicMax(l_rmax, rows_w);
     __syncthreads();
     const int R_l = *l_rmax;
+#if MHIP_EXP == 11
+    if (A.dbg && tid == 0) A.dbg[(size_t)b * 8 + 2] = wall_clock64();
+#endif
+
     uint16_t* l_dst = reinterpret_cast<uint16_t*>(l_rmax + 4);
     const bool via_lds = (size_t)A.JS * R_l * A.BI * 8 <= (size_t)A.lds_list_bytes;
     uint16_t* dst16 = via_lds ? l_dst : reinterpret_cast<uint16_t*>(A.dst);
@@ -102,12 +114,19 @@ __global__ void __launch_bounds__(1024) k_regroup(RegroupArgs A) {
     // pad my destination sub-list (positions nobody else writes)
     const uint16_t SENT = (uint16_t)((A.tile_cnt[b] + GS - 1) >> A.lgGS);
     for (int p = n_mine; p < 4 * rows_w; ++p) dst16[at(js, p)] = SENT;
+#if MHIP_EXP == 11
+    if (A.dbg && tid == 0) A.dbg[(size_t)b * 8 + 3] = wall_clock64();
+#endif
+
     if (via_lds) {
         __syncthreads();
         const uint2* l_rows = reinterpret_cast<const uint2*>(l_dst);
         uint2* out = A.dst + ((sub0 + js) * A.R_cap) * A.BI + li;
         for (int r = 0; r < rows_w; ++r) out[(int64_t)r * A.BI] = l_rows[(js * R_l + r) * A.BI + li];
     }
+#if MHIP_EXP == 11
+    if (A.dbg && tid == 0) A.dbg[(size_t)b * 8 + 4] = wall_clock64();
+#endif
 }
 
 // ---- k_forces_gs: one group of one block ----------------------------------------------------------------------------------------------------
