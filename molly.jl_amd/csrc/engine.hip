@@ -1069,7 +1069,7 @@ template <class T> class Engine final : public EngineBase {
             if (prune && GS > 0 && !lanes_sorted && !rebalance) {      // the list this prune wrote, dealt to the groups (it stays as it is for every other kind of pass)
                 nbr_gs.reserve((size_t)n_blocks * JS * R_cap * BI); rows_gs.reserve((size_t)n_blocks * JS * (BI / WAVE));
                 RegroupArgs R{BI, ilog2(BI), JS, GS, ilog2(GS), R_cap, (const uint2*)nbr_in.p, (const uint16_t*)cnt_in.p, (const int32_t*)tile_cnt_in.p, nbr_gs.p, rows_gs.p,
-                              (int)std::min<size_t>((size_t)MAX_LDS_BYTES - (size_t)JS * BI * 8 - 64, (size_t)JS * R_cap * BI * 8)};
+                              (int)std::min<size_t>((size_t)MAX_LDS_BYTES - (size_t)JS * BI * 16 - 64, (size_t)JS * R_cap * BI * 8)};
                 tr("k_regroup");
                 launch_regroup(R, n_blocks, stream);
                 gs_list_id = n_filters + 1;      // (n_filters counts this prune below)
@@ -1105,7 +1105,7 @@ template <class T> class Engine final : public EngineBase {
         MHIP_HIP(hipMemcpyAsync(pos_snap_in.p, pos[cur].p, (size_t)n_tot * sizeof(T4), hipMemcpyDeviceToDevice, stream));
         nbr_gs.reserve((size_t)n_blocks * JS * R_cap * BI); rows_gs.reserve((size_t)n_blocks * JS * (BI / WAVE));
         RegroupArgs R{BI, ilog2(BI), JS, GS, ilog2(GS), R_cap, (const uint2*)nbr.p, (const uint16_t*)cnt_outer.p, (const int32_t*)tile_cnt.p, nbr_gs.p, rows_gs.p,
-                      (int)std::min<size_t>((size_t)MAX_LDS_BYTES - (size_t)JS * BI * 8 - 64, (size_t)JS * R_cap * BI * 8)};
+                      (int)std::min<size_t>((size_t)MAX_LDS_BYTES - (size_t)JS * BI * 16 - 64, (size_t)JS * R_cap * BI * 8)};
         static const int dbg_rg = env_int("MOLLYHIP_DBG_TIMES", 0);
         if (dbg_rg) { dbg_buf.reserve((size_t)n_blocks * 16 * 8); R.dbg = dbg_buf.p; }
         tr("k_regroup (outer list)");

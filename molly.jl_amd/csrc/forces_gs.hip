@@ -41,7 +41,11 @@ __global__ void __launch_bounds__(1024) k_regroup(RegroupArgs A) {
     const int n = (int)A.cnt[(sub0 + js) * A.BI + li], nrow = (n + 3) >> 2;
     const uint2* rows = A.src + ((sub0 + js) * A.R_cap) * A.BI + li;
     constexpr int NB = 8;
-    unsigned long long C = 0;
+    // SPECIAL entries (1-4 pairs: bit 15) are counted apart and dealt BEHIND an atom's other entries: the pass takes its two-partner packed loop only for rows
+    // without a special entry in any lane, and a wave of protein atoms had one in 60 % of its rows (3 094 special pairs, all of them in the ≈ 40 protein blocks
+    // — the blocks a launch waits for); at the tail of the lists they sit in the last row or two.
+    unsigned long long* l_cs = l_c + (size_t)A.JS * A.BI;                          // [JS][BI]: the special ones among them
+    unsigned long long C = 0, CS = 0;
 #if MHIP_EXP == 11
     if (A.dbg && tid == 0) A.dbg[(size_t)b * 8 + 0] = wall_clock64();
 #endif
@@ -54,20 +58,24 @@ __global__ void __launch_bounds__(1024) k_regroup(RegroupArgs A) {
         for (int j = 0; j < NB; ++j) {
             const uint32_t e[4] = {rw[j].x & 0xffffu, rw[j].x >> 16, rw[j].y & 0xffffu, rw[j].y >> 16};
 #pragma unroll
-            for (int t = 0; t < 4; ++t) if (4 * (r0 + j) + t < n) C += 1ull << ((e[t] & gmask) * 16);
+            for (int t = 0; t < 4; ++t) if (4 * (r0 + j) + t < n) { const unsigned long long one = 1ull << ((e[t] & gmask) * 16); if (e[t] & 0x8000u) CS += one; else C += one; }
         }
     }
-    l_c[js * A.BI + li] = C;
+    l_c[js * A.BI + li] = C; l_cs[js * A.BI + li] = CS;
 #if MHIP_EXP == 11
     if (A.dbg && tid == 0) A.dbg[(size_t)b * 8 + 1] = wall_clock64();
 #endif
 
     __syncthreads();
-    unsigned long long K = 0, TOT = 0;                                              // numbers of my first entries per group; the atom's totals
-    for (int q = 0; q < A.JS; ++q) { const unsigned long long v = l_c[q * A.BI + li]; TOT += v; if (q < js) K += v; }
+    unsigned long long K = 0, TOT = 0, KS = 0, TOTS = 0;                            // numbers of my first (special) entries per group; the atom's totals
+    for (int q = 0; q < A.JS; ++q) {
+        const unsigned long long v = l_c[q * A.BI + li], vs = l_cs[q * A.BI + li];
+        TOT += v; TOTS += vs; if (q < js) { K += v; KS += vs; }
+    }
+    KS += TOT;                                                                      // (the special entries are numbered behind all the others of the atom and group)
     // as a DESTINATION lane (group gd, wave wd of the group): how many entries come my way, the row count of my wave
     const int gd = js >> lgW, wd = js & (JSW - 1);
-    const int tot_d = (int)((TOT >> (gd * 16)) & 0xffffull);
+    const int tot_d = (int)(((TOT + TOTS) >> (gd * 16)) & 0xffffull);
     const int n_mine = max(tot_d - wd + JSW - 1, 0) >> lgW;
     int rows_w = (n_mine + 3) >> 2;
 #pragma unroll
@@ -76,7 +84,7 @@ __global__ void __launch_bounds__(1024) k_regroup(RegroupArgs A) {
     // The scatter goes through LDS when the block's new list fits behind the counters (rows of the longest wave × sub-lists × 512 bytes:
     // ≈ 100 KB for a 6mrr block) and leaves as whole 8-byte rows, a wave's 512 bytes at a time; 2-byte stores scattered straight into
     // global memory cost 45 µs per prune where the prune itself takes 61.
-    int* l_rmax = reinterpret_cast<int*>(l_c + (size_t)A.JS * A.BI);
+    int* l_rmax = reinterpret_cast<int*>(l_c + 2 * (size_t)A.JS * A.BI);
     if (tid == 0) *l_rmax = 0;
     __syncthreads();
     if ((tid & (WAVE - 1)) == 0) atomicMax(l_rmax, rows_w);
@@ -104,8 +112,9 @@ __global__ void __launch_bounds__(1024) k_regroup(RegroupArgs A) {
             for (int t = 0; t < 4; ++t) {
                 if (4 * (r0 + j) + t < n) {
                     const uint32_t g = e[t] & gmask;
-                    const int k = (int)((K >> (g * 16)) & 0xffffull);
-                    K += 1ull << (g * 16);
+                    const bool spc = (e[t] & 0x8000u) != 0u;
+                    const int k = (int)(((spc ? KS : K) >> (g * 16)) & 0xffffull);
+                    if (spc) KS += 1ull << (g * 16); else K += 1ull << (g * 16);
                     dst16[at((int)g * JSW + (k & (JSW - 1)), k >> lgW)] = (uint16_t)(((e[t] & 0x7fffu) >> A.lgGS) | (e[t] & 0x8000u));
                 }
             }
@@ -265,7 +274,7 @@ __global__ void __launch_bounds__(256, 4) k_pair_spread_bonded(GsArgs A, int n_p
 size_t gs_lds_bytes(int q_lds, int BI, int JSW) { return std::max((size_t)(q_lds + 1) * (sizeof(float4) + sizeof(float2)), (size_t)JSW * 3 * BI * sizeof(float)) + 64; }
 
 void launch_regroup(const RegroupArgs& A, int n_blocks, hipStream_t stream) {
-    const size_t lds = (size_t)A.JS * A.BI * sizeof(unsigned long long) + 16 + (size_t)A.lds_list_bytes;
+    const size_t lds = 2 * (size_t)A.JS * A.BI * sizeof(unsigned long long) + 16 + (size_t)A.lds_list_bytes;
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) { MHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_regroup), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
     hipLaunchKernelGGL(k_regroup, dim3(n_blocks), dim3(A.BI * A.JS), lds, stream, A);
