@@ -967,6 +967,7 @@ template <class T> class Engine final : public EngineBase {
                     Z.n_blocks = n_blocks; Z.spread = std::max(1, n_blocks / GS + 5);
                     Z.pos = pos[cur].p; Z.lj = lj[cur].p; Z.tile_idx = inner_is_outer ? tile_idx.p : tile_idx_in.p; Z.tile_cnt = inner_is_outer ? tile_cnt.p : tile_cnt_in.p; Z.nbr = nbr_gs.p; Z.wave_rows = rows_gs.p; Z.blk_center = blk_center.p;
                     Z.frc = frc[cur].p; Z.parts = frc_parts.p; Z.part_stride = cap;
+                    Z.item_of = gs_balance_on ? gs_item.p : nullptr;
                     Z.dbg = nullptr;
                     static const int dbg_gs = env_int("MOLLYHIP_DBG_TIMES", 0);
                     if (dbg_gs) { dbg_buf.reserve((size_t)n_blocks * GS * 4 * 8); MHIP_HIP(hipMemsetAsync(dbg_buf.p, 0, (size_t)n_blocks * GS * 4 * 8 * sizeof(unsigned long long), stream)); Z.dbg = dbg_buf.p; }
@@ -1072,6 +1073,7 @@ template <class T> class Engine final : public EngineBase {
                               (int)std::min<size_t>((size_t)MAX_LDS_BYTES - (size_t)JS * BI * 16 - 64, (size_t)JS * R_cap * BI * 8)};
                 tr("k_regroup");
                 launch_regroup(R, n_blocks, stream);
+                gs_balance();
                 gs_list_id = n_filters + 1;      // (n_filters counts this prune below)
             }
         }
@@ -1097,6 +1099,16 @@ template <class T> class Engine final : public EngineBase {
         }
     }
 
+    // the (block, group) items of the group-split pass handed to its workgroups so that every compute unit gets a like share of rows (forces_gs.hip, k_gs_balance)
+    DBuf<uint16_t> gs_item; const bool gs_balance_on = env_int("MOLLYHIP_GS_BALANCE", 1) != 0; int cu_count = 0;
+    void gs_balance() {
+        if (!gs_balance_on) return;
+        if (!cu_count) { int dev = 0; MHIP_HIP(hipGetDevice(&dev)); hipDeviceProp_t pr; MHIP_HIP(hipGetDeviceProperties(&pr, dev)); cu_count = std::max(1, pr.multiProcessorCount); }
+        const int GS = gs_groups();
+        gs_item.reserve((size_t)n_blocks * GS);
+        launch_gs_balance((const int32_t*)rows_gs.p, n_blocks, JS, GS, BI / WAVE, cu_count, gs_item.p, stream);
+    }
+
     // the outer list, searched at this step with the radius the inner list would be pruned to, becomes the inner list (see inner_is_outer)
     void adopt_outer_list() {
         const int GS = gs_groups();
@@ -1116,6 +1128,7 @@ template <class T> class Engine final : public EngineBase {
             MHIP_HIP(hipMemcpy(h.data(), dbg_buf.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
             if (const char* path = std::getenv("MOLLYHIP_DBG_DUMP_REGROUP")) { if (FILE* f = std::fopen(path, "wb")) { std::fwrite(h.data(), sizeof(unsigned long long), h.size(), f); std::fclose(f); } }
         }
+        gs_balance();
         prof.end(4, stream);
         MHIP_HIP(hipGetLastError());
         inner_is_outer = true; max_tile_in = max_tile; last_prune_step = pass_step;

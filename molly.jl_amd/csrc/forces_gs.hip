@@ -138,12 +138,42 @@ __global__ void __launch_bounds__(1024) k_regroup(RegroupArgs A) {
 #endif
 }
 
+// ---- k_gs_balance: which (block, group) a workgroup of the pass takes ---------------------------------------------------------------------------
+// The time stamps of the pass (tools/gs_times.py) show the hardware placing workgroup w on compute unit w mod 256, every workgroup resident from the start, and
+// a compute unit finishing when the rows of its four workgroups are walked (correlation 0.93) — 116 … 192 wave-rows per unit around a mean of 166.  So the
+// (block, group) items are ranked by their rows (counting rank of a thousand items: sixteen lanes per item) and handed out in a serpentine: the `period` heaviest to
+// workgroups 0 … period − 1, the next `period` in the opposite direction, and so on, which pairs heavy with light on every compute unit.
+__global__ void __launch_bounds__(1024) k_gs_balance(const int32_t* __restrict__ rows_gs, int n_blocks, int JS, int GS, int wps, int period, uint16_t* item_of) {
+    extern __shared__ int32_t l_work[];
+    const int n_items = n_blocks * GS, JSW = JS / GS;
+    for (int t = threadIdx.x; t < n_items; t += blockDim.x) {      // (every workgroup: the rows of all items)
+        const int g = t / n_blocks, b = t - g * n_blocks;
+        int w = 0;
+        for (int q = 0; q < JSW * wps; ++q) w += rows_gs[((int64_t)b * JS + g * JSW) * wps + q];
+        l_work[t] = w;
+    }
+    __syncthreads();
+    // 64 items per workgroup, sixteen lanes per item: each counts its sixteenth of the items that come before (more rows; equal rows and a smaller number)
+    const int t = (int)blockIdx.x * 64 + (int)(threadIdx.x >> 4), sub = (int)(threadIdx.x & 15);
+    const int tc = min(t, n_items - 1), mine = l_work[tc];
+    int rank = 0;
+    for (int u = sub; u < n_items; u += 16) { const int o = l_work[u]; rank += (o > mine || (o == mine && u < tc)) ? 1 : 0; }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) rank += __shfl_xor(rank, o, 64);
+    if (t < n_items && sub == 0) {
+        const int layer = rank / period, pos = rank - layer * period;
+        const int in_layer = min(period, n_items - layer * period);
+        item_of[layer * period + ((layer & 1) ? in_layer - 1 - pos : pos)] = (uint16_t)t;
+    }
+}
+
 // ---- k_forces_gs: one group of one block ----------------------------------------------------------------------------------------------------
 template <int COULM, bool MINIMG>
 __device__ inline void forces_gs_body(const GsArgs& A, int wg, unsigned char* smem) {
     const GridP<float>& G = A.G;
-    const int g = wg / A.n_blocks, bq = wg - g * A.n_blocks;
-    const int b = (bq + g * A.spread) % A.n_blocks;
+    const int item = A.item_of ? (int)A.item_of[wg] : wg;
+    const int g = item / A.n_blocks, bq = item - g * A.n_blocks;
+    const int b = A.item_of ? bq : (bq + g * A.spread) % A.n_blocks;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int li = tid & (A.BI - 1), jw = tid >> A.BI_shift, JSW = A.JS >> A.lgGS, js = g * JSW + jw;
     // timing experiment (-DMHIP_EXP=11): per wave — [0] shader clock at entry, [1] rows walked, [2] block | group << 20 | HW_ID << 32, [3] XCC_ID,
@@ -278,6 +308,10 @@ void launch_regroup(const RegroupArgs& A, int n_blocks, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) { MHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_regroup), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
     hipLaunchKernelGGL(k_regroup, dim3(n_blocks), dim3(A.BI * A.JS), lds, stream, A);
+}
+
+void launch_gs_balance(const int32_t* rows_gs, int n_blocks, int JS, int GS, int waves_per_sub, int period, uint16_t* item_of, hipStream_t stream) {
+    hipLaunchKernelGGL(k_gs_balance, dim3((unsigned)((n_blocks * GS + 63) / 64)), dim3(1024), (size_t)n_blocks * GS * sizeof(int32_t), stream, rows_gs, n_blocks, JS, GS, waves_per_sub, period, item_of);
 }
 
 void launch_forces_gs(const GsArgs& A, int coulm, bool minimg, hipStream_t stream) {

@@ -24,10 +24,12 @@ struct GsArgs {
     int64_t n_owned; int BI, BI_shift, JS, GS, lgGS, R_cap, T_cap, Q_lds, n_blocks, spread;
     const float4* pos; const float2* lj; const int32_t* tile_idx; const int32_t* tile_cnt; const uint2* nbr; const int32_t* wave_rows; const float4* blk_center;
     float4* frc; float4* parts; int64_t part_stride;                      // group 0 → frc, group g → parts + (g − 1)·part_stride
+    const uint16_t* item_of;                                              // [n_blocks·GS] nullable: which (group · n_blocks + block) workgroup w takes (k_gs_balance)
     unsigned long long* dbg;                                              // builds with -DMHIP_EXP=11: [workgroup][wave][8] time stamps (engine: MOLLYHIP_DBG_TIMES, tools/gs_times.py)
 };
 size_t gs_lds_bytes(int q_lds, int BI, int JSW);
 void launch_regroup(const RegroupArgs& A, int n_blocks, hipStream_t stream);
+void launch_gs_balance(const int32_t* rows_gs, int n_blocks, int JS, int GS, int waves_per_sub, int period, uint16_t* item_of, hipStream_t stream);
 void launch_forces_gs(const GsArgs& A, int coulm, bool minimg, hipStream_t stream);
 template <class T> struct PmeP; template <class T> struct BondedArgs;
 void launch_pair_spread_bonded(const GsArgs& A, int n_pair, int coulm, bool minimg, int order, int64_t n_atoms, float* rgrid, const PmeP<float>& P, int n_spread, const BondedArgs<float>& B, int n_term_wg,

@@ -34,6 +34,10 @@ def main():
     per_cu_rows = np.bincount(inv, weights=rows.sum(axis=1)); per_cu_n = np.bincount(inv); per_cu_end = np.zeros(len(keys)); np.maximum.at(per_cu_end, inv, end)
     print(f"  {len(keys)} compute units seen; workgroups per CU min {per_cu_n.min()} mean {per_cu_n.mean():.2f} max {per_cu_n.max()}; wave-rows per CU min {per_cu_rows.min():.0f} mean {per_cu_rows.mean():.0f} max {per_cu_rows.max():.0f}")
     print(f"  CU finish time: p10 {np.percentile(per_cu_end, 10):.2f} p50 {np.median(per_cu_end):.2f} p90 {np.percentile(per_cu_end, 90):.2f} max {per_cu_end.max():.2f}; corr(rows on CU, finish) {np.corrcoef(per_cu_rows, per_cu_end)[0, 1]:.2f}")
+    # which workgroups share a compute unit (is the placement the round robin it looks like?)
+    wg = np.nonzero(np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 4, 8)[:, 0, 7] != 0)[0]
+    same = sum(1 for k in range(len(keys)) if len(set(int(w) % 256 for w in wg[inv == k])) == 1)
+    print(f"  compute units whose workgroups are all congruent mod 256: {same} of {len(keys)}; examples: " + " | ".join(str(list(wg[inv == k])) for k in range(3)))
     print(f"  workgroup duration mean {dur.mean():.2f} p90 {np.percentile(dur, 90):.2f} max {dur.max():.2f}; corr(duration, rows of the workgroup) {np.corrcoef(dur, rows.max(axis=1))[0, 1]:.2f}")
 
 
