@@ -1051,6 +1051,10 @@ template <class T> class Engine final : public EngineBase {
             if (lds_force > (size_t)MAX_LDS_BYTES) throw ApiError{MHIP_ERR_CAPACITY, "prune pass LDS carve-up exceeds 160 KiB"};
         }
         A.blk_center = blk_center.p; A.frc = frc_override ? frc_override : frc[cur].p; A.pe_part = red_part.p;
+        // inside vv_run: the Σ m v partials of the integrator launch before this pass become one partial here (kernels.h, cm_finalize_in_block)
+        A.cm_fin_in = nullptr; A.cm_fin_n = 0; A.cm_fin_out = nullptr;
+        const bool cm_fin = cm_fin_on && in_vv_fused && n_ghost == 0 && part == 0 && cm_pending == 2 && n_cm_step > 1 && n_cm_step <= 4096;
+        if (cm_fin) { cm_fin_buf.reserve(4); A.cm_fin_in = cm_src(); A.cm_fin_n = n_cm_step; A.cm_fin_out = cm_fin_buf.p; }
         static const int level_env = env_int("MOLLYHIP_LEVEL_PAIRS", 1);
         A.level_pairs = (prune && level_env && JS == 2 && !lanes_sorted && !rebalance) ? 1 : 0;
         A.dbg = nullptr;
@@ -1059,6 +1063,7 @@ template <class T> class Engine final : public EngineBase {
         prof.begin(prune ? 4 : 0, stream);   // stage 4 = force passes that also prune the outer list
         tr(prune ? "k_forces (prune)" : (energy ? "k_forces (energy)" : "k_forces"));
         launch_forces_any(A, energy);
+        if (cm_fin) { cm_ext = cm_fin_buf.p; n_cm_step = 1; }
         tr("after k_forces");
         if (prune && rebalance && !lanes_sorted) {
             RebalArgs R{BI, ilog2(BI), JS, R_cap, eshift, (const uint2*)nbr_tmp.p, (const uint16_t*)cnt_in.p, (const int32_t*)tile_cnt_in.p, nbr_in.p, wave_rows_in.p};
@@ -1098,6 +1103,8 @@ template <class T> class Engine final : public EngineBase {
             if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] prune: max disp %.5f nm (margin %.3f) rows %lld exceeded %d calls %lld\n", std::sqrt((double)d2), prune_margin(), (long long)total_rows, (int)prune_disp_exceeded, (long long)n_force_calls);
         }
     }
+
+    DBuf<double> cm_fin_buf; const bool cm_fin_on = env_int("MOLLYHIP_CM_IN_PAIR_PASS", 1) != 0;
 
     // the (block, group) items of the group-split pass handed to its workgroups so that every compute unit gets a like share of rows (forces_gs.hip, k_gs_balance)
     DBuf<uint16_t> gs_item; const bool gs_balance_on = env_int("MOLLYHIP_GS_BALANCE", 1) != 0; int cu_count = 0;

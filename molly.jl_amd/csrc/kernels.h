@@ -1073,7 +1073,22 @@ template <class T> struct ForceArgs {
     // MOLLYHIP_DBG_TIMES (builds with -DMHIP_EXP=11 only): [n_blocks][waves][8] — shader clock and 100 MHz wall clock at kernel entry, behind the
     // staging barrier, behind the row walk and at the end, per wave
     unsigned long long* dbg;
+    // Σ m v of the integrator launch before this pass, still per-block partials (k_vv_mid): workgroup 0 of this pass adds them up into ONE partial behind its own
+    // work, so that the integrator launch behind it can run as many short blocks as it likes without each of them re-summing the partials first.  nullptr: nothing to do
+    const double* cm_fin_in; int cm_fin_n; double* cm_fin_out;
 };
+// (runs behind everything else of workgroup 0: nothing of it is live in the pair loop — in front of it the packed loop spilled 12 bytes, as a call it needed a stack)
+[[maybe_unused]] static __device__ inline void cm_finalize_in_block(const double* __restrict__ part, int n_part, double* out4, unsigned char* smem) {
+    double a[4] = {0, 0, 0, 0};
+    for (int q = threadIdx.x; q < n_part; q += blockDim.x) { const double* p = part + 4 * (int64_t)q; a[0] += p[0]; a[1] += p[1]; a[2] += p[2]; a[3] += p[3]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) for (int c = 0; c < 4; ++c) a[c] += __shfl_xor(a[c], o, 64);
+    double* sh = reinterpret_cast<double*>(smem);
+    if ((threadIdx.x & 63) == 0) for (int c = 0; c < 4; ++c) sh[4 * (threadIdx.x >> 6) + c] = a[c];
+    __syncthreads();
+    if (threadIdx.x < 4) { double t = 0; for (int q = 0; q < (int)(blockDim.x >> 6); ++q) t += sh[4 * q + threadIdx.x]; out4[threadIdx.x] = t; }
+    __syncthreads();
+}
 // strides the packed loop is compiled for (odd numbers of dwords): tiles of up to stride − 1 atoms, 12·stride bytes of LDS.  The
 // smallest that holds the tile is used: 36 KiB leaves room for four 512-lane blocks per CU, 48 KiB for three (measured: −12 % per pass).
 constexpr int SOA_STRIDES[3] = {2049, 3073, 4097};
@@ -1622,6 +1637,9 @@ k_forces(ForceArgs<T> A) {
     }
     if (js == 0 && valid) A.frc[si] = make4<T>(fx, fy, fz, T(0));
     stamp(3);
+    if constexpr (!ENERGY) {
+        if (A.cm_fin_out && wg == 0) { __syncthreads(); cm_finalize_in_block(A.cm_fin_in, A.cm_fin_n, A.cm_fin_out, smem); }
+    }
     if constexpr (ENERGY) {
         if (A.JS > 1) {   // j-split partial sums of the virial, two rounds through the same four LDS slots
             T* red = reinterpret_cast<T*>(smem);
