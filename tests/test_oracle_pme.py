@@ -137,3 +137,26 @@ def test_triclinic_reciprocal_space_zero_tilt_is_the_cubic_one_and_a_sheared_cel
         e1 = sh.potential_energy(None, pairwise=False, general=True)
         assert np.abs(f1 - f0).max() < 5e-5 * np.abs(f0).max(), (basis, np.abs(f1 - f0).max() / np.abs(f0).max())
         assert abs(e1 - e0) < 0.1, (basis, e1 - e0)
+
+
+def test_triclinic_reciprocal_virial_is_the_strain_derivative_of_the_energy():
+    """The reciprocal-space virial on a sheared cell (recip_conv_inner!, ewald.jl:701-723, with m · recip_box) has no fixture in the reference either; it is pinned by
+    what a virial is: W_ab = −∂E/∂ε_ab under the homogeneous strain x → (1 + ε) x of coordinates and cell.  Central differences of the oracle's own reciprocal energy
+    (self term constant, net-charge term ∝ 1/V: its share charge_E · I is part of the tensor, :925-927) on a 48³ mesh, the three diagonal strains and the three shears."""
+    x, q, L = _charges_in_a_box(n=300, L=2.6, seed=3)
+    q = q + 0.02                                                    # a net charge: the charge_E term takes part
+    basis = np.array([[L, 0, 0], [0.35 * L, L, 0], [-0.2 * L, 0.3 * L, L]])
+
+    def energy_and_virial(strain):
+        F = np.eye(3) + strain                                      # x' = F x (row vectors: x @ F.T)
+        o = _pme_case(x @ F.T, q, L, basis=basis @ F.T, mesh=(48, 48, 48)).oracle(np.float64)
+        return o.potential_energy(None, pairwise=False, general=True), o.virial(None, pairwise=False, specific=False, general=True)
+
+    e0, w = energy_and_virial(np.zeros((3, 3)))
+    h = 2e-5
+    for a, b in ((0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2)):      # (upper-triangular shears keep v1 along x and v2 in the xy plane)
+        s = np.zeros((3, 3)); s[a, b] = h
+        de = (energy_and_virial(s)[0] - energy_and_virial(-s)[0]) / (2 * h)
+        # the B-spline weights do not change under a homogeneous strain, so the mesh energy's derivative IS the tensor: agreement at the level of the difference quotient
+        assert abs(-de - w[a, b]) < 1e-6 * np.abs(w).max(), ((a, b), -de, w[a, b])
+    assert np.abs(w - w.T).max() < 1e-9 * np.abs(w).max()
