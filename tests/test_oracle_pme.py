@@ -160,3 +160,19 @@ def test_triclinic_reciprocal_virial_is_the_strain_derivative_of_the_energy():
         # the B-spline weights do not change under a homogeneous strain, so the mesh energy's derivative IS the tensor: agreement at the level of the difference quotient
         assert abs(-de - w[a, b]) < 1e-6 * np.abs(w).max(), ((a, b), -de, w[a, b])
     assert np.abs(w - w.T).max() < 1e-9 * np.abs(w).max()
+
+
+def test_triclinic_reciprocal_forces_are_the_gradient_of_the_energy():
+    """interpolate_force_inner! with a triclinic recip_box (ewald.jl:846-849): the smooth-PME force is the exact gradient of the mesh energy, so central differences of
+    the oracle's reciprocal energy must give it back — on a sheared cell, for a handful of atoms and all three components"""
+    x, q, L = _charges_in_a_box(n=300, L=2.6, seed=5)
+    basis = np.array([[L, 0, 0], [0.35 * L, L, 0], [-0.2 * L, 0.3 * L, L]])
+    f = _pme_case(x, q, L, basis=basis, mesh=(40, 42, 45)).oracle(np.float64).forces(None, pairwise=False, specific=False, general=True)
+    h = 1e-5
+    for i in (0, 17, 123, 299):
+        for d in range(3):
+            xp, xm = x.copy(), x.copy()
+            xp[i, d] += h; xm[i, d] -= h
+            ep = _pme_case(xp, q, L, basis=basis, mesh=(40, 42, 45)).oracle(np.float64).potential_energy(None, pairwise=False, general=True)
+            em = _pme_case(xm, q, L, basis=basis, mesh=(40, 42, 45)).oracle(np.float64).potential_energy(None, pairwise=False, general=True)
+            assert abs(-(ep - em) / (2 * h) - f[i, d]) < 1e-6 * np.abs(f).max(), (i, d, -(ep - em) / (2 * h), f[i, d])
