@@ -176,3 +176,18 @@ def test_triclinic_reciprocal_forces_are_the_gradient_of_the_energy():
             ep = _pme_case(xp, q, L, basis=basis, mesh=(40, 42, 45)).oracle(np.float64).potential_energy(None, pairwise=False, general=True)
             em = _pme_case(xm, q, L, basis=basis, mesh=(40, 42, 45)).oracle(np.float64).potential_energy(None, pairwise=False, general=True)
             assert abs(-(ep - em) / (2 * h) - f[i, d]) < 1e-6 * np.abs(f).max(), (i, d, -(ep - em) / (2 * h), f[i, d])
+
+
+def test_triclinic_ewald_total_energy_does_not_depend_on_the_splitting():
+    """direct space (minimum image on the sheared cell, erfc) + reciprocal space (triclinic recip_box) + self term: the Ewald sum's value must not depend on how α
+    splits it between the two — two cutoffs give two α (α = √(−ln 2 tol) / r_c, ewald.jl:368), the totals agree to the sums' own tolerance"""
+    x, q, L = _charges_in_a_box(n=250, L=2.8, seed=9)
+    basis = np.array([[L, 0, 0], [0.3 * L, L, 0], [0.2 * L, -0.25 * L, L]])
+    e = []
+    for rc in (0.8, 1.15):
+        from tests import systems as S
+        case = S.Case(x, list(np.diag(basis)), coul=dict(kind="ewald", rc=rc, tol=1e-6, approx=False), r_list=rc + 0.05, charge=q, sigma=np.zeros(len(x)), eps=np.zeros(len(x)),
+                      mass=np.ones(len(x)), pme=dict(order=6, mesh=(72, 72, 72)), triclinic=dict(basis=basis, approx_images=False))
+        o = case.oracle(np.float64)
+        e.append(o.potential_energy(o.neighbors("brute"), pairwise=True, general=True))
+    assert abs(e[0] - e[1]) < 2e-5 * abs(e[0]), e
