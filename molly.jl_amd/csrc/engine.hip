@@ -1053,7 +1053,7 @@ template <class T> class Engine final : public EngineBase {
         A.blk_center = blk_center.p; A.frc = frc_override ? frc_override : frc[cur].p; A.pe_part = red_part.p;
         // inside vv_run: the Σ m v partials of the integrator launch before this pass become one partial here (kernels.h, cm_finalize_in_block)
         A.cm_fin_in = nullptr; A.cm_fin_n = 0; A.cm_fin_out = nullptr;
-        const bool cm_fin = cm_fin_on && in_vv_fused && n_ghost == 0 && part == 0 && cm_pending == 2 && n_cm_step > 1 && n_cm_step <= 4096;
+        const bool cm_fin = cm_fin_on && in_vv_fused && !energy && n_ghost == 0 && part == 0 && cm_pending == 2 && n_cm_step > 1 && n_cm_step <= 4096;      // (the energy variants do not carry the sum)
         if (cm_fin) { cm_fin_buf.reserve(4); A.cm_fin_in = cm_src(); A.cm_fin_n = n_cm_step; A.cm_fin_out = cm_fin_buf.p; }
         static const int level_env = env_int("MOLLYHIP_LEVEL_PAIRS", 1);
         A.level_pairs = (prune && level_env && JS == 2 && !lanes_sorted && !rebalance) ? 1 : 0;
