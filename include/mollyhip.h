@@ -421,6 +421,40 @@ int32_t mhip_set_halo_routes(mhip_ctx* ctx, const mhip_halo_routes* routes);
 int32_t mhip_domain_run(mhip_ctx* ctx, int64_t first_step, int64_t n_steps, double dt, int32_t remove_cm_every, double* cm_parts_dev, int32_t n_parts,
                         int64_t* steps_done, int32_t* reason, int64_t* counters3);
 
+
+/* ---- the re-plan INSIDE the engine (SURVEY §8(e) "Migration: every neighbour rebuild ... counts first, then payload"; no reference
+ * counterpart: README.md:54) --------------------------------------------------------------------------------------------------------
+ * mhip_domain_run used to return (*reason = 1) whenever ownership and ghosts had to be redone, and the host migrated atoms, chose ghosts
+ * and registered a new plan (mhip_set_atom_counts / mhip_set_atoms / mhip_set_state / mhip_set_halo_plan / mhip_set_halo_routes).  A
+ * context that knows the decomposition does all of that on the device, in the middle of the step that found the plan stale: behind the
+ * unpack of the step's ghost rows, in front of its force pass — which prunes the freshly searched outer list, as a single domain's pass
+ * does behind an outer search — and the run goes on.  Leavers (position, velocity, parameters, global id) and the new ghosts (shifted
+ * coordinates + parameters) travel as peer stores into a plan area behind each receive region's row halves, their counts as rows of a
+ * count matrix in the region headers; every order is fixed (stayers in local order, arrivals by source rank then sender order, ghosts by
+ * source rank, direction, sender order) — the layout molly.jl_amd/domain.py's host planner makes, so both planners give the same sums.
+ *
+ *   mhip_set_domain    : after the FIRST plan has been set up by the host (atoms, state, halo plan, routes).  grid = bricks per axis
+ *                        (world = their product <= 64; rank r owns brick (r % gx, (r / gx) % gy, r / (gx gy))), box = the periodic box
+ *                        that is cut, r_ghost = r_list + ghost margin.  Cut axes must be open in the context (mhip_config.periodic = 0),
+ *                        uncut ones periodic.  global_ids_dev (nullable: 0 .. n_owned-1): the global index of every owned atom, local
+ *                        order, device int64.  MHIP_ERR_UNSUPPORTED when some rank is not a neighbour of every other (more than two
+ *                        bricks on an axis): such decompositions keep the host planner.  NULL geometry switches the device planner off.
+ *   mhip_domain_info   : out4 = { owned atoms, ghost atoms, re-plans made by the engine, atoms that arrived in them }
+ *   mhip_domain_export : what a host planner keeps per owned atom, local order, device memory (either may be NULL): global ids
+ *                        (int64[n_owned]) and {q, sigma, eps, mass} (real[n_owned][4]).  With mhip_get_state this is the whole
+ *                        sub-domain (gather of a final state, hand-over to a host re-plan).
+ * A re-plan that does not fit (a context's atom capacity, a receive region) fails on EVERY rank with MHIP_ERR_CAPACITY — all of them
+ * see the same count matrix — before anything is committed.  MOLLYHIP_DEVICE_REPLAN=0 keeps the host planner. */
+typedef struct {
+    int32_t grid[3];
+    int32_t rank;
+    double box[3];
+    double r_ghost;
+} mhip_domain_geometry;
+int32_t mhip_set_domain(mhip_ctx* ctx, const mhip_domain_geometry* geometry, const int64_t* global_ids_dev);
+int32_t mhip_domain_info(mhip_ctx* ctx, int64_t* out4);
+int32_t mhip_domain_export(mhip_ctx* ctx, int64_t* global_ids_dev, void* params4_dev);
+
 #ifdef __cplusplus
 }
 #endif

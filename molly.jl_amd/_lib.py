@@ -67,6 +67,11 @@ class HaloRoutes(C.Structure):
                 ("dst_row", C.POINTER(C.c_int64)), ("recv_rows", C.POINTER(C.c_int64))]
 
 
+class DomainGeometry(C.Structure):
+    """mhip_domain_geometry: the brick decomposition as one rank sees it (the re-plan inside the engine)"""
+    _fields_ = [("grid", C.c_int32 * 3), ("rank", C.c_int32), ("box", C.c_double * 3), ("r_ghost", C.c_double)]
+
+
 class LaunchTrial(C.Structure):
     """mhip_launch_trial: one timed workgroup shape of mhip_optimize_launch_config"""
     _fields_ = [("block_atoms", C.c_int32), ("j_split", C.c_int32), ("us_per_pass", C.c_float)]
@@ -145,6 +150,9 @@ SIGNATURES = {
     "mhip_halo_selftest": (_I32, [_P, C.POINTER(_I32)]),
     "mhip_set_halo_routes": (_I32, [_P, C.POINTER(HaloRoutes)]),
     "mhip_domain_run": (_I32, [_P, _I64, _I64, _D, _I32, _P, _I32, C.POINTER(_I64), C.POINTER(_I32), C.POINTER(_I64)]),
+    "mhip_set_domain": (_I32, [_P, C.POINTER(DomainGeometry), _P]),
+    "mhip_domain_info": (_I32, [_P, C.POINTER(_I64 * 4)]),
+    "mhip_domain_export": (_I32, [_P, _P, _P]),
 }
 
 

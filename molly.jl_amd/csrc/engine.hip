@@ -20,6 +20,7 @@
 #include "prune_lean.h"
 #include "hilbert.h"
 #include "kernels.h"
+#include "replan.h"
 #include "forces_launch.h"
 #include "sortscan.h"
 
@@ -99,6 +100,9 @@ struct EngineBase {
     virtual void set_launch_config(int, int) = 0;
     virtual int tune_launch(int, mhip_launch_trial*, int) = 0;
     virtual void domain_run(int64_t, int64_t, double, int32_t, double*, int32_t, int64_t*, int32_t*, int64_t*) = 0;
+    virtual void set_domain(const mhip_domain_geometry*, const int64_t*) = 0;
+    virtual void domain_info(int64_t*) = 0;
+    virtual void domain_export(int64_t*, void*) = 0;
 };
 
 // hipEvent stage timers (only active while profiling is on)
@@ -194,6 +198,7 @@ template <class T> class Engine final : public EngineBase {
         const int want = gs_env > 0 ? gs_env : 4;
         if (want != 4 || JS % want != 0 || BI * (JS / want) != 256) return 0;      // (k_forces_gs is a 256-lane workgroup: 64 atoms × 4 waves of a 16-way j-split)
         if (gs_env < 0 && (int64_t)n_blocks * JS * (BI / WAVE) > 2 * 4096) return 0;      // enough workgroups already: large systems balance themselves
+        if ((int64_t)n_blocks * want > 16384) return 0;      // (forced or not: the (block, group) items are uint16 and k_gs_balance stages n_blocks·GS ints in 64 KiB of LDS)
         return want;
     }
     // (measured, profiles/r04_force_ab.txt §2: the 1M-atom plain pass gains 6.7 % — 136 M → 128 M slots — and the copy of the 272 MB list costs
@@ -316,7 +321,7 @@ template <class T> class Engine final : public EngineBase {
         nbr_tmp.release(); rows_tmp.release(); nbr_gs.release(); rows_gs.release(); frc_parts.release(); wave_rows_in.release(); nbr_in.release(); pos_snap.release(); blk_disp2.release(); tile_idx_in.release(); tile_cnt_in.release(); rows_x.release(); nbr_x.release(); tile_idx_x.release(); tile_cnt_x.release(); blk_ghost.release(); blk_ghost_in.release();
         xl_start.release(); xl_list.release(); tile_idx.release(); tile_cnt.release(); wave_rows.release(); nbr.release(); blk_center.release();
         flags.release(); red_part.release(); red_out.release(); cm_step.release(); vcm.release(); stage_a.release(); stage_b.release(); stage_i.release(); bonded.release(); pme.release(); frc_scratch.release(); nl_counter.release(); state_changed.release();
-        xf_release();
+        xf_release(); dom_release();
         prof.release();
         for (int k = 0; k < 2; ++k) { if (side[k]) { (void)hipStreamSynchronize(side[k]); (void)hipStreamDestroy(side[k]); } if (ev_side[k]) (void)hipEventDestroy(ev_side[k]); frc_side[k].release(); }
         if (ev_pos) (void)hipEventDestroy(ev_pos);
@@ -963,7 +968,8 @@ template <class T> class Engine final : public EngineBase {
                 if (gs_lds_bytes(q_lds, BI, JS / GS) <= (size_t)MAX_LDS_BYTES / GS) {
                     frc_parts.reserve((size_t)(GS - 1) * cap);
                     GsArgs Z;
-                    Z.G = G; Z.I = I; Z.n_owned = n_owned; Z.BI = BI; Z.BI_shift = ilog2(BI); Z.JS = JS; Z.GS = GS; Z.lgGS = ilog2(GS); Z.R_cap = R_cap; Z.T_cap = T_cap; Z.Q_lds = q_lds;
+                    Z.G = G; Z.I = I; Z.n_owned = n_owned; Z.BI = BI; Z.BI_shift = ilog2(BI); Z.JS = JS; Z.GS = GS; Z.lgGS = ilog2(GS); Z.R_cap = GS * R_cap;      // (the group-split list's own row capacity: RegroupArgs::R_cap_dst)
+                     Z.T_cap = T_cap; Z.Q_lds = q_lds;
                     Z.n_blocks = n_blocks; Z.spread = std::max(1, n_blocks / GS + 5);
                     Z.pos = pos[cur].p; Z.lj = lj[cur].p; Z.tile_idx = inner_is_outer ? tile_idx.p : tile_idx_in.p; Z.tile_cnt = inner_is_outer ? tile_cnt.p : tile_cnt_in.p; Z.nbr = nbr_gs.p; Z.wave_rows = rows_gs.p; Z.blk_center = blk_center.p;
                     Z.frc = frc[cur].p; Z.parts = frc_parts.p; Z.part_stride = cap;
@@ -1073,9 +1079,9 @@ template <class T> class Engine final : public EngineBase {
         }
         if constexpr (std::is_same<T, float>::value) {
             if (prune && GS > 0 && !lanes_sorted && !rebalance) {      // the list this prune wrote, dealt to the groups (it stays as it is for every other kind of pass)
-                nbr_gs.reserve((size_t)n_blocks * JS * R_cap * BI); rows_gs.reserve((size_t)n_blocks * JS * (BI / WAVE));
+                nbr_gs.reserve((size_t)n_blocks * JS * GS * R_cap * BI); rows_gs.reserve((size_t)n_blocks * JS * (BI / WAVE));
                 RegroupArgs R{BI, ilog2(BI), JS, GS, ilog2(GS), R_cap, (const uint2*)nbr_in.p, (const uint16_t*)cnt_in.p, (const int32_t*)tile_cnt_in.p, nbr_gs.p, rows_gs.p,
-                              (int)std::min<size_t>((size_t)MAX_LDS_BYTES - (size_t)JS * BI * 16 - 64, (size_t)JS * R_cap * BI * 8)};
+                              (int)std::min<size_t>((size_t)MAX_LDS_BYTES - (size_t)JS * BI * 16 - 64, (size_t)JS * R_cap * BI * 8), GS * R_cap};
                 tr("k_regroup");
                 launch_regroup(R, n_blocks, stream);
                 gs_balance();
@@ -1122,9 +1128,9 @@ template <class T> class Engine final : public EngineBase {
         prof.begin(4, stream);
         pos_snap_in.reserve(cap);
         MHIP_HIP(hipMemcpyAsync(pos_snap_in.p, pos[cur].p, (size_t)n_tot * sizeof(T4), hipMemcpyDeviceToDevice, stream));
-        nbr_gs.reserve((size_t)n_blocks * JS * R_cap * BI); rows_gs.reserve((size_t)n_blocks * JS * (BI / WAVE));
+        nbr_gs.reserve((size_t)n_blocks * JS * GS * R_cap * BI); rows_gs.reserve((size_t)n_blocks * JS * (BI / WAVE));
         RegroupArgs R{BI, ilog2(BI), JS, GS, ilog2(GS), R_cap, (const uint2*)nbr.p, (const uint16_t*)cnt_outer.p, (const int32_t*)tile_cnt.p, nbr_gs.p, rows_gs.p,
-                      (int)std::min<size_t>((size_t)MAX_LDS_BYTES - (size_t)JS * BI * 16 - 64, (size_t)JS * R_cap * BI * 8)};
+                      (int)std::min<size_t>((size_t)MAX_LDS_BYTES - (size_t)JS * BI * 16 - 64, (size_t)JS * R_cap * BI * 8), GS * R_cap};
         static const int dbg_rg = env_int("MOLLYHIP_DBG_TIMES", 0);
         if (dbg_rg) { dbg_buf.reserve((size_t)n_blocks * 16 * 8); R.dbg = dbg_buf.p; }
         tr("k_regroup (outer list)");
@@ -1388,15 +1394,7 @@ template <class T> class Engine final : public EngineBase {
             MHIP_HIP(hipMemcpyAsync(&h2[0], ds, sizeof(T), hipMemcpyDeviceToHost, stream));
             MHIP_HIP(hipMemcpyAsync(&h2[1], de, sizeof(T), hipMemcpyDeviceToHost, stream));
             MHIP_HIP(hipStreamSynchronize(stream));
-            const bool uni = h_flags[FLAG_NAN] == 0 && h2[0] != T(0) && h2[1] != T(0);
-            if (uni) {
-                T sm = (h2[0] + h2[0]) / T(2), em = std::sqrt(h2[1] * h2[1]);   // the mixing rules applied to equal values
-                I.lj_s2 = sm * sm; I.lj_24e = T(24) * em; I.lj_4e = T(4) * em;
-                const double s6 = std::pow((double)sm, 6), c6 = 24.0 * (double)em * s6, c12 = 48.0 * (double)em * s6 * s6;
-                const bool normal = c12 > 1e-30 && c12 < 1e30 && c6 > 1e-30 && c6 < 1e30;   // else: the generic loop, which works on σ²/r²
-                I.lj_c6 = normal ? T(c6) : T(0); I.lj_c12 = normal ? T(c12) : T(0);
-                ljm = LJ_DIST_UNIFORM;
-            }
+            apply_uniform(h_flags[FLAG_NAN] == 0, h2[0], h2[1]);
         }
         if (want_eshift() != eshift) stale = true;   // the lists in use are in the other entry format
         pc_valid = false;   // Σq, Σq² of the PME self / net-charge terms are read back only when an energy asks for them
@@ -1909,6 +1907,7 @@ template <class T> class Engine final : public EngineBase {
                                pos[cur].p, cm_all.p, std::max(hp.cm_rows, 1), W);
         }
         cur_dt = dt;
+        if (replan_now) { replan_now = false; device_replan(step_n); }            // (mhip_domain_run: ownership, ghosts and the outer list redone here, in front of the step's force pass)
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         const bool due = check_due(step_n, every) && step_n != last_build_step && (n_ghost == 0 || dual);
         if (due && dual) refresh(step_n);
@@ -1947,6 +1946,7 @@ template <class T> class Engine final : public EngineBase {
         uint32_t seq = 0, plan_seq = 0;
         float* h_red3 = nullptr; int32_t* h_err = nullptr; hipEvent_t ev_plan = nullptr;
         bool plan_pending = false; int64_t plan_step = -1, next_check = -1;
+        RpPlanPtrs plan{}; uint32_t rp_seq = 0;      // every rank's plan area; number of the last re-plan made inside the engine (replan.h)
     } xf;
     bool xf_direct = false;      // inside mhip_domain_run: k_halo_pack stores into the peers' regions, k_halo_unpack waits for theirs
     T* xf_rows(int parity) const { return reinterpret_cast<T*>(xf.region + XFER_ROWS_OFF) + (size_t)parity * xf.rows_cap * 3; }
@@ -1965,13 +1965,15 @@ template <class T> class Engine final : public EngineBase {
         MHIP_HIP(hipStreamSynchronize(stream));
         if (!xf.region || xf.rows_cap < rows_cap || xf.world != world || xf.rank != my_rank) {
             if (xf.region) xf_release();
-            const size_t bytes = XFER_ROWS_OFF + 2 * (size_t)rows_cap * 3 * sizeof(T);
+            const size_t bytes = xfer_region_bytes<T>(rows_cap);      // header | two row halves | plan area (replan.h)
             MHIP_HIP(hipExtMallocWithFlags((void**)&xf.region, bytes, hipDeviceMallocFinegrained));
             MHIP_HIP(hipMemset(xf.region, 0, bytes));
             MHIP_HIP(hipMemcpy(xf.region + offsetof(XferHeader, rows_cap), &rows_cap, sizeof(int64_t), hipMemcpyHostToDevice));
             xf.rows_cap = rows_cap; xf.world = world; xf.rank = my_rank; xf.seq = 0; xf.plan_seq = 0; xf.routes = false;
             for (int r = 0; r < XFER_MAX_RANKS; ++r) xf.peers.region[r] = nullptr;
-            xf.peers.region[my_rank] = xf.region;
+            xf.peers.region[my_rank] = xf.region; xf.peer_cap[my_rank] = rows_cap;
+            for (int r = 0; r < XFER_MAX_RANKS; ++r) xf.plan.area[r] = nullptr;
+            xf.plan.area[my_rank] = xf.region + xfer_plan_off<T>(rows_cap);
             xf.done.reserve(1); xf.err.reserve(1); xf.mine3.reserve(4); xf.red3.reserve(4);
             MHIP_HIP(hipMemset(xf.done.p, 0, sizeof(unsigned int))); MHIP_HIP(hipMemset(xf.err.p, 0, sizeof(int32_t)));
             if (!xf.h_red3) MHIP_HIP(hipHostMalloc((void**)&xf.h_red3, 4 * sizeof(float)));
@@ -1996,6 +1998,7 @@ template <class T> class Engine final : public EngineBase {
         xf.peers.region[rank] = (unsigned char*)base; xf.opened[rank] = true;
         // the peer may have been created with another capacity than this rank: its own header is the authority on what fits there
         MHIP_HIP(hipMemcpy(&xf.peer_cap[rank], (unsigned char*)base + offsetof(XferHeader, rows_cap), sizeof(int64_t), hipMemcpyDeviceToHost));
+        xf.plan.area[rank] = (unsigned char*)base + xfer_plan_off<T>(xf.peer_cap[rank]);
     }
     // where the rows of the current ghost plan travel: consecutive segments of the send buffer → (peer, first row in the peer's half)
     void set_halo_routes(const mhip_halo_routes* rt) override {
@@ -2100,8 +2103,11 @@ template <class T> class Engine final : public EngineBase {
                 if (ghost_margin <= 0 && n_ghost > 0) replan = s % every == 0;      // no margin: ownership and ghosts are redone at every rebuild step
                 else if (s % every == 0 || (xf.next_check >= 0 && s >= xf.next_check)) { xf.next_check = -1; xf_issue_plan_check(s); if (counters) counters[0] += 1; }
             }
+            // the re-plan inside the engine (replan.h): the step goes on — unpack, re-plan + search, forces (pruning), integrator, pack with the new plan
+            const bool replan_here = replan && dev_replan_ok();
+            if (replan_here) { replan = false; replan_now = true; }
             const bool stop = replan || s == last;
-            if (n_ghost > 0 && xf.n_peers > 0) (void)halo_interior(s);          // the blocks that need no ghost, while the peers' rows arrive
+            if (n_ghost > 0 && xf.n_peers > 0 && !replan_here) (void)halo_interior(s);          // the blocks that need no ghost, while the peers' rows arrive
             halo_mid(s, dt, (cm ? 1 : 0) | (stop ? 2 : 0), (cm && stop) ? cm_parts_dev : nullptr, (cm && stop) ? n_parts : 0);   // waits + unpacks … packs + sends
             ++*steps_done;
             // (a check issued at the LAST step of this call stays pending: the first step of the next call reads it, one step late like any
@@ -2110,6 +2116,192 @@ template <class T> class Engine final : public EngineBase {
             if (stop) { *reason = replan ? 1 : 0; if (replan) xf.plan_pending = false; break; }
         }
         xf_check_errors();      // (one stream sync per call: a chunk is ≈ 100 steps)
+    }
+
+
+    // ---- the re-plan inside the engine (replan.h; SURVEY §8(e) "Migration"): ownership, ghosts and the per-step message tables are redone on the
+    // device when the collective check says so, in the middle of mhip_domain_run's step — behind the unpack of the step's ghost rows (which also
+    // carry the peers' Σ m v of the step before), in front of its force pass, which then prunes the freshly searched outer list exactly as a
+    // single domain's pass does behind an outer search.  The host reads one table (counts, error word) and runs the search.
+    struct Dom {
+        bool ready = false; int world = 1, me = 0; int64_t n_replans = 0, n_migrated = 0;
+        DBuf<int64_t> gid[2]; int gcur = 0;
+        DBuf<RpTab> tab; RpTab* h_tab = nullptr; T* h_lj0 = nullptr;
+        DBuf<uint32_t> mask; DBuf<int32_t> blk_cnt, blk_off, err, ranks;
+        DBuf<int32_t> send_idx, send_cm_pos, recv_dst; DBuf<T> send_shift;
+        int64_t tables_cap = 0;
+    } dom;
+    ReplanGeom<T> dom_g{};
+    const bool dev_replan_env = env_int("MOLLYHIP_DEVICE_REPLAN", 1) != 0;
+    bool replan_now = false;
+    T uni_s0 = T(0), uni_e0 = T(0);      // σ, ϵ of the one atom type the uniform-LJ constants were made for (set_atoms)
+
+    void dom_release() {
+        dom.gid[0].release(); dom.gid[1].release(); dom.tab.release(); dom.mask.release(); dom.blk_cnt.release(); dom.blk_off.release(); dom.err.release(); dom.ranks.release();
+        dom.send_idx.release(); dom.send_cm_pos.release(); dom.recv_dst.release(); dom.send_shift.release();
+        if (dom.h_tab) (void)hipHostFree(dom.h_tab); if (dom.h_lj0) (void)hipHostFree(dom.h_lj0);
+        dom.h_tab = nullptr; dom.h_lj0 = nullptr; dom.ready = false;
+    }
+
+    // ≙ BrickGrid of molly.jl_amd/domain.py: the bricks, this rank's neighbour directions sorted by (peer rank, direction vector), the periodic shift of
+    // each, the face thresholds in T — every number formed the way the host planner forms it, so that both planners select the same atoms
+    void set_domain(const mhip_domain_geometry* gm, const int64_t* gids_dev) override {
+        if (!gm) { dom.ready = false; return; }
+        const int gx = gm->grid[0], gy = gm->grid[1], gz = gm->grid[2];
+        if (gx < 1 || gy < 1 || gz < 1 || (int64_t)gx * gy * gz > XFER_MAX_RANKS) throw ApiError{MHIP_ERR_INVALID, "domain geometry: 1 .. 64 bricks"};
+        const int world = gx * gy * gz, me = gm->rank;
+        if (me < 0 || me >= world) throw ApiError{MHIP_ERR_INVALID, "domain geometry: rank out of range"};
+        if (!(gm->r_ghost > 0) && world > 1) throw ApiError{MHIP_ERR_INVALID, "domain geometry: ghost reach must be positive"};
+        const int grid[3] = {gx, gy, gz}, coord[3] = {me % gx, (me / gx) % gy, me / (gx * gy)};
+        ReplanGeom<T> g{};
+        g.world = world; g.me = me; g.cm_rows = sizeof(T) == 4 ? 3 : 2;
+        for (int d = 0; d < 3; ++d) {
+            if (!(gm->box[d] > 0)) throw ApiError{MHIP_ERR_INVALID, "domain geometry: box sides must be positive"};
+            const double brick = gm->box[d] / grid[d], lo = brick * coord[d], hi = lo + brick;
+            g.grid[d] = grid[d]; g.box[d] = T(gm->box[d]); g.brick[d] = T(brick); g.cut[d] = grid[d] > 1 ? 1 : 0;
+            g.near_lo[d] = T(lo + gm->r_ghost); g.near_hi[d] = T(hi - gm->r_ghost);
+            if (grid[d] > 1 && brick < gm->r_ghost) throw ApiError{MHIP_ERR_INVALID, "domain geometry: a brick is narrower than the ghost reach"};
+            if ((grid[d] > 1) == (cfg.periodic[d] != 0)) throw ApiError{MHIP_ERR_INVALID, "domain geometry: cut axes must be open in the context, uncut ones periodic"};
+        }
+        struct Dir { int peer; int v[3]; double sh[3]; };
+        std::vector<Dir> dirs;
+        for (int a = -1; a <= 1; ++a) for (int b = -1; b <= 1; ++b) for (int c = -1; c <= 1; ++c) {
+            const int v[3] = {a, b, c};
+            if ((!a && !b && !c) || (a && gx == 1) || (b && gy == 1) || (c && gz == 1)) continue;
+            Dir D{}; int pc[3];
+            for (int d = 0; d < 3; ++d) {
+                int q = coord[d] + v[d]; double sh = 0;
+                if (q < 0) { q += grid[d]; sh = +gm->box[d]; } else if (q >= grid[d]) { q -= grid[d]; sh = -gm->box[d]; }
+                pc[d] = q; D.v[d] = v[d]; D.sh[d] = sh;
+            }
+            D.peer = (pc[2] * gy + pc[1]) * gx + pc[0];
+            dirs.push_back(D);
+        }
+        std::sort(dirs.begin(), dirs.end(), [](const Dir& x, const Dir& y) { if (x.peer != y.peer) return x.peer < y.peer; for (int d = 0; d < 3; ++d) if (x.v[d] != y.v[d]) return x.v[d] < y.v[d]; return false; });
+        if ((int)dirs.size() > RP_MAX_DIRS) throw ApiError{MHIP_ERR_INVALID, "domain geometry: more than 26 directions"};
+        std::vector<char> is_peer(world, 0);
+        g.n_dirs = (int)dirs.size();
+        for (int k = 0; k < g.n_dirs; ++k) {
+            if (dirs[k].peer == me) throw ApiError{MHIP_ERR_UNSUPPORTED, "domain geometry: a brick that neighbours itself (one brick on a cut axis)"};
+            is_peer[dirs[k].peer] = 1; g.dir_peer[k] = dirs[k].peer;
+            for (int d = 0; d < 3; ++d) { g.dvec[k][d] = (signed char)dirs[k].v[d]; g.dir_shift[k][d] = T(dirs[k].sh[d]); }
+        }
+        // the fused per-step message (Σ m v on the ghost rows) needs every other rank as a peer: 1, 2, 4, 8 bricks
+        for (int r = 0; r < world; ++r) if (r != me && !is_peer[r]) throw ApiError{MHIP_ERR_UNSUPPORTED, "the in-engine re-plan covers decompositions in which every other rank is a neighbour (1, 2, 4 or 8 bricks)"};
+        MHIP_HIP(hipStreamSynchronize(stream));
+        dom_g = g; dom.world = world; dom.me = me;
+        dom.gid[0].reserve(cap); dom.gid[1].reserve(cap); dom.gcur = 0;
+        if (gids_dev) MHIP_HIP(hipMemcpyAsync(dom.gid[0].p, gids_dev, (size_t)n_owned * sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
+        else { std::vector<int64_t> io((size_t)n_owned); for (int64_t i = 0; i < n_owned; ++i) io[i] = i; MHIP_HIP(hipMemcpy(dom.gid[0].p, io.data(), io.size() * sizeof(int64_t), hipMemcpyHostToDevice)); }
+        dom.tab.reserve(1); dom.err.reserve(1); dom.ranks.reserve(XFER_MAX_RANKS);
+        MHIP_HIP(hipMemsetAsync(dom.err.p, 0, sizeof(int32_t), stream));
+        if (!dom.h_tab) MHIP_HIP(hipHostMalloc((void**)&dom.h_tab, sizeof(RpTab)));
+        if (!dom.h_lj0) MHIP_HIP(hipHostMalloc((void**)&dom.h_lj0, 2 * sizeof(T)));
+        std::vector<int32_t> others; for (int r = 0; r < world; ++r) if (r != me) others.push_back(r);
+        if (!others.empty()) MHIP_HIP(hipMemcpyAsync(dom.ranks.p, others.data(), others.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        MHIP_HIP(hipStreamSynchronize(stream));
+        dom.ready = true;
+    }
+    void domain_info(int64_t* out4) override { out4[0] = n_owned; out4[1] = n_ghost; out4[2] = dom.n_replans; out4[3] = dom.n_migrated; }
+    void domain_export(int64_t* gid_dev, void* par4_dev) override {
+        if (!dom.ready) throw ApiError{MHIP_ERR_STATE, "mhip_set_domain first"};
+        hipLaunchKernelGGL(k_rp_export<T>, dim3(cdiv(n_owned, 256)), dim3(256), 0, stream, n_owned, (const int32_t*)inv.p, (const T4*)pos[cur].p, (const T4*)vel[cur].p, (const T2*)lj[cur].p,
+                           (const int64_t*)dom.gid[dom.gcur].p, gid_dev, (T*)par4_dev);
+        MHIP_HIP(hipGetLastError());
+    }
+    bool dev_replan_ok() const {
+        if (!dom.ready || !dev_replan_env || !hp_set) return false;
+        if (dom.world == 1) return n_ghost == 0;
+        if (!xf.region || !xf.routes || xf.n_peers != dom.world - 1 || xf.world != dom.world || hp.cm_rows != dom_g.cm_rows) return false;
+        for (int r = 0; r < dom.world; ++r) if (!xf.peers.region[r] || !xf.plan.area[r]) return false;
+        return true;
+    }
+    // the one-type LJ decision of set_atoms, from σ and ϵ of atom 0 and the "some atom differs" word of the device check
+    void apply_uniform(bool all_equal, T s0, T e0) {
+        ljm = ljm_base;
+        if (ljm_base == LJ_DIST && !tri_mode && !env_int("MOLLYHIP_NO_UNIFORM_LJ", 0) && all_equal && s0 != T(0) && e0 != T(0)) {
+            T sm = (s0 + s0) / T(2), em = std::sqrt(e0 * e0);   // the mixing rules applied to equal values
+            I.lj_s2 = sm * sm; I.lj_24e = T(24) * em; I.lj_4e = T(4) * em;
+            const double s6 = std::pow((double)sm, 6), c6 = 24.0 * (double)em * s6, c12 = 48.0 * (double)em * s6 * s6;
+            const bool normal = c12 > 1e-30 && c12 < 1e30 && c6 > 1e-30 && c6 < 1e30;   // else: the generic loop, which works on σ²/r²
+            I.lj_c6 = normal ? T(c6) : T(0); I.lj_c12 = normal ? T(c12) : T(0);
+            ljm = LJ_DIST_UNIFORM;
+        }
+        uni_s0 = s0; uni_e0 = e0;
+    }
+    void device_replan(int64_t step_n) {
+        ++dom.n_replans;
+        if (dom.world == 1) { rebuild(step_n); return; }      // one brick: nobody to hand atoms to, no ghosts — an outer-list rebuild, as in mhip_vv_run
+        const ReplanGeom<T>& g = dom_g;
+        const int world = g.world, me = g.me, cr = g.cm_rows;
+        const int o = cur, n = 1 - cur, go = dom.gcur, gn = 1 - dom.gcur;
+        const int nb = cdiv(cap, 256);
+        if (dom.tables_cap < xf.rows_cap) {
+            dom.send_idx.reserve(xf.rows_cap); dom.send_shift.reserve(3 * (size_t)xf.rows_cap); dom.recv_dst.reserve(xf.rows_cap); dom.send_cm_pos.reserve((size_t)XFER_MAX_RANKS * 4);
+            xf.row_peer.reserve(xf.rows_cap); xf.row_dst.reserve(xf.rows_cap);
+            dom.tables_cap = xf.rows_cap;
+        }
+        dom.mask.reserve(cap); dom.blk_cnt.reserve((size_t)RP_MAX_DIRS * nb); dom.blk_off.reserve((size_t)RP_MAX_DIRS * nb);
+        const uint32_t seq = ++xf.rp_seq;
+        const XferHeader* mine = reinterpret_cast<const XferHeader*>(xf.region);
+        const unsigned long long ticks = xf_ticks();
+        const int n_old = (int)n_owned;
+        MHIP_HIP(hipMemsetAsync(dom.tab.p, 0, sizeof(RpTab), stream));
+        // A. migration
+        tr("k_rp_owner_keys");
+        hipLaunchKernelGGL(k_rp_owner_keys<T>, dim3(cdiv(n_owned, 256)), dim3(256), 0, stream, n_owned, (const T4*)pos[o].p, (const int32_t*)inv.p, g, key_in.p, idx_in.p, dom.tab.p);
+        size_t tb = cub_tmp.n;
+        MHIP_HIP(sort_pairs_u32(cub_tmp.p, tb, key_in.p, key_out.p, idx_in.p, perm.p, n_old, ilog2(world + 1) + 1, stream));
+        tr("k_rp_exchange<0>");
+        hipLaunchKernelGGL(k_rp_exchange<0>, dim3(1), dim3(64), 0, stream, xf.peers, mine, world, me, seq, dom.tab.p, cr, n_old, (int)cap, (int)xf.rows_cap, dom.err.p, ticks);
+        tr("k_rp_mig_send");
+        hipLaunchKernelGGL(k_rp_mig_send<T>, dim3(64), dim3(256), 0, stream, (const RpTab*)dom.tab.p, (const uint32_t*)key_out.p, (const int32_t*)perm.p, (const int32_t*)inv.p, (const T4*)pos[o].p,
+                           (const T4*)vel[o].p, (const T2*)lj[o].p, (const int64_t*)dom.gid[go].p, g, xf.plan, xf.peers, (const int32_t*)dom.ranks.p, world - 1, seq, xf.done.p);
+        hipLaunchKernelGGL(k_rp_wait_rows<0>, dim3(1), dim3(64), 0, stream, mine, world, me, seq, dom.tab.p, dom.err.p, ticks);
+        tr("k_rp_compact");
+        hipLaunchKernelGGL(k_rp_compact<T>, dim3(std::min(cdiv(cap, 256), 1024)), dim3(256), 0, stream, (const RpTab*)dom.tab.p, (const int32_t*)perm.p, (const int32_t*)inv.p, (const T4*)pos[o].p,
+                           (const T4*)vel[o].p, (const T2*)lj[o].p, (const int64_t*)dom.gid[go].p, g, (const unsigned char*)xf.plan.area[me], pos[n].p, vel[n].p, lj[n].p, dom.gid[gn].p);
+        // B. ghost plan
+        tr("k_rp_ghost_count");
+        hipLaunchKernelGGL(k_rp_ghost_count<T>, dim3(nb), dim3(256), 0, stream, (const RpTab*)dom.tab.p, (const T4*)pos[n].p, g, dom.mask.p, dom.blk_cnt.p);
+        hipLaunchKernelGGL(k_rp_ghost_scan<T>, dim3(1), dim3(1024), 0, stream, dom.tab.p, g, nb, (const int32_t*)dom.blk_cnt.p, dom.blk_off.p);
+        tr("k_rp_exchange<1>");
+        hipLaunchKernelGGL(k_rp_exchange<1>, dim3(1), dim3(64), 0, stream, xf.peers, mine, world, me, seq, dom.tab.p, cr, n_old, (int)cap, (int)xf.rows_cap, dom.err.p, ticks);
+        tr("k_rp_ghost_send");
+        hipLaunchKernelGGL(k_rp_ghost_send<T>, dim3(nb + 1), dim3(256), 0, stream, (const RpTab*)dom.tab.p, (const T4*)pos[n].p, (const T4*)vel[n].p, (const T2*)lj[n].p, (const uint32_t*)dom.mask.p,
+                           (const int32_t*)dom.blk_off.p, nb, g, dom.send_idx.p, dom.send_shift.p, dom.send_cm_pos.p, xf.row_peer.p, xf.row_dst.p, xf.plan, xf.peers, (const int32_t*)dom.ranks.p, world - 1, seq, xf.done.p);
+        hipLaunchKernelGGL(k_rp_wait_rows<1>, dim3(1), dim3(64), 0, stream, mine, world, me, seq, dom.tab.p, dom.err.p, ticks);
+        tr("k_rp_ghost_recv");
+        hipLaunchKernelGGL(k_rp_ghost_recv<T>, dim3(std::min(cdiv(cap, 256), 1024)), dim3(256), 0, stream, dom.tab.p, g, (const unsigned char*)xf.plan.area[me], pos[n].p, vel[n].p, lj[n].p, dom.recv_dst.p);
+        MHIP_HIP(hipGetLastError());
+        MHIP_HIP(hipMemcpyAsync(dom.h_tab, dom.tab.p, sizeof(RpTab), hipMemcpyDeviceToHost, stream));
+        MHIP_HIP(hipMemcpyAsync(dom.h_lj0, lj[n].p, sizeof(T2), hipMemcpyDeviceToHost, stream));
+        MHIP_HIP(hipStreamSynchronize(stream));
+        const RpTab& t = *dom.h_tab;
+        if (t.err) {
+            MHIP_HIP(hipMemset(dom.err.p, 0, sizeof(int32_t)));
+            if (t.err & RP_ERR_TIMEOUT) throw ApiError{MHIP_ERR_STATE, "re-plan: a peer's counts or rows did not arrive in time (MOLLYHIP_XFER_TIMEOUT_MS)"};
+            throw ApiError{MHIP_ERR_CAPACITY, std::string("re-plan: ") + ((t.err & RP_ERR_ATOMS) ? "a sub-domain's atoms + ghosts exceed its context capacity" : (t.err & RP_ERR_PLAN_AREA) ? "the migrating atoms exceed a plan area"
+                                             : "the ghost rows exceed a receive region") + " (create the contexts with more room)"};
+        }
+        if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip %d] re-plan at step %lld: %d stay, %d leave, %d arrive; %d ghost rows out, %d ghosts in\n", me, (long long)step_n, t.n_stay, t.n_leave, t.n_arrive, t.n_send, t.n_ghost);
+        // commit: the new local set in its identity order
+        cur = n; dom.gcur = gn; dom.n_migrated += t.n_arrive;
+        n_owned = t.n_owned; n_ghost = t.n_ghost; n_tot = n_owned + n_ghost;
+        hipLaunchKernelGGL(k_iota2, dim3(std::min(cdiv(n_tot, 256), 1024)), dim3(256), 0, stream, n_tot, orig[cur].p, inv.p);
+        MHIP_HIP(hipMemsetAsync(frc[cur].p, 0, n_tot * sizeof(T4), stream));
+        stale = true; frc_valid = false; trk_issued = false; interior_done = false; frc_run_total = false; coords_moved = false; state_pending = false;
+        const int size_class = n_owned >= 100000 ? 2 : (n_owned >= 40000 ? 1 : 0);
+        const long long key = (n_ghost > 0 ? 1 : 0) | (dual_disabled ? 2 : 0) | (size_class << 2) | (margin_halvings << 4) | (margin_zero ? 128 : 0) | ((long long)std::llround(ghost_margin * 1e6) << 8);
+        if (key != grid_key) { setup_grid(); choose_blocking(); grid_key = key; }
+        const bool all_equal = t.uni_bad == 0;
+        if ((ljm == LJ_DIST_UNIFORM) != (ljm_base == LJ_DIST && all_equal && dom.h_lj0[0] != T(0) && dom.h_lj0[1] != T(0)) || dom.h_lj0[0] != uni_s0 || dom.h_lj0[1] != uni_e0) apply_uniform(all_equal, dom.h_lj0[0], dom.h_lj0[1]);
+        // the per-step message of the new plan (mhip_halo_plan, mhip_halo_routes): tables made by the kernels above
+        hp.first_ghost = n_owned; hp.n_recv_rows = t.n_ghost + (world - 1) * cr; hp.recv = nullptr; hp.recv_dst = dom.recv_dst.p;
+        hp.n_cm_peers = world - 1; hp.cm_rows = cr; hp.send_idx = dom.send_idx.p; hp.send_shift = dom.send_shift.p;
+        hp.n_send_rows = t.n_send + (world - 1) * cr; hp.send = nullptr; hp.send_cm_pos = dom.send_cm_pos.p; hp.n_send_cm = (world - 1) * cr;
+        xf.plan_pending = false; xf.next_check = -1;
+        rebuild(step_n);
     }
 
     // one MD step of a ghosted sub-domain in two calls around the ghost exchange
@@ -2536,6 +2728,9 @@ int32_t mhip_domain_run(mhip_ctx* ctx, int64_t first_step, int64_t n_steps, doub
         if (remove_cm_every != 0 && (!cm_parts_dev || n_parts < 1 || n_parts > 1024)) throw mhip::ApiError{MHIP_ERR_INVALID, "mhip_domain_run: n_parts must be 1..1024 when the centre-of-mass motion is removed"};
         ctx->e->domain_run(first_step, n_steps, dt, remove_cm_every, cm_parts_dev, n_parts, steps_done, reason, counters3); });
 }
+int32_t mhip_set_domain(mhip_ctx* ctx, const mhip_domain_geometry* g, const int64_t* gids_dev) { NEED_CTX(); return guard(ctx, [&] { ctx->e->set_domain(g, gids_dev); }); }
+int32_t mhip_domain_info(mhip_ctx* ctx, int64_t* out4) { NEED_CTX(); return guard(ctx, [&] { if (!out4) throw mhip::ApiError{MHIP_ERR_INVALID, "null output"}; ctx->e->domain_info(out4); }); }
+int32_t mhip_domain_export(mhip_ctx* ctx, int64_t* gid_dev, void* par4_dev) { NEED_CTX(); return guard(ctx, [&] { ctx->e->domain_export(gid_dev, par4_dev); }); }
 int32_t mhip_vv_halo_begin(mhip_ctx* ctx, double dt, const int32_t* idx, const void* shift, int64_t n, void* out) { NEED_CTX(); return guard(ctx, [&] { ctx->e->halo_begin(dt, idx, shift, n, out); }); }
 int32_t mhip_vv_halo_interior(mhip_ctx* ctx, int64_t step_n, int32_t* launched) { NEED_CTX(); return guard(ctx, [&] { int r = ctx->e->halo_interior(step_n); if (launched) *launched = r; }); }
 int32_t mhip_vv_halo_end(mhip_ctx* ctx, int64_t step_n, double dt, int64_t first, int64_t n, const void* in, double* cm_out4) {

@@ -28,6 +28,8 @@ namespace mhip {
 // dst: same geometry; an atom's entries with slot ≡ g (mod GS), numbered k = 0, 1, … in the order of the source sub-lists, are DEALT to the
 // JSW waves of group g: entry k goes to sub-list g·JSW + (k mod JSW), position k / JSW, as slot / GS | special << 15; each sub-list is
 // padded with the group-local sentinel index qmax = ⌈tile_n / GS⌉ to the row count of its wave (rows_dst).
+// The destination has a row capacity of its own, R_cap_dst = GS · R_cap: a group's share of an atom's entries is only statistically a GS-th of
+// them, but it can never exceed ALL of them (JS sub-lists × 4 · R_cap entries, dealt over JS / GS waves), so no share overflows its sub-list.
 // One pass to count, one to scatter — every lane fetches its rows eight at a time (a version that walked the source rows one dependent
 // load after the other took 70 µs per prune on 6mrr, more than the prune itself).  The running numbers of the four groups travel as four
 // 16-bit fields of one 64-bit word: the prefix over the source sub-lists is a packed sum, and no register array is indexed dynamically.
@@ -98,7 +100,7 @@ __global__ void __launch_bounds__(1024) k_regroup(RegroupArgs A) {
     const bool via_lds = (size_t)A.JS * R_l * A.BI * 8 <= (size_t)A.lds_list_bytes;
     uint16_t* dst16 = via_lds ? l_dst : reinterpret_cast<uint16_t*>(A.dst);
     auto at = [&](int sub, int p) -> int64_t {
-        return via_lds ? (int64_t)(((((sub * R_l) + (p >> 2)) * A.BI + li) << 2) + (p & 3)) : ((((sub0 + sub) * A.R_cap + (p >> 2)) * A.BI + li) << 2) + (p & 3);
+        return via_lds ? (int64_t)(((((sub * R_l) + (p >> 2)) * A.BI + li) << 2) + (p & 3)) : ((((sub0 + sub) * A.R_cap_dst + (p >> 2)) * A.BI + li) << 2) + (p & 3);
     };
     // scatter my entries
     for (int r0 = 0; r0 < nrow; r0 += NB) {
@@ -130,7 +132,7 @@ __global__ void __launch_bounds__(1024) k_regroup(RegroupArgs A) {
     if (via_lds) {
         __syncthreads();
         const uint2* l_rows = reinterpret_cast<const uint2*>(l_dst);
-        uint2* out = A.dst + ((sub0 + js) * A.R_cap) * A.BI + li;
+        uint2* out = A.dst + ((sub0 + js) * A.R_cap_dst) * A.BI + li;
         for (int r = 0; r < rows_w; ++r) out[(int64_t)r * A.BI] = l_rows[(js * R_l + r) * A.BI + li];
     }
 #if MHIP_EXP == 11
@@ -305,12 +307,12 @@ size_t gs_lds_bytes(int q_lds, int BI, int JSW) { return std::max((size_t)(q_lds
 
 void launch_regroup(const RegroupArgs& A, int n_blocks, hipStream_t stream) {
     const size_t lds = 2 * (size_t)A.JS * A.BI * sizeof(unsigned long long) + 16 + (size_t)A.lds_list_bytes;
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) { MHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_regroup), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+    if (lds > 64 * 1024) MHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_regroup), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      // (per launch, like every other launcher: a capacity retry or a second context may need more than the first call did)
     hipLaunchKernelGGL(k_regroup, dim3(n_blocks), dim3(A.BI * A.JS), lds, stream, A);
 }
 
 void launch_gs_balance(const int32_t* rows_gs, int n_blocks, int JS, int GS, int waves_per_sub, int period, uint16_t* item_of, hipStream_t stream) {
+    // (items are uint16 and staged as n_blocks·GS ints of dynamic LDS: Engine::gs_groups() keeps n_blocks·GS <= 16 384)
     hipLaunchKernelGGL(k_gs_balance, dim3((unsigned)((n_blocks * GS + 63) / 64)), dim3(1024), (size_t)n_blocks * GS * sizeof(int32_t), stream, rows_gs, n_blocks, JS, GS, waves_per_sub, period, item_of);
 }
 

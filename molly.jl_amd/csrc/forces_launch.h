@@ -17,6 +17,7 @@ struct RegroupArgs {
     const uint2* src; const uint16_t* cnt; const int32_t* tile_cnt;      // the inner list as the prune wrote it, entries per (sub-list, lane), compacted tile sizes
     uint2* dst; int32_t* rows_dst;                                        // the group-split list
     int lds_list_bytes;                                                    // LDS the launch sets aside for staging a block's new list (the scatter goes to global memory if it does not fit)
+    int R_cap_dst;                                                         // row capacity of a destination sub-list: GS · R_cap (a group's share of an atom's entries cannot exceed all of them)
     unsigned long long* dbg;                                              // builds with -DMHIP_EXP=11: [block][8] wall-clock stamps of wave 0 (entry, counted, dealt, scattered, end)
 };
 struct GsArgs {

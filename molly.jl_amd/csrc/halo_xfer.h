@@ -20,8 +20,18 @@ struct XferHeader {
     uint32_t plan_seq[2][XFER_MAX_RANKS];      // [parity][rank]: number of the last validity check whose triple is in plan_val
     float plan_val[2][XFER_MAX_RANKS][4];      // {max |x − x_plan|², max |x − x_prune|², max |v|², –} of that rank
     int64_t rows_cap;                          // rows per half of THIS region, written by its owner: a sender checks its segments against it
+    // the re-plan inside the engine (replan.h): two collective count exchanges per re-plan (leavers per destination, ghost rows per peer) — every rank
+    // stores its row of the count matrix into every rank's table — and the sequence words of the payload rows that follow them into the plan area
+    uint32_t rp_cnt_seq[2][XFER_MAX_RANKS];    // [phase][sender]: number of the last re-plan whose count row is in rp_cnt
+    uint32_t rp_row_seq[2][XFER_MAX_RANKS];    // [phase][sender]: number of the last re-plan whose payload rows are complete in the plan area
+    int32_t rp_cnt[2][XFER_MAX_RANKS][XFER_MAX_RANKS + 2];   // [phase][sender][destination]; [..][XFER_MAX_RANKS] = the sender's atom capacity, [.. + 1] = its region's rows_cap
 };
 constexpr size_t XFER_ROWS_OFF = (sizeof(XferHeader) + 255) & ~(size_t)255;
+// behind the two row halves: the PLAN AREA, rows_cap × XFER_PLAN_WORDS reals — payload of a re-plan (migrating atoms: 12 words each; new ghosts: 8 words each)
+constexpr int XFER_PLAN_WORDS = 8;
+constexpr int XFER_MIG_WORDS = 12, XFER_GHOST_WORDS = 8;
+template <class T> constexpr size_t xfer_plan_off(int64_t rows_cap) { return XFER_ROWS_OFF + 2 * (size_t)rows_cap * 3 * sizeof(T); }
+template <class T> constexpr size_t xfer_region_bytes(int64_t rows_cap) { return xfer_plan_off<T>(rows_cap) + (size_t)rows_cap * XFER_PLAN_WORDS * sizeof(T); }
 
 __device__ inline void xfer_store_release(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ inline uint32_t xfer_load_acquire(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -62,6 +72,19 @@ __device__ inline void xfer_announce(const XferSend& X) {
             for (int q = 0; q < X.n_peers; ++q)
                 xfer_store_release(&reinterpret_cast<XferHeader*>(X.P.region[X.peers[q]])->seq_in[X.parity][X.my_rank], X.seq);
             __hip_atomic_store(X.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+// the same for any sequence word of the header (byte offset `word_off` of the sender's own word inside an XferHeader): the payload rows of a re-plan
+__device__ inline void xfer_announce_word(XferPeers P, const int32_t* ranks, int n_ranks, size_t word_off, uint32_t seq, unsigned int* done) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int before = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (before == gridDim.x - 1) {
+            __threadfence_system();
+            for (int q = 0; q < n_ranks; ++q) xfer_store_release(reinterpret_cast<uint32_t*>(P.region[ranks[q]] + word_off), seq);
+            __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

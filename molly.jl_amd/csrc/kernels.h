@@ -1514,7 +1514,9 @@ k_forces(ForceArgs<T> A) {
                         }
                         const v2f qa = da * da, qb = db * db;
                         v2f r2 = {__builtin_fmaf(dza, dza, qa.x + qa.y), __builtin_fmaf(dzb, dzb, qb.x + qb.y)};
-                        if constexpr (MINIMG) { if (G.triclinic) { if (!real_a) r2.x = 1.0e30f; if (!real_b) r2.y = 1.0e30f; } }
+                        // (1e12, not 1e30: pair_eval2's reaction-field branch forms r³ = r²·(r²/r), and 1e30·1e15 is +inf — inf·0 from the sentinel's
+                        // zero charge was a NaN in every padded row; r² = 1e12 is beyond any cutoff and keeps r³, the erfc argument and 1/r² finite)
+                        if constexpr (MINIMG) { if (G.triclinic) { if (!real_a) r2.x = 1.0e12f; if (!real_b) r2.y = 1.0e12f; } }
                         if constexpr (PRUNE) {
                             if (valid && real_a && r2.x <= (float)A.r_prune2) emit(make_entry((uint32_t)l_new[sa], 0u, 0));
                             if (valid && real_b && r2.y <= (float)A.r_prune2) emit(make_entry((uint32_t)l_new[sb], 0u, 0));

@@ -706,12 +706,14 @@ template <class T> struct Pme {
             tw[d].set(w); mh[d].set(m); bsm[d].set(bm[d]);
         }
         nzh = P.n[2] / 2 + 1;
-        grid.alloc((size_t)P.n[0] * P.n[1] * nzh);
-        rgrid.alloc((size_t)P.n[0] * P.n[1] * P.n[2]);
-        MHIP_HIP(hipMemset(rgrid.p, 0, rgrid.n * sizeof(T)));     // from here on k_pme_z_r2c leaves the meshes zeroed behind it
-        phi.alloc((size_t)P.n[0] * P.n[1] * P.n[2]);
-        fft = long_axis || fft_env == 1;
-        if (fft) plan.create(P.n[0], P.n[1], P.n[2], sizeof(T) == 8);
+        try {      // (a mesh whose arrays or library work areas do not fit leaves a context without PME, not one with half of it)
+            grid.alloc((size_t)P.n[0] * P.n[1] * nzh);
+            rgrid.alloc((size_t)P.n[0] * P.n[1] * P.n[2]);
+            MHIP_HIP(hipMemset(rgrid.p, 0, rgrid.n * sizeof(T)));     // from here on k_pme_z_r2c leaves the meshes zeroed behind it
+            phi.alloc((size_t)P.n[0] * P.n[1] * P.n[2]);
+            fft = long_axis || fft_env == 1;
+            if (fft) plan.create(P.n[0], P.n[1], P.n[2], sizeof(T) == 8);
+        } catch (...) { release(); throw; }
     }
 
     DftArgs<T> dft_args(int axis, int sign, int C, double* e_part) const {

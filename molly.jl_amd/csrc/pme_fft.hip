@@ -17,10 +17,14 @@ static void fft_check(hipfftResult r, const char* what) {
 void FftPlan3d::create(int nx, int ny, int nz, bool double_precision) {
     destroy();
     dbl = double_precision;
+    // each handle is stored as soon as it exists, so that a failure of the second plan (work areas of a 2^30-point mesh run to gigabytes)
+    // leaves nothing behind that destroy() cannot see
     hipfftHandle a, b;
     fft_check(hipfftPlan3d(&a, nx, ny, nz, dbl ? HIPFFT_D2Z : HIPFFT_R2C), "plan (real to complex)");
-    fft_check(hipfftPlan3d(&b, nx, ny, nz, dbl ? HIPFFT_Z2D : HIPFFT_C2R), "plan (complex to real)");
-    r2c = (void*)a; c2r = (void*)b;
+    r2c = (void*)a;
+    const hipfftResult rb = hipfftPlan3d(&b, nx, ny, nz, dbl ? HIPFFT_Z2D : HIPFFT_C2R);
+    if (rb != HIPFFT_SUCCESS) { destroy(); fft_check(rb, "plan (complex to real)"); }
+    c2r = (void*)b;
 }
 
 void FftPlan3d::destroy() {

@@ -246,6 +246,24 @@ class HipDomainEngine:
             self._chk(rc)
         return done.value, reason.value
 
+    # -- the re-plan inside the engine (include/mollyhip.h: mhip_set_domain … mhip_domain_export) --------------------------------------
+    def set_domain(self, grid, rank, box, r_ghost, gid_i64):
+        g = _lib.DomainGeometry()
+        for d in range(3):
+            g.grid[d], g.box[d] = int(grid[d]), float(box[d])
+        g.rank, g.r_ghost = int(rank), float(r_ghost)
+        self._gid_keep = gid_i64.contiguous()
+        self._chk(self.L.mhip_set_domain(self.ctx, C.byref(g), self._p(self._gid_keep)))
+
+    def domain_info(self):
+        """(owned atoms, ghost atoms, re-plans made by the engine, atoms that arrived in them)"""
+        out = (C.c_int64 * 4)()
+        self._chk(self.L.mhip_domain_info(self.ctx, C.byref(out)))
+        return tuple(int(v) for v in out)
+
+    def domain_export(self, gid_i64, par4):
+        self._chk(self.L.mhip_domain_export(self.ctx, self._p(gid_i64), self._p(par4)))
+
     def plan_state(self, out3_f32):       # device float[3]: max displacement² since the plan / since the last prune, max speed²
         self._chk(self.L.mhip_plan_state_dev(self.ctx, self._p(out3_f32)))
 
@@ -261,6 +279,15 @@ class HipDomainEngine:
 
     def request_prune(self):
         self._chk(self.L.mhip_request_prune(self.ctx))
+
+    def export_neighbors(self):
+        """the sub-domain's neighbour list of NOW in local indices (owned atoms first, then ghosts): pairs (i, j), i owned, i < j"""
+        n = C.c_int64(0)
+        self._chk(self.L.mhip_export_neighbors(self.ctx, None, None, None, 0, C.byref(n)))
+        i = np.empty(n.value, np.int32); j = np.empty(n.value, np.int32); sp = np.empty(n.value, np.uint8)
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._chk(self.L.mhip_export_neighbors(self.ctx, ptr(i), ptr(j), ptr(sp), n.value, C.byref(n)))
+        return i[: n.value], j[: n.value]
 
     def get_state(self, x_all, v_owned):
         self._chk(self.L.mhip_get_state(self.ctx, self._p(x_all), self._p(v_owned), _lib.MEM_DEVICE))
@@ -319,6 +346,10 @@ class DomainRun:
         self.engine_loop = (self.fused and hasattr(engine, "domain_run") and _os.environ.get("MOLLYHIP_ENGINE_LOOP", "1") != "0"
                             and _os.environ.get("MOLLYHIP_HOST_PRUNE", "0") == "0")
         self._ipc_ready = False
+        # the re-plan inside the engine as well (mhip_set_domain): migration, ghost selection and the new routes are device compactions and peer
+        # stores, mhip_domain_run never comes back for them; MOLLYHIP_DEVICE_REPLAN=0 (or an engine without the entry point) keeps migrate() below
+        self.device_replan = self.engine_loop and hasattr(engine, "set_domain") and _os.environ.get("MOLLYHIP_DEVICE_REPLAN", "1") != "0"
+        self._dev_replans_seen = 0
         self._counters = (C.c_int64 * 3)(0, 0, 0)
         self.stats = {"exchange_calls": 0, "ghost_atoms": 0, "migrated": 0, "plans": 0, "plan_checks": 0, "prunes": 0, "interior_passes": 0}
         self.overlap = _os.environ.get("MOLLYHIP_HALO_OVERLAP", "1") != "0" and hasattr(engine, "halo_interior")
@@ -390,6 +421,18 @@ class DomainRun:
         self.x, self.v = x[idx].contiguous(), tt(velocities)
         self.par = torch.stack([tt(charge), tt(sigma), tt(eps), tt(mass)], dim=1).contiguous()
         self._plan_and_load(step)
+        self._hand_over_domain()
+
+    def _hand_over_domain(self):
+        """after a plan made by the host: the engine learns the decomposition and the global ids, and re-plans on its own from now on"""
+        if not (self.device_replan and self.engine_loop):
+            self.device_replan = False
+            return
+        try:
+            self.e.set_domain(self.g.grid, self.rank, self.g.box, self.g.r_ghost, self.gid)
+            self._dev_replans_seen = self.e.domain_info()[2]
+        except _lib.MollyHipError:                         # (a decomposition the device planner does not cover: the host keeps planning)
+            self.device_replan = False
 
     # -- ghost plan: which of my atoms go to which neighbour, with which periodic shift -------------------------------
     def _plan_and_load(self, step):
@@ -589,6 +632,7 @@ class DomainRun:
                 if reason == 1:
                     self.migrate(s)
             self.stats["plan_checks"], self.stats["prunes"] = int(self._counters[0]), int(self._counters[1])
+            self._sync_from_engine()
             return
         if not self.fused:
             for s in range(first_step + 1, first_step + n_steps + 1):
@@ -627,7 +671,25 @@ class DomainRun:
                     self.e.halo_start(dt)
 
     # -- migration at the rebuild cadence -------------------------------------------------------------------------------
+    def _sync_from_engine(self):
+        """the engine re-planned on its own since the host last looked: atom counts, global ids and parameters as they are now"""
+        if not self.device_replan:
+            return
+        n_owned, n_ghost, n_replans, n_arrived = self.e.domain_info()
+        if n_replans == self._dev_replans_seen:
+            return
+        self.stats["plans"] += n_replans - self._dev_replans_seen
+        self._dev_replans_seen = n_replans
+        self.stats["migrated"] = n_arrived
+        self.n_owned, self.n_ghost = n_owned, n_ghost
+        self.stats["ghost_atoms"] = n_ghost
+        self.gid = torch.empty(n_owned, dtype=torch.int64, device=self.device)
+        self.par = torch.empty((n_owned, 4), dtype=self.tdtype, device=self.device)
+        self.e.domain_export(self.gid, self.par)
+        self.v = torch.empty((n_owned, 3), dtype=self.tdtype, device=self.device)
+
     def pull(self):
+        self._sync_from_engine()
         x_all = torch.empty((self.n_owned + self.n_ghost, 3), dtype=self.tdtype, device=self.device)
         self.e.get_state(x_all, self.v)
         self.x = x_all[: self.n_owned].contiguous()
@@ -640,6 +702,8 @@ class DomainRun:
         if self.world == 1:
             self.x = x
             self._plan_and_load(step)
+            if self.device_replan:
+                self._hand_over_domain()
             return
         dest = self.g.owner_of(x)
         li = torch.nonzero(dest != self.rank).squeeze(1)               # leavers (one host sync; the list is short)
@@ -668,6 +732,8 @@ class DomainRun:
         else:
             self.x = x
         self._plan_and_load(step)
+        if self.device_replan:
+            self._hand_over_domain()
 
     # -- gather the whole system on every rank (tests / final state) ------------------------------------------------------
     def gather_global(self, n_total):

@@ -46,6 +46,7 @@ def _worker(rank, world, port, n_side, n_steps, dtype_name, out_dir, gm=0.0, hos
     if rank == 0:
         st = eng.stats()
         np.savez(os.path.join(out_dir, tag + ".npz"), engine_loop=int(run.engine_loop), x=xs, v=vs, ghosts=run.n_ghost, migrated=run.stats["migrated"], plans=run.stats["plans"],
+                 dev_replans=eng.domain_info()[2] if getattr(run, "device_replan", False) else 0,
                  checks=run.stats["plan_checks"], outer=st["n_outer_builds"], prunes=st["n_filter_passes"], host_prunes=run.stats["prunes"], fused=int(run.fused))
     dist.barrier()
     eng.close()
@@ -150,3 +151,121 @@ def test_engine_loop_replans_match_host_loop(gm, n_steps, tmp_path, monkeypatch)
         assert int(eng["plans"]) >= n_steps // 10
     assert abs(int(eng["plans"]) - int(host["plans"])) <= 1          # (the engine loop reads its collective check one step late)
     assert np.abs(eng["x"] - host["x"]).max() < 1e-9 and np.abs(eng["v"] - host["v"]).max() < 1e-8
+
+
+@pytest.mark.parametrize("world,gm,n_steps", [(2, 0.0, 40), (4, 0.0, 40), (8, 0.0, 30), (2, 0.03, 120), (4, 0.03, 80)])
+def test_device_replan_matches_host_planner_and_oracle(world, gm, n_steps, tmp_path, monkeypatch):
+    """The re-plan inside the engine (mhip_set_domain; replan.h): migration, ghost selection and the per-step message tables made by device
+    compactions and peer stores in the middle of mhip_domain_run's step.  Against the host planner driving the same engine loop
+    (MOLLYHIP_DEVICE_REPLAN=0: mhip_domain_run returns for every re-plan) and against the single-domain oracle: the same re-plans, atoms
+    that really changed owner, the same trajectory to fp64 round-off of differently ordered sums."""
+    monkeypatch.setenv("MOLLYHIP_DEVICE_REPLAN", "1")
+    dev = _run_variant(tmp_path, monkeypatch, "dev", world, n_steps, True, 0, gm=gm, skin_pm=20)
+    monkeypatch.setenv("MOLLYHIP_DEVICE_REPLAN", "0")
+    host = _run_variant(tmp_path, monkeypatch, "hostplan", world, n_steps, True, 0, gm=gm, skin_pm=20)
+    assert int(dev["engine_loop"]) == 1 and int(host["engine_loop"]) == 1
+    assert int(dev["dev_replans"]) >= (n_steps // 10 if gm == 0.0 else 1) and int(host["dev_replans"]) == 0
+    slack = 0 if gm == 0.0 else 1      # (a stale plan is found by the same check in both; the searches behind it see the step from different sides)
+    assert abs(int(dev["plans"]) - int(host["plans"])) <= slack and abs(int(dev["outer"]) - int(host["outer"])) <= slack
+    assert int(dev["migrated"]) > 0
+    assert np.abs(dev["x"] - host["x"]).max() < 1e-9 and np.abs(dev["v"] - host["v"]).max() < 1e-8
+    case = S.lj_fluid(16, dtype=np.float64, rebuild_every=10)
+    o = case.oracle(np.float64)
+    o.vv_run(n_steps, 0.002, remove_cm_every=1)
+    d = dev["x"] - o.coords
+    d -= np.round(d / case.box) * case.box
+    assert np.abs(d).max() < 1e-9 and np.abs(dev["v"] - o.vel).max() < 1e-8
+
+
+def test_device_replan_chunked_run_is_the_same_run(tmp_path, monkeypatch):
+    """a run cut into calls (on and off the rebuild cadence) re-plans at the same steps and ends in the same state as the run in one call"""
+    whole = _run_variant(tmp_path, monkeypatch, "whole", 2, 60, True, 0, gm=0.0, skin_pm=20)
+    cut = _run_variant(tmp_path, monkeypatch, "cut", 2, 60, True, 7, gm=0.0, skin_pm=20)
+    assert int(whole["dev_replans"]) >= 6 and int(cut["dev_replans"]) == int(whole["dev_replans"])
+    assert np.abs(cut["x"] - whole["x"]).max() < 1e-11 and np.abs(cut["v"] - whole["v"]).max() < 1e-10
+
+
+def _big_worker(rank, world, port, n_side, n_steps, out_dir, gm, with_pairs):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import molly_loader
+    molly_loader.load()
+    from molly_jl_amd import domain
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    case = S.lj_fluid(n_side, dtype=np.float32, rebuild_every=10)
+    grid = domain.choose_grid(world, case.box)
+    bg = domain.BrickGrid(case.box, grid, rank, case.r_list + gm)
+    box, origin, periodic = bg.engine_box(pad=0.3)
+    vol_frac = np.prod([b / L for b, L in zip(box, case.box)])
+    capacity = int(case.n * min(1.0, vol_frac) * 1.25) + 4096            # (bench_distributed's sizing)
+    eng = domain.HipDomainEngine(domain.make_interactions(case, np.float32), np.float32, capacity, box, origin, periodic, case.r_list, case.rebuild_every, 0, ghost_margin=gm)
+    run = domain.DomainRun(bg, eng, torch.float32, dev, case.rebuild_every, ghost_margin=gm, skin=case.r_list - 1.0)
+    run.setup_from_global(case.coords, case.velocities, np.zeros(case.n), case.sigma, case.eps, case.mass)
+    run.run(0, n_steps, 0.002, remove_cm_every=1)
+    xs, vs = run.gather_global(case.n)
+    extra = {}
+    if with_pairs:      # this rank's list of NOW in local indices, its local coordinates (owned then ghosts) and the owned atoms' global ids
+        i, j = eng.export_neighbors()
+        x_all = torch.empty((run.n_owned + run.n_ghost, 3), dtype=torch.float32, device=dev)
+        eng.get_state(x_all, run.v)
+        extra = dict(pi=i, pj=j, x_all=x_all.cpu().numpy(), gid=run.gid.cpu().numpy(), n_owned=run.n_owned)
+    st = eng.stats()
+    np.savez(os.path.join(out_dir, f"big{rank}.npz"), x=xs, v=vs, engine_loop=int(run.engine_loop), dev_replans=eng.domain_info()[2] if run.device_replan else 0,
+             migrated=run.stats["migrated"], plans=run.stats["plans"], ghosts=run.n_ghost, outer=st["n_outer_builds"], prunes=st["n_filter_passes"], block_atoms=st["block_atoms"], **extra)
+    dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,gm,n_steps,with_pairs", [(2, 0.0, 20, True), (8, 0.0, 20, True), (8, 0.03, 25, False), (8, 0.2, 25, False)])
+def test_benchmark_size_bricks_against_single_domain_and_oracle_list(pkg, world, gm, n_steps, with_pairs, tmp_path):
+    """BASELINE.json configs[1]'s fluid (262 144 atoms, fp32) cut 2×1×1 and 2×2×2 on the one GPU, with the benchmark's own capacity rule: tile
+    counts, row capacities and 30 000+ ghosts per rank that the 4 096-atom cases never reach.  Steps across rebuilds and migrations (no margin:
+    a re-plan inside the engine at steps 10 and 20; thin margin: when the plan goes stale; the benchmark's 0.2 nm: one plan, prunes only).
+    Coordinates against the single-domain engine at the fp32 trajectory bar of the small cases; and, where the run ends on a re-plan step, the
+    UNION of the ranks' exported neighbour lists — ghosts identified by their coordinates — against the fp32 oracle's list of the gathered
+    coordinates (neighbors.jl:409-411): the same pairs, up to those that sit within rounding of r_list (a ghost's coordinate is the owner's
+    plus a box length, rounded once more)."""
+    n_side = 64
+    mp.spawn(_big_worker, args=(world, _free_port(), n_side, n_steps, str(tmp_path), gm, with_pairs), nprocs=world, join=True)
+    res = [np.load(os.path.join(tmp_path, f"big{r}.npz")) for r in range(world)]
+    case = S.lj_fluid(n_side, dtype=np.float32, rebuild_every=10)
+    s = case.system(pkg, np.float32)
+    pkg.simulate(s, pkg.VelocityVerlet(dt=0.002), n_steps)
+    xs = res[0]["x"]
+    d = xs - s.coords.astype(np.float64)
+    d -= np.round(d / case.box) * case.box
+    assert np.abs(d).mean() < 1e-5 and np.abs(d).max() < 1e-3, (np.abs(d).mean(), np.abs(d).max())
+    assert all(int(r["engine_loop"]) == 1 and int(r["ghosts"]) > 10000 for r in res)
+    if gm < 0.2:
+        assert all(int(r["dev_replans"]) >= (2 if gm == 0.0 else 1) for r in res) and sum(int(r["migrated"]) for r in res) > 0
+    else:
+        assert all(int(r["plans"]) == 1 and int(r["outer"]) == 1 and int(r["prunes"]) >= 1 for r in res)
+    if not with_pairs:
+        return
+    from scipy.spatial import cKDTree
+    box = float(case.box[0])
+    xw = xs - np.floor(xs / box) * box
+    xw[xw >= box] = 0.0
+    tree = cKDTree(xw, boxsize=box)
+    keys = []
+    for r in res:
+        n_owned, gid, x_all = int(r["n_owned"]), r["gid"], r["x_all"].astype(np.float64)
+        gw = x_all[n_owned:] - np.floor(x_all[n_owned:] / box) * box
+        gw[gw >= box] = 0.0
+        dist_g, idx_g = tree.query(gw, k=1)
+        assert dist_g.max() < 1e-4                                            # every ghost IS some owner's atom (to the rounding of the shift)
+        lg = np.concatenate([gid, idx_g.astype(np.int64)])
+        assert np.array_equal(np.sort(np.unique(gid)), np.sort(gid)) and np.abs(x_all[:n_owned] - xs[gid]).max() < 1e-6
+        keys.append(S.pair_keys(lg[r["pi"]], lg[r["pj"]]))
+    got = np.unique(np.concatenate(keys))
+    o32 = case.oracle(np.float32, coords=xs)
+    oi, oj, _ = o32.neighbors("cell", nthreads=16)
+    ref = S.pair_keys(oi, oj)
+    only_got, only_ref = np.setdiff1d(got, ref, assume_unique=True), np.setdiff1d(ref, got, assume_unique=True)
+    assert len(only_got) + len(only_ref) <= 1e-6 * len(ref), (len(only_got), len(only_ref), len(ref))
+    for k in np.concatenate([only_got, only_ref]):                            # … and those few sit on the list radius
+        a, b = int(k >> np.uint64(32)), int(k & np.uint64(0xffffffff))
+        dv = xs[a] - xs[b]; dv -= np.round(dv / box) * box
+        assert abs(np.linalg.norm(dv) - case.r_list) < 1e-5

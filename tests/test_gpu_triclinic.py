@@ -217,3 +217,28 @@ def test_triclinic_constructor_refusals_and_pme_on_a_sheared_cell(pkg):
     case.triclinic = dict(basis=np.diag(case.box) + np.array([[0, 0, 0], [0.1, 0, 0], [0, 0, 0]]))
     s = case.system(pkg, np.float64)
     pkg.forces(s); pkg.virial(s)                                                       # PME on a sheared cell works (tests/test_gpu_pme.py: forces, energy, virial)
+
+
+@pytest.mark.parametrize("approx", [True, False])
+@pytest.mark.parametrize("kind", ["rf", "ewald"])
+def test_triclinic_fp32_charged_per_atom_lj_small_cell_is_finite_and_matches_oracle(pkg, kind, approx):
+    """fp32, per-atom σ / ϵ, CoulombReactionField (and Ewald direct space) in the reference's small sheared cell: every block takes the exact
+    in-loop minimum image and the two-partner packed loop, whose padded slots are pushed out to r² = 1e12 — with 1e30 the reaction-field
+    branch formed r³ = +inf and inf·0 made every force NaN.  Forces finite and inside the fp32 bar of the fp64 oracle."""
+    rng = np.random.default_rng(9)
+    n = 90
+    g = np.stack(np.meshgrid(*[np.arange(5)] * 3, indexing="ij"), -1).reshape(-1, 3)[:n].astype(np.float64)
+    x = (((g + 0.5) / 5 + rng.uniform(-0.03, 0.03, g.shape)) @ BASIS).astype(np.float32).astype(np.float64)
+    q = rng.uniform(-0.8, 0.8, n); q -= q.mean()
+    coul = dict(kind="rf", rc=0.8, eps_rf=78.3) if kind == "rf" else dict(kind="ewald", rc=0.8, tol=5e-4)
+    case = S.Case(x, np.diag(BASIS), lj=dict(cutoff=("distance", 0.8)), coul=coul, r_list=0.9, velocities=np.zeros((n, 3)), charge=q,
+                  sigma=rng.uniform(0.2, 0.32, n), eps=rng.uniform(0.3, 1.0, n), mass=np.full(n, 12.0),
+                  triclinic=dict(basis=BASIS, approx_images=approx), name="tri_rf32")
+    tol, o, nl = S.fp32_force_tolerance(case)
+    f_ref = o.forces(nl)
+    s = case.system(pkg, np.float32)
+    f = pkg.forces(s).astype(np.float64)
+    assert np.isfinite(f).all()
+    err = np.linalg.norm(f - f_ref, axis=1)
+    assert (err <= tol).all(), float((err / tol).max())
+    assert S.rel_rms(err, f_ref) < 2e-5
