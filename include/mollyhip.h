@@ -439,7 +439,8 @@ int32_t mhip_domain_run(mhip_ctx* ctx, int64_t first_step, int64_t n_steps, doub
  *                        uncut ones periodic.  global_ids_dev (nullable: 0 .. n_owned-1): the global index of every owned atom, local
  *                        order, device int64.  MHIP_ERR_UNSUPPORTED when some rank is not a neighbour of every other (more than two
  *                        bricks on an axis): such decompositions keep the host planner.  NULL geometry switches the device planner off.
- *   mhip_domain_info   : out4 = { owned atoms, ghost atoms, re-plans made by the engine, atoms that arrived in them }
+ *   mhip_domain_info   : out8 = { owned atoms, ghost atoms, re-plans made by the engine, atoms that arrived in them, host microseconds spent
+ *                        planning (launches + the one read-back), host microseconds in the searches behind the plans, 0, 0 }
  *   mhip_domain_export : what a host planner keeps per owned atom, local order, device memory (either may be NULL): global ids
  *                        (int64[n_owned]) and {q, sigma, eps, mass} (real[n_owned][4]).  With mhip_get_state this is the whole
  *                        sub-domain (gather of a final state, hand-over to a host re-plan).
@@ -452,7 +453,7 @@ typedef struct {
     double r_ghost;
 } mhip_domain_geometry;
 int32_t mhip_set_domain(mhip_ctx* ctx, const mhip_domain_geometry* geometry, const int64_t* global_ids_dev);
-int32_t mhip_domain_info(mhip_ctx* ctx, int64_t* out4);
+int32_t mhip_domain_info(mhip_ctx* ctx, int64_t* out8);
 int32_t mhip_domain_export(mhip_ctx* ctx, int64_t* global_ids_dev, void* params4_dev);
 
 #ifdef __cplusplus

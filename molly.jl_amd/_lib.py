@@ -151,7 +151,7 @@ SIGNATURES = {
     "mhip_set_halo_routes": (_I32, [_P, C.POINTER(HaloRoutes)]),
     "mhip_domain_run": (_I32, [_P, _I64, _I64, _D, _I32, _P, _I32, C.POINTER(_I64), C.POINTER(_I32), C.POINTER(_I64)]),
     "mhip_set_domain": (_I32, [_P, C.POINTER(DomainGeometry), _P]),
-    "mhip_domain_info": (_I32, [_P, C.POINTER(_I64 * 4)]),
+    "mhip_domain_info": (_I32, [_P, C.POINTER(_I64 * 8)]),
     "mhip_domain_export": (_I32, [_P, _P, _P]),
 }
 

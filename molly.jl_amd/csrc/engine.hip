@@ -2124,7 +2124,7 @@ template <class T> class Engine final : public EngineBase {
     // carry the peers' Σ m v of the step before), in front of its force pass, which then prunes the freshly searched outer list exactly as a
     // single domain's pass does behind an outer search.  The host reads one table (counts, error word) and runs the search.
     struct Dom {
-        bool ready = false; int world = 1, me = 0; int64_t n_replans = 0, n_migrated = 0;
+        bool ready = false; int world = 1, me = 0; int64_t n_replans = 0, n_migrated = 0; double plan_ms = 0, search_ms = 0;      // host wall time inside the re-plans: planning (launches + the one sync) / the search behind it
         DBuf<int64_t> gid[2]; int gcur = 0;
         DBuf<RpTab> tab; RpTab* h_tab = nullptr; T* h_lj0 = nullptr;
         DBuf<uint32_t> mask; DBuf<int32_t> blk_cnt, blk_off, err, ranks;
@@ -2202,7 +2202,9 @@ template <class T> class Engine final : public EngineBase {
         MHIP_HIP(hipStreamSynchronize(stream));
         dom.ready = true;
     }
-    void domain_info(int64_t* out4) override { out4[0] = n_owned; out4[1] = n_ghost; out4[2] = dom.n_replans; out4[3] = dom.n_migrated; }
+    void domain_info(int64_t* out8) override {
+        out8[0] = n_owned; out8[1] = n_ghost; out8[2] = dom.n_replans; out8[3] = dom.n_migrated; out8[4] = (int64_t)std::llround(dom.plan_ms * 1e3); out8[5] = (int64_t)std::llround(dom.search_ms * 1e3); out8[6] = out8[7] = 0;
+    }
     void domain_export(int64_t* gid_dev, void* par4_dev) override {
         if (!dom.ready) throw ApiError{MHIP_ERR_STATE, "mhip_set_domain first"};
         hipLaunchKernelGGL(k_rp_export<T>, dim3(cdiv(n_owned, 256)), dim3(256), 0, stream, n_owned, (const int32_t*)inv.p, (const T4*)pos[cur].p, (const T4*)vel[cur].p, (const T2*)lj[cur].p,
@@ -2231,7 +2233,9 @@ template <class T> class Engine final : public EngineBase {
     }
     void device_replan(int64_t step_n) {
         ++dom.n_replans;
-        if (dom.world == 1) { rebuild(step_n); return; }      // one brick: nobody to hand atoms to, no ghosts — an outer-list rebuild, as in mhip_vv_run
+        const auto t_begin = std::chrono::steady_clock::now();
+        auto ms_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+        if (dom.world == 1) { rebuild(step_n); dom.search_ms += ms_since(t_begin); return; }      // one brick: nobody to hand atoms to, no ghosts — an outer-list rebuild, as in mhip_vv_run
         const ReplanGeom<T>& g = dom_g;
         const int world = g.world, me = g.me, cr = g.cm_rows;
         const int o = cur, n = 1 - cur, go = dom.gcur, gn = 1 - dom.gcur;
@@ -2301,7 +2305,10 @@ template <class T> class Engine final : public EngineBase {
         hp.n_cm_peers = world - 1; hp.cm_rows = cr; hp.send_idx = dom.send_idx.p; hp.send_shift = dom.send_shift.p;
         hp.n_send_rows = t.n_send + (world - 1) * cr; hp.send = nullptr; hp.send_cm_pos = dom.send_cm_pos.p; hp.n_send_cm = (world - 1) * cr;
         xf.plan_pending = false; xf.next_check = -1;
+        dom.plan_ms += ms_since(t_begin);
+        const auto t_search = std::chrono::steady_clock::now();
         rebuild(step_n);
+        dom.search_ms += ms_since(t_search);
     }
 
     // one MD step of a ghosted sub-domain in two calls around the ghost exchange
@@ -2729,7 +2736,7 @@ int32_t mhip_domain_run(mhip_ctx* ctx, int64_t first_step, int64_t n_steps, doub
         ctx->e->domain_run(first_step, n_steps, dt, remove_cm_every, cm_parts_dev, n_parts, steps_done, reason, counters3); });
 }
 int32_t mhip_set_domain(mhip_ctx* ctx, const mhip_domain_geometry* g, const int64_t* gids_dev) { NEED_CTX(); return guard(ctx, [&] { ctx->e->set_domain(g, gids_dev); }); }
-int32_t mhip_domain_info(mhip_ctx* ctx, int64_t* out4) { NEED_CTX(); return guard(ctx, [&] { if (!out4) throw mhip::ApiError{MHIP_ERR_INVALID, "null output"}; ctx->e->domain_info(out4); }); }
+int32_t mhip_domain_info(mhip_ctx* ctx, int64_t* out8) { NEED_CTX(); return guard(ctx, [&] { if (!out8) throw mhip::ApiError{MHIP_ERR_INVALID, "null output"}; ctx->e->domain_info(out8); }); }
 int32_t mhip_domain_export(mhip_ctx* ctx, int64_t* gid_dev, void* par4_dev) { NEED_CTX(); return guard(ctx, [&] { ctx->e->domain_export(gid_dev, par4_dev); }); }
 int32_t mhip_vv_halo_begin(mhip_ctx* ctx, double dt, const int32_t* idx, const void* shift, int64_t n, void* out) { NEED_CTX(); return guard(ctx, [&] { ctx->e->halo_begin(dt, idx, shift, n, out); }); }
 int32_t mhip_vv_halo_interior(mhip_ctx* ctx, int64_t step_n, int32_t* launched) { NEED_CTX(); return guard(ctx, [&] { int r = ctx->e->halo_interior(step_n); if (launched) *launched = r; }); }

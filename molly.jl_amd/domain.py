@@ -256,8 +256,8 @@ class HipDomainEngine:
         self._chk(self.L.mhip_set_domain(self.ctx, C.byref(g), self._p(self._gid_keep)))
 
     def domain_info(self):
-        """(owned atoms, ghost atoms, re-plans made by the engine, atoms that arrived in them)"""
-        out = (C.c_int64 * 4)()
+        """(owned atoms, ghost atoms, re-plans made by the engine, atoms that arrived in them, host µs planning, host µs searching, 0, 0)"""
+        out = (C.c_int64 * 8)()
         self._chk(self.L.mhip_domain_info(self.ctx, C.byref(out)))
         return tuple(int(v) for v in out)
 
@@ -675,7 +675,7 @@ class DomainRun:
         """the engine re-planned on its own since the host last looked: atom counts, global ids and parameters as they are now"""
         if not self.device_replan:
             return
-        n_owned, n_ghost, n_replans, n_arrived = self.e.domain_info()
+        n_owned, n_ghost, n_replans, n_arrived = self.e.domain_info()[:4]
         if n_replans == self._dev_replans_seen:
             return
         self.stats["plans"] += n_replans - self._dev_replans_seen
