@@ -12,6 +12,11 @@
 namespace mhip {
 
 constexpr int WAVE = 64;
+// The one compile-time experiment switch of the product sources: -DMHIP_STAMPS=1 builds a library whose block kernels (k_forces, k_forces_gs, k_build,
+// k_regroup) leave wall-clock stamps per wave for tools/gs_times.py and tools/build_times.py (MOLLYHIP_DBG_TIMES / MOLLYHIP_DBG_DUMP* in the engine).
+#ifndef MHIP_STAMPS
+#define MHIP_STAMPS 0
+#endif
 // dynamic LDS a kernel may ask for: the 160 KiB of a gfx950 CU (MI355X_MICROARCH.md) minus room for the kernels' static __shared__
 // arrays (k_build: ≈ 1.6 KB) — the sum is what hipFuncSetAttribute / the launch are checked against
 constexpr int MAX_LDS_BYTES = 160 * 1024 - 2048;

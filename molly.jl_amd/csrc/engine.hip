@@ -252,6 +252,7 @@ template <class T> class Engine final : public EngineBase {
     // MOLLYHIP_TRACE=1: drain the stream, then name the launch that follows on stderr — the last name a dying process printed is the
     // kernel that faulted (a GPU fault aborts the process from the runtime's callback, no status ever comes back)
     const bool trace_on = env_int("MOLLYHIP_TRACE", 0) != 0;
+    const bool debug_on = env_int("MOLLYHIP_DEBUG", 0) != 0;      // MOLLYHIP_DEBUG=1: the list-maintenance decisions on stderr (read once, when the context is made)
     void tr(const char* what) {
         if (!trace_on) return;
         (void)hipStreamSynchronize(stream);
@@ -406,7 +407,7 @@ template <class T> class Engine final : public EngineBase {
         if (!tri_lists_ok) outer_margin = 0;
         dual = (outer_margin > 0 || (margin_zero && n_ghost == 0 && !G.no_list && !dual_disabled)) && outer_every > 1 && lj_cut_ok && coul_cut_ok && skin > 0 && tri_lists_ok;   // ghosted: only with a ghost margin (else re-planned every rebuild)
         lazy_single = !dual && !G.no_list && lj_cut_ok && coul_cut_ok && skin > 0 && n_ghost == 0 && !strict_cadence && tri_lists_ok;
-        if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] grid: dual %d margin %.3f skin %.3f lj_ok %d coul_ok %d ghosts %lld\n", (int)dual, outer_margin, skin, (int)lj_cut_ok, (int)coul_cut_ok, (long long)n_ghost);
+        if (debug_on) std::fprintf(stderr, "[mhip] grid: dual %d margin %.3f skin %.3f lj_ok %d coul_ok %d ghosts %lld\n", (int)dual, outer_margin, skin, (int)lj_cut_ok, (int)coul_cut_ok, (long long)n_ghost);
         const double r_search = G.no_list ? 0.0 : cfg.r_list + (dual ? outer_margin : 0.0);
         G.r_list = G.no_list ? std::numeric_limits<T>::infinity() : T(r_search);
         G.r_list2 = G.no_list ? std::numeric_limits<T>::infinity() : (dual ? G.r_list * G.r_list : r_in2);
@@ -592,7 +593,7 @@ template <class T> class Engine final : public EngineBase {
             // numbers, mhip_plan_decide — without the dual list mhip_plan_state_dev reports +inf and every rank re-plans at every rebuild step)
             if (n_ghost > 0 || ghost_margin > 0 || host_prune) dual_disabled = true;
             else if (outer_margin > 0.06) ++margin_halvings; else if (!margin_zero) margin_zero = true; else dual_disabled = true;
-            if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] dual list %s (capacity): %s\n", dual_disabled ? "off" : (margin_zero ? "without outer margin" : "margin halved"), e.msg.c_str());
+            if (debug_on) std::fprintf(stderr, "[mhip] dual list %s (capacity): %s\n", dual_disabled ? "off" : (margin_zero ? "without outer margin" : "margin halved"), e.msg.c_str());
             setup_grid(); choose_blocking(); stale = true;
             rebuild(step_n);
         }
@@ -643,14 +644,11 @@ template <class T> class Engine final : public EngineBase {
             A.xl_start = has_exc ? xl_start.p : nullptr; A.xl_list = xl_list.p; A.xl_span = xl_span; A.X_cap = X_CAP;
             A.tile_idx = tile_idx.p; A.tile_cnt = tile_cnt.p; A.nbr = nbr.p; A.wave_rows = wave_rows.p; A.blk_center = blk_center.p; A.flags = flags.p;
             A.margin = G.no_list ? T(0) : G.r_list * T(1e-3);
-            A.debug = env_int("MOLLYHIP_BUILD_DEBUG", 0);
             A.approx = dual && !env_int("MOLLYHIP_EXACT_OUTER", 0) ? 1 : 0;
             A.walk = walk ? 1 : 0;
             A.eshift = eshift = want_eshift();
             A.cnt_out = nullptr; cnt_outer_valid = false;
-            A.dbg = nullptr;
-            static const int dbg_build = env_int("MOLLYHIP_DBG_TIMES", 0);
-            if (dbg_build) { dbg_buf.reserve((size_t)n_blocks * 16 * 8); MHIP_HIP(hipMemsetAsync(dbg_buf.p, 0, (size_t)n_blocks * 16 * 8 * sizeof(unsigned long long), stream)); A.dbg = dbg_buf.p; }
+            A.dbg = stamps_begin((size_t)n_blocks * 16 * 8);
             if ((sort_lanes_on && dual && BI > 64) || (gs_groups() > 0 && adopt_env)) { cnt_outer.reserve((size_t)n_blocks * JS * BI); A.cnt_out = cnt_outer.p; cnt_outer_valid = true; }
             prof.begin(1, stream);
             tr("k_build");
@@ -663,11 +661,7 @@ template <class T> class Engine final : public EngineBase {
             MHIP_HIP(hipGetLastError());
             MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
             MHIP_HIP(hipStreamSynchronize(stream));
-            if (A.dbg) {      // (experiment builds) the raw stamps of this search → $MOLLYHIP_DBG_DUMP_BUILD, for tools/build_times.py
-                std::vector<unsigned long long> h((size_t)n_blocks * 16 * 8);
-                MHIP_HIP(hipMemcpy(h.data(), dbg_buf.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-                if (const char* path = std::getenv("MOLLYHIP_DBG_DUMP_BUILD")) { if (FILE* f = std::fopen(path, "wb")) { std::fwrite(h.data(), sizeof(unsigned long long), h.size(), f); std::fclose(f); } }
-            }
+            if (A.dbg) stamps_dump("MOLLYHIP_DBG_DUMP_BUILD", (size_t)n_blocks * 16 * 8);      // (stamp builds: tools/build_times.py)
             int ovf = h_flags[FLAG_OVERFLOW];
             if (!ovf) break;
             if (ovf & OVF_SLOT) {
@@ -740,7 +734,7 @@ template <class T> class Engine final : public EngineBase {
         F.pos = pos[cur].p; F.pos_snap = pos_snap.p; F.tile_idx = tile_idx.p; F.tile_cnt = tile_cnt.p; F.nbr_out = nbr.p; F.rows_out = wave_rows.p;
         F.nbr_in = d_nbr.p; F.rows_in = d_rows.p; F.tile_idx_in = d_tidx.p; F.tile_cnt_in = d_tcnt.p; F.blk_center = blk_center.p; F.blk_disp2 = blk_disp2.p; F.flags = flags.p;
         F.eshift = eshift;
-        F.r_in = r_in; F.r_in2 = to_inner ? r_prune2 : r_in2; F.exact_all = minimg ? 1 : 0; F.approx = to_inner && r_prune2 != r_in2 ? 1 : 0; F.debug = env_int("MOLLYHIP_FILTER_DEBUG", 0);
+        F.r_in = r_in; F.r_in2 = to_inner ? r_prune2 : r_in2; F.exact_all = minimg ? 1 : 0; F.approx = to_inner && r_prune2 != r_in2 ? 1 : 0;
         F.T_lds = std::min<int>(max_tile, (MAX_LDS_BYTES - 256) / (int)sizeof(float4));
         F.T_lds = minimg ? 0 : F.T_lds;
         size_t lds = (size_t)F.T_lds * sizeof(float4) + (size_t)((T_cap + 8) & ~7) + (size_t)((T_cap + 2) & ~1) * 2 + (size_t)BI * JS * 4 + 64;
@@ -786,7 +780,7 @@ template <class T> class Engine final : public EngineBase {
         // list is not due before ≈ skin_in/2: with outer_margin <= 2·skin_in − skin every outer list is pruned exactly once, and its
         // margin only makes the search dearer.
         if (n_ghost == 0 && outer_margin > 0 && outer_margin <= 2.0 * skin_in - skin + 0.02) want_margin_zero = true;
-        if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] inner skin raised to %.3f nm (drift per check interval %.4f nm)\n", skin_in, drift_per_interval);
+        if (debug_on) std::fprintf(stderr, "[mhip] inner skin raised to %.3f nm (drift per check interval %.4f nm)\n", skin_in, drift_per_interval);
     }
     double drift_ahead(double d_so_far, int64_t steps_so_far, int every) const {
         const double empirical = 1.5 * d_so_far * (double)every / (double)std::max<int64_t>(steps_so_far, 1);
@@ -818,7 +812,7 @@ template <class T> class Engine final : public EngineBase {
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         const int64_t so_far = trk_step - last_prune_step;
         const double ahead = drift_ahead(d, so_far, every);
-        if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] step %lld: measured at %lld: d %.5f d_outer %.5f v_max %.4f\n", (long long)step, (long long)trk_step, d, d_outer, last_vmax);
+        if (debug_on) std::fprintf(stderr, "[mhip] step %lld: measured at %lld: d %.5f d_outer %.5f v_max %.4f\n", (long long)step, (long long)trk_step, d, d_outer, last_vmax);
         adapt_inner_skin(ahead);
         bool reprune = !inner_valid || 2.0 * (d + ahead) > skin_in * 0.98;
         next_check_step = -1;
@@ -852,13 +846,13 @@ template <class T> class Engine final : public EngineBase {
     void refresh(int64_t step_n) {
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         if (want_margin_zero && !margin_zero && n_ghost == 0) {
-            if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] outer margin dropped (inner skin %.3f nm leaves it no second prune)\n", skin_in);
+            if (debug_on) std::fprintf(stderr, "[mhip] outer margin dropped (inner skin %.3f nm leaves it no second prune)\n", skin_in);
             margin_zero = true; setup_grid(); choose_blocking(); stale = true;
         }
         if (!dual && lazy_single && !stale && step_n > last_prune_step) {
             // single list built with r_list at step last_prune_step: it still holds every pair within the cutoffs unless somebody moved skin/2
             const double d = std::sqrt((double)max_disp2_since(pos_snap_in));
-            if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] step %lld: max disp %.5f nm since the build of step %lld (skin %.3f), v_max %.4f\n", (long long)step_n, d, (long long)last_prune_step, skin, last_vmax);
+            if (debug_on) std::fprintf(stderr, "[mhip] step %lld: max disp %.5f nm since the build of step %lld (skin %.3f), v_max %.4f\n", (long long)step_n, d, (long long)last_prune_step, skin, last_vmax);
             next_check_step = -1;
             if (2.0 * (d + drift_ahead(d, step_n - last_prune_step, every)) <= skin * 0.98) { last_build_step = step_n; ++n_skipped; return; }
             if (const int k = steps_within(d, 0.49 * skin, step_n - last_prune_step, every)) { next_check_step = step_n + k; last_build_step = step_n; ++n_skipped; return; }
@@ -901,7 +895,7 @@ template <class T> class Engine final : public EngineBase {
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         // If that keeps happening before the outer list has paid for itself (fast light atoms, small time step), the dual list
         // is a loss: fall back to a fresh search at every rebuild step.
-        if (step_n - last_outer_step <= 2 * (int64_t)every) { if (++early_outer >= 3) { if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] dual list off (outer list outrun 3x)\n"); dual_disabled = true; setup_grid(); choose_blocking(); stale = true; } }
+        if (step_n - last_outer_step <= 2 * (int64_t)every) { if (++early_outer >= 3) { if (debug_on) std::fprintf(stderr, "[mhip] dual list off (outer list outrun 3x)\n"); dual_disabled = true; setup_grid(); choose_blocking(); stale = true; } }
         else early_outer = 0;
         rebuild(step_n);
     }
@@ -974,9 +968,7 @@ template <class T> class Engine final : public EngineBase {
                     Z.pos = pos[cur].p; Z.lj = lj[cur].p; Z.tile_idx = inner_is_outer ? tile_idx.p : tile_idx_in.p; Z.tile_cnt = inner_is_outer ? tile_cnt.p : tile_cnt_in.p; Z.nbr = nbr_gs.p; Z.wave_rows = rows_gs.p; Z.blk_center = blk_center.p;
                     Z.frc = frc[cur].p; Z.parts = frc_parts.p; Z.part_stride = cap;
                     Z.item_of = gs_balance_on ? gs_item.p : nullptr;
-                    Z.dbg = nullptr;
-                    static const int dbg_gs = env_int("MOLLYHIP_DBG_TIMES", 0);
-                    if (dbg_gs) { dbg_buf.reserve((size_t)n_blocks * GS * 4 * 8); MHIP_HIP(hipMemsetAsync(dbg_buf.p, 0, (size_t)n_blocks * GS * 4 * 8 * sizeof(unsigned long long), stream)); Z.dbg = dbg_buf.p; }
+                    Z.dbg = stamps_begin((size_t)n_blocks * GS * 4 * 8);
                     last_pass_tile = max_tile_in;
                     prof.begin(0, stream);
                     tr("k_forces_gs");
@@ -995,12 +987,7 @@ template <class T> class Engine final : public EngineBase {
                     prof.end(0, stream);
                     MHIP_HIP(hipGetLastError());
                     ++n_force_calls; ++n_gs_passes; gs_used = true;
-                    if (Z.dbg && (n_gs_passes % dbg_gs) == 0) {      // (experiment builds) the raw stamps of this pass → $MOLLYHIP_DBG_DUMP, for tools/gs_times.py
-                        std::vector<unsigned long long> h((size_t)n_blocks * GS * 4 * 8);
-                        MHIP_HIP(hipStreamSynchronize(stream));
-                        MHIP_HIP(hipMemcpy(h.data(), dbg_buf.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-                        if (const char* path = std::getenv("MOLLYHIP_DBG_DUMP")) { if (FILE* f = std::fopen(path, "wb")) { std::fwrite(h.data(), sizeof(unsigned long long), h.size(), f); std::fclose(f); } }
-                    }
+                    if (Z.dbg && (n_gs_passes % stamps_every()) == 0) stamps_dump("MOLLYHIP_DBG_DUMP", (size_t)n_blocks * GS * 4 * 8);      // (stamp builds: tools/gs_times.py)
                     return;
                 }
             }
@@ -1061,11 +1048,12 @@ template <class T> class Engine final : public EngineBase {
         A.cm_fin_in = nullptr; A.cm_fin_n = 0; A.cm_fin_out = nullptr;
         const bool cm_fin = cm_fin_on && in_vv_fused && !energy && n_ghost == 0 && part == 0 && cm_pending == 2 && n_cm_step > 1 && n_cm_step <= 4096;      // (the energy variants do not carry the sum)
         if (cm_fin) { cm_fin_buf.reserve(4); A.cm_fin_in = cm_src(); A.cm_fin_n = n_cm_step; A.cm_fin_out = cm_fin_buf.p; }
+        else if (cm_fin_solo_src && !energy && n_ghost == 0 && part == 0 && !cm_fin_solo_done) {      // (mhip_domain_run on one brick: halo_mid's partials)
+            cm_fin_buf.reserve(4); A.cm_fin_in = cm_fin_solo_src; A.cm_fin_n = n_cm_step; A.cm_fin_out = cm_fin_buf.p; cm_fin_solo_done = true;
+        }
         static const int level_env = env_int("MOLLYHIP_LEVEL_PAIRS", 1);
         A.level_pairs = (prune && level_env && JS == 2 && !lanes_sorted && !rebalance) ? 1 : 0;
-        A.dbg = nullptr;
-        static const int dbg_times = env_int("MOLLYHIP_DBG_TIMES", 0);
-        if (dbg_times && !prune && !energy) { dbg_buf.reserve((size_t)n_blocks * 16 * 8); MHIP_HIP(hipMemsetAsync(dbg_buf.p, 0, (size_t)n_blocks * 16 * 8 * sizeof(unsigned long long), stream)); A.dbg = dbg_buf.p; }
+        A.dbg = (!prune && !energy) ? stamps_begin((size_t)n_blocks * 16 * 8) : nullptr;
         prof.begin(prune ? 4 : 0, stream);   // stage 4 = force passes that also prune the outer list
         tr(prune ? "k_forces (prune)" : (energy ? "k_forces (energy)" : "k_forces"));
         launch_forces_any(A, energy);
@@ -1091,7 +1079,7 @@ template <class T> class Engine final : public EngineBase {
         prof.end(prune ? 4 : 0, stream);
         MHIP_HIP(hipGetLastError());
         ++n_force_calls;
-        if (A.dbg && (n_force_calls % dbg_times) == 0) dbg_report();
+        if (A.dbg && (n_force_calls % stamps_every()) == 0) stamps_report();
         if (prune) {   // validity of the pruned list: nobody moved more than half the margin since the outer search
             // one single-block launch that leaves its figures in pinned host memory (no zeroing launch, no copy launch) …
             hipLaunchKernelGGL(k_prune_summary, dim3(1), dim3(1024), 0, stream, n_blocks, n_blocks * JS * (BI / WAVE), n_blocks * (BI / WAVE), R_cap,
@@ -1106,11 +1094,12 @@ template <class T> class Engine final : public EngineBase {
             total_rows = h_flags[FLAG_TOTAL_ROWS]; max_tile_in = h_flags[FLAG_MAX_TILE];
             ++n_filters; ghost_flags_in_ok = false; next_check_step = -1;
             inner_valid = true; prune_disp_exceeded = 2.0 * std::sqrt((double)d2) > prune_margin() * 0.98;
-            if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] prune: max disp %.5f nm (margin %.3f) rows %lld exceeded %d calls %lld\n", std::sqrt((double)d2), prune_margin(), (long long)total_rows, (int)prune_disp_exceeded, (long long)n_force_calls);
+            if (debug_on) std::fprintf(stderr, "[mhip] prune: max disp %.5f nm (margin %.3f) rows %lld exceeded %d calls %lld\n", std::sqrt((double)d2), prune_margin(), (long long)total_rows, (int)prune_disp_exceeded, (long long)n_force_calls);
         }
     }
 
     DBuf<double> cm_fin_buf; const bool cm_fin_on = env_int("MOLLYHIP_CM_IN_PAIR_PASS", 1) != 0;
+    const double* cm_fin_solo_src = nullptr; bool cm_fin_solo_done = false;
 
     // the (block, group) items of the group-split pass handed to its workgroups so that every compute unit gets a like share of rows (forces_gs.hip, k_gs_balance)
     DBuf<uint16_t> gs_item; const bool gs_balance_on = env_int("MOLLYHIP_GS_BALANCE", 1) != 0; int cu_count = 0;
@@ -1131,16 +1120,10 @@ template <class T> class Engine final : public EngineBase {
         nbr_gs.reserve((size_t)n_blocks * JS * GS * R_cap * BI); rows_gs.reserve((size_t)n_blocks * JS * (BI / WAVE));
         RegroupArgs R{BI, ilog2(BI), JS, GS, ilog2(GS), R_cap, (const uint2*)nbr.p, (const uint16_t*)cnt_outer.p, (const int32_t*)tile_cnt.p, nbr_gs.p, rows_gs.p,
                       (int)std::min<size_t>((size_t)MAX_LDS_BYTES - (size_t)JS * BI * 16 - 64, (size_t)JS * R_cap * BI * 8), GS * R_cap};
-        static const int dbg_rg = env_int("MOLLYHIP_DBG_TIMES", 0);
-        if (dbg_rg) { dbg_buf.reserve((size_t)n_blocks * 16 * 8); R.dbg = dbg_buf.p; }
+        R.dbg = stamps_begin((size_t)n_blocks * 16 * 8);
         tr("k_regroup (outer list)");
         launch_regroup(R, n_blocks, stream);
-        if (R.dbg) {
-            std::vector<unsigned long long> h((size_t)n_blocks * 8);
-            MHIP_HIP(hipStreamSynchronize(stream));
-            MHIP_HIP(hipMemcpy(h.data(), dbg_buf.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-            if (const char* path = std::getenv("MOLLYHIP_DBG_DUMP_REGROUP")) { if (FILE* f = std::fopen(path, "wb")) { std::fwrite(h.data(), sizeof(unsigned long long), h.size(), f); std::fclose(f); } }
-        }
+        if (R.dbg) stamps_dump("MOLLYHIP_DBG_DUMP_REGROUP", (size_t)n_blocks * 8);
         gs_balance();
         prof.end(4, stream);
         MHIP_HIP(hipGetLastError());
@@ -1148,12 +1131,27 @@ template <class T> class Engine final : public EngineBase {
         ++n_filters; ++n_adopted; gs_list_id = n_filters;
         ghost_flags_in_ok = false; next_check_step = -1; lanes_sorted = false; cnt_in_valid = false;
         inner_valid = true; prune_disp_exceeded = false;
-        if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] outer list adopted as the inner list (no prune): rows %lld calls %lld\n", (long long)total_rows, (long long)n_force_calls);
+        if (debug_on) std::fprintf(stderr, "[mhip] outer list adopted as the inner list (no prune): rows %lld calls %lld\n", (long long)total_rows, (long long)n_force_calls);
     }
 
-    // timing experiment (library built with -DMHIP_EXP=11, MOLLYHIP_DBG_TIMES=n: every n-th plain pass): per-wave phase times of the pair kernel
+    // Time stamps inside the block kernels — only in libraries built with -DMHIP_STAMPS=1 (common.h), where MOLLYHIP_DBG_TIMES=n arms them (every n-th pass
+    // is reported / dumped to $MOLLYHIP_DBG_DUMP*, tools/gs_times.py, tools/build_times.py).  The product build carries none of it: its kernels get a null pointer.
+#if MHIP_STAMPS
     DBuf<unsigned long long> dbg_buf;
-    void dbg_report() {
+    static int stamps_every() { static const int n = env_int("MOLLYHIP_DBG_TIMES", 0); return std::max(n, 1); }
+    unsigned long long* stamps_begin(size_t words) {
+        static const int on = env_int("MOLLYHIP_DBG_TIMES", 0);
+        if (!on) return nullptr;
+        dbg_buf.reserve(words); MHIP_HIP(hipMemsetAsync(dbg_buf.p, 0, words * sizeof(unsigned long long), stream));
+        return dbg_buf.p;
+    }
+    void stamps_dump(const char* env_name, size_t words) {
+        std::vector<unsigned long long> h(words);
+        MHIP_HIP(hipStreamSynchronize(stream));
+        MHIP_HIP(hipMemcpy(h.data(), dbg_buf.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (const char* path = std::getenv(env_name)) { if (FILE* f = std::fopen(path, "wb")) { std::fwrite(h.data(), sizeof(unsigned long long), h.size(), f); std::fclose(f); } }
+    }
+    void stamps_report() {
         const int nw = BI * JS / WAVE;
         std::vector<unsigned long long> h((size_t)n_blocks * nw * 8);
         MHIP_HIP(hipStreamSynchronize(stream));
@@ -1173,6 +1171,12 @@ template <class T> class Engine final : public EngineBase {
         std::fprintf(stderr, "[mhip dbg] pair kernel: %d waves, first entry -> last exit %.2f us | per wave mean (max) us: staging %.2f (%.2f) row walk %.2f (%.2f) reduce+store %.2f (%.2f) | row walk p10 %.2f p50 %.2f p90 %.2f | shader clock %.3f GHz\n",
                      n, (double)(w3 - w0) * 0.01, sum[0] / n, mx[0], sum[1] / n, mx[1], sum[2] / n, mx[2], loop_us[n / 10], loop_us[n / 2], loop_us[(size_t)n * 9 / 10], clk / n);
     }
+#else
+    static int stamps_every() { return 1; }
+    unsigned long long* stamps_begin(size_t) { return nullptr; }
+    void stamps_dump(const char*, size_t) {}
+    void stamps_report() {}
+#endif
     // How far atoms may have moved since the outer search for a prune to be trustworthy: the outer list holds every pair within
     // r_list + outer_margin of then, the prune wants every pair within rc_max + skin_in of now.
     double prune_margin() const { return outer_margin + (skin - skin_in); }
@@ -1230,7 +1234,7 @@ template <class T> class Engine final : public EngineBase {
         total_rows = h_flags[FLAG_TOTAL_ROWS]; max_tile_in = h_flags[FLAG_MAX_TILE];
         ++n_filters; ghost_flags_in_ok = false; next_check_step = -1;
         inner_valid = true; prune_disp_exceeded = 2.0 * std::sqrt((double)d2) > prune_margin() * 0.98;
-        if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip] prune (kernel): max disp %.5f nm (margin %.3f) rows %lld exceeded %d\n", std::sqrt((double)d2), prune_margin(), (long long)total_rows, (int)prune_disp_exceeded);
+        if (debug_on) std::fprintf(stderr, "[mhip] prune (kernel): max disp %.5f nm (margin %.3f) rows %lld exceeded %d\n", std::sqrt((double)d2), prune_margin(), (long long)total_rows, (int)prune_disp_exceeded);
     }
 
     double read_sum(int n_part) {
@@ -1843,7 +1847,8 @@ template <class T> class Engine final : public EngineBase {
         ++n_disp_checks;
         bool reprune = !inner_valid || std::isinf(red3[1]);
         if (!reprune) {
-            const double d = std::sqrt((double)red3[1]), ahead = drift_ahead(d, step_n - last_prune_step, every + late);
+            // (measured at step_n, applied `late` steps later; the list is walked up to the pass of step_n + every — the next check's own step — as in resolve_track)
+            const double d = std::sqrt((double)red3[1]), ahead = drift_ahead(d, step_n - last_prune_step, every + std::max(late - 1, 0));
             adapt_inner_skin(ahead);
             reprune = !inner_valid || 2.0 * (d + ahead) > skin_in * 0.98;
             // not good for a whole interval, but for k steps: the host looks again then (it owns the step loop)
@@ -1911,12 +1916,18 @@ template <class T> class Engine final : public EngineBase {
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         const bool due = check_due(step_n, every) && step_n != last_build_step && (n_ghost == 0 || dual);
         if (due && dual) refresh(step_n);
-        step_forces(step_n);
-        if (cm_pending) flush_cm();                                               // (a removal registered through the stepwise entry points)
         const bool solo = hp.n_cm_peers == 0 && hp.n_send_rows == 0;              // no peers: the partials of the launch before are the whole sum
-        const double* cm_in = halo_cm_in ? (solo ? (const double*)cm_step.p + (size_t)(cm_half ^ 1) * 4 * 1024 : (const double*)cm_all.p) : (const double*)nullptr;
-        const int n_in = solo ? n_cm_step : 1 + hp.n_cm_peers;
-        const int nb = (cm && last) ? n_parts : std::min(cdiv(n_owned, 256), 1024);
+        // … which workgroup 0 of the pair pass in between adds up into ONE partial, as inside mhip_vv_run (ForceArgs::cm_fin_in): the integrator's blocks
+        // then do not each re-sum hundreds of partials first
+        cm_fin_solo_src = (solo && halo_cm_in && cm_fin_on && n_ghost == 0 && n_cm_step > 1 && n_cm_step <= 4096) ? (const double*)cm_step.p + (size_t)(cm_half ^ 1) * 4 * 1024 : (const double*)nullptr;
+        cm_fin_solo_done = false;
+        step_forces(step_n);
+        cm_fin_solo_src = nullptr;
+        if (cm_pending) flush_cm();                                               // (a removal registered through the stepwise entry points)
+        const double* cm_in = halo_cm_in ? (solo ? (cm_fin_solo_done ? (const double*)cm_fin_buf.p : (const double*)cm_step.p + (size_t)(cm_half ^ 1) * 4 * 1024) : (const double*)cm_all.p) : (const double*)nullptr;
+        const int n_in = solo ? (cm_fin_solo_done ? 1 : n_cm_step) : 1 + hp.n_cm_peers;
+        // (block count: mhip_vv_run's — fewer, longer blocks at these sizes, see there)
+        const int nb = (cm && last) ? n_parts : std::min(cdiv(n_owned, 256), solo ? (int)std::max<int64_t>(256, std::min<int64_t>(512, n_owned / 2048)) : 1024);
         double* cm_out = cm ? (last ? cm_parts_dev : cm_step.p + (size_t)(solo ? cm_half : 0) * 4 * 1024) : (double*)nullptr;
         prof.begin(2, stream);
         tr("k_vv_mid");
@@ -1945,7 +1956,7 @@ template <class T> class Engine final : public EngineBase {
         DBuf<int32_t> row_peer, row_dst, d_peers; DBuf<unsigned int> done; DBuf<int32_t> err; DBuf<float> mine3, red3;
         uint32_t seq = 0, plan_seq = 0;
         float* h_red3 = nullptr; int32_t* h_err = nullptr; hipEvent_t ev_plan = nullptr;
-        bool plan_pending = false; int64_t plan_step = -1, next_check = -1;
+        bool plan_pending = false; int64_t plan_step = -1, next_check = -1, plan_prune_id = -1, plan_outer_id = -1;      // (ids: the running counts of prunes / outer searches when the check was issued)
         RpPlanPtrs plan{}; uint32_t rp_seq = 0;      // every rank's plan area; number of the last re-plan made inside the engine (replan.h)
     } xf;
     bool xf_direct = false;      // inside mhip_domain_run: k_halo_pack stores into the peers' regions, k_halo_unpack waits for theirs
@@ -2062,7 +2073,7 @@ template <class T> class Engine final : public EngineBase {
             hipLaunchKernelGGL(k_plan_reduce, dim3(1), dim3(64), 0, stream, reinterpret_cast<const XferHeader*>(xf.region), xf.world, (int)(xf.plan_seq & 1u), xf.plan_seq, xf.red3.p, xf.h_red3, xf.err.p, xf_ticks());
         } else MHIP_HIP(hipMemcpyAsync(xf.h_red3, xf.mine3.p, 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
         MHIP_HIP(hipEventRecord(xf.ev_plan, stream));
-        xf.plan_pending = true; xf.plan_step = s;
+        xf.plan_pending = true; xf.plan_step = s; xf.plan_prune_id = n_filters; xf.plan_outer_id = n_outer;
     }
     // A run of ghosted steps in ONE call (≙ DomainRun.run of domain.py, fused form): returns after n_steps (reason 0) or behind the second
     // kick of the step after which ownership and ghosts have to be re-planned (reason 1); *steps_done steps were taken.  When the last
@@ -2094,7 +2105,12 @@ template <class T> class Engine final : public EngineBase {
                 if (xf.world > 1 && xf.h_red3[3] != 0.f) { xf_check_errors(); throw ApiError{MHIP_ERR_STATE, "ghost exchange timed out"}; }
                 int32_t check_in = 0;
                 const float red[3] = {xf.h_red3[0], xf.h_red3[1], xf.h_red3[2]};
-                const int action = std::isinf(red[0]) ? 2 : plan_decide_late(xf.plan_step, red, &check_in, (int)(s - xf.plan_step));
+                // A check issued at a step whose own force pass went on to prune (or search) measured lists that no longer exist — a check asked for k steps
+                // after a cadence step is read exactly at the next cadence step, where the next check is issued before the pass that carries out ITS prune:
+                // acting on it pruned again one step later (the lj1m domain loop pruned every 20 steps where mhip_vv_run prunes every 25).  Every rank counts
+                // the same prunes and searches, so every rank drops the same measurements; the fresh list is looked at at the next cadence step.
+                const bool lists_replaced = n_filters != xf.plan_prune_id || n_outer != xf.plan_outer_id;
+                const int action = lists_replaced ? 0 : (std::isinf(red[0]) ? 2 : plan_decide_late(xf.plan_step, red, &check_in, (int)(s - xf.plan_step)));
                 if (counters) { counters[1] += action == 1; counters[2] += action == 2; }
                 xf.next_check = check_in > 0 ? xf.plan_step + check_in : -1;
                 replan = action == 2;
@@ -2288,7 +2304,7 @@ template <class T> class Engine final : public EngineBase {
             throw ApiError{MHIP_ERR_CAPACITY, std::string("re-plan: ") + ((t.err & RP_ERR_ATOMS) ? "a sub-domain's atoms + ghosts exceed its context capacity" : (t.err & RP_ERR_PLAN_AREA) ? "the migrating atoms exceed a plan area"
                                              : "the ghost rows exceed a receive region") + " (create the contexts with more room)"};
         }
-        if (env_int("MOLLYHIP_DEBUG", 0)) std::fprintf(stderr, "[mhip %d] re-plan at step %lld: %d stay, %d leave, %d arrive; %d ghost rows out, %d ghosts in\n", me, (long long)step_n, t.n_stay, t.n_leave, t.n_arrive, t.n_send, t.n_ghost);
+        if (debug_on) std::fprintf(stderr, "[mhip %d] re-plan at step %lld: %d stay, %d leave, %d arrive; %d ghost rows out, %d ghosts in\n", me, (long long)step_n, t.n_stay, t.n_leave, t.n_arrive, t.n_send, t.n_ghost);
         // commit: the new local set in its identity order
         cur = n; dom.gcur = gn; dom.n_migrated += t.n_arrive;
         n_owned = t.n_owned; n_ghost = t.n_ghost; n_tot = n_owned + n_ghost;

@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(1024) k_regroup(RegroupArgs A) {
     // — the blocks a launch waits for); at the tail of the lists they sit in the last row or two.
     unsigned long long* l_cs = l_c + (size_t)A.JS * A.BI;                          // [JS][BI]: the special ones among them
     unsigned long long C = 0, CS = 0;
-#if MHIP_EXP == 11
+#if MHIP_STAMPS
     if (A.dbg && tid == 0) A.dbg[(size_t)b * 8 + 0] = wall_clock64();
 #endif
 
@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(1024) k_regroup(RegroupArgs A) {
         }
     }
     l_c[js * A.BI + li] = C; l_cs[js * A.BI + li] = CS;
-#if MHIP_EXP == 11
+#if MHIP_STAMPS
     if (A.dbg && tid == 0) A.dbg[(size_t)b * 8 + 1] = wall_clock64();
 #endif
 
@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(1024) k_regroup(RegroupArgs A) {
     if ((tid & (WAVE - 1)) == 0) atomicMax(l_rmax, rows_w);
     __syncthreads();
     const int R_l = *l_rmax;
-#if MHIP_EXP == 11
+#if MHIP_STAMPS
     if (A.dbg && tid == 0) A.dbg[(size_t)b * 8 + 2] = wall_clock64();
 #endif
 
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(1024) k_regroup(RegroupArgs A) {
     // pad my destination sub-list (positions nobody else writes)
     const uint16_t SENT = (uint16_t)((A.tile_cnt[b] + GS - 1) >> A.lgGS);
     for (int p = n_mine; p < 4 * rows_w; ++p) dst16[at(js, p)] = SENT;
-#if MHIP_EXP == 11
+#if MHIP_STAMPS
     if (A.dbg && tid == 0) A.dbg[(size_t)b * 8 + 3] = wall_clock64();
 #endif
 
@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(1024) k_regroup(RegroupArgs A) {
         uint2* out = A.dst + ((sub0 + js) * A.R_cap_dst) * A.BI + li;
         for (int r = 0; r < rows_w; ++r) out[(int64_t)r * A.BI] = l_rows[(js * R_l + r) * A.BI + li];
     }
-#if MHIP_EXP == 11
+#if MHIP_STAMPS
     if (A.dbg && tid == 0) A.dbg[(size_t)b * 8 + 4] = wall_clock64();
 #endif
 }
@@ -178,10 +178,10 @@ __device__ inline void forces_gs_body(const GsArgs& A, int wg, unsigned char* sm
     const int b = A.item_of ? bq : (bq + g * A.spread) % A.n_blocks;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int li = tid & (A.BI - 1), jw = tid >> A.BI_shift, JSW = A.JS >> A.lgGS, js = g * JSW + jw;
-    // timing experiment (-DMHIP_EXP=11): per wave — [0] shader clock at entry, [1] rows walked, [2] block | group << 20 | HW_ID << 32, [3] XCC_ID,
+    // timing experiment (-DMHIP_STAMPS=1): per wave — [0] shader clock at entry, [1] rows walked, [2] block | group << 20 | HW_ID << 32, [3] XCC_ID,
     // [4..7] the 100 MHz wall clock at entry, behind the staging barrier, behind the row walk, at the end
     [[maybe_unused]] auto stamp = [&](int k, unsigned long long v) {
-#if MHIP_EXP == 11
+#if MHIP_STAMPS
         if (A.dbg && (tid & 63) == 0) A.dbg[((size_t)wg * (nthr >> 6) + (tid >> 6)) * 8 + k] = v;
 #endif
     };

@@ -18,7 +18,7 @@ struct RegroupArgs {
     uint2* dst; int32_t* rows_dst;                                        // the group-split list
     int lds_list_bytes;                                                    // LDS the launch sets aside for staging a block's new list (the scatter goes to global memory if it does not fit)
     int R_cap_dst;                                                         // row capacity of a destination sub-list: GS · R_cap (a group's share of an atom's entries cannot exceed all of them)
-    unsigned long long* dbg;                                              // builds with -DMHIP_EXP=11: [block][8] wall-clock stamps of wave 0 (entry, counted, dealt, scattered, end)
+    unsigned long long* dbg;                                              // builds with -DMHIP_STAMPS=1: [block][8] wall-clock stamps of wave 0 (entry, counted, dealt, scattered, end)
 };
 struct GsArgs {
     GridP<float> G; InterP<float> I;
@@ -26,7 +26,7 @@ struct GsArgs {
     const float4* pos; const float2* lj; const int32_t* tile_idx; const int32_t* tile_cnt; const uint2* nbr; const int32_t* wave_rows; const float4* blk_center;
     float4* frc; float4* parts; int64_t part_stride;                      // group 0 → frc, group g → parts + (g − 1)·part_stride
     const uint16_t* item_of;                                              // [n_blocks·GS] nullable: which (group · n_blocks + block) workgroup w takes (k_gs_balance)
-    unsigned long long* dbg;                                              // builds with -DMHIP_EXP=11: [workgroup][wave][8] time stamps (engine: MOLLYHIP_DBG_TIMES, tools/gs_times.py)
+    unsigned long long* dbg;                                              // builds with -DMHIP_STAMPS=1: [workgroup][wave][8] time stamps (engine: MOLLYHIP_DBG_TIMES, tools/gs_times.py)
 };
 size_t gs_lds_bytes(int q_lds, int BI, int JSW);
 void launch_regroup(const RegroupArgs& A, int n_blocks, hipStream_t stream);

@@ -263,12 +263,11 @@ template <class T> struct BuildArgs {
     typename Vec<T>::T4* blk_center; // [n_blocks] centre (xyz) of the block's bounding box at build time
     int32_t* flags;
     T margin;
-    int debug;                       // MOLLYHIP_BUILD_DEBUG: stop after stage n (timing experiments only)
     int approx;                      // outer list of the dual scheme: any superset of r_list will do, skip the exact band test
     int walk;                        // search by walking every i-atom's cell stencil over the tile (1) or transposed, tile groups against the wave's i-atoms (0)
     int eshift;                      // entry format of the emitted rows (0 | ESHIFT_SCALED)
     uint16_t* cnt_out;               // [n_blocks][JS][BI] entries emitted per (j-split, atom), nullable (first lane order of the inner list)
-    unsigned long long* dbg;         // builds with -DMHIP_EXP=11 (MOLLYHIP_DBG_TIMES): [block][wave][8] — wall clock at entry / behind the staging / behind the search / at the end, entries found, exception-list lengths
+    unsigned long long* dbg;         // builds with -DMHIP_STAMPS=1 (MOLLYHIP_DBG_TIMES): [block][wave][8] — wall clock at entry / behind the staging / behind the search / at the end, entries found, exception-list lengths
 };
 
 // exclusive prefix sum of a[0..n) in LDS, in place; a[n] receives the total.  `part` holds blockDim ints.
@@ -312,7 +311,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv_all = tid >> 6, NW_ALL = nthr >> 6;
     const int li = tid & (A.BI - 1), js = tid >> A.BI_shift;   // thread = (j-split, i-atom); every j-split group sees the same i-atoms
     const int wv = li >> 6, NW = A.BI >> 6;                    // i-wave of my atom, i-waves per block
-#if MHIP_EXP == 11
+#if MHIP_STAMPS
     if (A.dbg && lane == 0) { unsigned long long* d = A.dbg + ((size_t)b * NW_ALL + wv_all) * 8; d[0] = wall_clock64(); }
 #endif
     // tile atoms in block-local coordinates, ALWAYS fp32: the search only needs them for the cheap pre-test, whose
@@ -384,7 +383,6 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
         else A.blk_center[b] = make4<T>(s_ctr[0], s_ctr[1], s_ctr[2], T(0));
     }
     __syncthreads();
-    if (A.debug == 1) return;
     const int lx = s_boxlen[0], ly = s_boxlen[1], lz = s_boxlen[2];
     const int ncb = lx * ly * lz;
     const bool exact_only = s_exact != 0;
@@ -455,7 +453,6 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
     }
     __syncthreads();
     const int nraw = block_excl_scan(c_raw, ncb, part, tid, nthr);
-    if (A.debug == 2) return;
 
     // 2. atom-level pruning + ordered compaction into the LDS tile (cell-major, sorted order inside a cell)
     if constexpr (WALK) { for (int q = tid; q <= ncb; q += nthr) t_off[q] = 0; __syncthreads(); }
@@ -523,8 +520,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
     }
     if (tid == 0) A.tile_cnt[b] = tile_n;
     if (WALK && !exact_only) block_excl_scan(t_off, ncb, part, tid, nthr);   // → first tile slot of every box cell, t_off[ncb] = tile_n
-    if (A.debug == 3) return;
-#if MHIP_EXP == 11
+#if MHIP_STAMPS
     if (A.dbg && lane == 0) { unsigned long long* d = A.dbg + ((size_t)b * NW_ALL + wv_all) * 8; d[1] = wall_clock64(); }
 #endif
 
@@ -589,7 +585,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
             }
             return (hit & XL_EXCLUDED) ? -1 : (int)(hit >> 31);
         };
-#if MHIP_EXP == 11
+#if MHIP_STAMPS
         if (A.dbg) { int x = nxl; for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, WAVE); if (lane == 0) A.dbg[((size_t)b * NW_ALL + wv_all) * 8 + 6] = (unsigned long long)x; }
 #endif
         T my_loc[3], my_ub[3]; localise3(my[0], my[1], my[2], my_loc, my_ub);
@@ -674,7 +670,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
                     near = acc <= reach2f;
                 }
             }
-            if (__ballot(near) == 0ull || A.debug == 8) continue;          // the whole group is out of this wave's reach
+            if (__ballot(near) == 0ull) continue;          // the whole group is out of this wave's reach
             int mine_lo = 0, mine_hi = 0;                  // lane i: mask of its neighbours within this group
             if (!exact_only) {
                 // which of my wave's i-atoms can reach this group at all?  bounding box of the group's near atoms
@@ -731,7 +727,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
             }
             // each lane unpacks its own mask (slot order = tile order: deterministic lists)
             unsigned long long mm = ((unsigned long long)(uint32_t)mine_hi << 32) | (uint32_t)mine_lo;
-            if (!((valid_mask >> lane) & 1ull) || A.debug == 7) mm = 0;
+            if (!((valid_mask >> lane) & 1ull)) mm = 0;
             while (mm) {
                 const int bit = __builtin_ctzll(mm);
                 mm &= mm - 1;
@@ -747,8 +743,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
         }
         }   // transposed search
     }
-    if (A.debug == 4) return;
-#if MHIP_EXP == 11
+#if MHIP_STAMPS
     if (A.dbg) {
         int c = cnt, x = 0;
         for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, WAVE);
@@ -763,7 +758,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
     const int rows_keep = rows_wave > A.R_cap ? 0 : rows_wave;
     while (((cnt + 3) >> 2) < rows_keep || (cnt & 3)) emit(SENT);
     if (lane == 0) A.wave_rows[(b * A.JS + js) * NW + wv] = rows_wave;   // > R_cap reports the required capacity; k_build_summary zeroes it
-#if MHIP_EXP == 11
+#if MHIP_STAMPS
     if (A.dbg && lane == 0) { unsigned long long* d = A.dbg + ((size_t)b * NW_ALL + wv_all) * 8; d[3] = wall_clock64(); }
 #endif
 }
@@ -897,7 +892,6 @@ template <class T> struct FilterArgs {
     T r_in, r_in2;                            // r_list and r_list² as the reference forms them (dist_cutoff ^ 2)
     int exact_all;                            // small boxes: block-local coordinates are ambiguous, decide every pair exactly
     int approx;                               // any superset of r_in will do (the force passes' inner list): no exact decisions in the band
-    int debug;                                // MOLLYHIP_FILTER_DEBUG (timing experiments only): 1 no row stores, 2 and no marks, 3 and no compaction / renumbering
     int eshift;                               // entry format of both lists (0 | ESHIFT_SCALED)
 };
 
@@ -956,7 +950,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_filter(FilterAr
         if (k == 0) { pack[0] = 0; pack[1] = 0; }
         pack[k >> 1] |= e << (16 * (k & 1));
         ++cnt;
-        if (k == 3 && A.debug < 1) dst[(int64_t)((cnt >> 2) - 1) * A.BI] = make_uint2(pack[0], pack[1]);
+        if (k == 3) dst[(int64_t)((cnt >> 2) - 1) * A.BI] = make_uint2(pack[0], pack[1]);
     };
     uint2 e_next = (0 < rows) ? src[0] : make_uint2(0, 0);
     for (int r = 0; r < rows; ++r) {
@@ -981,14 +975,13 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_filter(FilterAr
                 min_image_exact<T>(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z, G, ex, ey, ez);
                 in = norm2_exact(ex, ey, ez) <= A.r_in2;
             }
-            if (in) { emit(e); if (A.debug < 2) l_used[slot] = 1; }   // benign race: every writer stores the same byte
+            if (in) { emit(e); l_used[slot] = 1; }   // benign race: every writer stores the same byte
         }
     }
     int rows_mine = (cnt + 3) >> 2;
     int rows_wave = wave_max(rows_mine);
     while (((cnt + 3) >> 2) < rows_wave || (cnt & 3)) emit(make_entry(SENT, 0u, esh));
     if (lane == 0) A.rows_in[wslot] = rows_wave;
-    if (A.debug >= 3) return;
     // compact the tile to the referenced atoms: rank of every used slot (ordered), new tile list, rows rewritten in place
     __syncthreads();
     {
@@ -1070,7 +1063,7 @@ template <class T> struct ForceArgs {
     // are still on the wire) or only the others (part 2); 0 = every block
     const int32_t* blk_ghost; int part;
     int level_pairs;                 // PRUNE, two sub-lists per atom: level the two lanes' entry counts before padding
-    // MOLLYHIP_DBG_TIMES (builds with -DMHIP_EXP=11 only): [n_blocks][waves][8] — shader clock and 100 MHz wall clock at kernel entry, behind the
+    // MOLLYHIP_DBG_TIMES (builds with -DMHIP_STAMPS=1 only): [n_blocks][waves][8] — shader clock and 100 MHz wall clock at kernel entry, behind the
     // staging barrier, behind the row walk and at the end, per wave
     unsigned long long* dbg;
     // Σ m v of the integrator launch before this pass, still per-block partials (k_vv_mid): workgroup 0 of this pass adds them up into ONE partial behind its own
@@ -1100,23 +1093,8 @@ __host__ __device__ inline size_t prune_lds_bytes(int t_seg, int nthr) { return 
 #ifndef MHIP_FAST_MIN_WAVES
 #define MHIP_FAST_MIN_WAVES 8
 #endif
-#ifndef MHIP_D
-#define MHIP_D 2        // rows in flight in the packed loop (3 and 4 need scratch under the 64-VGPR bound: measured slower, +10 %)
-#endif
 #ifndef MHIP_SB
 #define MHIP_SB 4       // atoms per lane and staging round of the packed loop
-#endif
-#ifndef MHIP_HOIST
-#define MHIP_HOIST 0    // request the first rows before the tile is staged (1: 12 bytes of scratch, measured +4 %)
-#endif
-#ifndef MHIP_PEXP
-#define MHIP_PEXP 0     // timing experiments of the pruning pass
-#endif
-#ifndef MHIP_PK2
-#define MHIP_PK2 1      // the two-partner packed loop of the fp32 per-atom-parameter variants (0: the one-partner loop everywhere, for A/B runs)
-#endif
-#ifndef MHIP_EXP
-#define MHIP_EXP 0      // timing experiments of the packed loop (tools/force_ab.py); 0 = the product
 #endif
 template <class T, int LJM, int COULM, bool ENERGY, bool MINIMG, bool SEG, bool PRUNE>
 constexpr int force_min_waves() { return (std::is_same<T, float>::value && LJM == LJ_DIST_UNIFORM && COULM == MHIP_COUL_NONE && !ENERGY && !MINIMG && !SEG && !PRUNE) ? MHIP_FAST_MIN_WAVES : 1; }
@@ -1137,7 +1115,7 @@ k_forces(ForceArgs<T> A) {
     if (A.part != 0 && (A.blk_ghost[b] != 0) != (A.part == 2)) return;
     const int tid = threadIdx.x, nthr = blockDim.x;
     [[maybe_unused]] auto stamp = [&](int k) {
-        if constexpr (MHIP_EXP == 11 && !PRUNE) {
+        if constexpr (MHIP_STAMPS != 0 && !PRUNE) {
             if (A.dbg && (tid & 63) == 0) { unsigned long long* d = A.dbg + ((size_t)b * (nthr >> 6) + (tid >> 6)) * 8; d[k] = __builtin_readcyclecounter(); d[4 + k] = wall_clock64(); }
         }
     };
@@ -1147,7 +1125,6 @@ k_forces(ForceArgs<T> A) {
     T2* l_lj = reinterpret_cast<T2*>(l_pos + (A.T_lds + 1));
     const T4 ctr = A.blk_center[b];
     // only the fp32 one-type variants ever see the scaled entry format (the engine chooses it for them alone)
-    constexpr int EXPV = PRUNE ? 0 : MHIP_EXP;   // (timing experiments never touch the pruning passes: the lists stay the product's)
     constexpr bool MAY_SCALE = std::is_same<T, float>::value && LJM == LJ_DIST_UNIFORM && COULM == MHIP_COUL_NONE;
     const int esh = MAY_SCALE ? A.eshift : 0;
 
@@ -1175,9 +1152,7 @@ k_forces(ForceArgs<T> A) {
     auto pre_e = [](T2 v) { if constexpr (PRE_E) { v.y = v.x == T(0) ? T(0) : M<T>::sqrt(v.y); v.x *= T(0.5); } return v; };   // (σ/2 as well: LorentzMixing becomes one add, and halving is exact)
     lji = pre_e(lji);
     // this wave's own sub-list (the j-split was done by k_build); the row count is the same for all 64 lanes: a scalar
-    // (timing experiments — MHIP_EXP 6: staging and reduction only; 8 / 9: no wave walks more than 8 / 4 rows, i.e. every block as light as an average / a half one)
-    const int rows_all = (MHIP_EXP == 6 && !PRUNE) ? 0 : __builtin_amdgcn_readfirstlane(A.wave_rows[(b * A.JS + js) * (A.BI >> 6) + (li >> 6)]);
-    const int rows = (MHIP_EXP == 8 && !PRUNE) ? min(rows_all, 8) : (MHIP_EXP == 9 && !PRUNE) ? min(rows_all, 4) : rows_all;
+    const int rows = __builtin_amdgcn_readfirstlane(A.wave_rows[(b * A.JS + js) * (A.BI >> 6) + (li >> 6)]);
     const uint2* my_rows = A.nbr + (((int64_t)b * A.JS + js) * A.R_cap) * A.BI + li;
     const int32_t* tix = A.tile_idx + (int64_t)b * A.T_cap;
     T fx = T(0), fy = T(0), fz = T(0), pe = T(0);
@@ -1262,13 +1237,6 @@ k_forces(ForceArgs<T> A) {
     };
 
     constexpr bool FAST_CT = std::is_same<T, float>::value && LJM == LJ_DIST_UNIFORM && COULM == MHIP_COUL_NONE && !ENERGY && !MINIMG && !SEG;
-    // the packed loop keeps four rows in flight; the first four are requested here, before the tile is staged, so that the row
-    // stream's first memory latency passes behind the staging (indices clamped to the last row: always a valid address)
-    [[maybe_unused]] uint2 pre0 = make_uint2(0, 0), pre1 = pre0, pre2 = pre0, pre3 = pre0;
-    if constexpr (FAST_CT && MHIP_HOIST) {
-        const int last = max(rows - 1, 0);
-        pre0 = my_rows[0]; pre1 = my_rows[(int64_t)min(1, last) * A.BI]; pre2 = my_rows[(int64_t)min(2, last) * A.BI]; pre3 = my_rows[(int64_t)min(3, last) * A.BI];
-    }
     // The tile normally fits the LDS carve-up in one piece.  SEG: a tile larger than the LDS budget is
     // processed in segments; every segment re-walks the row stream and treats slots outside it as sentinels.
     const int seg_cap = A.T_lds;
@@ -1298,7 +1266,6 @@ k_forces(ForceArgs<T> A) {
                     if (k < kmax) {
                         const int t = min(t0 + k * nthr + tid, n_here - 1);     // (clamped: the loads of a lane past the end are harmless duplicates)
                         s[k] = tix[seg_lo + t];
-                        if constexpr (EXPV == 3 || EXPV == 5) s[k] = (int)((int64_t)b * A.BI) + (t & (A.BI - 1));   // timing experiment: no staging gathers (the block's own atoms over and over)
                     }
                 }
 #pragma unroll
@@ -1414,10 +1381,6 @@ k_forces(ForceArgs<T> A) {
                 typedef __attribute__((address_space(3))) const char* lds_cptr;
                 const lds_cptr lbase = (lds_cptr)(uintptr_t)0;
                 auto lds3 = [&](uint32_t oa, uint32_t ob, v2f& dx, v2f& dy, v2f& dz) {
-                    if constexpr (EXPV == 1 || EXPV == 5) {   // timing experiment: no LDS gathers (coordinates made up from the entry bits)
-                        dx = (v2f){__uint_as_float(0x3f000000u | oa), __uint_as_float(0x3f000000u | ob)} - pix; dy = (v2f){__uint_as_float(0x3f100000u | oa), __uint_as_float(0x3f200000u | ob)} - piy; dz = (v2f){__uint_as_float(0x3f300000u | ob), __uint_as_float(0x3f400000u | oa)} - piz;
-                        return;
-                    }
                     typedef __attribute__((address_space(3))) const float* lds_fptr;
                     const lds_fptr pa = (lds_fptr)(lbase + oa), pb = (lds_fptr)(lbase + ob);
                     dx = (v2f){pa[0], pb[0]} - pix; dy = (v2f){pa[SOA_STRIDE], pb[SOA_STRIDE]} - piy; dz = (v2f){pa[2 * SOA_STRIDE], pb[2 * SOA_STRIDE]} - piz;
@@ -1432,9 +1395,7 @@ k_forces(ForceArgs<T> A) {
                         // the four new slot numbers are fetched up front, with the coordinates: looked up inside the branches, each kept
                         // entry waited for an LDS round trip of its own
                         const uint32_t na = l_new[oa >> 2], nb = l_new[ob >> 2], nc = l_new[oc >> 2], nd = l_new[od >> 2];
-                        if constexpr (MHIP_PEXP != 1) {    // (MHIP_PEXP: timing experiments of the pruning pass, 1 = no emission, 2 = no LJ arithmetic)
-                            emit4(na << ESHIFT_SCALED, nb << ESHIFT_SCALED, nc << ESHIFT_SCALED, nd << ESHIFT_SCALED, r20.x <= rp2, r20.y <= rp2, r21.x <= rp2, r21.y <= rp2);
-                        }
+                        emit4(na << ESHIFT_SCALED, nb << ESHIFT_SCALED, nc << ESHIFT_SCALED, nd << ESHIFT_SCALED, r20.x <= rp2, r20.y <= rp2, r21.x <= rp2, r21.y <= rp2);
                     }
                     const float t0 = __builtin_amdgcn_rcpf(r20.x * r20.y), t1 = __builtin_amdgcn_rcpf(r21.x * r21.y);
                     const v2f u0 = (v2f){r20.y, r20.x} * t0, u1 = (v2f){r21.y, r21.x} * t1;       // 1/r² of each partner
@@ -1446,24 +1407,19 @@ k_forces(ForceArgs<T> A) {
                     const v2f c0 = q0 * u0, c1 = q1 * u1;                                        // 1/r⁶
                     const v2f g0 = __builtin_elementwise_fma(c0, c48v, -c24v), g1 = __builtin_elementwise_fma(c1, c48v, -c24v);
                     const v2f h0 = c0 * w0, h1 = c1 * w1;
-                    v2f f0 = g0 * h0, f1 = g1 * h1;                                              // (48ϵσ¹²/r⁶ − 24ϵσ⁶)/r⁸ inside the cutoff, else 0
-                    if constexpr (EXPV == 4 || (PRUNE && MHIP_PEXP == 2)) { f0 = in0; f1 = in1; }   // timing experiment: no LJ arithmetic
+                    const v2f f0 = g0 * h0, f1 = g1 * h1;                                        // (48ϵσ¹²/r⁶ − 24ϵσ⁶)/r⁸ inside the cutoff, else 0
                     fx2 -= dx0 * f0; fy2 -= dy0 * f0; fz2 -= dz0 * f0;
                     fx2 -= dx1 * f1; fy2 -= dy1 * f1; fz2 -= dz1 * f1;
                 };
-                // Four rows per trip, each fetched three rows ahead of its use (a wave spends ≈ 1.3 µs on a row, less than a loaded
-                // HBM round trip), loop control on the scalar unit.  The fetches are unconditional — the index is clamped to the last
-                // row, a few redundant loads per lane — so that the compiler can count them: behind a branch it waits for ALL
-                // outstanding loads, the one it has just issued included.
+                // Two rows per trip, each fetched two rows ahead of its use, loop control on the scalar unit (three and four rows in flight, and
+                // first rows requested before the staging, spill under the 64-VGPR bound: +4 … +10 % per pass, profiles/r03_force_ab.txt).  The
+                // fetches are unconditional — the index is clamped to the last row, a few redundant loads per lane — so that the compiler can
+                // count them: behind a branch it waits for ALL outstanding loads, the one it has just issued included.
                 if (rows > 0) {
                     const int last = rows - 1;
-                    constexpr int D = PRUNE ? 2 : MHIP_D;      // (the pruning variant carries its emission state: two rows in flight)
-                    uint2 e[4] = {pre0, pre1, pre2, pre3};
-                    if constexpr (!MHIP_HOIST) { e[0] = my_rows[0]; e[1] = my_rows[(int64_t)min(1, last) * A.BI]; if constexpr (D > 2) e[2] = my_rows[(int64_t)min(2, last) * A.BI]; if constexpr (D > 3) e[3] = my_rows[(int64_t)min(3, last) * A.BI]; }
-                    auto next = [&](int q) -> uint2 {
-                        if constexpr (EXPV == 2 || EXPV == 5) return make_uint2(((uint32_t)q * 0x00240014u + e[0].x) & 0x1ffc1ffcu, ((uint32_t)q * 0x00140024u + e[1].y) & 0x1ffc1ffcu);   // timing experiment: no row stream
-                        return my_rows[(int64_t)min(q, last) * A.BI];
-                    };
+                    constexpr int D = 2;
+                    uint2 e[D] = {my_rows[0], my_rows[(int64_t)min(1, last) * A.BI]};
+                    auto next = [&](int q) -> uint2 { return my_rows[(int64_t)min(q, last) * A.BI]; };
                     int r = 0;
                     for (; r + D <= rows; r += D) {
 #pragma unroll
@@ -1481,7 +1437,7 @@ k_forces(ForceArgs<T> A) {
             // displacement is taken per partner — (dx, dy) as one packed subtraction out of the record's first register pair —, r² and
             // the per-partner parameters land in the halves of register pairs, and everything behind them is packed.  A row that names a
             // special (1-4) pair in any lane of the wave takes the one-partner loop below (3 094 of 4.6 M pairs in 6mrr).
-            constexpr bool PK2 = std::is_same<T, float>::value && LJM == LJ_DIST && (COULM == MHIP_COUL_EWALD_DIRECT || COULM == MHIP_COUL_REACTION_FIELD) && !ENERGY && MHIP_PK2;
+            constexpr bool PK2 = std::is_same<T, float>::value && LJM == LJ_DIST && (COULM == MHIP_COUL_EWALD_DIRECT || COULM == MHIP_COUL_REACTION_FIELD) && !ENERGY;
             [[maybe_unused]] bool pk2_ok = false;
             if constexpr (PK2) pk2_ok = Pk2Consts::usable(reinterpret_cast<const InterP<float>&>(A.I));
             [[maybe_unused]] auto row_pk2 = [&](const uint2 e4) {
@@ -1496,13 +1452,8 @@ k_forces(ForceArgs<T> A) {
                         [[maybe_unused]] const bool real_a = SEG ? (sa - (uint32_t)seg_lo) < (uint32_t)n_here : sa < (uint32_t)tile_n, real_b = SEG ? (sb - (uint32_t)seg_lo) < (uint32_t)n_here : sb < (uint32_t)tile_n;
                         if constexpr (SEG) { sa = real_a ? sa - (uint32_t)seg_lo : (uint32_t)n_here; sb = real_b ? sb - (uint32_t)seg_lo : (uint32_t)n_here; }   // slots of other segments: the sentinel
                         float4 pa, pb; float2 la, lb;
-                        if constexpr (EXPV == 7) {   // timing experiment: no LDS gathers (records made up from the entry bits)
-                            pa = make_float4(__uint_as_float(0x3f000000u | sa), __uint_as_float(0x3f100000u | sa), __uint_as_float(0x3f200000u | sa), 0.4f); pb = make_float4(__uint_as_float(0x3f300000u | sb), __uint_as_float(0x3f400000u | sb), __uint_as_float(0x3f000000u | sb), -0.8f);
-                            la = make_float2(0.15f, 0.8f); lb = make_float2(0.f, 0.f);
-                        } else {
-                            pa = *reinterpret_cast<const float4*>(&l_pos[sa]); pb = *reinterpret_cast<const float4*>(&l_pos[sb]);
-                            la = *reinterpret_cast<const float2*>(&l_lj[sa]); lb = *reinterpret_cast<const float2*>(&l_lj[sb]);
-                        }
+                        pa = *reinterpret_cast<const float4*>(&l_pos[sa]); pb = *reinterpret_cast<const float4*>(&l_pos[sb]);
+                        la = *reinterpret_cast<const float2*>(&l_lj[sa]); lb = *reinterpret_cast<const float2*>(&l_lj[sb]);
                         v2f da, db; float dza, dzb;
                         if constexpr (MINIMG) {
                             float x, y, z;
@@ -1534,10 +1485,6 @@ k_forces(ForceArgs<T> A) {
             constexpr int UNROLL = (sizeof(T) == 8 && (COULM == MHIP_COUL_EWALD_DIRECT || COULM == COUL_EWALD_EXACT)) ? (MINIMG ? 1 : (LJM == LJ_GENERIC && ENERGY ? 2 : 4)) : 4;
             for (int r = 0; r < rows; ++r) {
                 const uint2 e4 = e_next;
-                if constexpr (EXPV == 10) {   // timing experiment: no row stream (slots made up from the row number)
-                    const uint32_t m = (uint32_t)max(tile_n - 1, 1), q = ((uint32_t)r * 0x9E3779B1u + (uint32_t)li * 4u);
-                    e_next = make_uint2(((q % m) | (((q + 1) % m) << 16)), (((q + 2) % m) | (((q + 3) % m) << 16)));
-                } else
                 if (r + 1 < rows) e_next = my_rows[(int64_t)(r + 1) * A.BI];
                 if constexpr (PK2) {
                     if (pk2_ok && (!SPEC || __builtin_amdgcn_ballot_w64(((e4.x | e4.y) & 0x80008000u) != 0u) == 0ull)) { row_pk2(e4); continue; }

@@ -24,7 +24,6 @@ template <class T> struct PmeP {
     T invL[3], n_over_L[3];
     T f_div_er, factor, pi_V;        // ke/ϵr, π²/α², π·V
     int tri; T r[3][3];              // TriclinicBoundary: recip_box = invert_box_vectors(boundary) (spatial.jl:338-347), r[e][d] = recip_box[e+1][d+1]; lower triangular
-    int debug;                       // MOLLYHIP_PME_DEBUG: timing experiments only
 };
 
 // update_bsplines_inner! (:518-556) for one fractional offset: θ and dθ/du of the ORDER B-spline weights
@@ -282,7 +281,7 @@ __device__ inline void pme_gather_blocks(int bid, int nblk, int64_t n_atoms, con
 #pragma unroll
                     for (int ix = 0; ix < ORDER; ++ix) {
                         int xi = i0x + ix; xi -= xi >= P.n[0] ? P.n[0] : 0;
-                        g[ix] = (P.debug & 1) ? T(1) : col[(int64_t)xi * P.n[1] * P.n[2]];
+                        g[ix] = col[(int64_t)xi * P.n[1] * P.n[2]];
                     }
 #pragma unroll
                     for (int ix = 0; ix < ORDER; ++ix) {
@@ -679,7 +678,6 @@ template <class T> struct Pme {
         const T a = T(alpha);
         T V = T(1);
         for (int d = 0; d < 3; ++d) { P.n[d] = mesh[d]; P.invL[d] = T(1) / T(box[d]); P.n_over_L[d] = T(mesh[d]) * (T(1) / T(box[d])); V *= T(box[d]); }
-        { const char* v = std::getenv("MOLLYHIP_PME_DEBUG"); P.debug = v && *v ? std::atoi(v) : 0; }
         P.tri = bv9 ? 1 : 0;
         for (int e = 0; e < 3; ++e) for (int d = 0; d < 3; ++d) P.r[e][d] = T(0);
         if (bv9) {      // invert_box_vectors(::TriclinicBoundary), spatial.jl:338-347, in T
