@@ -1985,10 +1985,10 @@ template <class T> class Engine final : public EngineBase {
             xf.peers.region[my_rank] = xf.region; xf.peer_cap[my_rank] = rows_cap;
             for (int r = 0; r < XFER_MAX_RANKS; ++r) xf.plan.area[r] = nullptr;
             xf.plan.area[my_rank] = xf.region + xfer_plan_off<T>(rows_cap);
-            xf.done.reserve(1); xf.err.reserve(1); xf.mine3.reserve(4); xf.red3.reserve(4);
-            MHIP_HIP(hipMemset(xf.done.p, 0, sizeof(unsigned int))); MHIP_HIP(hipMemset(xf.err.p, 0, sizeof(int32_t)));
+            xf.done.reserve(1); xf.err.reserve(4); xf.mine3.reserve(4); xf.red3.reserve(4);
+            MHIP_HIP(hipMemset(xf.done.p, 0, sizeof(unsigned int))); MHIP_HIP(hipMemset(xf.err.p, 0, 4 * sizeof(int32_t)));
             if (!xf.h_red3) MHIP_HIP(hipHostMalloc((void**)&xf.h_red3, 4 * sizeof(float)));
-            if (!xf.h_err) MHIP_HIP(hipHostMalloc((void**)&xf.h_err, sizeof(int32_t)));
+            if (!xf.h_err) MHIP_HIP(hipHostMalloc((void**)&xf.h_err, 4 * sizeof(int32_t)));
             if (!xf.ev_plan) MHIP_HIP(hipEventCreateWithFlags(&xf.ev_plan, hipEventDisableTiming));
         }
         if (handle_out) {
@@ -2049,7 +2049,7 @@ template <class T> class Engine final : public EngineBase {
         MHIP_HIP(hipMemcpyAsync(xf.h_err, xf.err.p, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         MHIP_HIP(hipStreamSynchronize(stream));
         const bool ok = *xf.h_err == 0 && xf.h_red3[0] == (float)xf.world;      // the MAX of the tokens is the highest rank's
-        if (*xf.h_err) MHIP_HIP(hipMemset(xf.err.p, 0, sizeof(int32_t)));
+        if (*xf.h_err) MHIP_HIP(hipMemset(xf.err.p, 0, 4 * sizeof(int32_t)));
         return ok ? 1 : 0;
     }
     // bound of every in-kernel wait for a peer, in ticks of the 100 MHz wall clock (MOLLYHIP_XFER_TIMEOUT_MS; 2 s unless set: a peer may be
@@ -2058,11 +2058,22 @@ template <class T> class Engine final : public EngineBase {
         static const unsigned long long t = (unsigned long long)std::max(1, env_int("MOLLYHIP_XFER_TIMEOUT_MS", 2000)) * 100000ull;
         return t;
     }
+    // what a wait that gave up recorded (halo_xfer.h, xfer_wait): which kernel waited for which rank, for which sequence number, and what it last saw
+    static std::string wait_report(const int32_t* e) {
+        if (!e[1]) return "";
+        static const char* const what[] = {"?", "the ghost rows (k_halo_unpack)", "the validity triple (k_plan_reduce)", "the migration counts", "the ghost counts", "the migrating atoms", "the new ghosts"};
+        const int who = e[1] - 1, k = (who >> 8) & 0xff;
+        return std::string(": waited for ") + what[k < 7 ? k : 0] + " of rank " + std::to_string(who & 0xff) + ", sequence number " + std::to_string((uint32_t)e[2]) + ", last seen " + std::to_string((uint32_t)e[3]);
+    }
     void xf_check_errors() {
         if (!xf.region) return;
-        MHIP_HIP(hipMemcpyAsync(xf.h_err, xf.err.p, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        MHIP_HIP(hipMemcpyAsync(xf.h_err, xf.err.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         MHIP_HIP(hipStreamSynchronize(stream));
-        if (*xf.h_err) { MHIP_HIP(hipMemset(xf.err.p, 0, sizeof(int32_t))); throw ApiError{MHIP_ERR_STATE, "ghost exchange timed out: a peer's rows (or its validity triple) did not arrive in time (MOLLYHIP_XFER_TIMEOUT_MS)"}; }
+        if (*xf.h_err) {
+            const std::string rep = wait_report(xf.h_err);
+            MHIP_HIP(hipMemset(xf.err.p, 0, 4 * sizeof(int32_t)));
+            throw ApiError{MHIP_ERR_STATE, "ghost exchange timed out: a peer's rows (or its validity triple) did not arrive in time (MOLLYHIP_XFER_TIMEOUT_MS)" + rep + "; this rank is at exchange " + std::to_string(xf.seq)};
+        }
     }
     // the collective validity check of the pair lists, issued at step s and read one step later (nothing waits for it)
     void xf_issue_plan_check(int64_t s) {
@@ -2209,8 +2220,8 @@ template <class T> class Engine final : public EngineBase {
         dom.gid[0].reserve(cap); dom.gid[1].reserve(cap); dom.gcur = 0;
         if (gids_dev) MHIP_HIP(hipMemcpyAsync(dom.gid[0].p, gids_dev, (size_t)n_owned * sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
         else { std::vector<int64_t> io((size_t)n_owned); for (int64_t i = 0; i < n_owned; ++i) io[i] = i; MHIP_HIP(hipMemcpy(dom.gid[0].p, io.data(), io.size() * sizeof(int64_t), hipMemcpyHostToDevice)); }
-        dom.tab.reserve(1); dom.err.reserve(1); dom.ranks.reserve(XFER_MAX_RANKS);
-        MHIP_HIP(hipMemsetAsync(dom.err.p, 0, sizeof(int32_t), stream));
+        dom.tab.reserve(1); dom.err.reserve(4); dom.ranks.reserve(XFER_MAX_RANKS);
+        MHIP_HIP(hipMemsetAsync(dom.err.p, 0, 4 * sizeof(int32_t), stream));
         if (!dom.h_tab) MHIP_HIP(hipHostMalloc((void**)&dom.h_tab, sizeof(RpTab)));
         if (!dom.h_lj0) MHIP_HIP(hipHostMalloc((void**)&dom.h_lj0, 2 * sizeof(T)));
         std::vector<int32_t> others; for (int r = 0; r < world; ++r) if (r != me) others.push_back(r);
@@ -2299,10 +2310,16 @@ template <class T> class Engine final : public EngineBase {
         MHIP_HIP(hipStreamSynchronize(stream));
         const RpTab& t = *dom.h_tab;
         if (t.err) {
-            MHIP_HIP(hipMemset(dom.err.p, 0, sizeof(int32_t)));
-            if (t.err & RP_ERR_TIMEOUT) throw ApiError{MHIP_ERR_STATE, "re-plan: a peer's counts or rows did not arrive in time (MOLLYHIP_XFER_TIMEOUT_MS)"};
+            int32_t e4[4] = {0, 0, 0, 0};
+            MHIP_HIP(hipMemcpy(e4, dom.err.p, sizeof(e4), hipMemcpyDeviceToHost));
+            MHIP_HIP(hipMemset(dom.err.p, 0, 4 * sizeof(int32_t)));
+            std::string tabs = " [rank " + std::to_string(me) + " at step " + std::to_string(step_n) + ": " + std::to_string(n_old) + " owned before, " + std::to_string(t.n_stay) + " stay, " + std::to_string(t.n_leave) + " leave, " +
+                               std::to_string(t.n_arrive) + " arrive, " + std::to_string(t.n_send) + " ghost rows out, " + std::to_string(t.n_ghost) + " ghosts in, capacity " + std::to_string(cap) + " atoms / " + std::to_string(xf.rows_cap) + " rows; to / from each rank:";
+            for (int r = 0; r < world; ++r) tabs += " " + std::to_string(t.leave_cnt[r]) + "/" + std::to_string(t.arr_from[r]) + "|" + std::to_string(t.send_to[r]) + "/" + std::to_string(t.gh_from[r]);
+            tabs += "]";
+            if (t.err & RP_ERR_TIMEOUT) throw ApiError{MHIP_ERR_STATE, "re-plan: a peer's counts or rows did not arrive in time (MOLLYHIP_XFER_TIMEOUT_MS)" + wait_report(e4) + tabs};
             throw ApiError{MHIP_ERR_CAPACITY, std::string("re-plan: ") + ((t.err & RP_ERR_ATOMS) ? "a sub-domain's atoms + ghosts exceed its context capacity" : (t.err & RP_ERR_PLAN_AREA) ? "the migrating atoms exceed a plan area"
-                                             : "the ghost rows exceed a receive region") + " (create the contexts with more room)"};
+                                             : "the ghost rows exceed a receive region") + " (create the contexts with more room)" + tabs};
         }
         if (debug_on) std::fprintf(stderr, "[mhip %d] re-plan at step %lld: %d stay, %d leave, %d arrive; %d ghost rows out, %d ghosts in\n", me, (long long)step_n, t.n_stay, t.n_leave, t.n_arrive, t.n_send, t.n_ghost);
         // commit: the new local set in its identity order

@@ -38,13 +38,19 @@ __device__ inline uint32_t xfer_load_acquire(const uint32_t* p) { return __hip_a
 // wait until *p has reached `want` (sequence numbers only grow; wrap-safe compare); false after `ticks` of the 100 MHz wall clock
 // (MOLLYHIP_XFER_TIMEOUT_MS, 2 s unless set) — or AT ONCE when the error word is already raised: after one time-out every later
 // launch of the chunk is queued already, and each of them waiting its own full time-out turned one lost peer into minutes of stall
-__device__ inline bool xfer_wait(const uint32_t* p, uint32_t want, const int32_t* err, unsigned long long ticks) {
+// err: int32[4] — [0] the error flags the caller raises, [1..3] filled by the FIRST wait that gave up: who (caller's tag << 8 | the peer waited for) + 1, the
+// sequence number wanted, the one last seen (a peer one exchange behind is slow; one that never moved is gone)
+__device__ inline bool xfer_wait(const uint32_t* p, uint32_t want, int32_t* err, unsigned long long ticks, int who = 0) {
     if ((int32_t)(xfer_load_acquire(p) - want) >= 0) return true;
     if (err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
     const unsigned long long t0 = wall_clock64();
-    while ((int32_t)(xfer_load_acquire(p) - want) < 0) {
+    uint32_t seen = 0;
+    while ((int32_t)((seen = xfer_load_acquire(p)) - want) < 0) {
         __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > ticks) return false;
+        if (wall_clock64() - t0 > ticks) {
+            if (err && atomicCAS(&err[1], 0, who + 1) == 0) { err[2] = (int32_t)want; err[3] = (int32_t)seen; }
+            return false;
+        }
     }
     return true;
 }
@@ -90,7 +96,7 @@ __device__ inline void xfer_announce_word(XferPeers P, const int32_t* ranks, int
 }
 // every block waits for the senders' words itself (a handful of uncached loads), then all its threads go on
 __device__ inline void xfer_wait_block(const XferWait& W) {
-    if ((int)threadIdx.x < W.n_peers && !xfer_wait(&W.mine->seq_in[W.parity][W.peers[threadIdx.x]], W.seq, W.err, W.ticks)) atomicOr(W.err, 1);
+    if ((int)threadIdx.x < W.n_peers && !xfer_wait(&W.mine->seq_in[W.parity][W.peers[threadIdx.x]], W.seq, W.err, W.ticks, (1 << 8) | W.peers[threadIdx.x])) atomicOr(W.err, 1);
     __syncthreads();
 }
 
@@ -109,7 +115,7 @@ __device__ inline void xfer_wait_block(const XferWait& W) {
     __shared__ float sh[XFER_MAX_RANKS][3];
     const int r = threadIdx.x;
     if (r < world) {
-        if (!xfer_wait(&mine->plan_seq[parity][r], seq, err, ticks)) atomicOr(err, 2);
+        if (!xfer_wait(&mine->plan_seq[parity][r], seq, err, ticks, (2 << 8) | r)) atomicOr(err, 2);
         for (int c = 0; c < 3; ++c) sh[r][c] = __hip_atomic_load(&mine->plan_val[parity][r][c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __syncthreads();

@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(64) k_rp_exchange(XferPeers P, const XferHeade
         __threadfence_system();
         xfer_store_release(&h->rp_cnt_seq[PHASE][me], seq);
     }
-    if (t < world && !xfer_wait(&mine->rp_cnt_seq[PHASE][t], seq, err, ticks)) atomicOr(err, RP_ERR_TIMEOUT);
+    if (t < world && !xfer_wait(&mine->rp_cnt_seq[PHASE][t], seq, err, ticks, ((3 + PHASE) << 8) | t)) atomicOr(err, RP_ERR_TIMEOUT);
     __syncthreads();
     if (t < world) {
         for (int d = 0; d < world; ++d) Msh[t][d] = __hip_atomic_load(&mine->rp_cnt[PHASE][t][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(64) k_rp_exchange(XferPeers P, const XferHeade
 template <int PHASE>
 __global__ void __launch_bounds__(64) k_rp_wait_rows(const XferHeader* mine, int world, int me, uint32_t seq, RpTab* tab, int32_t* err, unsigned long long ticks) {
     const int t = threadIdx.x;
-    if (t < world && t != me && !xfer_wait(&mine->rp_row_seq[PHASE][t], seq, err, ticks)) atomicOr(err, RP_ERR_TIMEOUT);
+    if (t < world && t != me && !xfer_wait(&mine->rp_row_seq[PHASE][t], seq, err, ticks, ((5 + PHASE) << 8) | t)) atomicOr(err, RP_ERR_TIMEOUT);
     __syncthreads();
     if (t == 0) tab->err = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -32,3 +32,27 @@ def pkg():
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture
+def slack(request):
+    """slack(name, achieved, allowed): how much of a tolerance a test used.  Asserts achieved <= allowed, prints the ratio and appends it to
+    gpurun_out/tolerance_slack.jsonl (on the GPU box the directory is merged back: DESIGN.md §2 quotes these numbers, and a bar with more than
+    3× slack gets tightened)."""
+    import json
+    rows = []
+
+    def record(name, achieved, allowed):
+        achieved, allowed = float(achieved), float(allowed)
+        rows.append({"test": request.node.nodeid, "what": name, "achieved": achieved, "allowed": allowed, "ratio": achieved / allowed if allowed else float("inf")})
+        print(f"[slack] {request.node.name}: {name}: {achieved:.4g} of {allowed:.4g} allowed ({achieved / allowed:.3f})")
+        assert achieved <= allowed, f"{name}: {achieved:.6g} > {allowed:.6g}"
+    yield record
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "tolerance_slack.jsonl"), "a") as f:
+            for r in rows:
+                f.write(json.dumps(r) + "\n")
+    except OSError:
+        pass

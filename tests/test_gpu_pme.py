@@ -84,7 +84,7 @@ def test_100_step_pme_trajectory_vs_openmm_fp64(pkg):
     assert np.linalg.norm(s.velocities - d["openmm_velocities_100steps"], axis=1).max() < 1e-7
 
 
-def test_all_pme_fp32_total_force_vs_openmm(pkg):
+def test_all_pme_fp32_total_force_vs_openmm(pkg, slack):
     """The configuration bench.py TIMES (6mrr_pme: Float32, LJ + Ewald direct space with the A&S erfc + bonded + EwaldExclusion + PME
     reciprocal space) as ONE force evaluation against OpenMM's forces_all_pme.txt.
     Two parts, because two things separate an fp32 engine from that file.  (a) The INPUTS: coordinates rounded to fp32 (ulp/2 = 2.4e-7 nm
@@ -107,15 +107,18 @@ def test_all_pme_fp32_total_force_vs_openmm(pkg):
     f = pkg.forces(s).astype(np.float64)
     bar = tol + 2e-5 * bonded_scale + 2e-4 * pme_scale + 1e-3
     err = np.linalg.norm(f - f_ref, axis=1)
-    assert np.all(err <= bar), f"worst ratio {(err / bar).max():.2f} at atom {(err / bar).argmax()}"
+    w = int((err / bar).argmax())
+    slack(f"arithmetic: worst per-atom error / bar (atom {w}: pair part {tol[w]:.3g}, bonded part {2e-5 * bonded_scale[w]:.3g}, mesh part {2e-4 * pme_scale:.3g}, erfc part 1e-3)", (err / bar).max(), 1.0)
+    slack("arithmetic: worst per-atom error against the pair bar ALONE (how much the other three allowances are needed)", (err / tol).max(), (bar / tol).max())
     err_omm = np.linalg.norm(f - f_omm, axis=1)
-    assert np.all(err_omm <= bar + input_term) and err_omm.max() < 1.0
-    assert S.rel_rms(err_omm, f_omm) < 2e-5
+    slack("against OpenMM: worst per-atom error / (bar + input rounding)", (err_omm / (bar + input_term)).max(), 1.0)
+    slack("against OpenMM: worst per-atom error, kJ/mol/nm", err_omm.max(), 1.0)
+    slack("against OpenMM: relative RMS", S.rel_rms(err_omm, f_omm), 2e-5)
     e = pkg.potential_energy(s) + G.lj_dispersion_correction(d)
-    assert abs(e - float(d["openmm_energy_all_pme"])) < 0.2 + 0.6
+    slack("potential energy against OpenMM, kJ/mol", abs(e - float(d["openmm_energy_all_pme"])), 0.2 + 0.6)
 
 
-def test_100_step_pme_trajectory_vs_openmm_fp32(pkg):
+def test_100_step_pme_trajectory_vs_openmm_fp32(pkg, slack):
     """test/protein.jl:278-299 with the timed configuration's arithmetic (Float32, approximate erfc, the complete MD step) through
     mhip_vv_run: 100 steps of 0.5 fs from OpenMM's start velocities against coordinates_100steps.txt at SURVEY §8(c)'s fp32 trajectory
     bar, 5e-4 nm per atom (test/simulation.jl:625), mean displacement error 2e-5 nm; velocities 0.05 nm/ps (hydrogens move at ≈ 3)."""
@@ -127,8 +130,9 @@ def test_100_step_pme_trajectory_vs_openmm_fp32(pkg):
     dx = s.coords.astype(np.float64) - (xo - np.floor(xo / box) * box)
     dx -= np.round(dx / box) * box
     dev = np.linalg.norm(dx, axis=1)
-    assert dev.max() < 5e-4 and dev.mean() < 2e-5, (dev.max(), dev.mean())
-    assert np.linalg.norm(s.velocities.astype(np.float64) - d["openmm_velocities_100steps"], axis=1).max() < 0.05
+    slack("worst coordinate deviation after 100 steps, nm", dev.max(), 5e-4)
+    slack("mean coordinate deviation after 100 steps, nm", dev.mean(), 2e-5)
+    slack("worst velocity deviation after 100 steps, nm/ps", np.linalg.norm(s.velocities.astype(np.float64) - d["openmm_velocities_100steps"], axis=1).max(), 0.05)
 
 
 def test_pme_rejects_what_it_does_not_cover(pkg):

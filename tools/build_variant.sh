@@ -1,8 +1,8 @@
 #!/bin/bash
-# tools/build_variant.sh <name> <extra hipcc flags...>: a build of libmollyhip.so whose packed pair loop (forces_uniform.hip) is compiled
-# with extra -D switches, for A/B timing (tools/force_ab.py); the in-tree build is restored afterwards
+# tools/build_variant.sh <name> <extra hipcc flags...>: a second build of libmollyhip.so under ab/lib_<name>.so (every translation unit recompiled with
+# the extra flags, e.g. -DMHIP_STAMPS=1 for the time-stamp library of tools/gpu_stamps.sh); the in-tree build is left as it was.
 name=$1; shift
 cd "$(dirname "$0")/../molly.jl_amd/csrc" || exit 1
-mkdir -p ../../ab
-touch forces_uniform.hip; make -j8 EXTRA="$*" 2>&1 | grep -E " error|Error " ; cp ../libmollyhip.so ../../ab/lib_$name.so
-touch forces_uniform.hip; make -j8 2>&1 | grep -E " error|Error "
+mkdir -p ../../ab /tmp/mhip_variant_$name
+make -j16 EXTRA="$*" OUT=../../ab/lib_$name.so BUILD=/tmp/mhip_variant_$name 2>&1 | grep -E " error|Error "
+ls -la ../../ab/lib_$name.so

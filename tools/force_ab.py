@@ -26,7 +26,7 @@ def child(workload, steps, equil, static=False):
     s = case.system(m, dtype)
     s.push_state(velocities=True)
     ctx = s.engine()
-    if static:   # frozen coordinates: only force passes (libraries built with -DMHIP_EXP=n compute garbage: no dynamics with them)
+    if static:   # frozen coordinates: only force passes (timing a force pass on its own)
         import numpy as np
         import torch
         f = torch.empty((case.n, 3), dtype=torch.float32 if dtype == np.float32 else torch.float64, device="cuda")

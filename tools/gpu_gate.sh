@@ -1,6 +1,6 @@
 #!/bin/bash
 # the round's gate on the GPU box, as the driver runs it: every -m gpu test, smoke(), bench.py in the driver's form and in its default form
-out=gpurun_out; mkdir -p $out; tag=${1:-r04}
+out=gpurun_out; mkdir -p $out; tag=${1:-r05}
 timeout 3000 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider > $out/${tag}_gputest.log 2>&1; echo "rc $?" >> $out/${tag}_gputest.log
 tail -4 $out/${tag}_gputest.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/${tag}_smoke.log 2>&1; tail -2 $out/${tag}_smoke.log

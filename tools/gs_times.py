@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-wave time stamps of the group-split pair pass (library built with -DMHIP_EXP=11, MOLLYHIP_DBG_TIMES=n, MOLLYHIP_DBG_DUMP=file):
+"""Per-wave time stamps of the group-split pair pass (library built with -DMHIP_STAMPS=1, MOLLYHIP_DBG_TIMES=n, MOLLYHIP_DBG_DUMP=file):
 where a pass's time goes — per workgroup start, staging, row walk, reduction — and how evenly the compute units are loaded.
 
     python tools/gs_times.py dump.bin
