@@ -139,3 +139,64 @@ def test_entry_point_count_in_design_is_current():
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
     m = re.search(r"\((\d+) entry points", design)
     assert m and int(m.group(1)) == len(protos), (m and m.group(1), len(protos))
+
+
+# ---- the shim's method heads against the reference's own (tests/golden/reference_signatures.json, made by tools/ref_signatures.py) ------------
+def _golden_signatures():
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "reference_signatures.json")))
+
+
+def _integration_heads(fname):
+    """every `function fname(…)` head of INTEGRATION.md: [(positional [(name, type)], keywords)]"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_signatures", os.path.join(ROOT, "tools", "ref_signatures.py"))
+    rs = importlib.util.module_from_spec(spec); spec.loader.exec_module(rs)
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    out = []
+    for m in re.finditer(r"^function\s+(?:[A-Za-z]+\.)*" + re.escape(fname) + r"\s*\(", text, flags=re.M):
+        inner, _ = rs.balanced(text, m.end() - 1)
+        out.append(rs.parse_params(inner))
+    return out
+
+
+def test_overriding_method_heads_line_up_with_the_reference():
+    """Nothing here can run Julia, so the class of bug that breaks dispatch without an error — a method head whose positional arguments do not
+    line up with the generic's, so that the stock method keeps being called — is caught statically: for each generic the shim overrides
+    (ext/MollyCUDAExt.jl:845, 936, 2373; generics src/kernels.jl:91, 393) the positional argument COUNT equals the reference's at the method
+    heads and at the call sites (src/force.jl:1223, 1228; src/energy.jl:422, 427 — SURVEY §0 records a 5-against-6 mismatch of exactly this kind
+    inside the reference), the argument NAMES are the CUDA extension's in the same order, `nbs::Nothing` and `::Val{needs_vir}` sit where the
+    extension has them (they select the no-neighbour-list path), and the array type is the only thing specialised."""
+    g = _golden_signatures()
+    for fname in ("pairwise_forces_loop_gpu!", "pairwise_pe_loop_gpu!", "remove_CM_motion!"):
+        ref = g["heads"][fname + "/cuda"]
+        heads = _integration_heads(fname)
+        assert len(heads) == 1, (fname, len(heads))
+        pos, kws = heads[0]
+        assert len(pos) == len(ref["positional"]), (fname, pos, ref["positional"])
+        assert not kws and not ref["keywords"]
+        for (n_i, t_i), (n_r, t_r) in zip(pos, ref["positional"]):
+            assert n_i == n_r, (fname, n_i, n_r)                                   # same names in the same order (anonymous ::Val{…} included)
+            if n_r == "sys":
+                assert t_r.replace(" ", "").startswith("System{") and "<:CuArray" in t_r and "<:ROCArray" in t_i, (fname, t_i, t_r)
+            elif t_r in ("Nothing", "Val{needs_vir}"):
+                assert t_i == t_r, (fname, n_i, t_i, t_r)
+        for key, call in g["calls"].items():
+            if key.startswith(fname + "/"):
+                assert call["n_positional"] == len(pos), (key, call, pos)
+        if fname + "/generic" in g["heads"]:
+            assert len(g["heads"][fname + "/generic"]["positional"]) == len(pos)
+
+
+def test_reference_signature_fixture_is_current():
+    """where the reference checkout is present (this container, not the GPU box) the committed fixture is what tools/ref_signatures.py extracts now"""
+    import json
+    import subprocess
+    import sys
+    import pytest
+    if not os.path.isdir("/root/reference/ext"):
+        pytest.skip("no reference checkout here")
+    before = open(os.path.join(ROOT, "tests", "golden", "reference_signatures.json")).read()
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ref_signatures.py"), "/root/reference"], check=True, capture_output=True)
+    after = open(os.path.join(ROOT, "tests", "golden", "reference_signatures.json")).read()
+    assert json.loads(before) == json.loads(after)
