@@ -90,10 +90,12 @@ def test_all_pme_fp32_total_force_vs_openmm(pkg, slack):
     Two parts, because two things separate an fp32 engine from that file.  (a) The INPUTS: coordinates rounded to fp32 (ulp/2 = 2.4e-7 nm
     at 5 nm) under bond constants of 4e5 kJ mol⁻¹ nm⁻² move a force by ≈ 0.1 per bond whatever the arithmetic — the fp64 oracle on the
     rounded inputs is 0.31 kJ mol⁻¹ nm⁻¹ off OpenMM at the worst atom (on forces of up to 6 300).  (b) The ARITHMETIC: the engine against
-    that fp64 oracle on the same rounded inputs, per atom within the fp32 pair bar 4e-5·Σ_j‖f_ij‖ (tests/systems.py) + 2e-5 of the atom's
-    bonded force scale + 2e-4 of the largest reciprocal-space force (fp32 mesh sums) + 1e-3 (the reference's approximate-erfc bar
-    against OpenMM, test/protein.jl:274).  Against OpenMM itself: (a) + (b) per atom, 1 kJ mol⁻¹ nm⁻¹ at the worst atom, relative RMS 2e-5.
-    Energy: the reference's approximate-erfc bar 0.2 kJ/mol + 1e-6 of Σ|e_ij| ≈ 6e5 in fp32."""
+    that fp64 oracle on the same rounded inputs, per atom within the fp32 pair bar 4e-5·Σ_j‖f_ij‖ (tests/systems.py) + 5e-6 of the atom's
+    bonded force scale + 5e-5 of the largest reciprocal-space force (fp32 mesh sums) + 2.5e-4.  Round 4 allowed four times each of the three
+    add-ons; the recorded slack (the `slack` fixture) showed the worst atom at 0.36 of that bar and — at 0.76 — inside the PAIR bar
+    alone, so they were cut to a quarter.  Against OpenMM itself: (a) + (b) per atom, 0.5 kJ mol⁻¹ nm⁻¹ at the worst atom (measured 0.31: the
+    input rounding), relative RMS 2e-5 (measured 1.6e-5).  Energy: the reference's approximate-erfc bar 0.2 kJ/mol (test/protein.jl:274) + 5e-7
+    of Σ|e_ij| ≈ 6e5 in fp32 (measured 0.26)."""
     d = G.data()
     case = G.case("ewald", np.float32, bonded=True, pme=True)                 # approximate_erfc = True: the default, and what is timed
     tol, o, nl = S.fp32_force_tolerance(case)
@@ -105,23 +107,24 @@ def test_all_pme_fp32_total_force_vs_openmm(pkg, slack):
     assert input_term.max() < 0.5
     s = case.system(pkg, np.float32)
     f = pkg.forces(s).astype(np.float64)
-    bar = tol + 2e-5 * bonded_scale + 2e-4 * pme_scale + 1e-3
+    bar = tol + 5e-6 * bonded_scale + 5e-5 * pme_scale + 2.5e-4
     err = np.linalg.norm(f - f_ref, axis=1)
     w = int((err / bar).argmax())
-    slack(f"arithmetic: worst per-atom error / bar (atom {w}: pair part {tol[w]:.3g}, bonded part {2e-5 * bonded_scale[w]:.3g}, mesh part {2e-4 * pme_scale:.3g}, erfc part 1e-3)", (err / bar).max(), 1.0)
+    slack(f"arithmetic: worst per-atom error / bar (atom {w}: pair part {tol[w]:.3g}, bonded part {5e-6 * bonded_scale[w]:.3g}, mesh part {5e-5 * pme_scale:.3g}, constant 2.5e-4)", (err / bar).max(), 1.0)
     slack("arithmetic: worst per-atom error against the pair bar ALONE (how much the other three allowances are needed)", (err / tol).max(), (bar / tol).max())
     err_omm = np.linalg.norm(f - f_omm, axis=1)
     slack("against OpenMM: worst per-atom error / (bar + input rounding)", (err_omm / (bar + input_term)).max(), 1.0)
-    slack("against OpenMM: worst per-atom error, kJ/mol/nm", err_omm.max(), 1.0)
+    slack("against OpenMM: worst per-atom error, kJ/mol/nm", err_omm.max(), 0.5)
     slack("against OpenMM: relative RMS", S.rel_rms(err_omm, f_omm), 2e-5)
     e = pkg.potential_energy(s) + G.lj_dispersion_correction(d)
-    slack("potential energy against OpenMM, kJ/mol", abs(e - float(d["openmm_energy_all_pme"])), 0.2 + 0.6)
+    slack("potential energy against OpenMM, kJ/mol", abs(e - float(d["openmm_energy_all_pme"])), 0.2 + 0.3)
 
 
 def test_100_step_pme_trajectory_vs_openmm_fp32(pkg, slack):
     """test/protein.jl:278-299 with the timed configuration's arithmetic (Float32, approximate erfc, the complete MD step) through
-    mhip_vv_run: 100 steps of 0.5 fs from OpenMM's start velocities against coordinates_100steps.txt at SURVEY §8(c)'s fp32 trajectory
-    bar, 5e-4 nm per atom (test/simulation.jl:625), mean displacement error 2e-5 nm; velocities 0.05 nm/ps (hydrogens move at ≈ 3)."""
+    mhip_vv_run: 100 steps of 0.5 fs from OpenMM's start velocities against coordinates_100steps.txt.  SURVEY §8(c)'s fp32 trajectory bar is
+    5e-4 nm per atom (test/simulation.jl:625); the recorded slack showed 1.7e-5 nm at the worst atom, 1.8e-6 nm on average and
+    2.8e-3 nm/ps in the velocities (hydrogens move at ≈ 3), so the test holds 5e-5 nm, 5e-6 nm and 8e-3 nm/ps — a tenth of the reference's bar."""
     d = G.data()
     case = G.case("ewald", np.float32, bonded=True, pme=True)
     s = case.system(pkg, np.float32)
@@ -130,9 +133,9 @@ def test_100_step_pme_trajectory_vs_openmm_fp32(pkg, slack):
     dx = s.coords.astype(np.float64) - (xo - np.floor(xo / box) * box)
     dx -= np.round(dx / box) * box
     dev = np.linalg.norm(dx, axis=1)
-    slack("worst coordinate deviation after 100 steps, nm", dev.max(), 5e-4)
-    slack("mean coordinate deviation after 100 steps, nm", dev.mean(), 2e-5)
-    slack("worst velocity deviation after 100 steps, nm/ps", np.linalg.norm(s.velocities.astype(np.float64) - d["openmm_velocities_100steps"], axis=1).max(), 0.05)
+    slack("worst coordinate deviation after 100 steps, nm", dev.max(), 5e-5)
+    slack("mean coordinate deviation after 100 steps, nm", dev.mean(), 5e-6)
+    slack("worst velocity deviation after 100 steps, nm/ps", np.linalg.norm(s.velocities.astype(np.float64) - d["openmm_velocities_100steps"], axis=1).max(), 8e-3)
 
 
 def test_pme_rejects_what_it_does_not_cover(pkg):
