@@ -1100,7 +1100,6 @@ template <class T> class Engine final : public EngineBase {
 
     DBuf<double> cm_fin_buf; const bool cm_fin_on = env_int("MOLLYHIP_CM_IN_PAIR_PASS", 1) != 0;
     const double* cm_fin_solo_src = nullptr; bool cm_fin_solo_done = false;
-    const bool vv_batch = env_int("MOLLYHIP_VV_BATCH", 1) != 0;      // the integrator launch with four atoms in flight per lane (kernels.h, k_vv_mid UB); 0: one atom ahead
 
     // the (block, group) items of the group-split pass handed to its workgroups so that every compute unit gets a like share of rows (forces_gs.hip, k_gs_balance)
     DBuf<uint16_t> gs_item; const bool gs_balance_on = env_int("MOLLYHIP_GS_BALANCE", 1) != 0; int cu_count = 0;
@@ -1936,8 +1935,7 @@ template <class T> class Engine final : public EngineBase {
             hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, stream, n_owned, pos[cur].p, vel[cur].p, (const T4*)frc[cur].p, T(dt), T(dt) / T(2),
                                cm_in, n_in, cm_out, (const T4*)pend_a, (const T4*)pend_b, G, (const T4*)nullptr, (const T4*)nullptr, (float*)nullptr);
         };
-        if (vv_batch) { if (last) { if (cm) go(k_vv_mid<T, true, true, 4>); else go(k_vv_mid<T, false, true, 4>); } else { if (cm) go(k_vv_mid<T, true, false, 4>); else go(k_vv_mid<T, false, false, 4>); } }
-        else if (last) { if (cm) go(k_vv_mid<T, true, true>); else go(k_vv_mid<T, false, true>); }
+        if (last) { if (cm) go(k_vv_mid<T, true, true>); else go(k_vv_mid<T, false, true>); }
         else { if (cm) go(k_vv_mid<T, true, false>); else go(k_vv_mid<T, false, false>); }
         prof.end(2, stream);
         pend_a = pend_b = nullptr; cm_pending = 0; cm_ext = nullptr;
@@ -2423,8 +2421,7 @@ template <class T> class Engine final : public EngineBase {
                                    cm_in, n_cm_step, cm_out, (const T4*)pend_a, (const T4*)pend_b, G,
                                    measure ? (const T4*)pos_snap_in.p : (const T4*)nullptr, measure ? (const T4*)pos_snap.p : (const T4*)nullptr, measure ? trk_part.p : (float*)nullptr);
             };
-            if (vv_batch) { if (step == last) { if (cm) go(k_vv_mid<T, true, true, 4>); else go(k_vv_mid<T, false, true, 4>); } else { if (cm) go(k_vv_mid<T, true, false, 4>); else go(k_vv_mid<T, false, false, 4>); } }
-            else if (step == last) { if (cm) go(k_vv_mid<T, true, true>); else go(k_vv_mid<T, false, true>); }
+            if (step == last) { if (cm) go(k_vv_mid<T, true, true>); else go(k_vv_mid<T, false, true>); }
             else { if (cm) go(k_vv_mid<T, true, false>); else go(k_vv_mid<T, false, false>); }
             prof.end(2, stream);
             if (measure) {   // the check of step + 1: reduce, copy, event — read by resolve_track at step + 2

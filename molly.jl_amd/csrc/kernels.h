@@ -1775,12 +1775,8 @@ __global__ void k_vv2(int64_t n, typename Vec<T>::T4* vel, typename Vec<T>::T4* 
 // removal), carries on with the unshifted velocity, and the NEXT launch subtracts v_cm from the velocity it finds and v_cm·dt from
 // the position that was drifted with it.  The forces in between saw every atom translated by the same v_cm·dt (≈ 1e-11 nm): they are
 // translation invariant.  LAST: stop after the second kick (the run's final step), leaving v_n and x_n for the caller.
-// UB: atoms a lane has in flight.  0 = one atom integrated while the next one's records travel (rounds 2-4).  4 = four atoms' records requested
-// together, then integrated in order: a launch of this kernel puts one or two 256-lane workgroups on a compute unit, a wave per SIMD, and with one
-// atom ahead a compute unit had ≈ 24 KB in flight — 2.7 TB/s at 262 144 atoms, 4.5 TB/s at 10⁶ — where the memory system wants ≈ 100 KB to stream at
-// its rate.  Same arithmetic per atom, same order of every lane's sums: the runs are the same runs bit for bit.
-template <class T, bool CM, bool LAST, int UB = 0>
-__global__ void __launch_bounds__(256) k_vv_mid(int64_t n, typename Vec<T>::T4* pos, typename Vec<T>::T4* vel, const typename Vec<T>::T4* __restrict__ fr, T dt, T dt2,
+template <class T, bool CM, bool LAST>
+__global__ void k_vv_mid(int64_t n, typename Vec<T>::T4* pos, typename Vec<T>::T4* vel, const typename Vec<T>::T4* __restrict__ fr, T dt, T dt2,
                          const double* __restrict__ cm_in, int n_cm_in, double* cm_out,
                          const typename Vec<T>::T4* __restrict__ fa, const typename Vec<T>::T4* __restrict__ fb, GridP<T> G,
                          const typename Vec<T>::T4* __restrict__ snap_a = nullptr, const typename Vec<T>::T4* __restrict__ snap_b = nullptr, float* trk_part = nullptr) {
@@ -1790,12 +1786,26 @@ __global__ void __launch_bounds__(256) k_vv_mid(int64_t n, typename Vec<T>::T4* 
     float v2m = 0.f, dam = 0.f, dbm = 0.f;
     T vc[3] = {T(0), T(0), T(0)};
     const bool sub = cm_in != nullptr;
+    // A lane's first atom is requested BEFORE the centre-of-mass partials are re-summed (32 KB of L2 reads, two barriers): the
+    // streaming part of the launch then starts behind that latency instead of after it.
     using T4q = typename Vec<T>::T4;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    T sh[3] = {T(0), T(0), T(0)};
+    int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, sn = s;
+    T4q vq = make4<T>(T(0), T(0), T(0), T(1)), fq = vq, pq = vq, gaq = vq, gbq = vq;
+    auto fetch = [&](int64_t a) {
+        vq = vel[a]; fq = frc[a];
+        if (!LAST || sub) pq = pos[a];
+        if (fa) gaq = fa[a];
+        if (fb) gbq = fb[a];
+    };
+    if (s < n) fetch(s);
+    if (sub) block_vcm<T>(cm_in, n_cm_in, vc);
+    const T sh[3] = {M<T>::mul(vc[0], dt), M<T>::mul(vc[1], dt), M<T>::mul(vc[2], dt)};
     double px = 0, py = 0, pz = 0, m = 0;
-    // one atom: everything between its records and what is stored for it
-    auto integrate = [&](int64_t s, const T4q& v0, const T4q& f0, const T4q& p0, const T4q& ga0, const T4q& gb0) {
+    for (; s < n; s = sn) {
+        sn = s + stride;
+        const auto v0 = vq, f0 = fq, p0 = pq, ga0 = gaq, gb0 = gbq;
+        if (sn < n) fetch(sn);                                                 // the next atom's data travel while this one is integrated
         auto v = v0; auto f = f0; auto p = p0;
         if (fa) { f.x += ga0.x; f.y += ga0.y; f.z += ga0.z; }
         if (fb) { f.x += gb0.x; f.y += gb0.y; f.z += gb0.z; }
@@ -1827,60 +1837,13 @@ __global__ void __launch_bounds__(256) k_vv_mid(int64_t n, typename Vec<T>::T4* 
             disp_image(ex, ey, ez, G);
             dbm = fmaxf(dbm, (float)(ex * ex + ey * ey + ez * ez));
         }
-    };
-    const T4q none = make4<T>(T(0), T(0), T(0), T(1));
-    if constexpr (UB == 0) {
-        // A lane's first atom is requested BEFORE the centre-of-mass partials are re-summed (32 KB of L2 reads, two barriers): the
-        // streaming part of the launch then starts behind that latency instead of after it.
-        int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, sn = s;
-        T4q vq = none, fq = none, pq = none, gaq = none, gbq = none;
-        auto fetch = [&](int64_t a) {
-            vq = vel[a]; fq = frc[a];
-            if (!LAST || sub) pq = pos[a];
-            if (fa) gaq = fa[a];
-            if (fb) gbq = fb[a];
-        };
-        if (s < n) fetch(s);
-        if (sub) block_vcm<T>(cm_in, n_cm_in, vc);
-        sh[0] = M<T>::mul(vc[0], dt); sh[1] = M<T>::mul(vc[1], dt); sh[2] = M<T>::mul(vc[2], dt);
-        for (; s < n; s = sn) {
-            sn = s + stride;
-            const auto v0 = vq, f0 = fq, p0 = pq, ga0 = gaq, gb0 = gbq;
-            if (sn < n) fetch(sn);                                                 // the next atom's data travel while this one is integrated
-            integrate(s, v0, f0, p0, ga0, gb0);
-        }
-    } else {
-        constexpr int NB = UB > 0 ? UB : 1;
-        const int64_t first = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-        T4q vq[NB], fq[NB], pq[NB], gaq[NB], gbq[NB];
-        auto fetch_batch = [&](int64_t s0) {
-#pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                const int64_t a = s0 + k * stride;
-                vq[k] = none; fq[k] = none; pq[k] = none; gaq[k] = none; gbq[k] = none;
-                if (a < n) {
-                    vq[k] = vel[a]; fq[k] = frc[a];
-                    if (!LAST || sub) pq[k] = pos[a];
-                    if (fa) gaq[k] = fa[a];
-                    if (fb) gbq[k] = fb[a];
-                }
-            }
-        };
-        fetch_batch(first);                                                        // (requested before the partials are re-summed, as above)
-        if (sub) block_vcm<T>(cm_in, n_cm_in, vc);
-        sh[0] = M<T>::mul(vc[0], dt); sh[1] = M<T>::mul(vc[1], dt); sh[2] = M<T>::mul(vc[2], dt);
-        for (int64_t s0 = first; s0 < n; s0 += NB * stride) {
-            if (s0 != first) fetch_batch(s0);
-#pragma unroll
-            for (int k = 0; k < NB; ++k) { const int64_t a = s0 + k * stride; if (a < n) integrate(a, vq[k], fq[k], pq[k], gaq[k], gbq[k]); }
-        }
     }
     if (trk_part) {
         __shared__ float sht[3][16];
         dam = wave_max(dam); dbm = wave_max(dbm); v2m = wave_max(v2m);
         if ((threadIdx.x & 63) == 0) { sht[0][threadIdx.x >> 6] = dam; sht[1][threadIdx.x >> 6] = dbm; sht[2][threadIdx.x >> 6] = v2m; }
         __syncthreads();
-        if (threadIdx.x < 3) { float mm = 0.f; for (int q = 0; q < (int)(blockDim.x >> 6); ++q) mm = fmaxf(mm, sht[threadIdx.x][q]); trk_part[threadIdx.x * gridDim.x + blockIdx.x] = mm; }
+        if (threadIdx.x < 3) { float m = 0.f; for (int q = 0; q < (int)(blockDim.x >> 6); ++q) m = fmaxf(m, sht[threadIdx.x][q]); trk_part[threadIdx.x * gridDim.x + blockIdx.x] = m; }
     }
     if constexpr (CM) {
         __shared__ double shm[4][4];
