@@ -650,10 +650,23 @@ template <class T> class Engine final : public EngineBase {
             A.cnt_out = nullptr; cnt_outer_valid = false;
             A.dbg = stamps_begin((size_t)n_blocks * 16 * 8);
             if ((sort_lanes_on && dual && BI > 64) || (gs_groups() > 0 && adopt_env)) { cnt_outer.reserve((size_t)n_blocks * JS * BI); A.cnt_out = cnt_outer.p; cnt_outer_valid = true; }
+            // The walk with BOTH the exact band decisions and the exception lookups compiled in (k_build<T, true, false, true>: a single list of a system
+            // with exclusions) is kept away from blocks of more than 64 atoms: at 128- and 256-atom blocks every i-wave but the first came out with an empty list (round 5,
+            // tools/micro/xl_waves.py: 2.86 M of 5.70 M pairs of a 46 656-atom charged fluid; forces off by the mean force on half the atoms), and with
+            // exception-free systems routed through it a 100-atom lattice aborted the process.  Each half works on its own at every shape — exact
+            // decisions without lookups (tools/micro/nondual_check.py), lookups with the candidate-set test (every dual list of a protein) —; together
+            // they are 10 658 lines of ISA with 104 / 477 SGPR spills to VGPR lanes and back under the 128-VGPR bound.  Larger blocks of such systems take
+            // the transposed search, which is exact at every shape (same tool); exception-free systems the walk without the lookups; 64-atom blocks — one
+            // i-wave, the one that always came out right, four rounds of parity tests — keep the variant.  (A triclinic cell grid has no transposed
+            // search — its box tests are Cartesian —: there the blocks are cut to 64 atoms instead.)
+            if (A.walk && A.xl_start && !A.approx && BI > 64) {
+                if (!tri_grid) { A.walk = 0; walk = false; lds = build_lds_bytes(T_cap, BI, C_cap, false); }
+                else { BI = 64; JS = std::min(16, MAX_THREADS / BI); estimate_capacities(); continue; }
+            }
             prof.begin(1, stream);
             tr("k_build");
             auto go = [&](auto kern) { set_lds_limit(kern, lds); hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(BI * JS), lds, stream, A); };
-            if (A.walk && A.approx && !A.xl_start) go(k_build<T, true, true, false>);       // one-type fluids: neither exact re-decisions nor exception lookups
+            if (A.walk && !A.xl_start) { if (A.approx) go(k_build<T, true, true, false>); else go(k_build<T, true, false, false>); }       // no exception lists: their lookups are not compiled
             else if (A.walk) { if (A.approx) go(k_build<T, true, true>); else go(k_build<T, true, false>); }
             else { if (A.approx) go(k_build<T, false, true>); else go(k_build<T, false, false>); }
             hipLaunchKernelGGL(k_build_summary, dim3(std::min(64, cdiv(n_blocks * JS * (BI / WAVE), 256))), dim3(256), 0, stream, n_blocks, n_blocks * JS * (BI / WAVE), R_cap, (const int32_t*)tile_cnt.p, wave_rows.p, (const float*)nullptr, flags.p);

@@ -412,3 +412,28 @@ def test_fused_velocity_verlet_with_net_momentum_matches_oracle(pkg, n_steps, cm
     assert np.abs(d).max() < 1e-10 and np.abs(s.velocities - o.vel).max() < 1e-9
     f_ref = o.forces(o.neighbors("cell"))
     assert np.abs(pkg.forces(s) - f_ref).max() < 1e-7 * np.abs(f_ref).max()
+
+
+@pytest.mark.parametrize("kind,n_side", [("lj", 40), ("lj", 48), ("charged", 36)])
+def test_single_pair_list_with_128_and_256_atom_blocks(pkg, kind, n_side, monkeypatch):
+    """The single (non-dual) pair list — what a context falls back to when the dual list does not pay or does not fit, and what a sub-domain without a
+    ghost margin uses — at the sizes where the blocks hold 128 (40 000+ atoms) and 256 atoms (100 000+).  Round 5 found the search with exact band
+    decisions AND exception lookups compiled in leaving every i-wave but the first of such blocks with an empty list (half / three quarters of the
+    pairs gone; tools/micro/xl_waves.py), on exception-free systems too, because they were routed through the same instantiation; nothing in the
+    suite built a single list beyond 64-atom blocks.  Pair SET against the oracle's of the same precision, forces against the fp64 oracle."""
+    monkeypatch.setenv("MOLLYHIP_OUTER_MARGIN_PM", "0")
+    if kind == "lj":
+        case = S.lj_fluid(n_side, dtype=np.float32)
+    else:
+        case = S.charged_fluid(n_side, dict(kind="rf", rc=1.0, weight_special=0.8333333333333334), dtype=np.float32, stable=True)
+    s = case.system(pkg, np.float32)
+    tol, o, nl = S.fp32_force_tolerance(case)
+    f_ref = o.forces(nl, nthreads=16)
+    f = pkg.forces(s).astype(np.float64)
+    st = s.stats()
+    assert st["block_atoms"] >= 128, st["block_atoms"]
+    err = np.linalg.norm(f - f_ref, axis=1)
+    assert np.all(err <= tol), f"{int((err > tol).sum())} atoms over the bar, worst err/tol {(err / tol).max():.3g}"
+    keys, n_special = S.export_keys(pkg, s)
+    oi, oj, osp = case.oracle(np.float32).neighbors("cell", nthreads=16)
+    assert np.array_equal(keys, S.pair_keys(oi, oj)) and n_special == int(np.asarray(osp).sum())
