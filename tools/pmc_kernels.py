@@ -4,7 +4,7 @@ f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)[0]
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 seen = set()
 for r in csv.DictReader(open(f)):
-    k = r["Kernel_Name"][:46]
+    k = r["Kernel_Name"][:int(__import__("os").environ.get("PMC_NAME_CHARS", "46"))]
     acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
     key = (r["Dispatch_Id"], k)
     if key not in seen:
