@@ -99,7 +99,7 @@ def cpu_baseline(case, dtype, dt, budget_s=20.0):
 def load_traffic(workload):
     """HBM bytes per force-kernel launch from the rocprofv3 PMC passes committed under profiles/ (collected by
     profiles/collect.sh: separate FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE×2 gfx950 correction)."""
-    for tag in ("r04_", "r03_", ""):
+    for tag in ("r05_", "r04_", "r03_", ""):
         p = os.path.join(ROOT, "profiles", f"{tag}traffic_{workload}.json")
         if os.path.exists(p):
             try:
@@ -224,14 +224,17 @@ def make_record(workload, case, dtype, dt, ms_per_step, st, extra, world, args, 
     ns_day = steps_s * (dt * 1e3) * 86400 * 1e-6        # dt [ps] → fs
     n_atoms = case.n
     force_ms = st["prof_ms"][0] / max(st["prof_calls"][0], 1)
-    fbytes = st["force_pass_bytes"]
+    # the large one-type fluids run the plain pair pass with the integrator in its epilogue (k_forces STEP: no force array, no integrator launch): such a launch
+    # carries the step's algorithmic bytes, SURVEY §8(d)'s N(R_p + 22w) + 4L, not only the force pass's N(R_p + 3w) + 4L
+    fused = st.get("n_fused_steps", 0) > 0
+    fbytes = st["algorithmic_bytes_step"] if fused else st["force_pass_bytes"]
     achieved = fbytes / (force_ms * 1e-3) / 1e9 if force_ms > 0 else None
     traffic, traffic_src = load_traffic(workload)
     per_step = lambda k: st["prof_ms"][k] / max(profile_steps, 1)
-    roofline = {"bound": "hbm", "kernel": "k_forces", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roofline = {"bound": "hbm", "kernel": "k_forces<STEP> (pair pass + velocity-Verlet update in its epilogue)" if fused else "k_forces", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                 "traffic_source": (f"{traffic_src}: rocprofv3 PMC passes of an earlier run of this command (FETCH_SIZE x2 + WRITE_SIZE), not measured in this run" if traffic_src else None),
-                "algorithmic_bytes_per_launch": fbytes, "avg_launch_ms": force_ms,
+                "algorithmic_bytes_per_launch": fbytes, "avg_launch_ms": force_ms, "fused_step": fused, "force_pass_bytes": st["force_pass_bytes"],
                 "avg_launch_source": "hipEvents on the engine's stream around every plain force pass of a separate profiling pass in this run",
                 "step_bytes": st["algorithmic_bytes_step"],
                 "step_frac": st["algorithmic_bytes_step"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -321,7 +321,7 @@ template <class T> class Engine final : public EngineBase {
         pos_snap_in.release(); lane_atom_in.release(); cnt_in.release(); cnt_outer.release();
         nbr_tmp.release(); rows_tmp.release(); nbr_gs.release(); rows_gs.release(); frc_parts.release(); wave_rows_in.release(); nbr_in.release(); pos_snap.release(); blk_disp2.release(); tile_idx_in.release(); tile_cnt_in.release(); rows_x.release(); nbr_x.release(); tile_idx_x.release(); tile_cnt_x.release(); blk_ghost.release(); blk_ghost_in.release();
         xl_start.release(); xl_list.release(); tile_idx.release(); tile_cnt.release(); wave_rows.release(); nbr.release(); blk_center.release();
-        flags.release(); red_part.release(); red_out.release(); cm_step.release(); vcm.release(); stage_a.release(); stage_b.release(); stage_i.release(); bonded.release(); pme.release(); frc_scratch.release(); nl_counter.release(); state_changed.release();
+        flags.release(); red_part.release(); red_out.release(); cm_step.release(); vcm.release(); stage_a.release(); stage_b.release(); stage_i.release(); bonded.release(); pme.release(); frc_scratch.release(); nl_counter.release(); state_changed.release(); pos_alt.release(); cm_blk.release(); cm_pub.release();
         xf_release(); dom_release();
         prof.release();
         for (int k = 0; k < 2; ++k) { if (side[k]) { (void)hipStreamSynchronize(side[k]); (void)hipStreamDestroy(side[k]); } if (ev_side[k]) (void)hipEventDestroy(ev_side[k]); frc_side[k].release(); }
@@ -1059,7 +1059,8 @@ template <class T> class Engine final : public EngineBase {
         A.blk_center = blk_center.p; A.frc = frc_override ? frc_override : frc[cur].p; A.pe_part = red_part.p;
         // inside vv_run: the Σ m v partials of the integrator launch before this pass become one partial here (kernels.h, cm_finalize_in_block)
         A.cm_fin_in = nullptr; A.cm_fin_n = 0; A.cm_fin_out = nullptr;
-        const bool cm_fin = cm_fin_on && in_vv_fused && !energy && n_ghost == 0 && part == 0 && cm_pending == 2 && n_cm_step > 1 && n_cm_step <= 4096;      // (the energy variants do not carry the sum)
+        A.vel = nullptr; A.pos_next = nullptr; A.dt = T(0); A.dt2 = T(0); A.cm_in = nullptr; A.cm_n = 0; A.cm_pub = nullptr; A.step_seq = 0; A.cm_out = nullptr; A.trk_part = nullptr; A.snap_a = nullptr; A.snap_b = nullptr;
+        const bool cm_fin = cm_fin_on && in_vv_fused && !energy && n_ghost == 0 && part == 0 && cm_pending == 2 && n_cm_step > 1 && n_cm_step <= 65536;      // (the energy variants do not carry the sum)
         if (cm_fin) { cm_fin_buf.reserve(4); A.cm_fin_in = cm_src(); A.cm_fin_n = n_cm_step; A.cm_fin_out = cm_fin_buf.p; }
         else if (cm_fin_solo_src && !energy && n_ghost == 0 && part == 0 && !cm_fin_solo_done) {      // (mhip_domain_run on one brick: halo_mid's partials)
             cm_fin_buf.reserve(4); A.cm_fin_in = cm_fin_solo_src; A.cm_fin_n = n_cm_step; A.cm_fin_out = cm_fin_buf.p; cm_fin_solo_done = true;
@@ -1067,10 +1068,31 @@ template <class T> class Engine final : public EngineBase {
         static const int level_env = env_int("MOLLYHIP_LEVEL_PAIRS", 1);
         A.level_pairs = (prune && level_env && JS == 2 && !lanes_sorted && !rebalance) ? 1 : 0;
         A.dbg = (!prune && !energy) ? stamps_begin((size_t)n_blocks * 16 * 8) : nullptr;
+        // the fused step: this pass also integrates (see step_req)
+        step_done = false;
+        bool do_step = false;
+        if constexpr (std::is_same<T, float>::value) {
+            do_step = step_req.on && fuse_step_env && fast_f32 && A.soa != 0 && use_inner && !prune && part == 0 && !frc_override && n_ghost == 0 && !A.lane_atom && !A.dbg && cm_pending != 1;
+            if (do_step) {
+                pos_alt.reserve(cap); cm_blk.reserve(2 * 4 * (size_t)n_blocks + 8); cm_pub.reserve(4);
+                A.vel = vel[cur].p; A.pos_next = pos_alt.p; A.dt = T(step_req.dt); A.dt2 = T(step_req.dt) / T(2);
+                A.cm_in = cm_pending == 2 ? cm_src() : (const double*)nullptr; A.cm_n = n_cm_step; A.cm_pub = cm_pub.p; A.step_seq = ++step_seq;
+                A.cm_out = step_req.cm ? cm_blk.p + (size_t)step_half * 4 * n_blocks : (double*)nullptr;
+                A.trk_part = nullptr; A.snap_a = pos_snap_in.p; A.snap_b = pos_snap.p;
+                if (step_req.measure) { trk_part.reserve(3 * (size_t)std::max(n_blocks, 1024)); trk_out.reserve(4); A.trk_part = trk_part.p; }
+                A.cm_fin_in = nullptr; A.cm_fin_n = 0; A.cm_fin_out = nullptr;      // (the head workgroup of the launch sums the partials instead)
+            }
+        }
         prof.begin(prune ? 4 : 0, stream);   // stage 4 = force passes that also prune the outer list
-        tr(prune ? "k_forces (prune)" : (energy ? "k_forces (energy)" : "k_forces"));
-        launch_forces_any(A, energy);
-        if (cm_fin) { cm_ext = cm_fin_buf.p; n_cm_step = 1; }
+        tr(prune ? "k_forces (prune)" : (energy ? "k_forces (energy)" : (do_step ? "k_forces (fused step)" : "k_forces")));
+        if constexpr (std::is_same<T, float>::value) {
+            if (do_step) {
+                launch_forces_uniform_f32(A, false, false, lds_force, (unsigned)(BI * JS), stream, true);
+                std::swap(pos[cur].p, pos_alt.p);      // the epilogues wrote the drifted coordinates into the other buffer: it is the current one now
+                step_done = true; ++n_fused_steps;
+            } else launch_forces_any(A, energy);
+        } else launch_forces_any(A, energy);
+        if (cm_fin && !do_step) { cm_ext = cm_fin_buf.p; n_cm_step = 1; }
         tr("after k_forces");
         if (prune && rebalance && !lanes_sorted) {
             RebalArgs R{BI, ilog2(BI), JS, R_cap, eshift, (const uint2*)nbr_tmp.p, (const uint16_t*)cnt_in.p, (const int32_t*)tile_cnt_in.p, nbr_in.p, wave_rows_in.p};
@@ -1113,6 +1135,13 @@ template <class T> class Engine final : public EngineBase {
 
     DBuf<double> cm_fin_buf; const bool cm_fin_on = env_int("MOLLYHIP_CM_IN_PAIR_PASS", 1) != 0;
     const double* cm_fin_solo_src = nullptr; bool cm_fin_solo_done = false;
+    // The fused step of the large one-type fluids inside mhip_vv_run (kernels.h, k_forces STEP): a plain pair pass whose epilogue is the integrator launch — second kick
+    // of this step, first kick + drift of the next, into the other position buffer (swapped in behind the launch) — with Σ m v summed and published by the grid's first
+    // workgroup.  Asked for by vv_run (step_req), carried out by launch_pair_kernel when the pass is a packed plain one; every other pass keeps pair pass + k_vv_mid.
+    struct StepReq { bool on = false, cm = false, measure = false; double dt = 0; } step_req;
+    bool step_done = false; int step_half = 0; uint32_t step_seq = 0; int64_t n_fused_steps = 0;
+    DBuf<T4> pos_alt; DBuf<double> cm_blk; DBuf<unsigned long long> cm_pub;
+    const bool fuse_step_env = env_int("MOLLYHIP_FUSE_STEP", 1) != 0;
 
     // the (block, group) items of the group-split pass handed to its workgroups so that every compute unit gets a like share of rows (forces_gs.hip, k_gs_balance)
     DBuf<uint16_t> gs_item; const bool gs_balance_on = env_int("MOLLYHIP_GS_BALANCE", 1) != 0; int cu_count = 0;
@@ -2416,7 +2445,26 @@ template <class T> class Engine final : public EngineBase {
                 if (!pre && check_due(step, every)) refresh(step);
                 continue;
             }
+            // the validity check of step + 1 is measured where its coordinates are made: by this step's integrator launch — or by the pair pass itself when it integrates
+            const bool measure = step != last && async_ok() && !trk_issued && check_due(step + 1, every);
+            step_req.on = step != last && !bonded.any() && !pme.on(); step_req.cm = cm;      // (one kernel either way: its stage time is its own, so the stage timers leave it fused)
+             step_req.measure = measure; step_req.dt = dt;
             step_forces(step);
+            step_req.on = false;
+            if (step_done) {      // the pair pass integrated on the way (k_forces STEP): no integrator launch for this step
+                step_done = false;
+                if (measure) {
+                    if (!h_trk) MHIP_HIP(hipHostMalloc((void**)&h_trk, 4 * sizeof(float)));
+                    if (!ev_trk) MHIP_HIP(hipEventCreateWithFlags(&ev_trk, hipEventDisableTiming));
+                    hipLaunchKernelGGL(k_track_reduce, dim3(1), dim3(256), 0, stream, n_blocks, (const float*)trk_part.p, trk_out.p, h_trk);
+                    MHIP_HIP(hipEventRecord(ev_trk, stream));
+                    trk_issued = true; trk_step = step + 1; trk_prev_vmax = last_vmax; trk_prune_id = n_filters; trk_outer_id = n_outer;
+                }
+                pend_a = pend_b = nullptr; cm_pending = 0; cm_ext = nullptr;
+                if (cm) { cm_pending = 2; cm_ext = cm_blk.p + (size_t)step_half * 4 * n_blocks; n_cm_step = n_blocks; step_half ^= 1; }
+                frc_valid = false;
+                continue;
+            }
             if (!pre && check_due(step, every)) { fold_side_forces(); refresh(step); }   // the sort permutes vel / frc with the atoms; Σ m v does not care
             // every block re-sums the previous step's per-block Σ m v partials (32 bytes each), so fewer, longer blocks pay: 1024 blocks
             // re-read 32 MB from L2 per launch — more than the 21 MB of atoms of the 256k-atom fluid (13.0 → 10.0 µs with 256 blocks;
@@ -2426,18 +2474,18 @@ template <class T> class Engine final : public EngineBase {
             const double* cm_in = cm_pending == 2 ? cm_src() : (const double*)nullptr;
             double* cm_out = cm ? cm_step.p + (size_t)half * 4 * 1024 : (double*)nullptr;
             prof.begin(2, stream);
-            // the speeds for a check that the next step's force pass will measure (see resolve_track)
-            const bool measure = step != last && async_ok() && !trk_issued && check_due(step + 1, every);
-            if (measure) { trk_part.reserve(3 * 1024); trk_out.reserve(4); }
+            // the speeds for a check that the next step's force pass will measure (see resolve_track); evaluated behind the pass: a prune inside it makes the lists checkable again
+            const bool measure_mid = step != last && async_ok() && !trk_issued && check_due(step + 1, every);
+            if (measure_mid) { trk_part.reserve(3 * (size_t)std::max(n_blocks, 1024)); trk_out.reserve(4); }
             auto go = [&](auto kern) {
                 hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, stream, n_owned, pos[cur].p, vel[cur].p, (const T4*)frc[cur].p, T(dt), T(dt) / T(2),
                                    cm_in, n_cm_step, cm_out, (const T4*)pend_a, (const T4*)pend_b, G,
-                                   measure ? (const T4*)pos_snap_in.p : (const T4*)nullptr, measure ? (const T4*)pos_snap.p : (const T4*)nullptr, measure ? trk_part.p : (float*)nullptr);
+                                   measure_mid ? (const T4*)pos_snap_in.p : (const T4*)nullptr, measure_mid ? (const T4*)pos_snap.p : (const T4*)nullptr, measure_mid ? trk_part.p : (float*)nullptr);
             };
             if (step == last) { if (cm) go(k_vv_mid<T, true, true>); else go(k_vv_mid<T, false, true>); }
             else { if (cm) go(k_vv_mid<T, true, false>); else go(k_vv_mid<T, false, false>); }
             prof.end(2, stream);
-            if (measure) {   // the check of step + 1: reduce, copy, event — read by resolve_track at step + 2
+            if (measure_mid) {   // the check of step + 1: reduce, copy, event — read by resolve_track at step + 2
                 if (!h_trk) MHIP_HIP(hipHostMalloc((void**)&h_trk, 4 * sizeof(float)));
                 if (!ev_trk) MHIP_HIP(hipEventCreateWithFlags(&ev_trk, hipEventDisableTiming));
                 hipLaunchKernelGGL(k_track_reduce, dim3(1), dim3(256), 0, stream, nb, (const float*)trk_part.p, trk_out.p, h_trk);   // (straight into pinned host memory)
@@ -2584,6 +2632,7 @@ template <class T> class Engine final : public EngineBase {
         s->last_rebuild_ms = last_rebuild_ms; s->lds_bytes = (int64_t)lds_force;
         s->tile_segments = segmented ? cdiv(std::max(last_pass_tile, 1), std::max(tile_lds, 1)) : 1;
         s->n_group_split_passes = n_gs_passes; s->group_split = gs_groups(); s->n_adopted_outer_lists = (int32_t)std::min<int64_t>(n_adopted, INT32_MAX);
+        s->n_fused_steps = n_fused_steps;
         s->n_list_slots = total_rows * 4 * WAVE;
         if (!stale) {
             std::vector<int32_t> tc(n_blocks);

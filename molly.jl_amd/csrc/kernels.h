@@ -1028,6 +1028,12 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_filter(FilterAr
 
 // ---------------------------------------------------------------------------------------------------
 // the hot kernel: LJ + Coulomb forces (and energy) on the owned atoms from the LDS-staged tile
+// The integrator's arithmetic is the reference's, operation by operation (no fused multiply-add, a true division): a = f / m with 0 for
+// massless atoms (calc_accels, force.jl:17), v += a·dt/2 (simulators.jl:594, 616), x += v·dt (:602).  Every integrator kernel and the STEP
+// epilogue of k_forces go through these two helpers, so a run cut into chunks repeats the uncut run bit for bit (test/simulation.jl:16-57).
+template <class T> __device__ inline T accel_of(T f, T m) { return m == T(0) ? T(0) : f / m; }
+template <class T> __device__ inline T step_add(T x, T rate, T h) { return M<T>::add(x, M<T>::mul(rate, h)); }
+
 template <class T> struct ForceArgs {
     GridP<T> G;
     InterP<T> I;
@@ -1069,7 +1075,34 @@ template <class T> struct ForceArgs {
     // Σ m v of the integrator launch before this pass, still per-block partials (k_vv_mid): workgroup 0 of this pass adds them up into ONE partial behind its own
     // work, so that the integrator launch behind it can run as many short blocks as it likes without each of them re-summing the partials first.  nullptr: nothing to do
     const double* cm_fin_in; int cm_fin_n; double* cm_fin_out;
+    // STEP variants (the plain fp32 one-type passes inside mhip_vv_run): the velocity-Verlet update of the block's own atoms in the epilogue — second kick of this
+    // step, first kick and drift of the next (what k_vv_mid does in a launch of its own) — into vel and into the OTHER position buffer (every block still reads
+    // this step's positions for its tile); no force array is written.  cm_in / cm_n: Σ m v partials of the launch before, summed and published as v_cm by an extra
+    // workgroup at the head of the grid (step_cm_publish), subtracted here one launch late as in k_vv_mid; cm_out: this launch's partials, one per block (nullable);
+    // trk_part: per-block maxima for the validity check of the pair lists (nullable), against snap_a / snap_b.
+    typename Vec<T>::T4* vel; typename Vec<T>::T4* pos_next; T dt, dt2;
+    const double* cm_in; int cm_n; unsigned long long* cm_pub; uint32_t step_seq; double* cm_out;
+    float* trk_part; const typename Vec<T>::T4* snap_a; const typename Vec<T>::T4* snap_b;
 };
+// STEP launches: the first workgroup of the grid does nothing but this — Σ m v of the launch before (n_part partials, the fixed order of cm_finalize_in_block)
+// → v_cm = P / M rounded to T as block_vcm does → three words {value bits, launch number} that every other workgroup's epilogue polls (relaxed agent-scope
+// atomics: no fence, no cache write-back; the epilogues come ≈ 15 µs after this has finished)
+// (its scratch is the launch's dynamic LDS: a static __shared__ array would move the tile off LDS address 0, which the packed loop addresses from)
+[[maybe_unused]] static __device__ inline void step_cm_publish(const double* __restrict__ part, int n_part, unsigned long long* pub, uint32_t seq, unsigned char* smem) {
+    double (*sh_pub)[4] = reinterpret_cast<double (*)[4]>(smem);
+    double a[4] = {0, 0, 0, 0};
+    for (int q = threadIdx.x; q < n_part; q += blockDim.x) { const double* p = part + 4 * (int64_t)q; a[0] += p[0]; a[1] += p[1]; a[2] += p[2]; a[3] += p[3]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) for (int c = 0; c < 4; ++c) a[c] += __shfl_xor(a[c], o, 64);
+    if ((threadIdx.x & 63) == 0) for (int c = 0; c < 4; ++c) sh_pub[threadIdx.x >> 6][c] = a[c];
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double t = 0, m = 0;
+        for (int q = 0; q < (int)(blockDim.x >> 6); ++q) { t += sh_pub[q][threadIdx.x]; m += sh_pub[q][3]; }
+        const float vc = (float)(t / m);
+        __hip_atomic_store(&pub[threadIdx.x], (unsigned long long)__float_as_uint(vc) | ((unsigned long long)seq << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 // (runs behind everything else of workgroup 0: nothing of it is live in the pair loop — in front of it the packed loop spilled 12 bytes, as a call it needed a stack)
 [[maybe_unused]] static __device__ inline void cm_finalize_in_block(const double* __restrict__ part, int n_part, double* out4, unsigned char* smem) {
     double a[4] = {0, 0, 0, 0};
@@ -1099,7 +1132,7 @@ __host__ __device__ inline size_t prune_lds_bytes(int t_seg, int nthr) { return 
 template <class T, int LJM, int COULM, bool ENERGY, bool MINIMG, bool SEG, bool PRUNE>
 constexpr int force_min_waves() { return (std::is_same<T, float>::value && LJM == LJ_DIST_UNIFORM && COULM == MHIP_COUL_NONE && !ENERGY && !MINIMG && !SEG && !PRUNE) ? MHIP_FAST_MIN_WAVES : 1; }
 
-template <class T, int LJM, int COULM, bool ENERGY, bool MINIMG, bool SEG, bool PRUNE, int SOA_STRIDE = 4097>
+template <class T, int LJM, int COULM, bool ENERGY, bool MINIMG, bool SEG, bool PRUNE, int SOA_STRIDE = 4097, bool STEP = false>
 __global__ void __launch_bounds__(BlockLimits<T>::max_threads, (force_min_waves<T, LJM, COULM, ENERGY, MINIMG, SEG, PRUNE>()))
 k_forces(ForceArgs<T> A) {
     using T4 = typename Vec<T>::T4;
@@ -1109,7 +1142,11 @@ k_forces(ForceArgs<T> A) {
     const GridP<T>& G = A.G;
     // XCD-aware mapping: hardware places workgroup w on XCD w % 8; give each XCD a contiguous run of the
     // Hilbert-ordered blocks so that neighbouring blocks (which share most of their tiles) share an L2.
-    const int wg = blockIdx.x;
+    int wg = blockIdx.x;
+    if constexpr (STEP) {      // (the grid is one workgroup longer: the first one sums and publishes v_cm, the others take the blocks — XCD k + 1 gets the run XCD k had)
+        if (wg == 0) { if (A.cm_in) step_cm_publish(A.cm_in, A.cm_n, A.cm_pub, A.step_seq, smem); return; }
+        --wg;
+    }
     const int b = (wg & 7) * A.blocks_per_xcd + (wg >> 3);
     if (b >= A.n_blocks) return;
     if (A.part != 0 && (A.blk_ghost[b] != 0) != (A.part == 2)) return;
@@ -1584,7 +1621,59 @@ k_forces(ForceArgs<T> A) {
             }
         }
     }
-    if (js == 0 && valid) A.frc[si] = make4<T>(fx, fy, fz, T(0));
+    if constexpr (STEP) {
+        // velocity Verlet for the block's own atoms (simulators.jl:594-616): what k_vv_mid does, with the force still in registers.  Position and velocity
+        // are fetched HERE (kept across the pair loop they would cost it its registers); the new position goes to the other buffer.
+        double px = 0, py = 0, pz = 0, pm = 0;
+        float tr_a = 0.f, tr_b = 0.f, tr_v = 0.f;
+        if (js == 0 && valid) {
+            T4 v = A.vel[si]; T4 p = A.pos[si];
+            if (A.cm_in) {      // remove_CM_motion! of the step before, one launch late (k_vv_mid's scheme): v_cm as the head workgroup published it
+                T vc[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    unsigned long long w;
+                    do { w = __hip_atomic_load(&A.cm_pub[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((uint32_t)(w >> 32) != A.step_seq);
+                    vc[c] = (T)__uint_as_float((uint32_t)w);
+                }
+                v.x -= vc[0]; v.y -= vc[1]; v.z -= vc[2];
+                p.x = M<T>::sub(p.x, M<T>::mul(vc[0], A.dt)); p.y = M<T>::sub(p.y, M<T>::mul(vc[1], A.dt)); p.z = M<T>::sub(p.z, M<T>::mul(vc[2], A.dt));
+            }
+            const T kx = M<T>::mul(accel_of(fx, v.w), A.dt2), ky = M<T>::mul(accel_of(fy, v.w), A.dt2), kz = M<T>::mul(accel_of(fz, v.w), A.dt2);
+            v.x = M<T>::add(v.x, kx); v.y = M<T>::add(v.y, ky); v.z = M<T>::add(v.z, kz);   // :616, v_n before this step's CM removal
+            if (A.cm_out) { px = (double)v.x * v.w; py = (double)v.y * v.w; pz = (double)v.z * v.w; pm = v.w; }
+            v.x = M<T>::add(v.x, kx); v.y = M<T>::add(v.y, ky); v.z = M<T>::add(v.z, kz);   // :594 of the next step
+            p.x = step_add(p.x, v.x, A.dt); p.y = step_add(p.y, v.y, A.dt); p.z = step_add(p.z, v.z, A.dt);   // :602
+            wrap_point(p.x, p.y, p.z, G);                                      // :609
+            A.vel[si] = v; A.pos_next[si] = p;
+            if (A.trk_part) {
+                tr_v = (float)(v.x * v.x + v.y * v.y + v.z * v.z);
+                auto q = A.snap_a[si];
+                T ex = p.x - q.x, ey = p.y - q.y, ez = p.z - q.z;
+                disp_image(ex, ey, ez, G);
+                tr_a = (float)(ex * ex + ey * ey + ez * ez);
+                q = A.snap_b[si];
+                ex = p.x - q.x; ey = p.y - q.y; ez = p.z - q.z;
+                disp_image(ex, ey, ez, G);
+                tr_b = (float)(ex * ex + ey * ey + ez * ez);
+            }
+        }
+        if (A.cm_out || A.trk_part) {      // per-block sums / maxima: the waves of the i-atoms (js == 0) through LDS, fixed order
+            __syncthreads();
+            double* shd = reinterpret_cast<double*>(smem);          // [waves][4] doubles, then [waves][3] floats
+            const int nw = A.BI >> 6, w = li >> 6;
+            float* shf = reinterpret_cast<float*>(shd + 4 * nw);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { px += __shfl_xor(px, o, 64); py += __shfl_xor(py, o, 64); pz += __shfl_xor(pz, o, 64); pm += __shfl_xor(pm, o, 64); }
+            tr_a = wave_max(tr_a); tr_b = wave_max(tr_b); tr_v = wave_max(tr_v);
+            if (js == 0 && (li & 63) == 0) { shd[4 * w] = px; shd[4 * w + 1] = py; shd[4 * w + 2] = pz; shd[4 * w + 3] = pm; shf[3 * w] = tr_a; shf[3 * w + 1] = tr_b; shf[3 * w + 2] = tr_v; }
+            __syncthreads();
+            if (A.cm_out && tid < 4) { double a = 0; for (int q = 0; q < nw; ++q) a += shd[4 * q + tid]; A.cm_out[4 * (int64_t)b + tid] = a; }
+            if (A.trk_part && tid < 3) { float mm = 0.f; for (int q = 0; q < nw; ++q) mm = fmaxf(mm, shf[3 * q + tid]); A.trk_part[(int64_t)tid * A.n_blocks + b] = mm; }
+        }
+    } else {
+        if (js == 0 && valid) A.frc[si] = make4<T>(fx, fy, fz, T(0));
+    }
     stamp(3);
     if constexpr (!ENERGY) {
         if (A.cm_fin_out && wg == 0) { __syncthreads(); cm_finalize_in_block(A.cm_fin_in, A.cm_fin_n, A.cm_fin_out, smem); }
@@ -1723,8 +1812,7 @@ __device__ inline void block_vcm(const double* __restrict__ part, int n_part, T*
 // The integrator's arithmetic is the reference's, operation by operation (no fused multiply-add, a true division): a = f / m with 0 for
 // massless atoms (calc_accels, force.jl:17), v += a·dt/2 (simulators.jl:594, 616), x += v·dt (:602).  Every kernel below goes through
 // these two helpers, so a run cut into chunks repeats the uncut run bit for bit (test/simulation.jl:16-57).
-template <class T> __device__ inline T accel_of(T f, T m) { return m == T(0) ? T(0) : f / m; }
-template <class T> __device__ inline T step_add(T x, T rate, T h) { return M<T>::add(x, M<T>::mul(rate, h)); }
+// (accel_of / step_add are defined in front of k_forces, whose STEP variants integrate in their epilogue)
 
 template <class T>
 __global__ void k_vv1(int64_t n, typename Vec<T>::T4* pos, typename Vec<T>::T4* vel, const typename Vec<T>::T4* __restrict__ frc,
