@@ -1074,7 +1074,8 @@ template <class T> class Engine final : public EngineBase {
         if constexpr (std::is_same<T, float>::value) {
             do_step = step_req.on && fuse_step_env && fast_f32 && A.soa != 0 && use_inner && !prune && part == 0 && !frc_override && n_ghost == 0 && !A.lane_atom && !A.dbg && cm_pending != 1;
             if (do_step) {
-                pos_alt.reserve(cap); cm_blk.reserve(2 * 4 * (size_t)n_blocks + 8); cm_pub.reserve(4);
+                pos_alt.reserve(cap); cm_blk.reserve(2 * 4 * (size_t)n_blocks + 8);
+                if (!cm_pub.p) { cm_pub.reserve(4); MHIP_HIP(hipMemsetAsync(cm_pub.p, 0, 4 * sizeof(unsigned long long), stream)); }      // (launch numbers start at 1)
                 A.vel = vel[cur].p; A.pos_next = pos_alt.p; A.dt = T(step_req.dt); A.dt2 = T(step_req.dt) / T(2);
                 A.cm_in = cm_pending == 2 ? cm_src() : (const double*)nullptr; A.cm_n = n_cm_step; A.cm_pub = cm_pub.p; A.step_seq = ++step_seq;
                 A.cm_out = step_req.cm ? cm_blk.p + (size_t)step_half * 4 * n_blocks : (double*)nullptr;

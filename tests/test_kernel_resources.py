@@ -48,7 +48,8 @@ def _kernels(asm):
 def test_uniform_lj_kernels_fit_64_vgprs_without_scratch(tmp_path):
     ks = _kernels(_compile(tmp_path))
     plain = {n: v for n, v in ks.items() if "k_forces<float, 3, 0, false, false, false, false" in n}   # not SEG, not PRUNE: the passes of every step
-    assert len(plain) == 3                                            # the three tile strides
+    # the three tile strides, each as the plain pass and as the STEP variant (round 5: the integrator in the epilogue) — which must not cost the loop a register
+    assert len(plain) == 6 and sum(1 for n in plain if ", true>(" in n) == 3
     for n, (r, body) in plain.items():
         assert r["next_free_vgpr"] <= 64, (n, r)
         assert r["private_segment_fixed_size"] == 0, (n, r)
@@ -68,7 +69,14 @@ def test_packed_loop_issue_count(tmp_path):
     """The hot loop of the plain pass: at most 48 VALU instructions per row of four partners (round 2: 61, plus 15 s_nop), one
     address instruction per partner, row count in a scalar register."""
     ks = _kernels(_compile(tmp_path))
-    n, (r, body) = next((n, v) for n, v in ks.items() if "k_forces<float, 3, 0, false, false, false, false, 3073>" in n)
+    counts = {}
+    for variant in ("k_forces<float, 3, 0, false, false, false, false, 3073, false>", "k_forces<float, 3, 0, false, false, false, false, 3073, true>"):
+        counts[variant] = _loop_counts(ks, variant)
+    assert counts["k_forces<float, 3, 0, false, false, false, false, 3073, false>"] == counts["k_forces<float, 3, 0, false, false, false, false, 3073, true>"]      # the same loop in both
+
+
+def _loop_counts(ks, variant):
+    n, (r, body) = next((n, v) for n, v in ks.items() if variant in n)
     # the innermost loop that holds the clamped packed fma of the cutoff
     blocks, cur = [], []
     for line in body:
@@ -85,6 +93,7 @@ def test_packed_loop_issue_count(tmp_path):
     assert len(valu) / rows <= 48, (len(valu), rows)
     assert not any("scratch_" in l for l in loop)
     assert sum(1 for l in loop if "ds_read_b32" in l) == 12 * rows
+    return len(valu), rows, len(loop)
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
