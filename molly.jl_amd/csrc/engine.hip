@@ -1059,7 +1059,7 @@ template <class T> class Engine final : public EngineBase {
         A.blk_center = blk_center.p; A.frc = frc_override ? frc_override : frc[cur].p; A.pe_part = red_part.p;
         // inside vv_run: the Σ m v partials of the integrator launch before this pass become one partial here (kernels.h, cm_finalize_in_block)
         A.cm_fin_in = nullptr; A.cm_fin_n = 0; A.cm_fin_out = nullptr;
-        A.vel = nullptr; A.pos_next = nullptr; A.dt = T(0); A.dt2 = T(0); A.cm_in = nullptr; A.cm_n = 0; A.cm_pub = nullptr; A.step_seq = 0; A.cm_out = nullptr; A.trk_part = nullptr; A.snap_a = nullptr; A.snap_b = nullptr;
+        A.vel = nullptr; A.pos_next = nullptr; A.dt = T(0); A.dt2 = T(0); A.step_touch = 0; A.cm_in = nullptr; A.cm_n = 0; A.cm_pub = nullptr; A.step_seq = 0; A.cm_out = nullptr; A.trk_part = nullptr; A.snap_a = nullptr; A.snap_b = nullptr;
         const bool cm_fin = cm_fin_on && in_vv_fused && !energy && n_ghost == 0 && part == 0 && cm_pending == 2 && n_cm_step > 1 && n_cm_step <= 65536;      // (the energy variants do not carry the sum)
         if (cm_fin) { cm_fin_buf.reserve(4); A.cm_fin_in = cm_src(); A.cm_fin_n = n_cm_step; A.cm_fin_out = cm_fin_buf.p; }
         else if (cm_fin_solo_src && !energy && n_ghost == 0 && part == 0 && !cm_fin_solo_done) {      // (mhip_domain_run on one brick: halo_mid's partials)
@@ -1072,11 +1072,11 @@ template <class T> class Engine final : public EngineBase {
         step_done = false;
         bool do_step = false;
         if constexpr (std::is_same<T, float>::value) {
-            do_step = step_req.on && fuse_step_env && fast_f32 && A.soa != 0 && use_inner && !prune && part == 0 && !frc_override && n_ghost == 0 && !A.lane_atom && !A.dbg && cm_pending != 1;
+            do_step = step_req.on && fuse_step_env && fast_f32 && A.soa != 0 && use_inner && !prune && part == 0 && !frc_override && n_ghost == 0 && !A.lane_atom && cm_pending != 1;
             if (do_step) {
                 pos_alt.reserve(cap); cm_blk.reserve(2 * 4 * (size_t)n_blocks + 8);
                 if (!cm_pub.p) { cm_pub.reserve(4); MHIP_HIP(hipMemsetAsync(cm_pub.p, 0, 4 * sizeof(unsigned long long), stream)); }      // (launch numbers start at 1)
-                A.vel = vel[cur].p; A.pos_next = pos_alt.p; A.dt = T(step_req.dt); A.dt2 = T(step_req.dt) / T(2);
+                A.vel = vel[cur].p; A.pos_next = pos_alt.p; A.dt = T(step_req.dt); A.dt2 = T(step_req.dt) / T(2); A.step_touch = step_touch_env;
                 A.cm_in = cm_pending == 2 ? cm_src() : (const double*)nullptr; A.cm_n = n_cm_step; A.cm_pub = cm_pub.p; A.step_seq = ++step_seq;
                 A.cm_out = step_req.cm ? cm_blk.p + (size_t)step_half * 4 * n_blocks : (double*)nullptr;
                 A.trk_part = nullptr; A.snap_a = pos_snap_in.p; A.snap_b = pos_snap.p;
@@ -1143,6 +1143,7 @@ template <class T> class Engine final : public EngineBase {
     bool step_done = false; int step_half = 0; uint32_t step_seq = 0; int64_t n_fused_steps = 0;
     DBuf<T4> pos_alt; DBuf<double> cm_blk; DBuf<unsigned long long> cm_pub;
     const bool fuse_step_env = env_int("MOLLYHIP_FUSE_STEP", 1) != 0;
+    const int step_touch_env = std::max(0, env_int("MOLLYHIP_STEP_TOUCH", 4));      // rows before the end of a block's list at which the epilogue's records are read ahead
 
     // the (block, group) items of the group-split pass handed to its workgroups so that every compute unit gets a like share of rows (forces_gs.hip, k_gs_balance)
     DBuf<uint16_t> gs_item; const bool gs_balance_on = env_int("MOLLYHIP_GS_BALANCE", 1) != 0; int cu_count = 0;

@@ -66,6 +66,34 @@ template <class T> __device__ inline T wave_max(T v) {
     return v;
 }
 
+// Sums and maxima over the 16-lane ROWS of a wave without the LDS: data-parallel-primitive moves (DPP) instead of ds_bpermute — a butterfly of
+// __shfl_xor is six dependent LDS round trips per value, and in the epilogue of a pair pass the LDS pipe is what every other wave on the compute unit is
+// busy with.  dpp_lane<C>: the value of another lane of the row (quad_perm xor 1 = 0xB1, xor 2 = 0x4E; row_ror:n = 0x120 + n: lane i reads lane i − n mod 16).
+template <int CTRL> __device__ inline float dpp_lane(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true)); }
+template <int CTRL> __device__ inline double dpp_lane(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true), hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// Four sums at once: lanes 0..3 of every row return the row's sum of a, b, c, d respectively (the other lanes: partial sums of no use).  The association is
+// the xor butterfly's — ((x0 + x1) + (x2 + x3)) in the quads, then (q0 + q1) + (q2 + q3) — so that (r0 + r1) + (r2 + r3) over the four rows gives, bit for
+// bit, what `for (o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o)` leaves in every lane (the integrator kernels' partials, which these must agree with).
+__device__ inline double row_sum4(double a, double b, double c, double d, int lane) {
+    a += dpp_lane<0xB1>(a); b += dpp_lane<0xB1>(b); c += dpp_lane<0xB1>(c); d += dpp_lane<0xB1>(d);
+    a += dpp_lane<0x4E>(a); b += dpp_lane<0x4E>(b); c += dpp_lane<0x4E>(c); d += dpp_lane<0x4E>(d);
+    double s = (lane & 2) ? ((lane & 1) ? d : c) : ((lane & 1) ? b : a);
+    s += dpp_lane<0x12C>(s);      // lane i + lane i + 4
+    s += dpp_lane<0x128>(s);      // … + lanes i + 8, i + 12
+    return s;
+}
+__device__ inline float row_max3(float a, float b, float c, int lane) {      // lanes 0..2 of every row: the row's maximum of a, b, c
+    a = fmaxf(a, dpp_lane<0xB1>(a)); b = fmaxf(b, dpp_lane<0xB1>(b)); c = fmaxf(c, dpp_lane<0xB1>(c));
+    a = fmaxf(a, dpp_lane<0x4E>(a)); b = fmaxf(b, dpp_lane<0x4E>(b)); c = fmaxf(c, dpp_lane<0x4E>(c));
+    float s = (lane & 2) ? c : ((lane & 1) ? b : a);
+    s = fmaxf(s, dpp_lane<0x12C>(s));
+    s = fmaxf(s, dpp_lane<0x128>(s));
+    return s;
+}
+
 // triclinic boxes: fractional coordinates of the upper-triangular basis (a ∥ x, b in the xy plane) and their height-scaled form u
 template <class T> __device__ inline void frac_coords(T x, T y, T z, const GridP<T>& G, T s[3]) {
     s[2] = z * G.rs[2]; s[1] = (y - s[2] * G.bv[2][1]) * G.rs[1]; s[0] = (x - s[1] * G.bv[1][0] - s[2] * G.bv[2][0]) * G.rs[0];
@@ -1080,7 +1108,7 @@ template <class T> struct ForceArgs {
     // this step's positions for its tile); no force array is written.  cm_in / cm_n: Σ m v partials of the launch before, summed and published as v_cm by an extra
     // workgroup at the head of the grid (step_cm_publish), subtracted here one launch late as in k_vv_mid; cm_out: this launch's partials, one per block (nullable);
     // trk_part: per-block maxima for the validity check of the pair lists (nullable), against snap_a / snap_b.
-    typename Vec<T>::T4* vel; typename Vec<T>::T4* pos_next; T dt, dt2;
+    typename Vec<T>::T4* vel; typename Vec<T>::T4* pos_next; T dt, dt2; int step_touch;
     const double* cm_in; int cm_n; unsigned long long* cm_pub; uint32_t step_seq; double* cm_out;
     float* trk_part; const typename Vec<T>::T4* snap_a; const typename Vec<T>::T4* snap_b;
 };
@@ -1178,6 +1206,10 @@ k_forces(ForceArgs<T> A) {
     if constexpr (!PRUNE) { if (A.lane_atom) ai = (int)A.lane_atom[((int64_t)b * A.JS + js) * A.BI + li]; }
     const int64_t si = (int64_t)b * A.BI + ai;
     const bool valid = si < A.n_owned;
+    // (STEP, whose lanes are in atom order: the atom again, from the lane number, where it is needed late — the compiler forms such addresses at the top of the
+    // kernel otherwise, and carrying them past the pair loop costs the loop its 64 registers)
+    [[maybe_unused]] auto step_lane = [&]() -> int { int t = tid; asm volatile("" : "+v"(t)); return t & (A.BI - 1); };
+    [[maybe_unused]] auto step_atom = [&]() -> int64_t { return (int64_t)b * A.BI + step_lane(); };
     const T4 pi_raw = A.pos[valid ? si : (int64_t)b * A.BI];
     T4 pi = pi_raw;
     if constexpr (NO_TRI) pi = localise(pi, std::false_type{});
@@ -1608,6 +1640,19 @@ k_forces(ForceArgs<T> A) {
         if (js == 0 && (tid & 63) == 0) A.blk_disp2[b * (A.BI >> 6) + (li >> 6)] = d2;   // one word per wave of i-atoms: plain stores, nothing to zero beforehand
     }
     stamp(2);
+    [[maybe_unused]] T4 st_v, st_p;
+    [[maybe_unused]] int64_t se = 0;
+    [[maybe_unused]] unsigned long long st_w[3] = {0, 0, 0};
+    if constexpr (STEP) {      // (in flight across the reduction below: the records, and v_cm as the head workgroup published it — three words, ONE round trip)
+        se = step_atom();
+        if (js == 0 && se < A.n_owned) {
+            st_v = A.vel[se]; st_p = A.pos[se];
+            if (A.cm_in) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) st_w[c] = __hip_atomic_load(&A.cm_pub[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
     if (A.JS > 1) {   // deterministic reduction of the j-split partial sums through LDS
         __syncthreads();
         T* red = reinterpret_cast<T*>(smem);     // (indexed by ATOM: the groups' lane orders may differ)
@@ -1626,16 +1671,18 @@ k_forces(ForceArgs<T> A) {
         // are fetched HERE (kept across the pair loop they would cost it its registers); the new position goes to the other buffer.
         double px = 0, py = 0, pz = 0, pm = 0;
         float tr_a = 0.f, tr_b = 0.f, tr_v = 0.f;
-        if (js == 0 && valid) {
-            T4 v = A.vel[si]; T4 p = A.pos[si];
+        T4 v = st_v, p = st_p;
+        const bool mine = js == 0 && se < A.n_owned;
+        if (mine) {
             if (A.cm_in) {      // remove_CM_motion! of the step before, one launch late (k_vv_mid's scheme): v_cm as the head workgroup published it
+                // (the head workgroup was the first of the grid and finished ≈ 20 µs ago: the words read above are this launch's; if not, again — all three at once)
+                while ((uint32_t)(st_w[0] >> 32) != A.step_seq || (uint32_t)(st_w[1] >> 32) != A.step_seq || (uint32_t)(st_w[2] >> 32) != A.step_seq) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) st_w[c] = __hip_atomic_load(&A.cm_pub[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 T vc[3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    unsigned long long w;
-                    do { w = __hip_atomic_load(&A.cm_pub[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((uint32_t)(w >> 32) != A.step_seq);
-                    vc[c] = (T)__uint_as_float((uint32_t)w);
-                }
+                for (int c = 0; c < 3; ++c) vc[c] = (T)__uint_as_float((uint32_t)st_w[c]);
                 v.x -= vc[0]; v.y -= vc[1]; v.z -= vc[2];
                 p.x = M<T>::sub(p.x, M<T>::mul(vc[0], A.dt)); p.y = M<T>::sub(p.y, M<T>::mul(vc[1], A.dt)); p.z = M<T>::sub(p.z, M<T>::mul(vc[2], A.dt));
             }
@@ -1645,32 +1692,37 @@ k_forces(ForceArgs<T> A) {
             v.x = M<T>::add(v.x, kx); v.y = M<T>::add(v.y, ky); v.z = M<T>::add(v.z, kz);   // :594 of the next step
             p.x = step_add(p.x, v.x, A.dt); p.y = step_add(p.y, v.y, A.dt); p.z = step_add(p.z, v.z, A.dt);   // :602
             wrap_point(p.x, p.y, p.z, G);                                      // :609
-            A.vel[si] = v; A.pos_next[si] = p;
             if (A.trk_part) {
                 tr_v = (float)(v.x * v.x + v.y * v.y + v.z * v.z);
-                auto q = A.snap_a[si];
+                auto q = A.snap_a[se];
                 T ex = p.x - q.x, ey = p.y - q.y, ez = p.z - q.z;
                 disp_image(ex, ey, ez, G);
                 tr_a = (float)(ex * ex + ey * ey + ez * ez);
-                q = A.snap_b[si];
+                q = A.snap_b[se];
                 ex = p.x - q.x; ey = p.y - q.y; ez = p.z - q.z;
                 disp_image(ex, ey, ez, G);
                 tr_b = (float)(ex * ex + ey * ey + ez * ez);
             }
         }
-        if (A.cm_out || A.trk_part) {      // per-block sums / maxima: the waves of the i-atoms (js == 0) through LDS, fixed order
+        if (A.cm_out || A.trk_part) {      // per-block sums / maxima: the waves of the i-atoms (js == 0) by rows, then through LDS, in the fixed order of the integrator kernels
             __syncthreads();
-            double* shd = reinterpret_cast<double*>(smem);          // [waves][4] doubles, then [waves][3] floats
-            const int nw = A.BI >> 6, w = li >> 6;
-            float* shf = reinterpret_cast<float*>(shd + 4 * nw);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { px += __shfl_xor(px, o, 64); py += __shfl_xor(py, o, 64); pz += __shfl_xor(pz, o, 64); pm += __shfl_xor(pm, o, 64); }
-            tr_a = wave_max(tr_a); tr_b = wave_max(tr_b); tr_v = wave_max(tr_v);
-            if (js == 0 && (li & 63) == 0) { shd[4 * w] = px; shd[4 * w + 1] = py; shd[4 * w + 2] = pz; shd[4 * w + 3] = pm; shf[3 * w] = tr_a; shf[3 * w + 1] = tr_b; shf[3 * w + 2] = tr_v; }
+            double* shd = reinterpret_cast<double*>(smem);          // [waves][4 rows][4] doubles, then [waves][4 rows][4] floats
+            const int le = step_lane(), nw = A.BI >> 6, w = le >> 6, ln = le & 63;
+            float* shf = reinterpret_cast<float*>(shd + 16 * nw);
+            if (js == 0) {      // (wave-uniform)
+                if (A.cm_out) { const double sv = row_sum4(px, py, pz, pm, ln); if ((ln & 15) < 4) shd[(w * 4 + (ln >> 4)) * 4 + (ln & 3)] = sv; }
+                if (A.trk_part) { const float mv = row_max3(tr_a, tr_b, tr_v, ln); if ((ln & 15) < 3) shf[(w * 4 + (ln >> 4)) * 4 + (ln & 3)] = mv; }
+            }
             __syncthreads();
-            if (A.cm_out && tid < 4) { double a = 0; for (int q = 0; q < nw; ++q) a += shd[4 * q + tid]; A.cm_out[4 * (int64_t)b + tid] = a; }
-            if (A.trk_part && tid < 3) { float mm = 0.f; for (int q = 0; q < nw; ++q) mm = fmaxf(mm, shf[3 * q + tid]); A.trk_part[(int64_t)tid * A.n_blocks + b] = mm; }
+            if (A.cm_out && tid < 4) {
+                double a = 0;
+                for (int q = 0; q < nw; ++q) { const double* r4 = shd + 16 * q + tid; a += (r4[0] + r4[4]) + (r4[8] + r4[12]); }
+                A.cm_out[4 * (int64_t)b + tid] = a;
+            }
+            if (A.trk_part && tid < 3) { float mm = 0.f; for (int q = 0; q < 4 * nw; ++q) mm = fmaxf(mm, shf[4 * q + tid]); A.trk_part[(int64_t)tid * A.n_blocks + b] = mm; }
         }
+        // (the records go out LAST: a barrier behind a store waits until the store has been acknowledged, and the block would hold its place on the compute unit for that long)
+        if (mine) { A.vel[se] = v; A.pos_next[se] = p; }
     } else {
         if (js == 0 && valid) A.frc[si] = make4<T>(fx, fy, fz, T(0));
     }

@@ -238,3 +238,24 @@ def test_terms_added_between_two_runs_count_from_the_first_step(pkg):
     pkg.simulate(b, sim, 5, init_step=7)
     assert np.abs(a.coords - b.coords).max() < 1e-9 and np.abs(a.velocities - b.velocities).max() < 1e-7
 
+
+
+@pytest.mark.parametrize("remove_cm", [0, 1])
+def test_fused_step_repeats_the_separate_integrator_bit_for_bit(pkg, remove_cm, monkeypatch):
+    """Inside mhip_vv_run the plain pair passes of the fp32 one-type fluids integrate in their own epilogue (kernels.h, the STEP variants: no force array, no
+    integrator launch).  Same arithmetic, same order of the Σ m v partial sums (row sums by DPP in the association of the integrator kernels' butterfly), the
+    centre-of-mass velocity subtracted one launch late in both: 120 steps — outer searches, prunes and validity checks included, which take the separate
+    integrator either way — end in the SAME bits with the fused step on and off."""
+    case = S.lj_fluid(40, seed=2, dtype=np.float32)      # 64 000 atoms: the packed loop and the dual list, as in the benchmarks
+    sim = pkg.VelocityVerlet(dt=0.002, remove_CM_motion=remove_cm)
+    out = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("MOLLYHIP_FUSE_STEP", fuse)      # (read when the engine is created)
+        s = case.system(pkg, np.float32)
+        pkg.simulate(s, sim, 60)
+        pkg.simulate(s, sim, 60, init_step=60)
+        st = s.stats()
+        assert (st["n_fused_steps"] > 60) == (fuse == "1"), st["n_fused_steps"]
+        out.append((s.coords.copy(), s.velocities.copy()))
+        s.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])

@@ -93,7 +93,12 @@ def _loop_counts(ks, variant):
     assert len(valu) / rows <= 48, (len(valu), rows)
     assert not any("scratch_" in l for l in loop)
     assert sum(1 for l in loop if "ds_read_b32" in l) == 12 * rows
-    return len(valu), rows, len(loop)
+    # the SCHEDULE, not only the instruction count: a row's twelve LDS reads are issued together and waited for in stages, and the row fetched ahead
+    # stays in flight (a variant whose loop had the same 87 VALU instructions but drained lgkmcnt after every pair of reads and vmcnt once per trip
+    # walked its rows 40-65 % slower: profiles/r05_force_ab.txt §9)
+    waits = sorted(re.sub(r"\s+", " ", l.strip()) for l in loop if "s_waitcnt" in l)
+    assert sum(1 for w in waits if w == "s_waitcnt lgkmcnt(0)") <= rows and not any("vmcnt(0)" in w for w in waits), waits
+    return len(valu), rows, tuple(waits)
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
