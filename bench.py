@@ -224,10 +224,13 @@ def make_record(workload, case, dtype, dt, ms_per_step, st, extra, world, args, 
     ns_day = steps_s * (dt * 1e3) * 86400 * 1e-6        # dt [ps] → fs
     n_atoms = case.n
     force_ms = st["prof_ms"][0] / max(st["prof_calls"][0], 1)
-    # the large one-type fluids run the plain pair pass with the integrator in its epilogue (k_forces STEP: no force array, no integrator launch): such a launch
-    # carries the step's algorithmic bytes, SURVEY §8(d)'s N(R_p + 22w) + 4L, not only the force pass's N(R_p + 3w) + 4L
+    # the large one-type fluids run the plain pair pass with the integrator in its epilogue (k_forces STEP: no force array, no integrator launch).  Such a launch
+    # is priced by SURVEY §8(d)'s model — every per-atom array touched once per pass — applied to what it does: the force pass's N(R_p + 3w) + 4L without the
+    # force write (3w), plus the velocity read (4w) and the coordinate and velocity writes (2·4w): N(R_p + 12w) + 4L.  (The step's B_step = N(R_p + 22w) + 4L
+    # stays the yardstick of step_frac below; it counts the force array's round trip, which this launch does not make.)
     fused = st.get("n_fused_steps", 0) > 0
-    fbytes = st["algorithmic_bytes_step"] if fused else st["force_pass_bytes"]
+    w_bytes = 4 if dtype == np.float32 else 8
+    fbytes = st["force_pass_bytes"] + 9 * w_bytes * n_atoms if fused else st["force_pass_bytes"]
     achieved = fbytes / (force_ms * 1e-3) / 1e9 if force_ms > 0 else None
     traffic, traffic_src = load_traffic(workload)
     per_step = lambda k: st["prof_ms"][k] / max(profile_steps, 1)

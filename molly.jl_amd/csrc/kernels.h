@@ -1644,6 +1644,9 @@ k_forces(ForceArgs<T> A) {
     [[maybe_unused]] int64_t se = 0;
     [[maybe_unused]] unsigned long long st_w[3] = {0, 0, 0};
     if constexpr (STEP) {      // (in flight across the reduction below: the records, and v_cm as the head workgroup published it — three words, ONE round trip)
+        // From here on a wave is a chain of dependent instructions and waits — ≈ 150 of them, which take their turn with the row walks of the seven other
+        // waves of the SIMD — while its block keeps a quarter of the compute unit occupied: the arbiter is told to take these waves first.
+        __builtin_amdgcn_s_setprio(3);
         se = step_atom();
         if (js == 0 && se < A.n_owned) {
             st_v = A.vel[se]; st_p = A.pos[se];
