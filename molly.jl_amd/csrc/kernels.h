@@ -1708,8 +1708,8 @@ k_forces(ForceArgs<T> A) {
             }
         }
         if (A.cm_out || A.trk_part) {      // per-block sums / maxima: the waves of the i-atoms (js == 0) by rows, then through LDS, in the fixed order of the integrator kernels
-            __syncthreads();
-            double* shd = reinterpret_cast<double*>(smem);          // [waves][4 rows][4] doubles, then [waves][4 rows][4] floats
+            // (BEHIND the words of the j-split reduction, which slower waves may still be reading: no barrier in front of these stores; the tile they overwrite is done with)
+            double* shd = reinterpret_cast<double*>(smem + (((size_t)A.JS * 4 * A.BI * sizeof(T) + 15) & ~(size_t)15));          // [waves][4 rows][4] doubles, then [waves][4 rows][4] floats
             const int le = step_lane(), nw = A.BI >> 6, w = le >> 6, ln = le & 63;
             float* shf = reinterpret_cast<float*>(shd + 16 * nw);
             if (js == 0) {      // (wave-uniform)
