@@ -1210,18 +1210,34 @@ k_forces(ForceArgs<T> A) {
     // kernel otherwise, and carrying them past the pair loop costs the loop its 64 registers)
     [[maybe_unused]] auto step_lane = [&]() -> int { int t = tid; asm volatile("" : "+v"(t)); return t & (A.BI - 1); };
     [[maybe_unused]] auto step_atom = [&]() -> int64_t { return (int64_t)b * A.BI + step_lane(); };
-    const T4 pi_raw = A.pos[valid ? si : (int64_t)b * A.BI];
-    T4 pi = pi_raw;
-    if constexpr (NO_TRI) pi = localise(pi, std::false_type{});
-    else pi = tri_local ? localise(pi, std::true_type{}) : localise(pi, std::false_type{});
-    T2 lji = make2<T>(T(0), T(0));
-    if constexpr (PER_ATOM_LJ) lji = A.lj[valid ? si : (int64_t)b * A.BI];
+    // What a lane needs of its own — its record, its row count — is ASKED FOR here and looked at behind the tile's staging (own_ready below).  Looked at here,
+    // each was a memory latency of its own in front of the tile's index loads, which are one in front of the gathers: four dependent round trips of ≈ 2 µs under a
+    // 3 TB/s list stream before a wave walked its first row, during which its block kept a quarter of a compute unit (profiles/r05_force_ab.txt §10).
+    T4 pi_raw;
+    if constexpr (PRUNE || COULM != MHIP_COUL_NONE) pi_raw = A.pos[valid ? si : (int64_t)b * A.BI];
+    else {      // (no charge: three words — the fourth, unused, would be a register the compiler hands out again at once, and the write to it waits for the whole record)
+        const T* own = reinterpret_cast<const T*>(A.pos + (valid ? si : (int64_t)b * A.BI));
+        pi_raw = make4<T>(own[0], own[1], own[2], T(0));
+    }
+    T4 pi;
+    T2 lji_raw = make2<T>(T(0), T(0)), lji = lji_raw;
+    if constexpr (PER_ATOM_LJ) lji_raw = A.lj[valid ? si : (int64_t)b * A.BI];
     // fp32: the tile (and this lane's own record) carries √ϵ, 0 where σ = 0 — GeometricMixing + LJZeroShortcut become one product per pair
     constexpr bool PRE_E = PER_ATOM_LJ && sizeof(T) == 4;
     auto pre_e = [](T2 v) { if constexpr (PRE_E) { v.y = v.x == T(0) ? T(0) : M<T>::sqrt(v.y); v.x *= T(0.5); } return v; };   // (σ/2 as well: LorentzMixing becomes one add, and halving is exact)
-    lji = pre_e(lji);
     // this wave's own sub-list (the j-split was done by k_build); the row count is the same for all 64 lanes: a scalar
-    const int rows = __builtin_amdgcn_readfirstlane(A.wave_rows[(b * A.JS + js) * (A.BI >> 6) + (li >> 6)]);
+    const int rows_lane = A.wave_rows[(b * A.JS + js) * (A.BI >> 6) + (li >> 6)];
+    int rows = 0;
+    bool own_done = false;
+    auto own_ready = [&]() {
+        if (own_done) return;
+        own_done = true;
+        if constexpr (NO_TRI) pi = localise(pi_raw, std::false_type{});
+        else pi = tri_local ? localise(pi_raw, std::true_type{}) : localise(pi_raw, std::false_type{});
+        lji = pre_e(lji_raw);
+        rows = __builtin_amdgcn_readfirstlane(rows_lane);
+    };
+    if constexpr (PRUNE) own_ready();      // (the prune's bounding boxes are made of the block-local coordinates, before the staging)
     const uint2* my_rows = A.nbr + (((int64_t)b * A.JS + js) * A.R_cap) * A.BI + li;
     const int32_t* tix = A.tile_idx + (int64_t)b * A.T_cap;
     T fx = T(0), fy = T(0), fz = T(0), pe = T(0);
@@ -1324,6 +1340,31 @@ k_forces(ForceArgs<T> A) {
         // and round left every round waiting for two memory latencies in a row, 10–20 µs per block at six rounds)
         auto stage = [&](auto tri_tag) {
             constexpr int SB = (FAST_CT && !PRUNE) ? MHIP_SB : 4;
+            // The packed plain pass asks for the first round's tile indices WITHOUT knowing how many there are: tile_cnt[b] is a memory latency away, and a block keeps
+            // its place on the compute unit while it waits (3.3 of the ≈ 20 µs a wave lives, profiles/r05_force_ab.txt §10).  The index loads are bounded by the
+            // tile's capacity instead of its count, the first round runs unconditionally (a tile holds at least the block's own atoms), and the count is first needed
+            // where the gathers are issued: lanes past the end fetch the block's first atom — ONE address, the gathers are what the staging is bound by — and write nothing.
+            if constexpr (FAST_CT && !PRUNE) {
+                auto round = [&](int t0) {
+                    int s[SB]; T4 p[SB];
+#pragma unroll
+                    for (int k = 0; k < SB; ++k) s[k] = tix[min(t0 + k * nthr + tid, A.T_cap - 1)];
+#pragma unroll
+                    for (int k = 0; k < SB; ++k) { s[k] = (t0 + k * nthr + tid < n_here) ? s[k] : (int)((int64_t)b * A.BI); p[k] = A.pos[s[k]]; }
+#pragma unroll
+                    for (int k = 0; k < SB; ++k) {
+                        const int t = t0 + k * nthr + tid;
+                        if (t < n_here) {
+                            const T4 pl = localise(p[k], tri_tag);
+                            if (packed3) { l_p3[t] = (float)pl.x; l_p3[SOA_STRIDE + t] = (float)pl.y; l_p3[2 * SOA_STRIDE + t] = (float)pl.z; }
+                            else l_pos[t] = pl;
+                        }
+                    }
+                };
+                round(0);      // (straight-line code: in front of a loop header the compiler drains every load in flight, the lane's own record among them)
+                for (int t0 = SB * nthr; t0 < n_here; t0 += SB * nthr) round(t0);
+                return;
+            }
             for (int t0 = 0; t0 < n_here; t0 += SB * nthr) {
                 int s[SB]; T4 p[SB]; [[maybe_unused]] T2 q[SB];
                 // rounds of this batch that hold an atom at all (block-uniform; the packed plain pass goes without the test: with it the
@@ -1353,6 +1394,7 @@ k_forces(ForceArgs<T> A) {
         };
         if constexpr (NO_TRI) stage(std::false_type{});
         else { if (tri_local) stage(std::true_type{}); else stage(std::false_type{}); }
+        own_ready();
         if (tid == 0) {   // sentinel: far away (beyond every cutoff), no charge, no LJ
             if (packed3) { l_p3[n_here] = 1e4f; l_p3[SOA_STRIDE + n_here] = 1e4f; l_p3[2 * SOA_STRIDE + n_here] = 1e4f; }
             else l_pos[n_here] = make4<T>(T(1e4), T(1e4), T(1e4), T(0));
@@ -1458,6 +1500,10 @@ k_forces(ForceArgs<T> A) {
                     const uint32_t oa = e4.x & 0xffffu, ob = e4.x >> 16, oc = e4.y & 0xffffu, od = e4.y >> 16;
                     v2f dx0, dy0, dz0, dx1, dy1, dz1;
                     lds3(oa, ob, dx0, dy0, dz0); lds3(oc, od, dx1, dy1, dz1);
+                    // (the row's twelve ds_read_b32 in one run: left to itself the scheduler does that too — until a change somewhere else in the kernel shifts its
+                    // register estimate, and then it waits for the reads pair by pair: +40-65 % per walk, profiles/r05_force_ab.txt §9.  Pinned, the trip's wait pattern
+                    // is the same in every variant)
+                    __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
                     const v2f r20 = __builtin_elementwise_fma(dz0, dz0, __builtin_elementwise_fma(dy0, dy0, dx0 * dx0));
                     const v2f r21 = __builtin_elementwise_fma(dz1, dz1, __builtin_elementwise_fma(dy1, dy1, dx1 * dx1));
                     if constexpr (PRUNE) {   // (no slot test: the sentinel slot — padding, and everything a lane without an atom holds — lies 10⁴ nm away)
@@ -1589,6 +1635,7 @@ k_forces(ForceArgs<T> A) {
         if constexpr (LJM == LJ_DIST_UNIFORM && COULM == MHIP_COUL_NONE && !ENERGY) {
             if (A.any_special) walk_rows(std::true_type{}); else walk_rows(std::false_type{});
         } else walk_rows(std::true_type{});
+        if constexpr (!SEG) break;      // (one piece: said outright, or the compiler keeps a loop — and copies of everything that lives across it — around the whole pass)
     }
     if constexpr (PRUNE) {
         // finish the inner list: pad to the wave's row count; record how far the block's atoms moved since the outer build
