@@ -228,7 +228,7 @@ def make_record(workload, case, dtype, dt, ms_per_step, st, extra, world, args, 
     # is priced by SURVEY §8(d)'s model — every per-atom array touched once per pass — applied to what it does: the force pass's N(R_p + 3w) + 4L without the
     # force write (3w), plus the velocity read (4w) and the coordinate and velocity writes (2·4w): N(R_p + 12w) + 4L.  (The step's B_step = N(R_p + 22w) + 4L
     # stays the yardstick of step_frac below; it counts the force array's round trip, which this launch does not make.)
-    fused = st.get("n_fused_steps", 0) > 0
+    fused = st.get("n_fused_steps", 0) > 0 and workload.startswith("lj")      # (6mrr's steps fuse the integrator into their LAST launch, not into the pair kernel this block is about)
     w_bytes = 4 if dtype == np.float32 else 8
     fbytes = st["force_pass_bytes"] + 9 * w_bytes * n_atoms if fused else st["force_pass_bytes"]
     achieved = fbytes / (force_ms * 1e-3) / 1e9 if force_ms > 0 else None

@@ -207,16 +207,18 @@ constexpr int COLLECT_LANES = 8;
 // for a launch that runs next to another writer of the force array (step_fused.h) and leaves its share in a side array.
 // parts (nullable): n_parts more force arrays, part_stride atoms apart, whose entry of the atom is added in fixed order — the partial pair
 // forces of the group-split pass (forces_gs.hip), folded in by the one launch that visits every atom anyway.
-template <class T, bool ASSIGN>
-__device__ inline void bonded_collect_lane(int64_t gt, int64_t n_owned, const int32_t* __restrict__ orig, const int32_t* __restrict__ role_start, const int32_t* __restrict__ role_slot,
-                                           const typename Vec<T>::T4* __restrict__ slots, typename Vec<T>::T4* out,
-                                           const typename Vec<T>::T4* __restrict__ parts = nullptr, int n_parts = 0, int64_t part_stride = 0) {
+// the slot sums of atom gt / COLLECT_LANES by lane gt % COLLECT_LANES of its group (all COLLECT_LANES lanes of a group call it): the sum — slots in role order,
+// then the group-split pass's partial forces — in the group's lane 0; returns whether this lane is that lane of a live atom
+template <class T>
+__device__ inline bool bonded_collect_sum(int64_t gt, int64_t n_owned, const int32_t* __restrict__ orig, const int32_t* __restrict__ role_start, const int32_t* __restrict__ role_slot,
+                                          const typename Vec<T>::T4* __restrict__ slots, const typename Vec<T>::T4* __restrict__ parts, int n_parts, int64_t part_stride,
+                                          T& fx, T& fy, T& fz, bool& any) {
     const int64_t s = gt / COLLECT_LANES;
     const int l = (int)(gt % COLLECT_LANES);
     const bool live = s < n_owned;
     int r0 = 0, r1 = 0;
     if (live) { const int a = orig[s]; r0 = role_start[a]; r1 = role_start[a + 1]; }
-    T fx = T(0), fy = T(0), fz = T(0);
+    fx = T(0); fy = T(0); fz = T(0);
     // four of a lane's slots per round, their (dependent) fetches issued together — index, then record: an atom of the protein interior has 40 slots, five per
     // lane, and one after the other they were ten memory latencies in the one launch of the step that every atom waits for.  Same order of the adds as before.
     for (int r = r0 + l; r < r1; r += 4 * COLLECT_LANES) {
@@ -239,9 +241,19 @@ __device__ inline void bonded_collect_lane(int64_t gt, int64_t n_owned, const in
             for (int k = 0; k < 4; ++k) if (q0 + k < n_parts) { fx += pv[k].x; fy += pv[k].y; fz += pv[k].z; }
         }
     }
+    any = r1 > r0 || parts;
+    return live && l == 0;
+}
+template <class T, bool ASSIGN>
+__device__ inline void bonded_collect_lane(int64_t gt, int64_t n_owned, const int32_t* __restrict__ orig, const int32_t* __restrict__ role_start, const int32_t* __restrict__ role_slot,
+                                           const typename Vec<T>::T4* __restrict__ slots, typename Vec<T>::T4* out,
+                                           const typename Vec<T>::T4* __restrict__ parts = nullptr, int n_parts = 0, int64_t part_stride = 0) {
+    T fx, fy, fz; bool any;
+    const bool mine = bonded_collect_sum<T>(gt, n_owned, orig, role_start, role_slot, slots, parts, n_parts, part_stride, fx, fy, fz, any);
+    const int64_t s = gt / COLLECT_LANES;
     if constexpr (ASSIGN) {
-        if (live && l == 0) out[s] = make4<T>(fx, fy, fz, T(0));
-    } else if (live && l == 0 && (r1 > r0 || parts)) {
+        if (mine) out[s] = make4<T>(fx, fy, fz, T(0));
+    } else if (mine && any) {
         auto f = out[s];
         f.x += fx; f.y += fy; f.z += fz;
         out[s] = f;

@@ -990,10 +990,15 @@ template <class T> class Engine final : public EngineBase {
                         bonded.ensure_roles(stream, cap);
                         const bool with_spread = fuse_spread_next;
                         const int order = with_spread ? pme.order : 5;
+                        // inside vv_run: the Σ m v partials of the launch before become one partial in an extra workgroup of this launch (the step's last launch reads four words)
+                        const bool gs_cm_fin = cm_fin_on && in_vv_fused && !energy && cm_pending == 2 && n_cm_step > 1 && n_cm_step <= 65536;
+                        if (gs_cm_fin) cm_fin_buf.reserve(4);
                         const size_t lds = (with_spread ? std::max(gs_lds_bytes(q_lds, BI, JS / GS), std::min<size_t>((size_t)MAX_LDS_BYTES / GS, spread_head_bytes_f32(order) + (size_t)PME_BOX_BYTES)) : gs_lds_bytes(q_lds, BI, JS / GS)) & ~(size_t)15;
                         const int n_spread = with_spread ? (int)std::min<int64_t>(cdiv(n_owned, (int64_t)64), 4096) : 0;
                         launch_pair_spread_bonded(Z, n_blocks * GS, coulm, minimg, order, n_owned, reinterpret_cast<float*>(pme.rgrid.p), reinterpret_cast<const PmeP<float>&>(pme.P), n_spread,
-                                                  reinterpret_cast<const BondedArgs<float>&>(static_cast<const BondedArgs<T>&>(bonded.slot_args(G, I, pos[cur].p, inv.p))), cdiv(bonded.n_blocks(), 4), lds, stream);
+                                                  reinterpret_cast<const BondedArgs<float>&>(static_cast<const BondedArgs<T>&>(bonded.slot_args(G, I, pos[cur].p, inv.p))), cdiv(bonded.n_blocks(), 4), lds, stream,
+                                                  gs_cm_fin ? cm_src() : (const double*)nullptr, n_cm_step, gs_cm_fin ? cm_fin_buf.p : (double*)nullptr);
+                        if (gs_cm_fin) { cm_ext = cm_fin_buf.p; n_cm_step = 1; }
                         spread_fused = with_spread; terms_fused = !with_spread;
                     } else launch_forces_gs(Z, coulm, minimg, stream);
                     fuse_spread_next = fuse_terms_next = false;
@@ -1059,7 +1064,7 @@ template <class T> class Engine final : public EngineBase {
         A.blk_center = blk_center.p; A.frc = frc_override ? frc_override : frc[cur].p; A.pe_part = red_part.p;
         // inside vv_run: the Σ m v partials of the integrator launch before this pass become one partial here (kernels.h, cm_finalize_in_block)
         A.cm_fin_in = nullptr; A.cm_fin_n = 0; A.cm_fin_out = nullptr;
-        A.vel = nullptr; A.pos_next = nullptr; A.dt = T(0); A.dt2 = T(0); A.step_touch = 0; A.cm_in = nullptr; A.cm_n = 0; A.cm_pub = nullptr; A.step_seq = 0; A.cm_out = nullptr; A.trk_part = nullptr; A.snap_a = nullptr; A.snap_b = nullptr;
+        A.vel = nullptr; A.pos_next = nullptr; A.dt = T(0); A.dt2 = T(0); A.cm_in = nullptr; A.cm_n = 0; A.cm_pub = nullptr; A.step_seq = 0; A.cm_out = nullptr; A.trk_part = nullptr; A.snap_a = nullptr; A.snap_b = nullptr;
         const bool cm_fin = cm_fin_on && in_vv_fused && !energy && n_ghost == 0 && part == 0 && cm_pending == 2 && n_cm_step > 1 && n_cm_step <= 65536;      // (the energy variants do not carry the sum)
         if (cm_fin) { cm_fin_buf.reserve(4); A.cm_fin_in = cm_src(); A.cm_fin_n = n_cm_step; A.cm_fin_out = cm_fin_buf.p; }
         else if (cm_fin_solo_src && !energy && n_ghost == 0 && part == 0 && !cm_fin_solo_done) {      // (mhip_domain_run on one brick: halo_mid's partials)
@@ -1076,7 +1081,7 @@ template <class T> class Engine final : public EngineBase {
             if (do_step) {
                 pos_alt.reserve(cap); cm_blk.reserve(2 * 4 * (size_t)n_blocks + 8);
                 if (!cm_pub.p) { cm_pub.reserve(4); MHIP_HIP(hipMemsetAsync(cm_pub.p, 0, 4 * sizeof(unsigned long long), stream)); }      // (launch numbers start at 1)
-                A.vel = vel[cur].p; A.pos_next = pos_alt.p; A.dt = T(step_req.dt); A.dt2 = T(step_req.dt) / T(2); A.step_touch = step_touch_env;
+                A.vel = vel[cur].p; A.pos_next = pos_alt.p; A.dt = T(step_req.dt); A.dt2 = T(step_req.dt) / T(2);
                 A.cm_in = cm_pending == 2 ? cm_src() : (const double*)nullptr; A.cm_n = n_cm_step; A.cm_pub = cm_pub.p; A.step_seq = ++step_seq;
                 A.cm_out = step_req.cm ? cm_blk.p + (size_t)step_half * 4 * n_blocks : (double*)nullptr;
                 A.trk_part = nullptr; A.snap_a = pos_snap_in.p; A.snap_b = pos_snap.p;
@@ -1090,7 +1095,7 @@ template <class T> class Engine final : public EngineBase {
             if (do_step) {
                 launch_forces_uniform_f32(A, false, false, lds_force, (unsigned)(BI * JS), stream, true);
                 std::swap(pos[cur].p, pos_alt.p);      // the epilogues wrote the drifted coordinates into the other buffer: it is the current one now
-                step_done = true; ++n_fused_steps;
+                step_done = true; ++n_fused_steps; step_parts = n_blocks;
             } else launch_forces_any(A, energy);
         } else launch_forces_any(A, energy);
         if (cm_fin && !do_step) { cm_ext = cm_fin_buf.p; n_cm_step = 1; }
@@ -1139,11 +1144,13 @@ template <class T> class Engine final : public EngineBase {
     // The fused step of the large one-type fluids inside mhip_vv_run (kernels.h, k_forces STEP): a plain pair pass whose epilogue is the integrator launch — second kick
     // of this step, first kick + drift of the next, into the other position buffer (swapped in behind the launch) — with Σ m v summed and published by the grid's first
     // workgroup.  Asked for by vv_run (step_req), carried out by launch_pair_kernel when the pass is a packed plain one; every other pass keeps pair pass + k_vv_mid.
-    struct StepReq { bool on = false, cm = false, measure = false; double dt = 0; } step_req;
+    // (gcv: the same request for a small system's step, whose last force launch — interpolation + bonded sums — can integrate: step_fused.h, k_gather_collect_vv)
+    struct StepReq { bool on = false, gcv = false, cm = false, measure = false; double dt = 0; } step_req;
     bool step_done = false; int step_half = 0; uint32_t step_seq = 0; int64_t n_fused_steps = 0;
+    int step_parts = 0;      // per-block partials (Σ m v in cm_blk's current half, maxima in trk_part) the fused step left behind
+    const bool fuse_gcv_env = env_int("MOLLYHIP_FUSE_GATHER_VV", 1) != 0;
     DBuf<T4> pos_alt; DBuf<double> cm_blk; DBuf<unsigned long long> cm_pub;
     const bool fuse_step_env = env_int("MOLLYHIP_FUSE_STEP", 1) != 0;
-    const int step_touch_env = std::max(0, env_int("MOLLYHIP_STEP_TOUCH", 4));      // rows before the end of a block's list at which the epilogue's records are read ahead
 
     // the (block, group) items of the group-split pass handed to its workgroups so that every compute unit gets a like share of rows (forces_gs.hip, k_gs_balance)
     DBuf<uint16_t> gs_item; const bool gs_balance_on = env_int("MOLLYHIP_GS_BALANCE", 1) != 0; int cu_count = 0;
@@ -1361,9 +1368,23 @@ template <class T> class Engine final : public EngineBase {
         // small systems: charge spreading next to the bonded terms, force interpolation next to the bonded sums (step_fused.h)
         if (!overlap && fuse_small && bonded.any() && pme.on() && !Bonded<T>::use_atomics() && n_ghost == 0) {
             frc_side[0].reserve(cap);
+            // … and, on a mid-run step of vv_run, the integrator in that last launch (v_cm of the step before as ONE partial, or none pending)
+            GcvArgs<T> V; const GcvArgs<T>* vp = nullptr;
+            if (step_req.gcv && fuse_gcv_env && !redo && (cm_pending == 0 || (cm_pending == 2 && n_cm_step == 1)) && pme.order >= 4 && pme.order <= 6) {
+                const int nb = (int)Pme<T>::atom_blocks(n_owned);
+                cm_blk.reserve(2 * 4 * (size_t)nb + 8);
+                if (step_req.measure) { trk_part.reserve(3 * (size_t)std::max(nb, 1024)); trk_out.reserve(4); }
+                std::memset(&V, 0, sizeof(V));
+                V.vel = vel[cur].p; V.dt = T(step_req.dt); V.dt2 = T(step_req.dt) / T(2); V.G = G;
+                V.cm_in = cm_pending == 2 ? cm_src() : (const double*)nullptr;
+                V.cm_out = step_req.cm ? cm_blk.p + (size_t)step_half * 4 * nb : (double*)nullptr;
+                V.snap_a = pos_snap_in.p; V.snap_b = pos_snap.p; V.trk_part = step_req.measure ? trk_part.p : (float*)nullptr;
+                vp = &V; step_parts = nb;
+            }
             prof.begin(6, stream);
-            launch_pme_bonded_fused<T>(stream, pme, bonded, G, I, n_owned, cap, pos[cur].p, inv.p, orig[cur].p, frc[cur].p, frc_side[0].p, false, spread_fused);
+            launch_pme_bonded_fused<T>(stream, pme, bonded, G, I, n_owned, cap, pos[cur].p, inv.p, orig[cur].p, frc[cur].p, frc_side[0].p, false, spread_fused, vp);
             prof.end(6, stream);
+            if (vp) { step_done = true; ++n_fused_steps; pend_a = nullptr; frc_valid = false; return; }
             pend_a = frc_side[0].p;
             frc_valid = true;
             return;
@@ -2450,20 +2471,22 @@ template <class T> class Engine final : public EngineBase {
             // the validity check of step + 1 is measured where its coordinates are made: by this step's integrator launch — or by the pair pass itself when it integrates
             const bool measure = step != last && async_ok() && !trk_issued && check_due(step + 1, every);
             step_req.on = step != last && !bonded.any() && !pme.on(); step_req.cm = cm;      // (one kernel either way: its stage time is its own, so the stage timers leave it fused)
-             step_req.measure = measure; step_req.dt = dt;
+            step_req.gcv = step != last && bonded.any() && pme.on() && (pre || !check_due(step, every));      // (a re-sort behind the pass would want the total force array)
+            step_req.measure = measure; step_req.dt = dt;
+            step_done = false;
             step_forces(step);
-            step_req.on = false;
+            step_req.on = step_req.gcv = false;
             if (step_done) {      // the pair pass integrated on the way (k_forces STEP): no integrator launch for this step
                 step_done = false;
                 if (measure) {
                     if (!h_trk) MHIP_HIP(hipHostMalloc((void**)&h_trk, 4 * sizeof(float)));
                     if (!ev_trk) MHIP_HIP(hipEventCreateWithFlags(&ev_trk, hipEventDisableTiming));
-                    hipLaunchKernelGGL(k_track_reduce, dim3(1), dim3(256), 0, stream, n_blocks, (const float*)trk_part.p, trk_out.p, h_trk);
+                    hipLaunchKernelGGL(k_track_reduce, dim3(1), dim3(256), 0, stream, step_parts, (const float*)trk_part.p, trk_out.p, h_trk);
                     MHIP_HIP(hipEventRecord(ev_trk, stream));
                     trk_issued = true; trk_step = step + 1; trk_prev_vmax = last_vmax; trk_prune_id = n_filters; trk_outer_id = n_outer;
                 }
                 pend_a = pend_b = nullptr; cm_pending = 0; cm_ext = nullptr;
-                if (cm) { cm_pending = 2; cm_ext = cm_blk.p + (size_t)step_half * 4 * n_blocks; n_cm_step = n_blocks; step_half ^= 1; }
+                if (cm) { cm_pending = 2; cm_ext = cm_blk.p + (size_t)step_half * 4 * step_parts; n_cm_step = step_parts; step_half ^= 1; }
                 frc_valid = false;
                 continue;
             }

@@ -290,7 +290,8 @@ __global__ void __launch_bounds__(256, 4) k_forces_gs(GsArgs A) {     // (four w
 // tile quarter, so the spreading and the terms run through that phase instead of queueing behind the pair groups for a free slot.
 // Every role carves its LDS from the launch's dynamic pool (the spreading: its tables and whatever is left as the sub-mesh).
 template <int COULM, bool MINIMG, int ORDER>
-__global__ void __launch_bounds__(256, 4) k_pair_spread_bonded(GsArgs A, int n_pair, int64_t n_atoms, float* rgrid, PmeP<float> P, int n_spread, int lds_bytes, BondedArgs<float> B, int short_first) {
+__global__ void __launch_bounds__(256, 4) k_pair_spread_bonded(GsArgs A, int n_pair, int64_t n_atoms, float* rgrid, PmeP<float> P, int n_spread, int lds_bytes, BondedArgs<float> B, int short_first,
+                                                               int n_term_wg, const double* cm_fin_in, int cm_fin_n, double* cm_fin_out) {
     extern __shared__ __align__(32) unsigned char smem[];
     int wg = (int)blockIdx.x;
     if (short_first) {      // the short jobs at the head of the grid: they start with the pair groups and run through those groups' staging phase
@@ -299,6 +300,9 @@ __global__ void __launch_bounds__(256, 4) k_pair_spread_bonded(GsArgs A, int n_p
     }
     if (wg < n_pair) { forces_gs_body<COULM, MINIMG>(A, wg, smem); return; }
     if (wg < n_pair + n_spread) { pme_spread_blocks<float, ORDER, 64, true>(wg - n_pair, n_spread, n_atoms, A.pos, rgrid, P, smem, lds_bytes); return; }
+    // one more workgroup (cm_fin_in != nullptr): the Σ m v partials of the integrator launch before this step become ONE partial here (cm_finalize_in_block: the
+    // summation of block_vcm, by a 256-lane workgroup as there), so that the step's last launch — which integrates, step_fused.h — reads four words instead of re-summing
+    if (wg >= n_pair + n_spread + n_term_wg) { if (cm_fin_in) cm_finalize_in_block(cm_fin_in, cm_fin_n, cm_fin_out, smem); return; }
     double e = 0;
     bonded_terms<float, false, true>(B, (wg - n_pair - n_spread) * 4 + (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), 64, e);   // four 64-lane term blocks per workgroup
 }
@@ -329,12 +333,12 @@ void launch_forces_gs(const GsArgs& A, int coulm, bool minimg, hipStream_t strea
 
 // the fused form: pair groups + spreading + bonded terms; lds_bytes >= the pair groups' need and the spreading's head + a useful sub-mesh
 void launch_pair_spread_bonded(const GsArgs& A, int n_pair, int coulm, bool minimg, int order, int64_t n_atoms, float* rgrid, const PmeP<float>& P, int n_spread, const BondedArgs<float>& B, int n_term_wg,
-                               size_t lds_bytes, hipStream_t stream) {
-    const dim3 grid((unsigned)(n_pair + n_spread + n_term_wg)), block(256);
+                               size_t lds_bytes, hipStream_t stream, const double* cm_fin_in, int cm_fin_n, double* cm_fin_out) {
+    const dim3 grid((unsigned)(n_pair + n_spread + n_term_wg + (cm_fin_in ? 1 : 0))), block(256);
     auto go = [&](auto kern) {
         if (lds_bytes > 64 * 1024) MHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         static const int short_first = [] { const char* v = std::getenv("MOLLYHIP_GS_SHORT_FIRST"); return v && *v ? std::atoi(v) : 1; }();      // (measured: 26.4 -> 25.8 us per launch, profiles/r04_force_ab.txt §16)
-        hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, A, n_pair, n_atoms, rgrid, P, n_spread, (int)lds_bytes, B, short_first);
+        hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, A, n_pair, n_atoms, rgrid, P, n_spread, (int)lds_bytes, B, short_first, n_term_wg, cm_fin_in, cm_fin_n, cm_fin_out);
     };
     auto by_order = [&](auto coul_tag, auto mi_tag) {
         constexpr int C = decltype(coul_tag)::value; constexpr bool M = decltype(mi_tag)::value;

@@ -34,7 +34,7 @@ void launch_gs_balance(const int32_t* rows_gs, int n_blocks, int JS, int GS, int
 void launch_forces_gs(const GsArgs& A, int coulm, bool minimg, hipStream_t stream);
 template <class T> struct PmeP; template <class T> struct BondedArgs;
 void launch_pair_spread_bonded(const GsArgs& A, int n_pair, int coulm, bool minimg, int order, int64_t n_atoms, float* rgrid, const PmeP<float>& P, int n_spread, const BondedArgs<float>& B, int n_term_wg,
-                               size_t lds_bytes, hipStream_t stream);
+                               size_t lds_bytes, hipStream_t stream, const double* cm_fin_in = nullptr, int cm_fin_n = 0, double* cm_fin_out = nullptr);
 size_t spread_head_bytes_f32(int order);
 
 }  // namespace mhip

@@ -1108,7 +1108,7 @@ template <class T> struct ForceArgs {
     // this step's positions for its tile); no force array is written.  cm_in / cm_n: Σ m v partials of the launch before, summed and published as v_cm by an extra
     // workgroup at the head of the grid (step_cm_publish), subtracted here one launch late as in k_vv_mid; cm_out: this launch's partials, one per block (nullable);
     // trk_part: per-block maxima for the validity check of the pair lists (nullable), against snap_a / snap_b.
-    typename Vec<T>::T4* vel; typename Vec<T>::T4* pos_next; T dt, dt2; int step_touch;
+    typename Vec<T>::T4* vel; typename Vec<T>::T4* pos_next; T dt, dt2;
     const double* cm_in; int cm_n; unsigned long long* cm_pub; uint32_t step_seq; double* cm_out;
     float* trk_part; const typename Vec<T>::T4* snap_a; const typename Vec<T>::T4* snap_b;
 };

@@ -71,9 +71,9 @@ constexpr int PME_AB = 16;       // atoms per block and round of the gather kern
 // serial and identical for every mesh point of the atom) and parks first index, charge and the 3·ORDER weights (and
 // derivatives) in LDS, [value][atom] so that both the writes (lanes = atoms) and the later reads are conflict-free.
 template <class T, int ORDER, bool DERIV>
-__device__ inline void pme_atom_tables(int64_t a0, int64_t n_atoms, const typename Vec<T>::T4* __restrict__ pos, const PmeP<T>& P, T* l_w, int* l_i, T* l_q) {
-    const int t = threadIdx.x;
-    if (t < PME_AB) {
+__device__ inline void pme_atom_tables(int64_t a0, int64_t n_atoms, const typename Vec<T>::T4* __restrict__ pos, const PmeP<T>& P, T* l_w, int* l_i, T* l_q, int first_lane = 0) {
+    const int t = (int)threadIdx.x - first_lane;      // (first_lane: which lanes of the workgroup make the tables — the first PME_AB unless those are busy with something else)
+    if (t >= 0 && t < PME_AB) {
         const int64_t a = a0 + t;
         T q = T(0); int i0[3] = {0, 0, 0};
         T th[ORDER], dth[ORDER], dr;
@@ -255,6 +255,43 @@ __global__ void __launch_bounds__(256) k_pme_spread(int64_t n_atoms, const typen
 // interpolate_force_inner! (:805-840): Fs[i] -= q (∂θ/∂r ⊗ θ ⊗ θ) · φ, same two phases, shuffle reduction inside the half-wave
 // STORE: the reciprocal-space force of EVERY atom is written to frc (zero for an uncharged one) instead of being added to what is there —
 // for the chain that runs beside the pair kernel on a stream of its own and must not touch the array that kernel writes
+// one atom of a staged batch by one 32-lane half-wave (lane ↔ (iy, iz), loop over ix): the force per unit charge, the same value in every lane of the half
+template <class T, int ORDER>
+__device__ inline void pme_gather_one(int t, int sub, T q, const T* l_w, const int* l_i, const T* __restrict__ grid, const PmeP<T>& P, T& sx, T& sy, T& sz) {
+    const int i0x = l_i[t], i0y = l_i[PME_AB + t], i0z = l_i[2 * PME_AB + t];
+    T fx = T(0), fy = T(0), fz = T(0);
+    if (q != T(0)) {
+        for (int pr = sub; pr < ORDER * ORDER; pr += 32) {
+            const int iy = pr / ORDER, iz = pr - iy * ORDER;
+            int yi = i0y + iy; yi -= yi >= P.n[1] ? P.n[1] : 0;
+            int zi = i0z + iz; zi -= zi >= P.n[2] ? P.n[2] : 0;
+            const T ty = l_w[((ORDER + iy) * 2) * PME_AB + t], dty = l_w[((ORDER + iy) * 2 + 1) * PME_AB + t];
+            const T tz = l_w[((2 * ORDER + iz) * 2) * PME_AB + t], dtz = l_w[((2 * ORDER + iz) * 2 + 1) * PME_AB + t];
+            const T tyz = ty * tz, dty_tz = dty * tz, ty_dtz = ty * dtz;
+            const auto* col = grid + (int64_t)yi * P.n[2] + zi;
+            T g[ORDER];
+#pragma unroll
+            for (int ix = 0; ix < ORDER; ++ix) {
+                int xi = i0x + ix; xi -= xi >= P.n[0] ? P.n[0] : 0;
+                g[ix] = col[(int64_t)xi * P.n[1] * P.n[2]];
+            }
+#pragma unroll
+            for (int ix = 0; ix < ORDER; ++ix) {
+                const T tx = l_w[(ix * 2) * PME_AB + t], dtx = l_w[(ix * 2 + 1) * PME_AB + t];
+                fx += dtx * tyz * g[ix]; fy += tx * dty_tz * g[ix]; fz += tx * ty_dtz * g[ix];
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { fx += __shfl_xor(fx, o, 64); fy += __shfl_xor(fy, o, 64); fz += __shfl_xor(fz, o, 64); }   // stays inside the 32-lane half
+    // mesh derivatives → Cartesian force per unit charge: (fx·nx, fy·ny, fz·nz) · recip_box (:846-849)
+    sx = fx * P.n_over_L[0]; sy = fy * P.n_over_L[1]; sz = fz * P.n_over_L[2];
+    if (P.tri) {
+        const T gx = fx * T(P.n[0]), gy = fy * T(P.n[1]), gz = fz * T(P.n[2]);
+        sx = gx * P.r[0][0]; sy = gx * P.r[1][0] + gy * P.r[1][1]; sz = gx * P.r[2][0] + gy * P.r[2][1] + gz * P.r[2][2];
+    }
+}
+
 template <class T, int ORDER, bool STORE = false>
 __device__ inline void pme_gather_blocks(int bid, int nblk, int64_t n_atoms, const typename Vec<T>::T4* __restrict__ pos, const T* __restrict__ grid,
                                          typename Vec<T>::T4* frc, const PmeP<T>& P) {
@@ -266,38 +303,8 @@ __device__ inline void pme_gather_blocks(int bid, int nblk, int64_t n_atoms, con
         __syncthreads();
         for (int t = hw; t < PME_AB; t += 8) {                          // both halves of a wave run all 8 rounds (shuffles)
             const T q = l_q[t];
-            const int i0x = l_i[t], i0y = l_i[PME_AB + t], i0z = l_i[2 * PME_AB + t];
-            T fx = T(0), fy = T(0), fz = T(0);
-            if (q != T(0)) {
-                for (int pr = sub; pr < ORDER * ORDER; pr += 32) {
-                    const int iy = pr / ORDER, iz = pr - iy * ORDER;
-                    int yi = i0y + iy; yi -= yi >= P.n[1] ? P.n[1] : 0;
-                    int zi = i0z + iz; zi -= zi >= P.n[2] ? P.n[2] : 0;
-                    const T ty = l_w[((ORDER + iy) * 2) * PME_AB + t], dty = l_w[((ORDER + iy) * 2 + 1) * PME_AB + t];
-                    const T tz = l_w[((2 * ORDER + iz) * 2) * PME_AB + t], dtz = l_w[((2 * ORDER + iz) * 2 + 1) * PME_AB + t];
-                    const T tyz = ty * tz, dty_tz = dty * tz, ty_dtz = ty * dtz;
-                    const auto* col = grid + (int64_t)yi * P.n[2] + zi;
-                    T g[ORDER];
-#pragma unroll
-                    for (int ix = 0; ix < ORDER; ++ix) {
-                        int xi = i0x + ix; xi -= xi >= P.n[0] ? P.n[0] : 0;
-                        g[ix] = col[(int64_t)xi * P.n[1] * P.n[2]];
-                    }
-#pragma unroll
-                    for (int ix = 0; ix < ORDER; ++ix) {
-                        const T tx = l_w[(ix * 2) * PME_AB + t], dtx = l_w[(ix * 2 + 1) * PME_AB + t];
-                        fx += dtx * tyz * g[ix]; fy += tx * dty_tz * g[ix]; fz += tx * ty_dtz * g[ix];
-                    }
-                }
-            }
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) { fx += __shfl_xor(fx, o, 64); fy += __shfl_xor(fy, o, 64); fz += __shfl_xor(fz, o, 64); }   // stays inside the 32-lane half
-            // mesh derivatives → Cartesian force per unit charge: (fx·nx, fy·ny, fz·nz) · recip_box (:846-849)
-            T sx = fx * P.n_over_L[0], sy = fy * P.n_over_L[1], sz = fz * P.n_over_L[2];
-            if (P.tri) {
-                const T gx = fx * T(P.n[0]), gy = fy * T(P.n[1]), gz = fz * T(P.n[2]);
-                sx = gx * P.r[0][0]; sy = gx * P.r[1][0] + gy * P.r[1][1]; sz = gx * P.r[2][0] + gy * P.r[2][1] + gz * P.r[2][2];
-            }
+            T sx, sy, sz;
+            pme_gather_one<T, ORDER>(t, sub, q, l_w, l_i, grid, P, sx, sy, sz);
             if constexpr (STORE) {
                 if (sub == 0 && a0 + t < n_atoms) frc[a0 + t] = make4<T>(-(q * sx), -(q * sy), -(q * sz), T(0));
             } else if (sub == 0 && q != T(0)) {

@@ -183,3 +183,24 @@ def test_calls_behind_a_run_that_adopted_its_outer_list(pkg, monkeypatch):
     keys, n_special = S.export_keys(pkg, s)
     oi, oj, osp = case.oracle(np.float32, coords=x).neighbors("cell", nthreads=8)
     assert np.array_equal(keys, S.pair_keys(oi, oj)) and n_special == int(np.asarray(osp).sum())
+
+
+@pytest.mark.parametrize("remove_cm", [1, 0])
+def test_integrator_inside_the_last_force_launch_is_the_same_run(pkg, monkeypatch, remove_cm):
+    """Mid-run steps of the complete PME configuration integrate inside their last force launch (step_fused.h, k_gather_collect_vv: interpolation + bonded sums +
+    velocity Verlet, v_cm from the one partial the pair launch's extra workgroup leaves) instead of k_gather_collect + k_vv_mid.  Same sums in the same order, same
+    integrator helpers: 40 steps of 0.5 fs across two rebuilds agree with the two-launch form (MOLLYHIP_FUSE_GATHER_VV=0) to fp32 round-off — not bit for bit only
+    because the charge mesh is flushed with float atomics, which no two runs of either form repeat."""
+    def run(fuse):
+        monkeypatch.setenv("MOLLYHIP_FUSE_GATHER_VV", fuse)
+        case = G.case("ewald", np.float32, bonded=True, pme=True)
+        s = case.system(pkg, np.float32)
+        sim = pkg.VelocityVerlet(dt=0.0005, remove_CM_motion=remove_cm)
+        pkg.simulate(s, sim, 25)
+        pkg.simulate(s, sim, 15, init_step=25)
+        return np.array(s.coords, dtype=np.float64), np.array(s.velocities, dtype=np.float64), s.stats()
+    x1, v1, st1 = run("1")
+    x0, v0, st0 = run("0")
+    assert st1["n_fused_steps"] >= 30 and st0["n_fused_steps"] == 0, (st1["n_fused_steps"], st0["n_fused_steps"])
+    d = x1 - x0; d -= np.round(d / G.data()["box"]) * G.data()["box"]
+    assert np.abs(d).max() < 4e-6 and np.abs(v1 - v0).max() < 4e-3, (np.abs(d).max(), np.abs(v1 - v0).max())
