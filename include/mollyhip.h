@@ -137,8 +137,8 @@ typedef struct mhip_stats {
     int64_t n_group_split_passes;  /* plain force passes that ran as the group-split launch of small systems (csrc/forces_gs.hip) */
     int32_t group_split;           /* groups per block of that launch (0: not in use for this system)                             */
     int32_t n_adopted_outer_lists; /* rebuilds whose outer list became the inner list without a pruning pass (nothing to prune: inner radius = r_list) */
-    int64_t n_fused_steps;         /* steps of mhip_vv_run whose pair pass also integrated (k_forces STEP: second kick, first kick + drift in the epilogue;
-                                      fp32 one-type fluids): such a launch carries the whole step's algorithmic bytes */
+    int64_t n_fused_steps;         /* steps of mhip_vv_run without an integrator launch: the pair pass integrated in its epilogue (k_forces STEP, fp32 one-type
+                                      fluids) or, with bonded terms and PME, the step's last force launch did (k_gather_collect_vv) */
 } mhip_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
