@@ -1,7 +1,8 @@
 """Structural properties of the hot kernel that its speed depends on, checked on the compiler's output (no GPU needed: hipcc
-cross-compiles gfx950).  The packed one-type LJ loop runs four 512-lane blocks per CU only while it stays within 64 VGPRs, and it must
-not touch scratch: a spill instruction moves 512 bytes per wave, and 36 bytes of scratch per lane measured +10 % on the 1M-atom
-force pass."""
+cross-compiles gfx950).  The packed one-type LJ loop runs four 512-lane blocks per CU only while it stays within 64 VGPRs; it must
+not EXECUTE a spill anywhere (a reload is a memory round trip on the critical path of a wave that lives 20 µs: 10-25 % per pass with
+13 spill instructions outside every loop, profiles/r05_force_ab.txt §10), and its row loop must keep its wait pattern (§9: the same
+instructions re-scheduled around lgkmcnt(0) walked the rows 40-65 % slower)."""
 import os
 import re
 import shutil
