@@ -240,7 +240,7 @@ def test_terms_added_between_two_runs_count_from_the_first_step(pkg):
 
 
 
-@pytest.mark.parametrize("remove_cm", [0, 1])
+@pytest.mark.parametrize("remove_cm", [0, 1, 3])
 def test_fused_step_repeats_the_separate_integrator_bit_for_bit(pkg, remove_cm, monkeypatch):
     """Inside mhip_vv_run the plain pair passes of the fp32 one-type fluids integrate in their own epilogue (kernels.h, the STEP variants: no force array, no
     integrator launch).  Same arithmetic, same order of the Σ m v partial sums (row sums by DPP in the association of the integrator kernels' butterfly), the
