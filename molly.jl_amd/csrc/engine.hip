@@ -1094,7 +1094,7 @@ template <class T> class Engine final : public EngineBase {
         if constexpr (std::is_same<T, float>::value) {
             if (do_step) {
                 launch_forces_uniform_f32(A, false, false, lds_force, (unsigned)(BI * JS), stream, true);
-                std::swap(pos[cur].p, pos_alt.p);      // the epilogues wrote the drifted coordinates into the other buffer: it is the current one now
+                std::swap(pos[cur].p, pos_alt.p); std::swap(pos[cur].n, pos_alt.n);      // the epilogues wrote the drifted coordinates into the other buffer: it is the current one now
                 step_done = true; ++n_fused_steps; step_parts = n_blocks;
             } else launch_forces_any(A, energy);
         } else launch_forces_any(A, energy);
