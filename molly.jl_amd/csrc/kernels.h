@@ -825,9 +825,30 @@ __global__ void k_uniform_check(int64_t n, const T* __restrict__ sig, const T* _
                                                                                 const float* __restrict__ blk_disp2, int32_t* flags, int32_t* host_flags) {
     __shared__ int sh_t[16], sh_r[16], sh_s[16]; __shared__ float sh_d[16];
     int mt = 0, mr = 0, tot = 0; float md = 0.f;
-    for (int q = threadIdx.x; q < n_blocks; q += blockDim.x) mt = max(mt, tile_cnt[q]);
-    for (int q = threadIdx.x; q < n_disp; q += blockDim.x) md = fmaxf(md, blk_disp2[q]);
-    for (int q = threadIdx.x; q < n_waves; q += blockDim.x) { const int r = wave_rows[q]; mr = max(mr, r); if (r > R_cap) wave_rows[q] = 0; else tot += r; }
+    // (eight loads in flight per lane: one workgroup reads 50 000 words at a 1M-atom prune, and one load per trip was 52 memory latencies in a row — 25 µs)
+    constexpr int U = 8;
+    const int nt = (int)blockDim.x, t0 = (int)threadIdx.x;
+    for (int q = t0; q < n_blocks; q += U * nt) {
+        int v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) v[k] = tile_cnt[min(q + k * nt, n_blocks - 1)];
+#pragma unroll
+        for (int k = 0; k < U; ++k) mt = max(mt, v[k]);
+    }
+    for (int q = t0; q < n_disp; q += U * nt) {
+        float v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) v[k] = blk_disp2[min(q + k * nt, n_disp - 1)];
+#pragma unroll
+        for (int k = 0; k < U; ++k) md = fmaxf(md, v[k]);
+    }
+    for (int q = t0; q < n_waves; q += U * nt) {
+        int v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) v[k] = q + k * nt < n_waves ? wave_rows[q + k * nt] : 0;
+#pragma unroll
+        for (int k = 0; k < U; ++k) { const int r = v[k]; mr = max(mr, r); if (r > R_cap) wave_rows[q + k * nt] = 0; else tot += r; }      // (a slot past the end reads as 0 rows: neither branch does anything)
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { mt = max(mt, __shfl_xor(mt, o, 64)); mr = max(mr, __shfl_xor(mr, o, 64)); tot += __shfl_xor(tot, o, 64); md = fmaxf(md, __shfl_xor(md, o, 64)); }
     if ((threadIdx.x & 63) == 0) { sh_t[threadIdx.x >> 6] = mt; sh_r[threadIdx.x >> 6] = mr; sh_s[threadIdx.x >> 6] = tot; sh_d[threadIdx.x >> 6] = md; }
