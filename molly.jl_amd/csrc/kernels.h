@@ -811,7 +811,15 @@ __global__ void k_uniform_check(int64_t n, const T* __restrict__ sig, const T* _
 // (host: pinned host memory, nullable — the host reads it behind an event, no copy kernel in between)
 [[maybe_unused]] static __global__ void k_track_reduce(int n, const float* __restrict__ part, float* out, float* host = nullptr) {
     float m[3] = {0.f, 0.f, 0.f};
-    for (int q = threadIdx.x; q < n; q += blockDim.x) { m[0] = fmaxf(m[0], part[q]); m[1] = fmaxf(m[1], part[n + q]); m[2] = fmaxf(m[2], part[2 * n + q]); }
+    constexpr int U = 4;      // (twelve loads in flight per lane: 4 096 partials by 256 lanes were sixteen memory latencies in a row)
+    const int nt = (int)blockDim.x;
+    for (int q = threadIdx.x; q < n; q += U * nt) {
+        float v[3][U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) { const int i = min(q + k * nt, n - 1); v[0][k] = part[i]; v[1][k] = part[n + i]; v[2][k] = part[2 * n + i]; }
+#pragma unroll
+        for (int k = 0; k < U; ++k) { m[0] = fmaxf(m[0], v[0][k]); m[1] = fmaxf(m[1], v[1][k]); m[2] = fmaxf(m[2], v[2][k]); }
+    }
     __shared__ float sh[3][16];
     for (int c = 0; c < 3; ++c) { m[c] = wave_max(m[c]); if ((threadIdx.x & 63) == 0) sh[c][threadIdx.x >> 6] = m[c]; }
     __syncthreads();
