@@ -1,5 +1,5 @@
 """Timeline of one MD step from a rocprofv3 kernel trace (--kernel-trace --output-format csv): for every kernel between two consecutive
-integrator launches the median start offset, duration and the gap to the kernel before it.   python tools/step_timeline.py <kernel_trace.csv>"""
+integrating launches the median start offset, duration and the gap to the kernel before it.   python tools/step_timeline.py <kernel_trace.csv>"""
 import csv
 import re
 import statistics as st
@@ -12,7 +12,8 @@ short = lambda n: re.sub(r"^void |mhip::|\(.*$|<.*$", "", n)[:28]
 steps, cur = [], []
 for r in rows:
     cur.append((short(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
-    if "k_vv_mid" in r["Kernel_Name"]:
+    # a step ends with the launch that integrates: k_vv_mid, or — round 5 — the last force launch of a small system (k_gather_collect_vv) / the pair pass of a large fluid (STEP)
+    if "k_vv_mid" in r["Kernel_Name"] or "k_gather_collect_vv" in r["Kernel_Name"] or re.search(r"k_forces<float, 3, 0, false, false, false, false, \d+, true>", r["Kernel_Name"]):
         steps.append(cur); cur = []
 shape = Counter(tuple(k[0] for k in s) for s in steps).most_common(1)[0][0]      # the most common step shape
 sel = [s for s in steps if tuple(k[0] for k in s) == shape][5:]
