@@ -421,17 +421,25 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
     // a stored position → loc: Cartesian coordinates relative to the block centre, nearest periodic image (the tile, the search);
     // ub: the same point in the frame of the wave boxes, relative to the centre (cubic: the same numbers; triclinic grid: u)
     const T cfrac[3] = {G.tri_grid ? ctr[0] / G.hgt[0] : T(0), G.tri_grid ? ctr[1] / G.hgt[1] : T(0), G.tri_grid ? ctr[2] / G.hgt[2] : T(0)};
-    auto localise3 = [&](T x, T y, T z, T loc[3], T ub[3]) {
+    // (six scalars out, no arrays through pointers: with `T loc[3], T ub[3]` the two branches' stores were merged into stores through a pointer chosen at run
+    // time, and the arrays lived in scratch — a store → load round trip per staged atom)
+    struct Loc3 { T l0, l1, l2, u0, u1, u2; };
+    auto localise3 = [&](T x, T y, T z) -> Loc3 {
+        Loc3 r;
         if (G.tri_grid) {
-            T sf[3], fd[3]; frac_coords(x, y, z, G, sf);
-#pragma unroll
-            for (int d = 0; d < 3; ++d) { T t = sf[d] - cfrac[d]; t -= M<T>::rint(t); fd[d] = t; ub[d] = t * G.hgt[d]; }
-            loc[0] = fd[0] * G.bv[0][0] + fd[1] * G.bv[1][0] + fd[2] * G.bv[2][0]; loc[1] = fd[1] * G.bv[1][1] + fd[2] * G.bv[2][1]; loc[2] = fd[2] * G.bv[2][2];
+            T sf[3]; frac_coords(x, y, z, G, sf);
+            T f0 = sf[0] - cfrac[0]; f0 -= M<T>::rint(f0);
+            T f1 = sf[1] - cfrac[1]; f1 -= M<T>::rint(f1);
+            T f2 = sf[2] - cfrac[2]; f2 -= M<T>::rint(f2);
+            r.u0 = f0 * G.hgt[0]; r.u1 = f1 * G.hgt[1]; r.u2 = f2 * G.hgt[2];
+            r.l0 = f0 * G.bv[0][0] + f1 * G.bv[1][0] + f2 * G.bv[2][0]; r.l1 = f1 * G.bv[1][1] + f2 * G.bv[2][1]; r.l2 = f2 * G.bv[2][2];
         } else {
-            const T xyz[3] = {x, y, z};
-#pragma unroll
-            for (int d = 0; d < 3; ++d) { T t = xyz[d] - ctr[d]; if (G.periodic[d]) t -= G.L[d] * M<T>::rint(t * G.invL[d]); loc[d] = t; ub[d] = t; }
+            T t0 = x - ctr[0]; if (G.periodic[0]) t0 -= G.L[0] * M<T>::rint(t0 * G.invL[0]);
+            T t1 = y - ctr[1]; if (G.periodic[1]) t1 -= G.L[1] * M<T>::rint(t1 * G.invL[1]);
+            T t2 = z - ctr[2]; if (G.periodic[2]) t2 -= G.L[2] * M<T>::rint(t2 * G.invL[2]);
+            r.l0 = r.u0 = t0; r.l1 = r.u1 = t1; r.l2 = r.u2 = t2;
         }
+        return r;
     };
     // squared distance from a point (frame of the boxes) to the nearest per-wave bounding box ("full" axes never prune).  On a triclinic
     // grid the axes of that frame are not orthogonal: each |Δu_d| is a lower bound of the distance on its own, so the test is the
@@ -512,10 +520,10 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
 #pragma unroll
         for (int u = 0; u < SUB; ++u) {
             if (base + u * nthr + tid < nraw) {
-                T loc[3], ub[3]; localise3(p[u].x, p[u].y, p[u].z, loc, ub);
+                const Loc3 lc = localise3(p[u].x, p[u].y, p[u].z);
                 // exact_only blocks (small boxes): images are ambiguous, keep the whole cell-pruned set
-                keep[u] = exact_only ? true : sub_dist2(ub[0], ub[1], ub[2]) <= reach2;
-                p[u].x = loc[0]; p[u].y = loc[1]; p[u].z = loc[2];
+                keep[u] = exact_only ? true : sub_dist2(lc.u0, lc.u1, lc.u2) <= reach2;
+                p[u].x = lc.l0; p[u].y = lc.l1; p[u].z = lc.l2;
             }
             const unsigned long long m = __ballot(keep[u]);
             if (lane == 0) s_wtot[u * NW_ALL + wv_all] = __popcll(m);
@@ -616,8 +624,8 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
 #if MHIP_STAMPS
         if (A.dbg) { int x = nxl; for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, WAVE); if (lane == 0) A.dbg[((size_t)b * NW_ALL + wv_all) * 8 + 6] = (unsigned long long)x; }
 #endif
-        T my_loc[3], my_ub[3]; localise3(my[0], my[1], my[2], my_loc, my_ub);
-        const float ml[3] = {(float)my_loc[0], (float)my_loc[1], (float)my_loc[2]};
+        const Loc3 my_lc = localise3(my[0], my[1], my[2]);
+        const float ml[3] = {(float)my_lc.l0, (float)my_lc.l1, (float)my_lc.l2};
         const float rl2 = G.no_list ? 3.0e38f : (float)G.r_list2;
         const float band_lo = rl2 * (1.0f - 1e-4f), band_hi = G.no_list ? 3.0e38f : rl2 * (1.0f + 1e-4f);
         const float reach2f = G.no_list ? 3.0e38f : (float)reach2;
