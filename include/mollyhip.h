@@ -31,6 +31,24 @@
  * pointer is host or device (gfx950 HBM) memory.  A context is NOT thread-safe: one host thread
  * drives it (as Julia does for one System).  The context owns all device memory it allocates;
  * the caller owns every pointer it passes and may free it when the call returns.
+ *
+ * Environment (read when a context is created; the defaults are the product, every value below is exercised by a test of tests/):
+ *   MOLLYHIP_DEBUG=1               list-maintenance decisions (searches, prunes, skin changes) on stderr
+ *   MOLLYHIP_TRACE=1               drain the stream before every launch and name it on stderr (the last name a dying process printed faulted)
+ *   MOLLYHIP_XFER_TIMEOUT_MS=n     bound of every in-kernel wait for a peer rank (default 2000)
+ *   MOLLYHIP_OUTER_MARGIN_PM=n     margin of the outer pair list in picometres (default 200; 0: one list of radius r_list)
+ *   MOLLYHIP_INNER_SKIN_PM=n       skin of the inner pair list in picometres (default 100, never more than r_list − cutoff); MOLLYHIP_INNER_SKIN_FIXED=1 stops it growing
+ *   MOLLYHIP_LDS_BUDGET_KB=n       LDS a force pass may use for its tile (default 160): smaller values make it walk the tile in segments
+ *   MOLLYHIP_GROUP_SPLIT=0|4       the group-split pair pass of small systems off / forced (default: automatic); MOLLYHIP_ADOPT_OUTER=0: a pruning pass behind every search
+ *   MOLLYHIP_FUSE_STEP=0           plain pair passes write forces and a separate launch integrates (default: the pass integrates in its epilogue)
+ *   MOLLYHIP_FUSE_GATHER_VV=0      the same for a small system's last force launch
+ *   MOLLYHIP_REUSE_RUN_FORCES=0    every run recomputes the forces of its first step (see mhip_vv_run)
+ *   MOLLYHIP_PME_FFT=0|1           PME transforms through hipFFT never / always (default: meshes with more than 512 points on an axis)
+ *   MOLLYHIP_DEVICE_REPLAN=0       mhip_domain_run returns to the host planner for every re-plan (see mhip_set_domain)
+ * Host mirror only (molly.jl_amd/*.py): MOLLYHIP_GHOST_MARGIN_PM, MOLLYHIP_ENGINE_LOOP, MOLLYHIP_HALO_FUSED, MOLLYHIP_HOST_PRUNE, MOLLYHIP_DIST_BACKEND,
+ * MOLLYHIP_FORCE_DEVICE, MOLLYHIP_FORCE_DOMAIN (bench.py), MOLLYHIP_LIB_AB (another build of the library, tools/force_ab.py).  Builds with -DMHIP_STAMPS=1 only:
+ * MOLLYHIP_DBG_TIMES, MOLLYHIP_DBG_DUMP (time stamps inside the block kernels).  Every other switch of rounds 1-5 lost its measurement and was removed with
+ * its code in round 6 (profiles/r06_removed_switches.md keeps the numbers).
  */
 #ifndef MOLLYHIP_H
 #define MOLLYHIP_H

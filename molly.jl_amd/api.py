@@ -290,7 +290,7 @@ class System:
 
     def __init__(self, atoms=None, coords=None, boundary=None, velocities=None, pairwise_inters=(),
                  specific_inter_lists=(), neighbor_finder=None, dtype=np.float32, device_id=0,
-                 charge=None, sigma=None, eps=None, mass=None, general_inters=()):
+                 charge=None, sigma=None, eps=None, mass=None, general_inters=(), lam=None):
         self.dtype = np.dtype(dtype)
         if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
             raise ValueError("dtype must be float32 or float64")
@@ -306,7 +306,7 @@ class System:
             mass = [a.mass for a in atoms]; lam = [a.λ for a in atoms]
             self.λ = np.ascontiguousarray(lam, dtype=T)
         else:
-            self.λ = None
+            self.λ = None if lam is None else np.ascontiguousarray(lam, dtype=T).reshape(n)      # (plain-array form of Atom.λ)
         arr = lambda a, d: np.full(n, d, T) if a is None else np.ascontiguousarray(a, dtype=T).reshape(n)
         self.charge, self.σ, self.ϵ, self.masses = arr(charge, 0), arr(sigma, 0), arr(eps, 0), arr(mass, 1)
         if velocities is not None and len(velocities) != n:

@@ -338,23 +338,16 @@ template <class T> struct Bonded {
         return A;
     }
     int n_blocks() const { return cdiv(b_i.n, BT) + cdiv(a_i.n, BT) + cdiv(t_i.n, BT) + cdiv(x_i.n, BT); }
-    static bool use_atomics() { static const bool a = [] { const char* v = std::getenv("MOLLYHIP_BONDED_ATOMICS"); return v && *v && std::atoi(v) != 0; }(); return a; }
     // the slot path's tables for the current capacity (rebuilt after any set_*); args for the term kernel writing into the slots
     void ensure_roles(hipStream_t s, int64_t cap) { if (roles_dirty || roles_cap != cap) { MHIP_HIP(hipStreamSynchronize(s)); build_roles(cap); } }
     BondedArgs<T> slot_args(const GridP<T>& G, const InterP<T>& I, const T4* pos, const int32_t* inv) const { return args(G, I, pos, inv, slots, nullptr); }
 
     // forces ADDED to frc (sorted order; `orig` = sorted→caller map of the n_owned owned atoms, `cap` = context capacity).
-    // MOLLYHIP_BONDED_ATOMICS=1: the one-launch scatter with float atomics.
+    // (no atomics: a one-launch scatter with float atomics measured 2x slower and is not bit-reproducible)
     // terms_done: the term kernel's work was done by another launch already (forces_gs.hip runs the terms beside the pair groups): only the per-atom sums
     void launch_forces(hipStream_t s, const GridP<T>& G, const InterP<T>& I, const T4* pos, const int32_t* inv, T4* frc, const int32_t* orig, int64_t n_owned, int64_t cap, bool terms_done = false) {
         int nb = n_blocks();
         if (!nb) return;
-        static const bool atomics = [] { const char* v = std::getenv("MOLLYHIP_BONDED_ATOMICS"); return v && *v && std::atoi(v) != 0; }();
-        if (atomics) {
-            hipLaunchKernelGGL((k_bonded<T, false, false>), dim3(nb), dim3(BT), 0, s, args(G, I, pos, inv, frc, nullptr));
-            MHIP_HIP(hipGetLastError());
-            return;
-        }
         if (roles_dirty || roles_cap != cap) { MHIP_HIP(hipStreamSynchronize(s)); build_roles(cap); }
         if (!terms_done) hipLaunchKernelGGL((k_bonded<T, false, true>), dim3(nb), dim3(BT), 0, s, args(G, I, pos, inv, slots, nullptr));
         hipLaunchKernelGGL(k_bonded_collect<T>, dim3((unsigned)cdiv(n_owned * COLLECT_LANES, (int64_t)256)), dim3(256), 0, s, n_owned, orig, (const int32_t*)role_start.p, (const int32_t*)role_slot.p, (const T4*)slots, frc,

@@ -17,7 +17,6 @@
 #include "stochastic.h"
 #include "pme.h"
 #include "step_fused.h"
-#include "prune_lean.h"
 #include "hilbert.h"
 #include "kernels.h"
 #include "replan.h"
@@ -170,18 +169,15 @@ template <class T> class Engine final : public EngineBase {
     int eshift = 0;
     bool scaled_entries_off = false;   // a tile too large for 14-bit slots was met: back to the slot + flag format for good
     int want_eshift() const {
-        return (!scaled_entries_off && std::is_same<T, float>::value && ljm == LJ_DIST_UNIFORM && coulm == MHIP_COUL_NONE && n_special == 0 && !tri_mode && !G.no_list && !env_int("MOLLYHIP_NO_SCALED_ENTRIES", 0)) ? ESHIFT_SCALED : 0;
+        return (!scaled_entries_off && std::is_same<T, float>::value && ljm == LJ_DIST_UNIFORM && coulm == MHIP_COUL_NONE && n_special == 0 && !tri_mode && !G.no_list) ? ESHIFT_SCALED : 0;
     }
     int slot_cap() const { return ((want_eshift() ? SLOT_MAX_SCALED : TILE_SLOT_MAX) - 1) & ~3; }
     DBuf<int32_t> tile_idx, tile_cnt, wave_rows; DBuf<uint2> nbr; DBuf<T4> blk_center;
     // dual pair list: outer list (nbr / wave_rows, radius r_list + margin) and the inner list filtered from it
     DBuf<int32_t> wave_rows_in, tile_idx_in, tile_cnt_in, rows_x, tile_idx_x, tile_cnt_x; DBuf<uint2> nbr_in, nbr_x; DBuf<T4> pos_snap; DBuf<float> blk_disp2; int max_tile_in = 0;
     bool inner_valid = false, prune_disp_exceeded = false;
-    // lanes of the inner list sorted by row count (kernels.h, ForceArgs::lane_atom): the permutation of the list in use, the row counts
-    // it was emitted with (the order of the next prune) and the outer rows' counts (the order of the first prune after a search)
-    DBuf<uint16_t> lane_atom_in, cnt_in, cnt_outer; bool lanes_sorted = false, cnt_in_valid = false, cnt_outer_valid = false;
-    // the pruning pass writes into nbr_tmp / rows_tmp when its output is re-dealt over the j-split waves afterwards (k_rebalance)
-    DBuf<uint2> nbr_tmp; DBuf<int32_t> rows_tmp;
+    // entries per (sub-list, lane) of the inner list as the last prune wrote it / of the outer list as the search wrote it: what k_regroup deals to the groups
+    DBuf<uint16_t> cnt_in, cnt_outer; bool cnt_outer_valid = false;
     // the group-split pair pass of small systems (forces_gs.hip): the inner list re-dealt into GS groups per block after every prune, the
     // partial forces of groups 1 .. GS − 1 (group 0 writes the force array), and which prune the list belongs to
     DBuf<uint2> nbr_gs; DBuf<int32_t> rows_gs; DBuf<T4> frc_parts; int64_t gs_list_id = -1; bool gs_used = false;
@@ -190,26 +186,22 @@ template <class T> class Engine final : public EngineBase {
     // the outer arrays), and k_regroup deals it to the groups straight away.  It was a 61 µs pass (the PRUNE variant of k_forces, 1024-lane blocks) per
     // rebuild where the group-split launch that now computes the same forces takes 25 µs, spreading and bonded terms included.
     bool inner_is_outer = false; const bool adopt_env = env_int("MOLLYHIP_ADOPT_OUTER", 1) != 0; int64_t n_adopted = 0;
-    bool fuse_spread_next = false, spread_fused = false, fuse_terms_next = false, terms_fused = false; const bool gs_fuse_spread = env_int("MOLLYHIP_GS_FUSE_SPREAD", 1) != 0;
+    bool fuse_spread_next = false, spread_fused = false, fuse_terms_next = false, terms_fused = false;
     const int gs_env = env_int("MOLLYHIP_GROUP_SPLIT", -1);      // 0: off; 2 / 4: groups per block; −1: automatic
     int gs_groups() const {
         if (!std::is_same<T, float>::value || ljm != LJ_DIST || !(coulm == MHIP_COUL_REACTION_FIELD || (coulm == MHIP_COUL_EWALD_DIRECT && I.approx_erfc))) return 0;
-        if (!dual || tri_mode || n_ghost > 0 || G.no_list || sort_lanes_on || gs_env == 0) return 0;
+        if (!dual || tri_mode || n_ghost > 0 || G.no_list || gs_env == 0) return 0;
         const int want = gs_env > 0 ? gs_env : 4;
         if (want != 4 || JS % want != 0 || BI * (JS / want) != 256) return 0;      // (k_forces_gs is a 256-lane workgroup: 64 atoms × 4 waves of a 16-way j-split)
         if (gs_env < 0 && (int64_t)n_blocks * JS * (BI / WAVE) > 2 * 4096) return 0;      // enough workgroups already: large systems balance themselves
         if ((int64_t)n_blocks * want > 16384) return 0;      // (forced or not: the (block, group) items are uint16 and k_gs_balance stages n_blocks·GS ints in 64 KiB of LDS)
         return want;
     }
-    // (measured, profiles/r04_force_ab.txt §2: the 1M-atom plain pass gains 6.7 % — 136 M → 128 M slots — and the copy of the 272 MB list costs
-    // as much per prune as that saves in the ≈ 25 passes behind it; 6mrr: −6 % slots, −1.4 % time, the pass there is bound by its densest block. Off.)
-    const bool rebalance_on = env_int("MOLLYHIP_REBALANCE", 0) != 0;
-    const bool sort_lanes_on = env_int("MOLLYHIP_SORT_LANES", 0) != 0;   // (measured: 5.6 % fewer slots, but the force pass 5 % SLOWER — lanes that are no longer neighbours in space gather from all over the tile, more LDS bank conflicts)
     DBuf<int32_t> blk_ghost, blk_ghost_in; bool ghost_flags_ok = false, ghost_flags_in_ok = false, interior_done = false;
     int64_t last_prune_step = 0;
     int64_t pass_step = 0;       // the MD step whose coordinates the pair pass being launched sees (recorded as the step of a prune)
     DBuf<T4> pos_snap_in;        // coordinates at the last prune (validity of the inner list: 2·displacement <= skin)
-    double skin = 0; bool strict_cadence = false; int64_t n_disp_checks = 0;
+    double skin = 0; int64_t n_disp_checks = 0;
     // The inner list of the dual scheme only has to hold every pair inside the CUTOFFS (mhip_export_neighbors filters the outer list to
     // r_list itself): it is pruned to rc_max + skin_in, skin_in <= skin.  A smaller radius means fewer entries per force pass (∝ r³) and
     // more frequent prunes; MOLLYHIP_INNER_SKIN_PM (picometres, default 100) sets it, the ghosted path keeps skin_in = skin.
@@ -225,7 +217,7 @@ template <class T> class Engine final : public EngineBase {
     bool host_prune = false;     // ghost plans: the HOST decides, collectively over the ranks, when the inner list is re-pruned (mhip_request_prune)
     // single list, same idea: a rebuild step whose displacement check shows the list still covers every cutoff sphere is skipped
     bool lazy_single = false; int64_t n_skipped = 0;
-    bool dual = false, dual_disabled = false, margin_zero = false, want_margin_zero = false; int margin_halvings = 0; int early_outer = 0; double outer_margin = 0; int outer_every = 1; int64_t last_outer_step = 0, n_outer = 0, n_filters = 0; T r_in = 0, r_in2 = 0;
+    bool dual = false, dual_disabled = false, margin_zero = false, want_margin_zero = false; int margin_halvings = 0; int early_outer = 0; double outer_margin = 0; int64_t last_outer_step = 0, n_outer = 0, n_filters = 0; T r_in = 0, r_in2 = 0;
     DBuf<int32_t> flags; int32_t* h_flags = nullptr;
     int64_t total_rows = 0;
     // reductions
@@ -237,14 +229,12 @@ template <class T> class Engine final : public EngineBase {
     Bonded<T> bonded;
     // general interaction: PME reciprocal space (ewald.jl:361-929)
     Pme<T> pme; double pc_sum = 0, pc_abs2_sum = 0; bool pc_valid = false;
-    // bonded terms and PME run on side streams while the pair kernel runs on the main one; their forces land in frc_side[] and
-    // are folded in by the second kick
-    hipStream_t side[2] = {nullptr, nullptr}; hipEvent_t ev_pos = nullptr, ev_side[2] = {nullptr, nullptr};
-    DBuf<T4> frc_side[2]; const T4* pend_a = nullptr; const T4* pend_b = nullptr; bool overlap = true, chain_beside = false; hipStream_t stream_masked = nullptr;
+    // small systems (bonded terms + PME): the last launch of the force chain leaves bonded sums + reciprocal-space forces in frc_side; the integrator
+    // (or fold_side_forces) adds it.  (Side streams, CU-masked streams and any-order launches for these chains all measured slower than one stream: DESIGN §4.)
+    DBuf<T4> frc_side; const T4* pend_a = nullptr;
 
     int cm_pending = 0; bool stale = true, minimg = false, params_set = false, state_set = false, frc_valid = false;
     bool coords_moved = false, export_needs_search = false; int64_t n_set_state_refresh = 0;
-    const bool keep_lists_on_set_state = env_int("MOLLYHIP_SET_STATE_REBUILDS", 0) == 0;
     int64_t last_build_step = std::numeric_limits<int64_t>::min();
     int64_t n_rebuilds = 0, n_force_calls = 0, n_gs_passes = 0; double last_rebuild_ms = 0;
     size_t lds_force = 0; int tile_lds = 0; bool segmented = false; int last_pass_tile = 0;
@@ -271,32 +261,6 @@ template <class T> class Engine final : public EngineBase {
         if (device < 0 || device >= ndev) throw ApiError{MHIP_ERR_INVALID, "device_id out of range"};
         MHIP_HIP(hipSetDevice(device));
         MHIP_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); own_stream = true;
-        const int ov = env_int("MOLLYHIP_OVERLAP", 0);
-        overlap = ov == 1;   // measured on MI355X (6mrr): side streams gain nothing, the small kernels do not co-run profitably
-        chain_beside = ov == 2;   // the FUSED reciprocal + bonded chain on ONE side stream, the pair kernel on the main one (MOLLYHIP_SIDE_CUS: its compute units)
-        if (chain_beside) {
-            const int n_cu = env_int("MOLLYHIP_SIDE_CUS", 0);
-            if (n_cu > 0) {      // the side stream gets the LAST n_cu compute units of every group of 32 CU-mask bits … a plain contiguous range of the mask
-                hipDeviceProp_t prop; MHIP_HIP(hipGetDeviceProperties(&prop, device));
-                const int total = prop.multiProcessorCount, words = (total + 31) / 32;
-                std::vector<uint32_t> m_side(words, 0u), m_main(words, 0u);
-                const int stride = env_int("MOLLYHIP_SIDE_CU_STRIDE", 0);      // > 0: every stride-th CU goes to the side stream instead of the top n_cu
-                for (int c = 0; c < total; ++c) {
-                    const bool to_side = stride > 0 ? (c % stride == 0 && c / stride < n_cu) : c >= total - n_cu;
-                    (to_side ? m_side : m_main)[c >> 5] |= 1u << (c & 31);
-                }
-                MHIP_HIP(hipExtStreamCreateWithCUMask(&side[0], (uint32_t)words, m_side.data()));
-                if (env_int("MOLLYHIP_MAIN_MASKED", 1)) {      // … and everything else keeps off them: the main stream is recreated on the complement
-                    MHIP_HIP(hipExtStreamCreateWithCUMask(&stream_masked, (uint32_t)words, m_main.data()));
-                    (void)hipStreamDestroy(stream); stream = stream_masked; stream_masked = nullptr;
-                }
-            } else MHIP_HIP(hipStreamCreateWithFlags(&side[0], hipStreamNonBlocking));
-            MHIP_HIP(hipEventCreateWithFlags(&ev_side[0], hipEventDisableTiming)); MHIP_HIP(hipEventCreateWithFlags(&ev_pos, hipEventDisableTiming));
-        }
-        if (overlap) {   // side streams only when asked for: every extra stream is a hardware queue
-            for (int k = 0; k < 2; ++k) { MHIP_HIP(hipStreamCreateWithFlags(&side[k], hipStreamNonBlocking)); MHIP_HIP(hipEventCreateWithFlags(&ev_side[k], hipEventDisableTiming)); }
-            MHIP_HIP(hipEventCreateWithFlags(&ev_pos, hipEventDisableTiming));
-        }
         setup_inter(); setup_grid();
         for (int k = 0; k < 2; ++k) { pos[k].reserve(cap); vel[k].reserve(cap); frc[k].reserve(cap); lj[k].reserve(cap); orig[k].reserve(cap); }
         inv.reserve(cap); key_in.reserve(cap); key_out.reserve(cap); idx_in.reserve(cap); perm.reserve(cap);
@@ -318,15 +282,13 @@ template <class T> class Engine final : public EngineBase {
         if (stream) (void)hipStreamSynchronize(stream);
         for (int k = 0; k < 2; ++k) { pos[k].release(); vel[k].release(); frc[k].release(); lj[k].release(); orig[k].release(); }
         inv.release(); key_in.release(); key_out.release(); cell_rank.release(); idx_in.release(); perm.release(); cell_cnt.release(); cell_start.release(); cub_tmp.release();
-        pos_snap_in.release(); lane_atom_in.release(); cnt_in.release(); cnt_outer.release();
-        nbr_tmp.release(); rows_tmp.release(); nbr_gs.release(); rows_gs.release(); frc_parts.release(); wave_rows_in.release(); nbr_in.release(); pos_snap.release(); blk_disp2.release(); tile_idx_in.release(); tile_cnt_in.release(); rows_x.release(); nbr_x.release(); tile_idx_x.release(); tile_cnt_x.release(); blk_ghost.release(); blk_ghost_in.release();
+        pos_snap_in.release(); cnt_in.release(); cnt_outer.release();
+        nbr_gs.release(); rows_gs.release(); frc_parts.release(); wave_rows_in.release(); nbr_in.release(); pos_snap.release(); blk_disp2.release(); tile_idx_in.release(); tile_cnt_in.release(); rows_x.release(); nbr_x.release(); tile_idx_x.release(); tile_cnt_x.release(); blk_ghost.release(); blk_ghost_in.release();
         xl_start.release(); xl_list.release(); tile_idx.release(); tile_cnt.release(); wave_rows.release(); nbr.release(); blk_center.release();
         flags.release(); red_part.release(); red_out.release(); cm_step.release(); vcm.release(); stage_a.release(); stage_b.release(); stage_i.release(); bonded.release(); pme.release(); frc_scratch.release(); nl_counter.release(); state_changed.release(); pos_alt.release(); cm_blk.release(); cm_pub.release();
         xf_release(); dom_release();
         prof.release();
-        for (int k = 0; k < 2; ++k) { if (side[k]) { (void)hipStreamSynchronize(side[k]); (void)hipStreamDestroy(side[k]); } if (ev_side[k]) (void)hipEventDestroy(ev_side[k]); frc_side[k].release(); }
-        if (ev_pos) (void)hipEventDestroy(ev_pos);
-        if (stream_masked) (void)hipStreamDestroy(stream_masked);
+        frc_side.release();
         if (h_flags) (void)hipHostFree(h_flags);
         if (h_trk) (void)hipHostFree(h_trk);
         if (ev_trk) (void)hipEventDestroy(ev_trk);
@@ -363,15 +325,13 @@ template <class T> class Engine final : public EngineBase {
         G.no_list = !(cfg.r_list > 0) || std::isinf(cfg.r_list);
         r_in = G.no_list ? std::numeric_limits<T>::infinity() : T(cfg.r_list);
         r_in2 = G.no_list ? std::numeric_limits<T>::infinity() : r_in * r_in;                 // dist_cutoff^2, neighbors.jl:400
-        // dual pair list: search with r_list + margin every `outer_every` rebuild intervals, filter to exactly r_list at
-        // every rebuild step (MOLLYHIP_OUTER_MARGIN_PM in picometres, 0 disables; MOLLYHIP_OUTER_EVERY)
+        // dual pair list: search with r_list + margin (MOLLYHIP_OUTER_MARGIN_PM in picometres, 0 disables), prune to the inner radius when displacement
+        // says so, search again when the margin is used up
         outer_margin = (G.no_list || dual_disabled) ? 0.0 : std::ldexp(env_int("MOLLYHIP_OUTER_MARGIN_PM", 200) * 1e-3, -margin_halvings);
         // margin 0 keeps the two-list machinery without the wider search: the list is built with r_list and pruned once, right away —
         // which compacts the tile to the atoms the rows refer to (a tile that needed two LDS segments in fp64 then fits in one)
         if (margin_zero && n_ghost == 0) outer_margin = 0;
         if (n_ghost > 0) outer_margin = std::min(outer_margin, ghost_margin);   // the shell handed over must cover the outer radius
-        outer_every = std::max(1, env_int("MOLLYHIP_OUTER_EVERY", 1000));   // upper bound only: the outer list is re-searched when displacement says so
-        strict_cadence = env_int("MOLLYHIP_STRICT_CADENCE", 0) != 0;         // 1: re-prune at every rebuild step, whatever the displacement
         // extent of the cell grid per axis: the box side, or — TriclinicBoundary — the perpendicular height of the cell along that
         // axis (the grid lives in u = s·h, common.h): h = V / |b × c|, V / |c × a|, V / |a × b| for the basis a ∥ x, b in the xy plane
         double ext[3] = {cfg.box[0], cfg.box[1], cfg.box[2]};
@@ -397,16 +357,16 @@ template <class T> class Engine final : public EngineBase {
             const T rp = T(rc_max + skin_in);
             r_prune2 = (skin_in < skin) ? rp * rp : r_in2;
         }
-        const int S = std::max(1, env_int("MOLLYHIP_STENCIL", 2));
+        const int S = 2;      // cells of >= r_search / 2 per side of the stencil
         // A TriclinicBoundary keeps the dual list and the displacement-skipped rebuilds when the box still gets a real cell grid with the
         // wider search radius (displacements are measured on the nearest image, disp_image; pruning and searching work on block-local
         // Cartesian coordinates, kernels.h); a box too small for a grid keeps the one-cell form: plain fixed-cadence lists, exact images.
         bool tri_lists_ok = !tri_mode;
-        if (tri_mode && !G.no_list && env_int("MOLLYHIP_TRI_DUAL", 1) && !env_int("MOLLYHIP_TRI_ONE_CELL", 0))
+        if (tri_mode && !G.no_list)
             for (int d = 0; d < 3; ++d) tri_lists_ok = tri_lists_ok || (int)std::floor(ext[d] / ((cfg.r_list + outer_margin) / S)) > 2 * S + 1;
         if (!tri_lists_ok) outer_margin = 0;
-        dual = (outer_margin > 0 || (margin_zero && n_ghost == 0 && !G.no_list && !dual_disabled)) && outer_every > 1 && lj_cut_ok && coul_cut_ok && skin > 0 && tri_lists_ok;   // ghosted: only with a ghost margin (else re-planned every rebuild)
-        lazy_single = !dual && !G.no_list && lj_cut_ok && coul_cut_ok && skin > 0 && n_ghost == 0 && !strict_cadence && tri_lists_ok;
+        dual = (outer_margin > 0 || (margin_zero && n_ghost == 0 && !G.no_list && !dual_disabled)) && lj_cut_ok && coul_cut_ok && skin > 0 && tri_lists_ok;   // ghosted: only with a ghost margin (else re-planned every rebuild)
+        lazy_single = !dual && !G.no_list && lj_cut_ok && coul_cut_ok && skin > 0 && n_ghost == 0 && tri_lists_ok;
         if (debug_on) std::fprintf(stderr, "[mhip] grid: dual %d margin %.3f skin %.3f lj_ok %d coul_ok %d ghosts %lld\n", (int)dual, outer_margin, skin, (int)lj_cut_ok, (int)coul_cut_ok, (long long)n_ghost);
         const double r_search = G.no_list ? 0.0 : cfg.r_list + (dual ? outer_margin : 0.0);
         G.r_list = G.no_list ? std::numeric_limits<T>::infinity() : T(r_search);
@@ -424,7 +384,7 @@ template <class T> class Engine final : public EngineBase {
             }
             // A triclinic box gets a real cell grid when at least one axis has more cells than a stencil spans (else every block would
             // see every atom anyway: the one-cell form of round 1, all distances by the exact in-loop minimum image).
-            if (pass == 0 && tri_mode && !G.no_list && !env_int("MOLLYHIP_TRI_ONE_CELL", 0)) {
+            if (pass == 0 && tri_mode && !G.no_list) {
                 bool any = false;
                 for (int d = 0; d < 3; ++d) any = any || (int)std::floor(ext[d] / (r_search / S)) > 2 * S + 1;
                 if (any) { tri_grid = true; continue; }
@@ -470,11 +430,10 @@ template <class T> class Engine final : public EngineBase {
         if (n_owned >= 100000) { bi = 256; js = 2; }        // measured on MI355X: lj1m 256x2, 6mrr 64x16 (profiles/)
         else if (n_owned >= 40000) { bi = 128; js = 4; }
         else { bi = 64; js = 16; }
-        bi = env_int("MOLLYHIP_BLOCK_I", bi); js = env_int("MOLLYHIP_J_SPLIT", js);
         if (user_bi) { bi = user_bi; js = user_js; }         // mhip_set_launch_config / the winner of mhip_optimize_launch_config
-        if (bi != 64 && bi != 128 && bi != 256) throw ApiError{MHIP_ERR_INVALID, "MOLLYHIP_BLOCK_I must be 64, 128 or 256"};
+        if (bi != 64 && bi != 128 && bi != 256) throw ApiError{MHIP_ERR_INVALID, "block_atoms must be 64, 128 or 256"};
         js = std::min(js, MAX_THREADS / bi);                // the block kernels' launch bound (fp64: 512 lanes, 256 VGPRs per lane)
-        if (js < 1) throw ApiError{MHIP_ERR_INVALID, "MOLLYHIP_J_SPLIT must be positive"};
+        if (js < 1) throw ApiError{MHIP_ERR_INVALID, "j_split must be positive"};
         BI = bi; JS = js;
         estimate_capacities();
     }
@@ -601,7 +560,7 @@ template <class T> class Engine final : public EngineBase {
 
     void rebuild_impl(int64_t step_n) {
         next_check_step = -1;
-        const int sub_bits = (env_int("MOLLYHIP_SUBCELL_ORDER", 1) && ilog2(2 * G.ncell + 1) + 1 + 6 <= 32) ? 6 : 0;
+        const int sub_bits = (ilog2(2 * G.ncell + 1) + 1 + 6 <= 32) ? 6 : 0;      // atoms of a cell ordered by a 6-bit Morton position inside it
         if (!params_set || !state_set) throw ApiError{MHIP_ERR_STATE, "set_atoms and set_state must be called before forces"};
         auto t0 = std::chrono::steady_clock::now();
         const int o = cur, n = 1 - cur;
@@ -627,7 +586,7 @@ template <class T> class Engine final : public EngineBase {
 
         for (int attempt = 0; attempt < 12; ++attempt) {
             n_blocks = cdiv(n_owned, BI);
-            bool walk = (env_int("MOLLYHIP_BUILD_WALK", 1) || tri_grid) && !G.no_list && (!tri_mode || tri_grid);
+            bool walk = !G.no_list && (!tri_mode || tri_grid);
             size_t lds = build_lds_bytes(T_cap, BI, C_cap, walk);
             if (walk && !tri_grid && lds > (size_t)MAX_LDS_BYTES) { walk = false; lds = build_lds_bytes(T_cap, BI, C_cap, false); }   // no room for the cell offsets: transposed search (its box tests are Cartesian: not on a triclinic grid)
             if (lds > (size_t)MAX_LDS_BYTES) {
@@ -644,12 +603,12 @@ template <class T> class Engine final : public EngineBase {
             A.xl_start = has_exc ? xl_start.p : nullptr; A.xl_list = xl_list.p; A.xl_span = xl_span; A.X_cap = X_CAP;
             A.tile_idx = tile_idx.p; A.tile_cnt = tile_cnt.p; A.nbr = nbr.p; A.wave_rows = wave_rows.p; A.blk_center = blk_center.p; A.flags = flags.p;
             A.margin = G.no_list ? T(0) : G.r_list * T(1e-3);
-            A.approx = dual && !env_int("MOLLYHIP_EXACT_OUTER", 0) ? 1 : 0;
+            A.approx = dual ? 1 : 0;      // (an outer list is a candidate set: no exact band decisions)
             A.walk = walk ? 1 : 0;
             A.eshift = eshift = want_eshift();
             A.cnt_out = nullptr; cnt_outer_valid = false;
             A.dbg = stamps_begin((size_t)n_blocks * 16 * 8);
-            if ((sort_lanes_on && dual && BI > 64) || (gs_groups() > 0 && adopt_env)) { cnt_outer.reserve((size_t)n_blocks * JS * BI); A.cnt_out = cnt_outer.p; cnt_outer_valid = true; }
+            if (gs_groups() > 0 && adopt_env) { cnt_outer.reserve((size_t)n_blocks * JS * BI); A.cnt_out = cnt_outer.p; cnt_outer_valid = true; }
             // The walk with BOTH the exact band decisions and the exception lookups compiled in (k_build<T, true, false, true>: a single list of a system
             // with exclusions) is kept away from blocks of more than 64 atoms: at 128- and 256-atom blocks every i-wave but the first came out with an empty list (round 5,
             // tools/micro/xl_waves.py: 2.86 M of 5.70 M pairs of a 46 656-atom charged fluid; forces off by the mean force on half the atoms), and with
@@ -674,7 +633,7 @@ template <class T> class Engine final : public EngineBase {
             MHIP_HIP(hipGetLastError());
             MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
             MHIP_HIP(hipStreamSynchronize(stream));
-            if (A.dbg) stamps_dump("MOLLYHIP_DBG_DUMP_BUILD", (size_t)n_blocks * 16 * 8);      // (stamp builds: tools/build_times.py)
+            if (A.dbg) stamps_dump(".build", (size_t)n_blocks * 16 * 8);      // (stamp builds: tools/build_times.py)
             int ovf = h_flags[FLAG_OVERFLOW];
             if (!ovf) break;
             if (ovf & OVF_SLOT) {
@@ -691,7 +650,7 @@ template <class T> class Engine final : public EngineBase {
             if (ovf & OVF_ROWS) R_cap = (int)(h_flags[FLAG_MAX_ROWS] * 1.2) + 4;
             if (attempt == 11) throw ApiError{MHIP_ERR_CAPACITY, "neighbour structures did not converge"};
         }
-        minimg = h_flags[FLAG_MINIMG] != 0 || env_int("MOLLYHIP_FORCE_MINIMG", 0) != 0;
+        minimg = h_flags[FLAG_MINIMG] != 0;
         max_tile = h_flags[FLAG_MAX_TILE]; max_rows = h_flags[FLAG_MAX_ROWS]; total_rows = h_flags[FLAG_TOTAL_ROWS];
         carve_force_lds(max_tile);
         red_part.reserve(std::max<size_t>(7 * (size_t)n_blocks, 4 * (size_t)cdiv(n_owned, 256)) + 8);
@@ -700,7 +659,7 @@ template <class T> class Engine final : public EngineBase {
         if (dual) {   // remember where everybody was; the next force pass prunes the outer list into the inner one
             pos_snap.reserve(cap);
             MHIP_HIP(hipMemcpyAsync(pos_snap.p, pos[cur].p, (size_t)n_tot * sizeof(T4), hipMemcpyDeviceToDevice, stream));
-            inner_valid = false; inner_is_outer = false; prune_disp_exceeded = false; ghost_flags_in_ok = false; cnt_in_valid = false; lanes_sorted = false;
+            inner_valid = false; inner_is_outer = false; prune_disp_exceeded = false; ghost_flags_in_ok = false;
             if (cur_dt > 0 && skin_in < skin && !host_prune) {   // inside a run: how fast is the fastest atom? (sizes the inner skin before the first prune)
                 (void)max_disp2_since(pos_snap);
                 adapt_inner_skin(drift_ahead(0.0, 1, cfg.rebuild_every > 0 ? cfg.rebuild_every : 10));
@@ -731,23 +690,20 @@ template <class T> class Engine final : public EngineBase {
         if (lds_force > (size_t)MAX_LDS_BYTES) throw ApiError{MHIP_ERR_CAPACITY, "force-kernel LDS carve-up exceeds 160 KiB"};
     }
 
-    // inner list := outer entries with r2 <= r_list² at the current coordinates (+ max displacement since the outer build)
-    // to_inner = false: the exact list of radius r_list for mhip_export_neighbors, into its OWN arrays (nbr_x, tile_idx_x: the inner list
-    // of the force passes keeps referring to tile_idx_in).  to_inner = true: the prune of the dual scheme as a kernel of its own — the
-    // inner list (any superset of the pairs within rc_max + skin_in) into nbr_in / tile_idx_in.
-    void launch_filter(bool to_inner = false) {
-        DBuf<int32_t>& d_rows = to_inner ? wave_rows_in : rows_x; DBuf<uint2>& d_nbr = to_inner ? nbr_in : nbr_x;
-        DBuf<int32_t>& d_tidx = to_inner ? tile_idx_in : tile_idx_x; DBuf<int32_t>& d_tcnt = to_inner ? tile_cnt_in : tile_cnt_x;
-        d_rows.reserve((size_t)n_blocks * JS * (BI / WAVE)); d_nbr.reserve((size_t)n_blocks * JS * R_cap * BI);
-        d_tidx.reserve((size_t)n_blocks * T_cap); d_tcnt.reserve(n_blocks);
+    // the exact list of radius r_list at the current coordinates for mhip_export_neighbors: the outer list filtered with the reference's predicate into its
+    // OWN arrays (nbr_x, tile_idx_x: the inner list of the force passes keeps referring to tile_idx_in), + max displacement since the outer build.
+    // (The prune of the dual scheme as a kernel of this kind followed by a plain pass measured slower than pruning inside the pass: 0.72 + 0.09 against 0.58 ms.)
+    void launch_filter() {
+        rows_x.reserve((size_t)n_blocks * JS * (BI / WAVE)); nbr_x.reserve((size_t)n_blocks * JS * R_cap * BI);
+        tile_idx_x.reserve((size_t)n_blocks * T_cap); tile_cnt_x.reserve(n_blocks);
         MHIP_HIP(hipMemsetAsync(flags.p, 0, N_FLAGS * sizeof(int32_t), stream));
         blk_disp2.reserve(n_blocks);
         FilterArgs<T> F;
         F.G = G; F.n_owned = n_owned; F.BI = BI; F.BI_shift = ilog2(BI); F.JS = JS; F.T_cap = T_cap; F.R_cap = R_cap; F.n_blocks = n_blocks;
         F.pos = pos[cur].p; F.pos_snap = pos_snap.p; F.tile_idx = tile_idx.p; F.tile_cnt = tile_cnt.p; F.nbr_out = nbr.p; F.rows_out = wave_rows.p;
-        F.nbr_in = d_nbr.p; F.rows_in = d_rows.p; F.tile_idx_in = d_tidx.p; F.tile_cnt_in = d_tcnt.p; F.blk_center = blk_center.p; F.blk_disp2 = blk_disp2.p; F.flags = flags.p;
+        F.nbr_in = nbr_x.p; F.rows_in = rows_x.p; F.tile_idx_in = tile_idx_x.p; F.tile_cnt_in = tile_cnt_x.p; F.blk_center = blk_center.p; F.blk_disp2 = blk_disp2.p; F.flags = flags.p;
         F.eshift = eshift;
-        F.r_in = r_in; F.r_in2 = to_inner ? r_prune2 : r_in2; F.exact_all = minimg ? 1 : 0; F.approx = to_inner && r_prune2 != r_in2 ? 1 : 0;
+        F.r_in = r_in; F.r_in2 = r_in2; F.exact_all = minimg ? 1 : 0;
         F.T_lds = std::min<int>(max_tile, (MAX_LDS_BYTES - 256) / (int)sizeof(float4));
         F.T_lds = minimg ? 0 : F.T_lds;
         size_t lds = (size_t)F.T_lds * sizeof(float4) + (size_t)((T_cap + 8) & ~7) + (size_t)((T_cap + 2) & ~1) * 2 + (size_t)BI * JS * 4 + 64;
@@ -756,7 +712,7 @@ template <class T> class Engine final : public EngineBase {
         tr("k_filter");
         hipLaunchKernelGGL(k_filter<T>, dim3(n_blocks), dim3(BI * JS), lds, stream, F);
         hipLaunchKernelGGL(k_build_summary, dim3(std::min(64, cdiv(n_blocks * JS * (BI / WAVE), 256))), dim3(256), 0, stream, n_blocks, n_blocks * JS * (BI / WAVE), R_cap,
-                           (const int32_t*)d_tcnt.p, d_rows.p, (const float*)blk_disp2.p, flags.p);
+                           (const int32_t*)tile_cnt_x.p, rows_x.p, (const float*)blk_disp2.p, flags.p);
         prof.end(4, stream);
         MHIP_HIP(hipGetLastError());
     }
@@ -811,9 +767,8 @@ template <class T> class Engine final : public EngineBase {
     // 14 % through a different register assignment, with the same instructions: measured, dropped.)
     DBuf<float> trk_part, trk_out; float* h_trk = nullptr; hipEvent_t ev_trk = nullptr;
     bool trk_issued = false; int64_t trk_step = -1, trk_prune_id = -1, trk_outer_id = -1; double trk_prev_vmax = 0;   // (ids: the running counts of prunes / outer searches)
-    const bool async_checks = env_int("MOLLYHIP_ASYNC_CHECKS", 1) != 0;
     bool in_vv_fused = false;
-    bool async_ok() const { return async_checks && in_vv_fused && dual && n_ghost == 0 && !host_prune && !strict_cadence && inner_valid && !stale; }
+    bool async_ok() const { return in_vv_fused && dual && n_ghost == 0 && !host_prune && inner_valid && !stale; }
     void resolve_track(int64_t step) {
         if (!trk_issued) return;
         MHIP_HIP(hipEventSynchronize(ev_trk));
@@ -841,11 +796,10 @@ template <class T> class Engine final : public EngineBase {
     // Light, fast atoms (hydrogens at 0.5 fs: 0.06 nm of possible drift per 10 steps against 0.1 nm of slack) otherwise cost a
     // search at nearly every interval.  Only inside mhip_vv_run / mhip_langevin_run, which own the step loop.
     int64_t next_check_step = -1;
-    const bool fine_checks = env_int("MOLLYHIP_FINE_CHECKS", 1) != 0;
     bool check_due(int64_t step, int every) const { return step % every == 0 || (next_check_step >= 0 && step >= next_check_step); }
     // largest k < every such that a displacement of d now stays within `limit` for k more steps (0: none worth a check of its own)
     int steps_within(double d, double limit, int64_t steps_so_far, int every, bool caller_owns_loop = false) const {
-        if (!fine_checks || !(in_run || caller_owns_loop)) return 0;
+        if (!(in_run || caller_owns_loop)) return 0;
         const double per_step = drift_ahead(d, steps_so_far, 1);
         if (!(per_step > 0)) return 0;
         const int k = (int)std::min<double>(std::floor((limit - d) / per_step), every - 1);
@@ -870,12 +824,12 @@ template <class T> class Engine final : public EngineBase {
             if (2.0 * (d + drift_ahead(d, step_n - last_prune_step, every)) <= skin * 0.98) { last_build_step = step_n; ++n_skipped; return; }
             if (const int k = steps_within(d, 0.49 * skin, step_n - last_prune_step, every)) { next_check_step = step_n + k; last_build_step = step_n; ++n_skipped; return; }
         }
-        if (!dual || stale || (n_ghost == 0 && ((step_n - last_outer_step) >= (int64_t)outer_every * every || step_n < last_outer_step))) { rebuild(step_n); return; }
+        if (!dual || stale || (n_ghost == 0 && step_n < last_outer_step)) { rebuild(step_n); return; }
         // The inner list (pairs within r_list when it was pruned) provably contains every pair within the cutoffs as long as no atom
         // moved more than skin/2 since then — the condition the reference's fixed cadence only assumes.  Check it; re-prune (inside
         // the next force pass) only when it is about to fail.  mhip_export_neighbors always returns the exact list of NOW.
-        if (host_prune && inner_valid && !strict_cadence) { last_build_step = step_n; ++n_rebuilds; return; }   // the host calls mhip_request_prune
-        bool reprune = strict_cadence || !inner_valid;
+        if (host_prune && inner_valid) { last_build_step = step_n; ++n_rebuilds; return; }   // the host calls mhip_request_prune
+        bool reprune = !inner_valid;
         if (!reprune && trk_issued && trk_step == step_n && async_ok()) {   // measured by the integrator launch that made these coordinates; decided one step later
             last_build_step = step_n; ++n_rebuilds;
             return;
@@ -921,7 +875,7 @@ template <class T> class Engine final : public EngineBase {
     void start_lists(int64_t first_step) {
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         lists_after_set_state();
-        if (stale || !(dual || lazy_single) || !keep_lists_on_set_state) { vel_check_due = false; rebuild(first_step); return; }
+        if (stale || !(dual || lazy_single)) { vel_check_due = false; rebuild(first_step); return; }
         if ((check_due(first_step, every) && first_step != last_build_step) || vel_check_due) { vel_check_due = false; refresh(first_step); }
     }
 
@@ -959,14 +913,12 @@ template <class T> class Engine final : public EngineBase {
         A.pos = pos[cur].p; A.lj = lj[cur].p; A.tile_idx = tile_idx.p; A.tile_cnt = tile_cnt.p;
         // dual pair list: a force pass whose inner list is stale walks the OUTER list (always a valid superset — the cutoff is
         // applied per pair) and, if it is a plain force call, prunes it into the inner list on the way
-        if (dual && !inner_valid && !energy && (prune_by_kernel || prune_lean_ok())) prune_with_filter();
         if constexpr (std::is_same<T, float>::value) {
             if (dual && !inner_valid && !energy && allow_gs && part == 0 && !frc_override && adopt_env && gs_groups() > 0 && cnt_outer_valid && margin_zero && !(skin_in < skin)
-                && last_outer_step == pass_step && !lanes_sorted && !rebalance_on && n_ghost == 0 && !host_prune) adopt_outer_list();
+                && last_outer_step == pass_step && n_ghost == 0 && !host_prune) adopt_outer_list();
         }
         const bool use_inner = dual && inner_valid;
         const bool prune = dual && !inner_valid && !energy;
-        const bool rebalance = prune && rebalance_on && JS > 1 && !sort_lanes_on;
         const int GS = gs_groups();
         // a plain pass over an inner list that has its group-split form (made right behind the prune that wrote it)
         if constexpr (std::is_same<T, float>::value) {
@@ -980,18 +932,18 @@ template <class T> class Engine final : public EngineBase {
                     Z.n_blocks = n_blocks; Z.spread = std::max(1, n_blocks / GS + 5);
                     Z.pos = pos[cur].p; Z.lj = lj[cur].p; Z.tile_idx = inner_is_outer ? tile_idx.p : tile_idx_in.p; Z.tile_cnt = inner_is_outer ? tile_cnt.p : tile_cnt_in.p; Z.nbr = nbr_gs.p; Z.wave_rows = rows_gs.p; Z.blk_center = blk_center.p;
                     Z.frc = frc[cur].p; Z.parts = frc_parts.p; Z.part_stride = cap;
-                    Z.item_of = gs_balance_on ? gs_item.p : nullptr;
+                    Z.item_of = gs_item.p;
                     Z.dbg = stamps_begin((size_t)n_blocks * GS * 4 * 8);
                     last_pass_tile = max_tile_in;
                     prof.begin(0, stream);
                     tr("k_forces_gs");
                     spread_fused = false;
-                    if ((fuse_spread_next || fuse_terms_next) && gs_fuse_spread) {      // … with the charge spreading (PME) and the bonded terms of the step as further workgroups of the same launch
+                    if (fuse_spread_next || fuse_terms_next) {      // … with the charge spreading (PME) and the bonded terms of the step as further workgroups of the same launch
                         bonded.ensure_roles(stream, cap);
                         const bool with_spread = fuse_spread_next;
                         const int order = with_spread ? pme.order : 5;
                         // inside vv_run: the Σ m v partials of the launch before become one partial in an extra workgroup of this launch (the step's last launch reads four words)
-                        const bool gs_cm_fin = cm_fin_on && in_vv_fused && !energy && cm_pending == 2 && n_cm_step > 1 && n_cm_step <= 65536;
+                        const bool gs_cm_fin = in_vv_fused && !energy && cm_pending == 2 && n_cm_step > 1 && n_cm_step <= 65536;
                         if (gs_cm_fin) cm_fin_buf.reserve(4);
                         const size_t lds = (with_spread ? std::max(gs_lds_bytes(q_lds, BI, JS / GS), std::min<size_t>((size_t)MAX_LDS_BYTES / GS, spread_head_bytes_f32(order) + (size_t)PME_BOX_BYTES)) : gs_lds_bytes(q_lds, BI, JS / GS)) & ~(size_t)15;
                         const int n_spread = with_spread ? (int)std::min<int64_t>(cdiv(n_owned, (int64_t)64), 4096) : 0;
@@ -1005,7 +957,7 @@ template <class T> class Engine final : public EngineBase {
                     prof.end(0, stream);
                     MHIP_HIP(hipGetLastError());
                     ++n_force_calls; ++n_gs_passes; gs_used = true;
-                    if (Z.dbg && (n_gs_passes % stamps_every()) == 0) stamps_dump("MOLLYHIP_DBG_DUMP", (size_t)n_blocks * GS * 4 * 8);      // (stamp builds: tools/gs_times.py)
+                    if (Z.dbg && (n_gs_passes % stamps_every()) == 0) stamps_dump("", (size_t)n_blocks * GS * 4 * 8);      // (stamp builds: tools/gs_times.py)
                     return;
                 }
             }
@@ -1018,11 +970,11 @@ template <class T> class Engine final : public EngineBase {
         A.nbr = (use_inner && !inner_is_outer) ? nbr_in.p : nbr.p; A.wave_rows = (use_inner && !inner_is_outer) ? wave_rows_in.p : wave_rows.p;
         A.nbr_dst = nullptr; A.rows_dst = nullptr; A.pos_snap = nullptr; A.blk_disp2 = nullptr; A.r_prune2 = r_prune2;
         A.tile_idx_dst = nullptr; A.tile_cnt_dst = nullptr; A.mark_off = 0; A.snap_dst = nullptr; A.any_special = n_special > 0 ? 1 : 0; A.eshift = eshift;
-        A.lane_atom = (use_inner && lanes_sorted) ? lane_atom_in.p : nullptr; A.cnt_src = nullptr; A.cnt_dst = nullptr; A.perm_dst = nullptr;
+        A.cnt_dst = nullptr;
         // the packed fp32 one-type loop keeps the tile as three arrays SOA_STRIDE dwords apart
         const bool fast_f32 = std::is_same<T, float>::value && ljm == LJ_DIST_UNIFORM && coulm == MHIP_COUL_NONE && !energy && !minimg && !segmented && n_special == 0;
         A.soa = 0;
-        if (fast_f32 && !no_soa && eshift == ESHIFT_SCALED && I.lj_c12 != T(0))
+        if (fast_f32 && eshift == ESHIFT_SCALED && I.lj_c12 != T(0))
             for (int k = 2; k >= 0; --k) if ((use_inner ? max_tile_in : max_tile) + 1 < SOA_STRIDES[k]) A.soa = SOA_STRIDES[k];   // the smallest stride that holds tile + sentinel
         if (A.soa) lds_force = std::max((size_t)3 * A.soa * sizeof(float) + 64, (size_t)JS * 4 * BI * sizeof(T) + 32);   // x[], y[], z[] instead of the generic 16-byte records
         A.part = 0; A.blk_ghost = nullptr;
@@ -1035,7 +987,6 @@ template <class T> class Engine final : public EngineBase {
             }
             A.part = part; A.blk_ghost = fl.p;
         }
-        lds_force += (size_t)lds_pad_kb * 1024;   // occupancy experiments (MOLLYHIP_LDS_PAD_KB)
         if (prune) {
             wave_rows_in.reserve((size_t)n_blocks * JS * (BI / WAVE)); nbr_in.reserve((size_t)n_blocks * JS * R_cap * BI); blk_disp2.reserve((size_t)n_blocks * (BI / WAVE));
             A.nbr_dst = nbr_in.p; A.rows_dst = wave_rows_in.p; A.pos_snap = pos_snap.p; A.blk_disp2 = blk_disp2.p;
@@ -1046,17 +997,8 @@ template <class T> class Engine final : public EngineBase {
             last_prune_step = pass_step;
             tile_idx_in.reserve((size_t)n_blocks * T_cap); tile_cnt_in.reserve(n_blocks);
             A.tile_idx_dst = tile_idx_in.p; A.tile_cnt_dst = tile_cnt_in.p;
-            lanes_sorted = false; inner_is_outer = false;
-            if (sort_lanes_on && BI > 64 && cnt_outer_valid) {      // emit the rows ordered by the length they had last time (first prune: of the outer rows)
-                lane_atom_in.reserve((size_t)n_blocks * JS * BI); cnt_in.reserve((size_t)n_blocks * JS * BI);
-                A.cnt_src = cnt_in_valid ? cnt_in.p : cnt_outer.p; A.cnt_dst = cnt_in.p; A.perm_dst = lane_atom_in.p;
-                lanes_sorted = true; cnt_in_valid = true;
-            }
-            if (GS > 0 && !lanes_sorted && !rebalance) { cnt_in.reserve((size_t)n_blocks * JS * BI); A.cnt_dst = cnt_in.p; }   // (k_regroup wants the real entries per (sub-list, lane))
-            if (rebalance && !lanes_sorted) {      // the kept entries go to a scratch list, with their number per (sub-list, lane); k_rebalance deals them into nbr_in
-                nbr_tmp.reserve((size_t)n_blocks * JS * R_cap * BI); rows_tmp.reserve((size_t)n_blocks * JS * (BI / WAVE)); cnt_in.reserve((size_t)n_blocks * JS * BI);
-                A.nbr_dst = nbr_tmp.p; A.rows_dst = rows_tmp.p; A.cnt_dst = cnt_in.p;
-            }
+            inner_is_outer = false;
+            if (GS > 0) { cnt_in.reserve((size_t)n_blocks * JS * BI); A.cnt_dst = cnt_in.p; }   // (k_regroup wants the real entries per (sub-list, lane))
             A.mark_off = (int)((lds_force + 15) & ~(size_t)15);
             lds_force = (size_t)A.mark_off + prune_lds_bytes(tile_lds, BI * JS);   // + renumbering table + scan scratch + wave boxes
             if (lds_force > (size_t)MAX_LDS_BYTES) throw ApiError{MHIP_ERR_CAPACITY, "prune pass LDS carve-up exceeds 160 KiB"};
@@ -1065,19 +1007,18 @@ template <class T> class Engine final : public EngineBase {
         // inside vv_run: the Σ m v partials of the integrator launch before this pass become one partial here (kernels.h, cm_finalize_in_block)
         A.cm_fin_in = nullptr; A.cm_fin_n = 0; A.cm_fin_out = nullptr;
         A.vel = nullptr; A.pos_next = nullptr; A.dt = T(0); A.dt2 = T(0); A.cm_in = nullptr; A.cm_n = 0; A.cm_pub = nullptr; A.step_seq = 0; A.cm_out = nullptr; A.trk_part = nullptr; A.snap_a = nullptr; A.snap_b = nullptr;
-        const bool cm_fin = cm_fin_on && in_vv_fused && !energy && n_ghost == 0 && part == 0 && cm_pending == 2 && n_cm_step > 1 && n_cm_step <= 65536;      // (the energy variants do not carry the sum)
+        const bool cm_fin = in_vv_fused && !energy && n_ghost == 0 && part == 0 && cm_pending == 2 && n_cm_step > 1 && n_cm_step <= 65536;      // (the energy variants do not carry the sum)
         if (cm_fin) { cm_fin_buf.reserve(4); A.cm_fin_in = cm_src(); A.cm_fin_n = n_cm_step; A.cm_fin_out = cm_fin_buf.p; }
         else if (cm_fin_solo_src && !energy && n_ghost == 0 && part == 0 && !cm_fin_solo_done) {      // (mhip_domain_run on one brick: halo_mid's partials)
             cm_fin_buf.reserve(4); A.cm_fin_in = cm_fin_solo_src; A.cm_fin_n = n_cm_step; A.cm_fin_out = cm_fin_buf.p; cm_fin_solo_done = true;
         }
-        static const int level_env = env_int("MOLLYHIP_LEVEL_PAIRS", 1);
-        A.level_pairs = (prune && level_env && JS == 2 && !lanes_sorted && !rebalance) ? 1 : 0;
+        A.level_pairs = (prune && JS == 2) ? 1 : 0;      // (an atom's two sub-lists levelled before they are padded: kernels.h)
         A.dbg = (!prune && !energy) ? stamps_begin((size_t)n_blocks * 16 * 8) : nullptr;
         // the fused step: this pass also integrates (see step_req)
         step_done = false;
         bool do_step = false;
         if constexpr (std::is_same<T, float>::value) {
-            do_step = step_req.on && fuse_step_env && fast_f32 && A.soa != 0 && use_inner && !prune && part == 0 && !frc_override && n_ghost == 0 && !A.lane_atom && cm_pending != 1;
+            do_step = step_req.on && fuse_step_env && fast_f32 && A.soa != 0 && use_inner && !prune && part == 0 && !frc_override && n_ghost == 0 && cm_pending != 1;
             if (do_step) {
                 pos_alt.reserve(cap); cm_blk.reserve(2 * 4 * (size_t)n_blocks + 8);
                 if (!cm_pub.p) { cm_pub.reserve(4); MHIP_HIP(hipMemsetAsync(cm_pub.p, 0, 4 * sizeof(unsigned long long), stream)); }      // (launch numbers start at 1)
@@ -1100,14 +1041,8 @@ template <class T> class Engine final : public EngineBase {
         } else launch_forces_any(A, energy);
         if (cm_fin && !do_step) { cm_ext = cm_fin_buf.p; n_cm_step = 1; }
         tr("after k_forces");
-        if (prune && rebalance && !lanes_sorted) {
-            RebalArgs R{BI, ilog2(BI), JS, R_cap, eshift, (const uint2*)nbr_tmp.p, (const uint16_t*)cnt_in.p, (const int32_t*)tile_cnt_in.p, nbr_in.p, wave_rows_in.p};
-            tr("k_rebalance");
-            hipLaunchKernelGGL(k_rebalance, dim3(n_blocks), dim3(BI * JS), (size_t)JS * BI * sizeof(int32_t), stream, R);
-            MHIP_HIP(hipGetLastError());
-        }
         if constexpr (std::is_same<T, float>::value) {
-            if (prune && GS > 0 && !lanes_sorted && !rebalance) {      // the list this prune wrote, dealt to the groups (it stays as it is for every other kind of pass)
+            if (prune && GS > 0) {      // the list this prune wrote, dealt to the groups (it stays as it is for every other kind of pass)
                 nbr_gs.reserve((size_t)n_blocks * JS * GS * R_cap * BI); rows_gs.reserve((size_t)n_blocks * JS * (BI / WAVE));
                 RegroupArgs R{BI, ilog2(BI), JS, GS, ilog2(GS), R_cap, (const uint2*)nbr_in.p, (const uint16_t*)cnt_in.p, (const int32_t*)tile_cnt_in.p, nbr_gs.p, rows_gs.p,
                               (int)std::min<size_t>((size_t)MAX_LDS_BYTES - (size_t)JS * BI * 16 - 64, (size_t)JS * R_cap * BI * 8), GS * R_cap};
@@ -1139,7 +1074,7 @@ template <class T> class Engine final : public EngineBase {
         }
     }
 
-    DBuf<double> cm_fin_buf; const bool cm_fin_on = env_int("MOLLYHIP_CM_IN_PAIR_PASS", 1) != 0;
+    DBuf<double> cm_fin_buf;
     const double* cm_fin_solo_src = nullptr; bool cm_fin_solo_done = false;
     // The fused step of the large one-type fluids inside mhip_vv_run (kernels.h, k_forces STEP): a plain pair pass whose epilogue is the integrator launch — second kick
     // of this step, first kick + drift of the next, into the other position buffer (swapped in behind the launch) — with Σ m v summed and published by the grid's first
@@ -1153,9 +1088,8 @@ template <class T> class Engine final : public EngineBase {
     const bool fuse_step_env = env_int("MOLLYHIP_FUSE_STEP", 1) != 0;
 
     // the (block, group) items of the group-split pass handed to its workgroups so that every compute unit gets a like share of rows (forces_gs.hip, k_gs_balance)
-    DBuf<uint16_t> gs_item; const bool gs_balance_on = env_int("MOLLYHIP_GS_BALANCE", 1) != 0; int cu_count = 0;
+    DBuf<uint16_t> gs_item; int cu_count = 0;
     void gs_balance() {
-        if (!gs_balance_on) return;
         if (!cu_count) { int dev = 0; MHIP_HIP(hipGetDevice(&dev)); hipDeviceProp_t pr; MHIP_HIP(hipGetDeviceProperties(&pr, dev)); cu_count = std::max(1, pr.multiProcessorCount); }
         const int GS = gs_groups();
         gs_item.reserve((size_t)n_blocks * GS);
@@ -1174,19 +1108,19 @@ template <class T> class Engine final : public EngineBase {
         R.dbg = stamps_begin((size_t)n_blocks * 16 * 8);
         tr("k_regroup (outer list)");
         launch_regroup(R, n_blocks, stream);
-        if (R.dbg) stamps_dump("MOLLYHIP_DBG_DUMP_REGROUP", (size_t)n_blocks * 8);
+        if (R.dbg) stamps_dump(".regroup", (size_t)n_blocks * 8);
         gs_balance();
         prof.end(4, stream);
         MHIP_HIP(hipGetLastError());
         inner_is_outer = true; max_tile_in = max_tile; last_prune_step = pass_step;
         ++n_filters; ++n_adopted; gs_list_id = n_filters;
-        ghost_flags_in_ok = false; next_check_step = -1; lanes_sorted = false; cnt_in_valid = false;
+        ghost_flags_in_ok = false; next_check_step = -1;
         inner_valid = true; prune_disp_exceeded = false;
         if (debug_on) std::fprintf(stderr, "[mhip] outer list adopted as the inner list (no prune): rows %lld calls %lld\n", (long long)total_rows, (long long)n_force_calls);
     }
 
     // Time stamps inside the block kernels — only in libraries built with -DMHIP_STAMPS=1 (common.h), where MOLLYHIP_DBG_TIMES=n arms them (every n-th pass
-    // is reported / dumped to $MOLLYHIP_DBG_DUMP*, tools/gs_times.py, tools/build_times.py).  The product build carries none of it: its kernels get a null pointer.
+    // is reported / dumped to $MOLLYHIP_DBG_DUMP[.build|.regroup], tools/gs_times.py, tools/build_times.py).  The product build carries none of it: its kernels get a null pointer.
 #if MHIP_STAMPS
     DBuf<unsigned long long> dbg_buf;
     static int stamps_every() { static const int n = env_int("MOLLYHIP_DBG_TIMES", 0); return std::max(n, 1); }
@@ -1196,11 +1130,11 @@ template <class T> class Engine final : public EngineBase {
         dbg_buf.reserve(words); MHIP_HIP(hipMemsetAsync(dbg_buf.p, 0, words * sizeof(unsigned long long), stream));
         return dbg_buf.p;
     }
-    void stamps_dump(const char* env_name, size_t words) {
+    void stamps_dump(const char* suffix, size_t words) {      // → the file $MOLLYHIP_DBG_DUMP + suffix
         std::vector<unsigned long long> h(words);
         MHIP_HIP(hipStreamSynchronize(stream));
         MHIP_HIP(hipMemcpy(h.data(), dbg_buf.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        if (const char* path = std::getenv(env_name)) { if (FILE* f = std::fopen(path, "wb")) { std::fwrite(h.data(), sizeof(unsigned long long), h.size(), f); std::fclose(f); } }
+        if (const char* path = std::getenv("MOLLYHIP_DBG_DUMP")) { if (FILE* f = std::fopen((std::string(path) + suffix).c_str(), "wb")) { std::fwrite(h.data(), sizeof(unsigned long long), h.size(), f); std::fclose(f); } }
     }
     void stamps_report() {
         const int nw = BI * JS / WAVE;
@@ -1232,61 +1166,7 @@ template <class T> class Engine final : public EngineBase {
     // r_list + outer_margin of then, the prune wants every pair within rc_max + skin_in of now.
     double prune_margin() const { return outer_margin + (skin - skin_in); }
 
-    // the prune as a kernel of its own (k_filter into the inner arrays), followed by a plain force pass over the fresh inner list
-    const bool prune_by_kernel = env_int("MOLLYHIP_PRUNE_KERNEL", 0) != 0;
     const bool inner_skin_fixed = env_int("MOLLYHIP_INNER_SKIN_FIXED", 0) != 0;
-    const bool fuse_small = env_int("MOLLYHIP_FUSE_SMALL", 1) != 0;
-    const bool no_soa = env_int("MOLLYHIP_NO_SOA", 0) != 0; const int lds_pad_kb = env_int("MOLLYHIP_LDS_PAD_KB", 0);
-    // the fp32 one-type fluids prune with a kernel of their own (prune_lean.h): 16-bit fixed-point tile, integer distance test, no forces
-    const bool prune_lean_on = env_int("MOLLYHIP_PRUNE_LEAN", 0) != 0;   // (measured equal to the fused pass at 1M atoms: its emission costs what the fused pass hides, DESIGN §4 — off unless asked for)
-    bool prune_lean_ok() const {
-        return prune_lean_on && std::is_same<T, float>::value && ljm == LJ_DIST_UNIFORM && coulm == MHIP_COUL_NONE && n_special == 0 && eshift == ESHIFT_SCALED && !minimg && !tri_mode
-               && prune_lean_lds_bytes(max_tile + 1, BI * JS) <= (size_t)MAX_LDS_BYTES;
-    }
-    void launch_prune_lean() {
-        if constexpr (std::is_same<T, float>::value) {
-            wave_rows_in.reserve((size_t)n_blocks * JS * (BI / WAVE)); nbr_in.reserve((size_t)n_blocks * JS * R_cap * BI); blk_disp2.reserve((size_t)n_blocks * (BI / WAVE));
-            tile_idx_in.reserve((size_t)n_blocks * T_cap); tile_cnt_in.reserve(n_blocks); pos_snap_in.reserve(cap);
-            ForceArgs<float> A;
-            std::memset(&A, 0, sizeof(A));
-            A.G = G; A.I = I; A.n_owned = n_owned; A.BI = BI; A.BI_shift = ilog2(BI); A.JS = JS; A.T_cap = T_cap; A.T_lds = max_tile + 1; A.R_cap = R_cap;
-            A.n_blocks = n_blocks; A.blocks_per_xcd = cdiv(n_blocks, 8);
-            A.pos = pos[cur].p; A.tile_idx = tile_idx.p; A.tile_cnt = tile_cnt.p; A.nbr = nbr.p; A.wave_rows = wave_rows.p; A.blk_center = blk_center.p;
-            A.nbr_dst = nbr_in.p; A.rows_dst = wave_rows_in.p; A.pos_snap = pos_snap.p; A.blk_disp2 = blk_disp2.p; A.r_prune2 = r_prune2;
-            A.tile_idx_dst = tile_idx_in.p; A.tile_cnt_dst = tile_cnt_in.p; A.snap_dst = pos_snap_in.p; A.eshift = eshift;
-            if (n_ghost > 0) MHIP_HIP(hipMemcpyAsync(pos_snap_in.p + n_owned, pos[cur].p + n_owned, (size_t)n_ghost * sizeof(T4), hipMemcpyDeviceToDevice, stream));
-            const size_t lds = prune_lean_lds_bytes(A.T_lds, BI * JS);
-            set_lds_limit(k_prune_lean, lds);
-            prof.begin(4, stream);
-            tr("k_prune_lean");
-            hipLaunchKernelGGL(k_prune_lean, dim3(A.blocks_per_xcd * 8), dim3(BI * JS), lds, stream, A);
-            hipLaunchKernelGGL(k_prune_summary, dim3(1), dim3(1024), 0, stream, n_blocks, n_blocks * JS * (BI / WAVE), n_blocks * (BI / WAVE), R_cap,
-                               (const int32_t*)tile_cnt_in.p, wave_rows_in.p, (const float*)blk_disp2.p, flags.p, h_flags);
-            prof.end(4, stream);
-            MHIP_HIP(hipGetLastError());
-        }
-    }
-    void prune_with_filter() {
-        const bool lean = prune_lean_ok();
-        lanes_sorted = false; cnt_in_valid = false; inner_is_outer = false;      // (these kernels emit in atom order)
-        last_prune_step = pass_step;
-        if (lean) launch_prune_lean();
-        else {
-            pos_snap_in.reserve(cap);
-            MHIP_HIP(hipMemcpyAsync(pos_snap_in.p, pos[cur].p, (size_t)n_tot * sizeof(T4), hipMemcpyDeviceToDevice, stream));
-            launch_filter(true);
-        }
-        if (n_ghost > 0)   // the blocks record the displacement of the owned atoms; the ghosts' comes on top
-            hipLaunchKernelGGL(k_max_disp<T>, dim3(std::min(cdiv(n_ghost, 256), 1024)), dim3(256), 0, stream, n_ghost, (const T4*)pos[cur].p + n_owned, (const T4*)pos_snap.p + n_owned,
-                               reinterpret_cast<unsigned int*>(flags.p + FLAG_MAX_DISP2), G);
-        if (!lean || n_ghost > 0) MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-        MHIP_HIP(hipStreamSynchronize(stream));
-        float d2; std::memcpy(&d2, &h_flags[FLAG_MAX_DISP2], sizeof(float));
-        total_rows = h_flags[FLAG_TOTAL_ROWS]; max_tile_in = h_flags[FLAG_MAX_TILE];
-        ++n_filters; ghost_flags_in_ok = false; next_check_step = -1;
-        inner_valid = true; prune_disp_exceeded = 2.0 * std::sqrt((double)d2) > prune_margin() * 0.98;
-        if (debug_on) std::fprintf(stderr, "[mhip] prune (kernel): max disp %.5f nm (margin %.3f) rows %lld exceeded %d\n", std::sqrt((double)d2), prune_margin(), (long long)total_rows, (int)prune_disp_exceeded);
-    }
 
     double read_sum(int n_part) {
         hipLaunchKernelGGL(k_sum_double, dim3(1), dim3(256), 0, stream, n_part, (const double*)red_part.p, red_out.p);
@@ -1309,65 +1189,33 @@ template <class T> class Engine final : public EngineBase {
         MHIP_HIP(hipGetLastError());
     }
 
-    // all forces of one MD step: the pair kernel overwrites frc[cur] on the main stream while the bonded terms and the PME
-    // reciprocal part — independent, latency-bound chains of small kernels — run next to it on the side streams into
-    // frc_side[]; the consumer (second kick, or fold_side_forces) adds them
+    // all forces of one MD step: the pair kernel overwrites frc[cur]; the bonded terms and the PME reciprocal part ride in the same launch where the shapes
+    // allow (forces_gs.hip), else follow on the same stream; a second force array a fused launch leaves behind (pend_a) is added by the consumer
+    // (second kick, or fold_side_forces)
     void step_forces(int64_t step_n) {
         pass_step = step_n;
-        const bool side_b = overlap && bonded.any(), side_p = overlap && pme.on();
-        if (side_p && n_ghost > 0) throw ApiError{MHIP_ERR_UNSUPPORTED, "PME runs on a single domain (SURVEY §8(e): 6mrr-size systems are replicas only)"};
-        if (side_b || side_p) MHIP_HIP(hipEventRecord(ev_pos, stream));
-        for (int k = 0; k < 2; ++k) {
-            if (!(k == 0 ? side_b : side_p)) continue;
-            frc_side[k].reserve(cap);
-            MHIP_HIP(hipStreamWaitEvent(side[k], ev_pos, 0));
-            MHIP_HIP(hipMemsetAsync(frc_side[k].p, 0, (size_t)n_owned * sizeof(T4), side[k]));
-            prof.begin(k == 0 ? 5 : 6, side[k]);
-            if (k == 0) bonded.launch_forces(side[k], G, I, pos[cur].p, inv.p, frc_side[k].p, orig[cur].p, n_owned, cap);
-            else pme.run(side[k], n_owned, pos[cur].p, frc_side[k].p, nullptr);
-            prof.end(k == 0 ? 5 : 6, side[k]);
-            MHIP_HIP(hipEventRecord(ev_side[k], side[k]));
-        }
-        // the fused reciprocal + bonded chain beside the pair kernel: it reads positions only and leaves its forces in the two side arrays
-        const bool beside = chain_beside && fuse_small && bonded.any() && pme.on() && !Bonded<T>::use_atomics() && n_ghost == 0;
-        if (beside) {
-            frc_side[0].reserve(cap); frc_side[1].reserve(cap);
-            MHIP_HIP(hipEventRecord(ev_pos, stream));
-            MHIP_HIP(hipStreamWaitEvent(side[0], ev_pos, 0));
-            prof.begin(6, side[0]);
-            launch_pme_bonded_fused<T>(side[0], pme, bonded, G, I, n_owned, cap, pos[cur].p, inv.p, orig[cur].p, frc_side[1].p, frc_side[0].p, true);
-            prof.end(6, side[0]);
-            MHIP_HIP(hipEventRecord(ev_side[0], side[0]));
-        }
+        if (pme.on() && n_ghost > 0) throw ApiError{MHIP_ERR_UNSUPPORTED, "PME runs on a single domain (SURVEY §8(e): 6mrr-size systems are replicas only)"};
         // (group-split passes leave partial forces that the per-atom sums of the bonded slots fold in: only where such a launch follows)
-        const bool gs_ok = bonded.any() && !overlap && !chain_beside && !Bonded<T>::use_atomics() && n_ghost == 0;
-        const bool small_fused = !overlap && !chain_beside && fuse_small && bonded.any() && pme.on() && !Bonded<T>::use_atomics() && n_ghost == 0;
+        const bool gs_ok = bonded.any() && n_ghost == 0;
+        const bool small_fused = bonded.any() && pme.on() && n_ghost == 0;
         // (with the stage timers on, every job keeps its own launch: a stage's time is then that job's — bench.py's profiling pass, never its timed region)
-        fuse_spread_next = gs_ok && small_fused && pme.order >= 4 && pme.order <= 6 && !(prof.on && env_int("MOLLYHIP_PROF_FUSED", 0) == 0);
-        fuse_terms_next = gs_ok && !small_fused && !pme.on() && !(prof.on && env_int("MOLLYHIP_PROF_FUSED", 0) == 0);      // (no PME: the bonded terms alone ride with the pair groups)
+        fuse_spread_next = gs_ok && small_fused && pme.order >= 4 && pme.order <= 6 && !prof.on;
+        fuse_terms_next = gs_ok && !small_fused && !pme.on() && !prof.on;      // (no PME: the bonded terms alone ride with the pair groups)
         spread_fused = terms_fused = false;
         launch_pair_kernel(false, interior_done ? 2 : 0, gs_ok);   // (the blocks without ghosts may have run already, while the ghosts were on the wire)
         fuse_spread_next = fuse_terms_next = false;
         interior_done = false;
         bool redo = false;
         if (prune_disp_exceeded) {   // the outer list could not vouch for this pass: search again and redo it on the fresh list
-            for (int k = 0; k < 2; ++k) if (k == 0 ? side_b : side_p) MHIP_HIP(hipStreamWaitEvent(stream, ev_side[k], 0));   // they read the old order
-            if (beside) MHIP_HIP(hipStreamWaitEvent(stream, ev_side[0], 0));
             after_forces(step_n);
             launch_pair_kernel(false);
             redo = true;
         }
         if (gs_used) bonded.fold(frc_parts.p, gs_groups() - 1, cap);      // the next collect launch adds the groups' partial forces
-        pend_a = pend_b = nullptr;
-        if (beside && !redo) {      // (a redo re-sorted the atoms: the chain's side arrays are in the old order, the fused launches below repeat it)
-            MHIP_HIP(hipStreamWaitEvent(stream, ev_side[0], 0));
-            pend_a = frc_side[0].p; pend_b = frc_side[1].p;
-            frc_valid = true;
-            return;
-        }
+        pend_a = nullptr;
         // small systems: charge spreading next to the bonded terms, force interpolation next to the bonded sums (step_fused.h)
-        if (!overlap && fuse_small && bonded.any() && pme.on() && !Bonded<T>::use_atomics() && n_ghost == 0) {
-            frc_side[0].reserve(cap);
+        if (small_fused) {
+            frc_side.reserve(cap);
             // … and, on a mid-run step of vv_run, the integrator in that last launch (v_cm of the step before as ONE partial, or none pending)
             GcvArgs<T> V; const GcvArgs<T>* vp = nullptr;
             if (step_req.gcv && fuse_gcv_env && !redo && (cm_pending == 0 || (cm_pending == 2 && n_cm_step == 1)) && pme.order >= 4 && pme.order <= 6) {
@@ -1382,24 +1230,22 @@ template <class T> class Engine final : public EngineBase {
                 vp = &V; step_parts = nb;
             }
             prof.begin(6, stream);
-            launch_pme_bonded_fused<T>(stream, pme, bonded, G, I, n_owned, cap, pos[cur].p, inv.p, orig[cur].p, frc[cur].p, frc_side[0].p, false, spread_fused, vp);
+            launch_pme_bonded_fused<T>(stream, pme, bonded, G, I, n_owned, cap, pos[cur].p, inv.p, orig[cur].p, frc[cur].p, frc_side.p, spread_fused, vp);
             prof.end(6, stream);
             if (vp) { step_done = true; ++n_fused_steps; pend_a = nullptr; frc_valid = false; return; }
-            pend_a = frc_side[0].p;
+            pend_a = frc_side.p;
             frc_valid = true;
             return;
         }
-        if (redo || !side_b) { if (bonded.any()) { prof.begin(5, stream); bonded.launch_forces(stream, G, I, pos[cur].p, inv.p, frc[cur].p, orig[cur].p, n_owned, cap, terms_fused); prof.end(5, stream); } }
-        else { MHIP_HIP(hipStreamWaitEvent(stream, ev_side[0], 0)); pend_a = frc_side[0].p; }
-        if (redo || !side_p) launch_pme_forces();
-        else { MHIP_HIP(hipStreamWaitEvent(stream, ev_side[1], 0)); pend_b = frc_side[1].p; }
+        if (bonded.any()) { prof.begin(5, stream); bonded.launch_forces(stream, G, I, pos[cur].p, inv.p, frc[cur].p, orig[cur].p, n_owned, cap, terms_fused); prof.end(5, stream); }
+        launch_pme_forces();
         frc_valid = true;
     }
-    // frc[cur] += the side-stream contributions, for consumers other than the second kick
+    // frc[cur] += the second force array, for consumers other than the second kick
     void fold_side_forces() {
-        if (!pend_a && !pend_b) return;
-        hipLaunchKernelGGL(k_add_forces<T>, dim3(std::min(cdiv(n_owned, 256), 1024)), dim3(256), 0, stream, n_owned, frc[cur].p, pend_a, pend_b);
-        pend_a = pend_b = nullptr;
+        if (!pend_a) return;
+        hipLaunchKernelGGL(k_add_forces<T>, dim3(std::min(cdiv(n_owned, 256), 1024)), dim3(256), 0, stream, n_owned, frc[cur].p, pend_a);
+        pend_a = nullptr;
     }
 
     void launch_pme_forces() {
@@ -1454,7 +1300,7 @@ template <class T> class Engine final : public EngineBase {
         MHIP_HIP(hipStreamSynchronize(stream));
         // one atom type (every σ, ϵ equal and non-zero, no λ = 0) + DistanceCutoff → uniform-LJ kernel variant
         ljm = ljm_base;
-        if (ljm_base == LJ_DIST && ds && de && !tri_mode && !(env_int("MOLLYHIP_NO_UNIFORM_LJ", 0))) {   // (the one-type kernels know cubic boxes only)
+        if (ljm_base == LJ_DIST && ds && de && !tri_mode) {   // (the one-type kernels know cubic boxes only)
             // decided on the device (a sub-domain hands its parameters over at every re-plan): flag ≠ 0 if some σ, ϵ differs from atom 0's or a λ is 0
             MHIP_HIP(hipMemsetAsync(flags.p, 0, N_FLAGS * sizeof(int32_t), stream));
             hipLaunchKernelGGL(k_uniform_check<T>, dim3(std::min(cdiv(n_tot, 256), 1024)), dim3(256), 0, stream, n_tot, ds, de, dl, flags.p);
@@ -1530,7 +1376,7 @@ template <class T> class Engine final : public EngineBase {
             // moved coordinates at every call and redoes its sort / tile search only at the step cadence, ext/MollyCUDAExt.jl:774-783).
             // Whether the lists still cover every cutoff sphere is decided by displacement at the next force call (lists_after_set_state);
             // lists that have no skin to spend are rebuilt at once, as before.
-            if (!stale && keep_lists_on_set_state && (dual || lazy_single)) coords_moved = true; else stale = true;
+            if (!stale && (dual || lazy_single)) coords_moved = true; else stale = true;
             frc_valid = false; state_set = true;
         }
     }
@@ -1817,13 +1663,13 @@ template <class T> class Engine final : public EngineBase {
         tr("k_vv2");
         prof.begin(2, stream);
         if (cm) {
-            hipLaunchKernelGGL((k_vv2<T, true>), dim3(nb), dim3(256), 0, stream, n_owned, vel[cur].p, frc[cur].p, T(dt) / T(2), cm_parts_ext ? cm_parts_ext : cm_step.p, pend_a, pend_b);
+            hipLaunchKernelGGL((k_vv2<T, true>), dim3(nb), dim3(256), 0, stream, n_owned, vel[cur].p, frc[cur].p, T(dt) / T(2), cm_parts_ext ? cm_parts_ext : cm_step.p, pend_a);
             cm_pending = 2; n_cm_step = nb;   // the next k_vv1 (or any flush) re-sums the partials: no finalize launch
         } else {
-            hipLaunchKernelGGL((k_vv2<T, false>), dim3(nb), dim3(256), 0, stream, n_owned, vel[cur].p, frc[cur].p, T(dt) / T(2), (double*)nullptr, pend_a, pend_b);
+            hipLaunchKernelGGL((k_vv2<T, false>), dim3(nb), dim3(256), 0, stream, n_owned, vel[cur].p, frc[cur].p, T(dt) / T(2), (double*)nullptr, pend_a);
         }
         prof.end(2, stream);
-        pend_a = pend_b = nullptr;    // the kick wrote the total back into frc[cur]
+        pend_a = nullptr;    // the kick wrote the total back into frc[cur]
     }
     // the neighbour cadence of a stepwise-driven run: as in vv_run.  A ghosted sub-domain without the dual list is re-planned
     // (set_atom_counts / set_state → stale) by the host at every rebuild step instead.
@@ -1984,7 +1830,7 @@ template <class T> class Engine final : public EngineBase {
         const bool solo = hp.n_cm_peers == 0 && hp.n_send_rows == 0;              // no peers: the partials of the launch before are the whole sum
         // … which workgroup 0 of the pair pass in between adds up into ONE partial, as inside mhip_vv_run (ForceArgs::cm_fin_in): the integrator's blocks
         // then do not each re-sum hundreds of partials first
-        cm_fin_solo_src = (solo && halo_cm_in && cm_fin_on && n_ghost == 0 && n_cm_step > 1 && n_cm_step <= 4096) ? (const double*)cm_step.p + (size_t)(cm_half ^ 1) * 4 * 1024 : (const double*)nullptr;
+        cm_fin_solo_src = (solo && halo_cm_in && n_ghost == 0 && n_cm_step > 1 && n_cm_step <= 4096) ? (const double*)cm_step.p + (size_t)(cm_half ^ 1) * 4 * 1024 : (const double*)nullptr;
         cm_fin_solo_done = false;
         step_forces(step_n);
         cm_fin_solo_src = nullptr;
@@ -1998,12 +1844,12 @@ template <class T> class Engine final : public EngineBase {
         tr("k_vv_mid");
         auto go = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, stream, n_owned, pos[cur].p, vel[cur].p, (const T4*)frc[cur].p, T(dt), T(dt) / T(2),
-                               cm_in, n_in, cm_out, (const T4*)pend_a, (const T4*)pend_b, G, (const T4*)nullptr, (const T4*)nullptr, (float*)nullptr);
+                               cm_in, n_in, cm_out, (const T4*)pend_a, G, (const T4*)nullptr, (const T4*)nullptr, (float*)nullptr);
         };
         if (last) { if (cm) go(k_vv_mid<T, true, true>); else go(k_vv_mid<T, false, true>); }
         else { if (cm) go(k_vv_mid<T, true, false>); else go(k_vv_mid<T, false, false>); }
         prof.end(2, stream);
-        pend_a = pend_b = nullptr; cm_pending = 0; cm_ext = nullptr;
+        pend_a = nullptr; cm_pending = 0; cm_ext = nullptr;
         if (due && !dual) refresh(step_n);
         if (!last) {
             n_cm_step = nb;
@@ -2313,7 +2159,7 @@ template <class T> class Engine final : public EngineBase {
     // the one-type LJ decision of set_atoms, from σ and ϵ of atom 0 and the "some atom differs" word of the device check
     void apply_uniform(bool all_equal, T s0, T e0) {
         ljm = ljm_base;
-        if (ljm_base == LJ_DIST && !tri_mode && !env_int("MOLLYHIP_NO_UNIFORM_LJ", 0) && all_equal && s0 != T(0) && e0 != T(0)) {
+        if (ljm_base == LJ_DIST && !tri_mode && all_equal && s0 != T(0) && e0 != T(0)) {
             T sm = (s0 + s0) / T(2), em = std::sqrt(e0 * e0);   // the mixing rules applied to equal values
             I.lj_s2 = sm * sm; I.lj_24e = T(24) * em; I.lj_4e = T(4) * em;
             const double s6 = std::pow((double)sm, 6), c6 = 24.0 * (double)em * s6, c12 = 48.0 * (double)em * s6 * s6;
@@ -2447,8 +2293,7 @@ template <class T> class Engine final : public EngineBase {
         vv_init(first_step);                                                      // :564-571
         // fused stepping: first kick + drift once, then ONE integrator launch between consecutive force passes (k_vv_mid), the
         // plain second kick at the end.  A thermostat needs v_n between the kicks: the two-launch form then.
-        static const bool fuse_env = env_int("MOLLYHIP_VV_FUSE", 1) != 0;
-        const bool fused = fuse_env && !(andersen_prob > 0);
+        const bool fused = !(andersen_prob > 0);
         InRun guard_fused(in_vv_fused); in_vv_fused = fused;
         const bool pre = dual;                                                    // without the dual list: the reference's order
         const int64_t last = first_step + n_steps;
@@ -2485,7 +2330,7 @@ template <class T> class Engine final : public EngineBase {
                     MHIP_HIP(hipEventRecord(ev_trk, stream));
                     trk_issued = true; trk_step = step + 1; trk_prev_vmax = last_vmax; trk_prune_id = n_filters; trk_outer_id = n_outer;
                 }
-                pend_a = pend_b = nullptr; cm_pending = 0; cm_ext = nullptr;
+                pend_a = nullptr; cm_pending = 0; cm_ext = nullptr;
                 if (cm) { cm_pending = 2; cm_ext = cm_blk.p + (size_t)step_half * 4 * step_parts; n_cm_step = step_parts; step_half ^= 1; }
                 frc_valid = false;
                 continue;
@@ -2494,8 +2339,7 @@ template <class T> class Engine final : public EngineBase {
             // every block re-sums the previous step's per-block Σ m v partials (32 bytes each), so fewer, longer blocks pay: 1024 blocks
             // re-read 32 MB from L2 per launch — more than the 21 MB of atoms of the 256k-atom fluid (13.0 → 10.0 µs with 256 blocks;
             // 1M atoms: 21.2 → 20.2 µs with 512, 21.8 with 256)
-            static const int vv_blocks = env_int("MOLLYHIP_VV_BLOCKS", 0);
-            const int nb = std::min(cdiv(n_owned, 256), vv_blocks > 0 ? std::min(vv_blocks, 1024) : (int)std::max<int64_t>(256, std::min<int64_t>(512, n_owned / 2048)));
+            const int nb = std::min(cdiv(n_owned, 256), (int)std::max<int64_t>(256, std::min<int64_t>(512, n_owned / 2048)));
             const double* cm_in = cm_pending == 2 ? cm_src() : (const double*)nullptr;
             double* cm_out = cm ? cm_step.p + (size_t)half * 4 * 1024 : (double*)nullptr;
             prof.begin(2, stream);
@@ -2504,7 +2348,7 @@ template <class T> class Engine final : public EngineBase {
             if (measure_mid) { trk_part.reserve(3 * (size_t)std::max(n_blocks, 1024)); trk_out.reserve(4); }
             auto go = [&](auto kern) {
                 hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, stream, n_owned, pos[cur].p, vel[cur].p, (const T4*)frc[cur].p, T(dt), T(dt) / T(2),
-                                   cm_in, n_cm_step, cm_out, (const T4*)pend_a, (const T4*)pend_b, G,
+                                   cm_in, n_cm_step, cm_out, (const T4*)pend_a, G,
                                    measure_mid ? (const T4*)pos_snap_in.p : (const T4*)nullptr, measure_mid ? (const T4*)pos_snap.p : (const T4*)nullptr, measure_mid ? trk_part.p : (float*)nullptr);
             };
             if (step == last) { if (cm) go(k_vv_mid<T, true, true>); else go(k_vv_mid<T, false, true>); }
@@ -2517,8 +2361,8 @@ template <class T> class Engine final : public EngineBase {
                 MHIP_HIP(hipEventRecord(ev_trk, stream));
                 trk_issued = true; trk_step = step + 1; trk_prev_vmax = last_vmax; trk_prune_id = n_filters; trk_outer_id = n_outer;
             }
-            if (step == last) frc_run_total = pend_a == nullptr && pend_b == nullptr && n_ghost == 0;   // (side arrays are added by the kick, not folded)
-            pend_a = pend_b = nullptr;
+            if (step == last) frc_run_total = pend_a == nullptr && n_ghost == 0;   // (side arrays are added by the kick, not folded)
+            pend_a = nullptr;
             cm_pending = 0; cm_ext = nullptr;
             if (cm) { cm_pending = 2; cm_ext = cm_out; n_cm_step = nb; half ^= 1; }
             if (step != last) frc_valid = false;                                  // frc[cur] belongs to the coordinates before the drift

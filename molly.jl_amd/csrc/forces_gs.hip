@@ -290,11 +290,11 @@ __global__ void __launch_bounds__(256, 4) k_forces_gs(GsArgs A) {     // (four w
 // tile quarter, so the spreading and the terms run through that phase instead of queueing behind the pair groups for a free slot.
 // Every role carves its LDS from the launch's dynamic pool (the spreading: its tables and whatever is left as the sub-mesh).
 template <int COULM, bool MINIMG, int ORDER>
-__global__ void __launch_bounds__(256, 4) k_pair_spread_bonded(GsArgs A, int n_pair, int64_t n_atoms, float* rgrid, PmeP<float> P, int n_spread, int lds_bytes, BondedArgs<float> B, int short_first,
+__global__ void __launch_bounds__(256, 4) k_pair_spread_bonded(GsArgs A, int n_pair, int64_t n_atoms, float* rgrid, PmeP<float> P, int n_spread, int lds_bytes, BondedArgs<float> B,
                                                                int n_term_wg, const double* cm_fin_in, int cm_fin_n, double* cm_fin_out) {
     extern __shared__ __align__(32) unsigned char smem[];
     int wg = (int)blockIdx.x;
-    if (short_first) {      // the short jobs at the head of the grid: they start with the pair groups and run through those groups' staging phase
+    {      // the short jobs at the head of the grid: they start with the pair groups and run through those groups' staging phase (26.4 -> 25.8 us per launch, profiles/r04_force_ab.txt §16)
         const int n_short = (int)gridDim.x - n_pair;
         wg = wg < n_short ? n_pair + wg : wg - n_short;
     }
@@ -337,8 +337,7 @@ void launch_pair_spread_bonded(const GsArgs& A, int n_pair, int coulm, bool mini
     const dim3 grid((unsigned)(n_pair + n_spread + n_term_wg + (cm_fin_in ? 1 : 0))), block(256);
     auto go = [&](auto kern) {
         if (lds_bytes > 64 * 1024) MHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        static const int short_first = [] { const char* v = std::getenv("MOLLYHIP_GS_SHORT_FIRST"); return v && *v ? std::atoi(v) : 1; }();      // (measured: 26.4 -> 25.8 us per launch, profiles/r04_force_ab.txt §16)
-        hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, A, n_pair, n_atoms, rgrid, P, n_spread, (int)lds_bytes, B, short_first, n_term_wg, cm_fin_in, cm_fin_n, cm_fin_out);
+        hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, A, n_pair, n_atoms, rgrid, P, n_spread, (int)lds_bytes, B, n_term_wg, cm_fin_in, cm_fin_n, cm_fin_out);
     };
     auto by_order = [&](auto coul_tag, auto mi_tag) {
         constexpr int C = decltype(coul_tag)::value; constexpr bool M = decltype(mi_tag)::value;

@@ -655,8 +655,8 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
                 for (int qz = lo[2]; qz <= hi[2]; ++qz) for (int qy = lo[1]; qy <= hi[1]; ++qy) {
                     const int row = (qz * ly + qy) * lx;
                     const int t0 = t_off[row + lo[0]], t1 = t_off[row + hi[0] + 1];
-                    // this j-split takes the slots ≡ js (mod JS); JS is a power of two unless MOLLYHIP_J_SPLIT says otherwise (two integer
-                    // divisions per row of cells otherwise: 25 rows per atom)
+                    // this j-split takes the slots ≡ js (mod JS); JS is a power of two for every shape the engine hands out (the general form
+                    // costs two integer divisions per row of cells: 25 rows per atom)
                     int t = t0 + (js_pow2 ? ((js - t0) & (A.JS - 1)) : ((js - t0) % A.JS + A.JS) % A.JS);
                     auto consider = [&](int tc, const float4 pl) {
                         const float dx = pl.x - ml[0], dy = pl.y - ml[1], dz = pl.z - ml[2];
@@ -956,7 +956,6 @@ template <class T> struct FilterArgs {
     int32_t* flags;
     T r_in, r_in2;                            // r_list and r_list² as the reference forms them (dist_cutoff ^ 2)
     int exact_all;                            // small boxes: block-local coordinates are ambiguous, decide every pair exactly
-    int approx;                               // any superset of r_in will do (the force passes' inner list): no exact decisions in the band
     int eshift;                               // entry format of both lists (0 | ESHIFT_SCALED)
 };
 
@@ -1032,7 +1031,6 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_filter(FilterAr
                 float dx = pj.x - pil.x, dy = pj.y - pil.y, dz = pj.z - pil.z;
                 float r2 = dx * dx + dy * dy + dz * dz;
                 in = r2 < band_lo; maybe = !in && r2 <= band_hi;
-                if (A.approx) { in = in || maybe; maybe = false; }
             }
             if (maybe) {
                 T4 pj = A.pos[tix[slot]];
@@ -1122,14 +1120,7 @@ template <class T> struct ForceArgs {
     int any_special;                 // 0: no special (1-4) pair exists, the per-entry weight select is compiled out (uniform-LJ fluids)
     int soa;                         // != 0: the packed fp32 one-type loop with the tile as x[] / y[] / z[] arrays `soa` dwords apart
     int eshift;                      // entry format of the rows read and written (0 | ESHIFT_SCALED)
-    // Lanes sorted by row count.  A wave walks as many rows as its longest lane: 17 % of the slots of the 1M-atom inner list are
-    // padding, most of it because the split of an atom's neighbours over the j-split waves (tile slot mod JS) is uneven.  A PRUNE pass
-    // therefore emits, per j-split group, the rows of the block's atoms ordered by the number of entries they had at the prune before
-    // (cnt_src; right after a search: the length of their outer rows) — lane position perm⁻¹(atom) — and leaves the permutation in
-    // perm_dst; the passes over that list take it as lane_atom: lane L of group js works for atom lane_atom[js][L].  Each atom's own
-    // entries keep their order and the group sums are added per atom, so its force is the same sum as before.
-    const uint16_t* lane_atom;       // [n_blocks][JS][BI] (nullptr: lane = atom)
-    const uint16_t* cnt_src; uint16_t* cnt_dst; uint16_t* perm_dst;   // PRUNE: [n_blocks][JS][BI] entries kept per (j-split, atom); the permutation written
+    uint16_t* cnt_dst;               // PRUNE: [n_blocks][JS][BI] entries kept per (j-split, atom) — what k_regroup deals to the groups (nullable)
     // ghosted sub-domains: a pass over only the blocks whose tile holds no ghost atom (part 1: they can run while the ghost coordinates
     // are still on the wire) or only the others (part 2); 0 = every block
     const int32_t* blk_ghost; int part;
@@ -1239,9 +1230,7 @@ k_forces(ForceArgs<T> A) {
     constexpr bool NO_TRI = std::is_same<T, float>::value && LJM == LJ_DIST_UNIFORM && COULM == MHIP_COUL_NONE && !ENERGY;
     const bool tri_local = !MINIMG && !NO_TRI && G.tri_grid;
     const int li = tid & (A.BI - 1), js = tid >> A.BI_shift;
-    int ai = li;                                         // the atom of the block this lane works for
-    if constexpr (!PRUNE) { if (A.lane_atom) ai = (int)A.lane_atom[((int64_t)b * A.JS + js) * A.BI + li]; }
-    const int64_t si = (int64_t)b * A.BI + ai;
+    const int64_t si = (int64_t)b * A.BI + li;
     const bool valid = si < A.n_owned;
     // (STEP, whose lanes are in atom order: the atom again, from the lane number, where it is needed late — the compiler forms such addresses at the top of the
     // kernel otherwise, and carrying them past the pair loop costs the loop its 64 registers)
@@ -1291,7 +1280,6 @@ k_forces(ForceArgs<T> A) {
     [[maybe_unused]] uint16_t* l_new = nullptr; [[maybe_unused]] int32_t* l_scan = nullptr; [[maybe_unused]] float* l_box = nullptr;
     [[maybe_unused]] int32_t* l_cnt = nullptr; [[maybe_unused]] int32_t* l_wmax = nullptr; [[maybe_unused]] const uint2* l_lut = nullptr;
     [[maybe_unused]] int n_new = 0;          // compacted tile atoms so far (block-uniform)
-    [[maybe_unused]] int pos_l = li;         // PRUNE: the lane position this atom's rows are emitted at
     if constexpr (PRUNE) {
         l_new = reinterpret_cast<uint16_t*>(smem + A.mark_off);
         l_scan = reinterpret_cast<int32_t*>(smem + A.mark_off + ((A.T_lds + 8) & ~7) * 2);
@@ -1310,17 +1298,6 @@ k_forces(ForceArgs<T> A) {
                 ++p;
             }
             reinterpret_cast<uint2*>(l_cnt + nthr)[tid] = make_uint2(sel[0], sel[1]);
-        }
-        if (A.cnt_src) {     // rank of my atom among its j-split group's atoms by (entries last time, index): its lane position in the rows emitted now
-            l_cnt[tid] = ((int)A.cnt_src[((int64_t)b * A.JS + js) * A.BI + li] << 9) | li;
-            __syncthreads();
-            const int mine = l_cnt[tid];
-            const int32_t* grp = l_cnt + js * A.BI;
-            int rank = 0;
-            for (int q = 0; q < A.BI; q += 4) { const int4 v = *reinterpret_cast<const int4*>(grp + q); rank += (v.x < mine) + (v.y < mine) + (v.z < mine) + (v.w < mine); }
-            pos_l = rank;
-            A.perm_dst[((int64_t)b * A.JS + js) * A.BI + pos_l] = (uint16_t)li;
-            out_rows = A.nbr_dst + (((int64_t)b * A.JS + js) * A.R_cap) * A.BI + pos_l;
         }
         // bounding boxes of the i-atoms, eight per block (runs of BI/8 consecutive atoms: compact along the Hilbert curve), in the frame
         // of the staged tile (block-local coordinates).  One box per wave let half of a 64-atom water block's outer tile through.
@@ -1685,7 +1662,7 @@ k_forces(ForceArgs<T> A) {
         // after a barrier).  Every wave of a pass sees the whole tile, so which sub-list holds an entry changes nothing but the order of
         // the atom's sum — fixed, as before — and the pass walks 6 % fewer slots for a few stores per atom and prune (a separate
         // re-dealing pass over the 272 MB list cost what it saved, profiles/r04_force_ab.txt §2).
-        const bool level = A.level_pairs && A.JS == 2 && !A.cnt_src;
+        const bool level = A.level_pairs && A.JS == 2;
         if (level) {
             if (kept & 3) out_rows[(int64_t)(kept >> 2) * A.BI] = make_uint2((uint32_t)acc, (uint32_t)(acc >> 32));      // my pending entries: the row goes out as it is
             l_cnt[tid] = kept;
@@ -1702,10 +1679,10 @@ k_forces(ForceArgs<T> A) {
             kept = mine;
         }
         if (A.cnt_dst) A.cnt_dst[((int64_t)b * A.JS + js) * A.BI + li] = (uint16_t)min(kept, 65535);
-        // every lane pads to the row count of the wave its rows go to (its own wave unless the lanes are being sorted)
-        atomicMax(&l_wmax[js * NWB + (pos_l >> 6)], (kept + 3) >> 2);
+        // every lane pads to the row count of its wave
+        atomicMax(&l_wmax[js * NWB + (li >> 6)], (kept + 3) >> 2);
         __syncthreads();
-        const int rows_wave = l_wmax[js * NWB + (pos_l >> 6)];
+        const int rows_wave = l_wmax[js * NWB + (li >> 6)];
         if (level) {      // (the rows are in memory already: the padding goes there too, entry by entry)
             uint16_t* mine16 = reinterpret_cast<uint16_t*>(out_rows);
             for (int p2 = kept; p2 < 4 * rows_wave; ++p2) mine16[(((int64_t)(p2 >> 2) * A.BI) << 2) + (p2 & 3)] = (uint16_t)SENTP;
@@ -1742,14 +1719,14 @@ k_forces(ForceArgs<T> A) {
     }
     if (A.JS > 1) {   // deterministic reduction of the j-split partial sums through LDS
         __syncthreads();
-        T* red = reinterpret_cast<T*>(smem);     // (indexed by ATOM: the groups' lane orders may differ)
-        red[(js * 4 + 0) * A.BI + ai] = fx; red[(js * 4 + 1) * A.BI + ai] = fy;
-        red[(js * 4 + 2) * A.BI + ai] = fz; red[(js * 4 + 3) * A.BI + ai] = pe;
+        T* red = reinterpret_cast<T*>(smem);
+        red[(js * 4 + 0) * A.BI + li] = fx; red[(js * 4 + 1) * A.BI + li] = fy;
+        red[(js * 4 + 2) * A.BI + li] = fz; red[(js * 4 + 3) * A.BI + li] = pe;
         __syncthreads();
         if (js == 0) {
             for (int q = 1; q < A.JS; ++q) {
-                fx += red[(q * 4 + 0) * A.BI + ai]; fy += red[(q * 4 + 1) * A.BI + ai];
-                fz += red[(q * 4 + 2) * A.BI + ai]; pe += red[(q * 4 + 3) * A.BI + ai];
+                fx += red[(q * 4 + 0) * A.BI + li]; fy += red[(q * 4 + 1) * A.BI + li];
+                fz += red[(q * 4 + 2) * A.BI + li]; pe += red[(q * 4 + 3) * A.BI + li];
             }
         }
     }
@@ -1792,7 +1769,10 @@ k_forces(ForceArgs<T> A) {
             }
         }
         if (A.cm_out || A.trk_part) {      // per-block sums / maxima: the waves of the i-atoms (js == 0) by rows, then through LDS, in the fixed order of the integrator kernels
-            // (BEHIND the words of the j-split reduction, which slower waves may still be reading: no barrier in front of these stores; the tile they overwrite is done with)
+            // (BEHIND the words of the j-split reduction, which slower waves may still be reading: with a j-split its barriers also mean every wave is done with the
+            // tile these stores overwrite — a block of several i-waves WITHOUT a j-split has had no barrier since the staging: one here, or a fast wave's sums land in
+            // tile coordinates a slower wave is still gathering)
+            if (A.JS == 1 && A.BI > 64) __syncthreads();
             double* shd = reinterpret_cast<double*>(smem + (((size_t)A.JS * 4 * A.BI * sizeof(T) + 15) & ~(size_t)15));          // [waves][4 rows][4] doubles, then [waves][4 rows][4] floats
             const int le = step_lane(), nw = A.BI >> 6, w = le >> 6, ln = le & 63;
             float* shf = reinterpret_cast<float*>(shd + 16 * nw);
@@ -1824,9 +1804,9 @@ k_forces(ForceArgs<T> A) {
             for (int half = 0; half < 2; ++half) {
                 __syncthreads();
 #pragma unroll
-                for (int c = 0; c < 3; ++c) red[(js * 4 + c) * A.BI + ai] = vir[3 * half + c];
+                for (int c = 0; c < 3; ++c) red[(js * 4 + c) * A.BI + li] = vir[3 * half + c];
                 __syncthreads();
-                if (js == 0) for (int q = 1; q < A.JS; ++q) for (int c = 0; c < 3; ++c) vir[3 * half + c] += red[(q * 4 + c) * A.BI + ai];
+                if (js == 0) for (int q = 1; q < A.JS; ++q) for (int c = 0; c < 3; ++c) vir[3 * half + c] += red[(q * 4 + c) * A.BI + li];
             }
         }
         // block sums of the energy and the six virial components, each halved (every pair is visited from both ends);
@@ -1834,58 +1814,12 @@ k_forces(ForceArgs<T> A) {
         __syncthreads();
         double* dred = reinterpret_cast<double*>(smem);
         for (int c = 0; c < 7; ++c) {
-            if (js == 0) dred[ai] = valid ? 0.5 * (double)(c == 0 ? pe : vir[c - 1]) : 0.0;
+            if (js == 0) dred[li] = valid ? 0.5 * (double)(c == 0 ? pe : vir[c - 1]) : 0.0;
             __syncthreads();
             if (tid == 0) { double s = 0; for (int q = 0; q < A.BI; ++q) s += dred[q]; A.pe_part[(int64_t)c * A.n_blocks + b] = s; }
             __syncthreads();
         }
     }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Dealing an atom's inner-list entries evenly over its j-split waves.  k_build gives wave js of a block the tile atoms t ≡ js (mod JS), and
-// the pruning pass keeps that split; how many of an atom's n neighbours fall to one wave is then binomial(n, 1/JS), and a wave walks as many
-// rows as its longest lane: with 16 sub-lists of ≈ 28 entries (6mrr: 64-atom blocks × 16 waves) the longest of 64 lanes holds ≈ 40, and 38 %
-// of the slots a pass evaluates are padding (1M-atom fluid, two sub-lists of ≈ 58: 17 %).  Nothing in the force pass depends on WHICH
-// entries a wave holds — every wave sees the whole tile — so after each prune this kernel re-deals them: the atom's entries, in the order
-// sub-list 0, 1, …, are cut into JS runs of ⌈n/JS⌉ and run js becomes the new sub-list js (same row format; the order of an atom's
-// entries and hence the set per wave changes, the set per atom does not: the force is the same sum in another, still fixed, order).
-// src / cnt: what the prune wrote (rows [b][js][r][lane], kept entries per (b, js, lane)); dst / rows_dst: the balanced list.
-struct RebalArgs { int BI, BI_shift, JS, R_cap, eshift; const uint2* src; const uint16_t* cnt; const int32_t* tile_cnt; uint2* dst; int32_t* rows_dst; };
-[[maybe_unused]] static __global__ void __launch_bounds__(1024) k_rebalance(RebalArgs A) {
-    extern __shared__ __align__(16) unsigned char rb_smem[];
-    int32_t* l_cnt = reinterpret_cast<int32_t*>(rb_smem);                 // [JS][BI]
-    const int b = blockIdx.x, tid = threadIdx.x, li = tid & (A.BI - 1), js = tid >> A.BI_shift;
-    const int64_t sub0 = (int64_t)b * A.JS;
-    l_cnt[js * A.BI + li] = (int)A.cnt[(sub0 + js) * A.BI + li];
-    __syncthreads();
-    int total = 0;
-    for (int q = 0; q < A.JS; ++q) total += l_cnt[q * A.BI + li];
-    const int per = (total + A.JS - 1) / A.JS;                              // entries of this atom per destination wave
-    const int k0 = min(js * per, total), k1 = min(k0 + per, total);
-    int rows = (k1 - k0 + 3) >> 2;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) rows = max(rows, __shfl_xor(rows, o, WAVE));
-    if ((tid & (WAVE - 1)) == 0) A.rows_dst[(sub0 + js) * (A.BI >> 6) + (li >> 6)] = rows;
-    uint2* out = A.dst + ((sub0 + js) * A.R_cap) * A.BI + li;
-    uint64_t acc = 0; int n = 0;
-    auto put = [&](uint32_t e) {
-        acc |= (uint64_t)e << ((n & 3) * 16);
-        if ((n & 3) == 3) { out[(int64_t)(n >> 2) * A.BI] = make_uint2((uint32_t)acc, (uint32_t)(acc >> 32)); acc = 0; }
-        ++n;
-    };
-    int sj = 0, base = 0, c = l_cnt[li];                                    // source sub-list, its first entry's number, its length
-    for (int k = k0; k < k1;) {
-        const int idx = k - base;
-        if (idx >= c) { base += c; ++sj; c = l_cnt[sj * A.BI + li]; continue; }
-        const uint2 row = A.src[((sub0 + sj) * A.R_cap + (idx >> 2)) * A.BI + li];
-        const uint64_t w = (uint64_t)row.x | ((uint64_t)row.y << 32);
-        const int sub = idx & 3, take = min(4 - sub, min(c - idx, k1 - k));
-        for (int t = 0; t < take; ++t) put((uint32_t)(w >> ((sub + t) * 16)) & 0xffffu);
-        k += take;
-    }
-    const uint32_t SENT = make_entry((uint32_t)A.tile_cnt[b], 0u, A.eshift);
-    while ((n & 3) != 0 || (n >> 2) < rows) put(SENT);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1970,17 +1904,16 @@ __global__ void k_vv1(int64_t n, typename Vec<T>::T4* pos, typename Vec<T>::T4* 
     }
 }
 
-// fa / fb (nullable): force contributions computed concurrently on the side streams (bonded terms, PME reciprocal space); they are
-// folded in here and the total is written back so that the next first kick sees it
+// fa (nullable): a second force array — the bonded sums + reciprocal-space forces of a small system's fused launches (step_fused.h) —
+// folded in here; the total is written back so that the next first kick sees it
 template <class T, bool CM>
 __global__ void k_vv2(int64_t n, typename Vec<T>::T4* vel, typename Vec<T>::T4* frc, T dt2, double* cm_part,
-                      const typename Vec<T>::T4* __restrict__ fa, const typename Vec<T>::T4* __restrict__ fb) {
+                      const typename Vec<T>::T4* __restrict__ fa) {
     double px = 0, py = 0, pz = 0, m = 0;
     for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
         auto v = vel[s]; auto f = frc[s];
         if (fa) { const auto g = fa[s]; f.x += g.x; f.y += g.y; f.z += g.z; }
-        if (fb) { const auto g = fb[s]; f.x += g.x; f.y += g.y; f.z += g.z; }
-        if (fa || fb) frc[s] = f;
+        if (fa) frc[s] = f;
         v.x = step_add(v.x, accel_of(f.x, v.w), dt2); v.y = step_add(v.y, accel_of(f.y, v.w), dt2); v.z = step_add(v.z, accel_of(f.z, v.w), dt2);   // :616
         vel[s] = v;
         if constexpr (CM) { px += (double)v.x * v.w; py += (double)v.y * v.w; pz += (double)v.z * v.w; m += v.w; }
@@ -2005,7 +1938,7 @@ __global__ void k_vv2(int64_t n, typename Vec<T>::T4* vel, typename Vec<T>::T4* 
 template <class T, bool CM, bool LAST>
 __global__ void k_vv_mid(int64_t n, typename Vec<T>::T4* pos, typename Vec<T>::T4* vel, const typename Vec<T>::T4* __restrict__ fr, T dt, T dt2,
                          const double* __restrict__ cm_in, int n_cm_in, double* cm_out,
-                         const typename Vec<T>::T4* __restrict__ fa, const typename Vec<T>::T4* __restrict__ fb, GridP<T> G,
+                         const typename Vec<T>::T4* __restrict__ fa, GridP<T> G,
                          const typename Vec<T>::T4* __restrict__ snap_a = nullptr, const typename Vec<T>::T4* __restrict__ snap_b = nullptr, float* trk_part = nullptr) {
     const typename Vec<T>::T4* __restrict__ frc = fr;
     // trk_part (the validity check of the pair lists, taken where the new coordinates are made): per block the largest |x − snap_a|²,
@@ -2018,12 +1951,11 @@ __global__ void k_vv_mid(int64_t n, typename Vec<T>::T4* pos, typename Vec<T>::T
     using T4q = typename Vec<T>::T4;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, sn = s;
-    T4q vq = make4<T>(T(0), T(0), T(0), T(1)), fq = vq, pq = vq, gaq = vq, gbq = vq;
+    T4q vq = make4<T>(T(0), T(0), T(0), T(1)), fq = vq, pq = vq, gaq = vq;
     auto fetch = [&](int64_t a) {
         vq = vel[a]; fq = frc[a];
         if (!LAST || sub) pq = pos[a];
         if (fa) gaq = fa[a];
-        if (fb) gbq = fb[a];
     };
     if (s < n) fetch(s);
     if (sub) block_vcm<T>(cm_in, n_cm_in, vc);
@@ -2031,11 +1963,10 @@ __global__ void k_vv_mid(int64_t n, typename Vec<T>::T4* pos, typename Vec<T>::T
     double px = 0, py = 0, pz = 0, m = 0;
     for (; s < n; s = sn) {
         sn = s + stride;
-        const auto v0 = vq, f0 = fq, p0 = pq, ga0 = gaq, gb0 = gbq;
+        const auto v0 = vq, f0 = fq, p0 = pq, ga0 = gaq;
         if (sn < n) fetch(sn);                                                 // the next atom's data travel while this one is integrated
         auto v = v0; auto f = f0; auto p = p0;
         if (fa) { f.x += ga0.x; f.y += ga0.y; f.z += ga0.z; }
-        if (fb) { f.x += gb0.x; f.y += gb0.y; f.z += gb0.z; }
         if (sub) {                                                             // remove_CM_motion! of the previous step, one launch late
             v.x -= vc[0]; v.y -= vc[1]; v.z -= vc[2];
             p.x = M<T>::sub(p.x, sh[0]); p.y = M<T>::sub(p.y, sh[1]); p.z = M<T>::sub(p.z, sh[2]);
@@ -2051,7 +1982,7 @@ __global__ void k_vv_mid(int64_t n, typename Vec<T>::T4* pos, typename Vec<T>::T
             wrap_point(p.x, p.y, p.z, G);                                      // :609
             pos[s] = p;
         }
-        if (LAST && (fa || fb)) const_cast<typename Vec<T>::T4*>(frc)[s] = f;  // the total force of the last step stays readable
+        if (LAST && fa) const_cast<typename Vec<T>::T4*>(frc)[s] = f;  // the total force of the last step stays readable
         vel[s] = v;
         if (trk_part) {
             v2m = fmaxf(v2m, (float)(v.x * v.x + v.y * v.y + v.z * v.z));
@@ -2083,13 +2014,12 @@ __global__ void k_vv_mid(int64_t n, typename Vec<T>::T4* pos, typename Vec<T>::T
     }
 }
 
-// frc += fa (+ fb): the same fold outside the integrator
+// frc += fa: the same fold outside the integrator
 template <class T>
-__global__ void k_add_forces(int64_t n, typename Vec<T>::T4* frc, const typename Vec<T>::T4* __restrict__ fa, const typename Vec<T>::T4* __restrict__ fb) {
+__global__ void k_add_forces(int64_t n, typename Vec<T>::T4* frc, const typename Vec<T>::T4* __restrict__ fa) {
     for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
         auto f = frc[s];
         if (fa) { const auto g = fa[s]; f.x += g.x; f.y += g.y; f.z += g.z; }
-        if (fb) { const auto g = fb[s]; f.x += g.x; f.y += g.y; f.z += g.z; }
         frc[s] = f;
     }
 }

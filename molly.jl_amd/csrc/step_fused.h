@@ -22,12 +22,12 @@ __global__ void __launch_bounds__(256) k_spread_bonded(int64_t n_atoms, const ty
     bonded_terms<T, false, true>(B, ((int)blockIdx.x - n_spread) * 4 + (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), 64, e);   // four 64-lane term blocks per workgroup
 }
 
-template <class T, int ORDER, bool STORE = false>
+template <class T, int ORDER>
 __global__ void __launch_bounds__(256) k_gather_collect(int64_t n_atoms, const typename Vec<T>::T4* __restrict__ pos, const T* __restrict__ phi, typename Vec<T>::T4* frc, PmeP<T> P,
                                                         int n_gather, const int32_t* __restrict__ orig, const int32_t* __restrict__ role_start, const int32_t* __restrict__ role_slot,
                                                         const typename Vec<T>::T4* __restrict__ slots, typename Vec<T>::T4* side,
                                                         const typename Vec<T>::T4* __restrict__ parts, int n_parts, int64_t part_stride) {
-    if ((int)blockIdx.x < n_gather) { pme_gather_blocks<T, ORDER, STORE>((int)blockIdx.x, n_gather, n_atoms, pos, phi, frc, P); return; }
+    if ((int)blockIdx.x < n_gather) { pme_gather_blocks<T, ORDER>((int)blockIdx.x, n_gather, n_atoms, pos, phi, frc, P); return; }
     bonded_collect_lane<T, true>(((int64_t)blockIdx.x - n_gather) * blockDim.x + threadIdx.x, n_atoms, orig, role_start, role_slot, slots, side, parts, n_parts, part_stride);
 }
 
@@ -108,22 +108,19 @@ __global__ void __launch_bounds__(256) k_gather_collect_vv(GcvArgs<T> A) {
     if (A.trk_part && tid < 3) { float m = 0.f; for (int t = 0; t < PME_AB; ++t) m = fmaxf(m, l_tr[t][tid]); A.trk_part[tid * gridDim.x + blockIdx.x] = m; }
 }
 
-// reciprocal-space PME forces added to frc (store: written to frc, every owned atom), bonded forces left in `side` (every owned atom written)
+// reciprocal-space PME forces added to frc, bonded forces left in `side` (every owned atom written)
 template <class T>
 inline void launch_pme_bonded_fused(hipStream_t s, Pme<T>& pme, Bonded<T>& bonded, const GridP<T>& G, const InterP<T>& I, int64_t n_owned, int64_t cap,
-                                    const typename Vec<T>::T4* pos, const int32_t* inv, const int32_t* orig, typename Vec<T>::T4* frc, typename Vec<T>::T4* side, bool store = false,
+                                    const typename Vec<T>::T4* pos, const int32_t* inv, const int32_t* orig, typename Vec<T>::T4* frc, typename Vec<T>::T4* side,
                                     bool spread_done = false,        // spread_done: the charges are on the mesh and the terms in their slots already (forces_gs.hip's fused launch)
                                     const GcvArgs<T>* vv = nullptr) {      // vv: the last launch integrates (its dt / v_cm / partial / tracking fields filled in by the caller); frc then holds the pair forces and is only read
     bonded.ensure_roles(s, cap);
     const BondedArgs<T> B = bonded.slot_args(G, I, pos, inv);
     const int n_term_wg = cdiv(bonded.n_blocks(), 4);
-    static const int sb = [] { const char* v = std::getenv("MOLLYHIP_PME_SPREAD_BATCH"); return v && *v ? std::atoi(v) : 64; }();   // atoms per spreading batch
-    const int n_spread = (int)std::min<int64_t>(cdiv(n_owned, (int64_t)(sb <= 16 ? 16 : sb <= 32 ? 32 : 64)), 4096);
+    const int n_spread = (int)std::min<int64_t>(cdiv(n_owned, (int64_t)64), 4096);      // 64 atoms per spreading batch
     auto spread = [&](auto order_tag) {
         constexpr int ORDER = decltype(order_tag)::value;
-        if (sb <= 16) hipLaunchKernelGGL((k_spread_bonded<T, ORDER, 16>), dim3(n_spread + n_term_wg), dim3(256), 0, s, n_owned, pos, pme.rgrid.p, pme.P, n_spread, B);
-        else if (sb <= 32) hipLaunchKernelGGL((k_spread_bonded<T, ORDER, 32>), dim3(n_spread + n_term_wg), dim3(256), 0, s, n_owned, pos, pme.rgrid.p, pme.P, n_spread, B);
-        else hipLaunchKernelGGL((k_spread_bonded<T, ORDER, 64>), dim3(n_spread + n_term_wg), dim3(256), 0, s, n_owned, pos, pme.rgrid.p, pme.P, n_spread, B);
+        hipLaunchKernelGGL((k_spread_bonded<T, ORDER, 64>), dim3(n_spread + n_term_wg), dim3(256), 0, s, n_owned, pos, pme.rgrid.p, pme.P, n_spread, B);
     };
     if (!spread_done) { if (pme.order == 4) spread(std::integral_constant<int, 4>{}); else if (pme.order == 5) spread(std::integral_constant<int, 5>{}); else spread(std::integral_constant<int, 6>{}); }
     pme.mesh_to_potential(s, nullptr, true);
@@ -131,9 +128,7 @@ inline void launch_pme_bonded_fused(hipStream_t s, Pme<T>& pme, Bonded<T>& bonde
     const int n_collect = (int)cdiv(n_owned * COLLECT_LANES, (int64_t)256);
     auto gather = [&](auto order_tag) {
         constexpr int ORDER = decltype(order_tag)::value;
-        if (store) hipLaunchKernelGGL((k_gather_collect<T, ORDER, true>), dim3(n_gather + n_collect), dim3(256), 0, s, n_owned, pos, (const T*)pme.phi.p, frc, pme.P, n_gather, orig,
-                           (const int32_t*)bonded.role_start.p, (const int32_t*)bonded.role_slot.p, (const typename Vec<T>::T4*)bonded.slots, side, bonded.fold_parts, bonded.fold_n, bonded.fold_stride);
-        else hipLaunchKernelGGL((k_gather_collect<T, ORDER>), dim3(n_gather + n_collect), dim3(256), 0, s, n_owned, pos, (const T*)pme.phi.p, frc, pme.P, n_gather, orig,
+        hipLaunchKernelGGL((k_gather_collect<T, ORDER>), dim3(n_gather + n_collect), dim3(256), 0, s, n_owned, pos, (const T*)pme.phi.p, frc, pme.P, n_gather, orig,
                            (const int32_t*)bonded.role_start.p, (const int32_t*)bonded.role_slot.p, (const typename Vec<T>::T4*)bonded.slots, side, bonded.fold_parts, bonded.fold_n, bonded.fold_stride);
     };
     if (vv) {

@@ -49,7 +49,7 @@ def choose_grid(world, box):
 
 
 import os as _os
-CM_PARTS = int(_os.environ.get("MOLLYHIP_CM_PARTS", "256"))   # per-rank partial sums of the centre-of-mass momentum carried by the all-reduce (8 KB)
+CM_PARTS = 256   # per-rank partial sums of the centre-of-mass momentum carried by the all-reduce (8 KB)
 
 
 class BrickGrid:
@@ -352,7 +352,7 @@ class DomainRun:
         self._dev_replans_seen = 0
         self._counters = (C.c_int64 * 3)(0, 0, 0)
         self.stats = {"exchange_calls": 0, "ghost_atoms": 0, "migrated": 0, "plans": 0, "plan_checks": 0, "prunes": 0, "interior_passes": 0}
-        self.overlap = _os.environ.get("MOLLYHIP_HALO_OVERLAP", "1") != "0" and hasattr(engine, "halo_interior")
+        self.overlap = hasattr(engine, "halo_interior")      # interior blocks while the ghosts travel (host loop)
         # gloo cannot move device memory: stage through the host (used by the multi-process tests that share ONE GPU;
         # the production path is backend "nccl" = RCCL, device buffers end to end)
         self.stage_host = torch.device(device).type == "cuda" and dist.get_backend(group) == "gloo"

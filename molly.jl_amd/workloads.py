@@ -18,7 +18,7 @@ def pme_mesh(box, alpha, error_tol=0.0005):
 class Case:
     def __init__(self, coords, box, lj=None, coul=None, r_list=math.inf, rebuild_every=10, velocities=None, charge=None,
                  sigma=None, eps=None, mass=None, excluded=None, special=None, bonds=None, angles=None, torsions=None,
-                 ewald_excl=None, name="case", pme=None, triclinic=None):
+                 ewald_excl=None, name="case", pme=None, triclinic=None, lam=None):
         """lj: None | dict(cutoff=(kind, rc[, ra]), weight_special=1.0)
         coul: None | dict(kind="plain"|"rf"|"ewald", cutoff=(kind, rc[, ra]) (plain), rc=…, eps_rf=78.3, tol=5e-4,
                           approx=True, weight_special=1.0)"""
@@ -29,6 +29,7 @@ class Case:
         self.r_list, self.rebuild_every = r_list, rebuild_every
         self.velocities = None if velocities is None else np.asarray(velocities, dtype=np.float64)
         self.charge, self.sigma, self.eps, self.mass = charge, sigma, eps, mass
+        self.lam = lam       # None | per-atom λ (Atom.λ, types.jl:466-475): the unsoftened interactions read it in the LJZeroShortcut only (mixing.jl:7-11)
         self.excluded, self.special = excluded, special
         self.bonds, self.angles, self.torsions, self.ewald_excl = bonds, angles, torsions, ewald_excl
         self.name = name
@@ -116,7 +117,7 @@ class Case:
         return m.System(coords=self.coords if coords is None else coords, boundary=boundary,
                         velocities=self.velocities if velocities is None else velocities, pairwise_inters=tuple(inters),
                         specific_inter_lists=tuple(sils), neighbor_finder=nf, dtype=dtype, charge=self.charge,
-                        sigma=self.sigma, eps=self.eps, mass=self.mass, general_inters=tuple(gis))
+                        sigma=self.sigma, eps=self.eps, mass=self.mass, general_inters=tuple(gis), lam=self.lam)
 
 
 # ---- SURVEY §8(d) synthetic LJ fluid (argon at 1400 kg/m³, benchmark/benchmark_gpu_tiles.jl:18-25) ------

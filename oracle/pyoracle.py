@@ -54,7 +54,7 @@ class OrcSystem(C.Structure):
                 ("n_ewx", C.c_int64), ("x_i", C.c_void_p), ("x_j", C.c_void_p),
                 ("pme_order", C.c_int32), ("pme_mesh", C.c_int32 * 3), ("pme_eps_r", C.c_double),
                 ("andersen_kT", C.c_double), ("andersen_prob", C.c_double), ("andersen_seed", C.c_uint64),
-                ("triclinic", C.c_int32), ("pad1", C.c_int32), ("tri_bv", C.c_double * 9)]
+                ("triclinic", C.c_int32), ("pad1", C.c_int32), ("tri_bv", C.c_double * 9), ("lam", C.c_void_p)]
 
 
 def build(native=False, quiet=True):
@@ -119,7 +119,7 @@ class OracleSystem:
 
     def __init__(self, coords, box, inter, dtype=np.float64, velocities=None, charge=None, sigma=None, eps=None,
                  mass=None, r_list=float("inf"), rebuild_every=10, excluded=None, special=None, bonds=None,
-                 angles=None, torsions=None, ewald_excl=None, native=False, pme=None, triclinic=None):
+                 angles=None, torsions=None, ewald_excl=None, native=False, pme=None, triclinic=None, lam=None):
         self.dtype = np.dtype(dtype)
         self.prec = 32 if self.dtype == np.float32 else 64
         T = self.dtype
@@ -131,6 +131,7 @@ class OracleSystem:
         self.sigma = z.copy() if sigma is None else np.ascontiguousarray(sigma, dtype=T)
         self.eps = z.copy() if eps is None else np.ascontiguousarray(eps, dtype=T)
         self.mass = np.ones(self.n, T) if mass is None else np.ascontiguousarray(mass, dtype=T)
+        self.lam = None if lam is None else np.ascontiguousarray(lam, dtype=T)      # Atom.λ (None: all 1)
         self.box = np.asarray(box, dtype=np.float64).reshape(3)
         self.inter = inter if isinstance(inter, Interactions) else make_interactions(inter)
         self.r_list = float(r_list)
@@ -151,7 +152,7 @@ class OracleSystem:
         s = OrcSystem()
         s.n = self.n
         s.coords = _ptr(self.coords); s.vel = _ptr(self.vel); s.charge = _ptr(self.charge)
-        s.sigma = _ptr(self.sigma); s.eps = _ptr(self.eps); s.mass = _ptr(self.mass)
+        s.sigma = _ptr(self.sigma); s.eps = _ptr(self.eps); s.mass = _ptr(self.mass); s.lam = _ptr(self.lam)
         for d in range(3):
             s.box[d] = self.box[d]
         s.inter = self.inter
@@ -316,4 +317,4 @@ def from_case(case, dtype=np.float64, coords=None, velocities=None):
                         charge=case.charge, sigma=case.sigma, eps=case.eps, mass=case.mass, r_list=case.r_list,
                         rebuild_every=case.rebuild_every, excluded=case.excluded, special=case.special,
                         bonds=case.bonds, angles=case.angles, torsions=None if case.torsions is None else dict(case.torsions),
-                        ewald_excl=case.ewald_excl, pme=case.pme_params(dtype), triclinic=case.triclinic)
+                        ewald_excl=case.ewald_excl, pme=case.pme_params(dtype), triclinic=case.triclinic, lam=getattr(case, "lam", None))

@@ -63,6 +63,28 @@ def fp32_force_tolerance(case, coords=None, rel=4e-5):
     return rel * scale + 1.01 * jump + 1e-6, o, nl
 
 
+def fp32_check(err, tol, what="fp32 forces against the fp64 oracle"):
+    """assert err <= tol per atom, and leave how much of the bar was used in gpurun_out/tolerance_slack.jsonl (merged back from the GPU box; the table
+    of a round is committed as profiles/rNN_tolerance_slack.jsonl).  The bar is fp32_force_tolerance's 4e-5·Σ_j‖f_ij‖ — FOUR TIMES the 1e-5 that
+    SURVEY.md:622 states (first paragraph: the reference's own arithmetic in fp32 measures 2.9e-5) — so a ratio above 0.25 here is a
+    test that would fail the survey's bar."""
+    import json
+    err, tol = np.asarray(err, dtype=np.float64), np.asarray(tol, dtype=np.float64)
+    ratio = float((err / tol).max())
+    row = {"test": os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], "what": what + ": worst per-atom error / (4e-5·Σ‖f_ij‖ + cutoff jumps + 1e-6)", "achieved": ratio,
+           "allowed": 1.0, "ratio": ratio, "atoms_over_survey_bar_1e-5": int((err > 0.25 * tol).sum()), "n_atoms": int(err.size)}
+    print(f"[slack] {row['test']}: {what}: worst err/tol {ratio:.3f}; {row['atoms_over_survey_bar_1e-5']} of {err.size} atoms above a quarter of the bar")
+    try:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "tolerance_slack.jsonl"), "a") as f:
+            f.write(json.dumps(row) + "\n")
+    except OSError:
+        pass
+    w = int((err / tol).argmax())
+    assert ratio <= 1.0, f"{what}: {int((err > tol).sum())} atoms over the bar, worst err/tol {ratio:.3f} (atom {w}: err {err[w]:.3e}, tol {tol[w]:.3e})"
+
+
 def rel_rms(err, f_ref):
     return float(np.sqrt((err ** 2).sum() / (np.linalg.norm(f_ref, axis=1) ** 2).sum()))
 

@@ -21,7 +21,7 @@ def _check_forces(pkg, case, dtype, rel64=1e-9):
     else:
         tol, o, nl = S.fp32_force_tolerance(case)
         fo = o.forces(nl)
-        assert np.all(np.linalg.norm(f.astype(np.float64) - fo, axis=1) <= tol)
+        S.fp32_check(np.linalg.norm(f.astype(np.float64) - fo, axis=1), tol)
     return s, f
 
 

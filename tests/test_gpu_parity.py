@@ -86,7 +86,7 @@ def test_forces_and_energy_fp32(pkg, coul):
     s = case.system(pkg, np.float32)
     f = pkg.forces(s).astype(np.float64)
     err = np.linalg.norm(f - f_ref, axis=1)
-    assert np.all(err <= tol), f"worst atom: err {err.max():.3e}, tol there {tol[err.argmax()]:.3e}"
+    S.fp32_check(err, tol)
     assert S.rel_rms(err, f_ref) <= max(1.5 * S.fp32_reference_rms(case, f_ref), 5e-6)
     e_ref = o.potential_energy(nl)
     e = pkg.potential_energy(s)
@@ -323,7 +323,7 @@ def test_full_size_256k_lj_against_oracle(pkg):
     s = case.system(pkg, np.float32)
     f = pkg.forces(s).astype(np.float64)
     err = np.linalg.norm(f - f_ref, axis=1)
-    assert np.all(err <= tol), f"worst err {err.max():.3e} tol {tol[err.argmax()]:.3e}"
+    S.fp32_check(err, tol)
     assert S.rel_rms(err, f_ref) <= max(1.5 * S.fp32_reference_rms(case, f_ref), 5e-6)
     # Newton's third law: both directions of a pair are evaluated independently in fp32, so ΣF vanishes to rounding
     assert np.abs(f.sum(axis=0)).max() < 1e-6 * o.pair_force_scale.sum()
@@ -351,7 +351,7 @@ def test_full_size_256k_lj_against_oracle(pkg):
     tol3, o3, nl3 = S.fp32_force_tolerance(case, coords=s.coords.astype(np.float64))
     f3 = pkg.forces(s, step_n=40).astype(np.float64)
     err3 = np.linalg.norm(f3 - o3.forces(nl3, nthreads=8), axis=1)
-    assert np.all(err3 <= tol3), f"after a prune: worst err/tol {(err3 / tol3).max():.3f}"
+    S.fp32_check(err3, tol3, "fp32 forces after a prune")
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
@@ -433,7 +433,56 @@ def test_single_pair_list_with_128_and_256_atom_blocks(pkg, kind, n_side, monkey
     st = s.stats()
     assert st["block_atoms"] >= 128, st["block_atoms"]
     err = np.linalg.norm(f - f_ref, axis=1)
-    assert np.all(err <= tol), f"{int((err > tol).sum())} atoms over the bar, worst err/tol {(err / tol).max():.3g}"
+    S.fp32_check(err, tol)
     keys, n_special = S.export_keys(pkg, s)
     oi, oj, osp = case.oracle(np.float32).neighbors("cell", nthreads=16)
     assert np.array_equal(keys, S.pair_keys(oi, oj)) and n_special == int(np.asarray(osp).sum())
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_per_atom_lambda_zero_switches_the_lennard_jones_pair_off(pkg, dtype):
+    """Atom.λ (types.jl:466-475) enters the unsoftened interactions through the LJZeroShortcut alone: a pair with λ = 0 on either side has no
+    Lennard-Jones force or energy (mixing.jl:7-11), its Coulomb part is untouched (coulomb.jl:81 reads the charge only), and it STAYS in the
+    neighbour list (neighbors.jl:409-411 knows nothing of λ).  mhip_set_atoms(lambda) against the oracle's restatement of the shortcut: forces,
+    energy and the pair set, with every seventh atom at λ = 0, a few at λ = 0.5 (no effect without soft core) and the rest at 1."""
+    base = S.charged_fluid(12, dict(kind="rf", rc=1.0, weight_special=0.8333333333333334), dtype=dtype, stable=True)
+    lam = np.ones(base.n)
+    lam[::7] = 0.0
+    lam[3::11] = 0.5
+    case = S.Case(base.coords, base.box, lj=base.lj, coul=base.coul, r_list=base.r_list, rebuild_every=base.rebuild_every, velocities=base.velocities,
+                  charge=base.charge, sigma=base.sigma, eps=base.eps, mass=base.mass, excluded=base.excluded, special=base.special, lam=lam)
+    s = case.system(pkg, dtype)
+    off = lam == 0
+    assert s.λ is not None and (s.λ == 0).sum() == off.sum()
+    f = pkg.forces(s).astype(np.float64)
+    if dtype == np.float64:
+        o = case.oracle(np.float64)
+        nl = o.neighbors("cell")
+        f_ref = o.forces(nl)
+        assert np.abs(f - f_ref).max() <= 1e-9 * np.abs(f_ref).max() + 1e-7
+        assert pkg.potential_energy(s) == pytest.approx(o.potential_energy(nl), rel=1e-10, abs=1e-6)
+    else:
+        tol, o, nl = S.fp32_force_tolerance(case)
+        f_ref = o.forces(nl)
+        S.fp32_check(np.linalg.norm(f - f_ref, axis=1), tol, "fp32 forces with per-atom λ")
+    # the shortcut really bites: the same system with every λ = 1 has other forces on the λ = 0 atoms (and on their neighbours) …
+    f_all = base.oracle(np.float64).forces(base.oracle(np.float64).neighbors("cell"))
+    assert np.linalg.norm(f_all - f_ref, axis=1)[off].max() > 1e-2 * np.linalg.norm(f_all, axis=1).mean()
+    # … and equals the system whose λ = 0 atoms have ϵ = 0 instead (the engine folds λ = 0 in as σ = ϵ = 0: DESIGN §3)
+    eps0 = np.where(lam == 0, 0.0, np.broadcast_to(np.asarray(base.eps, dtype=np.float64), (base.n,)))
+    twin = S.Case(base.coords, base.box, lj=base.lj, coul=base.coul, r_list=base.r_list, rebuild_every=base.rebuild_every, charge=base.charge, sigma=base.sigma,
+                  eps=eps0, mass=base.mass, excluded=base.excluded, special=base.special).oracle(np.float64)
+    assert np.abs(twin.forces(twin.neighbors("cell")) - f_ref).max() <= 1e-12 * np.abs(f_ref).max()
+    # λ does not touch the neighbour list
+    keys, n_special = S.export_keys(pkg, s)
+    oi, oj, osp = case.oracle(dtype).neighbors("cell")
+    assert np.array_equal(keys, S.pair_keys(oi, oj)) and n_special == int(np.asarray(osp).sum())
+    # a one-type LJ fluid with some λ = 0 atoms must leave the uniform fast path (k_uniform_check) and still be right
+    lj = S.lj_fluid(12, dtype=dtype)
+    lam2 = np.ones(lj.n); lam2[5::9] = 0.0
+    case2 = S.Case(lj.coords, lj.box, lj=lj.lj, r_list=lj.r_list, rebuild_every=lj.rebuild_every, velocities=lj.velocities, sigma=lj.sigma, eps=lj.eps, mass=lj.mass, lam=lam2)
+    o2 = case2.oracle(np.float64)
+    f2_ref = o2.forces(o2.neighbors("cell"))
+    f2 = pkg.forces(case2.system(pkg, dtype)).astype(np.float64)
+    assert np.abs(f2[lam2 == 0]).max() == 0.0 and np.abs(f2_ref[lam2 == 0]).max() == 0.0
+    assert np.abs(f2 - f2_ref).max() <= (1e-9 if dtype == np.float64 else 2e-4) * np.abs(f2_ref).max()

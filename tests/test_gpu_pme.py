@@ -129,6 +129,9 @@ def test_100_step_pme_trajectory_vs_openmm_fp32(pkg, slack):
     case = G.case("ewald", np.float32, bonded=True, pme=True)
     s = case.system(pkg, np.float32)
     pkg.simulate(s, pkg.VelocityVerlet(dt=0.0005), 100)
+    st = s.stats()
+    # the timed path itself: the group-split pair pass with spreading and bonded terms in its launch, and the step's last launch integrating (k_gather_collect_vv)
+    assert st["n_fused_steps"] > 60 and st["n_group_split_passes"] > 60, (st["n_fused_steps"], st["n_group_split_passes"])
     xo = d["openmm_coordinates_100steps"]; box = case.box
     dx = s.coords.astype(np.float64) - (xo - np.floor(xo / box) * box)
     dx -= np.round(dx / box) * box

@@ -240,5 +240,5 @@ def test_triclinic_fp32_charged_per_atom_lj_small_cell_is_finite_and_matches_ora
     f = pkg.forces(s).astype(np.float64)
     assert np.isfinite(f).all()
     err = np.linalg.norm(f - f_ref, axis=1)
-    assert (err <= tol).all(), float((err / tol).max())
+    S.fp32_check(err, tol)
     assert S.rel_rms(err, f_ref) < 2e-5

@@ -224,3 +224,21 @@ def test_pairwise_virial_obeys_the_scaling_identity():
 
     h = 1e-6
     assert np.trace(w) == pytest.approx(-(energy(1 + h) - energy(1 - h)) / (2 * h), rel=1e-7)
+
+
+def test_lj_zero_shortcut_reads_lambda():
+    """shortcut_pair(::LJZeroShortcut, …) (src/mixing.jl:7-11): a pair is skipped when ϵ, σ OR λ of either atom is zero — the only place the unsoftened
+    Lennard-Jones reads Atom.λ (types.jl:466-475).  The oracle with per-atom λ: a λ = 0 atom feels and exerts no LJ force, which is exactly the system
+    with that atom's ϵ set to 0; λ = 0.5 changes nothing; the neighbour list does not know λ."""
+    from tests import systems as S
+    base = S.lj_fluid(6, dtype=np.float64)
+    lam = np.ones(base.n); lam[::5] = 0.0; lam[1::7] = 0.5
+    mk = lambda **kw: S.Case(base.coords, base.box, lj=base.lj, r_list=base.r_list, sigma=base.sigma, mass=base.mass, **kw).oracle(np.float64)
+    eps = np.broadcast_to(np.asarray(base.eps, dtype=np.float64), (base.n,))
+    o_lam, o_eps, o_one = mk(eps=eps, lam=lam), mk(eps=np.where(lam == 0, 0.0, eps)), mk(eps=eps)
+    nl = o_one.neighbors("cell")
+    assert [len(a) for a in o_lam.neighbors("cell")] == [len(a) for a in nl]
+    f_lam, f_eps, f_one = o_lam.forces(nl), o_eps.forces(nl), o_one.forces(nl)
+    off = lam == 0
+    assert np.array_equal(f_lam, f_eps) and np.abs(f_lam[off]).max() == 0.0
+    assert np.abs(f_one[off]).max() > 0 and o_lam.potential_energy(nl) == o_eps.potential_energy(nl) != o_one.potential_energy(nl)

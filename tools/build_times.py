@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-wave time stamps of k_build (library built with -DMHIP_STAMPS=1, MOLLYHIP_DBG_TIMES=1, MOLLYHIP_DBG_DUMP_BUILD=file): which blocks a search waits for.
+"""Per-wave time stamps of k_build (library built with -DMHIP_STAMPS=1, MOLLYHIP_DBG_TIMES=1, MOLLYHIP_DBG_DUMP=path: the search kernel's stamps land in path.build): which blocks a search waits for.
 
     python tools/build_times.py dump.bin
 """

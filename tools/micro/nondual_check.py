@@ -11,6 +11,8 @@ if len(sys.argv) > 2 and sys.argv[1] == "--child":
     from tests import systems as S
     case = S.lj_fluid(n_side, dtype=np.float32)
     s = case.system(pkg, np.float32)
+    if os.environ.get("TOOL_SHAPE"):      # (the launch shape through the API: mhip_set_launch_config)
+        bi, js = map(int, os.environ["TOOL_SHAPE"].split("x")); pkg.set_launch_config(s, bi, js)
     f = pkg.forces(s).astype(np.float64)
     st = s.stats()
     np.save(sys.argv[3], f)
@@ -18,9 +20,7 @@ if len(sys.argv) > 2 and sys.argv[1] == "--child":
     sys.exit(0)
 
 n_side = int(sys.argv[1])
-variants = [("dual (default)", {}), ("single list, walk", {"MOLLYHIP_OUTER_MARGIN_PM": "0"}), ("single list, transposed", {"MOLLYHIP_OUTER_MARGIN_PM": "0", "MOLLYHIP_BUILD_WALK": "0"}),
-            ("single list, walk, 64x16", {"MOLLYHIP_OUTER_MARGIN_PM": "0", "MOLLYHIP_BLOCK_I": "64", "MOLLYHIP_J_SPLIT": "16"}),
-            ("single list, walk, exact outer off", {"MOLLYHIP_OUTER_MARGIN_PM": "0", "MOLLYHIP_NO_SCALED_ENTRIES": "1"})]
+variants = [("dual (default)", {}), ("single list, walk", {"MOLLYHIP_OUTER_MARGIN_PM": "0"}), ("single list, walk, 64x16", {"MOLLYHIP_OUTER_MARGIN_PM": "0", "TOOL_SHAPE": "64x16"})]
 ref = None
 for name, env in variants:
     e = dict(os.environ); e.update(env)

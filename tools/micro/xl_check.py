@@ -11,6 +11,8 @@ if len(sys.argv) > 2 and sys.argv[1] == "--child":
     from tests import systems as S
     case = S.charged_fluid(n_side, dict(kind="rf", rc=1.0, weight_special=0.8333333333333334), dtype=np.float32, stable=True)
     s = case.system(pkg, np.float32)
+    if os.environ.get("TOOL_SHAPE"):      # (the launch shape through the API: mhip_set_launch_config)
+        bi, js = map(int, os.environ["TOOL_SHAPE"].split("x")); pkg.set_launch_config(s, bi, js)
     f = pkg.forces(s).astype(np.float64)
     nl = pkg.find_neighbors(s)
     st = s.stats()
@@ -28,7 +30,7 @@ nl = o.neighbors("cell", nthreads=16)
 f_ref = o.forces(nl, nthreads=16)
 scale = np.linalg.norm(f_ref, axis=1).mean()
 print(f"n_side {n_side}: {case.n} atoms, oracle {len(oi)} pairs, {int(np.asarray(osp).sum())} special")
-for name, env in [("default", {}), ("transposed search", {"MOLLYHIP_BUILD_WALK": "0"}), ("64 x 16", {"MOLLYHIP_BLOCK_I": "64", "MOLLYHIP_J_SPLIT": "16"}), ("single list", {"MOLLYHIP_OUTER_MARGIN_PM": "0"})]:
+for name, env in [("default", {}), ("64 x 16", {"TOOL_SHAPE": "64x16"}), ("single list", {"MOLLYHIP_OUTER_MARGIN_PM": "0"})]:
     e = dict(os.environ); e.update(env)
     out = f"/tmp/xl_{os.getpid()}.npy"
     r = subprocess.run([sys.executable, __file__, "--child", str(n_side), out], env=e, capture_output=True, text=True)
