@@ -20,6 +20,7 @@
 #include "hilbert.h"
 #include "kernels.h"
 #include "replan.h"
+#include "halo_step.h"
 #include "forces_launch.h"
 #include "sortscan.h"
 
@@ -286,7 +287,7 @@ template <class T> class Engine final : public EngineBase {
         nbr_gs.release(); rows_gs.release(); frc_parts.release(); wave_rows_in.release(); nbr_in.release(); pos_snap.release(); blk_disp2.release(); tile_idx_in.release(); tile_cnt_in.release(); rows_x.release(); nbr_x.release(); tile_idx_x.release(); tile_cnt_x.release(); blk_ghost.release(); blk_ghost_in.release();
         xl_start.release(); xl_list.release(); tile_idx.release(); tile_cnt.release(); wave_rows.release(); nbr.release(); blk_center.release();
         flags.release(); red_part.release(); red_out.release(); cm_step.release(); vcm.release(); stage_a.release(); stage_b.release(); stage_i.release(); bonded.release(); pme.release(); frc_scratch.release(); nl_counter.release(); state_changed.release(); pos_alt.release(); cm_blk.release(); cm_pub.release();
-        xf_release(); dom_release();
+        xf_release(); dom_release(); hx.release();
         prof.release();
         frc_side.release();
         if (h_flags) (void)hipHostFree(h_flags);
@@ -672,6 +673,7 @@ template <class T> class Engine final : public EngineBase {
         }
         stale = false; coords_moved = false; export_needs_search = false; ghost_flags_ok = false; ghost_flags_in_ok = false; last_build_step = step_n; ++n_rebuilds;
         frc_run_total = false;   // the sort moved the atoms
+        hx.plan_ok = hx.tile_ok = false; hx.trk_step = -1;
         last_rebuild_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
 
@@ -1018,7 +1020,8 @@ template <class T> class Engine final : public EngineBase {
         step_done = false;
         bool do_step = false;
         if constexpr (std::is_same<T, float>::value) {
-            do_step = step_req.on && fuse_step_env && fast_f32 && A.soa != 0 && use_inner && !prune && part == 0 && !frc_override && n_ghost == 0 && cm_pending != 1;
+            do_step = step_req.on && fuse_step_env && fast_f32 && A.soa != 0 && use_inner && !prune && part == 0 && !frc_override && (n_ghost == 0 || halo_req.on) && cm_pending != 1;
+            if (halo_req.on && !do_step) throw ApiError{MHIP_ERR_STATE, "internal: the fused ghosted step was asked for a pass that cannot integrate"};
             if (do_step) {
                 pos_alt.reserve(cap); cm_blk.reserve(2 * 4 * (size_t)n_blocks + 8);
                 if (!cm_pub.p) { cm_pub.reserve(4); MHIP_HIP(hipMemsetAsync(cm_pub.p, 0, 4 * sizeof(unsigned long long), stream)); }      // (launch numbers start at 1)
@@ -1028,13 +1031,22 @@ template <class T> class Engine final : public EngineBase {
                 A.trk_part = nullptr; A.snap_a = pos_snap_in.p; A.snap_b = pos_snap.p;
                 if (step_req.measure) { trk_part.reserve(3 * (size_t)std::max(n_blocks, 1024)); trk_out.reserve(4); A.trk_part = trk_part.p; }
                 A.cm_fin_in = nullptr; A.cm_fin_n = 0; A.cm_fin_out = nullptr;      // (the head workgroup of the launch sums the partials instead)
+                if (halo_req.on) hx_fill(A);
             }
         }
         prof.begin(prune ? 4 : 0, stream);   // stage 4 = force passes that also prune the outer list
-        tr(prune ? "k_forces (prune)" : (energy ? "k_forces (energy)" : (do_step ? "k_forces (fused step)" : "k_forces")));
+        tr(prune ? "k_forces (prune)" : (energy ? "k_forces (energy)" : (do_step ? (halo_req.on ? "k_forces (fused ghosted step)" : "k_forces (fused step)") : "k_forces")));
         if constexpr (std::is_same<T, float>::value) {
             if (do_step) {
-                launch_forces_uniform_f32(A, false, false, lds_force, (unsigned)(BI * JS), stream, true);
+                if (halo_req.on && xf.shared_device) {
+                    // Several ranks on ONE device: the peers need the same compute units to produce what this launch would wait for, and a grid of resident,
+                    // spinning workgroups can leave their kernels no room (a search kernel's 100 KB of LDS next to two spinning blocks per unit: a 2 s stall,
+                    // then the time-out).  A one-workgroup launch waits instead; the pass behind it finds every word in place.
+                    XferWait W{}; W.mine = reinterpret_cast<const XferHeader*>(xf.region); W.parity = (int)(xf.seq & 1u); W.seq = xf.seq; W.peers = xf.d_peers.p; W.n_peers = xf.n_peers; W.err = xf.err.p; W.ticks = xf_ticks();
+                    hipLaunchKernelGGL(k_xfer_wait_all, dim3(1), dim3(64), 0, stream, W);
+                }
+                launch_forces_uniform_f32(A, false, false, lds_force, (unsigned)(BI * JS), stream, true, halo_req.on);
+                if (halo_req.on) ++xf.seq;      // (the launch's last wave announces exchange xf.seq at the peers)
                 std::swap(pos[cur].p, pos_alt.p); std::swap(pos[cur].n, pos_alt.n);      // the epilogues wrote the drifted coordinates into the other buffer: it is the current one now
                 step_done = true; ++n_fused_steps; step_parts = n_blocks;
             } else launch_forces_any(A, energy);
@@ -1068,7 +1080,7 @@ template <class T> class Engine final : public EngineBase {
             MHIP_HIP(hipStreamSynchronize(stream));
             float d2; std::memcpy(&d2, &h_flags[FLAG_MAX_DISP2], sizeof(float));
             total_rows = h_flags[FLAG_TOTAL_ROWS]; max_tile_in = h_flags[FLAG_MAX_TILE];
-            ++n_filters; ghost_flags_in_ok = false; next_check_step = -1;
+            ++n_filters; ghost_flags_in_ok = false; next_check_step = -1; hx.tile_ok = false; hx.trk_step = -1;
             inner_valid = true; prune_disp_exceeded = 2.0 * std::sqrt((double)d2) > prune_margin() * 0.98;
             if (debug_on) std::fprintf(stderr, "[mhip] prune: max disp %.5f nm (margin %.3f) rows %lld exceeded %d calls %lld\n", std::sqrt((double)d2), prune_margin(), (long long)total_rows, (int)prune_disp_exceeded, (long long)n_force_calls);
         }
@@ -1086,6 +1098,108 @@ template <class T> class Engine final : public EngineBase {
     const bool fuse_gcv_env = env_int("MOLLYHIP_FUSE_GATHER_VV", 1) != 0;
     DBuf<T4> pos_alt; DBuf<double> cm_blk; DBuf<unsigned long long> cm_pub;
     const bool fuse_step_env = env_int("MOLLYHIP_FUSE_STEP", 1) != 0;
+    // Would a plain pass now be the packed one-type loop over a valid inner list — the only pass that can integrate?  (launch_pair_kernel's own conditions, asked
+    // BEFORE the step is put together: the domain loop leaves the unpack, integrator and pack launches out only when the pass will do their work)
+    bool packed_step_possible() {
+        if constexpr (!std::is_same<T, float>::value) return false;
+        if (!fuse_step_env || !dual || !inner_valid || stale || ljm != LJ_DIST_UNIFORM || coulm != MHIP_COUL_NONE || minimg || n_special != 0 || eshift != ESHIFT_SCALED || I.lj_c12 == T(0)) return false;
+        if (max_tile_in + 1 >= SOA_STRIDES[2]) return false;
+        carve_force_lds(max_tile_in);
+        return !segmented;
+    }
+
+    // ---- the fused step of a ghosted sub-domain (kernels.h HaloStep; tables: halo_step.h) -------------------------------------------------------------------
+    struct Hx {
+        DBuf<int32_t> order, flags, tsrc, ghost_row, cm_row, snd_start, snd_cnt, blk_send; DBuf<HaloSend> snd; DBuf<float*> cm_dst; DBuf<uint32_t*> ann;
+        bool plan_ok = false, tile_ok = false;      // per ghost plan + sort | per prune
+        int64_t trk_step = -1;                      // the step whose coordinates the last fused launch measured against the snapshots (trk_part), −1: none
+        int64_t n_steps = 0;
+        void release() { order.release(); flags.release(); tsrc.release(); ghost_row.release(); cm_row.release(); snd_start.release(); snd_cnt.release(); blk_send.release(); snd.release(); cm_dst.release(); ann.release(); }
+    } hx;
+    struct HaloReq { bool on = false, cm_in = false; } halo_req;
+    static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    void hx_build() {
+        if constexpr (std::is_same<T, float>::value) {
+            if (!hx.plan_ok) {
+                if (debug_on) { std::fprintf(stderr, "[mhip %d] %.3f hx_build: draining the stream first\n", xf.rank, now_ms()); MHIP_HIP(hipStreamSynchronize(stream)); std::fprintf(stderr, "[mhip %d] %.3f hx_build: drained\n", xf.rank, now_ms()); }
+                tr("k_hx_* (per plan)");
+                hx.ghost_row.reserve(std::max<int64_t>(n_ghost, 1)); hx.cm_row.reserve(XFER_MAX_RANKS * 4);
+                if (hp.n_recv_rows > 0) hipLaunchKernelGGL(k_hx_rows, dim3(cdiv(hp.n_recv_rows, 256)), dim3(256), 0, stream, hp.n_recv_rows, hp.recv_dst, hp.first_ghost, (const int32_t*)inv.p, n_owned, hx.ghost_row.p, hx.cm_row.p);
+                hx.snd_cnt.reserve(n_owned + 1); hx.snd_start.reserve(n_owned + 1);
+                MHIP_HIP(hipMemsetAsync(hx.snd_cnt.p, 0, (size_t)(n_owned + 1) * sizeof(int32_t), stream));
+                if (hp.n_send_rows > 0) hipLaunchKernelGGL(k_hx_send_count, dim3(cdiv(hp.n_send_rows, 256)), dim3(256), 0, stream, hp.n_send_rows, hp.send_idx, (const int32_t*)inv.p, hx.snd_cnt.p);
+                size_t tb = 0; MHIP_HIP(exclusive_sum_i32(nullptr, tb, hx.snd_cnt.p, hx.snd_start.p, (int)(n_owned + 1), stream));
+                if (tb + 256 > cub_tmp.n) { MHIP_HIP(hipStreamSynchronize(stream)); cub_tmp.reserve(tb + 256); }
+                tb = cub_tmp.n; MHIP_HIP(exclusive_sum_i32(cub_tmp.p, tb, hx.snd_cnt.p, hx.snd_start.p, (int)(n_owned + 1), stream));
+                MHIP_HIP(hipMemsetAsync(hx.snd_cnt.p, 0, (size_t)(n_owned + 1) * sizeof(int32_t), stream));
+                hx.snd.reserve(std::max<int64_t>(hp.n_send_rows, 1)); hx.cm_dst.reserve(std::max(hp.n_send_cm, 1));
+                if (hp.n_send_rows > 0) hipLaunchKernelGGL(k_hx_send_fill, dim3(cdiv(hp.n_send_rows, 256)), dim3(256), 0, stream, hp.n_send_rows, hp.send_idx, (const int32_t*)inv.p, (const float*)hp.send_shift,
+                                                           (const int32_t*)xf.row_peer.p, (const int32_t*)xf.row_dst.p, xf.peers, (const int32_t*)hx.snd_start.p, hx.snd_cnt.p, hx.snd.p);
+                if (hp.n_send_cm > 0) hipLaunchKernelGGL(k_hx_cm_dst, dim3(cdiv(hp.n_send_cm, 64)), dim3(64), 0, stream, hp.n_send_cm, hp.send_cm_pos, (const int32_t*)xf.row_peer.p, (const int32_t*)xf.row_dst.p, xf.peers, hx.cm_dst.p);
+                hx.blk_send.reserve(n_blocks);
+                hipLaunchKernelGGL(k_hx_blk_send, dim3(n_blocks), dim3(64), 0, stream, n_blocks, BI, n_owned, (const int32_t*)hx.snd_start.p, hx.blk_send.p);
+                // the peers' sequence words for my rows, as addresses (parity 0)
+                std::vector<uint32_t*> ann((size_t)std::max(xf.n_peers, 1), nullptr);
+                for (int q = 0; q < xf.n_peers; ++q) ann[q] = reinterpret_cast<uint32_t*>(xf.peers.region[xf.peer_rank[q]] + offsetof(XferHeader, seq_in)) + xf.rank;
+                hx.ann.reserve(ann.size());
+                MHIP_HIP(hipMemcpyAsync(hx.ann.p, ann.data(), ann.size() * sizeof(uint32_t*), hipMemcpyHostToDevice, stream));
+                MHIP_HIP(hipStreamSynchronize(stream));      // (ann is a host temporary; once per ghost plan)
+                if (debug_on) std::fprintf(stderr, "[mhip %d] %.3f hx_build: tables made\n", xf.rank, now_ms());
+                hx.plan_ok = true; hx.tile_ok = false;
+            }
+            if (!hx.tile_ok) {
+                tr("k_hx_* (per prune)");
+                const int bpx = cdiv(n_blocks, 8);
+                hx.tsrc.reserve((size_t)n_blocks * T_cap); hx.flags.reserve(n_blocks); hx.order.reserve((size_t)bpx * 8);
+                hipLaunchKernelGGL(k_hx_tile, dim3(n_blocks), dim3(256), 0, stream, n_blocks, T_cap, n_owned, (const int32_t*)(inner_is_outer ? tile_idx.p : tile_idx_in.p), (const int32_t*)(inner_is_outer ? tile_cnt.p : tile_cnt_in.p),
+                                   (const int32_t*)hx.ghost_row.p, (const int32_t*)hx.blk_send.p, hx.tsrc.p, hx.flags.p);
+                hipLaunchKernelGGL(k_hx_order, dim3(8), dim3(256), 0, stream, n_blocks, bpx, (const int32_t*)hx.flags.p, hx.order.p);
+                hx.tile_ok = true;
+            }
+            MHIP_HIP(hipGetLastError());
+        }
+    }
+    void hx_fill(ForceArgs<T>& A) {
+        if constexpr (std::is_same<T, float>::value) {
+            hx_build();
+            HaloStep& H = A.H;
+            const int par = (int)(xf.seq & 1u);
+            H.order = hx.order.p; H.flags = hx.flags.p; H.tsrc = hx.tsrc.p;
+            H.rows = xf_rows(par); H.seq_in = reinterpret_cast<const XferHeader*>(xf.region)->seq_in[par];
+            H.peers = xf.d_peers.p; H.n_peers = xf.n_peers; H.seq_wait = xf.seq; H.err = xf.err.p; H.ticks = xf_ticks();
+            H.snd_start = hx.snd_start.p; H.snd = hx.snd.p; H.half_stride = (int64_t)xf.rows_cap * 3;
+            H.parity_send = (int)((xf.seq + 1u) & 1u); H.seq_send = xf.seq + 1u;
+            H.ann = hx.ann.p; H.done = xf.done.p; H.n_done = (unsigned int)(n_blocks * (BI / WAVE));
+            H.cm_row = hx.cm_row.p; H.cm_dst = hx.cm_dst.p; H.cm_rows = hp.cm_rows; H.cm_all = cm_all.p;
+            A.cm_in = halo_req.cm_in ? (const double*)cm_all.p : (const double*)nullptr;      // (a flag here: v_cm comes from cm_all[0] and the peers' rows, halo_cm_publish)
+            A.cm_n = 0;
+            ++hx.n_steps;
+        }
+    }
+    // Can step_n of mhip_domain_run be ONE launch?  Peers reached through the mapped regions, a plan with the fused message layout, nothing but a plain packed pass due.
+    bool halo_fused_ok(int64_t step_n) {
+        if (!(xf_direct && xf.n_peers > 0 && n_ghost > 0 && hp_set && xf.routes) || replan_now) return false;
+        if (hp.cm_rows != 3 || hp.n_cm_peers != xf.n_peers || (int)xf.peer_rank.size() != xf.n_peers) return false;
+        const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
+        if (check_due(step_n, every) && step_n != last_build_step && !(host_prune && inner_valid)) return false;      // (refresh() of such a step only books it)
+        return packed_step_possible();
+    }
+    void halo_fused(int64_t step_n, double dt, bool cm, bool measure) {
+        const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
+        cur_dt = dt;
+        if (check_due(step_n, every) && step_n != last_build_step && dual) refresh(step_n);
+        step_req.on = true; step_req.gcv = false; step_req.cm = cm; step_req.measure = measure; step_req.dt = dt;
+        halo_req.on = true; halo_req.cm_in = halo_cm_in;
+        step_done = false;
+        struct Off { StepReq& s; HaloReq& h; ~Off() { s.on = false; h.on = false; } } off{step_req, halo_req};
+        step_forces(step_n);
+        if (!step_done) throw ApiError{MHIP_ERR_STATE, "internal: the fused ghosted step did not launch"};
+        step_done = false;
+        if (cm) step_half ^= 1;
+        halo_cm_in = cm; frc_valid = false; pend_a = nullptr; cm_pending = 0; cm_ext = nullptr;
+        hx.trk_step = measure ? step_n + 1 : -1;
+        MHIP_HIP(hipGetLastError());
+    }
 
     // the (block, group) items of the group-split pass handed to its workgroups so that every compute unit gets a like share of rows (forces_gs.hip, k_gs_balance)
     DBuf<uint16_t> gs_item; int cu_count = 0;
@@ -1114,7 +1228,7 @@ template <class T> class Engine final : public EngineBase {
         MHIP_HIP(hipGetLastError());
         inner_is_outer = true; max_tile_in = max_tile; last_prune_step = pass_step;
         ++n_filters; ++n_adopted; gs_list_id = n_filters;
-        ghost_flags_in_ok = false; next_check_step = -1;
+        ghost_flags_in_ok = false; next_check_step = -1; hx.tile_ok = false;
         inner_valid = true; prune_disp_exceeded = false;
         if (debug_on) std::fprintf(stderr, "[mhip] outer list adopted as the inner list (no prune): rows %lld calls %lld\n", (long long)total_rows, (long long)n_force_calls);
     }
@@ -1278,7 +1392,7 @@ template <class T> class Engine final : public EngineBase {
         hipLaunchKernelGGL(k_iota2, dim3(std::min(cdiv(n_tot, 256), 1024)), dim3(256), 0, stream, n_tot, orig[cur].p, inv.p);
         MHIP_HIP(hipMemsetAsync(frc[cur].p, 0, n_tot * sizeof(T4), stream));
         MHIP_HIP(hipGetLastError());
-        stale = true; cm_pending = 0; cm_ext = nullptr; frc_valid = false; hp_set = false; halo_cm_in = false; trk_issued = false;
+        stale = true; cm_pending = 0; cm_ext = nullptr; frc_valid = false; hp_set = false; halo_cm_in = false; trk_issued = false; hx.plan_ok = false; hx.trk_step = -1;
         // the search radius depends on whether there are ghosts and on the ghost margin, the blocking on the size class: a re-plan
         // that changes neither keeps the grid, its Hilbert table and the (already adapted) capacities
         const int size_class = n_owned >= 100000 ? 2 : (n_owned >= 40000 ? 1 : 0);
@@ -1783,7 +1897,7 @@ template <class T> class Engine final : public EngineBase {
         if ((p->n_recv_rows > 0 && (!p->recv || !p->recv_dst)) || (p->n_send_rows > 0 && (!p->send || !p->send_idx || !p->send_shift)) || (p->n_send_cm > 0 && !p->send_cm_pos))
             throw ApiError{MHIP_ERR_INVALID, "halo plan: null buffer"};
         if (p->cm_rows > 0 && p->cm_rows * 3 * (int)sizeof(T) < 32) throw ApiError{MHIP_ERR_INVALID, "halo plan: cm_rows rows cannot hold four doubles"};
-        hp = *p; hp_set = true; halo_cm_in = false; xf.routes = false;
+        hp = *p; hp_set = true; halo_cm_in = false; xf.routes = false; hx.plan_ok = false;
         cm_all.reserve(4 * 28);
         MHIP_HIP(hipMemsetAsync(cm_all.p, 0, 4 * 28 * sizeof(double), stream));
     }
@@ -1864,6 +1978,7 @@ template <class T> class Engine final : public EngineBase {
         unsigned char* region = nullptr; int64_t rows_cap = 0; int world = 0, rank = 0;
         XferPeers peers{}; bool opened[XFER_MAX_RANKS] = {}; int64_t peer_cap[XFER_MAX_RANKS] = {};   // peer_cap: rows per half of each peer's region (its header says)
         bool routes = false; int n_peers = 0; std::vector<int32_t> peer_rank;
+        uint64_t dev_key = 0; bool shared_device = false;      // some peer runs on THIS device (several ranks on one GPU: the test set-up)
         DBuf<int32_t> row_peer, row_dst, d_peers; DBuf<unsigned int> done; DBuf<int32_t> err; DBuf<float> mine3, red3;
         uint32_t seq = 0, plan_seq = 0;
         float* h_red3 = nullptr; int32_t* h_err = nullptr; hipEvent_t ev_plan = nullptr;
@@ -1891,6 +2006,12 @@ template <class T> class Engine final : public EngineBase {
             MHIP_HIP(hipExtMallocWithFlags((void**)&xf.region, bytes, hipDeviceMallocFinegrained));
             MHIP_HIP(hipMemset(xf.region, 0, bytes));
             MHIP_HIP(hipMemcpy(xf.region + offsetof(XferHeader, rows_cap), &rows_cap, sizeof(int64_t), hipMemcpyHostToDevice));
+            {
+                hipDeviceProp_t pr; MHIP_HIP(hipGetDeviceProperties(&pr, device));
+                xf.dev_key = (((uint64_t)(uint32_t)pr.pciDomainID << 32) | ((uint64_t)(uint32_t)pr.pciBusID << 16) | (uint64_t)(uint32_t)pr.pciDeviceID) + 1u;
+                MHIP_HIP(hipMemcpy(xf.region + offsetof(XferHeader, dev_key), &xf.dev_key, sizeof(uint64_t), hipMemcpyHostToDevice));
+                xf.shared_device = false;
+            }
             xf.rows_cap = rows_cap; xf.world = world; xf.rank = my_rank; xf.seq = 0; xf.plan_seq = 0; xf.routes = false;
             for (int r = 0; r < XFER_MAX_RANKS; ++r) xf.peers.region[r] = nullptr;
             xf.peers.region[my_rank] = xf.region; xf.peer_cap[my_rank] = rows_cap;
@@ -1921,6 +2042,9 @@ template <class T> class Engine final : public EngineBase {
         // the peer may have been created with another capacity than this rank: its own header is the authority on what fits there
         MHIP_HIP(hipMemcpy(&xf.peer_cap[rank], (unsigned char*)base + offsetof(XferHeader, rows_cap), sizeof(int64_t), hipMemcpyDeviceToHost));
         xf.plan.area[rank] = (unsigned char*)base + xfer_plan_off<T>(xf.peer_cap[rank]);
+        uint64_t key = 0;
+        MHIP_HIP(hipMemcpy(&key, (unsigned char*)base + offsetof(XferHeader, dev_key), sizeof(uint64_t), hipMemcpyDeviceToHost));
+        if (key != 0 && key == xf.dev_key) xf.shared_device = true;
     }
     // where the rows of the current ghost plan travel: consecutive segments of the send buffer → (peer, first row in the peer's half)
     void set_halo_routes(const mhip_halo_routes* rt) override {
@@ -1944,7 +2068,7 @@ template <class T> class Engine final : public EngineBase {
         xf.row_peer.reserve(std::max<size_t>(rp.size(), 1)); xf.row_dst.reserve(std::max<size_t>(rd.size(), 1)); xf.d_peers.reserve(std::max(rt->n_peers, 1));
         if (!rp.empty()) { MHIP_HIP(hipMemcpy(xf.row_peer.p, rp.data(), rp.size() * sizeof(int32_t), hipMemcpyHostToDevice)); MHIP_HIP(hipMemcpy(xf.row_dst.p, rd.data(), rd.size() * sizeof(int32_t), hipMemcpyHostToDevice)); }
         if (rt->n_peers) MHIP_HIP(hipMemcpy(xf.d_peers.p, rt->peer_rank, rt->n_peers * sizeof(int32_t), hipMemcpyHostToDevice));
-        xf.routes = true; xf.plan_pending = false; xf.next_check = -1;
+        xf.routes = true; xf.plan_pending = false; xf.next_check = -1; hx.plan_ok = false;
     }
     // One round of the collective number exchange over the mapped regions, before any step depends on it: every rank stores a token
     // into every rank's table and waits (bounded) for all of theirs.  0 = some rank's store did not become visible here within 2 s —
@@ -1972,9 +2096,10 @@ template <class T> class Engine final : public EngineBase {
     // what a wait that gave up recorded (halo_xfer.h, xfer_wait): which kernel waited for which rank, for which sequence number, and what it last saw
     static std::string wait_report(const int32_t* e) {
         if (!e[1]) return "";
-        static const char* const what[] = {"?", "the ghost rows (k_halo_unpack)", "the validity triple (k_plan_reduce)", "the migration counts", "the ghost counts", "the migrating atoms", "the new ghosts"};
+        static const char* const what[] = {"?", "the ghost rows (k_halo_unpack)", "the validity triple (k_plan_reduce)", "the migration counts", "the ghost counts", "the migrating atoms", "the new ghosts",
+                                           "the ghost rows (fused step, a block with ghosts)", "the centre-of-mass rows (fused step, head workgroup)", "the peer's read of the half before (fused step, a sending block without ghosts)"};
         const int who = e[1] - 1, k = (who >> 8) & 0xff;
-        return std::string(": waited for ") + what[k < 7 ? k : 0] + " of rank " + std::to_string(who & 0xff) + ", sequence number " + std::to_string((uint32_t)e[2]) + ", last seen " + std::to_string((uint32_t)e[3]);
+        return std::string(": waited for ") + what[k < 10 ? k : 0] + " of rank " + std::to_string(who & 0xff) + ", sequence number " + std::to_string((uint32_t)e[2]) + ", last seen " + std::to_string((uint32_t)e[3]);
     }
     void xf_check_errors() {
         if (!xf.region) return;
@@ -1988,7 +2113,11 @@ template <class T> class Engine final : public EngineBase {
     }
     // the collective validity check of the pair lists, issued at step s and read one step later (nothing waits for it)
     void xf_issue_plan_check(int64_t s) {
-        plan_state_dev(xf.mine3.p);
+        if (hx.trk_step == s && dual && inner_valid && !stale) {      // measured by the fused launch that made these coordinates (per-block maxima, kernels.h STEP epilogue)
+            hipLaunchKernelGGL(k_track_reduce, dim3(1), dim3(256), 0, stream, step_parts, (const float*)trk_part.p, xf.mine3.p, (float*)nullptr, 1);
+            MHIP_HIP(hipGetLastError());
+        } else plan_state_dev(xf.mine3.p);
+        hx.trk_step = -1;
         ++xf.plan_seq;
         if (xf.world > 1) {
             hipLaunchKernelGGL(k_plan_push, dim3(1), dim3(64), 0, stream, (const float*)xf.mine3.p, xf.peers, xf.world, xf.rank, (int)(xf.plan_seq & 1u), xf.plan_seq);
@@ -2011,6 +2140,29 @@ template <class T> class Engine final : public EngineBase {
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         const int64_t last = first_step + n_steps;
         InRun guard_in_run(in_run);
+        if (solo && n_ghost == 0 && xf.world <= 1) {
+            // One brick: nobody to exchange with, no ghosts, a re-plan IS an outer-list rebuild — the step loop of mhip_vv_run (fused steps, checks taken inside the
+            // launches), with the lists kept by the engine's own criteria.  The run's last Σ m v goes to cm_parts_dev for the caller's (one-rank) sum.
+            if (host_prune) {      // (set_ghost_margin handed the prune decisions to a host that has no peers to agree with)
+                host_prune = false; engine_sched = true;
+                skin_in = std::min(skin, std::max(skin_in_adapted, std::max(1, env_int("MOLLYHIP_INNER_SKIN_PM", 100)) * 1e-3));
+                const T rp = T(rc_max_ + skin_in);
+                r_prune2 = (skin_in < skin) ? rp * rp : r_in2;
+                inner_valid = false;
+            }
+            cur_dt = dt;
+            const int64_t c0 = n_disp_checks, f0 = n_filters, o0 = n_outer;
+            xf.plan_pending = false;
+            vv_loop(first_step, n_steps, dt, remove_cm_every, cm_parts_dev, n_parts);
+            flush_cm();
+            *steps_done = n_steps;
+            // (checks: those read so far + the one a launch has measured and the next call's first step will read)
+            if (counters) { counters[0] += n_disp_checks - c0 + (trk_issued ? 1 : 0); counters[1] += n_filters - f0; counters[2] += n_outer - o0; }
+            dom.n_replans += n_outer - o0;
+            MHIP_HIP(hipGetLastError());
+            MHIP_HIP(hipStreamSynchronize(stream));
+            return;
+        }
         struct Direct { bool& f; explicit Direct(bool& b) : f(b) { f = true; } ~Direct() { f = false; } } guard_direct(xf_direct);   // packs send, unpacks wait
         halo_start(dt);
         // a check carried over from the previous call belongs to that call's last step; a caller that continues somewhere else gets a
@@ -2045,6 +2197,16 @@ template <class T> class Engine final : public EngineBase {
             const bool replan_here = replan && dev_replan_ok();
             if (replan_here) { replan = false; replan_now = true; }
             const bool stop = replan || s == last;
+            if (!stop && !replan_here && halo_fused_ok(s)) {
+                // ONE launch: the blocks that need ghosts wait for the peers' rows themselves, every block integrates and sends in its epilogue (kernels.h, HaloStep).
+                // The maxima of the next step's validity check ride along when one is due.
+                const bool measure = ghost_margin > 0 && ((s + 1) % every == 0 || (xf.next_check >= 0 && s + 1 >= xf.next_check));
+                if (debug_on) std::fprintf(stderr, "[mhip %d] %.3f step %lld fused (reads exchange %u) measure %d\n", xf.rank, now_ms(), (long long)s, xf.seq, (int)measure);
+                halo_fused(s, dt, cm, measure);
+                ++*steps_done;
+                continue;
+            }
+            if (debug_on) std::fprintf(stderr, "[mhip %d] %.3f step %lld separate launches (reads exchange %u) replan %d stop %d inner_valid %d\n", xf.rank, now_ms(), (long long)s, xf.seq, (int)replan_here, (int)stop, (int)inner_valid);
             if (n_ghost > 0 && xf.n_peers > 0 && !replan_here) (void)halo_interior(s);          // the blocks that need no ghost, while the peers' rows arrive
             halo_mid(s, dt, (cm ? 1 : 0) | (stop ? 2 : 0), (cm && stop) ? cm_parts_dev : nullptr, (cm && stop) ? n_parts : 0);   // waits + unpacks … packs + sends
             ++*steps_done;
@@ -2248,7 +2410,7 @@ template <class T> class Engine final : public EngineBase {
         hp.first_ghost = n_owned; hp.n_recv_rows = t.n_ghost + (world - 1) * cr; hp.recv = nullptr; hp.recv_dst = dom.recv_dst.p;
         hp.n_cm_peers = world - 1; hp.cm_rows = cr; hp.send_idx = dom.send_idx.p; hp.send_shift = dom.send_shift.p;
         hp.n_send_rows = t.n_send + (world - 1) * cr; hp.send = nullptr; hp.send_cm_pos = dom.send_cm_pos.p; hp.n_send_cm = (world - 1) * cr;
-        xf.plan_pending = false; xf.next_check = -1;
+        xf.plan_pending = false; xf.next_check = -1; hx.plan_ok = false; hx.trk_step = -1;
         dom.plan_ms += ms_since(t_begin);
         const auto t_search = std::chrono::steady_clock::now();
         rebuild(step_n);
@@ -2286,11 +2448,19 @@ template <class T> class Engine final : public EngineBase {
     void vv_run(int64_t first_step, int64_t n_steps, double dt, int remove_cm_every) override {
         if (!state_set || !params_set) throw ApiError{MHIP_ERR_STATE, "set_atoms and set_state must be called before vv_run"};
         if (n_ghost > 0) throw ApiError{MHIP_ERR_STATE, "vv_run is single-domain; drive ghosted domains with vv_stage1/vv_stage2"};
-        const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         cur_dt = dt;
         InRun guard_in_run(in_run);
         if (first_step == 0 && remove_cm_every != 0) remove_cm();                 // simulators.jl:563
         vv_init(first_step);                                                      // :564-571
+        vv_loop(first_step, n_steps, dt, remove_cm_every, nullptr, 0);
+        flush_cm();
+        MHIP_HIP(hipGetLastError());
+        MHIP_HIP(hipStreamSynchronize(stream));
+    }
+    // the step loop of a single domain: forces of first_step are in place.  cm_parts_last (nullable): where the LAST step leaves its Σ m v partials (n_parts_last
+    // blocks) instead of registering their removal with the context — mhip_domain_run on one brick, whose caller sums them over the (one) rank.
+    void vv_loop(int64_t first_step, int64_t n_steps, double dt, int remove_cm_every, double* cm_parts_last, int n_parts_last) {
+        const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         // fused stepping: first kick + drift once, then ONE integrator launch between consecutive force passes (k_vv_mid), the
         // plain second kick at the end.  A thermostat needs v_n between the kicks: the two-launch form then.
         const bool fused = !(andersen_prob > 0);
@@ -2339,9 +2509,10 @@ template <class T> class Engine final : public EngineBase {
             // every block re-sums the previous step's per-block Σ m v partials (32 bytes each), so fewer, longer blocks pay: 1024 blocks
             // re-read 32 MB from L2 per launch — more than the 21 MB of atoms of the 256k-atom fluid (13.0 → 10.0 µs with 256 blocks;
             // 1M atoms: 21.2 → 20.2 µs with 512, 21.8 with 256)
-            const int nb = std::min(cdiv(n_owned, 256), (int)std::max<int64_t>(256, std::min<int64_t>(512, n_owned / 2048)));
+            const bool parts_out = step == last && cm && cm_parts_last != nullptr;
+            const int nb = parts_out ? n_parts_last : std::min(cdiv(n_owned, 256), (int)std::max<int64_t>(256, std::min<int64_t>(512, n_owned / 2048)));
             const double* cm_in = cm_pending == 2 ? cm_src() : (const double*)nullptr;
-            double* cm_out = cm ? cm_step.p + (size_t)half * 4 * 1024 : (double*)nullptr;
+            double* cm_out = cm ? (parts_out ? cm_parts_last : cm_step.p + (size_t)half * 4 * 1024) : (double*)nullptr;
             prof.begin(2, stream);
             // the speeds for a check that the next step's force pass will measure (see resolve_track); evaluated behind the pass: a prune inside it makes the lists checkable again
             const bool measure_mid = step != last && async_ok() && !trk_issued && check_due(step + 1, every);
@@ -2364,12 +2535,9 @@ template <class T> class Engine final : public EngineBase {
             if (step == last) frc_run_total = pend_a == nullptr && n_ghost == 0;   // (side arrays are added by the kick, not folded)
             pend_a = nullptr;
             cm_pending = 0; cm_ext = nullptr;
-            if (cm) { cm_pending = 2; cm_ext = cm_out; n_cm_step = nb; half ^= 1; }
+            if (cm && !parts_out) { cm_pending = 2; cm_ext = cm_out; n_cm_step = nb; half ^= 1; }
             if (step != last) frc_valid = false;                                  // frc[cur] belongs to the coordinates before the drift
         }
-        flush_cm();
-        MHIP_HIP(hipGetLastError());
-        MHIP_HIP(hipStreamSynchronize(stream));
     }
 
     // ---- stochastic dynamics (kernels in stochastic.hip) ------------------------------------------------------

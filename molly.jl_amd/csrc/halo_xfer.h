@@ -20,6 +20,8 @@ struct XferHeader {
     uint32_t plan_seq[2][XFER_MAX_RANKS];      // [parity][rank]: number of the last validity check whose triple is in plan_val
     float plan_val[2][XFER_MAX_RANKS][4];      // {max |x − x_plan|², max |x − x_prune|², max |v|², –} of that rank
     int64_t rows_cap;                          // rows per half of THIS region, written by its owner: a sender checks its segments against it
+    uint64_t dev_key;                          // which physical device the owner runs on (PCI domain / bus / device, + 1): ranks that find a peer on their OWN device
+                                               // — several processes sharing one GPU, the test set-up — never wait for it inside a kernel that fills the GPU (engine.hip, halo_fused)
     // the re-plan inside the engine (replan.h): two collective count exchanges per re-plan (leavers per destination, ghost rows per peer) — every rank
     // stores its row of the count matrix into every rank's table — and the sequence words of the payload rows that follow them into the plan area
     uint32_t rp_cnt_seq[2][XFER_MAX_RANKS];    // [phase][sender]: number of the last re-plan whose count row is in rp_cnt
@@ -98,6 +100,12 @@ __device__ inline void xfer_announce_word(XferPeers P, const int32_t* ranks, int
 __device__ inline void xfer_wait_block(const XferWait& W) {
     if ((int)threadIdx.x < W.n_peers && !xfer_wait(&W.mine->seq_in[W.parity][W.peers[threadIdx.x]], W.seq, W.err, W.ticks, (1 << 8) | W.peers[threadIdx.x])) atomicOr(W.err, 1);
     __syncthreads();
+}
+
+// every peer's rows of exchange `seq` are in: one small workgroup that does nothing else (ranks sharing ONE device put it in front of the fused step, whose own
+// waits then find the words already there — a grid that fills the GPU must not spin for a process that needs the same GPU to get there)
+[[maybe_unused]] static __global__ void k_xfer_wait_all(XferWait W) {
+    if ((int)threadIdx.x < W.n_peers && !xfer_wait(&W.mine->seq_in[W.parity][W.peers[threadIdx.x]], W.seq, W.err, W.ticks, (1 << 8) | W.peers[threadIdx.x])) atomicOr(W.err, 1);
 }
 
 // validity check of the pair lists over all ranks: my triple into every rank's table (my own included) …

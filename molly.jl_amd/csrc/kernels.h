@@ -817,7 +817,8 @@ __global__ void k_uniform_check(int64_t n, const T* __restrict__ sig, const T* _
 // reduce the per-block / per-wave results of k_build or k_filter into the flag words the host reads (flags zeroed before)
 // out[c] = max of part[c·n .. (c + 1)·n), c = 0, 1, 2 — one block, plain stores (the three maxima of a validity check, k_vv_mid)
 // (host: pinned host memory, nullable — the host reads it behind an event, no copy kernel in between)
-[[maybe_unused]] static __global__ void k_track_reduce(int n, const float* __restrict__ part, float* out, float* host = nullptr) {
+// (swap01: out[0] and out[1] exchanged — the validity triple of a ghost plan wants {since the search, since the prune, v²}, the partials are {prune, search, v²})
+[[maybe_unused]] static __global__ void k_track_reduce(int n, const float* __restrict__ part, float* out, float* host = nullptr, int swap01 = 0) {
     float m[3] = {0.f, 0.f, 0.f};
     constexpr int U = 4;      // (twelve loads in flight per lane: 4 096 partials by 256 lanes were sixteen memory latencies in a row)
     const int nt = (int)blockDim.x;
@@ -831,7 +832,11 @@ __global__ void k_uniform_check(int64_t n, const T* __restrict__ sig, const T* _
     __shared__ float sh[3][16];
     for (int c = 0; c < 3; ++c) { m[c] = wave_max(m[c]); if ((threadIdx.x & 63) == 0) sh[c][threadIdx.x >> 6] = m[c]; }
     __syncthreads();
-    if (threadIdx.x < 3) { float r = 0.f; for (int q = 0; q < (int)(blockDim.x >> 6); ++q) r = fmaxf(r, sh[threadIdx.x][q]); out[threadIdx.x] = r; if (host) host[threadIdx.x] = r; }
+    if (threadIdx.x < 3) {
+        float r = 0.f; for (int q = 0; q < (int)(blockDim.x >> 6); ++q) r = fmaxf(r, sh[threadIdx.x][q]);
+        const int o = (swap01 && threadIdx.x < 2) ? 1 - (int)threadIdx.x : (int)threadIdx.x;
+        out[o] = r; if (host) host[o] = r;
+    }
 }
 
 // The figures the host needs after a PRUNE pass — largest compacted tile, longest wave, rows in total, largest displacement since
@@ -1097,6 +1102,85 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_filter(FilterAr
 template <class T> __device__ inline T accel_of(T f, T m) { return m == T(0) ? T(0) : f / m; }
 template <class T> __device__ inline T step_add(T x, T rate, T h) { return M<T>::add(x, M<T>::mul(rate, h)); }
 
+// ---- the fused step of a ghosted sub-domain (k_forces STEP + HALO, fp32 one-type fluids inside mhip_domain_run) --------------------------------------------
+// ONE launch per MD step: the workgroups of blocks whose tile holds a ghost wait (bounded) for the peers' sequence words in their own prologue and stage the ghosts
+// STRAIGHT from this rank's receive half (no unpack launch, no ghost slots in pos[]); every epilogue integrates its block's atoms (as on a single domain) and
+// stores the new coordinates of the atoms the peers need — shifted — straight into the peers' receive halves (no pack launch); the last wave of the launch to
+// finish sums the blocks' Σ m v partials into the message's centre-of-mass rows and raises this rank's sequence word at every peer.  The wire format is the one
+// of k_halo_pack / k_halo_unpack (halo_xfer.h): a rank may take a fused step while a peer takes the separate launches.
+struct HaloSend { float* dst; float sx, sy, sz; int32_t pad; };      // one row an owned atom goes to: where in the peer's half (parity 0), with which periodic shift
+struct HaloStep {
+    const int32_t* order;            // [blocks_per_xcd · 8] block of workgroup w (−1: none): per XCD run the blocks WITHOUT ghosts first — the others wait for the peers
+    const int32_t* flags;            // [n_blocks] bit 0: the block's tile holds a ghost; bit 1: some atom of the block is sent to a peer
+    const int32_t* tsrc;             // [n_blocks · T_cap] the tile by source: >= 0 sorted slot of an owned atom (pos[]), < 0: row −1 − v of the receive half
+    const float* rows;               // this exchange's half of my receive region (3 floats per row)
+    const uint32_t* seq_in;          // my header's seq_in[parity of this exchange], indexed by rank
+    const int32_t* peers; int n_peers; uint32_t seq_wait;
+    int32_t* err; unsigned long long ticks;
+    const int32_t* snd_start;        // [n_owned + 1] CSR over sorted slots → snd
+    const HaloSend* snd;
+    int64_t half_stride;             // floats between the two halves of a region
+    int parity_send; uint32_t seq_send;
+    uint32_t* const* ann;            // [n_peers] &peer's header.seq_in[0][my rank]
+    unsigned int* done; unsigned int n_done;      // waves of i-atoms in the launch: the last to finish announces
+    const int32_t* cm_row;           // [n_peers · cm_rows] rows of my half that carry peer p's {ΣPx, ΣPy, ΣPz, ΣM}
+    float* const* cm_dst;            // [n_peers · cm_rows] where mine go in each peer's half (parity 0)
+    int cm_rows; double* cm_all;     // [1 + n_peers][4]: [0] my own sums of the step before (k_halo_pack's cm_own, or the tail of the fused launch before)
+};
+// workgroup 0 of a fused ghosted launch: v_cm of the step before from my own sums and the peers' (their rows of this exchange) — the sum k_vv_mid's block_vcm
+// forms over cm_all (entries in one wave, butterfly, P / M rounded to fp32) — published like step_cm_publish does
+[[maybe_unused]] static __device__ inline void halo_cm_publish(const HaloStep& H, unsigned long long* pub, uint32_t seq, unsigned char* smem) {
+    double (*tab)[4] = reinterpret_cast<double (*)[4]>(smem);
+    const int tid = threadIdx.x;
+    if (tid < H.n_peers && !xfer_wait(&H.seq_in[H.peers[tid]], H.seq_wait, H.err, H.ticks, (8 << 8) | H.peers[tid])) atomicOr(H.err, 1);
+    __syncthreads();
+    if (tid < 4) tab[0][tid] = H.cm_all[tid];
+    if (tid < H.n_peers * 8) {      // four doubles = eight words, three per row
+        const int p = tid >> 3, w = tid & 7;
+        reinterpret_cast<float*>(tab[1 + p])[w] = H.rows[3 * (size_t)H.cm_row[p * H.cm_rows + w / 3] + w % 3];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        double a[4] = {0, 0, 0, 0};
+        if (tid <= H.n_peers) for (int c = 0; c < 4; ++c) a[c] = tab[tid][c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) for (int c = 0; c < 4; ++c) a[c] += __shfl_xor(a[c], o, 64);
+        if (tid < 3) {
+            const double t = tid == 0 ? a[0] : tid == 1 ? a[1] : a[2];
+            const float vc = (float)(t / a[3]);
+            __hip_atomic_store(&pub[tid], (unsigned long long)__float_as_uint(vc) | ((unsigned long long)seq << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+// a block whose tile holds ghosts: wait for every sender's word before the staging reads their rows
+[[maybe_unused]] static __device__ inline void halo_wait_block(const HaloStep& H) {
+    if ((int)threadIdx.x < H.n_peers && !xfer_wait(&H.seq_in[H.peers[threadIdx.x]], H.seq_wait, H.err, H.ticks, (7 << 8) | H.peers[threadIdx.x])) atomicOr(H.err, 1);
+    __syncthreads();
+}
+// The last wave of the launch to finish (every wave of i-atoms counts itself in behind its own stores): this rank's Σ m v of the step — the blocks' partials, read
+// past the other XCDs' L2s — into cm_all[0] and into the centre-of-mass rows of every peer, then the sequence word: exchange seq_send is complete at the peers.
+[[maybe_unused]] static __device__ inline void halo_tail(const HaloStep& H, const double* cm_part, int n_part) {
+    const int lane = threadIdx.x & 63;
+    double a[4] = {0, 0, 0, 0};
+    if (cm_part) for (int q = lane; q < n_part; q += 64) for (int c = 0; c < 4; ++c) a[c] += __hip_atomic_load(&cm_part[4 * (int64_t)q + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) for (int c = 0; c < 4; ++c) a[c] += __shfl_xor(a[c], o, 64);
+    if (lane < 4) H.cm_all[lane] = lane == 0 ? a[0] : lane == 1 ? a[1] : lane == 2 ? a[2] : a[3];
+    for (int q = lane; q < H.n_peers * H.cm_rows; q += 64) {
+        const int r = q % H.cm_rows;
+        float* d = H.cm_dst[q] + (int64_t)H.parity_send * H.half_stride;
+        for (int c = 0; c < 3; ++c) {
+            const int i = 3 * r + c;
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(i < 2 ? a[0] : i < 4 ? a[1] : i < 6 ? a[2] : a[3]);
+            const float w = i < 8 ? __uint_as_float((uint32_t)((i & 1) ? bits >> 32 : bits)) : 0.f;
+            __hip_atomic_store(d + c, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    __threadfence_system();
+    if (lane < H.n_peers) xfer_store_release(H.ann[lane] + (size_t)H.parity_send * XFER_MAX_RANKS, H.seq_send);
+    if (lane == 0) __hip_atomic_store(H.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <class T> struct ForceArgs {
     GridP<T> G;
     InterP<T> I;
@@ -1139,6 +1223,7 @@ template <class T> struct ForceArgs {
     typename Vec<T>::T4* vel; typename Vec<T>::T4* pos_next; T dt, dt2;
     const double* cm_in; int cm_n; unsigned long long* cm_pub; uint32_t step_seq; double* cm_out;
     float* trk_part; const typename Vec<T>::T4* snap_a; const typename Vec<T>::T4* snap_b;
+    HaloStep H;                      // HALO variants only
 };
 // STEP launches: the first workgroup of the grid does nothing but this — Σ m v of the launch before (n_part partials, the fixed order of cm_finalize_in_block)
 // → v_cm = P / M rounded to T as block_vcm does → three words {value bits, launch number} that every other workgroup's epilogue polls (relaxed agent-scope
@@ -1188,9 +1273,10 @@ __host__ __device__ inline size_t prune_lds_bytes(int t_seg, int nthr) { return 
 template <class T, int LJM, int COULM, bool ENERGY, bool MINIMG, bool SEG, bool PRUNE>
 constexpr int force_min_waves() { return (std::is_same<T, float>::value && LJM == LJ_DIST_UNIFORM && COULM == MHIP_COUL_NONE && !ENERGY && !MINIMG && !SEG && !PRUNE) ? MHIP_FAST_MIN_WAVES : 1; }
 
-template <class T, int LJM, int COULM, bool ENERGY, bool MINIMG, bool SEG, bool PRUNE, int SOA_STRIDE = 4097, bool STEP = false>
+template <class T, int LJM, int COULM, bool ENERGY, bool MINIMG, bool SEG, bool PRUNE, int SOA_STRIDE = 4097, bool STEP = false, bool HALO = false>
 __global__ void __launch_bounds__(BlockLimits<T>::max_threads, (force_min_waves<T, LJM, COULM, ENERGY, MINIMG, SEG, PRUNE>()))
 k_forces(ForceArgs<T> A) {
+    static_assert(!HALO || (STEP && std::is_same<T, float>::value), "the ghosted form exists for the fused fp32 step only");
     using T4 = typename Vec<T>::T4;
     using T2 = typename Vec<T>::T2;
     constexpr bool PER_ATOM_LJ = (LJM == LJ_DIST || LJM == LJ_GENERIC);
@@ -1200,12 +1286,20 @@ k_forces(ForceArgs<T> A) {
     // Hilbert-ordered blocks so that neighbouring blocks (which share most of their tiles) share an L2.
     int wg = blockIdx.x;
     if constexpr (STEP) {      // (the grid is one workgroup longer: the first one sums and publishes v_cm, the others take the blocks — XCD k + 1 gets the run XCD k had)
-        if (wg == 0) { if (A.cm_in) step_cm_publish(A.cm_in, A.cm_n, A.cm_pub, A.step_seq, smem); return; }
+        if (wg == 0) {
+            if constexpr (HALO) { if (A.cm_in) halo_cm_publish(A.H, A.cm_pub, A.step_seq, smem); }
+            else if (A.cm_in) step_cm_publish(A.cm_in, A.cm_n, A.cm_pub, A.step_seq, smem);
+            return;
+        }
         --wg;
     }
-    const int b = (wg & 7) * A.blocks_per_xcd + (wg >> 3);
-    if (b >= A.n_blocks) return;
-    if (A.part != 0 && (A.blk_ghost[b] != 0) != (A.part == 2)) return;
+    int b = (wg & 7) * A.blocks_per_xcd + (wg >> 3);
+    [[maybe_unused]] int hflags = 0;
+    if constexpr (HALO) { b = A.H.order[wg]; if (b < 0) return; hflags = A.H.flags[b]; }
+    else {
+        if (b >= A.n_blocks) return;
+        if (A.part != 0 && (A.blk_ghost[b] != 0) != (A.part == 2)) return;
+    }
     const int tid = threadIdx.x, nthr = blockDim.x;
     [[maybe_unused]] auto stamp = [&](int k) {
         if constexpr (MHIP_STAMPS != 0 && !PRUNE) {
@@ -1265,7 +1359,8 @@ k_forces(ForceArgs<T> A) {
     };
     if constexpr (PRUNE) own_ready();      // (the prune's bounding boxes are made of the block-local coordinates, before the staging)
     const uint2* my_rows = A.nbr + (((int64_t)b * A.JS + js) * A.R_cap) * A.BI + li;
-    const int32_t* tix = A.tile_idx + (int64_t)b * A.T_cap;
+    const int32_t* tix = (HALO ? A.H.tsrc : A.tile_idx) + (int64_t)b * A.T_cap;
+    if constexpr (HALO) { if (hflags & 1) halo_wait_block(A.H); }      // (behind the requests for the lane's own record and row count: they travel meanwhile)
     T fx = T(0), fy = T(0), fz = T(0), pe = T(0);
     [[maybe_unused]] T vir[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};   // ENERGY: Σ fr·(dx², dy², dz², dx·dy, dx·dz, dy·dz), the pair virial dr ⊗ f (force.jl:848-852)
     // PRUNE: inner-list emission state (same row format as k_build)
@@ -1364,7 +1459,13 @@ k_forces(ForceArgs<T> A) {
 #pragma unroll
                     for (int k = 0; k < SB; ++k) s[k] = tix[min(t0 + k * nthr + tid, A.T_cap - 1)];
 #pragma unroll
-                    for (int k = 0; k < SB; ++k) { s[k] = (t0 + k * nthr + tid < n_here) ? s[k] : (int)((int64_t)b * A.BI); p[k] = A.pos[s[k]]; }
+                    for (int k = 0; k < SB; ++k) {
+                        s[k] = (t0 + k * nthr + tid < n_here) ? s[k] : (int)((int64_t)b * A.BI);
+                        if constexpr (HALO) {      // a ghost comes from the receive half (three words of a 12-byte row), an owned atom from pos[]
+                            if (s[k] >= 0) p[k] = A.pos[s[k]];
+                            else { const float* gr = A.H.rows + 3 * (size_t)(-1 - s[k]); p[k] = make4<T>((T)gr[0], (T)gr[1], (T)gr[2], T(0)); }
+                        } else p[k] = A.pos[s[k]];
+                    }
 #pragma unroll
                     for (int k = 0; k < SB; ++k) {
                         const int t = t0 + k * nthr + tid;
@@ -1704,11 +1805,13 @@ k_forces(ForceArgs<T> A) {
     [[maybe_unused]] T4 st_v, st_p;
     [[maybe_unused]] int64_t se = 0;
     [[maybe_unused]] unsigned long long st_w[3] = {0, 0, 0};
+    [[maybe_unused]] int snd0 = 0, snd1 = 0;
     if constexpr (STEP) {      // (in flight across the reduction below: the records, and v_cm as the head workgroup published it — three words, ONE round trip)
         // From here on a wave is a chain of dependent instructions and waits — ≈ 150 of them, which take their turn with the row walks of the seven other
         // waves of the SIMD — while its block keeps a quarter of the compute unit occupied: the arbiter is told to take these waves first.
         __builtin_amdgcn_s_setprio(3);
         se = step_atom();
+        if constexpr (HALO) { if ((hflags & 2) && js == 0 && se < A.n_owned) { snd0 = A.H.snd_start[se]; snd1 = A.H.snd_start[se + 1]; } }
         if (js == 0 && se < A.n_owned) {
             st_v = A.vel[se]; st_p = A.pos[se];
             if (A.cm_in) {
@@ -1740,6 +1843,20 @@ k_forces(ForceArgs<T> A) {
         if (mine) {
             if (A.cm_in) {      // remove_CM_motion! of the step before, one launch late (k_vv_mid's scheme): v_cm as the head workgroup published it
                 // (the head workgroup was the first of the grid and finished ≈ 20 µs ago: the words read above are this launch's; if not, again — all three at once)
+                if constexpr (HALO) {
+                    // (here the head workgroup publishes only once every PEER's sums of the step before have arrived: the wait can be a remote rank's — no
+                    // priority over the waves that still compute, a sleep between looks, and an end: the head gives up after the exchange's time-out and publishes anyway)
+                    if ((uint32_t)(st_w[0] >> 32) != A.step_seq || (uint32_t)(st_w[1] >> 32) != A.step_seq || (uint32_t)(st_w[2] >> 32) != A.step_seq) {
+                        __builtin_amdgcn_s_setprio(0);
+                        const unsigned long long t0 = wall_clock64();
+                        do {
+                            __builtin_amdgcn_s_sleep(16);
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) st_w[c] = __hip_atomic_load(&A.cm_pub[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        } while (((uint32_t)(st_w[0] >> 32) != A.step_seq || (uint32_t)(st_w[1] >> 32) != A.step_seq || (uint32_t)(st_w[2] >> 32) != A.step_seq) && wall_clock64() - t0 < 2 * A.H.ticks);
+                        __builtin_amdgcn_s_setprio(3);
+                    }
+                } else
                 while ((uint32_t)(st_w[0] >> 32) != A.step_seq || (uint32_t)(st_w[1] >> 32) != A.step_seq || (uint32_t)(st_w[2] >> 32) != A.step_seq) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) st_w[c] = __hip_atomic_load(&A.cm_pub[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1784,12 +1901,36 @@ k_forces(ForceArgs<T> A) {
             if (A.cm_out && tid < 4) {
                 double a = 0;
                 for (int q = 0; q < nw; ++q) { const double* r4 = shd + 16 * q + tid; a += (r4[0] + r4[4]) + (r4[8] + r4[12]); }
-                A.cm_out[4 * (int64_t)b + tid] = a;
+                if constexpr (HALO) __hip_atomic_store(&A.cm_out[4 * (int64_t)b + tid], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (read by the launch's last wave, on whatever XCD)
+                else A.cm_out[4 * (int64_t)b + tid] = a;
             }
             if (A.trk_part && tid < 3) { float mm = 0.f; for (int q = 0; q < 4 * nw; ++q) mm = fmaxf(mm, shf[4 * q + tid]); A.trk_part[(int64_t)tid * A.n_blocks + b] = mm; }
         }
         // (the records go out LAST: a barrier behind a store waits until the store has been acknowledged, and the block would hold its place on the compute unit for that long)
         if (mine) { A.vel[se] = v; A.pos_next[se] = p; }
+        if constexpr (HALO) {
+            if (js == 0) {      // (wave-uniform)
+                if (hflags & 2) {
+                    // A block WITHOUT ghosts has not looked at the peers' words yet: exchange seq_send goes into the half the peer read exchange seq_send − 2 from, and
+                    // its word for seq_wait = seq_send − 1 says it is done with that (it was sent behind the peer's last read).  Per wave, no barrier.
+                    if (!(hflags & 1)) { const int ln = tid & 63; if (ln < A.H.n_peers && !xfer_wait(&A.H.seq_in[A.H.peers[ln]], A.H.seq_wait, A.H.err, A.H.ticks, (9 << 8) | A.H.peers[ln])) atomicOr(A.H.err, 1); }
+                    if (mine) for (int r = snd0; r < snd1; ++r) {
+                        const HaloSend e = A.H.snd[r];
+                        float* d = e.dst + (int64_t)A.H.parity_send * A.H.half_stride;
+                        __hip_atomic_store(d, (float)p.x + e.sx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __hip_atomic_store(d + 1, (float)p.y + e.sy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __hip_atomic_store(d + 2, (float)p.z + e.sz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
+                // this wave's stores — rows at the peers, records, the block's partial — are written through and acknowledged before it counts itself in:
+                // the wave that finds itself last knows every row of the exchange is in place
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                unsigned int before = 0;
+                if ((tid & 63) == 0) before = __hip_atomic_fetch_add(A.H.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                before = (unsigned int)__builtin_amdgcn_readfirstlane((int)before);
+                if (before == A.H.n_done - 1u) halo_tail(A.H, A.cm_out, A.n_blocks);
+            }
+        }
     } else {
         if (js == 0 && valid) A.frc[si] = make4<T>(fx, fy, fz, T(0));
     }

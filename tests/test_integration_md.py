@@ -1,11 +1,17 @@
-"""INTEGRATION.md is the reference-side binding (Julia `ccall`s); Julia is not installed here, so nothing executes it.  This guard
-keeps the text from drifting: every `ccall((:mhip_…, libmollyhip), Ret, (ArgTypes…), …)` of the file is checked against the
-prototype of include/mollyhip.h — the symbol exists, the argument count matches, every Julia argument type is compatible with
-the C parameter type, the return type matches — and the `struct Mhip…` definitions mirror the C structs field by field."""
+"""The reference-side binding ships as Julia FILES (julia/ext/MollyHIPExt.jl + mhip_abi.jl, julia/MollyHIP/, julia/test/runtests.jl) that INTEGRATION.md prints
+verbatim; Julia is not installed here, so nothing executes them.  This guard keeps them from drifting: every `ccall((:mhip_…, libmollyhip), Ret, (ArgTypes…), …)`
+of the files is checked against the prototype of include/mollyhip.h — the symbol exists, the argument count matches, every Julia argument type is compatible
+with the C parameter type, the return type matches —, the `struct Mhip…` definitions mirror the C structs field by field, the overriding method heads line up
+with the reference's, and every Molly name and struct field the files use exists in the reference (tests/golden/reference_names.json)."""
 import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+JULIA_FILES = ["julia/ext/mhip_abi.jl", "julia/ext/MollyHIPExt.jl", "julia/MollyHIP/src/MollyHIP.jl", "julia/test/runtests.jl"]
+
+
+def julia_text(files=JULIA_FILES[:3]):
+    return "\n".join(open(os.path.join(ROOT, f), encoding="utf-8").read() for f in files)
 
 
 def _strip_comments(text):
@@ -90,8 +96,20 @@ def julia_ccalls(text):
     return calls
 
 
+def test_integration_md_prints_the_julia_files_verbatim():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sync_integration", os.path.join(ROOT, "tools", "sync_integration.py"))
+    si = importlib.util.module_from_spec(spec); spec.loader.exec_module(si)
+    text = open(os.path.join(ROOT, "INTEGRATION.md"), encoding="utf-8").read()
+    assert si.render(text) == text, "INTEGRATION.md differs from the files under julia/: run tools/sync_integration.py"
+    for f in JULIA_FILES + ["julia/Project.toml.fragment"]:
+        assert f"<!-- BEGIN FILE {f} -->" in text, f
+    frag = open(os.path.join(ROOT, "julia", "Project.toml.fragment")).read()
+    assert re.search(r"\[weakdeps\]\s*\nAMDGPU = \"[0-9a-f-]{36}\"", frag) and re.search(r"\[extensions\]\s*\nMollyHIPExt = \"AMDGPU\"", frag)      # ≙ /root/reference/Project.toml:41-54
+
+
 def test_every_ccall_matches_the_header():
-    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    text = julia_text()
     protos = c_prototypes()
     calls = julia_ccalls(text)
     assert len(calls) >= 40, len(calls)
@@ -112,7 +130,7 @@ def test_every_ccall_matches_the_header():
 
 
 def test_julia_structs_mirror_the_c_structs():
-    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    text = julia_text()
     for jname, cname in (("MhipInteractions", "mhip_interactions"), ("MhipConfig", "mhip_config"), ("MhipLaunchTrial", "mhip_launch_trial")):
         m = re.search(r"struct " + jname + r"\n(.*?)\nend", text, flags=re.S)
         assert m, jname
@@ -152,7 +170,7 @@ def _integration_heads(fname):
     import importlib.util
     spec = importlib.util.spec_from_file_location("ref_signatures", os.path.join(ROOT, "tools", "ref_signatures.py"))
     rs = importlib.util.module_from_spec(spec); spec.loader.exec_module(rs)
-    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    text = julia_text()
     out = []
     for m in re.finditer(r"^function\s+(?:[A-Za-z]+\.)*" + re.escape(fname) + r"\s*\(", text, flags=re.M):
         inner, _ = rs.balanced(text, m.end() - 1)
@@ -200,3 +218,81 @@ def test_reference_signature_fixture_is_current():
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ref_signatures.py"), "/root/reference"], check=True, capture_output=True)
     after = open(os.path.join(ROOT, "tests", "golden", "reference_signatures.json")).read()
     assert json.loads(before) == json.loads(after)
+
+
+# ---- every Molly name and struct field the Julia files use, against the reference's sources (tests/golden/reference_names.json, tools/ref_names.py) ------
+# what the shim reads of Molly's structs: (struct, [fields]) — a renamed field would be a runtime error on the first call, with no Julia here to raise it
+FIELDS_USED = {
+    "GPUNeighborFinder": ["dist_cutoff", "n_steps_reorder", "initialized", "cache_generation", "excluded_i", "excluded_j", "special_i", "special_j"],
+    "BuffersGPU": ["fs_mat", "virial_nounits", "step_n_preprocessed"],
+    "PME": ["mesh_dims", "order", "α"],
+    "TriclinicBoundary": ["basis_vectors"], "CubicBoundary": ["side_lengths"],
+    "Atom": ["charge", "σ", "λ"],
+    "HarmonicBond": ["k", "r0"], "HarmonicAngle": ["k", "θ0"], "PeriodicTorsion": ["periodicities", "phases", "ks"],
+    "AndersenThermostat": ["temperature", "coupling_const"],
+    "System": ["atoms", "coords", "boundary", "velocities", "pairwise_inters", "specific_inter_lists", "general_inters", "virtual_sites", "neighbor_finder", "loggers", "energy_units", "k"],
+    "InteractionList2Atoms": ["is", "js", "inters"], "InteractionList3Atoms": ["is", "js", "ks", "inters"], "InteractionList4Atoms": ["is", "js", "ks", "ls", "inters"],
+    "NeighborList": ["n", "list"],
+    "LennardJones": ["cutoff", "weight_special"], "Coulomb": ["cutoff", "weight_special", "coulomb_const"],
+    "CoulombReactionField": ["dist_cutoff", "solvent_dielectric", "weight_special", "coulomb_const"],
+    "CoulombEwald": ["dist_cutoff", "weight_special", "coulomb_const", "α", "approximate_erfc"],
+    "DistanceCutoff": ["dist_cutoff"], "CubicSplineCutoff": ["dist_activation", "dist_cutoff"],
+}
+# Molly functions / types the files call or extend (qualified `Molly.x`, `import Molly: x`, or exported names used bare)
+NAMES_USED = ["pairwise_forces_loop_gpu!", "pairwise_pe_loop_gpu!", "remove_CM_motion!", "uses_gpu_neighbor_finder", "simulate!", "random_velocities!", "from_device", "masses",
+              "ustrip_vec", "optimize_cuda_launch_config!", "apply_loggers!", "float_type", "find_neighbors", "forces", "potential_energy", "wrap_coords", "MolecularForceField",
+              "System", "Atom", "LennardJones", "Coulomb", "CoulombReactionField", "CoulombEwald", "NoCutoff", "DistanceCutoff", "ShiftedPotentialCutoff", "ShiftedForceCutoff",
+              "CubicSplineCutoff", "PolynomialCutoff", "CubicBoundary", "TriclinicBoundary", "GPUNeighborFinder", "DistanceNeighborFinder", "NoNeighborFinder", "NeighborList",
+              "InteractionList2Atoms", "InteractionList3Atoms", "InteractionList4Atoms", "HarmonicBond", "HarmonicAngle", "PeriodicTorsion", "EwaldExclusion", "PME",
+              "AndersenThermostat", "VelocityVerlet"]
+
+
+def _reference_names():
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "reference_names.json"), encoding="utf-8"))
+
+
+def test_molly_names_and_fields_used_by_the_julia_files_exist_in_the_reference():
+    g = _reference_names()
+    known = set(g["exported"]) | set(g["defined"])
+    text = julia_text(JULIA_FILES)
+    # (1) everything imported from / qualified with Molly in the files is in NAMES_USED (so that the list cannot silently fall behind the files) …
+    used = set()
+    code = re.sub(r"#[^\n]*", "", text)                                   # comments quote file names (Molly.jl) and prose
+    for m in re.finditer(r"import Molly:\s*((?:[^\n,]+,\s*\n?\s*)*[^\n,]+)", code):
+        used.update(t.strip() for t in m.group(1).replace("\n", " ").split(",") if t.strip())
+    used.update(re.findall(r"\bMolly\.([A-Za-z_]\w*!?)", code))
+    assert used <= set(NAMES_USED), sorted(used - set(NAMES_USED))
+    # … and every name of the list is defined by the reference and really appears in the files
+    for n in NAMES_USED:
+        assert n in known, f"the Julia files use Molly's `{n}`, which the reference does not define"
+        assert re.search(r"(?<![\w!])" + re.escape(n) + r"(?![\w!])", text), f"`{n}` is listed but not used"
+    # (2) struct fields
+    for st, fields in FIELDS_USED.items():
+        assert st in g["fields"], st
+        for f in fields:
+            assert f in g["fields"][st], f"{st}.{f} is read by the Julia files but the reference's struct has {g['fields'][st]}"
+            assert re.search(r"\." + re.escape(f) + r"(?![\w])", text), f"{st}.{f} is listed but no `.{f}` appears in the files"
+
+
+def test_reference_names_fixture_is_current():
+    """where the reference checkout is present the committed fixture is what tools/ref_names.py extracts now"""
+    import json
+    import subprocess
+    import sys
+    import pytest
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("no reference checkout here")
+    path = os.path.join(ROOT, "tests", "golden", "reference_names.json")
+    before = open(path, encoding="utf-8").read()
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ref_names.py"), "/root/reference"], check=True, capture_output=True)
+    assert json.loads(before) == json.loads(open(path, encoding="utf-8").read())
+
+
+def test_runtests_restates_the_reference_systems():
+    """julia/test/runtests.jl carries the closed-form systems of test/gpu_consistency.jl (33 / 100 / 10 / 20 atoms, their boxes, cutoffs, exception pairs) and the
+    reference's tolerances — the numbers SURVEY §8(c) lists — and takes its 6mrr bars from test/protein.jl:267-299"""
+    t = open(os.path.join(ROOT, "julia", "test", "runtests.jl"), encoding="utf-8").read()
+    for needle in ("diagonal(33)", "CubicBoundary(T64(20))", "lj_atoms(100, 1.0)", "T64(1.5)", "excluded=[(1, 2), (2, 3)], special=[(1, 3)]", "diagonal(20)", "use_list=false",
+                   "rtol=1e-8, atol=1e-10", "1e-7u\"kJ * mol^-1 * nm^-1\"", "1e-5u\"kJ * mol^-1\"", "1e-10u\"nm\"", "1e-7u\"nm * ps^-1\"", "ROCArray{Int32, 1}", "AMDGPU.functional()"):
+        assert needle in t, needle
