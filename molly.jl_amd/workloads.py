@@ -191,8 +191,10 @@ def charged_fluid(n_side, coul, seed=5, spacing=0.31, r_list=1.2, dtype=np.float
                 name=f"charged{n}", pme=pme)
 
 
-# ---- 6mrr (15 954 atoms, Amber ff99SB-ILDN + TIP3P): inputs from the parameter file tools/param_6mrr.py builds ----------------------
-PROTEIN_6MRR_NPZ = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "6mrr.npz")
+# ---- 6mrr (15 954 atoms, Amber ff99SB-ILDN + TIP3P): the reference's data/6mrr_equil.pdb + force-field XML as flat arrays (coordinates, box,
+# 300 K velocities, charges, σ, ϵ, masses, bonded terms, exclusions), written by tools/param_6mrr.py into the package's own data directory.
+# The OpenMM outputs the parity tests compare with live in tests/golden/6mrr.npz and are never read from here.
+PROTEIN_6MRR_NPZ = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "6mrr_system.npz")
 _npz_cache = {}
 
 

@@ -1,5 +1,8 @@
-"""Loader of tests/golden/6mrr.npz (built by tools/param_6mrr.py from the reference's data files): the solvated
-protein 6mrr, 15 954 atoms, Amber ff99SB-ILDN + TIP3P, with the OpenMM Reference-platform forces and energies."""
+"""The solvated protein 6mrr, 15 954 atoms, Amber ff99SB-ILDN + TIP3P (both files built by tools/param_6mrr.py from the reference's data files):
+the workload's inputs from molly.jl_amd/data/6mrr_system.npz, the OpenMM Reference-platform forces, energies and 100-step trajectory from
+tests/golden/6mrr.npz."""
+import os
+
 import numpy as np
 
 from tests import systems as S
@@ -7,8 +10,15 @@ from tests import systems as S
 _W = S._W
 
 
+_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "6mrr.npz")
+_cache = {}
+
+
 def data():
-    return _W.protein_6mrr_data()
+    if not _cache:
+        _cache.update(_W.protein_6mrr_data())
+        _cache.update(dict(np.load(_GOLDEN)))
+    return _cache
 
 
 def case(*args, **kw):

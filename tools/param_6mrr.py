@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""tools/param_6mrr.py — builds tests/golden/6mrr.npz from the reference's data files.  TEST-ONLY CODE.
+"""tools/param_6mrr.py — builds molly.jl_amd/data/6mrr_system.npz (the workload's INPUTS: coordinates, velocities, parameters, topology) and
+tests/golden/6mrr.npz (the OpenMM Reference-platform OUTPUTS the parity tests compare with) from the reference's data files.  Not product code.
 
 Restates just enough of Molly's setup (src/setup.jl:512-1010, src/residues.jl:190-723, src/force_field.jl:179-290)
 to turn data/6mrr_equil.pdb + ff99SBildn.xml + tip3p_standard.xml into flat parameter arrays, and copies the
 OpenMM Reference-platform force / energy / trajectory files of data/openmm_6mrr/ into the same archive, so that
 the parity tests can run on the GPU box where /root/reference does not exist.
 
-    python tools/param_6mrr.py [/root/reference] [tests/golden/6mrr.npz]
+    python tools/param_6mrr.py [/root/reference] [tests/golden/6mrr.npz] [molly.jl_amd/data/6mrr_system.npz]
 
 SURVEY.md Appendix C documents the rules restated here; self-checks at the bottom reproduce the reference's
 own assertions (test/protein.jl:141-190, test/basic.jl:592).
@@ -20,6 +21,7 @@ import numpy as np
 
 REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
 OUT = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "6mrr.npz")
+OUT_SYSTEM = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "molly.jl_amd", "data", "6mrr_system.npz")
 DATA = os.path.join(REF, "data")
 
 
@@ -294,9 +296,12 @@ def main():
     out["velocities_300K"] = np.loadtxt(os.path.join(omm, "velocities_300K.txt"))
     out["openmm_coordinates_100steps"] = np.loadtxt(os.path.join(omm, "amber", "coordinates_100steps.txt"))
     out["openmm_velocities_100steps"] = np.loadtxt(os.path.join(omm, "amber", "velocities_100steps.txt"))
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    np.savez_compressed(OUT, **out)
-    print("wrote", OUT, os.path.getsize(OUT) // 1024, "KiB")
+    golden = {k: v for k, v in out.items() if k.startswith("openmm_")}
+    system = {k: v for k, v in out.items() if not k.startswith("openmm_")}
+    for path, arrays in ((OUT, golden), (OUT_SYSTEM, system)):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        np.savez_compressed(path, **arrays)
+        print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
 if __name__ == "__main__":
