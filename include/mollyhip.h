@@ -157,6 +157,11 @@ typedef struct mhip_stats {
     int32_t n_adopted_outer_lists; /* rebuilds whose outer list became the inner list without a pruning pass (nothing to prune: inner radius = r_list) */
     int64_t n_fused_steps;         /* steps of mhip_vv_run without an integrator launch: the pair pass integrated in its epilogue (k_forces STEP, fp32 one-type
                                       fluids) or, with bonded terms and PME, the step's last force launch did (k_gather_collect_vv) */
+    /* list upkeep of the dual pair list, priced like the force pass (DESIGN §4 "Roofline and algorithmic bytes"; 2 bytes per list slot, padding included) */
+    int64_t n_outer_slots;         /* padded slots of the outer list: what an outer search writes and a pruning pass reads            */
+    int64_t outer_tile_atoms_total;/* Σ over blocks of the outer list's tile sizes                                                    */
+    int64_t build_pass_bytes;      /* ONE outer search: N·4w read + 2·n_outer_slots + 4·outer_tile_atoms_total written                */
+    int64_t prune_pass_bytes;      /* ONE pruning force pass: N(R_p + 3w) + 2·n_outer_slots + 4·outer tile read, 2·n_list_slots + 4·tile_atoms_total + N·4w (snapshot) written */
 } mhip_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */

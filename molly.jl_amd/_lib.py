@@ -47,7 +47,8 @@ class Stats(C.Structure):
                 ("force_pass_bytes", C.c_int64), ("prof_ms", C.c_double * 8), ("prof_calls", C.c_int64 * 8),
                 ("n_outer_builds", C.c_int64), ("n_filter_passes", C.c_int64), ("tile_segments", C.c_int64),
                 ("n_group_split_passes", C.c_int64), ("group_split", C.c_int32), ("n_adopted_outer_lists", C.c_int32),
-                ("n_fused_steps", C.c_int64)]
+                ("n_fused_steps", C.c_int64), ("n_outer_slots", C.c_int64), ("outer_tile_atoms_total", C.c_int64),
+                ("build_pass_bytes", C.c_int64), ("prune_pass_bytes", C.c_int64)]
 
     def as_dict(self):
         d = {name: getattr(self, name) for name, _ in self._fields_}

@@ -220,7 +220,7 @@ template <class T> class Engine final : public EngineBase {
     bool lazy_single = false; int64_t n_skipped = 0;
     bool dual = false, dual_disabled = false, margin_zero = false, want_margin_zero = false; int margin_halvings = 0; int early_outer = 0; double outer_margin = 0; int64_t last_outer_step = 0, n_outer = 0, n_filters = 0; T r_in = 0, r_in2 = 0;
     DBuf<int32_t> flags; int32_t* h_flags = nullptr;
-    int64_t total_rows = 0;
+    int64_t total_rows = 0, outer_rows = 0;      // rows (of four entries per lane, per wave) of the list the plain passes walk | of the outer list as searched
     // reductions
     DBuf<double> red_part, red_out, cm_step; double* h_red = nullptr; DBuf<T> vcm;
     int n_cm_step = 0;   // cm_pending == 2: v_cm still lives as the per-block partials of the last k_vv2 (cm_step[0..4*n_cm_step))
@@ -293,6 +293,8 @@ template <class T> class Engine final : public EngineBase {
         if (h_flags) (void)hipHostFree(h_flags);
         if (h_trk) (void)hipHostFree(h_trk);
         if (ev_trk) (void)hipEventDestroy(ev_trk);
+        if (h_prune) (void)hipHostFree(h_prune);
+        if (ev_prune) (void)hipEventDestroy(ev_prune);
         if (h_red) (void)hipHostFree(h_red);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
@@ -652,7 +654,7 @@ template <class T> class Engine final : public EngineBase {
             if (attempt == 11) throw ApiError{MHIP_ERR_CAPACITY, "neighbour structures did not converge"};
         }
         minimg = h_flags[FLAG_MINIMG] != 0;
-        max_tile = h_flags[FLAG_MAX_TILE]; max_rows = h_flags[FLAG_MAX_ROWS]; total_rows = h_flags[FLAG_TOTAL_ROWS];
+        max_tile = h_flags[FLAG_MAX_TILE]; max_rows = h_flags[FLAG_MAX_ROWS]; total_rows = outer_rows = h_flags[FLAG_TOTAL_ROWS];
         carve_force_lds(max_tile);
         red_part.reserve(std::max<size_t>(7 * (size_t)n_blocks, 4 * (size_t)cdiv(n_owned, 256)) + 8);
         bonded.on_reorder();
@@ -890,6 +892,25 @@ template <class T> class Engine final : public EngineBase {
         else if (check_due(step_n, every) && step_n != last_build_step) refresh(step_n);
     }
 
+    // What a pruning pass leaves for the host — the pruned list's largest tile and row total, the largest displacement since the outer search — read WITHOUT draining
+    // the stream inside mhip_domain_run on a ghosted sub-domain (the drain sat at exactly the step where every rank prunes, and each rank's device
+    // idled while its host woke up and queued the rest of the step): the summary kernel writes into pinned words of their own behind an event; until the host finds the
+    // event complete the next passes are shaped for the OUTER list's largest tile (a pruned tile is a subset of it: same results, a larger LDS carve-up for a step or
+    // two), and a displacement beyond the ghost margin — which fails the run on this path anyway (after_forces) — is reported when it is read, a step or two later.
+    int32_t* h_prune = nullptr; hipEvent_t ev_prune = nullptr; bool prune_pending = false; int64_t prune_pending_id = -1;
+    void prune_resolve(bool block) {
+        if (!prune_pending) return;
+        if (!block && hipEventQuery(ev_prune) != hipSuccess) { (void)hipGetLastError(); return; }
+        MHIP_HIP(hipEventSynchronize(ev_prune));
+        prune_pending = false;
+        if (n_filters != prune_pending_id || stale || !inner_valid) return;      // the list it described has been replaced meanwhile
+        float d2; std::memcpy(&d2, &h_prune[FLAG_MAX_DISP2], sizeof(float));
+        total_rows = h_prune[FLAG_TOTAL_ROWS]; max_tile_in = h_prune[FLAG_MAX_TILE];
+        if (debug_on) std::fprintf(stderr, "[mhip] prune (read late): max disp %.5f nm (margin %.3f) rows %lld tile %d\n", std::sqrt((double)d2), prune_margin(), (long long)total_rows, max_tile_in);
+        if (2.0 * std::sqrt((double)d2) > prune_margin() * 0.98)
+            throw ApiError{MHIP_ERR_STATE, "an atom moved more than half the ghost margin since the ghost plan: re-plan earlier (mhip_plan_disp2_dev)"};
+    }
+
     // ---------------------------------------------------------------------------------------------
     // the pair-kernel variants are compiled in forces_inst.hip (one translation unit per precision and Coulomb kind)
     void launch_forces_any(const ForceArgs<T>& A, bool energy) {
@@ -909,6 +930,7 @@ template <class T> class Engine final : public EngineBase {
     // pairwise forces of the current coordinates into frc[cur] (overwrites); energy → red_part[0..n_blocks)
     void launch_pair_kernel(bool energy, int part = 0, bool allow_gs = false) {
         gs_used = false;
+        prune_resolve(!(xf_direct && n_ghost > 0));      // figures a pruning pass left behind an event: taken if they have arrived (outside the ghosted run loop: waited for)
         ForceArgs<T> A;
         A.G = G; A.I = I; A.n_owned = n_owned; A.BI = BI; A.BI_shift = ilog2(BI); A.JS = JS; A.T_cap = T_cap; A.T_lds = tile_lds; A.R_cap = R_cap;
         A.n_blocks = n_blocks; A.blocks_per_xcd = cdiv(n_blocks, 8);
@@ -1070,19 +1092,30 @@ template <class T> class Engine final : public EngineBase {
         if (A.dbg && (n_force_calls % stamps_every()) == 0) stamps_report();
         if (prune) {   // validity of the pruned list: nobody moved more than half the margin since the outer search
             // one single-block launch that leaves its figures in pinned host memory (no zeroing launch, no copy launch) …
+            const bool late = xf_direct && n_ghost > 0 && prune_late_env;      // inside mhip_domain_run on a ghosted sub-domain: read behind an event (prune_resolve)
+            if (late && !h_prune) { MHIP_HIP(hipHostMalloc((void**)&h_prune, N_FLAGS * sizeof(int32_t))); MHIP_HIP(hipEventCreateWithFlags(&ev_prune, hipEventDisableTiming)); }
+            int32_t* const h_dst = late ? h_prune : h_flags;
             hipLaunchKernelGGL(k_prune_summary, dim3(1), dim3(1024), 0, stream, n_blocks, n_blocks * JS * (BI / WAVE), n_blocks * (BI / WAVE), R_cap,
-                               (const int32_t*)tile_cnt_in.p, wave_rows_in.p, (const float*)blk_disp2.p, flags.p, h_flags);
+                               (const int32_t*)tile_cnt_in.p, wave_rows_in.p, (const float*)blk_disp2.p, flags.p, h_dst);
             if (n_ghost > 0) {   // … the blocks recorded the displacement of the owned atoms; the ghosts' comes on top
                 hipLaunchKernelGGL(k_max_disp<T>, dim3(std::min(cdiv(n_ghost, 256), 1024)), dim3(256), 0, stream, n_ghost, (const T4*)pos[cur].p + n_owned, (const T4*)pos_snap.p + n_owned,
                                    reinterpret_cast<unsigned int*>(flags.p + FLAG_MAX_DISP2), G);
-                MHIP_HIP(hipMemcpyAsync(h_flags, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+                MHIP_HIP(hipMemcpyAsync(h_dst, flags.p, N_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
             }
-            MHIP_HIP(hipStreamSynchronize(stream));
-            float d2; std::memcpy(&d2, &h_flags[FLAG_MAX_DISP2], sizeof(float));
-            total_rows = h_flags[FLAG_TOTAL_ROWS]; max_tile_in = h_flags[FLAG_MAX_TILE];
             ++n_filters; ghost_flags_in_ok = false; next_check_step = -1; hx.tile_ok = false; hx.trk_step = -1;
-            inner_valid = true; prune_disp_exceeded = 2.0 * std::sqrt((double)d2) > prune_margin() * 0.98;
-            if (debug_on) std::fprintf(stderr, "[mhip] prune: max disp %.5f nm (margin %.3f) rows %lld exceeded %d calls %lld\n", std::sqrt((double)d2), prune_margin(), (long long)total_rows, (int)prune_disp_exceeded, (long long)n_force_calls);
+            inner_valid = true;
+            if (late) {
+                MHIP_HIP(hipEventRecord(ev_prune, stream));
+                prune_pending = true; prune_pending_id = n_filters; prune_disp_exceeded = false;
+                max_tile_in = max_tile;      // (an upper bound until the figures are read: the pruned tile of a block is a subset of its outer tile)
+            } else {
+                MHIP_HIP(hipStreamSynchronize(stream));
+                prune_pending = false;
+                float d2; std::memcpy(&d2, &h_flags[FLAG_MAX_DISP2], sizeof(float));
+                total_rows = h_flags[FLAG_TOTAL_ROWS]; max_tile_in = h_flags[FLAG_MAX_TILE];
+                prune_disp_exceeded = 2.0 * std::sqrt((double)d2) > prune_margin() * 0.98;
+                if (debug_on) std::fprintf(stderr, "[mhip] prune: max disp %.5f nm (margin %.3f) rows %lld exceeded %d calls %lld\n", std::sqrt((double)d2), prune_margin(), (long long)total_rows, (int)prune_disp_exceeded, (long long)n_force_calls);
+            }
         }
     }
 
@@ -1098,11 +1131,14 @@ template <class T> class Engine final : public EngineBase {
     const bool fuse_gcv_env = env_int("MOLLYHIP_FUSE_GATHER_VV", 1) != 0;
     DBuf<T4> pos_alt; DBuf<double> cm_blk; DBuf<unsigned long long> cm_pub;
     const bool fuse_step_env = env_int("MOLLYHIP_FUSE_STEP", 1) != 0;
+    const bool prune_late_env = env_int("MOLLYHIP_PRUNE_LATE", 1) != 0;      // 0: a pruning pass of a ghosted run drains the stream for its summary, as on a single domain (tests compare the two)
     // Would a plain pass now be the packed one-type loop over a valid inner list — the only pass that can integrate?  (launch_pair_kernel's own conditions, asked
     // BEFORE the step is put together: the domain loop leaves the unpack, integrator and pack launches out only when the pass will do their work)
     bool packed_step_possible() {
         if constexpr (!std::is_same<T, float>::value) return false;
         if (!fuse_step_env || !dual || !inner_valid || stale || ljm != LJ_DIST_UNIFORM || coulm != MHIP_COUL_NONE || minimg || n_special != 0 || eshift != ESHIFT_SCALED || I.lj_c12 == T(0)) return false;
+        prune_resolve(false);
+        if (prune_pending && max_tile_in + 1 >= SOA_STRIDES[2]) prune_resolve(true);      // (the outer list's bound does not fit the packed loop: the pruned list's own figure is needed now)
         if (max_tile_in + 1 >= SOA_STRIDES[2]) return false;
         carve_force_lds(max_tile_in);
         return !segmented;
@@ -1903,6 +1939,8 @@ template <class T> class Engine final : public EngineBase {
     }
     void halo_pack(bool with_cm) {
         if (hp.n_send_rows <= 0 && !with_cm) return;
+        // (after an in-engine re-plan the tables are the engine's own and there is no staging buffer: only mhip_domain_run's direct stores can carry them)
+        if (!(xf_direct && xf.n_peers > 0) && (hp.n_send_rows > 0 || with_cm) && !hp.send) throw ApiError{MHIP_ERR_STATE, "the current ghost plan was made inside the engine (mhip_set_domain) and has no send buffer: step it with mhip_domain_run, or hand a plan with buffers to mhip_set_halo_plan"};
         tr("k_halo_pack");
         XferSend X{};        // inside mhip_domain_run with peers: the rows go straight into the peers' regions, exchange number ++seq
         if (xf_direct && xf.n_peers > 0) {
@@ -1930,6 +1968,7 @@ template <class T> class Engine final : public EngineBase {
         if (cm && !last && hp.cm_rows <= 0 && hp.n_cm_peers > 0) throw ApiError{MHIP_ERR_INVALID, "halo plan carries no centre-of-mass rows"};
         if (hp.n_recv_rows > 0) {
             if (hp.first_ghost < 0 || hp.first_ghost > n_tot) throw ApiError{MHIP_ERR_INVALID, "halo plan: ghost range out of bounds"};
+            if (!(xf_direct && xf.n_peers > 0) && !hp.recv) throw ApiError{MHIP_ERR_STATE, "the current ghost plan was made inside the engine (mhip_set_domain) and has no receive buffer: step it with mhip_domain_run, or hand a plan with buffers to mhip_set_halo_plan"};
             tr("k_halo_unpack");
             XferWait W{};    // inside mhip_domain_run with peers: wait for exchange xf.seq, read my region's half
             if (xf_direct && xf.n_peers > 0) { W.mine = reinterpret_cast<const XferHeader*>(xf.region); W.parity = (int)(xf.seq & 1u); W.seq = xf.seq; W.peers = xf.d_peers.p; W.n_peers = xf.n_peers; W.err = xf.err.p; W.ticks = xf_ticks(); }
@@ -2216,6 +2255,7 @@ template <class T> class Engine final : public EngineBase {
             if (stop) { *reason = replan ? 1 : 0; if (replan) xf.plan_pending = false; break; }
         }
         xf_check_errors();      // (one stream sync per call: a chunk is ≈ 100 steps)
+        prune_resolve(true);    // (a pruning pass of the chunk's last steps: its figures, and its verdict on the ghost margin, belong to this call)
     }
 
 
@@ -2247,6 +2287,7 @@ template <class T> class Engine final : public EngineBase {
     // each, the face thresholds in T — every number formed the way the host planner forms it, so that both planners select the same atoms
     void set_domain(const mhip_domain_geometry* gm, const int64_t* gids_dev) override {
         if (!gm) { dom.ready = false; return; }
+        if (caller_indexed_topology()) throw ApiError{MHIP_ERR_UNSUPPORTED, "the in-engine re-plan moves atoms between ranks and resets the caller order: contexts with bonded terms, exception lists, special pairs or PME keep the host planner"};
         const int gx = gm->grid[0], gy = gm->grid[1], gz = gm->grid[2];
         if (gx < 1 || gy < 1 || gz < 1 || (int64_t)gx * gy * gz > XFER_MAX_RANKS) throw ApiError{MHIP_ERR_INVALID, "domain geometry: 1 .. 64 bricks"};
         const int world = gx * gy * gz, me = gm->rank;
@@ -2311,8 +2352,11 @@ template <class T> class Engine final : public EngineBase {
                            (const int64_t*)dom.gid[dom.gcur].p, gid_dev, (T*)par4_dev);
         MHIP_HIP(hipGetLastError());
     }
+    // caller order is reset by a device re-plan (k_rp_mig_send / k_rp_compact move x, v, q, σ, ϵ, m and the global id): anything indexed by caller order —
+    // bonded terms, exception lists, special pairs, the PME charge mesh's exclusions — would be scrambled, so such contexts keep the host planner
+    bool caller_indexed_topology() const { return bonded.any() || has_exc || n_special > 0 || pme.on(); }
     bool dev_replan_ok() const {
-        if (!dom.ready || !dev_replan_env || !hp_set) return false;
+        if (!dom.ready || !dev_replan_env || !hp_set || caller_indexed_topology()) return false;
         if (dom.world == 1) return n_ghost == 0;
         if (!xf.region || !xf.routes || xf.n_peers != dom.world - 1 || xf.world != dom.world || hp.cm_rows != dom_g.cm_rows) return false;
         for (int r = 0; r < dom.world; ++r) if (!xf.peers.region[r] || !xf.plan.area[r]) return false;
@@ -2664,6 +2708,7 @@ template <class T> class Engine final : public EngineBase {
 
     void get_stats(mhip_stats* s) override {
         std::memset(s, 0, sizeof(*s));
+        prune_resolve(true);
         s->n_atoms = n_tot; s->n_owned = n_owned; s->n_ghost = n_ghost; s->n_rebuilds = n_rebuilds; s->n_force_calls = n_force_calls;
         s->n_blocks = n_blocks; s->block_atoms = BI; s->j_split = JS; s->minimg_mode = minimg ? 1 : 0; s->max_tile_atoms = max_tile;
         s->last_rebuild_ms = last_rebuild_ms; s->lds_bytes = (int64_t)lds_force;
@@ -2674,12 +2719,20 @@ template <class T> class Engine final : public EngineBase {
         if (!stale) {
             std::vector<int32_t> tc(n_blocks);
             MHIP_HIP(hipMemcpy(tc.data(), tile_cnt.p, n_blocks * sizeof(int32_t), hipMemcpyDeviceToHost));
-            int64_t t = 0; for (int v : tc) t += v; s->tile_atoms_total = t;
+            int64_t t = 0; for (int v : tc) t += v; s->tile_atoms_total = s->outer_tile_atoms_total = t;
+            if (dual && inner_valid && !inner_is_outer && tile_cnt_in.p) {      // the plain passes stage the pruned list's compacted tile
+                MHIP_HIP(hipMemcpy(tc.data(), tile_cnt_in.p, n_blocks * sizeof(int32_t), hipMemcpyDeviceToHost));
+                t = 0; for (int v : tc) t += v; s->tile_atoms_total = t;
+            }
             s->n_pairs_full = 2 * export_list(nullptr, nullptr, nullptr, 0, false);
         }
         const int64_t w = sizeof(T), Rp = (coulm != MHIP_COUL_NONE ? 6 : 4) * w;
         s->algorithmic_bytes_step = n_owned * (Rp + 22 * w) + 4 * (s->n_pairs_full / 2);   // N(R_p + 22w) + 4L
         s->force_pass_bytes = n_owned * (Rp + 3 * w) + 4 * (s->n_pairs_full / 2);          // force pass: N(R_p + 3w) + 4L
+        // the list's upkeep, priced by the bytes of the lists themselves (2 per slot, padding included — the format's, not the pair count's) and every per-atom array once
+        s->n_outer_slots = outer_rows * 4 * WAVE;
+        s->build_pass_bytes = n_tot * 4 * w + 2 * s->n_outer_slots + 4 * s->outer_tile_atoms_total;
+        s->prune_pass_bytes = n_owned * (Rp + 3 * w) + 2 * s->n_outer_slots + 4 * s->outer_tile_atoms_total + 2 * s->n_list_slots + 4 * s->tile_atoms_total + n_tot * 4 * w;
         prof.resolve(stream);
         for (int k = 0; k < Prof::NS; ++k) { s->prof_ms[k] = prof.ms[k]; s->prof_calls[k] = prof.calls[k]; }
         s->n_outer_builds = n_outer; s->n_filter_passes = n_filters;

@@ -350,6 +350,7 @@ class DomainRun:
         # stores, mhip_domain_run never comes back for them; MOLLYHIP_DEVICE_REPLAN=0 (or an engine without the entry point) keeps migrate() below
         self.device_replan = self.engine_loop and hasattr(engine, "set_domain") and _os.environ.get("MOLLYHIP_DEVICE_REPLAN", "1") != "0"
         self._dev_replans_seen = 0
+        self._dev_arrived_seen = 0
         self._counters = (C.c_int64 * 3)(0, 0, 0)
         self.stats = {"exchange_calls": 0, "ghost_atoms": 0, "migrated": 0, "plans": 0, "plan_checks": 0, "prunes": 0, "interior_passes": 0}
         self.overlap = hasattr(engine, "halo_interior")      # interior blocks while the ghosts travel (host loop)
@@ -430,7 +431,8 @@ class DomainRun:
             return
         try:
             self.e.set_domain(self.g.grid, self.rank, self.g.box, self.g.r_ghost, self.gid)
-            self._dev_replans_seen = self.e.domain_info()[2]
+            info = self.e.domain_info()
+            self._dev_replans_seen, self._dev_arrived_seen = info[2], info[3]
         except _lib.MollyHipError:                         # (a decomposition the device planner does not cover: the host keeps planning)
             self.device_replan = False
 
@@ -680,7 +682,8 @@ class DomainRun:
             return
         self.stats["plans"] += n_replans - self._dev_replans_seen
         self._dev_replans_seen = n_replans
-        self.stats["migrated"] = n_arrived
+        self.stats["migrated"] += n_arrived - self._dev_arrived_seen      # (on top of what earlier host migrations counted: the engine's figure is a running total of its own)
+        self._dev_arrived_seen = n_arrived
         self.n_owned, self.n_ghost = n_owned, n_ghost
         self.stats["ghost_atoms"] = n_ghost
         self.gid = torch.empty(n_owned, dtype=torch.int64, device=self.device)

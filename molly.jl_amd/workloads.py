@@ -159,6 +159,27 @@ def argon_random(n_atoms=4096, box_multiplier=1.0, seed=42, r_cut=1.2, dtype=np.
                 name=f"argon{n_atoms}_x{box_multiplier:g}")
 
 
+MEMLIMIT = dict(volume_per_atom=0.013, sigma=0.001, eps=0.1, mass=10.0, r_cut=1.0, dt=0.0001, n_steps=100, n_steps_reorder=25)
+
+
+def memlimit_box(n_atoms):
+    """box side of the reference's "Testing GPU memory limits" recipe (docs/src/examples.md:975-981): V = n_atoms * 0.013f0 nm³, cbrt(V), both in Float32"""
+    return float(np.cbrt(np.float32(n_atoms) * np.float32(MEMLIMIT["volume_per_atom"]), dtype=np.float32))
+
+
+def memlimit_fluid(n_atoms, seed=7, dtype=np.float32):
+    """The system of docs/src/examples.md:969-1000: n atoms (mass 10, σ 0.001 nm, ϵ 0.1 kJ/mol, no charge) at UNIFORMLY RANDOM positions at 76.9 atoms/nm³,
+    LennardJones(DistanceCutoff(1.0)) over a GPUNeighborFinder(dist_cutoff = 1.0) (n_steps_reorder = 25, neighbors.jl:327), zero velocities,
+    VelocityVerlet(dt = 0.1 fs, remove_CM_motion = false).  bench.py --workload memlimit generates the same thing on the device for sizes a host array would not suit."""
+    box = memlimit_box(n_atoms)
+    rng = np.random.default_rng(seed)
+    x = (rng.random((n_atoms, 3), dtype=np.float32) * np.float32(box)).astype(dtype).astype(np.float64)
+    x = np.where(x >= np.float64(dtype(box)), 0.0, x)
+    P = MEMLIMIT
+    return Case(x, float(dtype(box)), lj=dict(cutoff=("distance", P["r_cut"])), r_list=P["r_cut"], rebuild_every=P["n_steps_reorder"], velocities=np.zeros((n_atoms, 3)),
+                sigma=np.full(n_atoms, P["sigma"]), eps=np.full(n_atoms, P["eps"]), mass=np.full(n_atoms, P["mass"]), name=f"memlimit{n_atoms}")
+
+
 def charged_fluid(n_side, coul, seed=5, spacing=0.31, r_list=1.2, dtype=np.float32, with_exceptions=True, stable=False, pme=None, box_scale=(1.0, 1.0, 1.0)):
     """A water-like-density mixed LJ + Coulomb fluid with per-atom σ, ϵ, q (two species + some LJ-less
     'hydrogens' with ϵ = 0) and random excluded / special pairs between close atoms.  The ϵ = 0 species exercises the

@@ -17,7 +17,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- $CMD > /dev/null 2> "$OUT/pmc_write.err"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY --kernel-trace --output-format csv -d "$OUT/pmc_sq" -- $CMD > /dev/null 2> "$OUT/pmc_sq.err"
 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_sq2" -- $CMD > /dev/null 2> "$OUT/pmc_sq2.err"
-python "$ROOT/profiles/summarize.py" "$OUT" "$WL" > "$OUT/summary.json" 2> "$OUT/summarize.err"
+python "$ROOT/profiles/summarize.py" "$OUT" "$WL" "${TAG%%_*}" > "$OUT/summary.json" 2> "$OUT/summarize.err"      # also writes <round>_traffic_<workload>{,_prune,_build}.json
 # keep the summaries, drop the per-dispatch raw tables (gpurun_out/ is capped at 64 MiB)
 cp $(find "$OUT/trace" -name "*kernel_stats.csv" | head -1) "$OUT/kernel_stats.csv" 2>/dev/null
 rm -rf "$OUT/trace" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq" "$OUT/pmc_sq2"

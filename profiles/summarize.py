@@ -70,6 +70,37 @@ def main():
         summ["hbm_bytes_per_force_launch"] = rd + wr
         summ["hbm_read_bytes_per_force_launch"] = rd
         summ["hbm_write_bytes_per_force_launch"] = wr
+    # one small file per kernel for bench.py's roofline entries (load_traffic): the plain pass, the pruning pass, the outer search — each with the id of the
+    # library the counters were taken with (bench.py compares it with the library it runs)
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        build_id = hashlib.sha256(open(os.path.join(root, "molly.jl_amd", "libmollyhip.so"), "rb").read()).hexdigest()[:16]
+    except OSError:
+        build_id = None
+    summ["lib_build_id"] = build_id
+    sys.path.insert(0, root)
+    try:
+        import bench
+        src_id = bench.kernel_src_id()
+    except Exception:
+        src_id = None
+    summ["kernel_src_id"] = src_id
+    tag = sys.argv[3] if len(sys.argv) > 3 else "rXX"
+    for kind, kern in (("", dom), ("_prune", "k_forces_prune"), ("_build", "k_build")):
+        c = summ["pmc"].get(kern, {})
+        if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+            continue
+        rd = c["FETCH_SIZE"]["per_launch"] * 1024 * 2; wr = c["WRITE_SIZE"]["per_launch"] * 1024
+        rec = {"workload": workload, "kernel": kern, "hbm_bytes_per_launch": rd + wr, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
+               "launches_counted": c["FETCH_SIZE"]["launches"], "avg_us_rocprofv3": summ["kernels"].get(kern, {}).get("avg_us"), "lib_build_id": build_id, "kernel_src_id": src_id,
+               "source": f"{tag}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, profiles/collect.sh), FETCH_SIZE x2 gfx950 correction, KiB units"}
+        if kind == "":
+            rec["hbm_bytes_per_force_launch"] = rd + wr
+        for extra in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAVES", "GRBM_GUI_ACTIVE", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE"):
+            if extra in c:
+                rec[extra + "_per_launch"] = c[extra]["per_launch"]
+        json.dump(rec, open(os.path.join(out_dir, f"{tag}_traffic_{workload}{kind}.json"), "w"), indent=1)
     try:
         summ["bench_line"] = json.loads(open(os.path.join(out_dir, "bench_trace.json")).read().strip().splitlines()[-1])
     except Exception as e:

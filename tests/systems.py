@@ -97,3 +97,20 @@ def fp32_reference_rms(case, f_ref64, coords=None, specific=False, nthreads=8):
     nl32 = o32.neighbors("cell", nthreads=nthreads) if math.isfinite(case.r_list) else None
     f32 = o32.forces(nl32, nthreads=1, specific=specific).astype(np.float64)
     return rel_rms(np.linalg.norm(f32 - f_ref64, axis=1), f_ref64)
+
+
+def cluster_case(case, coords, n_inner=100_000):
+    """A cube at the box centre holding ≈ n_inner atoms plus a shell of r_list around it, cut out of `case` as an isolated cluster in a box wide enough that no
+    image interacts: every list partner of an inner atom is in the cluster, so the oracle's force on it is the whole system's.  One-type LJ fluids only.
+    → (sub-case, indices into the full system, inner mask over the cluster)."""
+    box, r = float(case.box[0]), float(case.r_list)
+    a = (n_inner * box ** 3 / case.n) ** (1.0 / 3.0)
+    assert a + 2 * r + 0.5 < box, "box too small for an isolated cluster"
+    c = 0.5 * box
+    d = np.abs(coords - c).max(axis=1)
+    idx = np.nonzero(d < 0.5 * a + r)[0]
+    inner = d[idx] < 0.5 * a
+    lo = c - 0.5 * a - r
+    sub = Case(coords[idx] - lo, a + 3 * r + 0.5, lj=case.lj, r_list=case.r_list, rebuild_every=case.rebuild_every, velocities=np.zeros((len(idx), 3)),
+               sigma=case.sigma[idx], eps=case.eps[idx], mass=case.mass[idx], name=case.name + "_cluster")
+    return sub, idx, inner

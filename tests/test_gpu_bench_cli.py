@@ -60,7 +60,7 @@ def test_bench_default_workload_carries_the_other_configurations():
     assert list(d.keys())[-1] == "summary"
     for nm, r in (("lj1m", d), ("6mrr_pme", d["secondary"][0]), ("lj256k", d["secondary"][1])):
         assert abs(d["summary"][nm + "_ms_per_step"] - r["ms_per_step"]) < 1e-5 and abs(d["summary"][nm + "_ns_day"] - r["value"]) < 0.06
-    assert len(json.dumps(d["summary"])) < 700
+    assert len(json.dumps(d["summary"])) < 1200
 
 
 def test_bench_two_ranks_record():

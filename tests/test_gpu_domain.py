@@ -159,6 +159,21 @@ def test_engine_loop_chunked_on_cadence_boundaries_keeps_every_check(world, tmp_
     assert abs(int(whole["host_prunes"]) - int(host["host_prunes"])) <= 1 and int(whole["plans"]) == int(host["plans"])
 
 
+@pytest.mark.parametrize("world,dtype_name", [(2, "f32"), (4, "f64")])
+def test_prune_summary_read_late_is_the_same_run(world, dtype_name, tmp_path, monkeypatch):
+    """Inside mhip_domain_run a pruning pass on a ghosted sub-domain no longer drains the stream for its summary (largest pruned tile, row total, displacement since the
+    outer search): the words arrive behind an event and the next passes are shaped for the outer list's largest tile until they are read (engine.hip, prune_resolve).
+    MOLLYHIP_PRUNE_LATE=0 keeps the drain.  Both forms must prune equally often and end in the SAME state: the tile bound changes the LDS carve-up, never a sum."""
+    n_steps = 60
+    monkeypatch.setenv("MOLLYHIP_PRUNE_LATE", "1")
+    late = _run_variant(tmp_path, monkeypatch, "late", world, n_steps, True, 0, dtype_name=dtype_name)
+    monkeypatch.setenv("MOLLYHIP_PRUNE_LATE", "0")
+    drained = _run_variant(tmp_path, monkeypatch, "drained", world, n_steps, True, 0, dtype_name=dtype_name)
+    monkeypatch.delenv("MOLLYHIP_PRUNE_LATE")
+    assert int(late["engine_loop"]) == 1 and int(late["prunes"]) >= 2 and int(late["prunes"]) == int(drained["prunes"]) and int(late["outer"]) == int(drained["outer"])
+    assert np.array_equal(late["x"], drained["x"]) and np.array_equal(late["v"], drained["v"])
+
+
 @pytest.mark.parametrize("gm,n_steps", [(0.0, 40), (0.03, 120)])
 def test_engine_loop_replans_match_host_loop(gm, n_steps, tmp_path, monkeypatch):
     """Re-plans (migration + new ghost routes) BETWEEN engine calls.  No ghost margin: ownership and ghosts are redone at every rebuild

@@ -1,0 +1,71 @@
+"""Sizes beyond the benchmark's 10⁶ atoms (VERDICT r5 "missing" 5): index widths, capacity retries and tile slots where nothing had run before.
+The reference's only published figure on this path is how many atoms of its memory-limit recipe fit one GPU (docs/src/examples.md:969-1017:
+60 000 / 140 000 / 120 000 atoms on 11 / 48 / 32 GB cards); bench.py --workload memlimit answers it at full size (profiles/r06_memlimit.json),
+these tests hold the same code path to the oracle at sizes the oracle finishes in seconds."""
+import numpy as np
+import pytest
+
+from tests import systems as S
+
+pytestmark = pytest.mark.gpu
+
+
+def test_four_million_atom_benchmark_fluid(pkg):
+    """The benchmark fluid (argon, 21.1 atoms/nm³, r_c 1.0, r_list 1.2, fp32) at 159³ = 4 019 679 atoms: the engine's pair count equals the fp32
+    oracle's cell-list count exactly and sits on the closed-form density estimate; ΣF = 0; the forces of the 10⁵ atoms of a cube at the centre meet the fp32 bar
+    against the fp64 oracle; 30 steps (dual list: an outer search, prunes) stay finite and keep the momentum."""
+    import os
+    nt = min(len(os.sched_getaffinity(0)), 64)
+    case = S.lj_fluid(159, seed=11, dtype=np.float32)
+    assert case.n == 4_019_679
+    s = case.system(pkg, np.float32)
+    f = pkg.forces(s).astype(np.float64)
+    assert np.isfinite(f).all()
+    st = s.stats()
+    oi, oj, _ = case.oracle(np.float32).neighbors("cell", nthreads=nt)
+    assert st["n_pairs_full"] == 2 * len(oi)                                    # the fp32 reference search finds the same number of pairs …
+    rho = case.n / float(case.box[0]) ** 3
+    est = 0.5 * case.n * rho * 4.0 / 3.0 * np.pi * case.r_list ** 3             # … near the continuum estimate N ρ (4/3) π r³ / 2: a jittered simple-cubic lattice has its shells
+    assert abs(len(oi) / est - 1.0) < 0.05, (len(oi), est)                      # (the vectors of norm² 11 lie AT r_list / spacing = 3.3165: +3.3 % measured); a lost or doubled block of pairs is far outside
+    del oi, oj
+    sub, idx, inner = S.cluster_case(case, case.coords, 100_000)
+    tol, o, nl = S.fp32_force_tolerance(sub)
+    f_ref = o.forces(nl, nthreads=nt)
+    err = np.linalg.norm(f[idx] - f_ref, axis=1)[inner]
+    S.fp32_check(err, tol[inner], "fp32 forces of 10^5 atoms inside the 4M-atom fluid against the fp64 oracle")
+    assert S.rel_rms(err, f_ref[inner]) <= 1e-5
+    scale_mean = o.pair_force_scale[inner].mean()
+    assert np.abs(f.sum(axis=0)).max() < 1e-6 * scale_mean * case.n              # Newton's third law over the whole box
+    p0 = (case.velocities * case.mass[:, None]).sum(axis=0)
+    pkg.simulate(s, pkg.VelocityVerlet(dt=0.002, remove_CM_motion=0), 30)
+    assert np.isfinite(s.coords).all() and np.isfinite(s.velocities).all()
+    p1 = (s.velocities.astype(np.float64) * case.mass[:, None]).sum(axis=0)
+    assert np.abs(p1 - p0).max() < 1e-4 * np.abs(case.velocities * case.mass[:, None]).sum() / np.sqrt(case.n)
+    st = s.stats()
+    assert st["n_outer_builds"] >= 1 and st["n_filter_passes"] >= 1 and st["block_atoms"] * st["j_split"] <= 1024
+
+
+def test_memlimit_recipe_against_oracle(pkg):
+    """docs/src/examples.md:969-1000 at 300 000 atoms (more than twice the reference's largest published size, 140 000): uniformly random coordinates at 76.9 atoms/nm³,
+    σ = 0.001 nm, list radius = cutoff = 1.0 nm (no skin: a single list, rebuilt every 25 steps).  Pair SET and forces against the oracle, then the recipe's
+    100 steps of 0.1 fs."""
+    import importlib
+    W = importlib.import_module("molly_jl_amd.workloads")
+    case = W.memlimit_fluid(300_000, seed=7)
+    s = case.system(pkg, np.float32)
+    f = pkg.forces(s).astype(np.float64)
+    o32 = case.oracle(np.float32)
+    oi, oj, _ = o32.neighbors("cell", nthreads=16)
+    keys, n_special = S.export_keys(pkg, s)
+    assert n_special == 0 and np.array_equal(keys, S.pair_keys(oi, oj))         # 48 M pairs, the same set
+    expect = 0.5 * case.n * (case.n - 1) * (4.0 / 3.0) * np.pi / float(case.box[0]) ** 3
+    assert abs(len(oi) - expect) < 6 * np.sqrt(expect)
+    tol, o, nl = S.fp32_force_tolerance(case)
+    f_ref = o.forces(nl, nthreads=16)
+    S.fp32_check(np.linalg.norm(f - f_ref, axis=1), tol, "fp32 forces of the memory-limit recipe against the fp64 oracle")
+    pkg.simulate(s, pkg.VelocityVerlet(dt=W.MEMLIMIT["dt"], remove_CM_motion=0), W.MEMLIMIT["n_steps"])
+    assert np.isfinite(s.coords).all() and np.isfinite(s.velocities).all()
+    o.vv_run(W.MEMLIMIT["n_steps"], W.MEMLIMIT["dt"], remove_cm_every=0, nthreads=16)
+    d = s.coords.astype(np.float64) - o.coords
+    d -= np.round(d / case.box) * case.box
+    assert np.abs(d).mean() < 5e-4 and np.abs(d).max() < 5e-3                   # test/simulation.jl:625's fp32 trajectory bar

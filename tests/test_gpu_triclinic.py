@@ -143,6 +143,31 @@ def test_triclinic_cell_grid_list_and_forces(pkg, dtype, approx):
         assert pkg.potential_energy(s) == pytest.approx(e_ref, rel=3e-5)
 
 
+def test_triclinic_single_list_with_exceptions_beyond_64_atom_blocks(pkg, monkeypatch):
+    """the search variant with exact band decisions and exception lookups is kept to 64-atom blocks; on a triclinic cell grid (no transposed search to
+    fall back to) a system whose size class would take 128-atom blocks is cut to 64-atom blocks instead (engine.hip rebuild_impl).  42 875 atoms in a sheared cell,
+    excluded and special pairs, the single exact list (no outer margin): pair SET and special flags against the brute-force oracle of the same precision, forces
+    against the fp64 oracle."""
+    monkeypatch.setenv("MOLLYHIP_OUTER_MARGIN_PM", "0")
+    basis, case = sheared_fluid(np.float32, n_side=35)
+    idx = np.arange(case.n - 2)
+    case.excluded = np.stack([idx[idx % 3 == 0], idx[idx % 3 == 0] + 1], 1)
+    case.special = np.stack([idx[idx % 3 == 1], idx[idx % 3 == 1] + 2], 1)
+    case.lj = dict(cutoff=("distance", 1.0), weight_special=0.5)
+    ref = case.oracle(np.float32).neighbors("brute", nthreads=16)
+    s = case.system(pkg, np.float32)
+    got = pkg.find_neighbors(s)
+    assert got.n == len(ref[0])
+    assert all(np.array_equal(u, v) for u, v in zip(S.sorted_pairs(got.i, got.j, got.special), S.sorted_pairs(*ref)))
+    assert s.stats()["block_atoms"] == 64
+    o = case.oracle(np.float64)
+    nl = o.neighbors("brute", nthreads=16)
+    f_ref = o.forces(nl, nthreads=8)
+    scale, jump = o.force_scale(nl)      # (jump: the force step of a pair within 2e-6 of the hard cutoff, where fp32 may flip r <= rc — 0.037 kJ/mol/nm for argon at 1 nm)
+    f = pkg.forces(s).astype(np.float64)
+    assert np.all(np.linalg.norm(f - f_ref, axis=1) <= 6e-5 * scale + 1.01 * jump + 1e-4)
+
+
 def test_triclinic_cell_grid_trajectory(pkg):
     """60 velocity-Verlet steps (six list rebuilds, atoms crossing every face) of the sheared fluid against the oracle, fp64"""
     basis, case = sheared_fluid(np.float64, n_side=20)
