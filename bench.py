@@ -92,6 +92,8 @@ def make_case(workload):
         return W.lj_fluid(100, seed=4, dtype=np.float32), np.float32, 0.002
     if workload == "lj256k":
         return W.lj_fluid(64, seed=2, dtype=np.float32), np.float32, 0.002
+    if workload.startswith("lj_side"):      # the benchmark fluid at any size: n_side³ atoms (lj_side50 = 125 000: what one of eight bricks of lj1m owns — DESIGN §6's scaling model)
+        return W.lj_fluid(int(workload[7:]), seed=2, dtype=np.float32), np.float32, 0.002
     if workload in ("6mrr_pme", "6mrr_direct", "6mrr_rf64", "6mrr_rf32"):
         dtype = np.float64 if workload == "6mrr_rf64" else np.float32
         return W.protein_6mrr("rf" if workload.startswith("6mrr_rf") else "ewald", dtype=dtype, bonded=True, pme=(workload == "6mrr_pme")), dtype, 0.0005
@@ -180,6 +182,8 @@ def run_single(m, workload, args, steps, warmup, profile_steps):
     s = case.system(m, dtype)
     s.push_state(velocities=True)
     ctx = s.engine()
+    if args.block_atoms:      # an explicit launch shape (≙ set_cuda_launch_config!, src/cuda_config.jl:17-47) instead of the engine's choice by atom count
+        s._check(L.mhip_set_launch_config(ctx, args.block_atoms, args.j_split))
     if args.integrator == "langevin":   # thermostatted at the LJ fluid's 85 K / the protein's 300 K, friction 1 / ps
         kT = m.BOLTZMANN * (85.0 if workload.startswith("lj") else 300.0)
         run = lambda first, n: s._check(L.mhip_langevin_run(ctx, first, n, dt, kT, 1.0, 1, 0x9E3779B97F4A7C15, first))
@@ -498,7 +502,7 @@ def make_record(workload, case, dtype, dt, ms_per_step, st, extra, world, args, 
         "data": "reference fixture (data/6mrr_equil.pdb + ff99SBildn.xml / tip3p_standard.xml through tools/param_6mrr.py; velocities data/openmm_6mrr/velocities_300K.txt)" if workload.startswith("6mrr") else "synthetic",
         "lib_build_id": build_id, "kernel_src_id": src_id,
         "matom_steps_per_s": steps_s * n_atoms / 1e6,
-        "config": {"workload": WORKLOADS[workload],
+        "config": {"workload": WORKLOADS.get(workload, WORKLOADS["lj256k"].replace("256k-atom", f"{n_atoms}-atom") if workload.startswith("lj_side") else workload),
                    "name": workload, "integrator": args.integrator, "n_atoms": n_atoms, "dt_fs": dt * 1e3, "rebuild_every": case.rebuild_every,
                    "parallelism": "single domain" if world == 1 else extra.get("parallelism"),
                    "block_atoms": st["block_atoms"], "j_split": st["j_split"], "pairs_half_list": st["n_pairs_full"] // 2,
@@ -521,6 +525,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the 6mrr_pme and lj256k records that the default single-GPU run appends")
     ap.add_argument("--integrator", default="vv", choices=["vv", "langevin"], help="vv = the headline VelocityVerlet step; langevin = Langevin middle integrator (single GPU)")
     ap.add_argument("--profile-steps", type=int, default=200, help="steps of the separate hipEvent-timed pass")
+    ap.add_argument("--block-atoms", type=int, default=0, help="launch shape of the search and pair kernels: i-atoms per workgroup (64, 128, 256; 0 = the engine's choice)")
+    ap.add_argument("--j-split", type=int, default=0, help="launch shape: waves sharing one atom's list (a power of two, block_atoms * j_split <= 1024)")
     ap.add_argument("--memlimit-start", type=int, default=1_000_000, help="--workload memlimit: first atom count (doubled until a size fails)")
     ap.add_argument("--memlimit-max", type=int, default=0, help="--workload memlimit: stop doubling beyond this atom count (0: until a size fails)")
     ap.add_argument("--equil", type=int, default=None, help="untimed equilibration steps before the warm-up (SURVEY §8(d): 2000 for the LJ fluids, which start from a jittered lattice; 0 for 6mrr, which starts from an equilibrated structure)")

@@ -100,14 +100,14 @@ def test_triclinic_neighbour_list_of_1000_atoms_is_the_brute_force_set(pkg, dtyp
     assert all(np.array_equal(u, v) for u, v in zip(S.sorted_pairs(got.i, got.j, got.special), S.sorted_pairs(*ref)))
 
 
-def sheared_fluid(dtype, n_side=20, seed=17):
+def sheared_fluid(dtype, n_side=20, seed=17, jitter=0.008):
     """n_side³ argon-like atoms on a jittered lattice in the fractional coordinates of a sheared cell whose perpendicular heights
     (≈ 7 nm at 8000 atoms) hold 11 cells of r_list / 2 on every axis and leave every 64-atom block's neighbourhood well inside half a
     height: the cell-grid form of the triclinic search with block-local coordinates, not the one-cell form"""
     rng = np.random.default_rng(seed)
     g = np.stack(np.meshgrid(*[np.arange(n_side)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float64)
     basis = np.array([[6.0, 0.0, 0.0], [1.3, 5.8, 0.0], [-0.9, 1.5, 5.6]]) * (n_side / 16.0)
-    x = (((g + 0.5) / n_side + rng.uniform(-0.008, 0.008, g.shape)) @ basis).astype(dtype).astype(np.float64)
+    x = (((g + 0.5) / n_side + rng.uniform(-jitter, jitter, g.shape)) @ basis).astype(dtype).astype(np.float64)
     n = len(x)
     v = (rng.normal(size=(n, 3)) * 0.13).astype(dtype).astype(np.float64)
     v -= v.mean(axis=0)
@@ -149,7 +149,9 @@ def test_triclinic_single_list_with_exceptions_beyond_64_atom_blocks(pkg, monkey
     excluded and special pairs, the single exact list (no outer margin): pair SET and special flags against the brute-force oracle of the same precision, forces
     against the fp64 oracle."""
     monkeypatch.setenv("MOLLYHIP_OUTER_MARGIN_PM", "0")
-    basis, case = sheared_fluid(np.float32, n_side=35)
+    # (the jitter is fractional: scaled so that it stays the ±0.06 nm of the 8 000-atom cell — at ±0.1 nm atoms overlap, forces reach 2·10⁵ kJ mol⁻¹ nm⁻¹ ∝ r⁻¹³ and the
+    # fp32 rounding of a coordinate in a 13 nm cell, 1e-6 nm, is 1e-4 of such a force: tools/micro/tri_xl_check.py)
+    basis, case = sheared_fluid(np.float32, n_side=35, jitter=0.008 * 20 / 35)
     idx = np.arange(case.n - 2)
     case.excluded = np.stack([idx[idx % 3 == 0], idx[idx % 3 == 0] + 1], 1)
     case.special = np.stack([idx[idx % 3 == 1], idx[idx % 3 == 1] + 2], 1)
