@@ -45,6 +45,7 @@
  *   MOLLYHIP_REUSE_RUN_FORCES=0    every run recomputes the forces of its first step (see mhip_vv_run)
  *   MOLLYHIP_PME_FFT=0|1           PME transforms through hipFFT never / always (default: meshes with more than 512 points on an axis)
  *   MOLLYHIP_DEVICE_REPLAN=0       mhip_domain_run returns to the host planner for every re-plan (see mhip_set_domain)
+ *   MOLLYHIP_HALO_WAITER=0         ranks sharing ONE device (tests): no one-workgroup waiter in front of a fused ghosted step; the blocks' own bounded waits order it, as across devices
  *   MOLLYHIP_PRUNE_LATE=0          inside mhip_domain_run a pruning pass of a ghosted sub-domain drains the stream for its summary instead of reading it behind an event
  * Host mirror only (the Python files of molly.jl_amd): MOLLYHIP_GHOST_MARGIN_PM, MOLLYHIP_ENGINE_LOOP, MOLLYHIP_HALO_FUSED, MOLLYHIP_HOST_PRUNE, MOLLYHIP_DIST_BACKEND,
  * MOLLYHIP_FORCE_DEVICE, MOLLYHIP_FORCE_DOMAIN (bench.py), MOLLYHIP_LIB_AB (another build of the library, tools/force_ab.py).  Builds with -DMHIP_STAMPS=1 only:

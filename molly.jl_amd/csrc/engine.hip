@@ -1060,7 +1060,7 @@ template <class T> class Engine final : public EngineBase {
         tr(prune ? "k_forces (prune)" : (energy ? "k_forces (energy)" : (do_step ? (halo_req.on ? "k_forces (fused ghosted step)" : "k_forces (fused step)") : "k_forces")));
         if constexpr (std::is_same<T, float>::value) {
             if (do_step) {
-                if (halo_req.on && xf.shared_device) {
+                if (halo_req.on && xf.shared_device && halo_waiter_env) {
                     // Several ranks on ONE device: the peers need the same compute units to produce what this launch would wait for, and a grid of resident,
                     // spinning workgroups can leave their kernels no room (a search kernel's 100 KB of LDS next to two spinning blocks per unit: a 2 s stall,
                     // then the time-out).  A one-workgroup launch waits instead; the pass behind it finds every word in place.
@@ -1131,6 +1131,9 @@ template <class T> class Engine final : public EngineBase {
     const bool fuse_gcv_env = env_int("MOLLYHIP_FUSE_GATHER_VV", 1) != 0;
     DBuf<T4> pos_alt; DBuf<double> cm_blk; DBuf<unsigned long long> cm_pub;
     const bool fuse_step_env = env_int("MOLLYHIP_FUSE_STEP", 1) != 0;
+    // 0: no one-workgroup waiter in front of a fused ghosted step even when ranks share the device — the blocks' own (bounded) waits are then what orders the step,
+    // as on separate devices.  Safe only while the ranks' grids together fit the device (the small test systems); tests/test_gpu_domain.py runs it to exercise those waits
+    const bool halo_waiter_env = env_int("MOLLYHIP_HALO_WAITER", 1) != 0;
     const bool prune_late_env = env_int("MOLLYHIP_PRUNE_LATE", 1) != 0;      // 0: a pruning pass of a ghosted run drains the stream for its summary, as on a single domain (tests compare the two)
     // Would a plain pass now be the packed one-type loop over a valid inner list — the only pass that can integrate?  (launch_pair_kernel's own conditions, asked
     // BEFORE the step is put together: the domain loop leaves the unpack, integrator and pack launches out only when the pass will do their work)

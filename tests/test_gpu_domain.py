@@ -174,6 +174,22 @@ def test_prune_summary_read_late_is_the_same_run(world, dtype_name, tmp_path, mo
     assert np.array_equal(late["x"], drained["x"]) and np.array_equal(late["v"], drained["v"])
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_fused_ghosted_step_with_the_blocks_own_waits(world, tmp_path, monkeypatch):
+    """On separate devices nothing but the bounded waits INSIDE the fused ghosted launch orders a step against its peers: blocks whose tile holds ghosts wait for the
+    senders' sequence words, the head workgroup for the centre-of-mass rows, sending blocks without ghosts for the peer's read of the half they overwrite (kernels.h
+    HaloStep).  Ranks that share a device normally get a one-workgroup waiter in front, which makes every one of those waits return at once; MOLLYHIP_HALO_WAITER=0 takes it
+    away (safe here: two or four grids of 32 workgroups fit the device side by side), so that the waits really order the ranks.  Same bits as with the waiter."""
+    n_steps = 60
+    monkeypatch.setenv("MOLLYHIP_HALO_WAITER", "0")
+    bare = _run_variant(tmp_path, monkeypatch, "bare", world, n_steps, True, 0, dtype_name="f32")
+    monkeypatch.setenv("MOLLYHIP_HALO_WAITER", "1")
+    waiter = _run_variant(tmp_path, monkeypatch, "waiter", world, n_steps, True, 0, dtype_name="f32")
+    monkeypatch.delenv("MOLLYHIP_HALO_WAITER")
+    assert int(bare["engine_loop"]) == 1 and int(bare["fused_steps"]) >= n_steps // 2 and int(bare["fused_steps"]) == int(waiter["fused_steps"])
+    assert np.array_equal(bare["x"], waiter["x"]) and np.array_equal(bare["v"], waiter["v"])
+
+
 @pytest.mark.parametrize("gm,n_steps", [(0.0, 40), (0.03, 120)])
 def test_engine_loop_replans_match_host_loop(gm, n_steps, tmp_path, monkeypatch):
     """Re-plans (migration + new ghost routes) BETWEEN engine calls.  No ghost margin: ownership and ghosts are redone at every rebuild
