@@ -411,6 +411,9 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
         else A.blk_center[b] = make4<T>(s_ctr[0], s_ctr[1], s_ctr[2], T(0));
     }
     __syncthreads();
+#if MHIP_STAMPS
+    if (A.dbg && lane == 0) { unsigned long long* d = A.dbg + ((size_t)b * NW_ALL + wv_all) * 8; d[7] = wall_clock64(); }      // behind the boxes
+#endif
     const int lx = s_boxlen[0], ly = s_boxlen[1], lz = s_boxlen[2];
     const int ncb = lx * ly * lz;
     const bool exact_only = s_exact != 0;
@@ -489,6 +492,9 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
     }
     __syncthreads();
     const int nraw = block_excl_scan(c_raw, ncb, part, tid, nthr);
+#if MHIP_STAMPS
+    if (A.dbg && lane == 0 && !(XL && A.xl_start)) { unsigned long long* d = A.dbg + ((size_t)b * NW_ALL + wv_all) * 8; d[6] = wall_clock64(); }      // behind the cell pruning and its scan (systems without exception lists: slot 6 is theirs otherwise)
+#endif
 
     // 2. atom-level pruning + ordered compaction into the LDS tile (cell-major, sorted order inside a cell)
     if constexpr (WALK) { for (int q = tid; q <= ncb; q += nthr) t_off[q] = 0; __syncthreads(); }
@@ -570,15 +576,43 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
     //    change the outcome — are re-evaluated with the reference's exact arithmetic, so the emitted pair SET is
     //    bit-identical to the reference's.
     const uint32_t SENT = make_entry((uint32_t)tile_n, 0u, A.eshift);
-    // four 16-bit entries per row and lane, collected in a 64-bit shift register: the newest entry enters at the top, after four
-    // of them the oldest sits in bits 0-15 (two shifts and an OR per entry instead of indexed sub-word inserts)
-    uint64_t pack = 0;
+    // four 16-bit entries per row and lane: `acc` holds the cnt & 3 entries of the row being filled, oldest in the low 16 bits; a row is stored when four are complete
+    uint64_t acc = 0;
     int cnt = 0;
     uint2* my_rows = A.nbr + (((int64_t)b * A.JS + js) * A.R_cap) * A.BI + li;
     auto emit = [&](uint32_t e) {
-        pack = (pack >> 16) | ((uint64_t)e << 48);
+        const int np = cnt & 3;
+        acc |= (uint64_t)e << (np * 16);
+        if (np == 3) { const int row = cnt >> 2; if (row < A.R_cap) my_rows[(int64_t)row * A.BI] = make_uint2((uint32_t)acc, (uint32_t)(acc >> 32)); acc = 0; }
         ++cnt;
-        if ((cnt & 3) == 0) { int row = (cnt >> 2) - 1; if (row < A.R_cap) my_rows[(int64_t)row * A.BI] = make_uint2((uint32_t)pack, (uint32_t)(pack >> 32)); }
+    };
+    // emit4 (the walk over an outer list's candidates, round 6): four candidates' entries at once, no branch per candidate — keep mask → byte-permute selectors
+    // (16-entry LDS table) → the kept entries compacted, in order, to the low end of a 64-bit word → appended behind the cnt & 3 pending; at most one store per four
+    // candidates.  The scheme of the pruning pass's emission (k_forces PRUNE); the entry-by-entry form cost a divergent branch, a 64-bit shift pair and a counter
+    // test per CANDIDATE kept: 28 VALU instructions per candidate tested in the 1M-atom search (profiles/r06_traffic_lj1m_build.json)
+    __shared__ uint2 s_lut[16];
+    if (tid < 16) {
+        uint32_t sel[2] = {0x0c0c0c0cu, 0x0c0c0c0cu};
+        int p = 0;
+        for (int j = 0; j < 4; ++j) if ((tid >> j) & 1) {
+            const int sh = (p & 1) * 16;
+            sel[p >> 1] = (sel[p >> 1] & ~(0xffffu << sh)) | ((uint32_t)((2 * j) | ((2 * j + 1) << 8)) << sh);
+            ++p;
+        }
+        s_lut[tid] = make_uint2(sel[0], sel[1]);
+    }
+    [[maybe_unused]] auto emit4 = [&](uint32_t n0, uint32_t n1, uint32_t n2, uint32_t n3, bool k0, bool k1, bool k2, bool k3) {
+        const uint32_t m = (k0 ? 1u : 0u) | (k1 ? 2u : 0u) | (k2 ? 4u : 0u) | (k3 ? 8u : 0u);
+        const uint2 sel = s_lut[m];
+        const uint32_t x = __builtin_amdgcn_perm(n1, n0, 0x05040100u), y = __builtin_amdgcn_perm(n3, n2, 0x05040100u);
+        const uint64_t p = ((uint64_t)__builtin_amdgcn_perm(y, x, sel.y) << 32) | __builtin_amdgcn_perm(y, x, sel.x);
+        const int np = cnt & 3, sh = np * 16;
+        const uint64_t c_lo = acc | (p << sh), c_hi = (p >> 1) >> (63 - sh);     // (p >> (64 − sh), 0 for sh = 0)
+        const int c = __builtin_popcount(m);
+        const bool flush = np + c >= 4;
+        if (flush) { const int row = cnt >> 2; if (row < A.R_cap) my_rows[(int64_t)row * A.BI] = make_uint2((uint32_t)c_lo, (uint32_t)(c_lo >> 32)); }
+        acc = flush ? c_hi : c_lo;
+        cnt += c;
     };
     __syncthreads();
     {
@@ -622,7 +656,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
             return (hit & XL_EXCLUDED) ? -1 : (int)(hit >> 31);
         };
 #if MHIP_STAMPS
-        if (A.dbg) { int x = nxl; for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, WAVE); if (lane == 0) A.dbg[((size_t)b * NW_ALL + wv_all) * 8 + 6] = (unsigned long long)x; }
+        if (A.dbg && XL && A.xl_start) { int x = nxl; for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, WAVE); if (lane == 0) A.dbg[((size_t)b * NW_ALL + wv_all) * 8 + 6] = (unsigned long long)x; }
 #endif
         const Loc3 my_lc = localise3(my[0], my[1], my[2]);
         const float ml[3] = {(float)my_lc.l0, (float)my_lc.l1, (float)my_lc.l2};
@@ -652,6 +686,9 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
                     if (G.periodic[d]) { if (q < 0) q += G.nc[d]; else if (q >= G.nc[d]) q -= G.nc[d]; }
                     qc[d] = q; lo[d] = max(q - G.stencil[d], 0); hi[d] = min(q + G.stencil[d], s_boxlen[d] - 1);
                 }
+                // (Measured in round 6 and not kept: trimming every row of cells to what the atom's OWN position inside its cell can reach — rows beyond reach skipped, the others cut
+                // at their ends; it removes a third of a LANE's candidates and nothing of a WAVE's trips, whose count per row is the longest lane's: search phase of a block 60.2 →
+                // 63.7 µs at 1M atoms, 6mrr's search 105 → 114 µs.)
                 for (int qz = lo[2]; qz <= hi[2]; ++qz) for (int qy = lo[1]; qy <= hi[1]; ++qy) {
                     const int row = (qz * ly + qy) * lx;
                     const int t0 = t_off[row + lo[0]], t1 = t_off[row + hi[0] + 1];
@@ -679,6 +716,26 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
                     // four candidates per round, their coordinates fetched together: with four waves per SIMD the LDS latency of one
                     // dependent read per candidate was what the walk waited for
                     const int last = t1 - 1;
+                    if constexpr (APPROX && !XL) {
+                        // a candidate set (the outer list) of a system without exception lists: no exact band, no lookups, so the four verdicts are plain compares and
+                        // the kept entries go out together (emit4).  (With exception lists — 6mrr: 64-atom blocks, sixteen j-splits, two candidates per lane and row of
+                        // cells — the four-wide form measured 7 % SLOWER than the entry-by-entry loop below, 113 against 105 µs per search: it stays on that loop.)
+                        typedef float v2f __attribute__((ext_vector_type(2)));
+                        const v2f mx2 = {ml[0], ml[0]}, my2 = {ml[1], ml[1]}, mz2 = {ml[2], ml[2]};
+                        for (; t < t1; t += 4 * A.JS) {
+                            const int ta = t, tb = t + A.JS, tc = t + 2 * A.JS, td = t + 3 * A.JS;
+                            const int ib = min(tb, last), ic = min(tc, last), id = min(td, last);
+                            const v2f dx0 = (v2f){t_x[ta], t_x[ib]} - mx2, dy0 = (v2f){t_y[ta], t_y[ib]} - my2, dz0 = (v2f){t_z[ta], t_z[ib]} - mz2;
+                            const v2f dx1 = (v2f){t_x[ic], t_x[id]} - mx2, dy1 = (v2f){t_y[ic], t_y[id]} - my2, dz1 = (v2f){t_z[ic], t_z[id]} - mz2;
+                            const v2f r20 = __builtin_elementwise_fma(dz0, dz0, __builtin_elementwise_fma(dy0, dy0, dx0 * dx0));
+                            const v2f r21 = __builtin_elementwise_fma(dz1, dz1, __builtin_elementwise_fma(dy1, dy1, dx1 * dx1));
+                            const bool ka = r20.x <= band_hi && (uint32_t)ta != self_t;
+                            const bool kb = r20.y <= band_hi && (uint32_t)tb != self_t && tb < t1;
+                            const bool kc = r21.x <= band_hi && (uint32_t)tc != self_t && tc < t1;
+                            const bool kd = r21.y <= band_hi && (uint32_t)td != self_t && td < t1;
+                            emit4(make_entry((uint32_t)ta, 0u, A.eshift), make_entry((uint32_t)ib, 0u, A.eshift), make_entry((uint32_t)ic, 0u, A.eshift), make_entry((uint32_t)id, 0u, A.eshift), ka, kb, kc, kd);
+                        }
+                    } else {
                     for (; t < t1; t += 4 * A.JS) {
                         const int ta = t, tb = t + A.JS, tc = t + 2 * A.JS, td = t + 3 * A.JS;
                         const float4 pa = t_pos(ta), pb = t_pos(min(tb, last)), pc = t_pos(min(tc, last)), pd = t_pos(min(td, last));
@@ -686,6 +743,7 @@ __global__ void __launch_bounds__(BlockLimits<T>::max_threads) k_build(BuildArgs
                         if (tb < t1) consider(tb, pb);
                         if (tc < t1) consider(tc, pc);
                         if (td < t1) consider(td, pd);
+                    }
                     }
                 }
                 (void)qc;
