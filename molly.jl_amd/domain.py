@@ -22,6 +22,7 @@ MAX all-reduce of two floats per rebuild interval (DomainRun.replan_if_due).
 import ctypes as C
 import itertools
 import math
+import sys
 import time
 
 import numpy as np
@@ -795,14 +796,47 @@ def bench_distributed(m, case, dtype, dt, args, rank, local_rank, world):
     box, origin, periodic = bg.engine_box(pad=0.3)
     vol_frac = np.prod([b / L for b, L in zip(box, case.box)])
     capacity = int(case.n * min(1.0, vol_frac) * 1.25) + 4096
-    eng = HipDomainEngine(make_interactions(case, dtype), dtype, capacity, box, origin, periodic, case.r_list, case.rebuild_every, local_rank, ghost_margin=gm)
     rc_max = max([c[1] for c in ([case.lj.get("cutoff", ("none", 0.0))] if case.lj else []) if len(c) > 1] + ([case.coul.get("rc", 0.0)] if case.coul else []) + [0.0])
-    run = DomainRun(bg, eng, tdtype, device, case.rebuild_every, ghost_margin=gm, skin=case.r_list - rc_max)
-    run.setup_from_global(case.coords, case.velocities, np.zeros(case.n) if case.charge is None else case.charge, case.sigma, case.eps, case.mass)
-    # untimed: equilibrate the jittered lattice first (SURVEY §8(d) cfg 4), then the warm-up
     equil = getattr(args, "equil", None)
     equil = equil if equil is not None else (2000 if getattr(args, "workload", "lj1m").startswith("lj") else 0)
-    run.run(0, equil + args.warmup, dt)
+    # Three forms of the step loop, fastest first.  No rank pair of this repository has met over xGMI before the driver's scaling run, so a form that fails
+    # during the UNTIMED part — a wait for a peer that times out, a HIP error — does not end the job: every rank learns of it (MIN all-reduce of a flag), all contexts are
+    # dropped and the next form starts from the initial state.  The record names the form that ran.  (A fault that kills a process cannot be caught, of course.)
+    forms = [("fused", {}), ("separate launches", {"MOLLYHIP_FUSE_STEP": "0"}), ("host loop", {"MOLLYHIP_ENGINE_LOOP": "0"})]
+    if os.environ.get("MOLLYHIP_ENGINE_LOOP", "1") == "0":
+        forms = forms[2:]
+    elif os.environ.get("MOLLYHIP_FUSE_STEP", "1") == "0":
+        forms = forms[1:]
+    eng = run = None
+    for k, (form, env) in enumerate(forms):
+        os.environ.update(env)
+        ok, why = 1, ""
+        try:
+            eng = HipDomainEngine(make_interactions(case, dtype), dtype, capacity, box, origin, periodic, case.r_list, case.rebuild_every, local_rank, ghost_margin=gm)
+            run = DomainRun(bg, eng, tdtype, device, case.rebuild_every, ghost_margin=gm, skin=case.r_list - rc_max)
+            run.setup_from_global(case.coords, case.velocities, np.zeros(case.n) if case.charge is None else case.charge, case.sigma, case.eps, case.mass)
+            # (tests: the last rank gives up here, behind the collective set-up — its peers then run into the bounded waits of the engine loop, as they would if it had died)
+            if os.environ.get("MOLLYHIP_BENCH_FAIL_FORMS", "") and form in os.environ["MOLLYHIP_BENCH_FAIL_FORMS"].split(",") and rank == world - 1:
+                raise RuntimeError("injected failure (MOLLYHIP_BENCH_FAIL_FORMS, tests)")
+            # untimed: equilibrate the jittered lattice first (SURVEY §8(d) cfg 4), then the warm-up
+            run.run(0, equil + args.warmup, dt)
+            torch.cuda.synchronize()
+        except (_lib.MollyHipError, RuntimeError) as e:
+            ok, why = 0, str(e)
+            print(f"[bench rank {rank}] step loop form '{form}' failed in the untimed part: {why[:300]}", file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            break
+        try:
+            if eng is not None:
+                eng.close()
+        except Exception:
+            pass
+        eng = run = None
+        if k == len(forms) - 1:
+            raise SystemExit(f"every form of the multi-GPU step loop failed (last on this rank: {why[:300] or 'a peer failed'})")
+    loop_form = form
     first = equil + args.warmup
     # the K timed steps are taken as scheduled; windows shorter than a pair-list cycle are repeated back to back until they cover
     # 100 steps and the headline is their mean (bench.py's single-domain leg does the same)
@@ -836,8 +870,8 @@ def bench_distributed(m, case, dtype, dt, args, rank, local_rank, world):
         return None
     agg = torch.stack(per_rank).sum(0).tolist()
     st["n_pairs_full"] = int(agg[0])
-    transport = ("peer stores into IPC-mapped receive regions, step loop inside the engine (mhip_domain_run)" if run.engine_loop
-                 else "all_to_all_single (RCCL) from the host loop")
+    transport = (("peer stores into IPC-mapped receive regions, step loop inside the engine (mhip_domain_run" + (", one launch per plain step)" if loop_form == "fused" else ", separate launches per step)"))
+                 if run.engine_loop else "all_to_all_single (RCCL) from the host loop")
     extra = {"parallelism": f"spatial bricks {grid[0]}x{grid[1]}x{grid[2]}, full-shell ghost coordinates via {transport}, "
                             f"{int(agg[3] / world)} ghosts / {int(agg[4] / world)} owned atoms per GPU, ghost margin {gm:.2f} nm "
                             f"({run.stats['plans']} ghost plans, {run.stats['prunes']} prunes in {run.stats['plan_checks']} checks)",

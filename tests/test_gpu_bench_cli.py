@@ -17,8 +17,8 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _record(cmd, env=None):
-    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, **(env or {})), capture_output=True, text=True, timeout=600)
+def _record(cmd, env=None, timeout=600):
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, **(env or {})), capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout[-2000:]          # stdout carries exactly one line
@@ -71,3 +71,20 @@ def test_bench_two_ranks_record():
     _check_contract(d, 2, 20, 5)
     assert "spatial bricks 2x1x1" in d["config"]["parallelism"]
     assert "cpu_baseline" not in d                                     # rank 0 at N = 1 only
+
+
+def test_bench_two_ranks_falls_back_collectively_when_a_form_of_the_step_loop_fails():
+    """The driver's scaling run is the first time two ranks meet over xGMI.  A form of the step loop that fails in the untimed part on ANY rank — injected here on the
+    last rank, for the fused form and for the in-engine loop with separate launches — makes EVERY rank drop its context and start the next form from the initial state
+    (domain.py bench_distributed); the record names the form that ran."""
+    port = _free_port()
+    d = _record([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                 "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--workload", "lj256k", "--equil", "100"],
+                env={"MOLLYHIP_DIST_BACKEND": "gloo", "MOLLYHIP_FORCE_DEVICE": "0", "MOLLYHIP_BENCH_FAIL_FORMS": "fused,separate launches"}, timeout=240)
+    _check_contract(d, 2, 20, 5)
+    assert "host loop" in d["config"]["parallelism"]
+    port = _free_port()
+    d = _record([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                 "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--workload", "lj256k", "--equil", "100"],
+                env={"MOLLYHIP_DIST_BACKEND": "gloo", "MOLLYHIP_FORCE_DEVICE": "0", "MOLLYHIP_BENCH_FAIL_FORMS": "fused"}, timeout=240)
+    assert "separate launches per step" in d["config"]["parallelism"]
