@@ -174,6 +174,51 @@ def load_traffic(workload, kind=""):
     return None, None, (None, None)
 
 
+def measure_traffic(workload, timeout_s=180):
+    """HBM bytes per launch of the plain pass, the pruning pass and the outer search, MEASURED in this run: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE — they
+    do not fit one pass; counters with --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) of this same command on a shorter schedule, each in a
+    child process; FETCH_SIZE x2 (gfx950 counts 128-byte requests as 64) and KiB units as in profiles/summarize.py, whose kernel naming it shares.
+    → {"plain" | "prune" | "build": {"bytes", "read", "write", "launches"}} or None (no rocprofv3, a pass failed or timed out: the record falls back to the committed files)."""
+    import csv
+    import glob
+    import importlib.util
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe or os.environ.get("MOLLYHIP_BENCH_CHILD"):
+        return None
+    spec = importlib.util.spec_from_file_location("mhip_summarize", os.path.join(ROOT, "profiles", "summarize.py"))
+    summ = importlib.util.module_from_spec(spec); spec.loader.exec_module(summ)
+    env = dict(os.environ, MOLLYHIP_BENCH_CHILD="1", TMPDIR="/tmp")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "200", "--warmup", "50", "--profile-steps", "50", "--no-cpu-baseline", "--no-secondary"]
+    acc = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="mhip_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + cmd, cwd="/tmp", env=env, capture_output=True, timeout=timeout_s)
+            if r.returncode != 0:
+                return None
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") != ctr:
+                        continue
+                    a = acc.setdefault(summ.short(row.get("Kernel_Name", "")), {}).setdefault(ctr, [0.0, 0])
+                    a[0] += float(row.get("Counter_Value", 0)); a[1] += 1
+        except (subprocess.TimeoutExpired, OSError):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out = {}
+    for kind, names in (("plain", ("k_forces_step", "k_forces", "k_forces_gs")), ("prune", ("k_forces_prune",)), ("build", ("k_build",))):
+        k = next((n for n in names if n in acc and "FETCH_SIZE" in acc[n] and "WRITE_SIZE" in acc[n]), None)
+        if k:
+            rd = acc[k]["FETCH_SIZE"][0] / max(acc[k]["FETCH_SIZE"][1], 1) * 1024 * 2
+            wr = acc[k]["WRITE_SIZE"][0] / max(acc[k]["WRITE_SIZE"][1], 1) * 1024
+            out[kind] = {"bytes": rd + wr, "read": rd, "write": wr, "launches": acc[k]["FETCH_SIZE"][1], "kernel": k}
+    return out or None
+
+
 def run_single(m, workload, args, steps, warmup, profile_steps):
     """One workload on one GPU → (record, case, dtype, dt).  Timed region: exactly `steps` steps per window, inputs resident in HBM,
     stream drained on both sides."""
@@ -448,7 +493,7 @@ def run_memlimit(m, args):
             "reference_published": {"NVIDIA GeForce RTX 2080 Ti (11 GB)": 60000, "NVIDIA RTX A6000 (48 GB)": 140000, "NVIDIA GeForce RTX 5090 (32 GB)": 120000}}
 
 
-def make_record(workload, case, dtype, dt, ms_per_step, st, extra, world, args, steps, warmup, profile_steps):
+def make_record(workload, case, dtype, dt, ms_per_step, st, extra, world, args, steps, warmup, profile_steps, live=None):
     steps_s = 1e3 / ms_per_step
     ns_day = steps_s * (dt * 1e3) * 86400 * 1e-6        # dt [ps] → fs
     n_atoms = case.n
@@ -463,6 +508,9 @@ def make_record(workload, case, dtype, dt, ms_per_step, st, extra, world, args, 
     achieved = fbytes / (force_ms * 1e-3) / 1e9 if force_ms > 0 else None
     traffic, traffic_src, traffic_id = load_traffic(workload)
     build_id, src_id = lib_build_id(), kernel_src_id()
+    live = live or {}
+    if "plain" in live:      # measured in this run (measure_traffic): the library's own ids
+        traffic, traffic_src, traffic_id = live["plain"]["bytes"], None, (build_id, src_id)
     per_step = lambda k: st["prof_ms"][k] / max(profile_steps, 1)
     per_call = lambda k: st["prof_ms"][k] / max(st["prof_calls"][k], 1)
 
@@ -472,6 +520,8 @@ def make_record(workload, case, dtype, dt, ms_per_step, st, extra, world, args, 
         if not ms or not nbytes:
             return None
         t, src, tid = load_traffic(workload, kind)
+        if kind.strip("_") in live:
+            t, src, tid = live[kind.strip("_")]["bytes"], "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command in child processes (bench.py measure_traffic)", (build_id, src_id)
         return {"kernel": name, "avg_launch_ms": ms, "launches_in_profile_pass": st["prof_calls"][stage], "algorithmic_bytes_per_launch": nbytes,
                 "achieved": nbytes / (ms * 1e-3) / 1e9, "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": t, "traffic_over_algorithmic": (t / nbytes) if t else None,
                 "traffic_source": src, "traffic_lib_build_id": tid[0], "traffic_is_of_this_build": (tid[0] == build_id) if tid[0] else None,
@@ -479,7 +529,9 @@ def make_record(workload, case, dtype, dt, ms_per_step, st, extra, world, args, 
 
     roofline = {"bound": "hbm", "kernel": "k_forces<STEP> (pair pass + velocity-Verlet update in its epilogue)" if fused else "k_forces", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                "traffic_source": (f"{traffic_src}: rocprofv3 PMC passes of an earlier run of this command (FETCH_SIZE x2 + WRITE_SIZE), not measured in this run" if traffic_src else None),
+                "traffic_source": ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command in child processes (bench.py measure_traffic), FETCH_SIZE x2 gfx950 correction" if "plain" in live else
+                                   (f"{traffic_src}: rocprofv3 PMC passes of an earlier run of this command (FETCH_SIZE x2 + WRITE_SIZE), not measured in this run" if traffic_src else None)),
+                "traffic_read_write": ([live["plain"]["read"], live["plain"]["write"]] if "plain" in live else None),
                 "traffic_lib_build_id": traffic_id[0], "traffic_is_of_this_build": (traffic_id[0] == build_id) if traffic_id[0] else None,
                 "traffic_is_of_these_kernel_sources": (traffic_id[1] == src_id) if traffic_id[1] else None,
                 "traffic_over_algorithmic": (traffic / fbytes) if (traffic and fbytes) else None,
@@ -525,6 +577,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the 6mrr_pme and lj256k records that the default single-GPU run appends")
     ap.add_argument("--integrator", default="vv", choices=["vv", "langevin"], help="vv = the headline VelocityVerlet step; langevin = Langevin middle integrator (single GPU)")
     ap.add_argument("--profile-steps", type=int, default=200, help="steps of the separate hipEvent-timed pass")
+    ap.add_argument("--traffic", default="measure", choices=["measure", "file"], help="roofline.traffic of the main workload: two rocprofv3 PMC passes of this command in child processes (default, single GPU), or the committed files under profiles/")
     ap.add_argument("--block-atoms", type=int, default=0, help="launch shape of the search and pair kernels: i-atoms per workgroup (64, 128, 256; 0 = the engine's choice)")
     ap.add_argument("--j-split", type=int, default=0, help="launch shape: waves sharing one atom's list (a power of two, block_atoms * j_split <= 1024)")
     ap.add_argument("--memlimit-start", type=int, default=1_000_000, help="--workload memlimit: first atom count (doubled until a size fails)")
@@ -571,7 +624,10 @@ def main():
         return
     else:
         ms_per_step, st, extra, case, dtype, dt = run_single(m, args.workload, args, args.steps, args.warmup, args.profile_steps)
-        line = make_record(args.workload, case, dtype, dt, ms_per_step, st, extra, world, args, args.steps, args.warmup, args.profile_steps)
+        # the counters behind roofline.traffic, taken in THIS run (two PMC passes of the same command in child processes, ≈ 20 s each) unless switched off; a run that
+        # is itself such a child, or a box without rocprofv3, reads the committed files and says so
+        live = measure_traffic(args.workload) if args.traffic == "measure" and not args.block_atoms else None
+        line = make_record(args.workload, case, dtype, dt, ms_per_step, st, extra, world, args, args.steps, args.warmup, args.profile_steps, live=live)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(case, dtype, dt)
         if args.workload == "lj1m" and not args.no_secondary and args.integrator == "vv":

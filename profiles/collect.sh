@@ -10,7 +10,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --workload $WL --steps $STEPS --warmup 50 --profile-steps 50 --no-cpu-baseline --no-secondary"
+CMD="python $ROOT/bench.py --workload $WL --steps $STEPS --warmup 50 --profile-steps 50 --no-cpu-baseline --no-secondary --traffic file"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $CMD > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- $CMD > /dev/null 2> "$OUT/pmc_fetch.err"

@@ -37,7 +37,7 @@ def _check_contract(d, n_gpus, steps, warmup):
 
 
 def test_bench_single_gpu_record():
-    d = _record([sys.executable, "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--workload", "lj256k", "--equil", "300", "--no-cpu-baseline"])
+    d = _record([sys.executable, "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--workload", "lj256k", "--equil", "300", "--no-cpu-baseline", "--traffic", "file"])
     _check_contract(d, 1, 20, 5)
     assert d["config"]["parallelism"] == "single domain"
     assert d["config"]["timed_window"].startswith("as scheduled: mean of 5 consecutive windows of 20 steps")   # never placed
@@ -61,6 +61,12 @@ def test_bench_default_workload_carries_the_other_configurations():
     for nm, r in (("lj1m", d), ("6mrr_pme", d["secondary"][0]), ("lj256k", d["secondary"][1])):
         assert abs(d["summary"][nm + "_ms_per_step"] - r["ms_per_step"]) < 1e-5 and abs(d["summary"][nm + "_ns_day"] - r["value"]) < 0.06
     assert len(json.dumps(d["summary"])) < 1200
+    # roofline.traffic of the main workload is MEASURED in the run (two rocprofv3 PMC passes of the same command in child processes), with this library's ids;
+    # the secondaries read the committed counter files and say whether those were taken with this build
+    r = d["roofline"]
+    assert r["traffic_source"].startswith("measured in this run") and r["traffic_is_of_this_build"] is True and 0.9 < r["traffic_over_algorithmic"] < 1.3
+    assert r["list_upkeep"]["prune"]["traffic_source"].startswith("measured in this run") and r["list_upkeep"]["prune"]["traffic"] > 5e8
+    assert d["secondary"][1]["roofline"]["traffic_source"].startswith("profiles/") and d["lib_build_id"] and d["kernel_src_id"]
 
 
 def test_bench_two_ranks_record():
@@ -88,3 +94,16 @@ def test_bench_two_ranks_falls_back_collectively_when_a_form_of_the_step_loop_fa
                  "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--workload", "lj256k", "--equil", "100"],
                 env={"MOLLYHIP_DIST_BACKEND": "gloo", "MOLLYHIP_FORCE_DEVICE": "0", "MOLLYHIP_BENCH_FAIL_FORMS": "fused"}, timeout=240)
     assert "separate launches per step" in d["config"]["parallelism"]
+
+
+def test_bench_memlimit_cli():
+    """`bench.py --workload memlimit` (the reference's GPU memory-limit recipe, docs/src/examples.md:969-1017) at a single size: the record's contract, the pair count
+    on the closed form, Newton's third law over the box, the cube of 10^5 atoms against the oracle.  The full-size result is profiles/r06_memlimit_*.json."""
+    d = _record([sys.executable, "bench.py", "--workload", "memlimit", "--memlimit-start", "400000", "--memlimit-max", "500000"], timeout=400)
+    assert d["metric"] == "max_atoms_100_steps" and d["unit"] == "atoms" and d["value"] == 400000 and d["n_gpus"] == 1 and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert d["config"]["name"] == "memlimit" and "docs/src/examples.md:969-1017" in d["config"]["workload"]
+    t = d["trials"][0]
+    assert t["ok"] and abs(t["pairs_deviation_sigma"]) < 5 and t["net_force_over_abs_force"] < 1e-6 and t["ms_per_step"] > 0 and t["hbm_in_use_gb"] > 0
+    oc = t["oracle_check"]
+    assert oc["passed"] and oc["inner_atoms"] > 90000 and oc["worst_err_over_tol"] <= 1.0
+    assert d["smallest_that_failed"] is None and d["reference_published"]["NVIDIA RTX A6000 (48 GB)"] == 140000

@@ -242,3 +242,24 @@ def test_lj_zero_shortcut_reads_lambda():
     off = lam == 0
     assert np.array_equal(f_lam, f_eps) and np.abs(f_lam[off]).max() == 0.0
     assert np.abs(f_one[off]).max() > 0 and o_lam.potential_energy(nl) == o_eps.potential_energy(nl) != o_one.potential_energy(nl)
+
+
+def test_memory_limit_recipe_inputs():
+    """The system of the reference's "Testing GPU memory limits" example (docs/src/examples.md:969-1000) as molly.jl_amd/workloads.py builds it for
+    `bench.py --workload memlimit` and tests/test_gpu_large.py: V = n · 0.013 nm³ and its cube root in Float32, the list radius = the cutoff = 1.0 nm with the
+    GPUNeighborFinder's default cadence of 25 steps (src/neighbors.jl:327), zero velocities — and, for uniformly random points in a periodic box, a pair count on the
+    closed form N(N−1)/2 · (4/3)π r³ / V that the benchmark holds every size to."""
+    import importlib
+    from tests import systems as S
+    W = importlib.import_module("molly_jl_amd.workloads")
+    assert W.memlimit_box(140000) == float(np.cbrt(np.float32(140000) * np.float32(0.013), dtype=np.float32))
+    n = 30000
+    case = W.memlimit_fluid(n, seed=3)
+    assert case.r_list == 1.0 and case.lj["cutoff"] == ("distance", 1.0) and case.rebuild_every == 25 and not case.velocities.any()
+    assert np.all(case.sigma == 0.001) and np.all(case.eps == 0.1) and np.all(case.mass == 10.0)
+    assert case.coords.min() >= 0 and case.coords.max() < case.box[0]
+    oi, oj, _ = case.oracle(np.float32).neighbors("cell", nthreads=4)
+    expect = 0.5 * n * (n - 1) * (4.0 / 3.0) * math.pi / float(case.box[0]) ** 3
+    assert abs(len(oi) - expect) < 5 * math.sqrt(expect)
+    bi, bj, _ = case.oracle(np.float32).neighbors("brute")
+    assert np.array_equal(S.pair_keys(oi, oj), S.pair_keys(bi, bj))

@@ -6,7 +6,7 @@ timeout 1500 python -m pytest tests/test_gpu_domain.py tests/test_gpu_bench_cli.
 tail -5 $out/${tag}_domaintest.log
 for fd in 0 1; do
   if [ $fd = 1 ]; then export MOLLYHIP_FORCE_DOMAIN=1; else unset MOLLYHIP_FORCE_DOMAIN; fi
-  timeout 600 python bench.py --no-secondary --no-cpu-baseline --steps 2000 --warmup 200 > $out/${tag}_lj1m_fd$fd.json 2> $out/${tag}_lj1m_fd$fd.err
+  timeout 600 python bench.py --no-secondary --no-cpu-baseline --traffic file --steps 2000 --warmup 200 > $out/${tag}_lj1m_fd$fd.json 2> $out/${tag}_lj1m_fd$fd.err
   python - <<PY
 import json
 try:

@@ -4,16 +4,12 @@
 # Summaries land in gpurun_out/; copy the ones to be judged into profiles/.
 cd "$(dirname "$0")/.."; R=$PWD; out=$R/gpurun_out; mkdir -p $out; tag=${1:-r05}
 for wl in lj1m lj256k 6mrr_pme; do timeout 900 bash $R/profiles/collect.sh $wl ${tag}_$wl 200 > $out/collect_$wl.log 2>&1; cd $R
+  cp $out/prof_${tag}_$wl/${tag%%_*}_traffic_${wl}*.json $out/ 2>/dev/null      # per-kernel counter files with the library's ids (profiles/summarize.py): what bench.py's load_traffic reads
   python - <<PY
 import json
 try:
     d = json.load(open("$out/prof_${tag}_$wl/summary.json"))
-    k = d.get("dominant_kernel", "k_forces")
-    t = {"workload": "$wl", "hbm_bytes_per_force_launch": d.get("hbm_bytes_per_force_launch"), "hbm_read_bytes_per_force_launch": d.get("hbm_read_bytes_per_force_launch"),
-         "hbm_write_bytes_per_force_launch": d.get("hbm_write_bytes_per_force_launch"),
-         "source": "${tag}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, profiles/collect.sh), FETCH_SIZE x2 gfx950 correction, KiB units; kernel " + k + " (non-pruning passes); profiles/${tag}_${wl}_summary.json"}
-    json.dump(t, open("$out/${tag}_traffic_$wl.json", "w"), indent=1)
-    print("$wl", k, {n: round(v["avg_us"], 2) for n, v in sorted(d["kernels"].items(), key=lambda kv: -kv[1]["total_ns"])[:8]}, t["hbm_bytes_per_force_launch"])
+    print("$wl", d.get("dominant_kernel"), {n: round(v["avg_us"], 2) for n, v in sorted(d["kernels"].items(), key=lambda kv: -kv[1]["total_ns"])[:8]}, d.get("hbm_bytes_per_force_launch"), d.get("lib_build_id"))
 except Exception as e:
     print("$wl summary FAILED", e)
 PY

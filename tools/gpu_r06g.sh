@@ -2,7 +2,7 @@
 out=gpurun_out; mkdir -p $out
 timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_6mrr.py tests/test_gpu_cadence.py tests/test_gpu_edge_cases.py tests/test_gpu_triclinic.py -q -x --timeout 900 -p no:cacheprovider 2>&1 | tail -4
 for wl in lj1m lj256k 6mrr_pme; do
-    timeout 300 python bench.py --workload $wl --no-cpu-baseline --no-secondary --steps 4000 --warmup 1000 > $out/g.json 2> $out/g.err
+    timeout 300 python bench.py --workload $wl --no-cpu-baseline --no-secondary --traffic file --steps 4000 --warmup 1000 > $out/g.json 2> $out/g.err
     python - <<PY
 import json
 try:

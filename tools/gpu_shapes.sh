@@ -4,7 +4,7 @@ out=gpurun_out; mkdir -p $out
 for k in ${1:-50 63 79}; do
  for shape in "256 2" "256 4" "128 4" "128 8" "128 2" "64 8"; do
   set -- $shape
-  timeout 300 python bench.py --workload lj_side$k --no-cpu-baseline --no-secondary --steps 3000 --warmup 500 --block-atoms $1 --j-split $2 > $out/shape.json 2> $out/shape.err
+  timeout 300 python bench.py --workload lj_side$k --no-cpu-baseline --no-secondary --traffic file --steps 3000 --warmup 500 --block-atoms $1 --j-split $2 > $out/shape.json 2> $out/shape.err
   python - <<PY
 import json
 try:

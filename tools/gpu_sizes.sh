@@ -2,7 +2,7 @@
 # the benchmark fluid at the sizes a brick of lj1m owns on 2, 4 and 8 GPUs (the scaling model's pass times), single domain, fused steps
 out=gpurun_out; mkdir -p $out
 for k in 79 63 50; do
-  timeout 300 python bench.py --workload lj_side$k --no-cpu-baseline --no-secondary --steps 3000 --warmup 500 > $out/r06_size_$k.json 2> $out/r06_size_$k.err
+  timeout 300 python bench.py --workload lj_side$k --no-cpu-baseline --no-secondary --traffic file --steps 3000 --warmup 500 > $out/r06_size_$k.json 2> $out/r06_size_$k.err
   python - <<PY
 import json
 try:

@@ -2,7 +2,7 @@
 # which kernels surround the runtime's fill / copy kernels?  (kernel trace of a short run, dispatch order)
 out=$PWD/gpurun_out/trace_seq; mkdir -p $out; export TMPDIR=/tmp; wl=${1:-lj1m}; root=$PWD
 cd /tmp
-rocprofv3 --kernel-trace --output-format csv -d $out/t -- python $root/bench.py --workload $wl --steps 300 --warmup 50 --profile-steps 0 --no-cpu-baseline --no-secondary --equil 0 > /dev/null 2> $out/err.txt
+rocprofv3 --kernel-trace --output-format csv -d $out/t -- python $root/bench.py --workload $wl --steps 300 --warmup 50 --profile-steps 0 --no-cpu-baseline --no-secondary --traffic file --equil 0 > /dev/null 2> $out/err.txt
 python - "$out" <<'PY'
 import csv, glob, sys, re, collections
 f = glob.glob(sys.argv[1] + "/t/**/*kernel_trace.csv", recursive=True)[0]
