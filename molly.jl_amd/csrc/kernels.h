@@ -131,10 +131,16 @@ template <class T> __device__ inline T local_coord(T x, T c, T L, T invL) {
 // cubic 1M-atom fluid ran 12 % slower, 0.105 against 0.093 ms per pass)
 template <bool TRI, class T, class V4> __device__ inline void local_xyz_t(T& x, T& y, T& z, const V4& ctr, const GridP<T>& G) {
     if constexpr (TRI) {
+        // The fractional coordinates decide only WHICH image (three small integers); the local coordinates themselves are Cartesian differences against the
+        // centre's Cartesian position — the same number for every atom localised against this centre, so it cancels in every pair — minus whole lattice vectors.
+        // Round 6: going there and back through the fractional coordinates (s − ctr, × basis) cost an ulp of the CELL per atom — 1.5e-6 nm in a 13 nm fp32 cell,
+        // 7.6e-5 of a contact pair's force (tools/micro/tri_xl_check.py) — where an atom that needs no shift now carries the rounding of a small number.
         T s[3]; frac_coords(x, y, z, G, s);
-        T d0 = s[0] - ctr.x, d1 = s[1] - ctr.y, d2 = s[2] - ctr.z;
-        d0 -= M<T>::rint(d0); d1 -= M<T>::rint(d1); d2 -= M<T>::rint(d2);
-        x = d0 * G.bv[0][0] + d1 * G.bv[1][0] + d2 * G.bv[2][0]; y = d1 * G.bv[1][1] + d2 * G.bv[2][1]; z = d2 * G.bv[2][2];
+        const T n0 = M<T>::rint(s[0] - ctr.x), n1 = M<T>::rint(s[1] - ctr.y), n2 = M<T>::rint(s[2] - ctr.z);
+        const T cx = ctr.x * G.bv[0][0] + ctr.y * G.bv[1][0] + ctr.z * G.bv[2][0], cy = ctr.y * G.bv[1][1] + ctr.z * G.bv[2][1], cz = ctr.z * G.bv[2][2];
+        x = M<T>::fma(-n2, G.bv[2][0], M<T>::fma(-n1, G.bv[1][0], M<T>::fma(-n0, G.bv[0][0], x))) - cx;
+        y = M<T>::fma(-n2, G.bv[2][1], M<T>::fma(-n1, G.bv[1][1], y)) - cy;
+        z = M<T>::fma(-n2, G.bv[2][2], z) - cz;
     } else {
         x = G.periodic[0] ? local_coord(x, (T)ctr.x, G.L[0], G.invL[0]) : x - ctr.x;
         y = G.periodic[1] ? local_coord(y, (T)ctr.y, G.L[1], G.invL[1]) : y - ctr.y;

@@ -20,6 +20,7 @@ template <> struct M<float> {
     __device__ static inline float rint(float x) { return ::rintf(x); }
     __device__ static inline float floor(float x) { return ::floorf(x); }
     __device__ static inline float fabs(float x) { return ::fabsf(x); }
+    __device__ static inline float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
     // individually rounded operations: hipcc's default -ffp-contract=fast would otherwise fuse a*b+c into one
     // FMA (HIP's __fmul_rn/__fadd_rn are plain operators on AMD and do NOT prevent that)
     __device__ static inline float mul(float a, float b) {
@@ -45,6 +46,7 @@ template <> struct M<double> {
     __device__ static inline double rint(double x) { return ::rint(x); }
     __device__ static inline double floor(double x) { return ::floor(x); }
     __device__ static inline double fabs(double x) { return ::fabs(x); }
+    __device__ static inline double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
     __device__ static inline double mul(double a, double b) {
 #pragma clang fp contract(off)
         return a * b;
