@@ -1024,6 +1024,7 @@ template <class T> class Engine final : public EngineBase {
             inner_is_outer = false;
             if (GS > 0) { cnt_in.reserve((size_t)n_blocks * JS * BI); A.cnt_dst = cnt_in.p; }   // (k_regroup wants the real entries per (sub-list, lane))
             A.mark_off = (int)((lds_force + 15) & ~(size_t)15);
+            if (A.soa && A.mark_off != prune_mark_ct(A.soa)) throw ApiError{MHIP_ERR_STATE, "internal: the packed pruning pass expects its renumbering table at " + std::to_string(prune_mark_ct(A.soa)) + ", the carve-up put it at " + std::to_string(A.mark_off)};
             lds_force = (size_t)A.mark_off + prune_lds_bytes(tile_lds, BI * JS);   // + renumbering table + scan scratch + wave boxes
             if (lds_force > (size_t)MAX_LDS_BYTES) throw ApiError{MHIP_ERR_CAPACITY, "prune pass LDS carve-up exceeds 160 KiB"};
         }

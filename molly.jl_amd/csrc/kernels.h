@@ -1325,6 +1325,8 @@ template <class T> struct ForceArgs {
 constexpr int SOA_STRIDES[3] = {2049, 3073, 4097};
 // dynamic LDS a PRUNE pass needs behind its tile: the renumbering table (2 bytes per tile atom of a segment), scan scratch, eight boxes,
 // the atoms' row counts (lane order) and the destination waves' row counts
+// where the packed pruning pass keeps its renumbering table: right behind the three tile arrays of stride `soa` dwords (+ 64 bytes), as launch_pair_kernel carves it
+__host__ __device__ constexpr int prune_mark_ct(int soa) { return (3 * soa * 4 + 64 + 15) & ~15; }
 __host__ __device__ inline size_t prune_lds_bytes(int t_seg, int nthr) { return (size_t)(((t_seg + 8) & ~7) * 2) + ((size_t)nthr + 4) * 4 + 8 * 8 * 4 + ((size_t)nthr + 64) * 4 + 16 * 8 + 32; }   // (+ the 16 byte-permute selectors of the row compaction)
 
 // (the plain fp32 one-type passes run four 512-lane blocks per CU = eight waves per SIMD, which takes <= 64 VGPRs: held by attribute)
@@ -1637,7 +1639,8 @@ k_forces(ForceArgs<T> A) {
             {
                 int run = n_new + l_scan[tid];
                 for (int t = t0; t < t1; ++t) {
-                    if ((t - t0 < 32) ? ((keep_bits >> (t - t0)) & 1u) != 0u : stays(t)) { l_new[t] = (uint16_t)run; A.tile_idx_dst[(int64_t)b * A.T_cap + run] = tix[seg_lo + t]; ++run; }
+                    // (the packed loop reads the new slot as the ENTRY it emits — the slot's byte offset, slot << 2 — and saves the shift per entry)
+                    if ((t - t0 < 32) ? ((keep_bits >> (t - t0)) & 1u) != 0u : stays(t)) { l_new[t] = (uint16_t)(packed3 ? run << ESHIFT_SCALED : run); A.tile_idx_dst[(int64_t)b * A.T_cap + run] = tix[seg_lo + t]; ++run; }
                     else l_new[t] = (uint16_t)0xffffu;
                 }
             }
@@ -1688,8 +1691,13 @@ k_forces(ForceArgs<T> A) {
                     if constexpr (PRUNE) {   // (no slot test: the sentinel slot — padding, and everything a lane without an atom holds — lies 10⁴ nm away)
                         // the four new slot numbers are fetched up front, with the coordinates: looked up inside the branches, each kept
                         // entry waited for an LDS round trip of its own
-                        const uint32_t na = l_new[oa >> 2], nb = l_new[ob >> 2], nc = l_new[oc >> 2], nd = l_new[od >> 2];
-                        emit4(na << ESHIFT_SCALED, nb << ESHIFT_SCALED, nc << ESHIFT_SCALED, nd << ESHIFT_SCALED, r20.x <= rp2, r20.y <= rp2, r21.x <= rp2, r21.y <= rp2);
+                        // (round 6: the table sits at a compile-time LDS address behind the three tile arrays — A.mark_off, which the engine forms from the same numbers and
+                        // launch_pair_kernel checks — so an entry's look-up is ONE shift and a read with an immediate offset, and the table holds the new entries themselves:
+                        // 12 VALU instructions fewer per row of four than base + ((entry >> 2) << 1), read, << 2)
+                        typedef __attribute__((address_space(3))) const unsigned short* lds_hptr;
+                        auto new_entry = [&](uint32_t o) -> uint32_t { return (uint32_t)*(lds_hptr)(lbase + prune_mark_ct(SOA_STRIDE) + (o >> 1)); };
+                        const uint32_t na = new_entry(oa), nb = new_entry(ob), nc = new_entry(oc), nd = new_entry(od);
+                        emit4(na, nb, nc, nd, r20.x <= rp2, r20.y <= rp2, r21.x <= rp2, r21.y <= rp2);
                     }
                     const float t0 = __builtin_amdgcn_rcpf(r20.x * r20.y), t1 = __builtin_amdgcn_rcpf(r21.x * r21.y);
                     const v2f u0 = (v2f){r20.y, r20.x} * t0, u1 = (v2f){r21.y, r21.x} * t1;       // 1/r² of each partner
