@@ -577,6 +577,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the 6mrr_pme and lj256k records that the default single-GPU run appends")
     ap.add_argument("--integrator", default="vv", choices=["vv", "langevin"], help="vv = the headline VelocityVerlet step; langevin = Langevin middle integrator (single GPU)")
     ap.add_argument("--profile-steps", type=int, default=200, help="steps of the separate hipEvent-timed pass")
+    ap.add_argument("--fail-forms", default="", help=argparse.SUPPRESS)      # tests: forms of the multi-GPU step loop ("fused", "separate launches") that the last rank gives up in the untimed part
     ap.add_argument("--traffic", default="measure", choices=["measure", "file"], help="roofline.traffic of the main workload: two rocprofv3 PMC passes of this command in child processes (default, single GPU), or the committed files under profiles/")
     ap.add_argument("--block-atoms", type=int, default=0, help="launch shape of the search and pair kernels: i-atoms per workgroup (64, 128, 256; 0 = the engine's choice)")
     ap.add_argument("--j-split", type=int, default=0, help="launch shape: waves sharing one atom's list (a power of two, block_atoms * j_split <= 1024)")

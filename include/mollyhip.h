@@ -33,8 +33,8 @@
  * the caller owns every pointer it passes and may free it when the call returns.
  *
  * Environment (read when a context is created; the defaults are the product, every value below is exercised by a test of tests/):
- *   MOLLYHIP_DEBUG=1               list-maintenance decisions (searches, prunes, skin changes) on stderr
- *   MOLLYHIP_TRACE=1               drain the stream before every launch and name it on stderr (the last name a dying process printed faulted)
+ *   MOLLYHIP_DEBUG=1 | 2 | 3       1: list-maintenance decisions (searches, prunes, skin changes) on stderr; 2: drain the stream before every launch and name it
+ *                                  on stderr (the last name a dying process printed faulted); 3: both
  *   MOLLYHIP_XFER_TIMEOUT_MS=n     bound of every in-kernel wait for a peer rank (default 2000)
  *   MOLLYHIP_OUTER_MARGIN_PM=n     margin of the outer pair list in picometres (default 200; 0: one list of radius r_list)
  *   MOLLYHIP_INNER_SKIN_PM=n       skin of the inner pair list in picometres (default 100, never more than r_list − cutoff); MOLLYHIP_INNER_SKIN_FIXED=1 stops it growing

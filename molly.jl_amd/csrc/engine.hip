@@ -240,10 +240,10 @@ template <class T> class Engine final : public EngineBase {
     int64_t n_rebuilds = 0, n_force_calls = 0, n_gs_passes = 0; double last_rebuild_ms = 0;
     size_t lds_force = 0; int tile_lds = 0; bool segmented = false; int last_pass_tile = 0;
     Prof prof;
-    // MOLLYHIP_TRACE=1: drain the stream, then name the launch that follows on stderr — the last name a dying process printed is the
+    // MOLLYHIP_DEBUG=2: drain the stream, then name the launch that follows on stderr — the last name a dying process printed is the
     // kernel that faulted (a GPU fault aborts the process from the runtime's callback, no status ever comes back)
-    const bool trace_on = env_int("MOLLYHIP_TRACE", 0) != 0;
-    const bool debug_on = env_int("MOLLYHIP_DEBUG", 0) != 0;      // MOLLYHIP_DEBUG=1: the list-maintenance decisions on stderr (read once, when the context is made)
+    const bool trace_on = env_int("MOLLYHIP_DEBUG", 0) >= 2;
+    const bool debug_on = env_int("MOLLYHIP_DEBUG", 0) == 1 || env_int("MOLLYHIP_DEBUG", 0) >= 3;      // MOLLYHIP_DEBUG=1 (or 3: both): the list-maintenance decisions on stderr (read once, when the context is made)
     void tr(const char* what) {
         if (!trace_on) return;
         (void)hipStreamSynchronize(stream);

@@ -816,8 +816,8 @@ def bench_distributed(m, case, dtype, dt, args, rank, local_rank, world):
             run = DomainRun(bg, eng, tdtype, device, case.rebuild_every, ghost_margin=gm, skin=case.r_list - rc_max)
             run.setup_from_global(case.coords, case.velocities, np.zeros(case.n) if case.charge is None else case.charge, case.sigma, case.eps, case.mass)
             # (tests: the last rank gives up here, behind the collective set-up — its peers then run into the bounded waits of the engine loop, as they would if it had died)
-            if os.environ.get("MOLLYHIP_BENCH_FAIL_FORMS", "") and form in os.environ["MOLLYHIP_BENCH_FAIL_FORMS"].split(",") and rank == world - 1:
-                raise RuntimeError("injected failure (MOLLYHIP_BENCH_FAIL_FORMS, tests)")
+            if form in (getattr(args, "fail_forms", "") or "").split(",") and rank == world - 1:
+                raise RuntimeError("injected failure (bench.py --fail-forms, tests)")
             # untimed: equilibrate the jittered lattice first (SURVEY §8(d) cfg 4), then the warm-up
             run.run(0, equil + args.warmup, dt)
             torch.cuda.synchronize()

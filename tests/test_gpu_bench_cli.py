@@ -85,14 +85,14 @@ def test_bench_two_ranks_falls_back_collectively_when_a_form_of_the_step_loop_fa
     (domain.py bench_distributed); the record names the form that ran."""
     port = _free_port()
     d = _record([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                 "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--workload", "lj256k", "--equil", "100"],
-                env={"MOLLYHIP_DIST_BACKEND": "gloo", "MOLLYHIP_FORCE_DEVICE": "0", "MOLLYHIP_BENCH_FAIL_FORMS": "fused,separate launches"}, timeout=240)
+                 "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--workload", "lj256k", "--equil", "100", "--fail-forms", "fused,separate launches"],
+                env={"MOLLYHIP_DIST_BACKEND": "gloo", "MOLLYHIP_FORCE_DEVICE": "0"}, timeout=240)
     _check_contract(d, 2, 20, 5)
     assert "host loop" in d["config"]["parallelism"]
     port = _free_port()
     d = _record([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                 "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--workload", "lj256k", "--equil", "100"],
-                env={"MOLLYHIP_DIST_BACKEND": "gloo", "MOLLYHIP_FORCE_DEVICE": "0", "MOLLYHIP_BENCH_FAIL_FORMS": "fused"}, timeout=240)
+                 "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--workload", "lj256k", "--equil", "100", "--fail-forms", "fused"],
+                env={"MOLLYHIP_DIST_BACKEND": "gloo", "MOLLYHIP_FORCE_DEVICE": "0"}, timeout=240)
     assert "separate launches per step" in d["config"]["parallelism"]
 
 
