@@ -1,4 +1,5 @@
 #!/bin/bash
+# a quick gate while working on the kernels: the parity tests that build, prune and walk lists (123 cases, two minutes) + the three bench workloads' stage timers
 out=gpurun_out; mkdir -p $out
 timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_6mrr.py tests/test_gpu_cadence.py tests/test_gpu_edge_cases.py tests/test_gpu_triclinic.py -q -x --timeout 900 -p no:cacheprovider 2>&1 | tail -4
 for wl in lj1m lj256k 6mrr_pme; do
