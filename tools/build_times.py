@@ -20,14 +20,15 @@ def main():
     start, end = us[:, :, 0].min(axis=1), us[:, :, 3].max(axis=1)
     start -= start.min(); end -= us[:, :, 0].min()
     stage, search = (us[:, :, 1] - us[:, :, 0]).max(axis=1), (us[:, :, 2] - us[:, :, 1]).max(axis=1)
-    if d[:, :, 7].any():      # finer stamps of the staging part (systems without exception lists): boxes | cell pruning + scan | atom pruning + compaction (+ the cell-offset scan)
+    fine = d[:, :, 7].any() and (d[:, :, 6] > d[:, :, 0]).all()      # slot 6 is a time stamp only for systems without exception lists (else: the lists' lengths)
+    if fine:      # finer stamps of the staging part (systems without exception lists): boxes | cell pruning + scan | atom pruning + compaction (+ the cell-offset scan)
         t7 = (d[:, :, 7].astype(np.int64) - t0) * 0.01; t6 = (d[:, :, 6].astype(np.int64) - t0) * 0.01
         for name, a in (("  boxes", (t7 - us[:, :, 0]).max(axis=1)), ("  cell pruning + scan", (t6 - t7).max(axis=1)), ("  atoms: fetch, prune, compact", (us[:, :, 1] - t6).max(axis=1))):
             print(f"  {name:24s} mean {a.mean():.1f} p10 {np.percentile(a, 10):.1f} p50 {np.median(a):.1f} p90 {np.percentile(a, 90):.1f} max {a.max():.1f} us")
     print(f"{len(d)} blocks, first entry -> last exit {end.max():.1f} us; starts within {start.max():.1f} us")
     for name, a in (("boxes + cells + staging", stage), ("search", search), ("block total", end - start)):
         print(f"  {name:24s} mean {a.mean():.1f} p10 {np.percentile(a, 10):.1f} p50 {np.median(a):.1f} p90 {np.percentile(a, 90):.1f} max {a.max():.1f} us")
-    if d[:, :, 7].any():
+    if fine:
         nxl = nxl * 0
     x = nxl.sum(axis=1) / float(nw) / 64.0
     print(f"  exception-list entries per atom of a block: mean {x.mean():.1f} p10 {np.percentile(x, 10):.1f} p90 {np.percentile(x, 90):.1f} max {x.max():.1f}")
