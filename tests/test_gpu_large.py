@@ -69,3 +69,14 @@ def test_memlimit_recipe_against_oracle(pkg):
     d = s.coords.astype(np.float64) - o.coords
     d -= np.round(d / case.box) * case.box
     assert np.abs(d).mean() < 5e-4 and np.abs(d).max() < 5e-3                   # test/simulation.jl:625's fp32 trajectory bar
+
+
+def test_memlimit_recipe_at_sixteen_million_atoms(pkg):
+    """One size of `bench.py --workload memlimit` far beyond anything an oracle can follow — 16 000 000 atoms, 22 GB, 2.6·10⁹ pairs, device-generated inputs handed over as
+    device pointers — held to what does not need one: the pair count on the closed form N(N−1)/2 · (4/3)π r³ / V (± 5 σ), Newton's third law over the whole box, finite
+    state after the recipe's 100 + 100 steps.  114 times the reference's largest published size for this recipe (140 000 atoms on a 48 GB card)."""
+    import bench
+    r = bench.memlimit_trial(pkg, 16_000_000)
+    assert r["ok"], r
+    assert abs(r["pairs_deviation_sigma"]) < 5 and r["net_force_over_abs_force"] < 1e-6
+    assert 1.0 < r["hbm_in_use_gb"] < 40 and r["n_rebuilds"] >= 8 and r["block_atoms"] * r["j_split"] <= 1024
