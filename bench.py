@@ -174,7 +174,7 @@ def load_traffic(workload, kind=""):
     return None, None, (None, None)
 
 
-def measure_traffic(workload, timeout_s=180):
+def measure_traffic(workload, timeout_s=90):
     """HBM bytes per launch of the plain pass, the pruning pass and the outer search, MEASURED in this run: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE — they
     do not fit one pass; counters with --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) of this same command on a shorter schedule, each in a
     child process; FETCH_SIZE x2 (gfx950 counts 128-byte requests as 64) and KiB units as in profiles/summarize.py, whose kernel naming it shares.
