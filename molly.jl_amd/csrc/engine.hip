@@ -612,19 +612,15 @@ template <class T> class Engine final : public EngineBase {
             A.cnt_out = nullptr; cnt_outer_valid = false;
             A.dbg = stamps_begin((size_t)n_blocks * 16 * 8);
             if (gs_groups() > 0 && adopt_env) { cnt_outer.reserve((size_t)n_blocks * JS * BI); A.cnt_out = cnt_outer.p; cnt_outer_valid = true; }
-            // The walk with BOTH the exact band decisions and the exception lookups compiled in (k_build<T, true, false, true>: a single list of a system
-            // with exclusions) is kept away from blocks of more than 64 atoms: at 128- and 256-atom blocks every i-wave but the first came out with an empty list (round 5,
-            // tools/micro/xl_waves.py: 2.86 M of 5.70 M pairs of a 46 656-atom charged fluid; forces off by the mean force on half the atoms), and with
-            // exception-free systems routed through it a 100-atom lattice aborted the process.  Each half works on its own at every shape — exact
-            // decisions without lookups (tools/micro/nondual_check.py), lookups with the candidate-set test (every dual list of a protein) —; together
-            // they are 10 658 lines of ISA with 104 / 477 SGPR spills to VGPR lanes and back under the 128-VGPR bound.  Larger blocks of such systems take
-            // the transposed search, which is exact at every shape (same tool); exception-free systems the walk without the lookups; 64-atom blocks — one
-            // i-wave, the one that always came out right, four rounds of parity tests — keep the variant.  (A triclinic cell grid has no transposed
-            // search — its box tests are Cartesian —: there the blocks are cut to 64 atoms instead.)
-            if (A.walk && A.xl_start && !A.approx && BI > 64) {
-                if (!tri_grid) { A.walk = 0; walk = false; lds = build_lds_bytes(T_cap, BI, C_cap, false); }
-                else { BI = 64; JS = std::min(16, MAX_THREADS / BI); estimate_capacities(); continue; }
-            }
+            // (k_build<T, true, false, true> — the walk with BOTH the exact band decisions and the exception lookups compiled in, the single exact list of a system with
+            // exclusions — was kept to 64-atom blocks from the end of round 5: at 128- and 256-atom blocks every i-wave but the first had come out with an empty list
+            // (tools/micro/xl_waves.py: 2.86 M of 5.70 M pairs of a 46 656-atom charged fluid).  Round 6 bisected it: commit e502d9c shows the defect with the detour
+            // switched off, its successor 72454c0 does not.  That commit — made for speed, behind the detour — took the staged atom's local frame out of two private ARRAYS
+            // written through a pointer chosen at run time (the two branches' stores merged) and living in scratch; in this one instantiation, under the 128-VGPR bound with
+            // 104 SGPR spills, the arrays of the waves behind the first were not addressed where they were read back (an i-atom with garbage local coordinates finds no
+            // neighbour).  With the frame in six scalars the variant is right at every shape — fp32 and fp64, 128 x 4 and 256 x 2, cubic and triclinic grids, pair SET and
+            // special flags against the oracle — and the detour is gone; tests/test_gpu_parity.py::test_single_pair_list_with_128_and_256_atom_blocks[charged-*] and
+            // tests/test_gpu_triclinic.py::test_triclinic_single_list_with_exceptions_beyond_64_atom_blocks run it at those shapes.)
             prof.begin(1, stream);
             tr("k_build");
             auto go = [&](auto kern) { set_lds_limit(kern, lds); hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(BI * JS), lds, stream, A); };

@@ -414,7 +414,7 @@ def test_fused_velocity_verlet_with_net_momentum_matches_oracle(pkg, n_steps, cm
     assert np.abs(pkg.forces(s) - f_ref).max() < 1e-7 * np.abs(f_ref).max()
 
 
-@pytest.mark.parametrize("kind,n_side", [("lj", 40), ("lj", 48), ("charged", 36), ("charged", 14)])
+@pytest.mark.parametrize("kind,n_side", [("lj", 40), ("lj", 48), ("charged", 36), ("charged", 48), ("charged", 14)])
 def test_single_pair_list_with_128_and_256_atom_blocks(pkg, kind, n_side, monkeypatch):
     """The single (non-dual) pair list — what a context falls back to when the dual list does not pay or does not fit, and what a sub-domain without a
     ghost margin uses — at the sizes where the blocks hold 128 (40 000+ atoms) and 256 atoms (100 000+).  Round 5 found the search with exact band
@@ -431,10 +431,11 @@ def test_single_pair_list_with_128_and_256_atom_blocks(pkg, kind, n_side, monkey
     f_ref = o.forces(nl, nthreads=16)
     f = pkg.forces(s).astype(np.float64)
     st = s.stats()
-    # ("charged", 14): 2 744 atoms in 64-atom blocks — the one shape that still runs the walk with exact band decisions AND exception lookups compiled in
-    # (k_build<T, true, false, true>, engine.hip rebuild_impl); the larger charged case is the reroute of that variant to the transposed search
+    # the charged cases run the walk with exact band decisions AND exception lookups compiled in (k_build<T, true, false, true>) at 64 x 16 (n_side 14), 128 x 4 (36)
+    # and 256 x 2 (48): the variant whose defect round 6 bisected to private arrays in scratch (engine.hip rebuild_impl) and that was detoured beyond 64-atom blocks until then
     assert st["block_atoms"] >= 128 or n_side == 14, st["block_atoms"]
     assert n_side != 14 or st["block_atoms"] == 64
+    assert (kind, n_side) != ("charged", 48) or st["block_atoms"] == 256
     err = np.linalg.norm(f - f_ref, axis=1)
     S.fp32_check(err, tol)
     keys, n_special = S.export_keys(pkg, s)

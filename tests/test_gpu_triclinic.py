@@ -144,10 +144,11 @@ def test_triclinic_cell_grid_list_and_forces(pkg, dtype, approx):
 
 
 def test_triclinic_single_list_with_exceptions_beyond_64_atom_blocks(pkg, monkeypatch):
-    """the search variant with exact band decisions and exception lookups is kept to 64-atom blocks; on a triclinic cell grid (no transposed search to
-    fall back to) a system whose size class would take 128-atom blocks is cut to 64-atom blocks instead (engine.hip rebuild_impl).  42 875 atoms in a sheared cell,
-    excluded and special pairs, the single exact list (no outer margin): pair SET and special flags against the brute-force oracle of the same precision, forces
-    against the fp64 oracle."""
+    """the search variant with exact band decisions and exception lookups (k_build<T, true, false, true>) lost the lists of every i-wave but the first beyond
+    64-atom blocks and was detoured there — on a triclinic cell grid, which has no transposed search, by cutting the blocks to 64 atoms.  Round 6 bisected the defect
+    to private arrays in scratch that a later commit had already removed (engine.hip rebuild_impl) and took the detour out: 42 875 atoms in a sheared cell now search in
+    128-atom blocks.  Excluded and special pairs, the single exact list (no outer margin): pair SET and special flags against the brute-force oracle of the same
+    precision, forces against the fp64 oracle."""
     monkeypatch.setenv("MOLLYHIP_OUTER_MARGIN_PM", "0")
     # (the jitter is fractional: scaled so that it stays the ±0.06 nm of the 8 000-atom cell — at ±0.1 nm atoms overlap, forces reach 2·10⁵ kJ mol⁻¹ nm⁻¹ ∝ r⁻¹³ and the
     # fp32 rounding of a coordinate in a 13 nm cell, 1e-6 nm, is 1e-4 of such a force: tools/micro/tri_xl_check.py)
@@ -161,7 +162,7 @@ def test_triclinic_single_list_with_exceptions_beyond_64_atom_blocks(pkg, monkey
     got = pkg.find_neighbors(s)
     assert got.n == len(ref[0])
     assert all(np.array_equal(u, v) for u, v in zip(S.sorted_pairs(got.i, got.j, got.special), S.sorted_pairs(*ref)))
-    assert s.stats()["block_atoms"] == 64
+    assert s.stats()["block_atoms"] == 128
     o = case.oracle(np.float64)
     nl = o.neighbors("brute", nthreads=16)
     f_ref = o.forces(nl, nthreads=8)

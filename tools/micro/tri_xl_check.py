@@ -16,6 +16,10 @@ if with_xl:
     case.special = np.stack([idx[idx % 3 == 1], idx[idx % 3 == 1] + 2], 1)
     case.lj = dict(cutoff=("distance", 1.0), weight_special=0.5)
 s = case.system(pkg, np.float32)
+got = pkg.find_neighbors(s)
+ref = case.oracle(np.float32).neighbors("brute", nthreads=16)
+same = got.n == len(ref[0]) and all(np.array_equal(u, v) for u, v in zip(S.sorted_pairs(got.i, got.j, got.special), S.sorted_pairs(*ref)))
+print("pair set + special flags equal to the fp32 brute-force oracle:", same, got.n, len(ref[0]))
 o = case.oracle(np.float64)
 nl = o.neighbors("brute", nthreads=16)
 f_ref = o.forces(nl, nthreads=8)

@@ -9,8 +9,9 @@ import molly_loader
 pkg = molly_loader.load()
 from tests import systems as S
 n_side = int(sys.argv[1])
-case = S.charged_fluid(n_side, dict(kind="rf", rc=1.0, weight_special=0.8333333333333334), dtype=np.float32, stable=True)
-s = case.system(pkg, np.float32)
+DT = np.float64 if os.environ.get("XLW_DTYPE") == "f64" else np.float32
+case = S.charged_fluid(n_side, dict(kind="rf", rc=1.0, weight_special=0.8333333333333334), dtype=DT, stable=True)
+s = case.system(pkg, DT)
 nl = pkg.find_neighbors(s)
 st = s.stats()
 L = pkg.lib()
@@ -19,7 +20,7 @@ s._check(L.mhip_export_order(s.engine(), s._ptr(perm), case.n))       # perm[sor
 cnt = np.bincount(nl.i, minlength=case.n) + np.bincount(nl.j, minlength=case.n)
 per_slot = cnt[perm]
 bi = st["block_atoms"]
-oi, oj, _ = case.oracle(np.float32).neighbors("cell", nthreads=16)
+oi, oj, _ = case.oracle(DT).neighbors("cell", nthreads=16)
 ref = (np.bincount(oi, minlength=case.n) + np.bincount(oj, minlength=case.n))[perm]
 print(f"shape {bi}x{st['j_split']}, pairs {nl.n} of {len(oi)}")
 for b in (0, 1, 7, 100):
