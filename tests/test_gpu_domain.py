@@ -174,12 +174,12 @@ def test_prune_summary_read_late_is_the_same_run(world, dtype_name, tmp_path, mo
     assert np.array_equal(late["x"], drained["x"]) and np.array_equal(late["v"], drained["v"])
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_fused_ghosted_step_with_the_blocks_own_waits(world, tmp_path, monkeypatch):
     """On separate devices nothing but the bounded waits INSIDE the fused ghosted launch orders a step against its peers: blocks whose tile holds ghosts wait for the
     senders' sequence words, the head workgroup for the centre-of-mass rows, sending blocks without ghosts for the peer's read of the half they overwrite (kernels.h
     HaloStep).  Ranks that share a device normally get a one-workgroup waiter in front, which makes every one of those waits return at once; MOLLYHIP_HALO_WAITER=0 takes it
-    away (safe here: two or four grids of 32 workgroups fit the device side by side), so that the waits really order the ranks.  Same bits as with the waiter."""
+    away (safe here: two, four or eight grids of at most 32 workgroups fit the device side by side; with eight ranks every rank waits for seven peers), so that the waits really order the ranks.  Same bits as with the waiter."""
     n_steps = 60
     monkeypatch.setenv("MOLLYHIP_HALO_WAITER", "0")
     bare = _run_variant(tmp_path, monkeypatch, "bare", world, n_steps, True, 0, dtype_name="f32")
