@@ -1172,6 +1172,10 @@ template <class T> __device__ inline T step_add(T x, T rate, T h) { return M<T>:
 // stores the new coordinates of the atoms the peers need — shifted — straight into the peers' receive halves (no pack launch); the last wave of the launch to
 // finish sums the blocks' Σ m v partials into the message's centre-of-mass rows and raises this rank's sequence word at every peer.  The wire format is the one
 // of k_halo_pack / k_halo_unpack (halo_xfer.h): a rank may take a fused step while a peer takes the separate launches.
+// A word of a receive half, written by a PEER's stores (another device over xGMI, or another process on this one) and announced by its sequence word: read at system
+// scope, so that what arrives does not depend on how the fine-grained region happens to be cached on this device (a plain load behind one wave's acquire is enough on a
+// single device, where every writer goes through the same L2 — the only set-up this repository could run; round 6 made the reads explicit rather than find out on a node)
+template <class U> __device__ inline U peer_row_load(const U* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 struct HaloSend { float* dst; float sx, sy, sz; int32_t pad; };      // one row an owned atom goes to: where in the peer's half (parity 0), with which periodic shift
 struct HaloStep {
     const int32_t* order;            // [blocks_per_xcd · 8] block of workgroup w (−1: none): per XCD run the blocks WITHOUT ghosts first — the others wait for the peers
@@ -1201,7 +1205,7 @@ struct HaloStep {
     if (tid < 4) tab[0][tid] = H.cm_all[tid];
     if (tid < H.n_peers * 8) {      // four doubles = eight words, three per row
         const int p = tid >> 3, w = tid & 7;
-        reinterpret_cast<float*>(tab[1 + p])[w] = H.rows[3 * (size_t)H.cm_row[p * H.cm_rows + w / 3] + w % 3];
+        reinterpret_cast<float*>(tab[1 + p])[w] = peer_row_load(&H.rows[3 * (size_t)H.cm_row[p * H.cm_rows + w / 3] + w % 3]);
     }
     __syncthreads();
     if (tid < 64) {
@@ -1529,7 +1533,7 @@ k_forces(ForceArgs<T> A) {
                         s[k] = (t0 + k * nthr + tid < n_here) ? s[k] : (int)((int64_t)b * A.BI);
                         if constexpr (HALO) {      // a ghost comes from the receive half (three words of a 12-byte row), an owned atom from pos[]
                             if (s[k] >= 0) p[k] = A.pos[s[k]];
-                            else { const float* gr = A.H.rows + 3 * (size_t)(-1 - s[k]); p[k] = make4<T>((T)gr[0], (T)gr[1], (T)gr[2], T(0)); }
+                            else { const float* gr = A.H.rows + 3 * (size_t)(-1 - s[k]); p[k] = make4<T>((T)peer_row_load(gr), (T)peer_row_load(gr + 1), (T)peer_row_load(gr + 2), T(0)); }
                         } else p[k] = A.pos[s[k]];
                     }
 #pragma unroll
@@ -2398,11 +2402,11 @@ __global__ void k_halo_unpack(int64_t n, const T* __restrict__ in, const int32_t
     const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (k >= n) return;
     const int d = dst[k];
-    if (d >= 0) { const int s = inv[first + d]; pos[s].x = in[3 * k]; pos[s].y = in[3 * k + 1]; pos[s].z = in[3 * k + 2]; return; }
+    if (d >= 0) { const int s = inv[first + d]; pos[s].x = peer_row_load(in + 3 * k); pos[s].y = peer_row_load(in + 3 * k + 1); pos[s].z = peer_row_load(in + 3 * k + 2); return; }
     constexpr int NW = 32 / (int)sizeof(T);
     const int code = -1 - d, peer = code / cm_rows, r = code - peer * cm_rows;
     T* w = reinterpret_cast<T*>(cm_all + 4 * (int64_t)(1 + peer));
-    for (int c = 0; c < 3; ++c) if (3 * r + c < NW) w[3 * r + c] = in[3 * k + c];
+    for (int c = 0; c < 3; ++c) if (3 * r + c < NW) w[3 * r + c] = peer_row_load(in + 3 * k + c);
 }
 
 }  // namespace mhip
