@@ -164,6 +164,7 @@ typedef struct mhip_stats {
     int64_t outer_tile_atoms_total;/* Σ over blocks of the outer list's tile sizes                                                    */
     int64_t build_pass_bytes;      /* ONE outer search: N·4w read + 2·n_outer_slots + 4·outer_tile_atoms_total written                */
     int64_t prune_pass_bytes;      /* ONE pruning force pass: N(R_p + 3w) + 2·n_outer_slots + 4·outer tile read, 2·n_list_slots + 4·tile_atoms_total + N·4w (snapshot) written */
+    int64_t n_box_changes;         /* boundaries taken over by mhip_set_box (a barostat's trial moves, accepted or taken back)      */
 } mhip_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
@@ -239,6 +240,16 @@ int32_t mhip_general_forces(mhip_ctx* ctx, int32_t accumulate, void* f_xyz, int3
  * cell — every distance by the exact in-loop minimum image — and is then limited to 32 759 atoms.
  * approx_images != 0: the three-floor formula; 0: the search over the 27 neighbouring images. */
 int32_t mhip_set_triclinic(mhip_ctx* ctx, const double* basis9, int32_t approx_images);
+/* A new boundary for a live context: `sys.boundary = …` as scale_coords! does it for the barostats (spatial.jl:1184-1218 → coupling.jl:861-930; scale_boundary,
+ * spatial.jl:414-422).  The reference's entry points read sys.boundary at every call (ext/MollyCUDAExt.jl:845, 936; force.jl:1196-1257), so a Monte-Carlo or
+ * Berendsen barostat that stays in Julia works through this engine only if the engine follows the box: box3 = the new side lengths (a TriclinicBoundary:
+ * v1.x, v2.y, v3.z), basis9 = the new basis vectors row by row for a context that has a TriclinicBoundary, NULL otherwise (MHIP_ERR_INVALID when the two
+ * disagree; the image mode given to mhip_set_triclinic stays).  Kept: atoms and parameters, exception and bonded lists, the PME order / mesh / α (PME(...)
+ * stores them, ewald.jl:285-309 — only recip_box follows the boundary), the launch shape, the velocities.  Made again: cell grid, capacities, reciprocal
+ * box; every pair list is dropped.  The coordinates must be handed over again — they were scaled with the box — before the next force / energy / run call:
+ * mhip_set_state (MHIP_ERR_STATE otherwise).  Single domain (MHIP_ERR_UNSUPPORTED for a context with ghosts or a domain plan: plan the bricks again).
+ * A box the engine refuses leaves the context on its old box. */
+int32_t mhip_set_box(mhip_ctx* ctx, const double* box3, const double* basis9);
 /* E_recip + E_self + E_net-charge                                           (ewald.jl:898-928) */
 int32_t mhip_general_potential_energy(mhip_ctx* ctx, double* pe_out);
 /* reciprocal-space virial (recip_conv_inner!, ewald.jl:701-723, 747-750) + the net-charge term (:925-927), ADDED to 9 host doubles */

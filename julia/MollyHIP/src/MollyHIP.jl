@@ -28,7 +28,7 @@ xyzptr(a) = Ptr{Cvoid}(UInt(pointer(a)))                 # ROCArray: device poin
 
 function context!(sys::System{3}, inter::HIPNonbonded)
     c = lock(() -> get(CONTEXTS, sys, nothing), CONTEXTS_LOCK)
-    c === nothing || return c
+    c === nothing || return follow_boundary!(c, sys.boundary)      # (a barostat replaced sys.boundary: mhip_set_box)
     T = Molly.float_type(sys)
     b = sys.boundary
     cfg = MhipConfig(T == Float32 ? Int32(32) : Int32(64), Int32(0), length(sys), Tuple(Float64.(ustrip.(b.side_lengths))), (0.0, 0.0, 0.0),
@@ -36,7 +36,7 @@ function context!(sys::System{3}, inter::HIPNonbonded)
     out = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:mhip_create, libmollyhip), Int32, (Ref{Ptr{Cvoid}}, Ref{MhipConfig}), out, cfg)
     rc == 0 || error("libmollyhip: ", last_error(C_NULL))
-    c = HipContext(out[])
+    c = HipContext(out[], b)
     at = Array(sys.atoms)
     q = T[a.charge for a in at]; σ = T[ustrip(a.σ) for a in at]; ϵ = T[ustrip(a.ϵ) for a in at]; λ = T[a.λ for a in at]
     m = T.(ustrip.(Array(masses(sys))))

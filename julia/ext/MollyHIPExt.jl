@@ -68,7 +68,7 @@ function context!(sys::System{3, <:ROCArray, T}) where T
         out = Ref{Ptr{Cvoid}}(C_NULL)
         rc = ccall((:mhip_create, libmollyhip), Int32, (Ref{Ptr{Cvoid}}, Ref{MhipConfig}), out, cfg)
         rc == 0 || error("libmollyhip: ", last_error(C_NULL))
-        c = HipContext(out[])
+        c = HipContext(out[], b)
         check(c, ccall((:mhip_set_stream, libmollyhip), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), c.ptr, AMDGPU.stream().stream))   # kernels join the task's HIP stream
         if tric
             bv = Float64[ustrip(b.basis_vectors[r][k]) for r in 1:3 for k in 1:3]
@@ -83,6 +83,7 @@ function context!(sys::System{3, <:ROCArray, T}) where T
             CONTEXTS[sys] = c
         end
     end
+    follow_boundary!(c, sys.boundary)                                                # a barostat replaced sys.boundary (coupling.jl:861-1033): mhip_set_box
     push_exceptions!(c, nf)                                                          # also after append_excluded_pairs! (neighbors.jl:313)
     return c
 end

@@ -20,8 +20,9 @@ mutable struct HipContext
     ptr::Ptr{Cvoid}
     exceptions_generation::UInt64          # nf.cache_generation the engine's exception lists were built from
     bonded_sent::Bool
-    function HipContext(ptr)
-        c = new(ptr, typemax(UInt64), false)
+    boundary::Any                          # the sys.boundary the engine's box was made from (follow_boundary!)
+    function HipContext(ptr, boundary=nothing)
+        c = new(ptr, typemax(UInt64), false, boundary)
         finalizer(c) do x                   # GC-driven release; release!(sys) is the eager form
             x.ptr == C_NULL || ccall((:mhip_destroy, libmollyhip), Int32, (Ptr{Cvoid},), x.ptr)
             x.ptr = C_NULL
@@ -34,6 +35,26 @@ const CONTEXTS_LOCK = ReentrantLock()
 
 last_error(ptr) = unsafe_string(ccall((:mhip_last_error, libmollyhip), Cstring, (Ptr{Cvoid},), ptr))
 check(c::HipContext, rc) = rc == 0 ? nothing : error("libmollyhip: ", last_error(c.ptr))     # ≙ error(...) of ext:733-739
+
+# `sys.boundary = …` on a live system (scale_coords!, spatial.jl:1202; a barostat's rejected move, coupling.jl:930): the reference's entry points read
+# sys.boundary at every call (ext/MollyCUDAExt.jl:845, 936), so every look-up of a context compares it with the boundary the engine holds and hands a new one
+# over (mhip_set_box: grid, capacities and reciprocal box made again, lists dropped; the caller's mhip_set_state that follows brings the scaled coordinates).
+function follow_boundary!(c::HipContext, b)
+    c.boundary === b && return c
+    if c.boundary !== nothing
+        typeof(b).name === typeof(c.boundary).name || error("libmollyhip: a live System keeps its kind of boundary")
+        if hasproperty(b, :basis_vectors)                                              # TriclinicBoundary (spatial.jl:151-161)
+            bv = Float64[ustrip(b.basis_vectors[r][k]) for r in 1:3 for k in 1:3]
+            box = Float64[bv[1], bv[5], bv[9]]
+            check(c, ccall((:mhip_set_box, libmollyhip), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), c.ptr, box, bv))
+        else                                                                           # CubicBoundary (spatial.jl:40)
+            box = Float64[ustrip(x) for x in b.side_lengths]
+            check(c, ccall((:mhip_set_box, libmollyhip), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), c.ptr, box, Ptr{Float64}(C_NULL)))
+        end
+    end
+    c.boundary = b
+    return c
+end
 
 function release!(sys)
     lock(CONTEXTS_LOCK) do

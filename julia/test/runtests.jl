@@ -8,6 +8,7 @@
 #   test/gpu_consistency.jl:3-50     33 atoms on a diagonal, box 20, r_c 5: forces / energy, rtol 1e-8, atol 1e-10
 #   test/gpu_consistency.jl:52-114   100-atom lattice, spacing 1.5, σ = 1, r_c 4, through find_neighbors
 #   test/gpu_consistency.jl:339-405  10 atoms, excluded (1,2), (2,3), special (1,3)
+#   coupling.jl:861-932, README.md:126-133  the boundary replaced on a live system: scale_coords!, a move taken back, Langevin + MonteCarloBarostat
 #   test/gpu_consistency.jl:407-449  20 atoms without a neighbour list
 #   test/protein.jl:263-276          6mrr per-term forces / energies against the OpenMM files of the reference's data/ directory
 using Test, LinearAlgebra, DelimitedFiles
@@ -63,6 +64,27 @@ end
             coords = [SVector{3, T64}(i * a, j * a, k * a) for i in 1:side for j in 1:side for k in 1:side][1:100]
             gpu, cpu = lj_pair(coords, lj_atoms(100, 1.0), CubicBoundary(T64((side + 2) * a)), 4.0)
             same_forces_and_energy(gpu, cpu; with_list=true)
+        end
+        @testset "sys.boundary replaced on a live system" begin                          # scale_coords! (spatial.jl:1184-1210) as the barostats call it (coupling.jl:861-932)
+            side = ceil(Int, 100^(1 / 3)); a = T64(1.5)
+            coords = [SVector{3, T64}(i * a, j * a, k * a) for i in 1:side for j in 1:side for k in 1:side][1:100]
+            gpu, cpu = lj_pair(coords, lj_atoms(100, 1.0), CubicBoundary(T64((side + 2) * a)), 4.0)
+            same_forces_and_energy(gpu, cpu; with_list=true)                             # the engine's context and lists exist, on the old box
+            old_boundary, old_coords = gpu.boundary, copy(gpu.coords)
+            μ = SMatrix{3, 3, T64}(1.02, 0, 0, 0, 1.02, 0, 0, 0, 1.02)
+            scale_coords!(gpu, μ); scale_coords!(cpu, μ)
+            @test gpu.boundary != old_boundary
+            same_forces_and_energy(gpu, cpu; with_list=true)                             # mhip_set_box behind context!(sys): the new box
+            gpu.coords .= old_coords; gpu.boundary = old_boundary                        # a rejected Monte-Carlo move (coupling.jl:929-930)
+            cpu.coords .= Array(old_coords); cpu.boundary = old_boundary
+            same_forces_and_energy(gpu, cpu; with_list=true)
+            # the README's GPU example in small (README.md:126-133): the stock Langevin loop with a MonteCarloBarostat, every force and trial energy from the engine
+            temp = T64(1.0)
+            sim = Langevin(dt=T64(0.002), temperature=temp, friction=T64(1.0), coupling=MonteCarloBarostat(T64(1.0), temp, gpu.boundary; n_steps=5))
+            random_velocities!(gpu, temp)
+            simulate!(gpu, sim, 20)
+            @test all(isfinite, reduce(vcat, Array(gpu.coords)))
+            @test sim.coupling.n_attempted == 4
         end
         @testset "exclusions and a special pair" begin
             gpu, cpu = lj_pair(diagonal(10), lj_atoms(10, 0.3), CubicBoundary(T64(10)), 5.0; excluded=[(1, 2), (2, 3)], special=[(1, 3)])

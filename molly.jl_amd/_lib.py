@@ -48,7 +48,7 @@ class Stats(C.Structure):
                 ("n_outer_builds", C.c_int64), ("n_filter_passes", C.c_int64), ("tile_segments", C.c_int64),
                 ("n_group_split_passes", C.c_int64), ("group_split", C.c_int32), ("n_adopted_outer_lists", C.c_int32),
                 ("n_fused_steps", C.c_int64), ("n_outer_slots", C.c_int64), ("outer_tile_atoms_total", C.c_int64),
-                ("build_pass_bytes", C.c_int64), ("prune_pass_bytes", C.c_int64)]
+                ("build_pass_bytes", C.c_int64), ("prune_pass_bytes", C.c_int64), ("n_box_changes", C.c_int64)]
 
     def as_dict(self):
         d = {name: getattr(self, name) for name, _ in self._fields_}
@@ -130,6 +130,7 @@ SIGNATURES = {
     "mhip_general_virial": (_I32, [_P, _P]),
     "mhip_set_pme": (_I32, [_P, _I32, _P, _D, _D]),
     "mhip_set_triclinic": (_I32, [_P, _P, _I32]),
+    "mhip_set_box": (_I32, [_P, _P, _P]),
     "mhip_general_forces": (_I32, [_P, _I32, _P, _I32]),
     "mhip_general_potential_energy": (_I32, [_P, C.POINTER(_D)]),
     "mhip_set_ghost_margin": (_I32, [_P, _D]),

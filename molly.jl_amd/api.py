@@ -312,18 +312,44 @@ class System:
         if velocities is not None and len(velocities) != n:
             raise ValueError(f"there are {n} coordinates but {len(velocities)} velocities")
         self.velocities = np.zeros((n, 3), T) if velocities is None else np.ascontiguousarray(velocities, dtype=T).reshape(n, 3).copy()
-        self.boundary = boundary if isinstance(boundary, (CubicBoundary, TriclinicBoundary)) else CubicBoundary(boundary)
+        self._ctx = None
+        self._box_dirty = False
+        self.boundary = boundary
         self.pairwise_inters = tuple(pairwise_inters)
         self.specific_inter_lists = tuple(specific_inter_lists)
         self.general_inters = tuple(general_inters)
         self.neighbor_finder = neighbor_finder if neighbor_finder is not None else NoNeighborFinder()
         self.device_id = device_id
         self.total_mass = float(self.masses.sum(dtype=np.float64))
-        self._ctx = None
         self._pushed_atoms = False
 
     def __len__(self):
         return len(self.coords)
+
+    # `sys.boundary = …` on a live system (scale_coords!, spatial.jl:1202; the barostats' rejected moves, coupling.jl:930): the reference reads
+    # sys.boundary at every force / energy call, so the engine's context follows the assignment (mhip_set_box) the next time state is pushed
+    @property
+    def boundary(self):
+        return self._boundary
+
+    @boundary.setter
+    def boundary(self, b):
+        b = b if isinstance(b, (CubicBoundary, TriclinicBoundary)) else CubicBoundary(b)
+        old = getattr(self, "_boundary", None)
+        if self._ctx is not None and old is not None:
+            if type(b) is not type(old) or (isinstance(b, TriclinicBoundary) and b.approx_images != old.approx_images):
+                raise MollyHipError(-6, "a live System keeps its kind of boundary (CubicBoundary / TriclinicBoundary and its image mode)")
+            self._box_dirty = True
+        self._boundary = b
+
+    def _push_box(self):
+        if not self._box_dirty or self._ctx is None:
+            return
+        b = self._boundary
+        box = np.ascontiguousarray(b.side_lengths, dtype=np.float64)
+        bv = np.ascontiguousarray(b.basis_vectors, dtype=np.float64) if isinstance(b, TriclinicBoundary) else None
+        self._check(_lib.lib().mhip_set_box(self._ctx, self._ptr(box), self._ptr(bv)))
+        self._box_dirty = False
 
     # -- interaction tuple → mhip_interactions ------------------------------------------------------------
     def interactions(self):
@@ -437,6 +463,7 @@ class System:
     def push_state(self, velocities=True):
         L = _lib.lib()
         self.engine()
+        self._push_box()
         self._check(L.mhip_set_state(self._ctx, self._ptr(self.coords), self._ptr(self.velocities) if velocities else None, _lib.MEM_HOST))
 
     def pull_state(self):
@@ -586,27 +613,44 @@ def remove_CM_motion(sys):
 
 def simulate(sys, sim, n_steps, init_step=0, check_nans=False, rng=None):
     """simulate!(sys, sim, n_steps; init_step, rng) for VelocityVerlet (simulators.jl:547-668) and Langevin (:1099-1220), with
-    coupling nothing or AndersenThermostat.  The whole loop runs on the device; coordinates and velocities come back when the
-    call returns.  rng: a numpy Generator or a seed; as in the reference it only supplies the Philox key / counter words."""
+    coupling nothing, AndersenThermostat, MonteCarloBarostat or a tuple of the two.  The step loop runs on the device; with a barostat it is cut at the
+    multiples of barostat.n_steps, where apply_coupling! runs on the host side of the boundary with the engine's potential energies (the README's GPU
+    example: Langevin + MonteCarloBarostat).  Coordinates and velocities come back when the call returns.  rng: a numpy Generator or a seed; as in the
+    reference it supplies the Philox key / counter words and the barostat's uniform numbers."""
     if not isinstance(sim, (VelocityVerlet, Langevin)):
         raise MollyHipError(-6, f"simulator {type(sim).__name__} is outside the hot-path scope")
-    if sim.coupling is not None and not isinstance(sim.coupling, AndersenThermostat):
-        raise MollyHipError(-6, f"coupling {type(sim.coupling).__name__} is outside the hot-path scope")
+    couplings = sim.coupling if isinstance(sim.coupling, (tuple, list)) else (() if sim.coupling is None else (sim.coupling,))
+    thermostat = barostat = None
+    for c in couplings:
+        if isinstance(c, AndersenThermostat) and thermostat is None:
+            thermostat = c
+        elif isinstance(c, MonteCarloBarostat) and barostat is None:
+            barostat = c
+        else:
+            raise MollyHipError(-6, f"coupling {type(c).__name__} is outside the hot-path scope")
     if init_step < 0:   # check_simulate_inputs
         raise ValueError("init_step must be non-negative")
     L = _lib.lib()
     rng = _rng(rng)
     sys.push_state(velocities=True)
-    thermostat = sim.coupling
     if thermostat is not None:
         sys._check(L.mhip_set_andersen(sys._ctx, BOLTZMANN * float(thermostat.temperature), float(sim.dt) / float(thermostat.coupling_const), _rand_u64(rng)))
     try:
         if isinstance(sim, Langevin):
             key, ctr1 = _rand_u64(rng), _rand_u64(rng)             # simulators.jl:1149-1150
-            sys._check(L.mhip_langevin_run(sys._ctx, init_step, n_steps, sim.dt, BOLTZMANN * sim.temperature, sim.friction,
-                                           int(sim.remove_CM_motion), key, ctr1))
-        else:
-            sys._check(L.mhip_vv_run(sys._ctx, init_step, n_steps, float(sim.dt), int(sim.remove_CM_motion)))
+        first, last = init_step, init_step + n_steps
+        while first < last:
+            nxt = last if barostat is None else min(last, (first // barostat.n_steps + 1) * barostat.n_steps)
+            if isinstance(sim, Langevin):                         # ctr1 advances by one per step (simulators.jl:1190)
+                sys._check(L.mhip_langevin_run(sys._ctx, first, nxt - first, sim.dt, BOLTZMANN * sim.temperature, sim.friction,
+                                               int(sim.remove_CM_motion), key, (ctr1 + (first - init_step)) % 2 ** 64))
+            else:
+                sys._check(L.mhip_vv_run(sys._ctx, first, nxt - first, float(sim.dt), int(sim.remove_CM_motion)))
+            if barostat is not None and nxt % barostat.n_steps == 0:      # apply_coupling! at the end of step nxt (simulators.jl:1192)
+                sys.pull_state()
+                _apply_mc_barostat(sys, barostat, nxt, rng)
+                sys.push_state(velocities=True)                   # the accepted box and coordinates, or the old ones back after a rejected trial
+            first = nxt
     finally:
         if thermostat is not None:
             sys._check(L.mhip_set_andersen(sys._ctx, 0.0, 0.0, 0))
@@ -627,8 +671,12 @@ def random_velocities(sys, temp, rng=None):
     return sys
 
 
-def apply_coupling(sys, thermostat, sim, rng=None):
-    """apply_coupling!(sys, buffers, ::AndersenThermostat, sim) (coupling.jl:196-211): one application; returns False (no force recompute)"""
+def apply_coupling(sys, coupling, sim, rng=None, step_n=0):
+    """apply_coupling!(sys, buffers, coupling, sim, neighbors, step_n; rng): one application.  AndersenThermostat (coupling.jl:196-211) returns False;
+    MonteCarloBarostat (coupling.jl:861-1033) returns whether a move was accepted (the forces must be recomputed)."""
+    if isinstance(coupling, MonteCarloBarostat):
+        return _apply_mc_barostat(sys, coupling, step_n, _rng(rng))
+    thermostat = coupling
     if not isinstance(thermostat, AndersenThermostat):
         raise MollyHipError(-6, f"coupling {type(thermostat).__name__} is outside the hot-path scope")
     L = _lib.lib()
@@ -638,6 +686,139 @@ def apply_coupling(sys, thermostat, sim, rng=None):
     sys._check(L.mhip_andersen(sys._ctx, BOLTZMANN * float(thermostat.temperature), float(sim.dt) / float(thermostat.coupling_const), key, ctr1))
     sys.pull_state()
     return False
+
+
+# ---- the boundary as a variable: what the barostats of coupling.jl need from the engine ---------------------------------------------------------------
+BAR = 0.0602214076      # 1 bar in kJ mol⁻¹ nm⁻³ (1e5 Pa · 1e-27 m³/nm³ · N_A / 1e3)
+
+
+def volume(boundary):
+    """volume(boundary) (spatial.jl:365-372): the product of the side lengths; TriclinicBoundary: v1.x · v2.y · v3.z"""
+    return float(np.prod(np.asarray(boundary.side_lengths, dtype=np.float64)))
+
+
+def scale_boundary(boundary, scale):
+    """scale_boundary(boundary, scale) (spatial.jl:414-422): a number or one factor per axis"""
+    sc = np.broadcast_to(np.asarray(scale, dtype=np.float64), (3,))
+    if isinstance(boundary, TriclinicBoundary):
+        bv = boundary.basis_vectors
+        return TriclinicBoundary(bv[0] * sc, bv[1] * sc, bv[2] * sc, approx_images=boundary.approx_images)
+    return CubicBoundary(*(boundary.side_lengths * sc))
+
+
+def scale_coords(sys, scale_matrix, scale_velocities=False):
+    """scale_coords!(sys, μ; ignore_molecules=true) (spatial.jl:1184-1210, the branch of systems without a topology — every atom a molecule): box B′ = μ B,
+    r′ = μ r in the system's number type, optionally v′ = μ⁻¹ v.  The rigid-molecule branch (:1211-1290) is host code on molecule lists and stays outside the
+    engine; what the engine must do is follow the boundary (mhip_set_box)."""
+    T = sys.dtype.type
+    mu = np.asarray(scale_matrix, dtype=sys.dtype).reshape(3, 3)
+    b = sys.boundary
+    if isinstance(b, TriclinicBoundary):
+        nb = mu.astype(np.float64) @ b.basis_vectors.T            # columns = basis vectors (boxmatrix, spatial.jl:254)
+        sys.boundary = TriclinicBoundary(nb[:, 0], nb[:, 1], nb[:, 2], approx_images=b.approx_images)
+    else:
+        if np.any(mu != np.diag(np.diag(mu))):
+            raise ValueError("a CubicBoundary is scaled by a diagonal matrix")
+        sl = (np.diag(mu) * b.side_lengths.astype(sys.dtype)).astype(sys.dtype)   # μ · B in T, as the SMatrix product
+        sys.boundary = CubicBoundary(*[float(x) for x in sl])
+    sys.coords[:] = (sys.coords @ mu.T).astype(sys.dtype) if np.any(mu != np.diag(np.diag(mu))) else sys.coords * np.diag(mu)[None, :]
+    if scale_velocities:
+        mi = np.linalg.inv(mu.astype(np.float64)).astype(sys.dtype)
+        sys.velocities[:] = (sys.velocities @ mi.T).astype(sys.dtype)
+    del T
+    return sys
+
+
+class MonteCarloBarostat:
+    """MonteCarloBarostat(pressure, temperature, boundary; coupling_type=:isotropic, n_steps=30, n_iterations=1, scale_factor=0.01, scale_increment=1.1,
+    max_volume_frac=0.3, trial_find_neighbors=false) (coupling.jl:721-859).  pressure in bar: a number (isotropic) or the three diagonal entries Pxx, Pyy, Pzz
+    (semiisotropic, anisotropic).  The trial energies are full potential energies of the engine on the scaled box (the GPU path of the reference evaluates
+    the cutoff sphere from the coordinates at every call, so `trial_find_neighbors` has nothing to choose there; it is kept for the signature)."""
+
+    def __init__(self, pressure, temperature, boundary, coupling_type="isotropic", n_steps=30, n_iterations=1, scale_factor=0.01,
+                 scale_increment=1.1, max_volume_frac=0.3, trial_find_neighbors=False):
+        if coupling_type not in ("isotropic", "semiisotropic", "anisotropic"):      # coupling.jl:788-790
+            raise ValueError("coupling_type must be :isotropic, :semiisotropic, or :anisotropic")
+        p = np.asarray(pressure, dtype=np.float64)
+        if coupling_type == "isotropic":
+            if p.ndim != 0:
+                raise ValueError("isotropic pressure must be a scalar")
+            p = np.full(3, float(p))
+        elif p.shape != (3,):
+            raise ValueError(f"{coupling_type} pressure must have the three diagonal entries Pxx, Pyy, Pzz")
+        self.pressure = p.copy()                                  # bar
+        self.temperature = float(temperature)
+        self.coupling_type = coupling_type
+        self.n_steps, self.n_iterations = int(n_steps), int(n_iterations)
+        self.volume_scale = volume(boundary) * float(scale_factor)
+        self.scale_increment, self.max_volume_frac = float(scale_increment), float(max_volume_frac)
+        self.trial_find_neighbors = bool(trial_find_neighbors)
+        self.n_attempted = 0
+        self.n_accepted = 0
+
+
+def _mc_attempt(sys, barostat, E, rand, n_molecules):
+    """one trial of apply_coupling_mc! (coupling.jl:886-1033) up to the trial state: scales sys, returns (dW-without-ΔE as a function of E_trial, undo)"""
+    T = sys.dtype.type
+    V = T(volume(sys.boundary))
+    dV = T(barostat.volume_scale) * (T(2) * rand() - T(1))
+    v_scale = (V + dV) / V
+    kT = BOLTZMANN * barostat.temperature
+    P = barostat.pressure * BAR
+    if barostat.coupling_type == "isotropic":
+        l = np.cbrt(v_scale)
+        diag = (l, l, l)
+        work = float(P.sum()) * float(dV) / 3.0                                   # tr(P) · dV / 3
+    elif barostat.coupling_type == "semiisotropic":
+        w1, w2 = rand(), rand()
+        s_ = w1 + w2; w1, w2 = w1 / s_, w2 / s_
+        lxy, lz = v_scale ** w1, v_scale ** w2
+        diag = (lxy, lxy, lz)
+        work = float((w1 / T(2)) * P[0] + (w1 / T(2)) * P[1] + w2 * P[2]) * float(V + dV) * math.log(float(v_scale))
+    else:
+        w1, w2, w3 = rand(), rand(), rand()
+        s_ = w1 + w2 + w3; w1, w2, w3 = w1 / s_, w2 / s_, w3 / s_
+        diag = (v_scale ** w1, v_scale ** w2, v_scale ** w3)
+        work = float(w1 * P[0] + w2 * P[1] + w3 * P[2]) * float(V + dV) * math.log(float(v_scale))
+    old_coords, old_boundary = sys.coords.copy(), sys.boundary
+    scale_coords(sys, np.diag(np.asarray(diag, dtype=sys.dtype)))
+    dW_of = lambda E_trial: (E_trial - E) + work - n_molecules * kT * math.log(float(v_scale))
+
+    def undo():
+        sys.coords[:] = old_coords
+        sys.boundary = old_boundary
+    return dW_of, undo, kT
+
+
+def _apply_mc_barostat(sys, barostat, step_n, rng, energy=None):
+    """apply_coupling!(sys, buffers, ::MonteCarloBarostat, sim, neighbors, step_n; rng) (coupling.jl:861-884).  `energy`: the potential-energy function (tests
+    put the oracle's here to replay the same random numbers on the CPU)."""
+    if step_n % barostat.n_steps != 0:
+        return False
+    energy = energy or (lambda s: potential_energy(s, step_n))
+    T = sys.dtype.type
+    rand = lambda: T(rng.random(dtype=sys.dtype))                 # rand(rng, T)
+    n_molecules = len(sys)                                        # sys.topology === nothing
+    recompute = False
+    for _ in range(barostat.n_iterations):
+        E = energy(sys)
+        dW_of, undo, kT = _mc_attempt(sys, barostat, E, rand, n_molecules)
+        dW = dW_of(energy(sys))
+        if dW <= 0 or float(rand()) < math.exp(-dW / kT):
+            recompute = True
+            barostat.n_accepted += 1
+        else:
+            undo()
+        barostat.n_attempted += 1
+    if barostat.n_attempted >= 10:                                # coupling.jl:871-881
+        V_now = volume(sys.boundary)
+        if barostat.n_accepted < 0.25 * barostat.n_attempted:
+            barostat.volume_scale /= barostat.scale_increment
+        elif barostat.n_accepted > 0.75 * barostat.n_attempted:
+            barostat.volume_scale = min(barostat.volume_scale * barostat.scale_increment, V_now * barostat.max_volume_frac)
+        barostat.n_attempted = 0
+        barostat.n_accepted = 0
+    return recompute
 
 
 def wrap_coords(coords, boundary):

@@ -78,6 +78,7 @@ struct EngineBase {
     virtual void general_virial(double*) = 0;
     virtual void set_pme(int32_t, const int32_t*, double, double) = 0;
     virtual void set_triclinic(const double*, int32_t) = 0;
+    virtual void set_box(const double*, const double*) = 0;
     virtual void general_forces(int, void*, int) = 0;
     virtual double general_potential_energy() = 0;
     virtual void set_ghost_margin(double) = 0;
@@ -1683,6 +1684,40 @@ template <class T> class Engine final : public EngineBase {
         setup_grid(); choose_blocking();
         stale = true; frc_valid = false; state_set = false;
     }
+    // The boundary of a LIVE context replaced (≙ `sys.boundary = scale_boundary(…)`: scale_coords!, spatial.jl:1184-1218, as the barostats of coupling.jl call it —
+    // the reference's force and energy entry points read sys.boundary on every call, ext/MollyCUDAExt.jl:845, 936).  box3: the new side lengths (a TriclinicBoundary:
+    // v1.x, v2.y, v3.z); bv9: its basis, required exactly when the context is triclinic (the image mode stays).  Atoms, parameters, exception and bonded lists, the
+    // PME mesh and α, the launch shape and the velocities are kept; the cell grid, the capacities and the reciprocal box are made again, every list is
+    // dropped, and the coordinates must be handed over again (they were scaled with the box): mhip_set_state.
+    void set_box(const double* box3, const double* bv9) override {
+        if (n_ghost > 0 || dom.ready || xf.world > 1) throw ApiError{MHIP_ERR_UNSUPPORTED, "set_box: single domain (the bricks of a decomposition are cut from the box: plan again)"};
+        for (int d = 0; d < 3; ++d) if (!(box3[d] > 0) || std::isinf(box3[d]) || std::isnan(box3[d])) throw ApiError{MHIP_ERR_INVALID, "box side lengths must be positive and finite"};
+        if ((tri_mode != 0) != (bv9 != nullptr)) throw ApiError{MHIP_ERR_INVALID, tri_mode ? "set_box: the context has a TriclinicBoundary, its basis vectors are needed" : "set_box: basis vectors given for a context without a TriclinicBoundary"};
+        if (bv9) {
+            if (!(bv9[0] > 0) || bv9[1] != 0 || bv9[2] != 0 || !(bv9[4] > 0) || bv9[5] != 0 || !(bv9[8] > 0)) throw ApiError{MHIP_ERR_INVALID, "set_box: v1 along x, v2 in the xy plane, v3.z > 0 (spatial.jl:173-186)"};
+            if (std::fabs(bv9[0] - box3[0]) > 1e-12 * bv9[0] || std::fabs(bv9[4] - box3[1]) > 1e-12 * bv9[4] || std::fabs(bv9[8] - box3[2]) > 1e-12 * bv9[8])
+                throw ApiError{MHIP_ERR_INVALID, "set_box: the box must be (v1.x, v2.y, v3.z) of the triclinic basis"};
+        }
+        flush_cm();
+        MHIP_HIP(hipStreamSynchronize(stream));
+        const mhip_config old_cfg = cfg; double old_bv[9]; std::memcpy(old_bv, tri_bv, sizeof(old_bv));
+        for (int d = 0; d < 3; ++d) cfg.box[d] = box3[d];
+        if (bv9) std::memcpy(tri_bv, bv9, sizeof(tri_bv));
+        try {
+            if (pme.on()) pme.setup(pme_order_, pme_mesh_, pme_alpha_, cfg.inter.coul_ke, pme_eps_r_, cfg.box, cfg.periodic, tri_mode ? tri_bv : nullptr);
+            setup_grid(); choose_blocking();
+            size_t tb2 = 0; MHIP_HIP(exclusive_sum_i32(nullptr, tb2, cell_cnt.p, cell_start.p, 2 * G.ncell + 1, stream));
+            if (tb2 + 256 > cub_tmp.n) cub_tmp.reserve(tb2 + 256);
+        } catch (...) {      // (a box the engine cannot take — r_list beyond half a side with exact images off, a mesh the PME refuses: the context stays what it was)
+            cfg = old_cfg; std::memcpy(tri_bv, old_bv, sizeof(tri_bv));
+            if (pme.on() || pme_order_) pme.setup(pme_order_, pme_mesh_, pme_alpha_, cfg.inter.coul_ke, pme_eps_r_, cfg.box, cfg.periodic, tri_mode ? tri_bv : nullptr);
+            setup_grid(); choose_blocking(); stale = true; frc_valid = false; state_set = false;
+            throw;
+        }
+        stale = true; frc_valid = false; frc_run_total = false; frc_before_set_state = false; state_set = false;      // (Σq, Σq² of the PME's constant terms do not depend on the box: pc_valid stays)
+        ++n_box_changes;
+    }
+    int64_t n_box_changes = 0;
     int32_t pme_order_ = 0, pme_mesh_[3] = {0, 0, 0}; double pme_alpha_ = 0, pme_eps_r_ = 1;      // (as last set: a TriclinicBoundary set afterwards rebuilds the reciprocal box)
     void set_pme(int32_t order, const int32_t* mesh, double alpha, double eps_r) override {
         frc_run_total = false;
@@ -2714,7 +2749,7 @@ template <class T> class Engine final : public EngineBase {
         s->last_rebuild_ms = last_rebuild_ms; s->lds_bytes = (int64_t)lds_force;
         s->tile_segments = segmented ? cdiv(std::max(last_pass_tile, 1), std::max(tile_lds, 1)) : 1;
         s->n_group_split_passes = n_gs_passes; s->group_split = gs_groups(); s->n_adopted_outer_lists = (int32_t)std::min<int64_t>(n_adopted, INT32_MAX);
-        s->n_fused_steps = n_fused_steps;
+        s->n_fused_steps = n_fused_steps; s->n_box_changes = n_box_changes;
         s->n_list_slots = total_rows * 4 * WAVE;
         if (!stale) {
             std::vector<int32_t> tc(n_blocks);
@@ -2876,6 +2911,9 @@ int32_t mhip_philox4x32_10(const uint32_t* ctr4, const uint32_t* key2, uint32_t*
 }
 int32_t mhip_specific_virial(mhip_ctx* ctx, double* out9) { NEED_CTX(); return guard(ctx, [&] { if (!out9) throw mhip::ApiError{MHIP_ERR_INVALID, "null output"}; ctx->e->specific_virial(out9); }); }
 int32_t mhip_general_virial(mhip_ctx* ctx, double* out9) { NEED_CTX(); return guard(ctx, [&] { if (!out9) throw mhip::ApiError{MHIP_ERR_INVALID, "null output"}; ctx->e->general_virial(out9); }); }
+int32_t mhip_set_box(mhip_ctx* ctx, const double* box3, const double* basis9) {
+    NEED_CTX(); return guard(ctx, [&] { if (!box3) throw mhip::ApiError{MHIP_ERR_INVALID, "null box"}; ctx->e->set_box(box3, basis9); });
+}
 int32_t mhip_set_triclinic(mhip_ctx* ctx, const double* basis9, int32_t approx_images) {
     NEED_CTX(); return guard(ctx, [&] { if (!basis9) throw mhip::ApiError{MHIP_ERR_INVALID, "null basis"}; ctx->e->set_triclinic(basis9, approx_images); });
 }

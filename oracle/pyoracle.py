@@ -185,6 +185,18 @@ class OracleSystem:
                 s.pme_mesh[d] = int(pme["mesh"][d])
         self.s = s
 
+    def set_boundary(self, box, basis=None):
+        """`sys.boundary = …` (scale_coords!, spatial.jl:1202; coupling.jl:930): the reference reads the boundary at every call, so does orc_*: new side
+        lengths (a TriclinicBoundary: the diagonal of its basis) and, for a triclinic system, the new basis; the PME mesh and α stay (ewald.jl:285-309)"""
+        self.box = np.asarray(box, dtype=np.float64).reshape(3).copy()
+        for d in range(3):
+            self.s.box[d] = self.box[d]
+        if basis is not None:
+            bv = np.asarray(basis, dtype=np.float64).reshape(3, 3)
+            assert self.s.triclinic and np.allclose(self.box, np.diag(bv))
+            for k in range(9):
+                self.s.tri_bv[k] = float(bv.reshape(-1)[k])
+
     @property
     def L(self):
         return lib(self.native)

@@ -42,7 +42,7 @@ def test_struct_layouts_match_header(pkg):
     # sizes computed from the C declarations (LP64): see include/mollyhip.h
     assert C.sizeof(pkg.Interactions) == 4 * 2 + 8 * 3 + 4 * 2 + 8 * 6 + 4 * 2
     assert C.sizeof(pkg.Config) == 4 * 2 + 8 + 24 + 24 + 12 + 4 + 8 + C.sizeof(pkg.Interactions)
-    assert C.sizeof(pkg.Stats) == 8 * 9 + 4 * 4 + 8 * 3 + 8 + 8 * 8 + 8 * 8 + 24 + 8 + 4 * 2 + 8 + 8 * 4      # (… + n_group_split_passes, group_split, n_adopted_outer_lists, n_fused_steps, the four list-upkeep figures)
+    assert C.sizeof(pkg.Stats) == 8 * 9 + 4 * 4 + 8 * 3 + 8 + 8 * 8 + 8 * 8 + 24 + 8 + 4 * 2 + 8 + 8 * 4 + 8      # (… + n_group_split_passes, group_split, n_adopted_outer_lists, n_fused_steps, the four list-upkeep figures, n_box_changes)
     from molly_jl_amd import _lib
     assert C.sizeof(_lib.HaloPlan) == 8 * 2 + 8 * 2 + 4 * 2 + 8 * 2 + 8 + 8 + 8 + 4 + 4     # mhip_halo_plan (…, n_send_cm + tail padding)
 
