@@ -10,5 +10,5 @@ from .api import (  # noqa: F401
     HarmonicAngles, HarmonicBonds, Langevin, LennardJones, NeighborList, NoCutoff, NoNeighborFinder, PeriodicTorsions,
     PME, PolynomialCutoff, ShiftedForceCutoff, ShiftedPotentialCutoff, System, TriclinicBoundary, VelocityVerlet, find_neighbors, forces,
     kinetic_energy, potential_energy, pressure, scalar_pressure, random_velocities, apply_coupling, remove_CM_motion, scalar_virial, simulate, temperature, total_energy, use_neighbors, virial,
-    wrap_coords, optimize_launch_config, set_launch_config, MonteCarloBarostat, scale_boundary, scale_coords, volume, BAR,
+    wrap_coords, optimize_launch_config, set_launch_config, MonteCarloBarostat, SteepestDescentMinimizer, scale_boundary, scale_coords, volume, BAR,
 )

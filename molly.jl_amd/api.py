@@ -257,6 +257,16 @@ class VelocityVerlet:
 
 
 @dataclass
+class SteepestDescentMinimizer:
+    """SteepestDescentMinimizer(; step_size=0.01 nm, max_steps=1000, tol=1000 kJ mol⁻¹ nm⁻¹) (simulators.jl:112-135): x += hn · F / max|F|, the step taken when
+    the potential energy falls (hn · 6/5) and taken back otherwise (hn / 5), until max|F| < tol"""
+    step_size: float = 0.01
+    max_steps: int = 1000
+    tol: float = 1000.0
+    log_stream: object = None
+
+
+@dataclass
 class AndersenThermostat:
     """AndersenThermostat(temperature, coupling_const) (coupling.jl:188-211): every step each atom's velocity is re-drawn from the
     Maxwell-Boltzmann distribution with probability dt / coupling_const."""
@@ -611,14 +621,48 @@ def remove_CM_motion(sys):
     return sys
 
 
-def simulate(sys, sim, n_steps, init_step=0, check_nans=False, rng=None):
+def _minimize(sys, sim, init_step=0):
+    """simulate!(sys, ::SteepestDescentMinimizer) (simulators.jl:183-271; systems without constraints or virtual sites): every force and energy from the engine, the
+    update x += hn · F / max|F| and the accept / reject rule in the system's number type on the host side, as the reference's loop broadcasts them"""
+    T = sys.dtype.type
+    log = (lambda *a: print(*a, file=sim.log_stream)) if sim.log_stream is not None else (lambda *a: None)
+    sys.coords[:] = wrap_coords(sys.coords, sys.boundary)
+    E = potential_energy(sys, init_step)
+    log("Step", init_step, "- potential energy", E, "- max force N/A - N/A")
+    hn = T(sim.step_size)
+    for step_n in range(init_step + 1, init_step + sim.max_steps + 1):
+        F = forces(sys, step_n)
+        max_force = np.sqrt((F * F).sum(axis=1, dtype=sys.dtype)).max()               # maximum(norm.(F))
+        coords_copy = sys.coords.copy()
+        sys.coords[:] = wrap_coords(sys.coords + (hn * F / max_force).astype(sys.dtype), sys.boundary)
+        E_trial = potential_energy(sys, step_n)
+        if E_trial < E:
+            hn = T(6) * hn / T(5)
+            E = E_trial
+            log("Step", step_n, "- potential energy", E_trial, "- max force", max_force, "- accepted")
+        else:
+            sys.coords[:] = coords_copy
+            hn = hn / T(5)
+            log("Step", step_n, "- potential energy", E_trial, "- max force", max_force, "- rejected")
+        if max_force < sim.tol:
+            break
+    return sys
+
+
+def simulate(sys, sim, n_steps=None, init_step=0, check_nans=False, rng=None):
     """simulate!(sys, sim, n_steps; init_step, rng) for VelocityVerlet (simulators.jl:547-668) and Langevin (:1099-1220), with
     coupling nothing, AndersenThermostat, MonteCarloBarostat or a tuple of the two.  The step loop runs on the device; with a barostat it is cut at the
     multiples of barostat.n_steps, where apply_coupling! runs on the host side of the boundary with the engine's potential energies (the README's GPU
     example: Langevin + MonteCarloBarostat).  Coordinates and velocities come back when the call returns.  rng: a numpy Generator or a seed; as in the
     reference it supplies the Philox key / counter words and the barostat's uniform numbers."""
+    if isinstance(sim, SteepestDescentMinimizer):
+        if init_step < 0:
+            raise ValueError("init_step must be non-negative")
+        return _minimize(sys, sim, init_step)
     if not isinstance(sim, (VelocityVerlet, Langevin)):
         raise MollyHipError(-6, f"simulator {type(sim).__name__} is outside the hot-path scope")
+    if n_steps is None:
+        raise TypeError("simulate: n_steps is required for VelocityVerlet and Langevin")
     couplings = sim.coupling if isinstance(sim.coupling, (tuple, list)) else (() if sim.coupling is None else (sim.coupling,))
     thermostat = barostat = None
     for c in couplings:

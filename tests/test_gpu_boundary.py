@@ -249,3 +249,39 @@ def test_6mrr_pme_step_on_a_scaled_box(pkg):
     pkg.simulate(s2, sim, 20, init_step=10)
     assert s.stats()["n_fused_steps"] > n0
     assert np.abs(s.coords - s2.coords).max() < 5e-5 and np.abs(s.velocities - s2.velocities).max() < 8e-3      # (fp32 trajectory bars of tests/test_gpu_pme.py)
+
+
+def test_steepest_descent_minimizer_follows_the_oracle(pkg):
+    """SteepestDescentMinimizer (simulators.jl:183-271; the first call of the README's GPU example) on a charged fluid with PME and exception lists, fp64: the same
+    accept / reject sequence and coordinates as the loop restated over the oracle's forces and energies, and the energy falls"""
+    case, dtype = make("pme_fp64")
+    rng = np.random.default_rng(3)
+    x0 = case.coords + rng.normal(scale=0.01, size=case.coords.shape)              # off the lattice: forces to relax
+    s = case.system(pkg, dtype, coords=x0)
+    e0 = pkg.potential_energy(s)
+    lines = []
+
+    class Log:
+        def write(self, t):
+            lines.append(t)
+    pkg.simulate(s, pkg.SteepestDescentMinimizer(step_size=0.01, max_steps=12, tol=1.0, log_stream=Log()))
+    got = [w for w in "".join(lines).split() if w in ("accepted", "rejected")]
+    # the loop over the oracle (restated from simulators.jl:225-262)
+    o = case.oracle(np.float64, coords=x0)
+    full = dict(specific=True, general=True)
+    pe = lambda: o.potential_energy(o.neighbors("cell", nthreads=8), **full)
+    o.wrap()
+    E, hn, want = pe(), 0.01, []
+    for _ in range(12):
+        F = o.forces(o.neighbors("cell", nthreads=8), nthreads=4, **full)
+        keep = o.coords.copy()
+        o.coords += hn * F / np.linalg.norm(F, axis=1).max()
+        o.wrap()
+        E_trial = pe()
+        if E_trial < E:
+            hn, E = 6 * hn / 5, E_trial; want.append("accepted")
+        else:
+            o.coords[:] = keep; hn /= 5; want.append("rejected")
+    assert got == want and "accepted" in got, (got, want)
+    assert np.abs(s.coords - o.coords).max() < 1e-9
+    assert pkg.potential_energy(s) < e0 and pkg.potential_energy(s) == pytest.approx(E, rel=1e-9)
