@@ -51,12 +51,26 @@ function push_exceptions!(c::HipContext, nf::GPUNeighborFinder)                 
     nf.initialized = true
 end
 
+function push_atoms!(c::HipContext, sys::System{3, <:ROCArray, T}) where T          # Atom fields, types.jl:466-475
+    at = Array(sys.atoms)
+    q = T[a.charge for a in at]; σ = T[ustrip(a.σ) for a in at]; ϵ = T[ustrip(a.ϵ) for a in at]; λ = T[a.λ for a in at]
+    m = T.(ustrip.(Array(masses(sys))))
+    check(c, ccall((:mhip_set_atoms, libmollyhip), Int32, (Ptr{Cvoid}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Int32), c.ptr, q, σ, ϵ, m, λ, 0))
+    c.atoms = sys.atoms
+end
+
+# The reference reads sys.atoms, sys.boundary, sys.pairwise_inters and the neighbour finder's exception caches at EVERY call (ext/MollyCUDAExt.jl:845-873); the
+# engine keeps them in its context, so every look-up checks that what it keeps is still what the System holds: a replaced boundary goes through mhip_set_box, a
+# replaced atoms array through mhip_set_atoms, new exception pairs through mhip_set_exceptions, a replaced interaction tuple makes a new context.
 function context!(sys::System{3, <:ROCArray, T}) where T
     c = lock(CONTEXTS_LOCK) do
         get(CONTEXTS, sys, nothing)
     end
     nf = sys.neighbor_finder
     nf isa GPUNeighborFinder || error("MollyHIPExt expects the GPUNeighborFinder that setup picks for ROCArray systems (setup.jl:1938-1949)")
+    if c !== nothing && c.inters !== sys.pairwise_inters
+        release!(sys); c = nothing
+    end
     if c === nothing
         b = sys.boundary
         tric = b isa TriclinicBoundary
@@ -69,20 +83,18 @@ function context!(sys::System{3, <:ROCArray, T}) where T
         rc = ccall((:mhip_create, libmollyhip), Int32, (Ref{Ptr{Cvoid}}, Ref{MhipConfig}), out, cfg)
         rc == 0 || error("libmollyhip: ", last_error(C_NULL))
         c = HipContext(out[], b)
+        c.inters = sys.pairwise_inters
         check(c, ccall((:mhip_set_stream, libmollyhip), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), c.ptr, AMDGPU.stream().stream))   # kernels join the task's HIP stream
         if tric
             bv = Float64[ustrip(b.basis_vectors[r][k]) for r in 1:3 for k in 1:3]
             approx = typeof(b).parameters[end] === true                              # TriclinicBoundary{D, T, A, …}: A = approx_images
             check(c, ccall((:mhip_set_triclinic, libmollyhip), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int32), c.ptr, bv, approx ? 1 : 0))
         end
-        at = Array(sys.atoms)                                                        # Atom fields, types.jl:466-475
-        q = T[a.charge for a in at]; σ = T[ustrip(a.σ) for a in at]; ϵ = T[ustrip(a.ϵ) for a in at]; λ = T[a.λ for a in at]
-        m = T.(ustrip.(Array(masses(sys))))
-        check(c, ccall((:mhip_set_atoms, libmollyhip), Int32, (Ptr{Cvoid}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Int32), c.ptr, q, σ, ϵ, m, λ, 0))
         lock(CONTEXTS_LOCK) do
             CONTEXTS[sys] = c
         end
     end
+    c.atoms === sys.atoms || push_atoms!(c, sys)                                     # first use, or `sys.atoms = …` since (mhip_set_atoms drops what depended on them)
     follow_boundary!(c, sys.boundary)                                                # a barostat replaced sys.boundary (coupling.jl:861-1033): mhip_set_box
     push_exceptions!(c, nf)                                                          # also after append_excluded_pairs! (neighbors.jl:313)
     return c

@@ -21,8 +21,10 @@ mutable struct HipContext
     exceptions_generation::UInt64          # nf.cache_generation the engine's exception lists were built from
     bonded_sent::Bool
     boundary::Any                          # the sys.boundary the engine's box was made from (follow_boundary!)
+    atoms::Any                             # the sys.atoms array the engine's parameters were read from (=== : a replaced array is pushed again)
+    inters::Any                            # the sys.pairwise_inters tuple mhip_create fixed the kinds and cutoffs from (a replaced tuple: a new context)
     function HipContext(ptr, boundary=nothing)
-        c = new(ptr, typemax(UInt64), false, boundary)
+        c = new(ptr, typemax(UInt64), false, boundary, nothing, nothing)
         finalizer(c) do x                   # GC-driven release; release!(sys) is the eager form
             x.ptr == C_NULL || ccall((:mhip_destroy, libmollyhip), Int32, (Ptr{Cvoid},), x.ptr)
             x.ptr = C_NULL
