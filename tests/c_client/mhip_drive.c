@@ -76,17 +76,32 @@ int main(int argc, char** argv) {
     }
     CHECK(mhip_get_stats(ctx, &st1));
     CHECK(mhip_check_finite(ctx));
+    /* a barostat's trial move (coupling.jl:886-932): box and coordinates scaled by 1 %, the energy there, the move taken back, the old energy again */
+    double pe_scaled = 0, pe_back = 0;
+    {
+        const double box2[3] = {1.01 * box, 1.01 * box, 1.01 * box}, box1[3] = {box, box, box};
+        double* xs = (double*)malloc(sizeof(double) * 3 * n);
+        if (!xs) return 1;
+        for (int64_t k = 0; k < 3 * n; ++k) xs[k] = 1.01 * x1[k];
+        CHECK(mhip_set_box(ctx, box2, NULL));
+        CHECK(mhip_set_state(ctx, xs, NULL, MHIP_MEM_HOST));
+        CHECK(mhip_potential_energy(ctx, n_steps + 6, &pe_scaled));
+        CHECK(mhip_set_box(ctx, box1, NULL));
+        CHECK(mhip_set_state(ctx, x1, NULL, MHIP_MEM_HOST));
+        CHECK(mhip_potential_energy(ctx, n_steps + 6, &pe_back));
+        free(xs);
+    }
     CHECK(mhip_destroy(ctx));
 
     FILE* out = fopen(argv[3], "wb");
     if (!out) return 1;
     const double head[8] = {(double)n, box, dt, (double)n_steps, pe0, ke0, pe1, ke1};
-    const double tail[4] = {(double)(st1.n_outer_builds - st0.n_outer_builds), (double)(st1.n_filter_passes - st0.n_filter_passes),
-                            (double)(st1.n_force_calls - st0.n_force_calls), (double)st1.n_pairs_full};
+    const double tail[6] = {(double)(st1.n_outer_builds - st0.n_outer_builds), (double)(st1.n_filter_passes - st0.n_filter_passes),
+                            (double)(st1.n_force_calls - st0.n_force_calls), (double)st1.n_pairs_full, pe_scaled, pe_back};
     fwrite(head, sizeof(double), 8, out);
     fwrite(x, sizeof(double), 3 * n, out); fwrite(v, sizeof(double), 3 * n, out); fwrite(f0, sizeof(double), 3 * n, out);
     fwrite(x1, sizeof(double), 3 * n, out); fwrite(v1, sizeof(double), 3 * n, out); fwrite(f1, sizeof(double), 3 * n, out);
-    fwrite(tail, sizeof(double), 4, out);
+    fwrite(tail, sizeof(double), 6, out);
     fclose(out);
     printf("mhip_drive ok: %lld atoms, %d steps, PE %.6f -> %.6f kJ/mol, KE %.6f -> %.6f kJ/mol, searches during the set_state loop: %d\n",
            (long long)n, n_steps, pe0, pe1, ke0, ke1, (int)tail[0]);

@@ -1,5 +1,5 @@
 """The C ABI driven by a C program (tests/c_client/mhip_drive.c, gcc, no Python in the call path): create → set_atoms → set_state →
-forces / energies → vv_run → get_state → set_state + forces(step_n) × 5 → stats → destroy.  Its numbers are checked against the CPU
+forces / energies → vv_run → get_state → set_state + forces(step_n) × 5 → stats → set_box (a trial move and back) → destroy.  Its numbers are checked against the CPU
 oracle on the same inputs: fp64 forces and energies at the reference's bars (test/protein.jl:267, 274), the 20-step trajectory at
 1e-9 nm, and the drop-in cadence (no new neighbour search for unchanged coordinates)."""
 import os
@@ -27,7 +27,7 @@ def test_c_client_drives_the_engine(tmp_path):
     pe0, ke0, pe1, ke1 = raw[4:8]
     body = raw[8:8 + 18 * n].reshape(6, n, 3)
     x0, v0, f0, x1, v1, f1 = body
-    searches, prunes, calls, pairs_full = raw[8 + 18 * n:]
+    searches, prunes, calls, pairs_full, pe_scaled, pe_back = raw[8 + 18 * n:]
     assert n == n_side ** 3 and int(raw[3]) == n_steps
     case = S.Case(x0, box, lj=dict(cutoff=("distance", 1.0)), r_list=1.2, rebuild_every=10, velocities=v0,
                   sigma=np.full(n, 0.34), eps=np.full(n, 0.997), mass=np.full(n, 39.948))
@@ -49,3 +49,8 @@ def test_c_client_drives_the_engine(tmp_path):
     assert int(pairs_full) == 2 * len(nl2[0])                                # the statistics count the reference's list of the final coordinates
     assert np.abs(f1 - f1_ref).max() < 1e-7
     assert int(calls) == 5 and int(searches) == 0 and int(prunes) <= 1
+    # mhip_set_box: the energy on the box scaled by 1 % (coordinates with it), and the old energy after the move is taken back
+    o3 = S.Case(1.01 * x1, 1.01 * box, lj=dict(cutoff=("distance", 1.0)), r_list=1.2, rebuild_every=10, sigma=np.full(n, 0.34), eps=np.full(n, 0.997),
+                mass=np.full(n, 39.948)).oracle(np.float64)
+    assert pe_scaled == pytest.approx(o3.potential_energy(o3.neighbors("cell")), rel=1e-10, abs=1e-6)
+    assert pe_back == pytest.approx(pe1, rel=1e-11)
