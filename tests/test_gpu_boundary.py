@@ -285,3 +285,17 @@ def test_steepest_descent_minimizer_follows_the_oracle(pkg):
     assert got == want and "accepted" in got, (got, want)
     assert np.abs(s.coords - o.coords).max() < 1e-9
     assert pkg.potential_energy(s) < e0 and pkg.potential_energy(s) == pytest.approx(E, rel=1e-9)
+
+
+def test_readme_gpu_example_runs(tmp_path):
+    """examples/readme_6mrr_npt.py — the reference README's GPU example call by call — in small: 20 minimiser steps, 90 Langevin steps with three barostat trials"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "readme_6mrr_npt.py"), "--steps", "90", "--minimize-steps", "20"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["finite"] and d["pe_minimized_kj_mol"] < d["pe_before_kj_mol"] and d["barostat_trials"] == 3 and d["box_changes"] >= 3
+    assert 150.0 < d["temperature_K"] < 450.0 and abs(d["volume_nm3"][1] / d["volume_nm3"][0] - 1.0) < 0.05
