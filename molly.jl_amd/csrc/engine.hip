@@ -769,6 +769,7 @@ template <class T> class Engine final : public EngineBase {
     DBuf<float> trk_part, trk_out; float* h_trk = nullptr; hipEvent_t ev_trk = nullptr;
     bool trk_issued = false; int64_t trk_step = -1, trk_prune_id = -1, trk_outer_id = -1; double trk_prev_vmax = 0;   // (ids: the running counts of prunes / outer searches)
     bool in_vv_fused = false;
+    bool in_lang_fused = false;      // inside mhip_langevin_run of a small system whose last force launch integrates (the pair launch's extra workgroup then sums the Σ m v partials, as inside mhip_vv_run)
     bool async_ok() const { return in_vv_fused && dual && n_ghost == 0 && !host_prune && inner_valid && !stale; }
     void resolve_track(int64_t step) {
         if (!trk_issued) return;
@@ -964,7 +965,7 @@ template <class T> class Engine final : public EngineBase {
                         const bool with_spread = fuse_spread_next;
                         const int order = with_spread ? pme.order : 5;
                         // inside vv_run: the Σ m v partials of the launch before become one partial in an extra workgroup of this launch (the step's last launch reads four words)
-                        const bool gs_cm_fin = in_vv_fused && !energy && cm_pending == 2 && n_cm_step > 1 && n_cm_step <= 65536;
+                        const bool gs_cm_fin = (in_vv_fused || in_lang_fused) && !energy && cm_pending == 2 && n_cm_step > 1 && n_cm_step <= 65536;
                         if (gs_cm_fin) cm_fin_buf.reserve(4);
                         const size_t lds = (with_spread ? std::max(gs_lds_bytes(q_lds, BI, JS / GS), std::min<size_t>((size_t)MAX_LDS_BYTES / GS, spread_head_bytes_f32(order) + (size_t)PME_BOX_BYTES)) : gs_lds_bytes(q_lds, BI, JS / GS)) & ~(size_t)15;
                         const int n_spread = with_spread ? (int)std::min<int64_t>(cdiv(n_owned, (int64_t)64), 4096) : 0;
@@ -1029,7 +1030,7 @@ template <class T> class Engine final : public EngineBase {
         // inside vv_run: the Σ m v partials of the integrator launch before this pass become one partial here (kernels.h, cm_finalize_in_block)
         A.cm_fin_in = nullptr; A.cm_fin_n = 0; A.cm_fin_out = nullptr;
         A.vel = nullptr; A.pos_next = nullptr; A.dt = T(0); A.dt2 = T(0); A.cm_in = nullptr; A.cm_n = 0; A.cm_pub = nullptr; A.step_seq = 0; A.cm_out = nullptr; A.trk_part = nullptr; A.snap_a = nullptr; A.snap_b = nullptr;
-        const bool cm_fin = in_vv_fused && !energy && n_ghost == 0 && part == 0 && cm_pending == 2 && n_cm_step > 1 && n_cm_step <= 65536;      // (the energy variants do not carry the sum)
+        const bool cm_fin = (in_vv_fused || in_lang_fused) && !energy && n_ghost == 0 && part == 0 && cm_pending == 2 && n_cm_step > 1 && n_cm_step <= 65536;      // (the energy variants do not carry the sum)
         if (cm_fin) { cm_fin_buf.reserve(4); A.cm_fin_in = cm_src(); A.cm_fin_n = n_cm_step; A.cm_fin_out = cm_fin_buf.p; }
         else if (cm_fin_solo_src && !energy && n_ghost == 0 && part == 0 && !cm_fin_solo_done) {      // (mhip_domain_run on one brick: halo_mid's partials)
             cm_fin_buf.reserve(4); A.cm_fin_in = cm_fin_solo_src; A.cm_fin_n = n_cm_step; A.cm_fin_out = cm_fin_buf.p; cm_fin_solo_done = true;
@@ -1123,7 +1124,7 @@ template <class T> class Engine final : public EngineBase {
     // of this step, first kick + drift of the next, into the other position buffer (swapped in behind the launch) — with Σ m v summed and published by the grid's first
     // workgroup.  Asked for by vv_run (step_req), carried out by launch_pair_kernel when the pass is a packed plain one; every other pass keeps pair pass + k_vv_mid.
     // (gcv: the same request for a small system's step, whose last force launch — interpolation + bonded sums — can integrate: step_fused.h, k_gather_collect_vv)
-    struct StepReq { bool on = false, gcv = false, cm = false, measure = false; double dt = 0; } step_req;
+    struct StepReq { bool on = false, gcv = false, cm = false, measure = false; double dt = 0; const StochP<T>* lang = nullptr; } step_req;      // (lang: gcv with the Langevin-middle update, mhip_langevin_run)
     bool step_done = false; int step_half = 0; uint32_t step_seq = 0; int64_t n_fused_steps = 0;
     int step_parts = 0;      // per-block partials (Σ m v in cm_blk's current half, maxima in trk_part) the fused step left behind
     const bool fuse_gcv_env = env_int("MOLLYHIP_FUSE_GATHER_VV", 1) != 0;
@@ -1378,10 +1379,11 @@ template <class T> class Engine final : public EngineBase {
                 V.cm_in = cm_pending == 2 ? cm_src() : (const double*)nullptr;
                 V.cm_out = step_req.cm ? cm_blk.p + (size_t)step_half * 4 * nb : (double*)nullptr;
                 V.snap_a = pos_snap_in.p; V.snap_b = pos_snap.p; V.trk_part = step_req.measure ? trk_part.p : (float*)nullptr;
+                if (step_req.lang) V.S = *step_req.lang;
                 vp = &V; step_parts = nb;
             }
             prof.begin(6, stream);
-            launch_pme_bonded_fused<T>(stream, pme, bonded, G, I, n_owned, cap, pos[cur].p, inv.p, orig[cur].p, frc[cur].p, frc_side.p, spread_fused, vp);
+            launch_pme_bonded_fused<T>(stream, pme, bonded, G, I, n_owned, cap, pos[cur].p, inv.p, orig[cur].p, frc[cur].p, frc_side.p, spread_fused, vp, vp && step_req.lang);
             prof.end(6, stream);
             if (vp) { step_done = true; ++n_fused_steps; pend_a = nullptr; frc_valid = false; return; }
             pend_a = frc_side.p;
@@ -1704,13 +1706,13 @@ template <class T> class Engine final : public EngineBase {
         for (int d = 0; d < 3; ++d) cfg.box[d] = box3[d];
         if (bv9) std::memcpy(tri_bv, bv9, sizeof(tri_bv));
         try {
-            if (pme.on()) pme.setup(pme_order_, pme_mesh_, pme_alpha_, cfg.inter.coul_ke, pme_eps_r_, cfg.box, cfg.periodic, tri_mode ? tri_bv : nullptr);
+            pme.rebox(pme_alpha_, cfg.inter.coul_ke, pme_eps_r_, cfg.box, tri_mode ? tri_bv : nullptr);      // (order, mesh, α stay: only what depends on the box lengths is made again, nothing reallocated)
             setup_grid(); choose_blocking();
             size_t tb2 = 0; MHIP_HIP(exclusive_sum_i32(nullptr, tb2, cell_cnt.p, cell_start.p, 2 * G.ncell + 1, stream));
             if (tb2 + 256 > cub_tmp.n) cub_tmp.reserve(tb2 + 256);
         } catch (...) {      // (a box the engine cannot take — r_list beyond half a side with exact images off, a mesh the PME refuses: the context stays what it was)
             cfg = old_cfg; std::memcpy(tri_bv, old_bv, sizeof(tri_bv));
-            if (pme.on() || pme_order_) pme.setup(pme_order_, pme_mesh_, pme_alpha_, cfg.inter.coul_ke, pme_eps_r_, cfg.box, cfg.periodic, tri_mode ? tri_bv : nullptr);
+            pme.rebox(pme_alpha_, cfg.inter.coul_ke, pme_eps_r_, cfg.box, tri_mode ? tri_bv : nullptr);
             setup_grid(); choose_blocking(); stale = true; frc_valid = false; state_set = false;
             throw;
         }
@@ -2659,6 +2661,7 @@ template <class T> class Engine final : public EngineBase {
         const int every = cfg.rebuild_every > 0 ? cfg.rebuild_every : 10;
         cur_dt = dt;
         InRun guard_in_run(in_run);
+        InRun guard_lang(in_lang_fused); in_lang_fused = bonded.any() && pme.on() && fuse_gcv_env;
         if (first_step == 0 && remove_cm_every != 0) remove_cm();                 // :1115
         start_lists(first_step);                                                  // :1116
         const double vs = std::exp(-dt * friction);                               // :1091-1092
@@ -2668,16 +2671,29 @@ template <class T> class Engine final : public EngineBase {
         int half = 0;
         for (int64_t step = first_step + 1; step <= first_step + n_steps; ++step) {
             resolve_track(step);
-            step_forces(step);                                                    // :1173
-            fold_side_forces();
             const bool cm = remove_cm_every != 0 && step % remove_cm_every == 0;
             P.ctr1 = ctr1_0 + (uint64_t)(step - first_step - 1);
+            // a small system's step (bonded terms + PME): its last force launch — interpolation + bonded sums — runs the update as well (step_fused.h, k_gather_collect_vv<…, LANG>),
+            // every step of the run: a Langevin step is complete in itself, there is no closing half kick to keep a launch for
+            step_req.gcv = bonded.any() && pme.on(); step_req.lang = &P; step_req.cm = cm; step_req.measure = false; step_req.dt = dt;
+            step_done = false;
+            step_forces(step);                                                    // :1173
+            step_req.gcv = false; step_req.lang = nullptr;
+            if (step_done) {
+                step_done = false;
+                pend_a = nullptr; cm_pending = 0; cm_ext = nullptr; frc_valid = false;
+                if (cm) { cm_pending = 2; cm_ext = cm_blk.p + (size_t)step_half * 4 * step_parts; n_cm_step = step_parts; step_half ^= 1; }
+                apply_coupling(step);
+                if (check_due(step, every)) refresh(step);
+                continue;
+            }
             prof.begin(2, stream);
             double* cm_out = cm ? cm_step.p + (size_t)half * 4 * 1024 : (double*)nullptr;   // the other half may still be read by this launch
             launch_langevin<T>(stream, nb, n_owned, pos[cur].p, vel[cur].p, (const T4*)frc[cur].p, orig[cur].p, P,
                                cm_pending == 1 ? (const T*)vcm.p : (const T*)nullptr, cm_pending == 2 ? cm_src() : (const double*)nullptr, n_cm_step,
-                               cm_out, G);
+                               cm_out, G, (const T4*)pend_a);      // (the side array of a small system's step is added by the update itself, as k_vv_mid does: no k_add_forces launch)
             prof.end(2, stream);
+            pend_a = nullptr;
             cm_pending = 0; cm_ext = nullptr; frc_valid = false;
             if (cm) { cm_pending = 2; cm_ext = cm_out; n_cm_step = nb; half ^= 1; }   // :1204-1206, subtracted by the next consumer
             apply_coupling(step);                                                 // :1208

@@ -612,6 +612,7 @@ template <class U> struct PBuf {
     U* p = nullptr; size_t n = 0;
     void set(const std::vector<U>& h) { release(); n = h.size(); if (n) { MHIP_HIP(hipMalloc((void**)&p, n * sizeof(U))); MHIP_HIP(hipMemcpy(p, h.data(), n * sizeof(U), hipMemcpyHostToDevice)); } }
     void alloc(size_t m) { release(); n = m; if (n) MHIP_HIP(hipMalloc((void**)&p, n * sizeof(U))); }
+    void update(const std::vector<U>& h) { if (h.size() != n) { set(h); return; } if (n) MHIP_HIP(hipMemcpy(p, h.data(), n * sizeof(U), hipMemcpyHostToDevice)); }      // same length: the allocation stays
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
@@ -657,6 +658,35 @@ template <class T> struct Pme {
         }
     }
 
+    // what of the set-up depends on the BOX (as opposed to order, mesh and α): the scaling fields of P, the reciprocal box, the volume in the influence function and in
+    // the charge term, and the signed frequencies k / L of an orthorhombic box.  setup() calls it; so does rebox() when mhip_set_box replaces the boundary of a live
+    // context — the meshes, twiddle factors, B-spline moduli and library plans stay as they are, nothing is reallocated.
+    void box_fields(double alpha, double ke, double eps_r, const double* box, const double* bv9) {
+        const T a = T(alpha);
+        T V = T(1);
+        for (int d = 0; d < 3; ++d) { P.invL[d] = T(1) / T(box[d]); P.n_over_L[d] = T(P.n[d]) * (T(1) / T(box[d])); V *= T(box[d]); }
+        P.tri = bv9 ? 1 : 0;
+        for (int e = 0; e < 3; ++e) for (int d = 0; d < 3; ++d) P.r[e][d] = T(0);
+        if (bv9) {      // invert_box_vectors(::TriclinicBoundary), spatial.jl:338-347, in T
+            T bv[3][3]; for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) bv[i][k] = T(bv9[3 * i + k]);
+            const T vol = bv[0][0] * bv[1][1] * bv[2][2];
+            P.r[0][0] = (bv[1][1] * bv[2][2]) / vol;
+            P.r[1][0] = (-bv[1][0] * bv[2][2]) / vol; P.r[1][1] = (bv[0][0] * bv[2][2]) / vol;
+            P.r[2][0] = (bv[1][0] * bv[2][1] - bv[1][1] * bv[2][0]) / vol; P.r[2][1] = (-bv[0][0] * bv[2][1]) / vol; P.r[2][2] = (bv[0][0] * bv[1][1]) / vol;
+        } else for (int d = 0; d < 3; ++d) P.r[d][d] = P.invL[d];
+        P.f_div_er = T(ke) / T(eps_r); P.factor = T(M_PI) * T(M_PI) / (a * a); P.pi_V = T(M_PI) * V;
+        self_factor = -(double)P.f_div_er * (double)a / std::sqrt(M_PI);
+        charge_factor = -(double)P.f_div_er * M_PI / (2.0 * (double)V * (double)a * (double)a);
+        for (int d = 0; d < 3; ++d) {
+            const int nd = P.n[d];
+            std::vector<T> m(nd);
+            const T maxk = T(0.5) * T(nd + 1);
+            for (int k = 0; k < nd; ++k) m[k] = (T(k) < maxk ? T(k) : T(k - nd)) * (bv9 ? T(1) : P.invL[d]);      // (triclinic: the signed integer frequency, the kernel multiplies by recip_box)
+            mh[d].update(m);
+        }
+    }
+    void rebox(double alpha, double ke, double eps_r, const double* box, const double* bv9) { if (on()) box_fields(alpha, ke, eps_r, box, bv9); }
+
     // bv9 (nullable): the basis vectors of a TriclinicBoundary, row-major; box = (v1.x, v2.y, v3.z) then (box_sides, spatial.jl:359: mesh sizes and volume come from it)
     void setup(int ord, const int32_t* mesh, double alpha, double ke, double eps_r, const double* box, const int* periodic, const double* bv9 = nullptr) {
         release();
@@ -678,33 +708,18 @@ template <class T> struct Pme {
         if (long_axis && fft_env == 0) throw ApiError{MHIP_ERR_UNSUPPORTED, "PME mesh axis beyond 512 points needs the FFT path (MOLLYHIP_PME_FFT=0 turned it off)"};
         if ((int64_t)mesh[0] * mesh[1] * mesh[2] > ((int64_t)1 << 30)) throw ApiError{MHIP_ERR_CAPACITY, "PME mesh too large"};
         order = ord;
-        const T a = T(alpha);
-        T V = T(1);
-        for (int d = 0; d < 3; ++d) { P.n[d] = mesh[d]; P.invL[d] = T(1) / T(box[d]); P.n_over_L[d] = T(mesh[d]) * (T(1) / T(box[d])); V *= T(box[d]); }
-        P.tri = bv9 ? 1 : 0;
-        for (int e = 0; e < 3; ++e) for (int d = 0; d < 3; ++d) P.r[e][d] = T(0);
-        if (bv9) {      // invert_box_vectors(::TriclinicBoundary), spatial.jl:338-347, in T
-            T bv[3][3]; for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) bv[i][k] = T(bv9[3 * i + k]);
-            const T vol = bv[0][0] * bv[1][1] * bv[2][2];
-            P.r[0][0] = (bv[1][1] * bv[2][2]) / vol;
-            P.r[1][0] = (-bv[1][0] * bv[2][2]) / vol; P.r[1][1] = (bv[0][0] * bv[2][2]) / vol;
-            P.r[2][0] = (bv[1][0] * bv[2][1] - bv[1][1] * bv[2][0]) / vol; P.r[2][1] = (-bv[0][0] * bv[2][1]) / vol; P.r[2][2] = (bv[0][0] * bv[1][1]) / vol;
-        } else for (int d = 0; d < 3; ++d) P.r[d][d] = P.invL[d];
-        P.f_div_er = T(ke) / T(eps_r); P.factor = T(M_PI) * T(M_PI) / (a * a); P.pi_V = T(M_PI) * V;
-        self_factor = -(double)P.f_div_er * (double)a / std::sqrt(M_PI);
-        charge_factor = -(double)P.f_div_er * M_PI / (2.0 * (double)V * (double)a * (double)a);
+        for (int d = 0; d < 3; ++d) P.n[d] = mesh[d];
+        box_fields(alpha, ke, eps_r, box, bv9);
         std::vector<T> bm[3];
         moduli(ord, P.n, bm);
         for (int d = 0; d < 3; ++d) {
             const int nd = P.n[d];
-            std::vector<T2> w(nd); std::vector<T> m(nd);
-            const T maxk = T(0.5) * T(nd + 1);
+            std::vector<T2> w(nd);
             for (int k = 0; k < nd; ++k) {
                 const double ang = -2.0 * M_PI * k / nd;
                 w[k].x = (T)std::cos(ang); w[k].y = (T)std::sin(ang);
-                m[k] = (T(k) < maxk ? T(k) : T(k - nd)) * (bv9 ? T(1) : P.invL[d]);      // (triclinic: the signed integer frequency, the kernel multiplies by recip_box)
             }
-            tw[d].set(w); mh[d].set(m); bsm[d].set(bm[d]);
+            tw[d].set(w); bsm[d].set(bm[d]);
         }
         nzh = P.n[2] / 2 + 1;
         try {      // (a mesh whose arrays or library work areas do not fit leaves a context without PME, not one with half of it)

@@ -11,6 +11,7 @@
 #pragma once
 #include "bonded.h"
 #include "kernels.h"
+#include "philox.h"
 #include "pme.h"
 
 namespace mhip {
@@ -42,8 +43,11 @@ template <class T> struct GcvArgs {
     const int32_t* orig; const int32_t* role_start; const int32_t* role_slot; const typename Vec<T>::T4* slots; const typename Vec<T>::T4* parts; int n_parts; int64_t part_stride;
     T dt, dt2; const double* cm_in; double* cm_out; GridP<T> G;
     const typename Vec<T>::T4* snap_a; const typename Vec<T>::T4* snap_b; float* trk_part;      // validity check of the pair lists, as in k_vv_mid (nullable)
+    // LANG instantiations (mhip_langevin_run, round 6): the integrating lane runs the Langevin-middle update of stochastic.hip instead (philox.h, langevin_atom: the same
+    // function k_langevin calls); v_cm of the step before is subtracted from the velocity only, as k_langevin does (the reference removes it behind the step's drift)
+    StochP<T> S;
 };
-template <class T, int ORDER>
+template <class T, int ORDER, bool LANG = false>
 __global__ void __launch_bounds__(256) k_gather_collect_vv(GcvArgs<T> A) {
     using T4 = typename Vec<T>::T4;
     __shared__ T l_w[6 * ORDER * PME_AB]; __shared__ int l_i[3 * PME_AB]; __shared__ T l_q[PME_AB]; __shared__ T l_g[3 * PME_AB];
@@ -79,6 +83,13 @@ __global__ void __launch_bounds__(256) k_gather_collect_vv(GcvArgs<T> A) {
             const T q = l_q[ta];
             if (q != T(0)) { f.x -= q * l_g[3 * ta]; f.y -= q * l_g[3 * ta + 1]; f.z -= q * l_g[3 * ta + 2]; }      // (k_gather_collect: frc += reciprocal part)
             f.x += bx; f.y += by; f.z += bz;                                                                          // (k_vv_mid: + the bonded sums)
+            if constexpr (LANG) {
+                if (A.cm_in) { v.x -= vc[0]; v.y -= vc[1]; v.z -= vc[2]; }
+                langevin_atom<T>(v, p, f, A.S, (uint64_t)A.orig[s] + 1, A.G);
+                A.pos[s] = p; A.vel[s] = v;
+                if (A.cm_out) { px += (double)v.x * v.w; py += (double)v.y * v.w; pz += (double)v.z * v.w; pm += v.w; }
+                continue;
+            }
             if (A.cm_in) {
                 v.x -= vc[0]; v.y -= vc[1]; v.z -= vc[2];
                 p.x = M<T>::sub(p.x, sh[0]); p.y = M<T>::sub(p.y, sh[1]); p.z = M<T>::sub(p.z, sh[2]);
@@ -113,7 +124,8 @@ template <class T>
 inline void launch_pme_bonded_fused(hipStream_t s, Pme<T>& pme, Bonded<T>& bonded, const GridP<T>& G, const InterP<T>& I, int64_t n_owned, int64_t cap,
                                     const typename Vec<T>::T4* pos, const int32_t* inv, const int32_t* orig, typename Vec<T>::T4* frc, typename Vec<T>::T4* side,
                                     bool spread_done = false,        // spread_done: the charges are on the mesh and the terms in their slots already (forces_gs.hip's fused launch)
-                                    const GcvArgs<T>* vv = nullptr) {      // vv: the last launch integrates (its dt / v_cm / partial / tracking fields filled in by the caller); frc then holds the pair forces and is only read
+                                    const GcvArgs<T>* vv = nullptr,        // vv: the last launch integrates (its dt / v_cm / partial / tracking fields filled in by the caller); frc then holds the pair forces and is only read
+                                    bool lang = false) {                   // … with the Langevin-middle update (vv->S) instead of the velocity-Verlet one
     bonded.ensure_roles(s, cap);
     const BondedArgs<T> B = bonded.slot_args(G, I, pos, inv);
     const int n_term_wg = cdiv(bonded.n_blocks(), 4);
@@ -136,7 +148,12 @@ inline void launch_pme_bonded_fused(hipStream_t s, Pme<T>& pme, Bonded<T>& bonde
         V.n_atoms = n_owned; V.pos = const_cast<typename Vec<T>::T4*>(pos); V.frc = frc; V.phi = (const T*)pme.phi.p; V.P = pme.P;
         V.orig = orig; V.role_start = (const int32_t*)bonded.role_start.p; V.role_slot = (const int32_t*)bonded.role_slot.p; V.slots = (const typename Vec<T>::T4*)bonded.slots;
         V.parts = bonded.fold_parts; V.n_parts = bonded.fold_n; V.part_stride = bonded.fold_stride;
-        if (pme.order == 4) hipLaunchKernelGGL((k_gather_collect_vv<T, 4>), dim3(n_gather), dim3(256), 0, s, V);
+        if (lang) {
+            if (pme.order == 4) hipLaunchKernelGGL((k_gather_collect_vv<T, 4, true>), dim3(n_gather), dim3(256), 0, s, V);
+            else if (pme.order == 5) hipLaunchKernelGGL((k_gather_collect_vv<T, 5, true>), dim3(n_gather), dim3(256), 0, s, V);
+            else hipLaunchKernelGGL((k_gather_collect_vv<T, 6, true>), dim3(n_gather), dim3(256), 0, s, V);
+        }
+        else if (pme.order == 4) hipLaunchKernelGGL((k_gather_collect_vv<T, 4>), dim3(n_gather), dim3(256), 0, s, V);
         else if (pme.order == 5) hipLaunchKernelGGL((k_gather_collect_vv<T, 5>), dim3(n_gather), dim3(256), 0, s, V);
         else hipLaunchKernelGGL((k_gather_collect_vv<T, 6>), dim3(n_gather), dim3(256), 0, s, V);
     }

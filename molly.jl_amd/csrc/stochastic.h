@@ -25,7 +25,8 @@ template <class T> struct StochP {
 // one fused update of all owned atoms; cm_out (nullable) receives 4 doubles per block (Σ m v, Σ m) of the new velocities
 template <class T>
 void launch_langevin(hipStream_t s, int n_blocks, int64_t n, typename Vec<T>::T4* pos, typename Vec<T>::T4* vel, const typename Vec<T>::T4* frc,
-                     const int32_t* orig, const StochP<T>& P, const T* vcm, const double* cm_in, int n_cm_in, double* cm_out, const GridP<T>& G);
+                     const int32_t* orig, const StochP<T>& P, const T* vcm, const double* cm_in, int n_cm_in, double* cm_out, const GridP<T>& G,
+                     const typename Vec<T>::T4* frc_add = nullptr);      // frc_add (nullable): a second force array added on the way (a small system's bonded sums)
 // mode 0: Andersen re-draws (probability prob_u64 / 2⁶⁴ per atom); mode 1: every atom gets a Maxwell-Boltzmann velocity
 template <class T>
 void launch_redraw(hipStream_t s, int mode, int64_t n, typename Vec<T>::T4* vel, const int32_t* orig, const StochP<T>& P,

@@ -77,6 +77,32 @@ def test_langevin_fp32_6mrr_pme_tracks_fp32_oracle(pkg):
     d -= np.round(d / case.box) * case.box
     print("6mrr langevin fp32: max |dx|", np.abs(d).max(), "max |dv|", np.abs(s.velocities - o.vel).max())
     assert np.abs(d).max() < 2e-5 and np.abs(s.velocities - o.vel).max() < 5e-3
+    assert s.stats()["n_fused_steps"] >= 9          # the steps integrated inside their last force launch (k_gather_collect_vv<…, LANG>); the first follows remove_CM_motion!'s v_cm
+
+
+@pytest.mark.parametrize("remove_cm,andersen", [(1, False), (0, False), (1, True)])
+def test_langevin_inside_the_last_force_launch_is_the_same_run(pkg, monkeypatch, remove_cm, andersen):
+    """mhip_langevin_run on the complete PME configuration: every step's last force launch (interpolation + bonded sums) runs the Langevin-middle update too
+    (step_fused.h; the same langevin_atom the stand-alone kernel calls, the same Philox words) instead of k_gather_collect + k_langevin.  40 steps across rebuilds and a
+    chunk boundary against the two-launch form (MOLLYHIP_FUSE_GATHER_VV=0): fp32 round-off apart (the charge mesh is flushed with float atomics)."""
+    from tests import golden6mrr as G
+
+    def run(fuse):
+        monkeypatch.setenv("MOLLYHIP_FUSE_GATHER_VV", fuse)
+        case = G.case("ewald", np.float32, bonded=True, pme=True)
+        s = case.system(pkg, np.float32)
+        sim = pkg.Langevin(dt=0.0005, temperature=300.0, friction=1.0, remove_CM_motion=remove_cm,
+                           coupling=pkg.AndersenThermostat(300.0, 0.05) if andersen else None)
+        pkg.simulate(s, sim, 25, rng=9)
+        pkg.simulate(s, sim, 15, init_step=25, rng=10)
+        return np.array(s.coords, dtype=np.float64), np.array(s.velocities, dtype=np.float64), s.stats()
+    x1, v1, st1 = run("1")
+    x0, v0, st0 = run("0")
+    assert st1["n_fused_steps"] >= 36 and st0["n_fused_steps"] == 0, (st1["n_fused_steps"], st0["n_fused_steps"])
+    box = G.data()["box"]
+    d = x1 - x0; d -= np.round(d / box) * box
+    assert np.abs(d).max() < 4e-6 and np.abs(v1 - v0).max() < 4e-3, (np.abs(d).max(), np.abs(v1 - v0).max())
+
 
 
 def test_langevin_is_reproducible_and_chunks_continue(pkg):
