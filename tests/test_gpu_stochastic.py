@@ -80,6 +80,22 @@ def test_langevin_fp32_6mrr_pme_tracks_fp32_oracle(pkg):
     assert s.stats()["n_fused_steps"] >= 9          # the steps integrated inside their last force launch (k_gather_collect_vv<…, LANG>); the first follows remove_CM_motion!'s v_cm
 
 
+def test_langevin_fp64_6mrr_pme_matches_oracle(pkg):
+    """the same configuration in fp64, where the device's noise IS the oracle's (two Philox blocks per atom, double-precision Box-Muller): 8 steps of the complete step with
+    the update inside the last force launch against the oracle, at the fp64 trajectory bars"""
+    from tests import golden6mrr as G
+    case = G.case("ewald", np.float64, bonded=True, pme=True)
+    key, ctr1 = draws(6, 2)
+    o = case.oracle(np.float64)
+    o.langevin_run(8, 0.0005, KB * 300.0, 1.0, key=key, ctr1=ctr1, remove_cm_every=1, nthreads=8, specific=True, general=True)
+    s = case.system(pkg, np.float64)
+    pkg.simulate(s, pkg.Langevin(dt=0.0005, temperature=300.0, friction=1.0), 8, rng=6)
+    d = s.coords - o.coords
+    d -= np.round(d / case.box) * case.box
+    assert np.abs(d).max() < 1e-9 and np.abs(s.velocities - o.vel).max() < 1e-6
+    assert s.stats()["n_fused_steps"] >= 7
+
+
 @pytest.mark.parametrize("remove_cm,andersen", [(1, False), (0, False), (1, True)])
 def test_langevin_inside_the_last_force_launch_is_the_same_run(pkg, monkeypatch, remove_cm, andersen):
     """mhip_langevin_run on the complete PME configuration: every step's last force launch (interpolation + bonded sums) runs the Langevin-middle update too
