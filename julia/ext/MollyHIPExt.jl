@@ -9,6 +9,7 @@
 module MollyHIPExt
 
 using Molly, AMDGPU, StaticArrays, Unitful, Random
+using GPUArrays: AbstractGPUArray                                                    # (a dependency of Molly itself, src/Molly.jl:21: the generic methods' array type, for `invoke`)
 import Molly: pairwise_forces_loop_gpu!, pairwise_pe_loop_gpu!, remove_CM_motion!, uses_gpu_neighbor_finder, simulate!,
               random_velocities!, from_device, masses, ustrip_vec
 
@@ -62,14 +63,15 @@ end
 # The reference reads sys.atoms, sys.boundary, sys.pairwise_inters and the neighbour finder's exception caches at EVERY call (ext/MollyCUDAExt.jl:845-873); the
 # engine keeps them in its context, so every look-up checks that what it keeps is still what the System holds: a replaced boundary goes through mhip_set_box, a
 # replaced atoms array through mhip_set_atoms, new exception pairs through mhip_set_exceptions, a replaced interaction tuple makes a new context.
-function context!(sys::System{3, <:ROCArray, T}) where T
+function context!(sys::System{3, <:ROCArray, T}, inters::Tuple=sys.pairwise_inters; no_list::Bool=false) where T
+    table = no_list ? CONTEXTS_NOLIST : CONTEXTS
     c = lock(CONTEXTS_LOCK) do
-        get(CONTEXTS, sys, nothing)
+        get(table, sys, nothing)
     end
     nf = sys.neighbor_finder
-    nf isa GPUNeighborFinder || error("MollyHIPExt expects the GPUNeighborFinder that setup picks for ROCArray systems (setup.jl:1938-1949)")
-    if c !== nothing && c.inters !== sys.pairwise_inters
-        release!(sys); c = nothing
+    no_list || nf isa GPUNeighborFinder || error("MollyHIPExt expects the GPUNeighborFinder that setup picks for ROCArray systems (setup.jl:1938-1949)")
+    if c !== nothing && c.inters !== inters
+        release!(sys; table=table); c = nothing
     end
     if c === nothing
         b = sys.boundary
@@ -78,12 +80,12 @@ function context!(sys::System{3, <:ROCArray, T}) where T
                        Tuple(Float64.(ustrip.(b.side_lengths)))                      # spatial.jl:40, 151-161
         cfg = MhipConfig(T == Float32 ? Int32(32) : Int32(64), Int32(AMDGPU.device_id(AMDGPU.device()) - 1), length(sys),
                          Float64.(sides), (0.0, 0.0, 0.0), (Int32(1), Int32(1), Int32(1)),
-                         Int32(nf.n_steps_reorder), Float64(ustrip(nf.dist_cutoff)), interactions(sys.pairwise_inters))
+                         no_list ? Int32(10) : Int32(nf.n_steps_reorder), no_list ? Inf : Float64(ustrip(nf.dist_cutoff)), interactions(inters))   # r_list = +Inf: every pair interacts (include/mollyhip.h)
         out = Ref{Ptr{Cvoid}}(C_NULL)
         rc = ccall((:mhip_create, libmollyhip), Int32, (Ref{Ptr{Cvoid}}, Ref{MhipConfig}), out, cfg)
         rc == 0 || error("libmollyhip: ", last_error(C_NULL))
         c = HipContext(out[], b)
-        c.inters = sys.pairwise_inters
+        c.inters = inters
         check(c, ccall((:mhip_set_stream, libmollyhip), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), c.ptr, AMDGPU.stream().stream))   # kernels join the task's HIP stream
         if tric
             bv = Float64[ustrip(b.basis_vectors[r][k]) for r in 1:3 for k in 1:3]
@@ -91,12 +93,12 @@ function context!(sys::System{3, <:ROCArray, T}) where T
             check(c, ccall((:mhip_set_triclinic, libmollyhip), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int32), c.ptr, bv, approx ? 1 : 0))
         end
         lock(CONTEXTS_LOCK) do
-            CONTEXTS[sys] = c
+            table[sys] = c
         end
     end
     c.atoms === sys.atoms || push_atoms!(c, sys)                                     # first use, or `sys.atoms = …` since (mhip_set_atoms drops what depended on them)
     follow_boundary!(c, sys.boundary)                                                # a barostat replaced sys.boundary (coupling.jl:861-1033): mhip_set_box
-    push_exceptions!(c, nf)                                                          # also after append_excluded_pairs! (neighbors.jl:313)
+    no_list || push_exceptions!(c, nf)                                               # also after append_excluded_pairs! (neighbors.jl:313); NoNeighborList carries no exceptions (kernels.jl:98-100)
     return c
 end
 
@@ -105,7 +107,20 @@ end
 # the pair virial into buffers.virial_nounits (3×3 device matrix) when needs_vir (force.jl:1228, 1241).
 function pairwise_forces_loop_gpu!(buffers, sys::System{3, <:ROCArray, T}, pairwise_inters::Tuple, nbs::Nothing,
                                    ::Val{needs_vir}, step_n) where {T, needs_vir}
-    c = context!(sys)
+    return engine_forces!(buffers, sys, context!(sys, pairwise_inters), Val(needs_vir), step_n)       # (the tuple handed in: forces! passes the use_neighbors = true subset, force.jl:1226-1229)
+end
+
+# ≙ ext/MollyCUDAExt.jl:757 (generic kernels.jl:91-100): the use_neighbors = false interactions over EVERY pair, as forces! hands them over with a NoNeighborList
+# (force.jl:1219-1224).  The engine walks all pairs of one tile for up to 32 000 atoms (r_list = +Inf); beyond that the generic KernelAbstractions method keeps the call.
+const NOLIST_MAX_ATOMS = 32_000
+function pairwise_forces_loop_gpu!(buffers, sys::System{3, <:ROCArray, T}, pairwise_inters::Tuple, nbs::Molly.NoNeighborList,
+                                   ::Val{needs_vir}, step_n) where {T, needs_vir}
+    length(sys) <= NOLIST_MAX_ATOMS ||
+        return invoke(pairwise_forces_loop_gpu!, Tuple{Any, System{3, <:AbstractGPUArray}, Any, Any, Val{needs_vir}, Any}, buffers, sys, pairwise_inters, nbs, Val(needs_vir), step_n)
+    return engine_forces!(buffers, sys, context!(sys, pairwise_inters; no_list=true), Val(needs_vir), step_n)
+end
+
+function engine_forces!(buffers, sys::System{3, <:ROCArray, T}, c::HipContext, ::Val{needs_vir}, step_n) where {T, needs_vir}
     # coordinates may have changed since the last call (ext:778 "needs_reorder = true"); the engine keeps its lists if it can
     check(c, ccall((:mhip_set_state, libmollyhip), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32), c.ptr, devptr(sys.coords), C_NULL, 1))
     vir = zeros(Float64, 9)                                                          # row-major 3×3, host; mhip_forces ADDS Σ dr ⊗ f
@@ -120,7 +135,16 @@ end
 
 # ≙ ext/MollyCUDAExt.jl:936 — accumulates into the 1-element device vector (zeroed by the caller, energy.jl:417)
 function pairwise_pe_loop_gpu!(pe_vec_nounits, buffers, sys::System{3, <:ROCArray, T}, pairwise_inters::Tuple, nbs::Nothing, step_n) where T
-    c = context!(sys)
+    return engine_energy!(pe_vec_nounits, sys, context!(sys, pairwise_inters), step_n)
+end
+# (energy.jl:419-423: the use_neighbors = false interactions with a NoNeighborList)
+function pairwise_pe_loop_gpu!(pe_vec_nounits, buffers, sys::System{3, <:ROCArray, T}, pairwise_inters::Tuple, nbs::Molly.NoNeighborList, step_n) where T
+    length(sys) <= NOLIST_MAX_ATOMS ||
+        return invoke(pairwise_pe_loop_gpu!, Tuple{Any, Any, System{3, <:AbstractGPUArray}, Any, Any, Any}, pe_vec_nounits, buffers, sys, pairwise_inters, nbs, step_n)
+    return engine_energy!(pe_vec_nounits, sys, context!(sys, pairwise_inters; no_list=true), step_n)
+end
+
+function engine_energy!(pe_vec_nounits, sys::System{3, <:ROCArray, T}, c::HipContext, step_n) where T
     check(c, ccall((:mhip_set_state, libmollyhip), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32), c.ptr, devptr(sys.coords), C_NULL, 1))
     pe = Ref{Float64}(0.0)
     check(c, ccall((:mhip_potential_energy, libmollyhip), Int32, (Ptr{Cvoid}, Int64, Ref{Float64}), c.ptr, Int64(step_n), pe))

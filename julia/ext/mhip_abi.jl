@@ -32,7 +32,8 @@ mutable struct HipContext
         return c
     end
 end
-const CONTEXTS = IdDict{Any, HipContext}()      # System object → its engine context
+const CONTEXTS = IdDict{Any, HipContext}()      # System object → its engine context (the interactions that walk the neighbour list)
+const CONTEXTS_NOLIST = IdDict{Any, HipContext}()   # System object → the context of its use_neighbors = false interactions (NoNeighborList, force.jl:1219-1224): every pair, no exceptions
 const CONTEXTS_LOCK = ReentrantLock()
 
 last_error(ptr) = unsafe_string(ccall((:mhip_last_error, libmollyhip), Cstring, (Ptr{Cvoid},), ptr))
@@ -58,10 +59,12 @@ function follow_boundary!(c::HipContext, b)
     return c
 end
 
-function release!(sys)
+function release!(sys; table=nothing)
     lock(CONTEXTS_LOCK) do
-        c = pop!(CONTEXTS, sys, nothing)
-        c === nothing || finalize(c)
+        for t in (table === nothing ? (CONTEXTS, CONTEXTS_NOLIST) : (table,))
+            c = pop!(t, sys, nothing)
+            c === nothing || finalize(c)
+        end
     end
     return nothing
 end

@@ -90,9 +90,11 @@ end
             gpu, cpu = lj_pair(diagonal(10), lj_atoms(10, 0.3), CubicBoundary(T64(10)), 5.0; excluded=[(1, 2), (2, 3)], special=[(1, 3)])
             same_forces_and_energy(gpu, cpu; with_list=false)
         end
-        @testset "no neighbour list" begin
+        @testset "no neighbour list" begin                                               # use_neighbors = false → NoNeighborList (force.jl:1219-1224): the engine's all-pairs context
             gpu, cpu = lj_pair(diagonal(20), lj_atoms(20, 0.3), CubicBoundary(T64(10)), 5.0; use_list=false)
             same_forces_and_energy(gpu, cpu; with_list=false)
+            ext = Base.get_extension(Molly, :MollyHIPExt)
+            @test haskey(ext.CONTEXTS_NOLIST, gpu) && !haskey(ext.CONTEXTS, gpu)         # it was the engine that answered, not the generic KernelAbstractions method
         end
         @testset "remove_CM_motion! on the device" begin                                # ≙ ext/MollyCUDAExt.jl:2373 against spatial.jl:920
             gpu, cpu = lj_pair(diagonal(33), lj_atoms(33, 0.3), CubicBoundary(T64(20)), 5.0)
