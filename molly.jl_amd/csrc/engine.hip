@@ -770,7 +770,8 @@ template <class T> class Engine final : public EngineBase {
     bool trk_issued = false; int64_t trk_step = -1, trk_prune_id = -1, trk_outer_id = -1; double trk_prev_vmax = 0;   // (ids: the running counts of prunes / outer searches)
     bool in_vv_fused = false;
     bool in_lang_fused = false;      // inside mhip_langevin_run of a small system whose last force launch integrates (the pair launch's extra workgroup then sums the Σ m v partials, as inside mhip_vv_run)
-    bool async_ok() const { return in_vv_fused && dual && n_ghost == 0 && !host_prune && inner_valid && !stale; }
+    bool in_lang_async = false;      // … and whose list checks are measured by that launch (no Andersen coupling behind it: the speeds the check reads would not be the run's)
+    bool async_ok() const { return (in_vv_fused || in_lang_async) && dual && n_ghost == 0 && !host_prune && inner_valid && !stale; }
     void resolve_track(int64_t step) {
         if (!trk_issued) return;
         MHIP_HIP(hipEventSynchronize(ev_trk));
@@ -2662,6 +2663,7 @@ template <class T> class Engine final : public EngineBase {
         cur_dt = dt;
         InRun guard_in_run(in_run);
         InRun guard_lang(in_lang_fused); in_lang_fused = bonded.any() && pme.on() && fuse_gcv_env;
+        InRun guard_lang_async(in_lang_async); in_lang_async = in_lang_fused && !(andersen_prob > 0);
         if (first_step == 0 && remove_cm_every != 0) remove_cm();                 // :1115
         start_lists(first_step);                                                  // :1116
         const double vs = std::exp(-dt * friction);                               // :1091-1092
@@ -2670,17 +2672,27 @@ template <class T> class Engine final : public EngineBase {
         const int nb = std::min(cdiv(n_owned, 256), 1024);
         int half = 0;
         for (int64_t step = first_step + 1; step <= first_step + n_steps; ++step) {
-            resolve_track(step);
+            // a check measured by the update launch of step s (the coordinates x_s it made) is read at the top of step s + 2, behind a whole step of queued work — the
+            // scheme of mhip_vv_run, whose loop is one force pass ahead of this one (there the launch of step s makes x_(s+1)); a check left by a run before: at once
+            if (trk_issued && (!in_lang_async || step > trk_step + 1)) resolve_track(step);
             const bool cm = remove_cm_every != 0 && step % remove_cm_every == 0;
             P.ctr1 = ctr1_0 + (uint64_t)(step - first_step - 1);
             // a small system's step (bonded terms + PME): its last force launch — interpolation + bonded sums — runs the update as well (step_fused.h, k_gather_collect_vv<…, LANG>),
             // every step of the run: a Langevin step is complete in itself, there is no closing half kick to keep a launch for
-            step_req.gcv = bonded.any() && pme.on(); step_req.lang = &P; step_req.cm = cm; step_req.measure = false; step_req.dt = dt;
+            const bool measure = in_lang_async && async_ok() && !trk_issued && check_due(step, every);      // the check refresh(step) below would make with a drained stream
+            step_req.gcv = bonded.any() && pme.on(); step_req.lang = &P; step_req.cm = cm; step_req.measure = measure; step_req.dt = dt;
             step_done = false;
             step_forces(step);                                                    // :1173
-            step_req.gcv = false; step_req.lang = nullptr;
+            step_req.gcv = false; step_req.lang = nullptr; step_req.measure = false;
             if (step_done) {
                 step_done = false;
+                if (measure) {
+                    if (!h_trk) MHIP_HIP(hipHostMalloc((void**)&h_trk, 4 * sizeof(float)));
+                    if (!ev_trk) MHIP_HIP(hipEventCreateWithFlags(&ev_trk, hipEventDisableTiming));
+                    hipLaunchKernelGGL(k_track_reduce, dim3(1), dim3(256), 0, stream, step_parts, (const float*)trk_part.p, trk_out.p, h_trk);
+                    MHIP_HIP(hipEventRecord(ev_trk, stream));
+                    trk_issued = true; trk_step = step; trk_prev_vmax = last_vmax; trk_prune_id = n_filters; trk_outer_id = n_outer;
+                }
                 pend_a = nullptr; cm_pending = 0; cm_ext = nullptr; frc_valid = false;
                 if (cm) { cm_pending = 2; cm_ext = cm_blk.p + (size_t)step_half * 4 * step_parts; n_cm_step = step_parts; step_half ^= 1; }
                 apply_coupling(step);

@@ -86,20 +86,19 @@ __global__ void __launch_bounds__(256) k_gather_collect_vv(GcvArgs<T> A) {
             if constexpr (LANG) {
                 if (A.cm_in) { v.x -= vc[0]; v.y -= vc[1]; v.z -= vc[2]; }
                 langevin_atom<T>(v, p, f, A.S, (uint64_t)A.orig[s] + 1, A.G);
-                A.pos[s] = p; A.vel[s] = v;
                 if (A.cm_out) { px += (double)v.x * v.w; py += (double)v.y * v.w; pz += (double)v.z * v.w; pm += v.w; }
-                continue;
+            } else {
+                if (A.cm_in) {
+                    v.x -= vc[0]; v.y -= vc[1]; v.z -= vc[2];
+                    p.x = M<T>::sub(p.x, sh[0]); p.y = M<T>::sub(p.y, sh[1]); p.z = M<T>::sub(p.z, sh[2]);
+                }
+                const T kx = M<T>::mul(accel_of(f.x, v.w), A.dt2), ky = M<T>::mul(accel_of(f.y, v.w), A.dt2), kz = M<T>::mul(accel_of(f.z, v.w), A.dt2);
+                v.x = M<T>::add(v.x, kx); v.y = M<T>::add(v.y, ky); v.z = M<T>::add(v.z, kz);
+                if (A.cm_out) { px += (double)v.x * v.w; py += (double)v.y * v.w; pz += (double)v.z * v.w; pm += v.w; }
+                v.x = M<T>::add(v.x, kx); v.y = M<T>::add(v.y, ky); v.z = M<T>::add(v.z, kz);
+                p.x = step_add(p.x, v.x, A.dt); p.y = step_add(p.y, v.y, A.dt); p.z = step_add(p.z, v.z, A.dt);
+                wrap_point(p.x, p.y, p.z, A.G);
             }
-            if (A.cm_in) {
-                v.x -= vc[0]; v.y -= vc[1]; v.z -= vc[2];
-                p.x = M<T>::sub(p.x, sh[0]); p.y = M<T>::sub(p.y, sh[1]); p.z = M<T>::sub(p.z, sh[2]);
-            }
-            const T kx = M<T>::mul(accel_of(f.x, v.w), A.dt2), ky = M<T>::mul(accel_of(f.y, v.w), A.dt2), kz = M<T>::mul(accel_of(f.z, v.w), A.dt2);
-            v.x = M<T>::add(v.x, kx); v.y = M<T>::add(v.y, ky); v.z = M<T>::add(v.z, kz);
-            if (A.cm_out) { px += (double)v.x * v.w; py += (double)v.y * v.w; pz += (double)v.z * v.w; pm += v.w; }
-            v.x = M<T>::add(v.x, kx); v.y = M<T>::add(v.y, ky); v.z = M<T>::add(v.z, kz);
-            p.x = step_add(p.x, v.x, A.dt); p.y = step_add(p.y, v.y, A.dt); p.z = step_add(p.z, v.z, A.dt);
-            wrap_point(p.x, p.y, p.z, A.G);
             A.pos[s] = p; A.vel[s] = v;
             if (A.trk_part) {
                 v2m = fmaxf(v2m, (float)(v.x * v.x + v.y * v.y + v.z * v.z));

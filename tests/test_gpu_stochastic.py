@@ -121,6 +121,29 @@ def test_langevin_inside_the_last_force_launch_is_the_same_run(pkg, monkeypatch,
 
 
 
+def test_langevin_list_checks_measured_by_the_update_launch(pkg, monkeypatch):
+    """inside mhip_langevin_run of the complete PME configuration the validity checks of the pair lists are measured by the launch that makes the coordinates and read two
+    steps later (no drained stream), as inside mhip_vv_run; the two-launch form (MOLLYHIP_FUSE_GATHER_VV=0) keeps the drained check at the check step itself.  fp64, 90 steps in
+    two chunks across nine cadence steps at 350 K: a pair missing from a list for a single pass would show as a force jump — the runs agree to round-off"""
+    from tests import golden6mrr as G
+
+    def run(fuse):
+        monkeypatch.setenv("MOLLYHIP_FUSE_GATHER_VV", fuse)
+        case = G.case("ewald", np.float64, bonded=True, pme=True)
+        s = case.system(pkg, np.float64)
+        sim = pkg.Langevin(dt=0.001, temperature=350.0, friction=2.0, remove_CM_motion=1)
+        pkg.simulate(s, sim, 55, rng=12)
+        pkg.simulate(s, sim, 35, init_step=55, rng=13)
+        return np.array(s.coords), np.array(s.velocities), s.stats()
+    x1, v1, st1 = run("1")
+    x0, v0, st0 = run("0")
+    assert st1["n_fused_steps"] >= 85 and st0["n_fused_steps"] == 0
+    assert st1["n_filter_passes"] >= 2 and st0["n_filter_passes"] >= 2, (st1["n_filter_passes"], st0["n_filter_passes"])
+    box = G.data()["box"]
+    d = x1 - x0; d -= np.round(d / box) * box
+    assert np.abs(d).max() < 1e-8 and np.abs(v1 - v0).max() < 1e-6, (np.abs(d).max(), np.abs(v1 - v0).max())
+
+
 def test_langevin_is_reproducible_and_chunks_continue(pkg):
     """counter-based noise: two runs with the same rng are bit-identical in fp64 coordinates up to summation order (none here: no
     atomics on the pair path), and different seeds decorrelate"""
