@@ -933,6 +933,7 @@ template <class T> class Engine final : public EngineBase {
         ForceArgs<T> A;
         A.G = G; A.I = I; A.n_owned = n_owned; A.BI = BI; A.BI_shift = ilog2(BI); A.JS = JS; A.T_cap = T_cap; A.T_lds = tile_lds; A.R_cap = R_cap;
         A.n_blocks = n_blocks; A.blocks_per_xcd = cdiv(n_blocks, 8);
+        A.orig = nullptr; A.S = StochP<T>{};      // (LANG variants only)
         A.pos = pos[cur].p; A.lj = lj[cur].p; A.tile_idx = tile_idx.p; A.tile_cnt = tile_cnt.p;
         // dual pair list: a force pass whose inner list is stale walks the OUTER list (always a valid superset — the cutoff is
         // applied per pair) and, if it is a plain force call, prunes it into the inner list on the way
@@ -1054,6 +1055,7 @@ template <class T> class Engine final : public EngineBase {
                 if (step_req.measure) { trk_part.reserve(3 * (size_t)std::max(n_blocks, 1024)); trk_out.reserve(4); A.trk_part = trk_part.p; }
                 A.cm_fin_in = nullptr; A.cm_fin_n = 0; A.cm_fin_out = nullptr;      // (the head workgroup of the launch sums the partials instead)
                 if (halo_req.on) hx_fill(A);
+                if (step_req.lang) { if (halo_req.on) throw ApiError{MHIP_ERR_STATE, "internal: Langevin update asked of a ghosted step"}; A.orig = orig[cur].p; A.S = *step_req.lang; }
             }
         }
         prof.begin(prune ? 4 : 0, stream);   // stage 4 = force passes that also prune the outer list
@@ -1067,7 +1069,7 @@ template <class T> class Engine final : public EngineBase {
                     XferWait W{}; W.mine = reinterpret_cast<const XferHeader*>(xf.region); W.parity = (int)(xf.seq & 1u); W.seq = xf.seq; W.peers = xf.d_peers.p; W.n_peers = xf.n_peers; W.err = xf.err.p; W.ticks = xf_ticks();
                     hipLaunchKernelGGL(k_xfer_wait_all, dim3(1), dim3(64), 0, stream, W);
                 }
-                launch_forces_uniform_f32(A, false, false, lds_force, (unsigned)(BI * JS), stream, true, halo_req.on);
+                launch_forces_uniform_f32(A, false, false, lds_force, (unsigned)(BI * JS), stream, true, halo_req.on, step_req.lang != nullptr);
                 if (halo_req.on) ++xf.seq;      // (the launch's last wave announces exchange xf.seq at the peers)
                 std::swap(pos[cur].p, pos_alt.p); std::swap(pos[cur].n, pos_alt.n);      // the epilogues wrote the drifted coordinates into the other buffer: it is the current one now
                 step_done = true; ++n_fused_steps; step_parts = n_blocks;
@@ -2663,7 +2665,7 @@ template <class T> class Engine final : public EngineBase {
         cur_dt = dt;
         InRun guard_in_run(in_run);
         InRun guard_lang(in_lang_fused); in_lang_fused = bonded.any() && pme.on() && fuse_gcv_env;
-        InRun guard_lang_async(in_lang_async); in_lang_async = in_lang_fused && !(andersen_prob > 0);
+        InRun guard_lang_async(in_lang_async); in_lang_async = (in_lang_fused || (!bonded.any() && !pme.on() && fuse_step_env)) && !(andersen_prob > 0);
         if (first_step == 0 && remove_cm_every != 0) remove_cm();                 // :1115
         start_lists(first_step);                                                  // :1116
         const double vs = std::exp(-dt * friction);                               // :1091-1092
@@ -2680,10 +2682,10 @@ template <class T> class Engine final : public EngineBase {
             // a small system's step (bonded terms + PME): its last force launch — interpolation + bonded sums — runs the update as well (step_fused.h, k_gather_collect_vv<…, LANG>),
             // every step of the run: a Langevin step is complete in itself, there is no closing half kick to keep a launch for
             const bool measure = in_lang_async && async_ok() && !trk_issued && check_due(step, every);      // the check refresh(step) below would make with a drained stream
-            step_req.gcv = bonded.any() && pme.on(); step_req.lang = &P; step_req.cm = cm; step_req.measure = measure; step_req.dt = dt;
+            step_req.gcv = bonded.any() && pme.on(); step_req.on = !bonded.any() && !pme.on(); step_req.lang = &P; step_req.cm = cm; step_req.measure = measure; step_req.dt = dt;      // (on: the packed fp32 one-type pass runs the update in its epilogue, k_forces<…, STEP, ·, LANG>)
             step_done = false;
             step_forces(step);                                                    // :1173
-            step_req.gcv = false; step_req.lang = nullptr; step_req.measure = false;
+            step_req.gcv = step_req.on = false; step_req.lang = nullptr; step_req.measure = false;
             if (step_done) {
                 step_done = false;
                 if (measure) {

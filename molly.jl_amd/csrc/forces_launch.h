@@ -9,7 +9,7 @@ template <class T, int COULM>
 void launch_forces_tc(const ForceArgs<T>& A, int ljm, bool energy, bool minimg, bool seg, bool prune, size_t lds, unsigned threads, hipStream_t stream);
 
 // the fp32 one-type LJ variants (forces only, block-local coordinates)
-void launch_forces_uniform_f32(const ForceArgs<float>& A, bool seg, bool prune, size_t lds, unsigned threads, hipStream_t stream, bool step = false, bool halo = false);
+void launch_forces_uniform_f32(const ForceArgs<float>& A, bool seg, bool prune, size_t lds, unsigned threads, hipStream_t stream, bool step = false, bool halo = false, bool lang = false);
 
 // ---- the group-split pair pass of small systems (forces_gs.hip) ----
 struct RegroupArgs {

@@ -14,6 +14,7 @@
 #include <type_traits>
 #include "physics.h"
 #include "halo_xfer.h"
+#include "philox.h"
 
 namespace mhip {
 
@@ -1292,6 +1293,9 @@ template <class T> struct ForceArgs {
     const double* cm_in; int cm_n; unsigned long long* cm_pub; uint32_t step_seq; double* cm_out;
     float* trk_part; const typename Vec<T>::T4* snap_a; const typename Vec<T>::T4* snap_b;
     HaloStep H;                      // HALO variants only
+    // LANG variants (STEP with the Langevin-middle update of philox.h instead of the velocity-Verlet one: mhip_langevin_run on the fp32 one-type fluids): the noise
+    // parameters of this step and the atoms' ORIGINAL indices (the Philox counter does not follow the Hilbert order)
+    const int32_t* orig; StochP<T> S;
 };
 // STEP launches: the first workgroup of the grid does nothing but this — Σ m v of the launch before (n_part partials, the fixed order of cm_finalize_in_block)
 // → v_cm = P / M rounded to T as block_vcm does → three words {value bits, launch number} that every other workgroup's epilogue polls (relaxed agent-scope
@@ -1343,10 +1347,11 @@ __host__ __device__ inline size_t prune_lds_bytes(int t_seg, int nthr) { return 
 template <class T, int LJM, int COULM, bool ENERGY, bool MINIMG, bool SEG, bool PRUNE>
 constexpr int force_min_waves() { return (std::is_same<T, float>::value && LJM == LJ_DIST_UNIFORM && COULM == MHIP_COUL_NONE && !ENERGY && !MINIMG && !SEG && !PRUNE) ? MHIP_FAST_MIN_WAVES : 1; }
 
-template <class T, int LJM, int COULM, bool ENERGY, bool MINIMG, bool SEG, bool PRUNE, int SOA_STRIDE = 4097, bool STEP = false, bool HALO = false>
+template <class T, int LJM, int COULM, bool ENERGY, bool MINIMG, bool SEG, bool PRUNE, int SOA_STRIDE = 4097, bool STEP = false, bool HALO = false, bool LANG = false>
 __global__ void __launch_bounds__(BlockLimits<T>::max_threads, (force_min_waves<T, LJM, COULM, ENERGY, MINIMG, SEG, PRUNE>()))
 k_forces(ForceArgs<T> A) {
     static_assert(!HALO || (STEP && std::is_same<T, float>::value), "the ghosted form exists for the fused fp32 step only");
+    static_assert(!LANG || (STEP && !HALO), "the Langevin update rides in the fused single-domain step only");
     using T4 = typename Vec<T>::T4;
     using T2 = typename Vec<T>::T2;
     constexpr bool PER_ATOM_LJ = (LJM == LJ_DIST || LJM == LJ_GENERIC);
@@ -1941,14 +1946,20 @@ k_forces(ForceArgs<T> A) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) vc[c] = (T)__uint_as_float((uint32_t)st_w[c]);
                 v.x -= vc[0]; v.y -= vc[1]; v.z -= vc[2];
-                p.x = M<T>::sub(p.x, M<T>::mul(vc[0], A.dt)); p.y = M<T>::sub(p.y, M<T>::mul(vc[1], A.dt)); p.z = M<T>::sub(p.z, M<T>::mul(vc[2], A.dt));
+                if constexpr (!LANG) { p.x = M<T>::sub(p.x, M<T>::mul(vc[0], A.dt)); p.y = M<T>::sub(p.y, M<T>::mul(vc[1], A.dt)); p.z = M<T>::sub(p.z, M<T>::mul(vc[2], A.dt)); }      // (Langevin: the removal sits behind the step's drifts, simulators.jl:1203 — the velocity alone)
             }
+            if constexpr (LANG) {      // the Langevin-middle update (simulators.jl:1171-1201) — the function k_langevin calls — with the force still in registers
+                const T4 f4 = make4<T>(fx, fy, fz, T(0));
+                langevin_atom<T>(v, p, f4, A.S, (uint64_t)A.orig[se] + 1, G);
+                if (A.cm_out) { px = (double)v.x * v.w; py = (double)v.y * v.w; pz = (double)v.z * v.w; pm = v.w; }
+            } else {
             const T kx = M<T>::mul(accel_of(fx, v.w), A.dt2), ky = M<T>::mul(accel_of(fy, v.w), A.dt2), kz = M<T>::mul(accel_of(fz, v.w), A.dt2);
             v.x = M<T>::add(v.x, kx); v.y = M<T>::add(v.y, ky); v.z = M<T>::add(v.z, kz);   // :616, v_n before this step's CM removal
             if (A.cm_out) { px = (double)v.x * v.w; py = (double)v.y * v.w; pz = (double)v.z * v.w; pm = v.w; }
             v.x = M<T>::add(v.x, kx); v.y = M<T>::add(v.y, ky); v.z = M<T>::add(v.z, kz);   // :594 of the next step
             p.x = step_add(p.x, v.x, A.dt); p.y = step_add(p.y, v.y, A.dt); p.z = step_add(p.z, v.z, A.dt);   // :602
             wrap_point(p.x, p.y, p.z, G);                                      // :609
+            }
             if (A.trk_part) {
                 tr_v = (float)(v.x * v.x + v.y * v.y + v.z * v.z);
                 auto q = A.snap_a[se];

@@ -144,6 +144,35 @@ def test_langevin_list_checks_measured_by_the_update_launch(pkg, monkeypatch):
     assert np.abs(d).max() < 1e-8 and np.abs(v1 - v0).max() < 1e-6, (np.abs(d).max(), np.abs(v1 - v0).max())
 
 
+@pytest.mark.parametrize("remove_cm", [1, 0])
+def test_langevin_in_the_pair_pass_epilogue_of_the_lj_fluid(pkg, monkeypatch, remove_cm):
+    """mhip_langevin_run on the fp32 one-type fluids: the plain pair passes run the Langevin-middle update in their own epilogue (k_forces<…, STEP, ·, LANG>: the force
+    still in registers, langevin_atom of philox.h — the function the stand-alone kernel calls —, v_cm of the step before published by the head workgroup, list checks
+    measured on the way) — no force array, no k_langevin launch.  64 000 atoms, 80 steps in two chunks across searches, prunes and checks, against the two-launch form
+    (MOLLYHIP_FUSE_STEP=0: its checks and therefore its prunes fall on other steps, so fp32 round-off apart rather than bit for bit) and, over the first 20 steps,
+    against the fp32 oracle with the same Philox words."""
+    case = S.lj_fluid(40, seed=2, dtype=np.float32)
+    sim = pkg.Langevin(dt=0.002, temperature=85.0, friction=1.0, remove_CM_motion=remove_cm)
+    out = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("MOLLYHIP_FUSE_STEP", fuse)      # (read when the engine is created)
+        s = case.system(pkg, np.float32)
+        pkg.simulate(s, sim, 20, rng=31)
+        first = (s.coords.copy(), s.velocities.copy())
+        pkg.simulate(s, sim, 60, init_step=20, rng=32)
+        st = s.stats()
+        assert (st["n_fused_steps"] > 60) == (fuse == "1"), st["n_fused_steps"]
+        out.append((s.coords.astype(np.float64), s.velocities.astype(np.float64), first))
+        s.close()
+    d = out[0][0] - out[1][0]; d -= np.round(d / case.box) * case.box
+    assert np.abs(d).max() < 2e-5 and np.abs(out[0][1] - out[1][1]).max() < 5e-3, (np.abs(d).max(), np.abs(out[0][1] - out[1][1]).max())
+    key, ctr1 = draws(31, 2)
+    o = case.oracle(np.float32)
+    o.langevin_run(20, 0.002, KB * 85.0, 1.0, key=key, ctr1=ctr1, remove_cm_every=remove_cm, nthreads=8)
+    d = out[0][2][0].astype(np.float64) - o.coords; d -= np.round(d / case.box) * case.box
+    assert np.abs(d).max() < 2e-5 and np.abs(out[0][2][1] - o.vel).max() < 5e-3, (np.abs(d).max(), np.abs(out[0][2][1] - o.vel).max())
+
+
 def test_langevin_is_reproducible_and_chunks_continue(pkg):
     """counter-based noise: two runs with the same rng are bit-identical in fp64 coordinates up to summation order (none here: no
     atomics on the pair path), and different seeds decorrelate"""

@@ -51,7 +51,8 @@ def test_uniform_lj_kernels_fit_64_vgprs_without_scratch(tmp_path):
     plain = {n: v for n, v in ks.items() if "k_forces<float, 3, 0, false, false, false, false" in n}   # not SEG, not PRUNE: the passes of every step
     # the three tile strides, each as the plain pass, as the STEP variant (round 5: the integrator in the epilogue) and as the STEP + HALO variant (round 6: the
     # fused step of a ghosted sub-domain — waits for the peers' rows in its prologue, stores to the peers in its epilogue) — none of which may cost the loop a register
-    assert len(plain) == 9 and sum(1 for n in plain if ", true, false>(" in n) == 3 and sum(1 for n in plain if ", true, true>(" in n) == 3
+    # … and (round 6, third session) as the STEP + LANG variant: the Langevin-middle update in the epilogue (Philox block, Box-Muller pair) instead of the velocity-Verlet one
+    assert len(plain) == 12 and all(sum(1 for n in plain if t in n) == 3 for t in (", false, false, false>(", ", true, false, false>(", ", true, true, false>(", ", true, false, true>("))
     for n, (r, body) in plain.items():
         assert r["next_free_vgpr"] <= 64, (n, r)
         assert not any(re.match(r"\s+scratch_", l) for l in body), n      # no spill instruction anywhere in the kernel
@@ -76,10 +77,11 @@ def test_packed_loop_issue_count(tmp_path):
     ks = _kernels(_compile(tmp_path))
     counts = {}
     base = "k_forces<float, 3, 0, false, false, false, false, 3073, "
-    for variant in (base + "false, false>", base + "true, false>", base + "true, true>"):      # plain, STEP, STEP + HALO
-        counts[variant] = _loop_counts(ks, variant)
-    a, b2, c = (counts[base + t] for t in ("false, false>", "true, false>", "true, true>"))
-    assert a[:2] == b2[:2] == c[:2]      # the same loop in all three (each held to the wait pattern by _loop_counts; the exact stages may differ by one)
+    tags = ("false, false, false>", "true, false, false>", "true, true, false>", "true, false, true>")      # plain, STEP, STEP + HALO, STEP + LANG
+    for t in tags:
+        counts[base + t] = _loop_counts(ks, base + t)
+    a, b2, c, d = (counts[base + t] for t in tags)
+    assert a[:2] == b2[:2] == c[:2] == d[:2]      # the same loop in all four (each held to the wait pattern by _loop_counts; the exact stages may differ by one)
 
 
 def _loop_counts(ks, variant):
