@@ -202,19 +202,33 @@ function push_specific!(c::HipContext, sys::System{3, <:ROCArray, T}) where T
     c.bonded_sent = true
 end
 
-logger_chunk(sys, n_steps) = isempty(sys.loggers) ? n_steps : max(1, gcd(n_steps, (l.n_steps for l in values(sys.loggers) if hasproperty(l, :n_steps))...))
+# The run is cut where something on the host side is due: a logger (its n_steps; apply_loggers! fires at the multiples, simulators.jl:657) or a coupling the engine does not
+# carry — every coupling of coupling.jl except the AndersenThermostat, which is the engine's (mhip_set_andersen).  Those are applied by the reference's own
+# apply_coupling! between two chunks (coordinates, velocities and the boundary go back to the engine behind it; context! follows a replaced boundary: mhip_set_box), at
+# the multiples of their n_steps where they have one (MonteCarloBarostat, the Berendsen and C-rescale barostats) and after every step where they have not.
+couplers_of(sim) = sim.coupling === nothing ? () : (sim.coupling isa Union{Tuple, NamedTuple} ? Tuple(values(sim.coupling)) : (sim.coupling,))
+host_couplers(sim) = Tuple(c for c in couplers_of(sim) if !(c isa AndersenThermostat))
+host_intervals(sys, sim) = (Int[l.n_steps for l in values(sys.loggers) if hasproperty(l, :n_steps)]..., Int[hasproperty(c, :n_steps) ? c.n_steps : 1 for c in host_couplers(sim)]...)
+next_stop(first, last, intervals) = minimum((last, ((fld(first, k) + 1) * k for k in intervals if k > 0)...))
 
-function run_chunks!(step!, c::HipContext, sys::System{3, <:ROCArray, T}, n_steps, init_step, run_loggers) where T
+function run_chunks!(step!, c::HipContext, sys::System{3, <:ROCArray, T}, sim, n_steps, init_step, run_loggers, rng) where T
     push_specific!(c, sys)
     check(c, ccall((:mhip_set_state, libmollyhip), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32), c.ptr, devptr(sys.coords), devptr(sys.velocities), 1))
     Molly.apply_loggers!(sys, nothing, init_step, nothing, run_loggers)              # loggers.jl:44, simulators.jl:572
-    chunk = logger_chunk(sys, n_steps)
-    first = init_step
-    while first < init_step + n_steps
-        n = min(chunk, init_step + n_steps - first)
-        step!(first, n)                                                              # mhip_vv_run / mhip_langevin_run: returns after a stream sync
+    intervals = host_intervals(sys, sim)
+    on_host = host_couplers(sim)
+    buffers = isempty(on_host) ? nothing : Molly.init_buffers!(sys, Threads.nthreads())
+    first, last = init_step, init_step + n_steps
+    while first < last
+        stop = next_stop(first, last, intervals)
+        step!(first, stop - first)                                                   # mhip_vv_run / mhip_langevin_run: returns after a stream sync
         check(c, ccall((:mhip_get_state, libmollyhip), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32), c.ptr, devptr(sys.coords), devptr(sys.velocities), 1))
-        first += n
+        first = stop
+        if !isempty(on_host)                                                         # ≙ simulators.jl:630, 1208: apply_coupling! at the end of step `first`
+            Molly.apply_coupling!(sys, buffers, on_host, sim, nothing, first; n_threads=Threads.nthreads(), rng=rng)
+            c = context!(sys)                                                        # (a barostat replaced sys.boundary: the engine follows before it sees the scaled coordinates)
+            check(c, ccall((:mhip_set_state, libmollyhip), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32), c.ptr, devptr(sys.coords), devptr(sys.velocities), 1))
+        end
         Molly.apply_loggers!(sys, nothing, first, nothing, run_loggers)              # loggers call forces / potential_energy → the overrides above
     end
     return sys
@@ -224,9 +238,10 @@ struct HIPVelocityVerlet{T, C}; dt::T; coupling::C; remove_CM_motion::Int; end
 HIPVelocityVerlet(; dt, coupling=nothing, remove_CM_motion=1) = HIPVelocityVerlet(dt, coupling, Int(remove_CM_motion))   # ≙ VelocityVerlet, simulators.jl:280-300
 
 function with_andersen(f, c::HipContext, sys, sim, rng)                              # coupling.jl:188-211: kT, P = dt/τ, per-step Philox words
-    th = sim.coupling
-    th === nothing && return f()
-    th isa AndersenThermostat || error("MollyHIPExt: coupling $(typeof(th)) is outside the engine's scope (AndersenThermostat)")
+    ths = Tuple(x for x in couplers_of(sim) if x isa AndersenThermostat)
+    isempty(ths) && return f()
+    length(ths) == 1 || error("MollyHIPExt: one AndersenThermostat per simulator")
+    th = ths[1]
     check(c, ccall((:mhip_set_andersen, libmollyhip), Int32, (Ptr{Cvoid}, Float64, Float64, UInt64), c.ptr,
                    Float64(ustrip(th.temperature * sys.k)), Float64(ustrip(sim.dt / th.coupling_const)), rand(rng, UInt64)))
     try
@@ -240,7 +255,7 @@ function simulate!(sys::System{3, <:ROCArray, T}, sim::HIPVelocityVerlet, n_step
                    init_step::Integer=0, run_loggers=true, rng=Random.default_rng(), kwargs...) where T
     c = context!(sys)
     with_andersen(c, sys, sim, rng) do
-        run_chunks!(c, sys, n_steps, init_step, run_loggers) do first, n             # ≙ simulators.jl:589-666
+        run_chunks!(c, sys, sim, n_steps, init_step, run_loggers, rng) do first, n   # ≙ simulators.jl:589-666
             check(c, ccall((:mhip_vv_run, libmollyhip), Int32, (Ptr{Cvoid}, Int64, Int64, Float64, Int32),
                            c.ptr, Int64(first), Int64(n), Float64(ustrip(sim.dt)), Int32(sim.remove_CM_motion)))
         end
@@ -256,7 +271,7 @@ function simulate!(sys::System{3, <:ROCArray, T}, sim::HIPLangevin, n_steps::Int
     key, ctr1 = rand(rng, UInt64), rand(rng, UInt64)                                 # as simulators.jl:1149-1150 draws them
     kT = Float64(ustrip(sim.temperature * sys.k))
     with_andersen(c, sys, sim, rng) do
-        run_chunks!(c, sys, n_steps, init_step, run_loggers) do first, n             # ≙ simulators.jl:1099-1220; ctr1 advances one per step (:1190)
+        run_chunks!(c, sys, sim, n_steps, init_step, run_loggers, rng) do first, n   # ≙ simulators.jl:1099-1220; ctr1 advances one per step (:1190)
             check(c, ccall((:mhip_langevin_run, libmollyhip), Int32, (Ptr{Cvoid}, Int64, Int64, Float64, Float64, Float64, Int32, UInt64, UInt64),
                            c.ptr, Int64(first), Int64(n), Float64(ustrip(sim.dt)), kT, Float64(ustrip(sim.friction)), Int32(sim.remove_CM_motion),
                            key, ctr1 + UInt64(first - init_step)))

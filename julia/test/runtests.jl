@@ -85,6 +85,11 @@ end
             simulate!(gpu, sim, 20)
             @test all(isfinite, reduce(vcat, Array(gpu.coords)))
             @test sim.coupling.n_attempted == 4
+            # … and through the device-resident stepper: the run is cut at the barostat's steps, apply_coupling! runs between two chunks, the engine follows the box
+            ext = Base.get_extension(Molly, :MollyHIPExt)
+            baro = MonteCarloBarostat(T64(1.0), temp, gpu.boundary; n_steps=5)
+            simulate!(gpu, ext.HIPLangevin(dt=T64(0.002), temperature=temp, friction=T64(1.0), coupling=baro), 20)
+            @test baro.n_attempted == 4 && all(isfinite, reduce(vcat, Array(gpu.coords)))
         end
         @testset "exclusions and a special pair" begin
             gpu, cpu = lj_pair(diagonal(10), lj_atoms(10, 0.3), CubicBoundary(T64(10)), 5.0; excluded=[(1, 2), (2, 3)], special=[(1, 3)])
