@@ -217,6 +217,12 @@ function run_chunks!(step!, c::HipContext, sys::System{3, <:ROCArray, T}, sim, n
     Molly.apply_loggers!(sys, nothing, init_step, nothing, run_loggers)              # loggers.jl:44, simulators.jl:572
     intervals = host_intervals(sys, sim)
     on_host = host_couplers(sim)
+    # (a coupling that consumes the virial — the Berendsen and C-rescale barostats, needs_virial(c) = c.n_steps — reads it from the buffers of the force call of its step
+    # (pressure(…; recompute=false), coupling.jl:403): the stock simulators make that call, these steppers keep the forces on the device — such couplings run under the
+    # stock `VelocityVerlet` / `Langevin` loops, whose force and energy calls are the overrides above)
+    for cpl in on_host
+        isfinite(Molly.needs_virial(cpl)) && error("MollyHIPExt: $(typeof(cpl)) reads the virial of its step's force call; run it under Molly's own simulator loop (the ROCArray overrides serve it there)")
+    end
     buffers = isempty(on_host) ? nothing : Molly.init_buffers!(sys, Threads.nthreads())
     first, last = init_step, init_step + n_steps
     while first < last

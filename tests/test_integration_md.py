@@ -249,7 +249,7 @@ NAMES_USED = ["pairwise_forces_loop_gpu!", "pairwise_pe_loop_gpu!", "remove_CM_m
               "System", "Atom", "LennardJones", "Coulomb", "CoulombReactionField", "CoulombEwald", "NoCutoff", "DistanceCutoff", "ShiftedPotentialCutoff", "ShiftedForceCutoff",
               "CubicSplineCutoff", "PolynomialCutoff", "CubicBoundary", "TriclinicBoundary", "GPUNeighborFinder", "DistanceNeighborFinder", "NoNeighborFinder", "NeighborList",
               "InteractionList2Atoms", "InteractionList3Atoms", "InteractionList4Atoms", "HarmonicBond", "HarmonicAngle", "PeriodicTorsion", "EwaldExclusion", "PME",
-              "AndersenThermostat", "VelocityVerlet", "NoNeighborList", "init_buffers!", "apply_coupling!"]
+              "AndersenThermostat", "VelocityVerlet", "NoNeighborList", "init_buffers!", "apply_coupling!", "needs_virial"]
 
 
 def _reference_names():
