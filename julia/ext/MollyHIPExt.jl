@@ -205,7 +205,8 @@ end
 # The run is cut where something on the host side is due: a logger (its n_steps; apply_loggers! fires at the multiples, simulators.jl:657) or a coupling the engine does not
 # carry — every coupling of coupling.jl except the AndersenThermostat, which is the engine's (mhip_set_andersen).  Those are applied by the reference's own
 # apply_coupling! between two chunks (coordinates, velocities and the boundary go back to the engine behind it; context! follows a replaced boundary: mhip_set_box), at
-# the multiples of their n_steps where they have one (MonteCarloBarostat, the Berendsen and C-rescale barostats) and after every step where they have not.
+# the multiples of their n_steps where they have one (MonteCarloBarostat) and after every step where they have not (the rescaling thermostats); couplings that read the
+# virial of their step's force call are refused below.
 couplers_of(sim) = sim.coupling === nothing ? () : (sim.coupling isa Union{Tuple, NamedTuple} ? Tuple(values(sim.coupling)) : (sim.coupling,))
 host_couplers(sim) = Tuple(c for c in couplers_of(sim) if !(c isa AndersenThermostat))
 host_intervals(sys, sim) = (Int[l.n_steps for l in values(sys.loggers) if hasproperty(l, :n_steps)]..., Int[hasproperty(c, :n_steps) ? c.n_steps : 1 for c in host_couplers(sim)]...)
