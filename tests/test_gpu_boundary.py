@@ -299,3 +299,23 @@ def test_readme_gpu_example_runs(tmp_path):
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["finite"] and d["pe_minimized_kj_mol"] < d["pe_before_kj_mol"] and d["barostat_trials"] == 3 and d["box_changes"] >= 3
     assert 150.0 < d["temperature_K"] < 450.0 and abs(d["volume_nm3"][1] / d["volume_nm3"][0] - 1.0) < 0.05
+
+
+def test_velocity_verlet_with_andersen_and_barostat_couplings(pkg):
+    """a tuple of couplings as the reference takes it (coupling.jl:25-35): the AndersenThermostat inside the engine's loop, the MonteCarloBarostat between its chunks —
+    40 velocity-Verlet steps of the LJ fluid (fp64) with a trial every 10: the box follows every accepted move, the run stays finite and thermal"""
+    case, dtype = make("lj_fp64")
+    s = case.system(pkg, dtype)
+    baro = pkg.MonteCarloBarostat(1.0, 85.0, s.boundary, n_steps=10, scale_factor=0.002)
+    sim = pkg.VelocityVerlet(dt=0.002, coupling=(pkg.AndersenThermostat(85.0, 0.1), baro), remove_CM_motion=1)
+    v0 = pkg.volume(s.boundary)
+    pkg.simulate(s, sim, 40, rng=np.random.default_rng(8))
+    st = s.stats()
+    assert baro.n_attempted == 4 and st["n_box_changes"] >= 4
+    assert np.isfinite(s.coords).all() and 40.0 < pkg.temperature(s) < 200.0
+    assert abs(pkg.volume(s.boundary) / v0 - 1.0) < 0.02
+    # the engine's box is the system's: the energy of a context created on the final box agrees
+    s2 = on_box(case, dtype, s.coords, s.boundary.side_lengths).system(pkg, dtype)
+    assert pkg.potential_energy(s) == pytest.approx(pkg.potential_energy(s2), rel=1e-11)
+    with pytest.raises(pkg.MollyHipError):
+        pkg.simulate(s, pkg.VelocityVerlet(dt=0.002, coupling=(baro, baro)), 10)                     # one barostat per simulator
