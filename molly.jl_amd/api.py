@@ -754,22 +754,21 @@ def scale_coords(sys, scale_matrix, scale_velocities=False):
     """scale_coords!(sys, μ; ignore_molecules=true) (spatial.jl:1184-1210, the branch of systems without a topology — every atom a molecule): box B′ = μ B,
     r′ = μ r in the system's number type, optionally v′ = μ⁻¹ v.  The rigid-molecule branch (:1211-1290) is host code on molecule lists and stays outside the
     engine; what the engine must do is follow the boundary (mhip_set_box)."""
-    T = sys.dtype.type
     mu = np.asarray(scale_matrix, dtype=sys.dtype).reshape(3, 3)
+    diagonal = not np.any(mu != np.diag(np.diag(mu)))
     b = sys.boundary
     if isinstance(b, TriclinicBoundary):
         nb = mu.astype(np.float64) @ b.basis_vectors.T            # columns = basis vectors (boxmatrix, spatial.jl:254)
         sys.boundary = TriclinicBoundary(nb[:, 0], nb[:, 1], nb[:, 2], approx_images=b.approx_images)
     else:
-        if np.any(mu != np.diag(np.diag(mu))):
+        if not diagonal:
             raise ValueError("a CubicBoundary is scaled by a diagonal matrix")
         sl = (np.diag(mu) * b.side_lengths.astype(sys.dtype)).astype(sys.dtype)   # μ · B in T, as the SMatrix product
         sys.boundary = CubicBoundary(*[float(x) for x in sl])
-    sys.coords[:] = (sys.coords @ mu.T).astype(sys.dtype) if np.any(mu != np.diag(np.diag(mu))) else sys.coords * np.diag(mu)[None, :]
+    sys.coords[:] = sys.coords * np.diag(mu)[None, :] if diagonal else (sys.coords @ mu.T).astype(sys.dtype)
     if scale_velocities:
         mi = np.linalg.inv(mu.astype(np.float64)).astype(sys.dtype)
         sys.velocities[:] = (sys.velocities @ mi.T).astype(sys.dtype)
-    del T
     return sys
 
 
