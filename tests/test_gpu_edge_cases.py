@@ -107,3 +107,48 @@ def test_tiles_cut_into_lds_segments(pkg, monkeypatch, maker, dtype):
     pkg.simulate(s2, pkg.VelocityVerlet(dt=0.001), 25)
     d = s1.coords.astype(np.float64) - s2.coords.astype(np.float64); d -= np.round(d / case.box) * case.box
     assert np.abs(d).max() < (1e-10 if np.dtype(dtype) == np.float64 else 2e-5)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_random_gas_of_the_reference_tile_list_test(pkg, dtype):
+    """test/gpu_consistency.jl:159-216 ("GPU tile lists"): 100 LJ atoms (σ 0.3, ϵ 1, mass 10) at uniformly random positions in a 10 nm box, cutoff 3 nm — GPU forces and
+    energy over the GPUNeighborFinder against the CPU's all-pairs loop with the same cutoff (rtol 1e-8 / atol 1e-10 there).  Random positions put some pairs far
+    inside σ (forces of 1e10 and more): the relative bar is what holds."""
+    rng = np.random.default_rng(42)
+    n = 100
+    x = (rng.random((n, 3)) * 10.0).astype(dtype).astype(np.float64)
+    case = S.Case(x, 10.0, lj=dict(cutoff=("distance", 3.0)), r_list=3.0, rebuild_every=10, sigma=np.full(n, 0.3), eps=np.full(n, 1.0), mass=np.full(n, 10.0))
+    o = case.oracle(np.float64)
+    nl = o.neighbors("brute")
+    f_ref, e_ref = o.forces(nl), o.potential_energy(nl)
+    s = case.system(pkg, dtype)
+    f = pkg.forces(s).astype(np.float64)
+    got = pkg.find_neighbors(s)
+    if dtype == np.float64:
+        assert got.n == len(nl[0]) and all(np.array_equal(u, v) for u, v in zip(S.sorted_pairs(got.i, got.j, got.special), S.sorted_pairs(*nl)))
+        scale, _ = o.force_scale(nl)                                           # Σ_j‖f_ij‖: what the round-off of a sum in another order is relative to
+        assert np.all(np.linalg.norm(f - f_ref, axis=1) <= 1e-8 * np.linalg.norm(f_ref, axis=1) + 1e-10 + 1e-13 * scale)
+        assert pkg.potential_energy(s) == pytest.approx(e_ref, rel=1e-10, abs=1e-10)
+    else:
+        scale, jump = o.force_scale(nl)
+        assert np.all(np.linalg.norm(f - f_ref, axis=1) <= 4e-5 * scale + 1.01 * jump + 1e-6)
+        assert pkg.potential_energy(s) == pytest.approx(e_ref, rel=2e-5)
+
+
+def test_cutoff_beyond_the_box_needs_no_tile_capacity(pkg):
+    """test/gpu_consistency.jl:218-285: the same gas with a 20 nm cutoff in the 10 nm box — there the interacting-tile buffers overflow a deliberately tiny capacity and
+    the call must throw (ext/MollyCUDAExt.jl:733-739).  This engine has no fixed tile capacity to overflow (capacities grow and the search is redone, csrc/engine.hip
+    rebuild_impl), so the same system must simply come out right: every pair interacts once, through its minimum image."""
+    rng = np.random.default_rng(42)
+    n = 100
+    x = rng.random((n, 3)) * 10.0
+    case = S.Case(x, 10.0, lj=dict(cutoff=("distance", 20.0)), r_list=20.0, rebuild_every=10, sigma=np.full(n, 0.3), eps=np.full(n, 1.0), mass=np.full(n, 10.0))
+    o = case.oracle(np.float64)
+    nl = o.neighbors("brute")
+    assert len(nl[0]) == n * (n - 1) // 2
+    s = case.system(pkg, np.float64)
+    f, f_ref = pkg.forces(s), o.forces(nl)
+    scale, _ = o.force_scale(nl)
+    assert np.all(np.linalg.norm(f - f_ref, axis=1) <= 1e-8 * np.linalg.norm(f_ref, axis=1) + 1e-10 + 1e-13 * scale)
+    assert pkg.potential_energy(s) == pytest.approx(o.potential_energy(nl), rel=1e-10)
+    assert pkg.find_neighbors(s).n == n * (n - 1) // 2
