@@ -117,8 +117,9 @@ def test_langevin_inside_the_last_force_launch_is_the_same_run(pkg, monkeypatch,
     assert st1["n_fused_steps"] >= 36 and st0["n_fused_steps"] == 0, (st1["n_fused_steps"], st0["n_fused_steps"])
     box = G.data()["box"]
     d = x1 - x0; d -= np.round(d / box) * box
-    assert np.abs(d).max() < 4e-6 and np.abs(v1 - v0).max() < 4e-3, (np.abs(d).max(), np.abs(v1 - v0).max())
-
+    # (measured: 1.9e-6 nm = four fp32 ulps of a 6 nm coordinate, 1.0e-3 nm/ps — tools/micro/langevin_dev_check.py; the noise enters through the velocities, so the bar on the
+    # coordinates sits a little above the velocity-Verlet twin's 4e-6, tests/test_gpu_6mrr.py)
+    assert np.abs(d).max() < 1e-5 and np.abs(v1 - v0).max() < 4e-3, (np.abs(d).max(), np.abs(v1 - v0).max())
 
 
 def test_langevin_list_checks_measured_by_the_update_launch(pkg, monkeypatch):
